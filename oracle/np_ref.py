@@ -1,0 +1,365 @@
+"""TEST INFRASTRUCTURE ONLY - independent numpy restatement of the reference MSCKF(+plane) update path.
+
+This file is the *second* CPU restatement (the first is oracle/ovp_oracle.c).  It exists so the two
+can be checked against each other and against finite differences; nothing in the product path
+(ov_plane_amd/) may import it.  PARITY UNPINNED: the reference ships no golden vectors for this path
+ and cannot be compiled here (needs Eigen/Boost/ov_core), so the pins are
+finite-difference Jacobians, algebraic identities and C<->numpy cross-agreement.
+
+Each function cites the reference file:line (relative to /root/reference/ov_plane/src) it follows.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.stats import chi2 as _chi2
+
+from ov_plane_amd.synth import quat_2_rot, quat_boxplus, skew
+
+
+def chi2_095(k: int) -> float:
+    """boost::math::quantile(chi_squared(k), 0.95)  (update/UpdaterMSCKF.cpp:59-62)."""
+    return float(_chi2.ppf(0.95, k))
+
+
+# ------------------------------------------------------------------------------------------------
+# camera model: ext ov_core CamRadtan; call sites update/UpdaterHelper.cpp:365,389
+# ------------------------------------------------------------------------------------------------
+def radtan_distort_d(uv_norm, v):
+    fx, fy, cx, cy, k1, k2, p1, p2 = v
+    x, y = uv_norm
+    r2 = x * x + y * y
+    r4 = r2 * r2
+    x1 = x * (1 + k1 * r2 + k2 * r4) + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    y1 = y * (1 + k1 * r2 + k2 * r4) + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.array([fx * x1 + cx, fy * y1 + cy])
+
+
+def radtan_distort_jacobian(uv_norm, v):
+    fx, fy, cx, cy, k1, k2, p1, p2 = v
+    x, y = uv_norm
+    r2 = x * x + y * y
+    r4 = r2 * r2
+    g = 1 + k1 * r2 + k2 * r4
+    x1 = x * g + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    y1 = y * g + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    dz_dzn = np.zeros((2, 2))
+    dz_dzn[0, 0] = fx * (g + 2 * k1 * x * x + 4 * k2 * x * x * r2 + 2 * p1 * y + 6 * p2 * x)
+    dz_dzn[0, 1] = fx * (2 * k1 * x * y + 4 * k2 * x * y * r2 + 2 * p1 * x + 2 * p2 * y)
+    dz_dzn[1, 0] = fy * (2 * k1 * x * y + 4 * k2 * x * y * r2 + 2 * p1 * x + 2 * p2 * y)
+    dz_dzn[1, 1] = fy * (g + 2 * k1 * y * y + 4 * k2 * y * y * r2 + 6 * p1 * y + 2 * p2 * x)
+    dz_dzeta = np.zeros((2, 8))
+    dz_dzeta[0] = [x1, 0, 1, 0, fx * x * r2, fx * x * r4, 2 * fx * x * y, fx * (r2 + 2 * x * x)]
+    dz_dzeta[1] = [0, y1, 0, 1, fy * y * r2, fy * y * r4, fy * (r2 + 2 * y * y), 2 * fy * x * y]
+    return dz_dzn, dz_dzeta
+
+
+# ------------------------------------------------------------------------------------------------
+# Givens pieces (Eigen JacobiRotation::makeGivens / applyOnTheLeft(0,1,G.adjoint()))
+# ------------------------------------------------------------------------------------------------
+def make_givens(p, q):
+    if q == 0.0:
+        return (-1.0 if p < 0 else 1.0), 0.0
+    if p == 0.0:
+        return 0.0, (1.0 if q < 0 else -1.0)
+    if abs(p) > abs(q):
+        t = q / p
+        u = np.sqrt(1.0 + t * t)
+        if p < 0:
+            u = -u
+        c = 1.0 / u
+        s = -t * c
+        return c, s
+    t = p / q
+    u = np.sqrt(1.0 + t * t)
+    if q < 0:
+        u = -u
+    s = -1.0 / u
+    c = -t * s
+    return c, s
+
+
+def _rot2(M, r0, c, s, col0=0):
+    x = M[r0, col0:].copy()
+    y = M[r0 + 1, col0:].copy()
+    M[r0, col0:] = c * x - s * y
+    M[r0 + 1, col0:] = s * x + c * y
+
+
+def nullspace_project_inplace(H_f, H_x, res, H_cp=None):
+    """update/UpdaterHelper.cpp:515-546 (and the H_cp-carrying twin update/UpdaterPlane.cpp:483-517)."""
+    H_f = H_f.copy()
+    H_x = H_x.copy()
+    res = res.copy().reshape(-1, 1)
+    if H_cp is not None:
+        H_cp = H_cp.copy()
+    nf = H_f.shape[1]
+    for n in range(nf):
+        for m in range(H_f.shape[0] - 1, n, -1):
+            c, s = make_givens(H_f[m - 1, n], H_f[m, n])
+            _rot2(H_f, m - 1, c, s, n)
+            _rot2(H_x, m - 1, c, s)
+            if H_cp is not None:
+                _rot2(H_cp, m - 1, c, s)
+            _rot2(res, m - 1, c, s)
+    if H_cp is not None:
+        return H_x[nf:], res[nf:, 0], H_cp[nf:]
+    return H_x[nf:], res[nf:, 0]
+
+
+def measurement_compress_inplace(H_x, res, H_cp=None, use_qr=False):
+    """update/UpdaterHelper.cpp:548-579 (twin: update/UpdaterPlane.cpp:519-552).
+    use_qr=True swaps the sequential Givens for a Householder QR (same R up to row signs)."""
+    if H_x.shape[0] <= H_x.shape[1]:
+        return (H_x, res) if H_cp is None else (H_x, res, H_cp)
+    r = min(H_x.shape)
+    if use_qr:
+        Q, R = np.linalg.qr(H_x, mode="reduced")
+        out = (R, Q.T @ res)
+        if H_cp is not None:
+            out = out + (Q.T @ H_cp,)
+        return out
+    H_x = H_x.copy()
+    res = res.copy().reshape(-1, 1)
+    if H_cp is not None:
+        H_cp = H_cp.copy()
+    for n in range(H_x.shape[1]):
+        for m in range(H_x.shape[0] - 1, n, -1):
+            c, s = make_givens(H_x[m - 1, n], H_x[m, n])
+            _rot2(H_x, m - 1, c, s, n)
+            if H_cp is not None:
+                _rot2(H_cp, m - 1, c, s)
+            _rot2(res, m - 1, c, s)
+    if H_cp is not None:
+        return H_x[:r], res[:r, 0], H_cp[:r]
+    return H_x[:r], res[:r, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# Jacobians: update/UpdaterHelper.cpp:195-513 (GLOBAL_3D only: :39-43; plane rows :448-512)
+# ------------------------------------------------------------------------------------------------
+def feature_jacobian_full(sc, f, sigma_c=None, p_FinG=None, cp=None, cp_fej=None, plane_state_id=-1, planeid=0,
+                          state=None):
+    """Returns H_f, H_x, res, order  (order = list of (state_id, size) in the reference's local column order).
+
+    `state` may override the pose tables (dict with clone_q, clone_p, clone_q_fej, clone_p_fej, calib_q, calib_p, intr)."""
+    st = sc if state is None else state
+    o = sc.opts
+    m = int(sc.n_meas[f])
+    idx = sc.clone_idx[f, :m]
+    ids = sc.ids
+    # column bookkeeping (UpdaterHelper.cpp:205-277)
+    order = []
+    col_of = {}
+    tot = 0
+    if o["do_calib_pose"]:
+        col_of["calib"] = tot
+        order.append((int(ids["calib"]), 6))
+        tot += 6
+    if o["do_calib_intr"]:
+        col_of["intr"] = tot
+        order.append((int(ids["intr"]), 8))
+        tot += 8
+    for k in range(m):
+        ci = int(idx[k])
+        if ("c", ci) not in col_of:
+            col_of[("c", ci)] = tot
+            order.append((int(ids["clones"][ci]), 6))
+            tot += 6
+    plane_in_state = plane_state_id >= 0
+    if planeid != 0 and plane_in_state:
+        col_of["plane"] = tot
+        order.append((int(plane_state_id), 3))
+        tot += 3
+
+    p_f = np.asarray(sc.p_FinG[f] if p_FinG is None else p_FinG, dtype=np.float64)
+    p_f_fej = p_f  # MSCKF features: fej = value (UpdaterMSCKF.cpp:499-500,721-722)
+    jac = 3 + (3 if (planeid != 0 and not plane_in_state) else 0)
+    meas = 3 * m if planeid != 0 else 2 * m
+    res = np.zeros(meas)
+    H_f = np.zeros((meas, jac))
+    H_x = np.zeros((meas, tot))
+    white = 1.0 / o["sigma_px"]
+    R_ItoC = quat_2_rot(st["calib_q"])
+    p_IinC = np.asarray(st["calib_p"])
+    intr = np.asarray(st["intr"])
+    c = 0
+    for k in range(m):
+        ci = int(idx[k])
+        R_GtoIi = quat_2_rot(st["clone_q"][ci])
+        p_IiinG = st["clone_p"][ci]
+        p_FinIi = R_GtoIi @ (p_f - p_IiinG)
+        p_FinCi = R_ItoC @ p_FinIi + p_IinC
+        uv_norm = np.array([p_FinCi[0] / p_FinCi[2], p_FinCi[1] / p_FinCi[2]])
+        uv_dist = radtan_distort_d(uv_norm, intr)
+        uv_m = sc.uv[f, k].astype(np.float64)
+        res[c : c + 2] = white * (uv_m - uv_dist)
+        if o["do_fej"]:
+            R_GtoIi = quat_2_rot(st["clone_q_fej"][ci])
+            p_IiinG = st["clone_p_fej"][ci]
+            p_FinIi = R_GtoIi @ (p_f_fej - p_IiinG)
+            p_FinCi = R_ItoC @ p_FinIi + p_IinC
+        dz_dzn, dz_dzeta = radtan_distort_jacobian(uv_norm, intr)  # NOTE: non-FEJ uv_norm (:383,389)
+        z = p_FinCi[2]
+        dzn_dpfc = np.array([[1 / z, 0, -p_FinCi[0] / (z * z)], [0, 1 / z, -p_FinCi[1] / (z * z)]])
+        dpfc_dpfg = R_ItoC @ R_GtoIi
+        dpfc_dclone = np.zeros((3, 6))
+        dpfc_dclone[:, :3] = R_ItoC @ skew(p_FinIi)
+        dpfc_dclone[:, 3:] = -dpfc_dpfg
+        dz_dpfc = dz_dzn @ dzn_dpfc
+        dz_dpfg = dz_dpfc @ dpfc_dpfg
+        H_f[c : c + 2, :3] = white * dz_dpfg
+        cc = col_of[("c", ci)]
+        H_x[c : c + 2, cc : cc + 6] = white * dz_dpfc @ dpfc_dclone
+        if o["do_calib_pose"]:
+            dpfc_dcalib = np.zeros((3, 6))
+            dpfc_dcalib[:, :3] = skew(p_FinCi - p_IinC)
+            dpfc_dcalib[:, 3:] = np.eye(3)
+            cc = col_of["calib"]
+            H_x[c : c + 2, cc : cc + 6] += white * dz_dpfc @ dpfc_dcalib
+        if o["do_calib_intr"]:
+            cc = col_of["intr"]
+            H_x[c : c + 2, cc : cc + 8] = white * dz_dzeta
+        c += 2
+    if planeid != 0:
+        white_c = 1.0 / (o["sigma_c"] if sigma_c is None else sigma_c)
+        cp = np.asarray(cp, dtype=np.float64)
+        cp_fej = cp if cp_fej is None else np.asarray(cp_fej, dtype=np.float64)
+        for _ in range(max(m, 1)):
+            d = np.linalg.norm(cp)
+            n = cp / d
+            res[c] = white_c * (0.0 - (n @ p_f - d))
+            lp = p_f
+            cpj, dj, nj = cp, d, n
+            if o["do_fej"]:
+                lp = p_f_fej
+                cpj = cp_fej
+                dj = np.linalg.norm(cpj)
+                nj = cpj / dj
+            H_c_plane = white_c * 1.0 / dj * (lp - (nj @ lp) * nj - dj * nj)
+            if plane_in_state:
+                cc = col_of["plane"]
+                H_x[c, cc : cc + 3] = H_c_plane
+            else:
+                H_f[c, jac - 3 :] = H_c_plane
+            H_f[c, :3] = white_c * nj
+            c += 1
+    return H_f, H_x, res, order
+
+
+def order_cols(order):
+    cols = []
+    for sid, sz in order:
+        cols.extend(range(sid, sid + sz))
+    return np.array(cols, dtype=np.int64)
+
+
+def get_marginal_covariance(P, order):
+    """state/StateHelper.cpp:231-259."""
+    cols = order_cols(order)
+    return P[np.ix_(cols, cols)].copy()
+
+
+def ekf_update(P, order, H, res):
+    """state/StateHelper.cpp:121-202 with R = I. Returns (P_new, dx)."""
+    cols = order_cols(order)
+    M_a = P[:, cols] @ H.T
+    P_small = P[np.ix_(cols, cols)]
+    S = H @ P_small @ H.T + np.eye(H.shape[0])
+    S = np.triu(S) + np.triu(S, 1).T
+    Sinv = np.linalg.solve(S, np.eye(S.shape[0]))
+    Sinv = np.triu(Sinv) + np.triu(Sinv, 1).T
+    K = M_a @ Sinv
+    Pn = P - K @ M_a.T
+    Pn = np.triu(Pn) + np.triu(Pn, 1).T
+    dx = K @ res
+    return Pn, dx
+
+
+def ekf_propagation(P, new_start, phi_size, old_order, Phi, Q):
+    """state/StateHelper.cpp:41-119. old_order = list of (id,size); Phi [phi_size x sum(old sizes)]."""
+    Cov_PhiT = np.zeros((P.shape[0], phi_size))
+    loc = 0
+    for sid, sz in old_order:
+        Cov_PhiT += P[:, sid : sid + sz] @ Phi[:, loc : loc + sz].T
+        loc += sz
+    Qs = np.triu(Q) + np.triu(Q, 1).T
+    PCP = Qs.copy()
+    loc = 0
+    for sid, sz in old_order:
+        PCP += Phi[:, loc : loc + sz] @ Cov_PhiT[sid : sid + sz, :]
+        loc += sz
+    Pn = P.copy()
+    Pn[new_start : new_start + phi_size, :] = Cov_PhiT.T
+    Pn[:, new_start : new_start + phi_size] = Cov_PhiT
+    Pn[new_start : new_start + phi_size, new_start : new_start + phi_size] = PCP
+    return Pn
+
+
+def apply_dx(sc, dx):
+    """ext Type::update per variable: JPL left-multiplicative quats, additive vectors.
+    FEJ values are untouched."""
+    ids = sc.ids
+    out = dict(
+        clone_q=sc.clone_q.copy(),
+        clone_p=sc.clone_p.copy(),
+        clone_q_fej=sc.clone_q_fej,
+        clone_p_fej=sc.clone_p_fej,
+        calib_q=sc.calib_q.copy(),
+        calib_p=sc.calib_p.copy(),
+        intr=sc.intr.copy(),
+    )
+    for i in range(sc.C):
+        cid = ids["clones"][i]
+        out["clone_q"][i] = quat_boxplus(sc.clone_q[i], dx[cid : cid + 3])
+        out["clone_p"][i] = sc.clone_p[i] + dx[cid + 3 : cid + 6]
+    out["calib_q"] = quat_boxplus(sc.calib_q, dx[ids["calib"] : ids["calib"] + 3])
+    out["calib_p"] = sc.calib_p + dx[ids["calib"] + 3 : ids["calib"] + 6]
+    out["intr"] = sc.intr + dx[ids["intr"] : ids["intr"] + 8]
+    return out
+
+
+def msckf_point_update(sc, feats=None, use_qr=False):
+    """update/UpdaterMSCKF.cpp:671-814: point-feature loop -> gate -> stack (first-seen order) -> compress -> EKFUpdate.
+    Returns dict(dx, P, accepted[F] bool, chi2[F], rows[F], H, res, order)."""
+    feats = range(sc.F) if feats is None else feats
+    P = sc.P
+    Hx_mapping = {}
+    order_big = []
+    ct_jacob = 0
+    blocks = []
+    accepted = np.zeros(sc.F, dtype=bool)
+    chi2s = np.zeros(sc.F)
+    rows = np.zeros(sc.F, dtype=np.int32)
+    for f in feats:
+        H_f, H_x, res, order = feature_jacobian_full(sc, f)
+        H_x, res = nullspace_project_inplace(H_f, H_x, res)
+        P_marg = get_marginal_covariance(P, order)
+        S = H_x @ P_marg @ H_x.T + np.eye(H_x.shape[0])
+        chi2 = float(res @ np.linalg.solve(S, res))
+        chi2s[f] = chi2
+        rows[f] = res.shape[0]
+        if chi2 > sc.opts["chi2_mult"] * chi2_095(res.shape[0]):
+            continue
+        accepted[f] = True
+        for sid, sz in order:
+            if sid not in Hx_mapping:
+                Hx_mapping[sid] = ct_jacob
+                order_big.append((sid, sz))
+                ct_jacob += sz
+        blocks.append((H_x, res, order))
+    ct_meas = sum(b[1].shape[0] for b in blocks)
+    if ct_meas < 1:
+        return dict(dx=np.zeros(sc.N), P=P.copy(), accepted=accepted, chi2=chi2s, rows=rows)
+    Hx_big = np.zeros((ct_meas, ct_jacob))
+    res_big = np.zeros(ct_meas)
+    r0 = 0
+    for H_x, res, order in blocks:
+        c0 = 0
+        for sid, sz in order:
+            Hx_big[r0 : r0 + H_x.shape[0], Hx_mapping[sid] : Hx_mapping[sid] + sz] = H_x[:, c0 : c0 + sz]
+            c0 += sz
+        res_big[r0 : r0 + res.shape[0]] = res
+        r0 += res.shape[0]
+    Hc, rc = measurement_compress_inplace(Hx_big, res_big, use_qr=use_qr)
+    Pn, dx = ekf_update(P, order_big, Hc, rc)
+    return dict(dx=dx, P=Pn, accepted=accepted, chi2=chi2s, rows=rows, H=Hc, res=rc, order=order_big)

@@ -1,0 +1,750 @@
+/*
+ * TEST INFRASTRUCTURE ONLY - see ovp_oracle.h.  Plain C99 restatement of the reference CPU path, in the
+ * reference's loop order.  Citations are relative to /root/reference/ov_plane/src/.
+ */
+#include "ovp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define CM(A, ld, r, c) ((A)[(size_t)(c) * (size_t)(ld) + (size_t)(r)])
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ext ov_core quat_ops.h (JPL), SURVEY.md Appendix A
+ * ------------------------------------------------------------------------------------------- */
+void ovo_quat_2_rot(const double q[4], double R[9]) {
+  /* R = (2 q4^2 - 1) I - 2 q4 [qv]x + 2 qv qv^T */
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double a = 2.0 * w * w - 1.0;
+  R[0] = a + 2.0 * x * x;
+  R[1] = 2.0 * w * z + 2.0 * x * y;
+  R[2] = -2.0 * w * y + 2.0 * x * z;
+  R[3] = -2.0 * w * z + 2.0 * y * x;
+  R[4] = a + 2.0 * y * y;
+  R[5] = 2.0 * w * x + 2.0 * y * z;
+  R[6] = 2.0 * w * y + 2.0 * z * x;
+  R[7] = -2.0 * w * x + 2.0 * z * y;
+  R[8] = a + 2.0 * z * z;
+}
+
+static void quat_multiply(const double q[4], const double p[4], double out[4]) {
+  /* [[q4 I - [qv]x, qv], [-qv^T, q4]] * p, then q4>=0 and unit norm */
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  double r[4];
+  r[0] = w * p[0] + z * p[1] - y * p[2] + x * p[3];
+  r[1] = -z * p[0] + w * p[1] + x * p[2] + y * p[3];
+  r[2] = y * p[0] - x * p[1] + w * p[2] + z * p[3];
+  r[3] = -x * p[0] - y * p[1] - z * p[2] + w * p[3];
+  if (r[3] < 0) {
+    r[0] = -r[0];
+    r[1] = -r[1];
+    r[2] = -r[2];
+    r[3] = -r[3];
+  }
+  const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+  out[0] = r[0] / n;
+  out[1] = r[1] / n;
+  out[2] = r[2] / n;
+  out[3] = r[3] / n;
+}
+
+void ovo_quat_update(double q[4], const double dth[3]) {
+  /* ext JPLQuat::update: dq = quatnorm([0.5 dth; 1]); q <- dq (x) q */
+  double dq[4] = {0.5 * dth[0], 0.5 * dth[1], 0.5 * dth[2], 1.0};
+  const double n = sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+  dq[0] /= n;
+  dq[1] /= n;
+  dq[2] /= n;
+  dq[3] /= n;
+  double out[4];
+  quat_multiply(dq, q, out);
+  memcpy(q, out, sizeof(out));
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ext ov_core CamRadtan::distort_d / compute_distort_jacobian (call sites update/UpdaterHelper.cpp:365,389)
+ * ------------------------------------------------------------------------------------------- */
+void ovo_radtan_distort(const double v[8], const double uvn[2], double uvd[2]) {
+  const double x = uvn[0], y = uvn[1];
+  const double r2 = x * x + y * y, r4 = r2 * r2;
+  const double x1 = x * (1 + v[4] * r2 + v[5] * r4) + 2 * v[6] * x * y + v[7] * (r2 + 2 * x * x);
+  const double y1 = y * (1 + v[4] * r2 + v[5] * r4) + v[6] * (r2 + 2 * y * y) + 2 * v[7] * x * y;
+  uvd[0] = v[0] * x1 + v[2];
+  uvd[1] = v[1] * y1 + v[3];
+}
+
+void ovo_radtan_jacobian(const double v[8], const double uvn[2], double dz_dzn[4], double dz_dzeta[16]) {
+  /* dz_dzn row-major 2x2, dz_dzeta row-major 2x8 */
+  const double x = uvn[0], y = uvn[1];
+  const double r2 = x * x + y * y, r4 = r2 * r2;
+  const double fx = v[0], fy = v[1], k1 = v[4], k2 = v[5], p1 = v[6], p2 = v[7];
+  const double g = 1 + k1 * r2 + k2 * r4;
+  const double x1 = x * g + 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+  const double y1 = y * g + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+  dz_dzn[0] = fx * (g + 2 * k1 * x * x + 4 * k2 * x * x * r2 + 2 * p1 * y + 6 * p2 * x);
+  dz_dzn[1] = fx * (2 * k1 * x * y + 4 * k2 * x * y * r2 + 2 * p1 * x + 2 * p2 * y);
+  dz_dzn[2] = fy * (2 * k1 * x * y + 4 * k2 * x * y * r2 + 2 * p1 * x + 2 * p2 * y);
+  dz_dzn[3] = fy * (g + 2 * k1 * y * y + 4 * k2 * y * y * r2 + 6 * p1 * y + 2 * p2 * x);
+  memset(dz_dzeta, 0, 16 * sizeof(double));
+  dz_dzeta[0] = x1;
+  dz_dzeta[2] = 1;
+  dz_dzeta[4] = fx * x * r2;
+  dz_dzeta[5] = fx * x * r4;
+  dz_dzeta[6] = 2 * fx * x * y;
+  dz_dzeta[7] = fx * (r2 + 2 * x * x);
+  dz_dzeta[8 + 1] = y1;
+  dz_dzeta[8 + 3] = 1;
+  dz_dzeta[8 + 4] = fy * y * r2;
+  dz_dzeta[8 + 5] = fy * y * r4;
+  dz_dzeta[8 + 6] = fy * (r2 + 2 * y * y);
+  dz_dzeta[8 + 7] = 2 * fy * x * y;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Eigen::JacobiRotation<double>::makeGivens (real case) and applyOnTheLeft(0,1,G.adjoint())
+ * ------------------------------------------------------------------------------------------- */
+void ovo_make_givens(double p, double q, double *c, double *s) {
+  if (q == 0.0) {
+    *c = p < 0 ? -1.0 : 1.0;
+    *s = 0.0;
+  } else if (p == 0.0) {
+    *c = 0.0;
+    *s = q < 0 ? 1.0 : -1.0;
+  } else if (fabs(p) > fabs(q)) {
+    double t = q / p;
+    double u = sqrt(1.0 + t * t);
+    if (p < 0) u = -u;
+    *c = 1.0 / u;
+    *s = -t * (*c);
+  } else {
+    double t = p / q;
+    double u = sqrt(1.0 + t * t);
+    if (q < 0) u = -u;
+    *s = -1.0 / u;
+    *c = -t * (*s);
+  }
+}
+
+/* rows (r0, r0+1) of a column-major matrix, columns [c0, c1):  x' = c x - s y ; y' = s x + c y */
+static inline void rot_rows(double *A, int ld, int r0, int c0, int c1, double c, double s) {
+  for (int j = c0; j < c1; ++j) {
+    double *col = A + (size_t)j * (size_t)ld;
+    const double x = col[r0], y = col[r0 + 1];
+    col[r0] = c * x - s * y;
+    col[r0 + 1] = s * x + c * y;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * chi-square 0.95 quantile  (boost::math::quantile(chi_squared(k), 0.95), update/UpdaterMSCKF.cpp:59-62,749-750)
+ * regularised lower incomplete gamma by series / continued fraction + safeguarded Newton.
+ * ------------------------------------------------------------------------------------------- */
+static double gammap(double a, double x) {
+  if (x <= 0) return 0.0;
+  const double gln = lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 100000; ++n) {
+      ap += 1.0;
+      del *= x / ap;
+      sum += del;
+      if (fabs(del) < fabs(sum) * 1e-17) break;
+    }
+    return sum * exp(-x + a * log(x) - gln);
+  }
+  double b = x + 1.0 - a, c = 1.0 / 1e-300, d = 1.0 / b, h = d;
+  for (int i = 1; i < 100000; ++i) {
+    const double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (fabs(d) < 1e-300) d = 1e-300;
+    c = b + an / c;
+    if (fabs(c) < 1e-300) c = 1e-300;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) < 1e-17) break;
+  }
+  return 1.0 - exp(-x + a * log(x) - gln) * h;
+}
+
+double ovo_chi2_quantile_095(int dof) {
+  const double p = 0.95, a = 0.5 * (double)dof;
+  /* Wilson-Hilferty start */
+  const double z = 1.6448536269514722;
+  double t = 1.0 - 2.0 / (9.0 * dof) + z * sqrt(2.0 / (9.0 * dof));
+  double x = 0.5 * dof * t * t * t;
+  if (x <= 0) x = 0.5;
+  double lo = 0.0, hi = 1e300;
+  for (int it = 0; it < 200; ++it) {
+    const double f = gammap(a, x) - p;
+    if (f > 0) hi = x; else lo = x;
+    const double dens = exp((a - 1.0) * log(x) - x - lgamma(a));
+    double xn = x - f / dens;
+    if (!(xn > lo && xn < hi)) xn = (hi < 1e299) ? 0.5 * (lo + hi) : 2.0 * x;
+    if (fabs(xn - x) <= 1e-15 * fabs(xn)) {
+      x = xn;
+      break;
+    }
+    x = xn;
+  }
+  return 2.0 * x;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Eigen LLT (lower), column-major in place
+ * ------------------------------------------------------------------------------------------- */
+int ovo_llt(double *A, int n, int ld) {
+  for (int j = 0; j < n; ++j) {
+    double d = CM(A, ld, j, j);
+    for (int k = 0; k < j; ++k) d -= CM(A, ld, j, k) * CM(A, ld, j, k);
+    if (!(d > 0.0)) return j + 1;
+    d = sqrt(d);
+    CM(A, ld, j, j) = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = CM(A, ld, i, j);
+      for (int k = 0; k < j; ++k) s -= CM(A, ld, i, k) * CM(A, ld, j, k);
+      CM(A, ld, i, j) = s / d;
+    }
+  }
+  return 0;
+}
+
+/* solve L L^T x = b in place, L lower col-major */
+static void llt_solve_vec(const double *L, int n, int ld, double *b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= CM(L, ld, i, k) * b[k];
+    b[i] = s / CM(L, ld, i, i);
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= CM(L, ld, k, i) * b[k];
+    b[i] = s / CM(L, ld, i, i);
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * small 3x3 helpers (row-major)
+ * ------------------------------------------------------------------------------------------- */
+static void mat3_mul(const double *A, const double *B, double *C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static void mat3_vec(const double *A, const double *v, double *o) {
+  for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+static void skew3(const double *w, double *S) {
+  S[0] = 0;
+  S[1] = -w[2];
+  S[2] = w[1];
+  S[3] = w[2];
+  S[4] = 0;
+  S[5] = -w[0];
+  S[6] = -w[1];
+  S[7] = w[0];
+  S[8] = 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterHelper.cpp:195-513  (GLOBAL_3D: dpfg_dlambda = I, :39-43)
+ * ------------------------------------------------------------------------------------------- */
+int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, double sigma_c,
+                              int planeid, const double *cp, const double *cp_fej, int plane_state_id, double *H_f,
+                              double *H_x, double *res, int *rows_out, int *cols_out, int *hf_cols_out,
+                              int *order_id, int *order_size, int *n_order_out) {
+  const int m = fb->n_meas[f];
+  const int *cidx = fb->clone_idx + (size_t)f * fb->max_meas;
+  const float *uv = fb->uv + (size_t)f * fb->max_meas * 2;
+  const double *p_FinG = fb->p_FinG + (size_t)f * 3;
+  const double *p_FinG_fej = p_FinG; /* UpdaterMSCKF.cpp:499-500,721-722 */
+
+  /* column bookkeeping :205-277 */
+  int n_order = 0, total_hx = 0;
+  int col_calib = -1, col_intr = -1, col_plane = -1;
+  int *col_clone = (int *)malloc(sizeof(int) * (size_t)(st->n_clones > 0 ? st->n_clones : 1));
+  for (int i = 0; i < st->n_clones; ++i) col_clone[i] = -1;
+  if (o->do_calib_camera_pose) {
+    col_calib = total_hx;
+    order_id[n_order] = st->calib_id;
+    order_size[n_order++] = 6;
+    total_hx += 6;
+  }
+  if (o->do_calib_camera_intrinsics) {
+    col_intr = total_hx;
+    order_id[n_order] = st->intr_id;
+    order_size[n_order++] = 8;
+    total_hx += 8;
+  }
+  for (int k = 0; k < m; ++k) {
+    const int ci = cidx[k];
+    if (col_clone[ci] < 0) {
+      col_clone[ci] = total_hx;
+      order_id[n_order] = st->clone_id[ci];
+      order_size[n_order++] = 6;
+      total_hx += 6;
+    }
+  }
+  const int plane_in_state = plane_state_id >= 0;
+  if (planeid != 0 && plane_in_state) {
+    col_plane = total_hx;
+    order_id[n_order] = plane_state_id;
+    order_size[n_order++] = 3;
+    total_hx += 3;
+  }
+
+  /* sizes :309-318 */
+  int jacobsize = 3 + ((planeid != 0 && !plane_in_state) ? 3 : 0);
+  int meassize = (planeid != 0) ? 3 * m : 2 * m;
+  if (m == 0 && planeid != 0) meassize = 1;
+  const int ld = meassize;
+  memset(res, 0, sizeof(double) * (size_t)meassize);
+  memset(H_f, 0, sizeof(double) * (size_t)meassize * (size_t)jacobsize);
+  memset(H_x, 0, sizeof(double) * (size_t)meassize * (size_t)total_hx);
+
+  const double white_px = 1.0 / o->sigma_px;
+  double R_ItoC[9];
+  ovo_quat_2_rot(st->calib_q, R_ItoC);
+  const double *p_IinC = st->calib_p;
+
+  int c = 0;
+  for (int k = 0; k < m; ++k) {
+    const int ci = cidx[k];
+    double R_GtoIi[9];
+    ovo_quat_2_rot(st->clone_q + 4 * ci, R_GtoIi);
+    const double *p_IiinG = st->clone_p + 3 * ci;
+    /* :356-370 */
+    double d[3] = {p_FinG[0] - p_IiinG[0], p_FinG[1] - p_IiinG[1], p_FinG[2] - p_IiinG[2]};
+    double p_FinIi[3], p_FinCi[3];
+    mat3_vec(R_GtoIi, d, p_FinIi);
+    mat3_vec(R_ItoC, p_FinIi, p_FinCi);
+    p_FinCi[0] += p_IinC[0];
+    p_FinCi[1] += p_IinC[1];
+    p_FinCi[2] += p_IinC[2];
+    double uv_norm[2] = {p_FinCi[0] / p_FinCi[2], p_FinCi[1] / p_FinCi[2]};
+    double uv_dist[2];
+    ovo_radtan_distort(st->intrinsics, uv_norm, uv_dist);
+    const double uv_m[2] = {(double)uv[2 * k], (double)uv[2 * k + 1]};
+    res[c] = white_px * (uv_m[0] - uv_dist[0]);
+    res[c + 1] = white_px * (uv_m[1] - uv_dist[1]);
+    /* :376-385 FEJ */
+    if (o->do_fej) {
+      ovo_quat_2_rot(st->clone_q_fej + 4 * ci, R_GtoIi);
+      p_IiinG = st->clone_p_fej + 3 * ci;
+      d[0] = p_FinG_fej[0] - p_IiinG[0];
+      d[1] = p_FinG_fej[1] - p_IiinG[1];
+      d[2] = p_FinG_fej[2] - p_IiinG[2];
+      mat3_vec(R_GtoIi, d, p_FinIi);
+      mat3_vec(R_ItoC, p_FinIi, p_FinCi);
+      p_FinCi[0] += p_IinC[0];
+      p_FinCi[1] += p_IinC[1];
+      p_FinCi[2] += p_IinC[2];
+    }
+    /* :388-401 */
+    double dz_dzn[4], dz_dzeta[16];
+    ovo_radtan_jacobian(st->intrinsics, uv_norm, dz_dzn, dz_dzeta);
+    const double z = p_FinCi[2];
+    const double dzn_dpfc[6] = {1 / z, 0, -p_FinCi[0] / (z * z), 0, 1 / z, -p_FinCi[1] / (z * z)};
+    double dpfc_dpfg[9];
+    mat3_mul(R_ItoC, R_GtoIi, dpfc_dpfg);
+    double sk[9], Rsk[9];
+    skew3(p_FinIi, sk);
+    mat3_mul(R_ItoC, sk, Rsk);
+    double dpfc_dclone[18]; /* 3x6 row-major */
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        dpfc_dclone[6 * i + j] = Rsk[3 * i + j];
+        dpfc_dclone[6 * i + 3 + j] = -dpfc_dpfg[3 * i + j];
+      }
+    /* :407-408 */
+    double dz_dpfc[6], dz_dpfg[6];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) dz_dpfc[3 * i + j] = dz_dzn[2 * i] * dzn_dpfc[j] + dz_dzn[2 * i + 1] * dzn_dpfc[3 + j];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j)
+        dz_dpfg[3 * i + j] =
+            dz_dpfc[3 * i] * dpfc_dpfg[j] + dz_dpfc[3 * i + 1] * dpfc_dpfg[3 + j] + dz_dpfc[3 * i + 2] * dpfc_dpfg[6 + j];
+    /* :411 */
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) CM(H_f, ld, c + i, j) = white_px * dz_dpfg[3 * i + j];
+    /* :414 */
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 6; ++j)
+        CM(H_x, ld, c + i, col_clone[ci] + j) =
+            white_px * (dz_dpfc[3 * i] * dpfc_dclone[j] + dz_dpfc[3 * i + 1] * dpfc_dclone[6 + j] +
+                        dz_dpfc[3 * i + 2] * dpfc_dclone[12 + j]);
+    /* :426-435 */
+    if (o->do_calib_camera_pose) {
+      const double v[3] = {p_FinCi[0] - p_IinC[0], p_FinCi[1] - p_IinC[1], p_FinCi[2] - p_IinC[2]};
+      double skc[9];
+      skew3(v, skc);
+      double dpfc_dcalib[18];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          dpfc_dcalib[6 * i + j] = skc[3 * i + j];
+          dpfc_dcalib[6 * i + 3 + j] = (i == j) ? 1.0 : 0.0;
+        }
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j)
+          CM(H_x, ld, c + i, col_calib + j) +=
+              white_px * (dz_dpfc[3 * i] * dpfc_dcalib[j] + dz_dpfc[3 * i + 1] * dpfc_dcalib[6 + j] +
+                          dz_dpfc[3 * i + 2] * dpfc_dcalib[12 + j]);
+    }
+    /* :438-440 */
+    if (o->do_calib_camera_intrinsics) {
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 8; ++j) CM(H_x, ld, c + i, col_intr + j) = white_px * dz_dzeta[8 * i + j];
+    }
+    c += 2;
+  }
+
+  /* :448-512 point-on-plane constraint rows, one per measurement */
+  if (planeid != 0) {
+    const double white_c = 1.0 / sigma_c;
+    const int reps = (m == 0) ? 1 : m;
+    for (int rep = 0; rep < reps; ++rep) {
+      double dd = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+      double n[3] = {cp[0] / dd, cp[1] / dd, cp[2] / dd};
+      res[c] = white_c * (0.0 - (n[0] * p_FinG[0] + n[1] * p_FinG[1] + n[2] * p_FinG[2] - dd));
+      const double *lp = p_FinG;
+      if (o->do_fej) {
+        lp = p_FinG_fej;
+        dd = sqrt(cp_fej[0] * cp_fej[0] + cp_fej[1] * cp_fej[1] + cp_fej[2] * cp_fej[2]);
+        n[0] = cp_fej[0] / dd;
+        n[1] = cp_fej[1] / dd;
+        n[2] = cp_fej[2] / dd;
+      }
+      const double ndp = n[0] * lp[0] + n[1] * lp[1] + n[2] * lp[2];
+      for (int j = 0; j < 3; ++j) {
+        const double hcp = white_c * 1.0 / dd * (lp[j] - ndp * n[j] - dd * n[j]);
+        if (plane_in_state)
+          CM(H_x, ld, c, col_plane + j) = hcp;
+        else
+          CM(H_f, ld, c, jacobsize - 3 + j) = hcp;
+        CM(H_f, ld, c, j) = white_c * n[j];
+      }
+      c += 1;
+    }
+  }
+  free(col_clone);
+  *rows_out = meassize;
+  *cols_out = total_hx;
+  *hf_cols_out = jacobsize;
+  *n_order_out = n_order;
+  return 0;
+}
+
+/* update/UpdaterHelper.cpp:515-546 ; update/UpdaterPlane.cpp:483-517 */
+void ovo_nullspace_project(double *H_f, int rows, int hf_cols, double *H_x, int cols, double *H_cp, int cp_cols,
+                           double *res) {
+  for (int n = 0; n < hf_cols; ++n) {
+    for (int m = rows - 1; m > n; --m) {
+      double c, s;
+      ovo_make_givens(CM(H_f, rows, m - 1, n), CM(H_f, rows, m, n), &c, &s);
+      rot_rows(H_f, rows, m - 1, n, hf_cols, c, s);
+      rot_rows(H_x, rows, m - 1, 0, cols, c, s);
+      if (H_cp) rot_rows(H_cp, rows, m - 1, 0, cp_cols, c, s);
+      rot_rows(res, rows, m - 1, 0, 1, c, s);
+    }
+  }
+}
+
+/* update/UpdaterHelper.cpp:548-579 ; update/UpdaterPlane.cpp:519-552 */
+int ovo_measurement_compress(double *H_x, int rows, int cols, int ld, double *H_cp, int cp_cols, int ld_cp,
+                             double *res) {
+  if (rows <= cols) return rows;
+  for (int n = 0; n < cols; ++n) {
+    for (int m = rows - 1; m > n; --m) {
+      double c, s;
+      ovo_make_givens(CM(H_x, ld, m - 1, n), CM(H_x, ld, m, n), &c, &s);
+      rot_rows(H_x, ld, m - 1, n, cols, c, s);
+      if (H_cp) rot_rows(H_cp, ld_cp, m - 1, 0, cp_cols, c, s);
+      rot_rows(res, rows, m - 1, 0, 1, c, s);
+    }
+  }
+  return rows < cols ? rows : cols;
+}
+
+/* state/StateHelper.cpp:231-259 */
+void ovo_marginal_cov(const double *P, int n, const int *order_id, const int *order_size, int n_order, double *out) {
+  int cov_size = 0;
+  for (int i = 0; i < n_order; ++i) cov_size += order_size[i];
+  int i_index = 0;
+  for (int i = 0; i < n_order; ++i) {
+    int k_index = 0;
+    for (int k = 0; k < n_order; ++k) {
+      for (int cc = 0; cc < order_size[k]; ++cc)
+        for (int rr = 0; rr < order_size[i]; ++rr)
+          CM(out, cov_size, i_index + rr, k_index + cc) = CM(P, n, order_id[i] + rr, order_id[k] + cc);
+      k_index += order_size[k];
+    }
+    i_index += order_size[i];
+  }
+}
+
+/* state/StateHelper.cpp:121-202 (R = I) */
+int ovo_ekf_update(double *P, int n, const int *order_id, const int *order_size, int n_order, const double *H,
+                   int rows, int ld, const double *res, double *dx, int *neg_diag) {
+  int cols = 0;
+  for (int i = 0; i < n_order; ++i) cols += order_size[i];
+  int *gcol = (int *)malloc(sizeof(int) * (size_t)cols);
+  {
+    int t = 0;
+    for (int i = 0; i < n_order; ++i)
+      for (int k = 0; k < order_size[i]; ++k) gcol[t++] = order_id[i] + k;
+  }
+  /* M_a = P[:, gcol] * H^T   (n x rows) :142-151 */
+  double *M = (double *)calloc((size_t)n * (size_t)rows, sizeof(double));
+  for (int j = 0; j < rows; ++j)
+    for (int k = 0; k < cols; ++k) {
+      const double h = CM(H, ld, j, k);
+      if (h == 0.0) continue;
+      const double *pc = P + (size_t)gcol[k] * (size_t)n;
+      double *mc = M + (size_t)j * (size_t)n;
+      for (int r = 0; r < n; ++r) mc[r] += pc[r] * h;
+    }
+  /* S = H P_small H^T + I :156-161  ==  H * M[gcol,:] */
+  double *S = (double *)calloc((size_t)rows * (size_t)rows, sizeof(double));
+  for (int j = 0; j < rows; ++j)
+    for (int k = 0; k < cols; ++k) {
+      const double mkj = CM(M, n, gcol[k], j);
+      for (int i = 0; i <= j; ++i) CM(S, rows, i, j) += CM(H, ld, i, k) * mkj;
+    }
+  for (int i = 0; i < rows; ++i) CM(S, rows, i, i) += 1.0;
+  for (int j = 0; j < rows; ++j)
+    for (int i = j + 1; i < rows; ++i) CM(S, rows, i, j) = CM(S, rows, j, i);
+  /* Sinv via LLT :165-166 */
+  int info = ovo_llt(S, rows, rows);
+  if (info) {
+    free(gcol);
+    free(M);
+    free(S);
+    return -1;
+  }
+  double *Sinv = (double *)calloc((size_t)rows * (size_t)rows, sizeof(double));
+  for (int j = 0; j < rows; ++j) {
+    double *col = Sinv + (size_t)j * (size_t)rows;
+    col[j] = 1.0;
+    llt_solve_vec(S, rows, rows, col);
+  }
+  /* selfadjointView<Upper> of Sinv */
+  for (int j = 0; j < rows; ++j)
+    for (int i = j + 1; i < rows; ++i) CM(Sinv, rows, i, j) = CM(Sinv, rows, j, i);
+  /* K = M Sinv :167 */
+  double *K = (double *)calloc((size_t)n * (size_t)rows, sizeof(double));
+  for (int j = 0; j < rows; ++j)
+    for (int k = 0; k < rows; ++k) {
+      const double sv = CM(Sinv, rows, k, j);
+      const double *mc = M + (size_t)k * (size_t)n;
+      double *kc = K + (size_t)j * (size_t)n;
+      for (int r = 0; r < n; ++r) kc[r] += mc[r] * sv;
+    }
+  /* P.upper -= K M^T ; mirror :171-172 */
+  for (int k = 0; k < rows; ++k) {
+    const double *kc = K + (size_t)k * (size_t)n;
+    const double *mc = M + (size_t)k * (size_t)n;
+    for (int j = 0; j < n; ++j) {
+      const double mj = mc[j];
+      double *pc = P + (size_t)j * (size_t)n;
+      for (int i = 0; i <= j; ++i) pc[i] -= kc[i] * mj;
+    }
+  }
+  for (int j = 0; j < n; ++j)
+    for (int i = j + 1; i < n; ++i) CM(P, n, i, j) = CM(P, n, j, i);
+  *neg_diag = 0;
+  for (int i = 0; i < n; ++i)
+    if (CM(P, n, i, i) < 0.0) *neg_diag = 1;
+  /* dx = K res :190 */
+  for (int r = 0; r < n; ++r) dx[r] = 0.0;
+  for (int k = 0; k < rows; ++k) {
+    const double rv = res[k];
+    const double *kc = K + (size_t)k * (size_t)n;
+    for (int r = 0; r < n; ++r) dx[r] += kc[r] * rv;
+  }
+  free(gcol);
+  free(M);
+  free(S);
+  free(Sinv);
+  free(K);
+  return 0;
+}
+
+/* state/StateHelper.cpp:41-119 */
+int ovo_ekf_propagation(double *P, int n, int new_start, int phi_size, const int *old_id, const int *old_size,
+                        int n_old, const double *Phi, const double *Q, int *neg_diag) {
+  /* Phi is [phi_size x sum(old sizes)] column-major */
+  double *CPT = (double *)calloc((size_t)n * (size_t)phi_size, sizeof(double));
+  int loc = 0;
+  for (int i = 0; i < n_old; ++i) {
+    for (int k = 0; k < old_size[i]; ++k) {
+      const double *pc = P + (size_t)(old_id[i] + k) * (size_t)n;
+      for (int j = 0; j < phi_size; ++j) {
+        const double ph = CM(Phi, phi_size, j, loc + k);
+        double *cc = CPT + (size_t)j * (size_t)n;
+        for (int r = 0; r < n; ++r) cc[r] += pc[r] * ph;
+      }
+    }
+    loc += old_size[i];
+  }
+  double *PCP = (double *)calloc((size_t)phi_size * (size_t)phi_size, sizeof(double));
+  for (int j = 0; j < phi_size; ++j)
+    for (int i = 0; i < phi_size; ++i) CM(PCP, phi_size, i, j) = (i <= j) ? CM(Q, phi_size, i, j) : CM(Q, phi_size, j, i);
+  loc = 0;
+  for (int i = 0; i < n_old; ++i) {
+    for (int k = 0; k < old_size[i]; ++k)
+      for (int j = 0; j < phi_size; ++j) {
+        const double cv = CM(CPT, n, old_id[i] + k, j);
+        for (int r = 0; r < phi_size; ++r) CM(PCP, phi_size, r, j) += CM(Phi, phi_size, r, loc + k) * cv;
+      }
+    loc += old_size[i];
+  }
+  for (int j = 0; j < phi_size; ++j)
+    for (int r = 0; r < n; ++r) {
+      CM(P, n, new_start + j, r) = CM(CPT, n, r, j);
+      CM(P, n, r, new_start + j) = CM(CPT, n, r, j);
+    }
+  for (int j = 0; j < phi_size; ++j)
+    for (int i = 0; i < phi_size; ++i) CM(P, n, new_start + i, new_start + j) = CM(PCP, phi_size, i, j);
+  *neg_diag = 0;
+  for (int i = 0; i < n; ++i)
+    if (CM(P, n, i, i) < 0.0) *neg_diag = 1;
+  free(CPT);
+  free(PCP);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterMSCKF.cpp:671-814
+ * ------------------------------------------------------------------------------------------- */
+int ovo_msckf_point_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, double *P, double *dx,
+                           uint8_t *accepted, double *chi2_out, double *timings) {
+  const double t0 = now_s();
+  const int n = st->n_state;
+  const int F = fb->n_feats;
+  /* :671-691 sizes: 3 rows per measurement are reserved, full state width */
+  size_t max_meas = 0;
+  for (int f = 0; f < F; ++f) max_meas += 3 * (size_t)fb->n_meas[f];
+  const int max_hx = n;
+  double *res_big = (double *)calloc(max_meas ? max_meas : 1, sizeof(double));
+  double *Hx_big = (double *)calloc((max_meas ? max_meas : 1) * (size_t)max_hx, sizeof(double));
+  int *map_col = (int *)malloc(sizeof(int) * (size_t)n); /* Hx_mapping keyed by Type::id() */
+  for (int i = 0; i < n; ++i) map_col[i] = -1;
+  int *order_big_id = (int *)malloc(sizeof(int) * (size_t)(st->n_clones + 4));
+  int *order_big_size = (int *)malloc(sizeof(int) * (size_t)(st->n_clones + 4));
+  int n_order_big = 0;
+  size_t ct_jacob = 0, ct_meas = 0;
+
+  const int mm = fb->max_meas;
+  const int maxrows = 3 * mm + 1, maxcols = 6 * mm + 14 + 3;
+  double *H_f = (double *)malloc(sizeof(double) * (size_t)maxrows * 6);
+  double *H_x = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *res = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  double *Pm = (double *)malloc(sizeof(double) * (size_t)maxcols * (size_t)maxcols);
+  double *HP = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *S = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxrows);
+  double *tmp = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  int *oid = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *osz = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+
+  for (int f = 0; f < F; ++f) {
+    accepted[f] = 0;
+    chi2_out[f] = 0.0;
+    if (fb->n_meas[f] < 2) continue; /* UpdaterMSCKF.cpp:94-96 */
+    int rows, cols, hfc, no;
+    ovo_feature_jacobian_full(o, st, fb, f, o->sigma_constraint, 0, NULL, NULL, -1, H_f, H_x, res, &rows, &cols, &hfc,
+                              oid, osz, &no);
+    ovo_nullspace_project(H_f, rows, hfc, H_x, cols, NULL, 0, res); /* :736 */
+    const int q = rows - hfc;
+    /* :739-742 */
+    ovo_marginal_cov(P, n, oid, osz, no, Pm);
+    /* HP = Hp * Pm  (q x cols), Hp = rows [hfc, rows) of H_x */
+    for (int j = 0; j < cols; ++j)
+      for (int i = 0; i < q; ++i) CM(HP, q, i, j) = 0.0;
+    for (int k = 0; k < cols; ++k)
+      for (int j = 0; j < cols; ++j) {
+        const double pv = CM(Pm, cols, k, j);
+        for (int i = 0; i < q; ++i) CM(HP, q, i, j) += CM(H_x, rows, hfc + i, k) * pv;
+      }
+    for (int j = 0; j < q; ++j)
+      for (int i = 0; i < q; ++i) CM(S, q, i, j) = (i == j) ? 1.0 : 0.0;
+    for (int k = 0; k < cols; ++k)
+      for (int j = 0; j < q; ++j) {
+        const double hv = CM(H_x, rows, hfc + j, k);
+        for (int i = 0; i < q; ++i) CM(S, q, i, j) += CM(HP, q, i, k) * hv;
+      }
+    if (ovo_llt(S, q, q)) continue;
+    for (int i = 0; i < q; ++i) tmp[i] = res[hfc + i];
+    llt_solve_vec(S, q, q, tmp);
+    double chi2 = 0.0;
+    for (int i = 0; i < q; ++i) chi2 += res[hfc + i] * tmp[i];
+    chi2_out[f] = chi2;
+    /* :745-764 */
+    const double chi2_check = ovo_chi2_quantile_095(q);
+    if (chi2 > o->chi2_multiplier * chi2_check) continue;
+    accepted[f] = 1;
+    /* :767-785 */
+    int ct_hx = 0;
+    for (int v = 0; v < no; ++v) {
+      if (map_col[oid[v]] < 0) {
+        map_col[oid[v]] = (int)ct_jacob;
+        order_big_id[n_order_big] = oid[v];
+        order_big_size[n_order_big++] = osz[v];
+        ct_jacob += (size_t)osz[v];
+      }
+      for (int cc = 0; cc < osz[v]; ++cc)
+        for (int i = 0; i < q; ++i)
+          CM(Hx_big, max_meas, ct_meas + i, map_col[oid[v]] + cc) = CM(H_x, rows, hfc + i, ct_hx + cc);
+      ct_hx += osz[v];
+    }
+    for (int i = 0; i < q; ++i) res_big[ct_meas + i] = res[hfc + i];
+    ct_meas += (size_t)q;
+  }
+  const double t1 = now_s();
+  int rows_c = 0;
+  for (int i = 0; i < n; ++i) dx[i] = 0.0;
+  double t2 = t1, t3 = t1;
+  if (ct_meas >= 1) {
+    /* :801-802 conservativeResize */
+    double *Hc = (double *)malloc(sizeof(double) * ct_meas * (ct_jacob ? ct_jacob : 1));
+    for (size_t j = 0; j < ct_jacob; ++j)
+      memcpy(Hc + j * ct_meas, Hx_big + j * max_meas, sizeof(double) * ct_meas);
+    /* :805 */
+    rows_c = ovo_measurement_compress(Hc, (int)ct_meas, (int)ct_jacob, (int)ct_meas, NULL, 0, 0, res_big);
+    t2 = now_s();
+    /* :813-814 */
+    int neg = 0;
+    ovo_ekf_update(P, n, order_big_id, order_big_size, n_order_big, Hc, rows_c, (int)ct_meas, res_big, dx, &neg);
+    t3 = now_s();
+    free(Hc);
+    if (neg) rows_c = -2;
+  }
+  if (timings) {
+    timings[0] = t1 - t0;
+    timings[1] = t2 - t1;
+    timings[2] = t3 - t2;
+    timings[3] = t3 - t0;
+  }
+  free(res_big);
+  free(Hx_big);
+  free(map_col);
+  free(order_big_id);
+  free(order_big_size);
+  free(H_f);
+  free(H_x);
+  free(res);
+  free(Pm);
+  free(HP);
+  free(S);
+  free(tmp);
+  free(oid);
+  free(osz);
+  return rows_c;
+}

@@ -1,0 +1,112 @@
+/*
+ * TEST INFRASTRUCTURE ONLY  -  CPU restatement (plain C99, no dependencies) of the rpng/ov_plane
+ * MSCKF(+plane) EKF update path, written in the reference's own loop order (dense column-major
+ * matrices, sequential Givens rotations, per-feature H*P*H^T + LLT gate, standard P - K*M^T update).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product path (ov_plane_amd/, libovplane_hip.so) never does.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors / known-answer tests for this path
+ *  and cannot be compiled in this image (every TU needs Eigen3 + Boost + the
+ * un-vendored open_vins ov_core @74a63cf).  This restatement is pinned instead by: finite-difference
+ * Jacobian checks, algebraic identities, the scipy chi-square table, and agreement with an independent
+ * numpy restatement (oracle/np_ref.py).  External semantics (ov_type, quat_ops, CamRadtan, Eigen
+ * makeGivens / LLT) follow SURVEY.md Appendix A.
+ *
+ * All "file:line" citations are relative to /root/reference/ov_plane/src/.
+ */
+#ifndef OVP_ORACLE_H
+#define OVP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Options read on the path: update/UpdaterOptions.h:37-53, state/StateOptions.h:41-153 */
+typedef struct {
+  double sigma_px;          /* UpdaterOptions::sigma_pix */
+  double chi2_multiplier;   /* UpdaterOptions::chi2_multipler */
+  double sigma_constraint;  /* StateOptions::sigma_constraint */
+  int do_fej;               /* StateOptions::do_fej */
+  int do_calib_camera_pose; /* StateOptions::do_calib_camera_pose */
+  int do_calib_camera_intrinsics;
+  int reserved;
+} ovo_opts;
+
+/* Pose / calibration tables = the ov_type values the path reads (state/State.h:86-121). */
+typedef struct {
+  int n_state;               /* N = rows of State::_Cov */
+  int n_clones;
+  const double *clone_q;     /* [n_clones*4] JPL q_GtoI (x y z w) : PoseJPL::Rot()  */
+  const double *clone_p;     /* [n_clones*3] p_IinG               : PoseJPL::pos()  */
+  const double *clone_q_fej; /* PoseJPL::Rot_fej() */
+  const double *clone_p_fej; /* PoseJPL::pos_fej() */
+  const int *clone_id;       /* [n_clones] Type::id() (column offset in P) */
+  double calib_q[4];         /* R_ItoC  (State::_calib_IMUtoCAM) */
+  double calib_p[3];         /* p_IinC */
+  int calib_id;              /* -1 when not calibrating */
+  double intrinsics[8];      /* fx fy cx cy k1 k2 p1 p2 (State::_cam_intrinsics), radtan */
+  int intr_id;
+} ovo_state;
+
+/* SoA form of UpdaterHelper::UpdaterHelperFeature (update/UpdaterHelper.h:62-105), GLOBAL_3D. */
+typedef struct {
+  int n_feats;
+  int max_meas;
+  const float *uv;       /* [n_feats*max_meas*2]  raw pixels, f32 as in the reference */
+  const int *clone_idx;  /* [n_feats*max_meas]    index into the clone tables, -1 = padding */
+  const int *n_meas;     /* [n_feats] */
+  const double *p_FinG;  /* [n_feats*3]  linearisation point (fej == value for MSCKF feats) */
+} ovo_feats;
+
+/* ---- small building blocks (exported so tests can pin them individually) ---------------------- */
+void ovo_quat_2_rot(const double q[4], double R[9]);          /* row-major 3x3; ext quat_ops.h */
+void ovo_quat_update(double q[4], const double dth[3]);       /* ext JPLQuat::update */
+void ovo_radtan_distort(const double intr[8], const double uvn[2], double uvd[2]);
+void ovo_radtan_jacobian(const double intr[8], const double uvn[2], double dz_dzn[4], double dz_dzeta[16]);
+void ovo_make_givens(double p, double q, double *c, double *s); /* Eigen JacobiRotation::makeGivens */
+double ovo_chi2_quantile_095(int dof);                        /* boost::math::quantile(chi_squared(k),0.95) */
+int ovo_llt(double *A, int n, int ld);                        /* in-place lower Cholesky, col-major; 0 ok */
+
+/* update/UpdaterHelper.cpp:195-513.  Column-major outputs, caller-allocated:
+ *   H_f [rows x 3 (or 6)], H_x [rows x cols], res [rows]; order_id/order_size [<= n_meas+3].
+ * planeid==0: point feature.  planeid!=0: cp/cp_fej used; plane_state_id>=0 means plane in state. */
+int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, double sigma_c,
+                              int planeid, const double *cp, const double *cp_fej, int plane_state_id, double *H_f,
+                              double *H_x, double *res, int *rows, int *cols, int *hf_cols, int *order_id,
+                              int *order_size, int *n_order);
+
+/* update/UpdaterHelper.cpp:515-546 (H_cp==NULL) and update/UpdaterPlane.cpp:483-517 (H_cp!=NULL).
+ * Matrices column-major with leading dimension = rows. On return the first hf_cols rows are the ones to drop
+ * (callers read rows [hf_cols, rows)). */
+void ovo_nullspace_project(double *H_f, int rows, int hf_cols, double *H_x, int cols, double *H_cp, int cp_cols,
+                           double *res);
+
+/* update/UpdaterHelper.cpp:548-579 / update/UpdaterPlane.cpp:519-552. Returns the new row count. */
+int ovo_measurement_compress(double *H_x, int rows, int cols, int ld, double *H_cp, int cp_cols, int ld_cp,
+                             double *res);
+
+/* state/StateHelper.cpp:231-259 */
+void ovo_marginal_cov(const double *P, int n, const int *order_id, const int *order_size, int n_order, double *out);
+
+/* state/StateHelper.cpp:121-202 with dense H [rows x cols] (col-major, ld) in the local order.
+ * P updated in place, dx [n] returned. neg_diag set to 1 if any P_ii < 0 (reference would std::exit). */
+int ovo_ekf_update(double *P, int n, const int *order_id, const int *order_size, int n_order, const double *H,
+                   int rows, int ld, const double *res, double *dx, int *neg_diag);
+
+/* state/StateHelper.cpp:41-119 */
+int ovo_ekf_propagation(double *P, int n, int new_start, int phi_size, const int *old_id, const int *old_size,
+                        int n_old, const double *Phi, const double *Q, int *neg_diag);
+
+/* update/UpdaterMSCKF.cpp:671-814: the point-feature loop, gate, stack, compress, EKFUpdate.
+ * Outputs: dx[n], P in place, accepted[n_feats], chi2[n_feats]. timings[4] (seconds): feat system, compression,
+ * update, total.  Returns compressed row count (>=0) or <0 on error. */
+int ovo_msckf_point_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, double *P, double *dx,
+                           uint8_t *accepted, double *chi2, double *timings);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

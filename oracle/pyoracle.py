@@ -1,0 +1,162 @@
+"""TEST INFRASTRUCTURE ONLY - ctypes binding of oracle/libovp_oracle.so (the CPU restatement).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OvoOpts(C.Structure):
+    _fields_ = [
+        ("sigma_px", C.c_double),
+        ("chi2_multiplier", C.c_double),
+        ("sigma_constraint", C.c_double),
+        ("do_fej", C.c_int),
+        ("do_calib_camera_pose", C.c_int),
+        ("do_calib_camera_intrinsics", C.c_int),
+        ("reserved", C.c_int),
+    ]
+
+
+class OvoState(C.Structure):
+    _fields_ = [
+        ("n_state", C.c_int),
+        ("n_clones", C.c_int),
+        ("clone_q", C.POINTER(C.c_double)),
+        ("clone_p", C.POINTER(C.c_double)),
+        ("clone_q_fej", C.POINTER(C.c_double)),
+        ("clone_p_fej", C.POINTER(C.c_double)),
+        ("clone_id", C.POINTER(C.c_int)),
+        ("calib_q", C.c_double * 4),
+        ("calib_p", C.c_double * 3),
+        ("calib_id", C.c_int),
+        ("intrinsics", C.c_double * 8),
+        ("intr_id", C.c_int),
+    ]
+
+
+class OvoFeats(C.Structure):
+    _fields_ = [
+        ("n_feats", C.c_int),
+        ("max_meas", C.c_int),
+        ("uv", C.POINTER(C.c_float)),
+        ("clone_idx", C.POINTER(C.c_int)),
+        ("n_meas", C.POINTER(C.c_int)),
+        ("p_FinG", C.POINTER(C.c_double)),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libovp_oracle.so")
+    src = os.path.join(_HERE, "ovp_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libovp_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.ovo_chi2_quantile_095.restype = C.c_double
+        L.ovo_chi2_quantile_095.argtypes = [C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Packed:
+    """Keeps numpy buffers alive next to the ctypes structs built from a synth.Scene."""
+
+    def __init__(self, sc, feats=None):
+        o = sc.opts
+        self.opts = OvoOpts(o["sigma_px"], o["chi2_mult"], o["sigma_c"], int(o["do_fej"]), int(o["do_calib_pose"]),
+                            int(o["do_calib_intr"]), 0)
+        self.clone_q = np.ascontiguousarray(sc.clone_q, dtype=np.float64)
+        self.clone_p = np.ascontiguousarray(sc.clone_p, dtype=np.float64)
+        self.clone_q_fej = np.ascontiguousarray(sc.clone_q_fej, dtype=np.float64)
+        self.clone_p_fej = np.ascontiguousarray(sc.clone_p_fej, dtype=np.float64)
+        self.clone_id = np.ascontiguousarray(sc.ids["clones"], dtype=np.int32)
+        st = OvoState()
+        st.n_state = int(sc.N)
+        st.n_clones = int(sc.C)
+        st.clone_q = _dp(self.clone_q)
+        st.clone_p = _dp(self.clone_p)
+        st.clone_q_fej = _dp(self.clone_q_fej)
+        st.clone_p_fej = _dp(self.clone_p_fej)
+        st.clone_id = _ip(self.clone_id)
+        st.calib_q[:] = list(sc.calib_q)
+        st.calib_p[:] = list(sc.calib_p)
+        st.calib_id = int(sc.ids["calib"]) if o["do_calib_pose"] else -1
+        st.intrinsics[:] = list(sc.intr)
+        st.intr_id = int(sc.ids["intr"]) if o["do_calib_intr"] else -1
+        self.state = st
+        sel = slice(None) if feats is None else np.asarray(feats)
+        self.uv = np.ascontiguousarray(sc.uv[sel], dtype=np.float32)
+        self.clone_idx = np.ascontiguousarray(sc.clone_idx[sel], dtype=np.int32)
+        self.n_meas = np.ascontiguousarray(sc.n_meas[sel], dtype=np.int32)
+        self.p_FinG = np.ascontiguousarray(sc.p_FinG[sel], dtype=np.float64)
+        fb = OvoFeats()
+        fb.n_feats = int(self.uv.shape[0])
+        fb.max_meas = int(self.uv.shape[1])
+        fb.uv = self.uv.ctypes.data_as(C.POINTER(C.c_float))
+        fb.clone_idx = _ip(self.clone_idx)
+        fb.n_meas = _ip(self.n_meas)
+        fb.p_FinG = _dp(self.p_FinG)
+        self.feats = fb
+
+
+def feature_jacobian_full(sc, f, planeid=0, cp=None, cp_fej=None, plane_state_id=-1, sigma_c=None):
+    pk = Packed(sc)
+    m = int(sc.n_meas[f])
+    maxr, maxc = 3 * m + 1, 6 * m + 17
+    H_f = np.zeros(maxr * 6)
+    H_x = np.zeros(maxr * maxc)
+    res = np.zeros(maxr)
+    rows, cols, hfc, no = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    oid = np.zeros(m + 4, dtype=np.int32)
+    osz = np.zeros(m + 4, dtype=np.int32)
+    cpa = np.ascontiguousarray(cp if cp is not None else np.zeros(3), dtype=np.float64)
+    cpf = np.ascontiguousarray(cp_fej if cp_fej is not None else cpa, dtype=np.float64)
+    sc_ = float(sc.opts["sigma_c"] if sigma_c is None else sigma_c)
+    lib().ovo_feature_jacobian_full(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), C.c_int(f),
+                                    C.c_double(sc_), C.c_int(planeid), _dp(cpa), _dp(cpf), C.c_int(plane_state_id),
+                                    _dp(H_f), _dp(H_x), _dp(res), C.byref(rows), C.byref(cols), C.byref(hfc),
+                                    _ip(oid), _ip(osz), C.byref(no))
+    r, c, h, n = rows.value, cols.value, hfc.value, no.value
+    Hf = H_f[: r * h].reshape(h, r).T.copy()
+    Hx = H_x[: r * c].reshape(c, r).T.copy()
+    order = [(int(oid[i]), int(osz[i])) for i in range(n)]
+    return Hf, Hx, res[:r].copy(), order
+
+
+def msckf_point_update(sc, feats=None):
+    """Runs ovo_msckf_point_update. Returns dict(dx, P, accepted, chi2, rows_compressed, timings)."""
+    pk = Packed(sc, feats)
+    P = np.asfortranarray(sc.P.copy())
+    N = sc.N
+    F = pk.feats.n_feats
+    dx = np.zeros(N)
+    acc = np.zeros(F, dtype=np.uint8)
+    chi2 = np.zeros(F)
+    tim = np.zeros(4)
+    rc = lib().ovo_msckf_point_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), _dp(dx),
+                                      acc.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _dp(tim))
+    return dict(dx=dx, P=np.ascontiguousarray(P), accepted=acc.astype(bool), chi2=chi2, rows_compressed=rc, timings=tim)

@@ -1,0 +1,462 @@
+"""Deterministic synthetic clone/feature/plane batches for the MSCKF(+plane) update path.
+
+The generator imitates the reference simulator's input distribution:
+  * camera/IMU calibration of config/sim/kalibr_imucam_chain.yaml cam0 (radtan, 752x480)
+  * clones at 10 Hz (config/sim/estimator_config.yaml: sim_freq_cam), features at 2..5 m
+    (sim_min/max_feature_gen_dist), sigma_px = 1 (up_msckf_sigma_px), uv stored as f32
+    (ov_plane/src/update/UpdaterHelper.h:68)
+  * state order of ov_plane/src/state/State.cpp:33-82: IMU(15) | dt(1) | calib pose(6) | intrinsics(8) | clones(6 each)
+    [| SLAM landmarks (3 each) | planes (3 each)]
+It is *input generation only*: nothing here is on the measured path, and nothing here comes from /root/reference
+at run time (the numbers above are constants of the reference's public sim config).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# calibration constants (config/sim/kalibr_imucam_chain.yaml cam0)
+# ----------------------------------------------------------------------------------------------
+T_IMU_CAM = np.array(
+    [
+        [0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+        [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+        [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949],
+        [0.0, 0.0, 0.0, 1.0],
+    ]
+)
+INTRINSICS = np.array([458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
+IMG_W, IMG_H = 752.0, 480.0
+
+
+# ----------------------------------------------------------------------------------------------
+# JPL quaternion helpers (ext ov_core quat_ops.h semantics)
+# ----------------------------------------------------------------------------------------------
+def skew(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def quat_2_rot(q):
+    qv = np.asarray(q[:3], dtype=np.float64)
+    q4 = float(q[3])
+    return (2.0 * q4 * q4 - 1.0) * np.eye(3) - 2.0 * q4 * skew(qv) + 2.0 * np.outer(qv, qv)
+
+
+def rot_2_quat(R):
+    """JPL rot_2_quat (4-branch), q = [x y z w] with R = quat_2_rot(q)."""
+    T = np.trace(R)
+    q = np.zeros(4)
+    if R[0, 0] >= T and R[0, 0] >= R[1, 1] and R[0, 0] >= R[2, 2]:
+        q[0] = np.sqrt((1 + 2 * R[0, 0] - T) / 4)
+        q[1] = (1 / (4 * q[0])) * (R[0, 1] + R[1, 0])
+        q[2] = (1 / (4 * q[0])) * (R[0, 2] + R[2, 0])
+        q[3] = (1 / (4 * q[0])) * (R[1, 2] - R[2, 1])
+    elif R[1, 1] >= T and R[1, 1] >= R[0, 0] and R[1, 1] >= R[2, 2]:
+        q[1] = np.sqrt((1 + 2 * R[1, 1] - T) / 4)
+        q[0] = (1 / (4 * q[1])) * (R[0, 1] + R[1, 0])
+        q[2] = (1 / (4 * q[1])) * (R[1, 2] + R[2, 1])
+        q[3] = (1 / (4 * q[1])) * (R[2, 0] - R[0, 2])
+    elif R[2, 2] >= T and R[2, 2] >= R[0, 0] and R[2, 2] >= R[1, 1]:
+        q[2] = np.sqrt((1 + 2 * R[2, 2] - T) / 4)
+        q[0] = (1 / (4 * q[2])) * (R[0, 2] + R[2, 0])
+        q[1] = (1 / (4 * q[2])) * (R[1, 2] + R[2, 1])
+        q[3] = (1 / (4 * q[2])) * (R[0, 1] - R[1, 0])
+    else:
+        q[3] = np.sqrt((1 + T) / 4)
+        q[0] = (1 / (4 * q[3])) * (R[1, 2] - R[2, 1])
+        q[1] = (1 / (4 * q[3])) * (R[2, 0] - R[0, 2])
+        q[2] = (1 / (4 * q[3])) * (R[0, 1] - R[1, 0])
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def quat_multiply(q, p):
+    """JPL q (x) p, then sign/unit normalised."""
+    qv, q4 = q[:3], q[3]
+    Qm = np.zeros((4, 4))
+    Qm[:3, :3] = q4 * np.eye(3) - skew(qv)
+    Qm[:3, 3] = qv
+    Qm[3, :3] = -qv
+    Qm[3, 3] = q4
+    out = Qm @ p
+    if out[3] < 0:
+        out = -out
+    return out / np.linalg.norm(out)
+
+
+def quat_boxplus(q, dth):
+    """JPLQuat::update: dq = quatnorm([0.5*dth, 1]); q <- dq (x) q."""
+    dq = np.array([0.5 * dth[0], 0.5 * dth[1], 0.5 * dth[2], 1.0])
+    dq = dq / np.linalg.norm(dq)
+    return quat_multiply(dq, q)
+
+
+def rotz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def rotx(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]])
+
+
+def roty(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+
+
+# ----------------------------------------------------------------------------------------------
+# camera model (radtan) - vectorised; used only to synthesise measurements / triangulate
+# ----------------------------------------------------------------------------------------------
+def radtan_distort(xn, yn, intr):
+    fx, fy, cx, cy, k1, k2, p1, p2 = intr
+    r2 = xn * xn + yn * yn
+    g = 1.0 + k1 * r2 + k2 * r2 * r2
+    x1 = xn * g + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn)
+    y1 = yn * g + p1 * (r2 + 2.0 * yn * yn) + 2.0 * p2 * xn * yn
+    return fx * x1 + cx, fy * y1 + cy
+
+
+def project_all(p_f, R_GtoI, p_IinG, R_ItoC, p_IinC, intr):
+    """p_f [F,3]; R_GtoI [C,3,3]; p_IinG [C,3]  ->  uv [F,C,2], z [F,C]."""
+    d = p_f[:, None, :] - p_IinG[None, :, :]  # F,C,3
+    p_I = np.einsum("cij,fcj->fci", R_GtoI, d)
+    p_C = np.einsum("ij,fcj->fci", R_ItoC, p_I) + p_IinC[None, None, :]
+    z = p_C[..., 2]
+    xn = p_C[..., 0] / z
+    yn = p_C[..., 1] / z
+    u, v = radtan_distort(xn, yn, intr)
+    return np.stack([u, v], axis=-1), z
+
+
+# ----------------------------------------------------------------------------------------------
+# scene container
+# ----------------------------------------------------------------------------------------------
+class Scene(dict):
+    """Plain dict with attribute access. Keys documented in make_scene()."""
+
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def state_layout(C, n_slam=0, n_planes_in_state=0):
+    ids = dict(imu=0, dt=15, calib=16, intr=22)
+    ids["clones"] = np.array([30 + 6 * i for i in range(C)], dtype=np.int32)
+    base = 30 + 6 * C
+    ids["slam"] = np.array([base + 3 * i for i in range(n_slam)], dtype=np.int32)
+    base += 3 * n_slam
+    ids["planes"] = np.array([base + 3 * i for i in range(n_planes_in_state)], dtype=np.int32)
+    base += 3 * n_planes_in_state
+    ids["N"] = base
+    return ids
+
+
+def _trajectory(C, rng):
+    """C poses at 10 Hz: lateral motion ~0.8 m/s with the camera tracking a point ~3.5 m ahead."""
+    R_CtoI = T_IMU_CAM[:3, :3]
+    # camera axes in G at zero yaw: z_C -> +x_G, x_C -> -y_G, y_C -> -z_G
+    R_CtoG0 = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    Rs, ps = [], []
+    ph = rng.uniform(0, 2 * np.pi, size=4)
+    for i in range(C):
+        t = 0.1 * i
+        p = np.array([0.25 * np.sin(0.9 * t + ph[0]), 0.8 * t, 0.12 * np.sin(1.3 * t + ph[1])])
+        yaw = np.arctan2(1.2 - p[1], 3.5 - p[0])
+        roll = 0.04 * np.sin(1.1 * t + ph[2])
+        pitch = 0.03 * np.sin(0.7 * t + ph[3])
+        R_CtoG = rotz(yaw) @ roty(pitch) @ rotx(roll) @ R_CtoG0
+        R_GtoI = R_CtoI @ R_CtoG.T
+        Rs.append(R_GtoI)
+        ps.append(p)
+    return np.array(Rs), np.array(ps)
+
+
+def _cov(C, ids, rng, n_extra=0):
+    """SPD covariance with strong clone cross-correlation (common gauge error + random walk)."""
+    N = ids["N"]
+    nz = 6 + 6 * C + 64 + N
+    B = np.zeros((N, nz))
+    # common (gauge-like) error shared by every pose
+    s_th_c, s_p_c = 1.0e-2, 3.0e-2
+    s_th_w, s_p_w = 2.0e-3, 5.0e-3
+    col = 0
+    pose_ids = list(ids["clones"]) + [ids["imu"]]  # imu pose ~ newest clone (+ its own walk step)
+    for pid in pose_ids:
+        B[pid : pid + 3, 0:3] = s_th_c * np.eye(3)
+        B[pid + 3 : pid + 6, 3:6] = s_p_c * np.eye(3)
+    col = 6
+    for i in range(C):  # random-walk increment i affects clones i..C-1 and the imu
+        for j in range(i, C):
+            cid = ids["clones"][j]
+            B[cid : cid + 3, col : col + 3] = s_th_w * np.eye(3)
+            B[cid + 3 : cid + 6, col + 3 : col + 6] = s_p_w * np.eye(3)
+        B[0:3, col : col + 3] = s_th_w * np.eye(3)
+        B[3:6, col + 3 : col + 6] = s_p_w * np.eye(3)
+        col += 6
+    # generic dense mixing so every block of P is populated
+    scale = np.full(N, 1.0e-3)
+    scale[6:9] = 2.0e-2  # vel
+    scale[9:12] = 1.0e-3  # bg
+    scale[12:15] = 1.0e-2  # ba
+    scale[ids["dt"]] = 2.0e-3
+    scale[ids["calib"] : ids["calib"] + 3] = 3.0e-3
+    scale[ids["calib"] + 3 : ids["calib"] + 6] = 5.0e-3
+    scale[ids["intr"] : ids["intr"] + 4] = 0.5
+    scale[ids["intr"] + 4 : ids["intr"] + 8] = 2.0e-3
+    for k in range(len(ids["slam"])):
+        scale[ids["slam"][k] : ids["slam"][k] + 3] = 3.0e-2
+    for k in range(len(ids["planes"])):
+        scale[ids["planes"][k] : ids["planes"][k] + 3] = 1.0e-2
+    B[:, col : col + 64] = 0.35 * scale[:, None] * rng.standard_normal((N, 64)) / 8.0
+    col += 64
+    B[:, col : col + N] = np.diag(scale)
+    P = B @ B.T
+    P = 0.5 * (P + P.T)
+    return P
+
+
+def _triangulate_gn(p0, uv, mask, R_GtoI, p_IinG, R_ItoC, p_IinC, intr, iters=6):
+    """Vectorised Gauss-Newton on reprojection error with the *estimated* poses (stand-in for the
+    reference's upstream FeatureInitializer; SURVEY.md §8f rank 1 - input generation only here)."""
+    p = p0.copy()
+    eps = 1e-6
+    for _ in range(iters):
+        uv0, _ = project_all(p, R_GtoI, p_IinG, R_ItoC, p_IinC, intr)
+        r = (uv - uv0) * mask[..., None]  # F,C,2
+        J = np.zeros(uv0.shape + (3,))
+        for a in range(3):
+            dp = np.zeros(3)
+            dp[a] = eps
+            uva, _ = project_all(p + dp, R_GtoI, p_IinG, R_ItoC, p_IinC, intr)
+            J[..., a] = (uva - uv0) / eps
+        J = J * mask[..., None, None]
+        F = p.shape[0]
+        Jf = J.reshape(F, -1, 3)
+        rf = r.reshape(F, -1)
+        A = np.einsum("fka,fkb->fab", Jf, Jf) + 1e-9 * np.eye(3)[None]
+        b = np.einsum("fka,fk->fa", Jf, rf)
+        p = p + np.linalg.solve(A, b[..., None])[..., 0]
+    return p
+
+
+def make_scene(
+    C=11,
+    F=200,
+    seed=0,
+    ragged=False,
+    n_planes=0,
+    feats_per_plane=50,
+    planes_in_state_frac=0.5,
+    n_slam=0,
+    chi2_mult=1.0,
+    sigma_px=1.0,
+    sigma_c=0.05,
+    do_fej=True,
+    calib=True,
+    min_meas=5,
+):
+    """Build one synthetic update-step input.
+
+    Returns Scene with (all float64 unless noted):
+      C, F, N, ids (state_layout)
+      clone_q/clone_p [C,4]/[C,3] current estimates, clone_q_fej/clone_p_fej first estimates
+      imu_q,imu_p,imu_v,imu_bg,imu_ba ; calib_q [4] (R_ItoC), calib_p [3] (p_IinC) ; intr [8] ; dt
+      P [N,N]
+      uv [F,M,2] float32, clone_idx [F,M] int32 (-1 = padding), n_meas [F] int32, M = C
+      p_FinG [F,3] linearisation points (GLOBAL_3D)
+      plane_id [F] int32 (0 = free point), planes: cp [n_planes,3] estimates, cp_fej, in_state [n_planes] bool,
+             plane_state_id [n_planes] (column offset or -1)
+      opts: sigma_px, sigma_c, chi2_mult, do_fej, do_calib_pose, do_calib_intr
+      truth: dict of ground-truth quantities (for diagnostics only)
+    """
+    rng = np.random.default_rng(seed)
+    n_in_state = int(round(n_planes * planes_in_state_frac))
+    ids = state_layout(C, n_slam=n_slam, n_planes_in_state=n_in_state)
+    N = ids["N"]
+
+    R_true, p_true = _trajectory(C, rng)
+    R_CtoI = T_IMU_CAM[:3, :3]
+    p_CinI = T_IMU_CAM[:3, 3]
+    R_ItoC_true = R_CtoI.T
+    p_IinC_true = -R_ItoC_true @ p_CinI
+    intr_true = INTRINSICS.copy()
+
+    # ---- planes: faces of a box in front of the trajectory (cf. Simulator::generate_planes) ------------
+    planes_n, planes_d = [], []
+    for k in range(n_planes):
+        # alternate: back wall (normal ~ -x), floor (normal ~ +z), ceiling (normal ~ -z), side walls
+        kind = k % 4
+        jit = 0.08 * rng.standard_normal(3)
+        if kind == 0:
+            n = np.array([1.0, 0.0, 0.0]) + jit
+            d = 4.2 + 0.9 * (k // 4) / max(1, n_planes // 4) + 0.1 * rng.uniform()
+        elif kind == 1:
+            n = np.array([0.0, 0.0, 1.0]) + jit
+            d = -(1.2 + 0.5 * rng.uniform())
+        elif kind == 2:
+            n = np.array([0.0, 0.0, 1.0]) + jit
+            d = 1.3 + 0.5 * rng.uniform()
+        else:
+            n = np.array([0.25, 1.0, 0.0]) + jit
+            d = 3.6 + 0.8 * rng.uniform()
+        n = n / np.linalg.norm(n)
+        if d < 0:
+            n, d = -n, -d
+        planes_n.append(n)
+        planes_d.append(d)
+    planes_n = np.array(planes_n).reshape(-1, 3)
+    planes_d = np.array(planes_d)
+    cp_true = planes_n * planes_d[:, None]
+
+    # ---- features: rejection-sample points visible in every clone they are assigned to -----------------
+    def visible(pf, lo, hi):
+        uvp, z = project_all(pf, R_true[lo:hi], p_true[lo:hi], R_ItoC_true, p_IinC_true, intr_true)
+        ok = (z > 0.5) & (uvp[..., 0] > 15) & (uvp[..., 0] < IMG_W - 15) & (uvp[..., 1] > 15) & (uvp[..., 1] < IMG_H - 15)
+        return ok.all(axis=1)
+
+    n_planar = min(F, n_planes * feats_per_plane)
+    n_free = F - n_planar
+    if ragged:
+        n_meas = rng.integers(min(min_meas, C), C + 1, size=F).astype(np.int32)
+        start = np.array([rng.integers(0, C - m + 1) for m in n_meas], dtype=np.int32)
+    else:
+        n_meas = np.full(F, C, dtype=np.int32)
+        start = np.zeros(F, dtype=np.int32)
+
+    p_f = np.zeros((F, 3))
+    plane_id = np.zeros(F, dtype=np.int32)
+    mid = p_true[C // 2]
+    for f in range(F):
+        lo, hi = int(start[f]), int(start[f] + n_meas[f])
+        for _try in range(2000):
+            if f < n_free:
+                depth = rng.uniform(2.0, 5.0)
+                cand = mid + np.array([depth, rng.uniform(-2.5, 2.5), rng.uniform(-1.4, 1.4)])
+            else:
+                k = (f - n_free) % n_planes
+                # random point on plane k near the viewing volume
+                base = mid + np.array([rng.uniform(1.8, 5.2), rng.uniform(-2.5, 2.5), rng.uniform(-1.4, 1.4)])
+                cand = base - (planes_n[k] @ base - planes_d[k]) * planes_n[k]
+            if visible(cand[None], lo, hi)[0] and (cand[0] - mid[0]) > 1.5:
+                break
+        else:
+            raise RuntimeError("could not place feature %d" % f)
+        p_f[f] = cand
+        if f >= n_free:
+            plane_id[f] = 1 + (f - n_free) % n_planes
+
+    clone_idx = -np.ones((F, C), dtype=np.int32)
+    mask = np.zeros((F, C))
+    for f in range(F):
+        m = int(n_meas[f])
+        clone_idx[f, :m] = np.arange(start[f], start[f] + m)
+        mask[f, start[f] : start[f] + m] = 1.0
+
+    # ---- covariance and a consistent estimation error -------------------------------------------------
+    P = _cov(C, ids, rng)
+    Lc = np.linalg.cholesky(P)
+    # the filter is made slightly conservative (true error = 0.85 sigma) so that ~95 % of the features pass
+    # the 0.95 chi-square gate at chi2_mult = 1 despite second-order effects
+    err = 0.85 * (Lc @ rng.standard_normal(N))
+
+    clone_q = np.zeros((C, 4))
+    clone_p = np.zeros((C, 3))
+    for i in range(C):
+        cid = ids["clones"][i]
+        # estimate = truth [-] err  (so that truth = estimate [+] err)
+        clone_q[i] = quat_boxplus(rot_2_quat(R_true[i]), -err[cid : cid + 3])
+        clone_p[i] = p_true[i] - err[cid + 3 : cid + 6]
+    calib_q = calib_p = intr = None
+    if calib:
+        calib_q = quat_boxplus(rot_2_quat(R_ItoC_true), -err[ids["calib"] : ids["calib"] + 3])
+        calib_p = p_IinC_true - err[ids["calib"] + 3 : ids["calib"] + 6]
+        intr = intr_true - err[ids["intr"] : ids["intr"] + 8]
+    else:
+        calib_q = rot_2_quat(R_ItoC_true)
+        calib_p = p_IinC_true.copy()
+        intr = intr_true.copy()
+
+    # FEJ: value + small perturbation on a random half of the clones (UpdaterHelper.cpp:376-385 branch)
+    clone_q_fej = clone_q.copy()
+    clone_p_fej = clone_p.copy()
+    half = rng.permutation(C)[: C // 2]
+    for i in half:
+        clone_q_fej[i] = quat_boxplus(clone_q[i], 1e-3 * rng.standard_normal(3))
+        clone_p_fej[i] = clone_p[i] + 1e-3 * rng.standard_normal(3)
+
+    # ---- measurements (truth + N(0, sigma_px)), stored as f32 ------------------------------------------
+    uv_true, _ = project_all(p_f, R_true, p_true, R_ItoC_true, p_IinC_true, intr_true)
+    uv_noisy = uv_true + sigma_px * rng.standard_normal(uv_true.shape)
+    uv = np.zeros((F, C, 2), dtype=np.float32)
+    for f in range(F):
+        m = int(n_meas[f])
+        uv[f, :m] = uv_noisy[f, start[f] : start[f] + m].astype(np.float32)
+
+    # ---- linearisation points: GN triangulation with the *estimated* poses ----------------------------
+    R_est = np.array([quat_2_rot(q) for q in clone_q])
+    uv_dense = np.zeros((F, C, 2))
+    for f in range(F):
+        m = int(n_meas[f])
+        uv_dense[f, start[f] : start[f] + m] = uv[f, :m].astype(np.float64)
+    p0 = p_f + 0.02 * np.linalg.norm(p_f - mid, axis=1, keepdims=True) * rng.standard_normal((F, 3))
+    p_FinG = _triangulate_gn(p0, uv_dense, mask, R_est, clone_p, quat_2_rot(calib_q), calib_p, intr)
+
+    # ---- plane estimates ------------------------------------------------------------------------------
+    cp = cp_true + 0.01 * rng.standard_normal(cp_true.shape) if n_planes else np.zeros((0, 3))
+    in_state = np.zeros(n_planes, dtype=bool)
+    in_state[:n_in_state] = True
+    plane_state_id = -np.ones(n_planes, dtype=np.int32)
+    for k in range(n_in_state):
+        plane_state_id[k] = ids["planes"][k]
+        cp[k] = cp_true[k] - err[ids["planes"][k] : ids["planes"][k] + 3]
+    cp_fej = cp.copy()
+    for k in range(n_in_state):
+        cp_fej[k] = cp[k] + 1e-3 * rng.standard_normal(3)
+
+    # SLAM landmarks in state (values only; used by the SLAM-update widening)
+    slam_p = np.zeros((n_slam, 3))
+    for k in range(n_slam):
+        slam_p[k] = mid + np.array([rng.uniform(2, 5), rng.uniform(-2, 2), rng.uniform(-1, 1)])
+
+    sc = Scene(
+        C=C,
+        F=F,
+        N=N,
+        ids=ids,
+        clone_q=clone_q,
+        clone_p=clone_p,
+        clone_q_fej=clone_q_fej,
+        clone_p_fej=clone_p_fej,
+        imu_q=clone_q[-1].copy(),
+        imu_p=clone_p[-1].copy(),
+        imu_v=np.array([0.0, 0.8, 0.0]),
+        imu_bg=1e-3 * rng.standard_normal(3),
+        imu_ba=1e-2 * rng.standard_normal(3),
+        dt=0.0,
+        calib_q=calib_q,
+        calib_p=calib_p,
+        intr=intr,
+        P=P,
+        uv=uv,
+        clone_idx=clone_idx,
+        n_meas=n_meas,
+        p_FinG=p_FinG,
+        plane_id=plane_id,
+        cp=cp,
+        cp_fej=cp_fej,
+        plane_in_state=in_state,
+        plane_state_id=plane_state_id,
+        slam_p=slam_p,
+        opts=dict(
+            sigma_px=float(sigma_px),
+            sigma_c=float(sigma_c),
+            chi2_mult=float(chi2_mult),
+            do_fej=bool(do_fej),
+            do_calib_pose=bool(calib),
+            do_calib_intr=bool(calib),
+        ),
+        truth=dict(R=R_true, p=p_true, p_f=p_f, cp=cp_true, err=err),
+    )
+    return sc
