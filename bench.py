@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py - MSCKF update-step throughput on MI355X (BASELINE.json metric).
+
+A "step" is one full MSCKF point-feature update (UpdaterMSCKF::update, update/UpdaterMSCKF.cpp:671-814) over one
+synthetic batch: per-feature Jacobians -> nullspace projection -> chi2 gate -> compression -> EKF covariance/state
+update, inputs (feature batch, pose tables, covariance) resident in HBM, dx / accept mask fetched to the host at
+the end of every step.  N=1 workload = BASELINE.json configs[1]: 30 clones, 2000 MSCKF point features, 0 planes.
+N>1: features are sharded (every rank owns --feats features of the same filter, weak scaling), the information
+pair (A, b) is summed with one RCCL all-reduce and every rank applies the identical update to its replica of P.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+
+import numpy as np  # noqa: E402
+
+F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §5
+
+
+def algorithmic_flops_per_feature(m: int, calib: bool = True) -> float:
+    """reference-algorithm FLOPs of build + projection + gate for one feature with m observations."""
+    c = 6 * m + (14 if calib else 0)
+    q = 2 * m - 3
+    build = 400.0 * m
+    proj = 12.0 * (2 * m) * (c + 1)
+    gate = 2.0 * q * c * c + 2.0 * q * q * c + q**3 / 3.0 + 2.0 * q * q
+    return build + proj + gate
+
+
+def executed_flops_per_feature(m: int) -> float:
+    """FLOPs the structured kernel k_feat_gate actually issues per feature."""
+    n = 2 * m
+    phase_a = 450.0 * n
+    phase_a2 = n * (14 * 6 + 14 * 14) * 2.0
+    phase_b = n * m * 2 * (36 + 2 * 34)
+    chol = 64 * 64 * 64 / 3.0 * 2.0 * (n / 64.0) + 4 * n * 64.0
+    proj = 64.0 * (45 + 18 + 30) * 2
+    return phase_a + phase_a2 + phase_b + chol + proj
+
+
+class _DevArray:
+    """Zero-copy __cuda_array_interface__ view of a device buffer owned by the C library."""
+
+    def __init__(self, ptr, shape, typestr="<f8"):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2,
+                                             strides=None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--clones", type=int, default=30)
+    ap.add_argument("--feats", type=int, default=2000, help="features per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-feats", type=int, default=2000)
+    args = ap.parse_args()
+
+    import torch
+
+    from ov_plane_amd import capi
+    from ov_plane_amd.synth import make_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    C, F = args.clones, args.feats
+    sc = make_scene(C=C, F=F, seed=0, feat_seed=100 + rank, chi2_mult=1.0)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = capi.Context(sc.N, sc.C, sc.F, device=local_rank, stream=stream.cuda_stream)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)  # inputs resident in HBM before the timed region
+        P0 = torch.from_numpy(np.ascontiguousarray(sc.P)).to("cuda")
+        opts = capi.opts_from_scene(sc)
+        gram_t = None
+        if world > 1:
+            ptr, rows, ld = ctx.gram_buffer()
+            gram_t = torch.as_tensor(_DevArray(ptr, (rows * ld,)), device="cuda")
+
+        def step():
+            ctx.cov_set_device(P0.data_ptr(), sc.N, sc.N)
+            ctx.build_gate_gram_async(opts)
+            if world > 1:
+                dist.all_reduce(gram_t, op=dist.ReduceOp.SUM)
+            ctx.ekf_update_from_gram_async()
+            return ctx.fetch_results()
+
+        for _ in range(args.warmup):
+            out = step()
+        ctx.kernel_timer(enable=True, reset=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        k_ms, k_n = ctx.kernel_timer(enable=False, reset=False)
+        stage_ms = ctx.timings_ms()
+
+    elapsed = t1 - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    total_feats = F * world
+    value = total_feats * args.steps / elapsed
+
+    if rank == 0:
+        m = C
+        alg = algorithmic_flops_per_feature(m) * F
+        exe = executed_flops_per_feature(m) * F
+        k_s = max(k_ms, 1e-9) * 1e-3
+        roofline = {
+            "bound": "mfma",
+            "kernel": "k_feat_gate (per-feature build + nullspace projection + chi2 gate)",
+            "achieved": alg / k_s / 1e12,
+            "peak": F64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": alg / k_s / 1e12 / F64_PEAK_TFLOPS,
+            "traffic": None,
+            "avg_launch_ms": k_ms,
+            "launches_timed": k_n,
+            "algorithmic_flops_per_launch": alg,
+            "executed_flops_per_launch": exe,
+            "achieved_executed": exe / k_s / 1e12,
+            "frac_executed": exe / k_s / 1e12 / F64_PEAK_TFLOPS,
+            "note": "achieved = SURVEY 8(d) reference-algorithm FLOPs / launch time; the structured kernel issues "
+                    "~11x fewer FLOPs (executed_*), see DESIGN.md",
+        }
+        line = {
+            "metric": "MSCKF update-step features/sec at %d clones" % C,
+            "value": value,
+            "unit": "features/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%d clones, %d MSCKF point feats per GPU, 0 planes, calib on (N=%d)" % (C, F, sc.N),
+                       "clones": C, "feats_per_gpu": F, "state_dim": int(sc.N),
+                       "accepted": int(out["accepted"].sum()), "parallelism": "feature-shard x%d" % world},
+            "stage_ms": {"build_gate": float(stage_ms[0]), "gram": float(stage_ms[1]), "ekf": float(stage_ms[2]),
+                         "gpu_total": float(stage_ms[3])},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle
+
+            pyoracle.build()
+            nf = min(args.cpu_sample_feats, F)
+            tb = time.perf_counter()
+            ref = pyoracle.msckf_point_update(sc, feats=np.arange(nf))
+            tcpu = time.perf_counter() - tb
+            line["cpu_baseline"] = {
+                "value": nf / tcpu,
+                "unit": "features/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "oracle/ovp_oracle.c (reference loop order, 1 thread) on the first %d of %d features, one "
+                          "update step, %.2f s (feat system %.2f s, compression %.2f s, update %.3f s)"
+                          % (nf, F, tcpu, ref["timings"][0], ref["timings"][1], ref["timings"][2]),
+                "ms_per_step_sample": 1e3 * tcpu,
+            }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * libovplane_hip.so - C-ABI of the MI355X-native MSCKF(+plane) EKF update path for rpng/ov_plane.
+ *
+ * The reference has no FFI layer: the boundary is the C++ surface that VioManager calls
+ * (SURVEY.md §8b).  Each entry point below names the reference method(s) it replaces; citations are
+ * relative to /root/reference/ov_plane/src/.  Plain pointers and sizes only, no C++/torch types.
+ *
+ * Conventions
+ *   - all matrices are f64; the covariance is handed over ROW-major == column-major (it is symmetric)
+ *     with an explicit leading dimension;
+ *   - `id` always means Type::id() = column offset of a variable in State::_Cov;
+ *   - every function returns 0 on success, a positive hipError_t, or a negative OVP_E_* code;
+ *   - one context per filter, not thread-safe (matches the reference: at most one update in flight);
+ *   - work is enqueued on the context's stream; functions that return results to host memory
+ *     synchronise that stream unless their name ends in _async (then call ovp_sync()).
+ */
+#ifndef OVPLANE_HIP_H
+#define OVPLANE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVP_MAX_MEAS 32 /* max observations per feature handled by the wave-per-feature kernels */
+
+enum {
+  OVP_E_ARG = -1,       /* bad argument */
+  OVP_E_CAPACITY = -2,  /* exceeds the capacity given to ovp_ctx_create */
+  OVP_E_NOTSPD = -3,    /* a Cholesky factorisation hit a non-positive pivot */
+  OVP_E_NEGDIAG = -4,   /* negative covariance diagonal (reference: std::exit, StateHelper.cpp:177-187) */
+  OVP_E_NODEVICE = -5,  /* no HIP device / wrong architecture */
+  OVP_E_STATE = -6      /* call order violated (e.g. update before upload) */
+};
+
+typedef struct ovp_ctx ovp_ctx;
+
+/* Options read on the path: update/UpdaterOptions.h:37-53, state/StateOptions.h:41-153. */
+typedef struct {
+  double sigma_px;                /* UpdaterOptions::sigma_pix                 */
+  double chi2_multiplier;         /* UpdaterOptions::chi2_multipler            */
+  double sigma_constraint;        /* StateOptions::sigma_constraint            */
+  int do_fej;                     /* StateOptions::do_fej                      */
+  int do_calib_camera_pose;       /* StateOptions::do_calib_camera_pose        */
+  int do_calib_camera_intrinsics; /* StateOptions::do_calib_camera_intrinsics  */
+  int reserved;
+} ovp_update_opts;
+
+/* Values of the ov_type variables the Jacobians read (state/State.h:86-121): clone poses (value and
+ * first-estimate), camera extrinsics/intrinsics (monocular: cam 0, radtan). Host pointers. */
+typedef struct {
+  int n_state;               /* N = State::_Cov.rows()                       */
+  int n_clones;
+  const double *clone_q;     /* [n_clones*4] JPL q_GtoI: PoseJPL::Rot()      */
+  const double *clone_p;     /* [n_clones*3] p_IinG:     PoseJPL::pos()      */
+  const double *clone_q_fej; /* PoseJPL::Rot_fej()                           */
+  const double *clone_p_fej; /* PoseJPL::pos_fej()                           */
+  const int *clone_id;       /* [n_clones] Type::id()                        */
+  double calib_q[4];         /* R_ItoC (State::_calib_IMUtoCAM.at(0))        */
+  double calib_p[3];         /* p_IinC                                       */
+  int calib_id;              /* ignored unless do_calib_camera_pose          */
+  double intrinsics[8];      /* fx fy cx cy k1 k2 p1 p2 (State::_cam_intrinsics.at(0)) */
+  int intr_id;               /* ignored unless do_calib_camera_intrinsics    */
+} ovp_state_tables;
+
+/* SoA form of a vector of UpdaterHelper::UpdaterHelperFeature (update/UpdaterHelper.h:62-105),
+ * GLOBAL_3D representation (the only one the shipped configs use; UpdaterHelper.cpp:39-43,455-456). */
+typedef struct {
+  int n_feats;
+  int max_meas;          /* row pitch of uv / clone_idx, <= OVP_MAX_MEAS                       */
+  const float *uv;       /* [n_feats*max_meas*2] raw pixel measurements (f32, UpdaterHelper.h:68) */
+  const int *clone_idx;  /* [n_feats*max_meas] index into the clone tables, -1 = padding       */
+  const int *n_meas;     /* [n_feats]                                                          */
+  const double *p_FinG;  /* [n_feats*3] linearisation point (fej == value for MSCKF features)  */
+} ovp_feature_batch;
+
+/* Result summary of one update step. */
+typedef struct {
+  int n_accepted;      /* features that passed the chi2 gate (UpdaterMSCKF.cpp:755)            */
+  int n_rows;          /* stacked rows before compression = sum (2m-3) over accepted features   */
+  int n_cols;          /* involved state columns                                                */
+  int neg_diag;        /* 1 if the updated covariance has a negative diagonal entry             */
+  int not_spd;         /* 1 if a factorisation failed                                           */
+  int reserved[3];
+} ovp_update_info;
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to create one. */
+int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int n_feats_max, void *stream, ovp_ctx **out);
+int ovp_ctx_destroy(ovp_ctx *ctx);
+int ovp_sync(ovp_ctx *ctx);
+const char *ovp_version(void);
+const char *ovp_error_string(int code);
+
+/* ---- covariance residency (State::_Cov lives on the device) --------------------------------- */
+/* replaces direct access to State::_Cov (friend StateHelper, state/State.h:123-133) */
+int ovp_cov_upload(ovp_ctx *ctx, const double *P_host, int n, int ld);
+int ovp_cov_download(ovp_ctx *ctx, double *P_host, int n, int ld);
+/* device-to-device variant: P_dev is a device pointer (n x n, ld) */
+int ovp_cov_set_device(ovp_ctx *ctx, const double *P_dev, int n, int ld);
+/* StateHelper::get_marginal_covariance (state/StateHelper.cpp:231-259): out is host [sum(size)^2] col-major */
+int ovp_cov_marginal(ovp_ctx *ctx, const int *ids, const int *sizes, int n_vars, double *out_host);
+
+/* ---- state tables / feature batch ----------------------------------------------------------- */
+int ovp_state_upload(ovp_ctx *ctx, const ovp_state_tables *st);
+/* host -> device copy of a feature batch */
+int ovp_batch_upload(ovp_ctx *ctx, const ovp_feature_batch *host_batch);
+/* zero-copy: the pointers inside dev_batch are DEVICE pointers that stay valid until the next bind/upload */
+int ovp_batch_bind_device(ovp_ctx *ctx, const ovp_feature_batch *dev_batch);
+
+/* ---- the update step ------------------------------------------------------------------------ */
+/* UpdaterMSCKF::update point-feature path (update/UpdaterMSCKF.cpp:671-814):
+ *   get_feature_jacobian_full (UpdaterHelper.cpp:195-513) -> nullspace projection (:515-546) -> chi2 gate
+ *   (UpdaterMSCKF.cpp:739-764) -> stacking (:767-785) -> measurement compression (UpdaterHelper.cpp:548-579)
+ *   -> StateHelper::EKFUpdate (StateHelper.cpp:121-202) with R = I.
+ * On return P (device) holds the updated covariance; dx_host[n_state] is the correction the caller applies with
+ * Type::update; accepted_host[n_feats] / chi2_host[n_feats] mirror the per-feature gate (0 = rejected: the
+ * reference sets to_delete and erases it from feature_vec). Any of the host outputs may be NULL. */
+int ovp_msckf_update(ovp_ctx *ctx, const ovp_update_opts *opts, double *dx_host, uint8_t *accepted_host,
+                     double *chi2_host, ovp_update_info *info);
+
+/* Staged form of the same step, for feature-sharded multi-GPU runs:
+ *   stage 1 (per rank, local shard): build + project + gate + local information pair
+ *            Ab_dev = [A | b], A = sum_f Hp_f^T Hp_f (n_state x n_state), b = sum_f Hp_f^T r_f,
+ *            written to the device buffer returned by ovp_gram_buffer() (f64, (n_state+1) * ld_gram);
+ *   (caller all-reduces that buffer over RCCL)
+ *   stage 2 (every rank or rank 0): EKF update from the summed pair. */
+int ovp_msckf_build_gate_gram_async(ovp_ctx *ctx, const ovp_update_opts *opts);
+int ovp_gram_buffer(ovp_ctx *ctx, double **Ab_dev, int *n_rows, int *ld);
+int ovp_ekf_update_from_gram_async(ovp_ctx *ctx);
+int ovp_msckf_fetch_results(ovp_ctx *ctx, double *dx_host, uint8_t *accepted_host, double *chi2_host,
+                            ovp_update_info *info);
+
+/* StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for a dense H handed over by the host
+ * (UpdaterSLAM::update, StateHelper::initialize, merge_planes...): H is [rows x cols] column-major with leading
+ * dimension ld, col_ids[cols] gives the state column of every H column, R = I. */
+int ovp_ekf_update(ovp_ctx *ctx, const double *H_host, int rows, int cols, int ld, const int *col_ids,
+                   const double *res_host, double *dx_host, ovp_update_info *info);
+
+/* StateHelper::EKFPropagation (state/StateHelper.cpp:41-119): new variables occupy [new_start, new_start+phi_size),
+ * Phi is [phi_size x sum(old_sizes)] column-major, Q is [phi_size x phi_size] (upper triangle read). */
+int ovp_cov_propagate(ovp_ctx *ctx, int new_start, int phi_size, const int *old_ids, const int *old_sizes, int n_old,
+                      const double *Phi_host, const double *Q_host, int *neg_diag);
+
+/* StateHelper::clone (state/StateHelper.cpp:346-396): appends a copy of [src_id, src_id+size) at the end. */
+int ovp_cov_clone(ovp_ctx *ctx, int src_id, int size);
+/* StateHelper::marginalize (state/StateHelper.cpp:276-344): removes rows/cols [id, id+size). */
+int ovp_cov_marginalize(ovp_ctx *ctx, int id, int size);
+/* current covariance dimension */
+int ovp_cov_size(ovp_ctx *ctx);
+
+/* 0.95 chi-square quantile used by the gate (boost::math::quantile, update/UpdaterMSCKF.cpp:59-62) */
+double ovp_chi2_quantile_095(int dof);
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* copies an internal device buffer to host for tests: name in {"A","b","L","T","Lt","Y","G","rec","chi2",
+ * "gramS","syrk"}; returns the byte count copied (or <0). */
+long ovp_debug_read(ovp_ctx *ctx, const char *name, void *host, long max_bytes);
+/* per-stage GPU time of the last update in milliseconds: [0]=build/gate, [1]=gram, [2]=ekf, [3]=total */
+int ovp_last_timings(ovp_ctx *ctx, float *ms4);
+/* enables hipEvent timing of the dominant kernel; returns avg ms per launch since last reset */
+int ovp_kernel_timer(ovp_ctx *ctx, int enable, int reset, float *avg_ms_feat, int *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVPLANE_HIP_H */

@@ -1,0 +1,30 @@
+"""Builds libovplane_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["ovp_api.hip", "k_feat.hip", "k_gram.hip", "k_ekf.hip", "k_tile.hip"]
+HEADERS = ["ovp_dev.h", "ovp_kernels.h", os.path.join("..", "..", "include", "ovplane_hip.h")]
+OUT = os.path.join(_HERE, "libovplane_hip.so")
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I" + os.path.join(_HERE, "..", "include")] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT

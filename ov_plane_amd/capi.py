@@ -1,0 +1,327 @@
+"""ctypes binding of libovplane_hip.so (include/ovplane_hip.h).
+
+The library is the product: there is no CPU fallback.  Importing this module without the built extension, or
+creating a context without a gfx950 device, raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovplane_hip.so")
+OVP_MAX_MEAS = 32
+
+
+class OvpError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        try:
+            msg = lib().ovp_error_string(code).decode()
+        except Exception:  # pragma: no cover
+            msg = "?"
+        super().__init__("%s failed with code %d (%s)" % (where, code, msg))
+
+
+class UpdateOpts(C.Structure):
+    _fields_ = [
+        ("sigma_px", C.c_double),
+        ("chi2_multiplier", C.c_double),
+        ("sigma_constraint", C.c_double),
+        ("do_fej", C.c_int),
+        ("do_calib_camera_pose", C.c_int),
+        ("do_calib_camera_intrinsics", C.c_int),
+        ("reserved", C.c_int),
+    ]
+
+
+class StateTables(C.Structure):
+    _fields_ = [
+        ("n_state", C.c_int),
+        ("n_clones", C.c_int),
+        ("clone_q", C.POINTER(C.c_double)),
+        ("clone_p", C.POINTER(C.c_double)),
+        ("clone_q_fej", C.POINTER(C.c_double)),
+        ("clone_p_fej", C.POINTER(C.c_double)),
+        ("clone_id", C.POINTER(C.c_int)),
+        ("calib_q", C.c_double * 4),
+        ("calib_p", C.c_double * 3),
+        ("calib_id", C.c_int),
+        ("intrinsics", C.c_double * 8),
+        ("intr_id", C.c_int),
+    ]
+
+
+class FeatureBatch(C.Structure):
+    _fields_ = [
+        ("n_feats", C.c_int),
+        ("max_meas", C.c_int),
+        ("uv", C.c_void_p),
+        ("clone_idx", C.c_void_p),
+        ("n_meas", C.c_void_p),
+        ("p_FinG", C.c_void_p),
+    ]
+
+
+class UpdateInfo(C.Structure):
+    _fields_ = [
+        ("n_accepted", C.c_int),
+        ("n_rows", C.c_int),
+        ("n_cols", C.c_int),
+        ("neg_diag", C.c_int),
+        ("not_spd", C.c_int),
+        ("reserved", C.c_int * 3),
+    ]
+
+
+_LIB = None
+
+# every symbol include/ovplane_hip.h declares (checked by the CPU test-suite)
+EXPORTS = [
+    "ovp_ctx_create", "ovp_ctx_destroy", "ovp_sync", "ovp_version", "ovp_error_string", "ovp_cov_upload",
+    "ovp_cov_download", "ovp_cov_set_device", "ovp_cov_marginal", "ovp_state_upload", "ovp_batch_upload",
+    "ovp_batch_bind_device", "ovp_msckf_update", "ovp_msckf_build_gate_gram_async", "ovp_gram_buffer",
+    "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
+    "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
+    "ovp_last_timings", "ovp_kernel_timer",
+]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libovplane_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                "the HIP extension is mandatory, there is no CPU path")
+        L = C.CDLL(LIB_PATH)
+        L.ovp_version.restype = C.c_char_p
+        L.ovp_error_string.restype = C.c_char_p
+        L.ovp_error_string.argtypes = [C.c_int]
+        L.ovp_chi2_quantile_095.restype = C.c_double
+        L.ovp_chi2_quantile_095.argtypes = [C.c_int]
+        L.ovp_debug_read.restype = C.c_long
+        L.ovp_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
+        L.ovp_ctx_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.ovp_ctx_destroy.argtypes = [C.c_void_p]
+        L.ovp_sync.argtypes = [C.c_void_p]
+        L.ovp_cov_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ovp_cov_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ovp_cov_set_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ovp_cov_marginal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ovp_state_upload.argtypes = [C.c_void_p, C.POINTER(StateTables)]
+        L.ovp_batch_upload.argtypes = [C.c_void_p, C.POINTER(FeatureBatch)]
+        L.ovp_batch_bind_device.argtypes = [C.c_void_p, C.POINTER(FeatureBatch)]
+        L.ovp_msckf_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(UpdateInfo)]
+        L.ovp_msckf_build_gate_gram_async.argtypes = [C.c_void_p, C.POINTER(UpdateOpts)]
+        L.ovp_gram_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ovp_ekf_update_from_gram_async.argtypes = [C.c_void_p]
+        L.ovp_msckf_fetch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateInfo)]
+        L.ovp_ekf_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.POINTER(UpdateInfo)]
+        L.ovp_cov_propagate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.POINTER(C.c_int)]
+        L.ovp_cov_clone.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ovp_cov_marginalize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ovp_cov_size.argtypes = [C.c_void_p]
+        L.ovp_last_timings.argtypes = [C.c_void_p, C.c_void_p]
+        L.ovp_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def _chk(code, where):
+    if code != 0:
+        raise OvpError(code, where)
+
+
+def opts_from_scene(sc) -> UpdateOpts:
+    o = sc.opts
+    return UpdateOpts(o["sigma_px"], o["chi2_mult"], o["sigma_c"], int(o["do_fej"]), int(o["do_calib_pose"]),
+                      int(o["do_calib_intr"]), 0)
+
+
+class Context:
+    """One filter's device context: resident covariance, pose tables, feature batch, work buffers."""
+
+    def __init__(self, n_state_max, n_clones_max, n_feats_max, device=0, stream=None):
+        self._h = C.c_void_p()
+        self._keep = []
+        _chk(lib().ovp_ctx_create(device, int(n_state_max), int(n_clones_max), int(n_feats_max),
+                                  C.c_void_p(stream) if stream else None, C.byref(self._h)), "ovp_ctx_create")
+        self.n_state_max = int(n_state_max)
+        self.n_feats = 0
+
+    def close(self):
+        if self._h:
+            lib().ovp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- covariance -----------------------------------------------------------------------------
+    def cov_upload(self, P):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        n = P.shape[0]
+        _chk(lib().ovp_cov_upload(self._h, P.ctypes.data, n, n), "ovp_cov_upload")
+
+    def cov_set_device(self, dev_ptr, n, ld):
+        _chk(lib().ovp_cov_set_device(self._h, C.c_void_p(dev_ptr), n, ld), "ovp_cov_set_device")
+
+    def cov_download(self):
+        n = lib().ovp_cov_size(self._h)
+        P = np.zeros((n, n))
+        _chk(lib().ovp_cov_download(self._h, P.ctypes.data, n, n), "ovp_cov_download")
+        return P
+
+    def cov_size(self):
+        return lib().ovp_cov_size(self._h)
+
+    def cov_marginal(self, ids, sizes):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        m = int(sizes.sum())
+        out = np.zeros((m, m))
+        _chk(lib().ovp_cov_marginal(self._h, ids.ctypes.data, sizes.ctypes.data, len(ids), out.ctypes.data),
+             "ovp_cov_marginal")
+        return out
+
+    def cov_propagate(self, new_start, old_ids, old_sizes, Phi, Q):
+        Phi = np.asfortranarray(Phi, dtype=np.float64)
+        Q = np.asfortranarray(Q, dtype=np.float64)
+        old_ids = np.ascontiguousarray(old_ids, dtype=np.int32)
+        old_sizes = np.ascontiguousarray(old_sizes, dtype=np.int32)
+        neg = C.c_int(0)
+        _chk(lib().ovp_cov_propagate(self._h, int(new_start), int(Phi.shape[0]), old_ids.ctypes.data,
+                                     old_sizes.ctypes.data, len(old_ids), Phi.ctypes.data, Q.ctypes.data,
+                                     C.byref(neg)), "ovp_cov_propagate")
+        return neg.value
+
+    def cov_clone(self, src_id, size):
+        _chk(lib().ovp_cov_clone(self._h, int(src_id), int(size)), "ovp_cov_clone")
+
+    def cov_marginalize(self, vid, size):
+        _chk(lib().ovp_cov_marginalize(self._h, int(vid), int(size)), "ovp_cov_marginalize")
+
+    # -- state / batch ---------------------------------------------------------------------------
+    def state_upload(self, sc, state=None):
+        s = sc if state is None else state
+        bufs = dict(
+            clone_q=np.ascontiguousarray(s["clone_q"], dtype=np.float64),
+            clone_p=np.ascontiguousarray(s["clone_p"], dtype=np.float64),
+            clone_q_fej=np.ascontiguousarray(s["clone_q_fej"], dtype=np.float64),
+            clone_p_fej=np.ascontiguousarray(s["clone_p_fej"], dtype=np.float64),
+            clone_id=np.ascontiguousarray(sc.ids["clones"], dtype=np.int32),
+        )
+        st = StateTables()
+        st.n_state = int(sc.N)
+        st.n_clones = int(bufs["clone_q"].shape[0])
+        dp = C.POINTER(C.c_double)
+        st.clone_q = bufs["clone_q"].ctypes.data_as(dp)
+        st.clone_p = bufs["clone_p"].ctypes.data_as(dp)
+        st.clone_q_fej = bufs["clone_q_fej"].ctypes.data_as(dp)
+        st.clone_p_fej = bufs["clone_p_fej"].ctypes.data_as(dp)
+        st.clone_id = bufs["clone_id"].ctypes.data_as(C.POINTER(C.c_int))
+        st.calib_q[:] = list(s["calib_q"])
+        st.calib_p[:] = list(s["calib_p"])
+        st.calib_id = int(sc.ids["calib"])
+        st.intrinsics[:] = list(s["intr"])
+        st.intr_id = int(sc.ids["intr"])
+        _chk(lib().ovp_state_upload(self._h, C.byref(st)), "ovp_state_upload")
+
+    def batch_upload(self, uv, clone_idx, n_meas, p_FinG):
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        clone_idx = np.ascontiguousarray(clone_idx, dtype=np.int32)
+        n_meas = np.ascontiguousarray(n_meas, dtype=np.int32)
+        p_FinG = np.ascontiguousarray(p_FinG, dtype=np.float64)
+        fb = FeatureBatch(int(uv.shape[0]), int(uv.shape[1]) if uv.ndim > 1 else 1, uv.ctypes.data,
+                          clone_idx.ctypes.data, n_meas.ctypes.data, p_FinG.ctypes.data)
+        _chk(lib().ovp_batch_upload(self._h, C.byref(fb)), "ovp_batch_upload")
+        self.n_feats = int(uv.shape[0])
+
+    def batch_bind_device(self, n_feats, max_meas, uv_ptr, clone_idx_ptr, n_meas_ptr, p_ptr):
+        fb = FeatureBatch(int(n_feats), int(max_meas), uv_ptr, clone_idx_ptr, n_meas_ptr, p_ptr)
+        _chk(lib().ovp_batch_bind_device(self._h, C.byref(fb)), "ovp_batch_bind_device")
+        self.n_feats = int(n_feats)
+
+    def batch_upload_scene(self, sc, feats=None):
+        sel = slice(None) if feats is None else np.asarray(feats)
+        self.batch_upload(sc.uv[sel], sc.clone_idx[sel], sc.n_meas[sel], sc.p_FinG[sel])
+
+    # -- update ----------------------------------------------------------------------------------
+    def msckf_update(self, opts: UpdateOpts, raise_on_error=True):
+        n = self.cov_size()
+        dx = np.zeros(n)
+        acc = np.zeros(max(self.n_feats, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(self.n_feats, 1))
+        info = UpdateInfo()
+        rc = lib().ovp_msckf_update(self._h, C.byref(opts), dx.ctypes.data, acc.ctypes.data, chi2.ctypes.data,
+                                    C.byref(info))
+        if rc != 0 and raise_on_error:
+            raise OvpError(rc, "ovp_msckf_update")
+        return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
+
+    def build_gate_gram_async(self, opts: UpdateOpts):
+        _chk(lib().ovp_msckf_build_gate_gram_async(self._h, C.byref(opts)), "ovp_msckf_build_gate_gram_async")
+
+    def gram_buffer(self):
+        p = C.c_void_p()
+        rows, ld = C.c_int(), C.c_int()
+        _chk(lib().ovp_gram_buffer(self._h, C.byref(p), C.byref(rows), C.byref(ld)), "ovp_gram_buffer")
+        return p.value, rows.value, ld.value
+
+    def ekf_update_from_gram_async(self):
+        _chk(lib().ovp_ekf_update_from_gram_async(self._h), "ovp_ekf_update_from_gram_async")
+
+    def fetch_results(self, raise_on_error=True):
+        n = self.cov_size()
+        dx = np.zeros(n)
+        acc = np.zeros(max(self.n_feats, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(self.n_feats, 1))
+        info = UpdateInfo()
+        rc = lib().ovp_msckf_fetch_results(self._h, dx.ctypes.data, acc.ctypes.data, chi2.ctypes.data, C.byref(info))
+        if rc != 0 and raise_on_error:
+            raise OvpError(rc, "ovp_msckf_fetch_results")
+        return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
+
+    def ekf_update(self, H, col_ids, res):
+        """StateHelper::EKFUpdate with a dense H (rows x cols) and per-column state ids."""
+        H = np.asfortranarray(H, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        col_ids = np.ascontiguousarray(col_ids, dtype=np.int32)
+        n = self.cov_size()
+        dx = np.zeros(n)
+        info = UpdateInfo()
+        _chk(lib().ovp_ekf_update(self._h, H.ctypes.data, H.shape[0], H.shape[1], H.shape[0], col_ids.ctypes.data,
+                                  res.ctypes.data, dx.ctypes.data, C.byref(info)), "ovp_ekf_update")
+        return dx, info
+
+    def sync(self):
+        _chk(lib().ovp_sync(self._h), "ovp_sync")
+
+    def timings_ms(self):
+        t = np.zeros(4, dtype=np.float32)
+        lib().ovp_last_timings(self._h, t.ctypes.data)
+        return t
+
+    def kernel_timer(self, enable=True, reset=False):
+        ms, nl = C.c_float(0), C.c_int(0)
+        lib().ovp_kernel_timer(self._h, int(enable), int(reset), C.byref(ms), C.byref(nl))
+        return ms.value, nl.value
+
+    def debug_read(self, name, shape, dtype=np.float64):
+        out = np.zeros(shape, dtype=dtype)
+        nb = lib().ovp_debug_read(self._h, name.encode(), out.ctypes.data, out.nbytes)
+        if nb < 0:
+            raise OvpError(nb, "ovp_debug_read(%s)" % name)
+        return out

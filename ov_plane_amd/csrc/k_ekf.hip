@@ -1,0 +1,319 @@
+// K3: EKF update from the information pair (A, b), covariance resident on the device, plus the covariance
+// bookkeeping kernels (propagation, clone, marginalise, marginal gather).
+//
+// StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) computes, for whitened noise R = I,
+//     P+ = P - P H^T (H P H^T + I)^-1 H P ,   dx = P H^T (H P H^T + I)^-1 r .
+// Both depend on H, r only through A = H^T H and b = H^T r:
+//     P+ = (P^-1 + A)^-1 = L (I + L^T A L)^-1 L^T ,   dx = P+ b ,        with  P = L L^T .
+// That form is SPD end to end (no P - K M^T cancellation, P+ symmetric PSD by construction):
+//     L  = chol(P)            T = I + L^T (A L)          Lt = chol(T)
+//     Y  = L Lt^-T            P+ = Y Y^T                 dx = P+ b
+// The dense products run on v_mfma_f64_16x16x4_f64; the two factorizations are latency-bound single-workgroup
+// kernels (N ~ 200-400), chol(P) is independent of the measurements and is overlapped with K1/K2 by the host.
+#include "ovp_dev.h"
+#include "ovp_kernels.h"
+
+namespace ovp {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky, one workgroup of 1024 threads, panel in LDS.
+// W (n x n, ld) holds the symmetric input on entry (only the lower triangle is read) and L on exit
+// (strict upper triangle zeroed).
+// ------------------------------------------------------------------------------------------------
+static constexpr int CH_NB = 32;
+static constexpr int CH_T = 1024;
+
+__global__ __launch_bounds__(CH_T) void k_chol(const double* __restrict__ A, double* __restrict__ W, int n, int ld,
+                                               int* __restrict__ flag, int add_identity) {
+  extern __shared__ __attribute__((aligned(16))) double panel[];  // [n][CH_NB+1]
+  const int t = threadIdx.x;
+  const int PL = CH_NB + 1;
+  // copy lower triangle of A (+I) into W, zero the strict upper triangle
+  for (int idx = t; idx < n * n; idx += CH_T) {
+    const int i = idx / n, j = idx - i * n;
+    double v = 0.0;
+    if (j <= i) {
+      v = A[(size_t)i * ld + j];
+      if (add_identity && i == j) v += 1.0;
+    }
+    W[(size_t)i * ld + j] = v;
+  }
+  __syncthreads();
+  for (int kb = 0; kb < n; kb += CH_NB) {
+    const int nb = min(CH_NB, n - kb);
+    const int mrem = n - kb;
+    // load panel rows kb..n-1, columns kb..kb+nb-1
+    for (int idx = t; idx < mrem * nb; idx += CH_T) {
+      const int i = idx / nb, j = idx - i * nb;
+      panel[i * PL + j] = W[(size_t)(kb + i) * ld + kb + j];
+    }
+    __syncthreads();
+    // factor the panel column by column (left-looking inside the panel)
+    for (int j = 0; j < nb; ++j) {
+      const double d = panel[j * PL + j];
+      if (t == 0 && !(d > 0.0)) *flag = 1;
+      const double inv = 1.0 / sqrt(d);
+      __syncthreads();
+      // scale column j (rows j..mrem-1); row j gets sqrt(d)
+      for (int i = j + t; i < mrem; i += CH_T) panel[i * PL + j] *= inv;
+      __syncthreads();
+      // update the remaining panel columns c in (j, nb): panel[i][c] -= panel[i][j] * panel[c][j], i >= c
+      const int ncol = nb - j - 1;
+      if (ncol > 0) {
+        const int nrow = mrem - j - 1;
+        for (int idx = t; idx < nrow * ncol; idx += CH_T) {
+          const int i = j + 1 + idx / ncol, c = j + 1 + (idx % ncol);
+          if (i >= c) panel[i * PL + c] -= panel[i * PL + j] * panel[c * PL + j];
+        }
+      }
+      __syncthreads();
+    }
+    // write the factored panel back
+    for (int idx = t; idx < mrem * nb; idx += CH_T) {
+      const int i = idx / nb, j = idx - i * nb;
+      W[(size_t)(kb + i) * ld + kb + j] = (j <= i) ? panel[i * PL + j] : 0.0;
+    }
+    // trailing update: W[i][j] -= sum_c panel[i][c] panel[j][c],  i >= j >= kb+nb
+    const int tr0 = nb;  // first trailing row inside the panel
+    const int ntr = mrem - nb;
+    if (ntr > 0) {
+      // 2D thread tiling: each thread handles a 2x2 micro-tile walk over the lower triangle
+      for (int idx = t; idx < ntr * ntr; idx += CH_T) {
+        const int i = idx / ntr, j = idx - i * ntr;
+        if (j <= i) {
+          double s = 0.0;
+          const double* pi = panel + (tr0 + i) * PL;
+          const double* pj = panel + (tr0 + j) * PL;
+#pragma unroll 8
+          for (int c = 0; c < nb; ++c) s = fma(pi[c], pj[c], s);
+          W[(size_t)(kb + nb + i) * ld + kb + nb + j] -= s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small dense GEMM on v_mfma_f64_16x16x4_f64: one wave per 16x16 tile of C = op(A) op(B) (+ I).
+// ------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(64) void k_gemm(int M, int N, int K, const double* __restrict__ A, int lda,
+                                             const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
+                                             int add_identity) {
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int lane = threadIdx.x;
+  const int kk = lane >> 4, ij = lane & 15;
+  const int ai = i0 + ij, bj = j0 + ij;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + kk;
+    double av = 0.0, bv = 0.0;
+    if (k < K) {
+      if (ai < M) av = TA ? A[(size_t)k * lda + ai] : A[(size_t)ai * lda + k];
+      if (bj < N) bv = TB ? B[(size_t)bj * ldb + k] : B[(size_t)k * ldb + bj];
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = i0 + (lane >> 4) + 4 * v, col = j0 + (lane & 15);
+    if (row < M && col < N) C[(size_t)row * ldc + col] = acc[v] + ((add_identity && row == col) ? 1.0 : 0.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y Lt^T = L  (Lt lower triangular): every row y of Y solves Lt y^T = l^T by forward substitution.
+// block = 256 threads = 16 rows x 16 column lanes; the 16 lanes of a row live in one wave.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm_right_lt(const double* __restrict__ L, const double* __restrict__ Lt,
+                                                        double* __restrict__ Y, int n, int ld) {
+  extern __shared__ __attribute__((aligned(16))) double ybuf[];  // [16][n]
+  const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + rl;
+  double* y = ybuf + (size_t)rl * n;
+  const bool rv = row < n;
+  for (int j = 0; j < n; ++j) {
+    const double* ltj = Lt + (size_t)j * ld;
+    double s = 0.0;
+    for (int p = cl; p < j; p += 16) s = fma(ltj[p], y[p], s);
+    // reduce over the 16 lanes of this row
+    s += shfl_xor_f64(s, 8);
+    s += shfl_xor_f64(s, 4);
+    s += shfl_xor_f64(s, 2);
+    s += shfl_xor_f64(s, 1);
+    if (cl == 0) {
+      const double lij = rv ? L[(size_t)row * ld + j] : 0.0;
+      y[j] = (lij - s) / ltj[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  if (rv)
+    for (int j = cl; j < n; j += 16) Y[(size_t)row * ld + j] = y[j];
+}
+
+// dx = P b ; negdiag flag
+__global__ void k_dx_negdiag(const double* __restrict__ P, int n, int ldp, const double* __restrict__ b,
+                             double* __restrict__ dx, int* __restrict__ negdiag) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const double* pr = P + (size_t)r * ldp;
+  double s = 0.0;
+  for (int c = 0; c < n; ++c) s = fma(pr[c], b[c], s);
+  dx[r] = s;
+  if (pr[r] < 0.0) *negdiag = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// covariance bookkeeping (keeps State::_Cov resident)
+// ------------------------------------------------------------------------------------------------
+// StateHelper::get_marginal_covariance: out[i*m + k] = P[cols[i]][cols[k]]
+__global__ void k_gather_marginal(const double* __restrict__ P, int ldp, const int* __restrict__ cols, int m,
+                                  double* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k < m) out[(size_t)i * m + k] = P[(size_t)cols[i] * ldp + cols[k]];
+}
+
+// StateHelper::clone: P[new..new+sz) rows/cols = copies of [src..src+sz)
+__global__ void k_cov_clone(double* __restrict__ P, int ldp, int n_old, int src, int sz) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_new = n_old + sz;
+  if (idx >= n_new * sz) return;
+  const int r = idx / sz, k = idx - r * sz;  // r over all (new) rows, k over the new columns
+  if (r < n_old) {
+    // Cov.block(0,new,old,sz) = Cov.block(0,old_loc,...) ; Cov.block(new,0,sz,old) = Cov.block(old_loc,0,...)
+    P[(size_t)r * ldp + n_old + k] = P[(size_t)r * ldp + src + k];
+    P[(size_t)(n_old + k) * ldp + r] = P[(size_t)(src + k) * ldp + r];
+  } else {
+    P[(size_t)r * ldp + n_old + k] = P[(size_t)(src + (r - n_old)) * ldp + src + k];
+  }
+}
+
+// StateHelper::marginalize: compact rows/cols [id, id+sz) out of src into dst
+__global__ void k_cov_marginalize(const double* __restrict__ src, double* __restrict__ dst, int ld, int n_old, int id,
+                                  int sz) {
+  const int n_new = n_old - sz;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= n_new) return;
+  const int rs = r < id ? r : r + sz, cs = c < id ? c : c + sz;
+  dst[(size_t)r * ld + c] = src[(size_t)rs * ld + cs];
+}
+
+// StateHelper::EKFPropagation, step 1: CPT[r][j] = sum_k P[r][oldcol[k]] Phi[j][k]   (n x phi)
+__global__ void k_prop_cpt(const double* __restrict__ P, int ldp, int n, const int* __restrict__ oldcol, int nold,
+                           const double* __restrict__ Phi, int phi, double* __restrict__ CPT) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (j >= phi) return;
+  double s = 0.0;
+  for (int k = 0; k < nold; ++k) s = fma(P[(size_t)r * ldp + oldcol[k]], Phi[(size_t)k * phi + j], s);  // Phi col-major
+  CPT[(size_t)r * phi + j] = s;
+}
+// step 2: PCP[i][j] = Qsym[i][j] + sum_k Phi[i][k] CPT[oldcol[k]][j]
+__global__ void k_prop_pcp(const double* __restrict__ CPT, const int* __restrict__ oldcol, int nold,
+                           const double* __restrict__ Phi, const double* __restrict__ Q, int phi,
+                           double* __restrict__ PCP) {
+  const int j = threadIdx.x, i = blockIdx.x;
+  if (j >= phi) return;
+  double s = (i <= j) ? Q[(size_t)j * phi + i] : Q[(size_t)i * phi + j];  // Q col-major, upper triangle read
+  for (int k = 0; k < nold; ++k) s = fma(Phi[(size_t)k * phi + i], CPT[(size_t)oldcol[k] * phi + j], s);
+  PCP[(size_t)i * phi + j] = s;
+}
+// step 3: write the row strip, column strip and diagonal block; negative-diagonal check
+__global__ void k_prop_write(double* __restrict__ P, int ldp, int n, int start, int phi, const double* __restrict__ CPT,
+                             const double* __restrict__ PCP, int* __restrict__ negdiag) {
+  const int j = threadIdx.x, r = blockIdx.x;
+  if (j >= phi) return;
+  const bool inblk = (r >= start && r < start + phi);
+  const double v = inblk ? PCP[(size_t)(r - start) * phi + j] : CPT[(size_t)r * phi + j];
+  P[(size_t)r * ldp + start + j] = v;
+  if (!inblk) P[(size_t)(start + j) * ldp + r] = v;
+  if (inblk && (r - start) == j && v < 0.0) *negdiag = 1;
+}
+__global__ void k_check_negdiag(const double* __restrict__ P, int ldp, int n, int* __restrict__ negdiag) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && P[(size_t)r * ldp + r] < 0.0) *negdiag = 1;
+}
+
+}  // namespace ovp
+
+extern "C" {
+
+hipError_t ovp_launch_chol(const double* A, double* L, int n, int ld, int* flag, int add_identity,
+                           hipStream_t stream) {
+  const size_t shmem = (size_t)n * (ovp::CH_NB + 1) * sizeof(double);
+  if (shmem > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)ovp::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ovp::k_chol, dim3(1), dim3(ovp::CH_T), shmem, stream, A, L, n, ld, flag, add_identity);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_gemm(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
+                           int ldb, double* C, int ldc, int add_identity, hipStream_t stream) {
+  dim3 grid((N + 15) / 16, (M + 15) / 16), block(64);
+  if (!transA && !transB)
+    hipLaunchKernelGGL((ovp::k_gemm<false, false>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc, add_identity);
+  else if (transA && !transB)
+    hipLaunchKernelGGL((ovp::k_gemm<true, false>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc, add_identity);
+  else if (!transA && transB)
+    hipLaunchKernelGGL((ovp::k_gemm<false, true>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc, add_identity);
+  else
+    hipLaunchKernelGGL((ovp::k_gemm<true, true>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc, add_identity);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_trsm_right_lt(const double* L, const double* Lt, double* Y, int n, int ld, hipStream_t stream) {
+  const size_t shmem = (size_t)16 * n * sizeof(double);
+  hipLaunchKernelGGL(ovp::k_trsm_right_lt, dim3((n + 15) / 16), dim3(256), shmem, stream, L, Lt, Y, n, ld);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_cov_finish(const double* Y, int n, int ld, const double* b, double* P, int ldp, double* dx,
+                                 int* negdiag, hipStream_t stream) {
+  hipError_t e = ovp_launch_gemm(0, 1, n, n, n, Y, ld, Y, ld, P, ldp, 0, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ovp::k_dx_negdiag, dim3((n + 63) / 64), dim3(64), 0, stream, P, n, ldp, b, dx, negdiag);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out,
+                                      hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_gather_marginal, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, cols, m, out);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, hipStream_t stream) {
+  const int total = (n_old + sz) * sz;
+  hipLaunchKernelGGL(ovp::k_cov_clone, dim3((total + 255) / 256), dim3(256), 0, stream, P, ldp, n_old, src, sz);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, int n_old, int id, int sz,
+                                      hipStream_t stream) {
+  const int n_new = n_old - sz;
+  if (n_new <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ovp::k_cov_marginalize, dim3((n_new + 127) / 128, n_new), dim3(128), 0, stream, src, dst, ld,
+                     n_old, id, sz);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, const int* oldcol, int nold,
+                                const double* Phi, const double* Q, double* CPT, double* PCP, int* negdiag,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_prop_cpt, dim3((phi + 63) / 64, n), dim3(64), 0, stream, P, ldp, n, oldcol, nold, Phi, phi,
+                     CPT);
+  hipLaunchKernelGGL(ovp::k_prop_pcp, dim3(phi), dim3(((phi + 63) / 64) * 64), 0, stream, CPT, oldcol, nold, Phi, Q, phi,
+                     PCP);
+  hipLaunchKernelGGL(ovp::k_prop_write, dim3(n), dim3(((phi + 63) / 64) * 64), 0, stream, P, ldp, n, start, phi, CPT,
+                     PCP, negdiag);
+  hipLaunchKernelGGL(ovp::k_check_negdiag, dim3((n + 255) / 256), dim3(256), 0, stream, P, ldp, n, negdiag);
+  return hipGetLastError();
+}
+}

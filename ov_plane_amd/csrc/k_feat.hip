@@ -1,0 +1,450 @@
+// K1: per-feature build -> (implicit) left-nullspace projection -> chi2 gate -> projector rows.
+//
+// One wavefront per MSCKF point feature (lane i <-> measurement row i, lanes 2a and 2a+1 <-> observation a).
+// Replaces the per-feature body of UpdaterMSCKF::update (update/UpdaterMSCKF.cpp:695-786):
+//   get_feature_jacobian_full   update/UpdaterHelper.cpp:195-513  (GLOBAL_3D, radtan, mono)
+//   nullspace_project_inplace   update/UpdaterHelper.cpp:515-546
+//   gate                        update/UpdaterMSCKF.cpp:739-764
+// MI355X-first formulation: the stacked Jacobian is never densified.  Row pair a of H_x only
+// touches clone(a)'s 6 columns and the 14 calibration columns, so
+//   B = H_x P H_x^T + I                      is built from 6x6 / 6x14 / 14x14 blocks of P,
+//   chi2 = r^T N (N^T B N)^-1 N^T r          = y^T y - (Z^T y)^T (Z^T Z)^-1 (Z^T y),  L L^T = B, y = L^-1 r, Z = L^-1 H_f
+// (N = left nullspace of H_f; identity valid for any orthonormal N), and the feature's contribution to the
+// information pair is  Hp^T Hp = H_x^T H_x - G^T G,  Hp^T rp = H_x^T r - G^T g  with  G = Q1^T H_x, g = Q1^T r,
+// Q1 an orthonormal basis of range(H_f).  The kernel emits the sparse rows (rec) and G|g; K2 reduces them.
+#include "ovp_dev.h"
+#include "ovp_kernels.h"
+#include <utility>
+
+namespace ovp {
+
+static constexpr int NR = 64;               // rows handled by one wave (2 * OVP_MAX_MEAS)
+static constexpr int TRI = NR * (NR + 1) / 2;
+
+// compile-time loop: guarantees that register arrays are only ever indexed by constants
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  // two Newton steps: y <- y * (1.5 - 0.5 x y^2)
+  double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+__global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int m = p.n_meas[f];
+  const int n = 2 * m;
+
+  __shared__ __attribute__((aligned(16))) double sJ[NR * 6];
+  __shared__ __attribute__((aligned(16))) double sC[NR * 14];
+  __shared__ __attribute__((aligned(16))) double sE[NR * 14];
+  __shared__ __attribute__((aligned(16))) double sB[TRI];
+
+  const int a = lane >> 1, r = lane & 1;
+  long long tstamp[8];
+  tstamp[0] = __builtin_readcyclecounter();
+  const bool valid = lane < n;
+  const bool feat_ok = (m >= 2) && (m <= OVP_MAX_MEAS_DEV);  // UpdaterMSCKF.cpp:94-96
+  const int* cidx = p.clone_idx + (size_t)f * p.max_meas;
+  const int ci = cidx[valid ? a : 0];
+  const int ida = p.clone_id[ci];
+
+  // ------------------------------------------------------------------------------------------
+  // Phase A: measurement model for observation a, keep row r.   UpdaterHelper.cpp:345-444
+  // ------------------------------------------------------------------------------------------
+  double jrow[6], crow[14], hf[3], res;
+  {
+    const double pf0 = p.p_FinG[3 * f], pf1 = p.p_FinG[3 * f + 1], pf2 = p.p_FinG[3 * f + 2];
+    const double* R = p.clone_R + 9 * ci;
+    const double* pp = p.clone_p + 3 * ci;
+    double d0 = pf0 - pp[0], d1 = pf1 - pp[1], d2 = pf2 - pp[2];
+    double pI0 = R[0] * d0 + R[1] * d1 + R[2] * d2;
+    double pI1 = R[3] * d0 + R[4] * d1 + R[5] * d2;
+    double pI2 = R[6] * d0 + R[7] * d1 + R[8] * d2;
+    const double* Rc = p.R_ItoC;
+    double pC0 = Rc[0] * pI0 + Rc[1] * pI1 + Rc[2] * pI2 + p.p_IinC[0];
+    double pC1 = Rc[3] * pI0 + Rc[4] * pI1 + Rc[5] * pI2 + p.p_IinC[1];
+    double pC2 = Rc[6] * pI0 + Rc[7] * pI1 + Rc[8] * pI2 + p.p_IinC[2];
+    const double x = pC0 / pC2, y = pC1 / pC2;
+    // ext CamRadtan::distort_d (call site UpdaterHelper.cpp:365)
+    const double fx = p.intr[0], fy = p.intr[1], cx = p.intr[2], cy = p.intr[3];
+    const double k1 = p.intr[4], k2 = p.intr[5], p1 = p.intr[6], p2 = p.intr[7];
+    const double r2 = x * x + y * y, r4 = r2 * r2;
+    const double g = 1.0 + k1 * r2 + k2 * r4;
+    const double x1 = x * g + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+    const double y1 = y * g + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+    const double ud = fx * x1 + cx, vd = fy * y1 + cy;
+    const float* uvp = p.uv + ((size_t)f * p.max_meas + (valid ? a : 0)) * 2;
+    const double um = (double)uvp[0], vm = (double)uvp[1];
+    res = p.white_px * (r ? (vm - vd) : (um - ud));
+    // FEJ re-evaluation :376-385
+    if (p.do_fej) {
+      R = p.clone_R_fej + 9 * ci;
+      pp = p.clone_p_fej + 3 * ci;
+      d0 = pf0 - pp[0];
+      d1 = pf1 - pp[1];
+      d2 = pf2 - pp[2];
+      pI0 = R[0] * d0 + R[1] * d1 + R[2] * d2;
+      pI1 = R[3] * d0 + R[4] * d1 + R[5] * d2;
+      pI2 = R[6] * d0 + R[7] * d1 + R[8] * d2;
+      pC0 = Rc[0] * pI0 + Rc[1] * pI1 + Rc[2] * pI2 + p.p_IinC[0];
+      pC1 = Rc[3] * pI0 + Rc[4] * pI1 + Rc[5] * pI2 + p.p_IinC[1];
+      pC2 = Rc[6] * pI0 + Rc[7] * pI1 + Rc[8] * pI2 + p.p_IinC[2];
+    }
+    // ext CamRadtan::compute_distort_jacobian at the non-FEJ uv_norm (:383,389), row r only
+    double dzn0, dzn1;  // dz_dzn[r][0..1]
+    if (r == 0) {
+      dzn0 = fx * (g + 2.0 * k1 * x * x + 4.0 * k2 * x * x * r2 + 2.0 * p1 * y + 6.0 * p2 * x);
+      dzn1 = fx * (2.0 * k1 * x * y + 4.0 * k2 * x * y * r2 + 2.0 * p1 * x + 2.0 * p2 * y);
+      crow[6] = x1;
+      crow[7] = 0.0;
+      crow[8] = 1.0;
+      crow[9] = 0.0;
+      crow[10] = fx * x * r2;
+      crow[11] = fx * x * r4;
+      crow[12] = 2.0 * fx * x * y;
+      crow[13] = fx * (r2 + 2.0 * x * x);
+    } else {
+      dzn0 = fy * (2.0 * k1 * x * y + 4.0 * k2 * x * y * r2 + 2.0 * p1 * x + 2.0 * p2 * y);
+      dzn1 = fy * (g + 2.0 * k1 * y * y + 4.0 * k2 * y * y * r2 + 6.0 * p1 * y + 2.0 * p2 * x);
+      crow[6] = 0.0;
+      crow[7] = y1;
+      crow[8] = 0.0;
+      crow[9] = 1.0;
+      crow[10] = fy * y * r2;
+      crow[11] = fy * y * r4;
+      crow[12] = fy * (r2 + 2.0 * y * y);
+      crow[13] = 2.0 * fy * x * y;
+    }
+    // dzn_dpfc (:392-393) folded with dz_dzn (:407): dz_dpfc row r
+    const double iz = 1.0 / pC2;
+    const double z0 = dzn0 * iz, z1 = dzn1 * iz, z2 = -(dzn0 * pC0 + dzn1 * pC1) * iz * iz;
+    const double w = p.white_px;
+    // dpfc_dpfg = R_ItoC R_GtoIi (:396);  H_f row (:411)
+    // v = (dz_dpfc row) * R_ItoC   (1x3)
+    const double v0 = z0 * Rc[0] + z1 * Rc[3] + z2 * Rc[6];
+    const double v1 = z0 * Rc[1] + z1 * Rc[4] + z2 * Rc[7];
+    const double v2 = z0 * Rc[2] + z1 * Rc[5] + z2 * Rc[8];
+    hf[0] = w * (v0 * R[0] + v1 * R[3] + v2 * R[6]);
+    hf[1] = w * (v0 * R[1] + v1 * R[4] + v2 * R[7]);
+    hf[2] = w * (v0 * R[2] + v1 * R[5] + v2 * R[8]);
+    // clone block (:399-401,414): [ dz_dpfc R_ItoC skew(p_FinIi) , -dz_dpfg ]
+    jrow[0] = w * (v1 * pI2 - v2 * pI1);
+    jrow[1] = w * (v2 * pI0 - v0 * pI2);
+    jrow[2] = w * (v0 * pI1 - v1 * pI0);
+    jrow[3] = -hf[0];
+    jrow[4] = -hf[1];
+    jrow[5] = -hf[2];
+    // extrinsics block (:426-435): [ dz_dpfc skew(p_FinCi - p_IinC) , dz_dpfc ]
+    const double q0 = pC0 - p.p_IinC[0], q1 = pC1 - p.p_IinC[1], q2 = pC2 - p.p_IinC[2];
+    crow[0] = w * (z1 * q2 - z2 * q1);
+    crow[1] = w * (z2 * q0 - z0 * q2);
+    crow[2] = w * (z0 * q1 - z1 * q0);
+    crow[3] = w * z0;
+    crow[4] = w * z1;
+    crow[5] = w * z2;
+#pragma unroll
+    for (int k = 6; k < 14; ++k) crow[k] *= w;  // intrinsics block (:438-440)
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+      if (!((p.calmask >> k) & 1)) crow[k] = 0.0;
+    if (!valid) {
+      res = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) jrow[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 14; ++k) crow[k] = 0.0;
+      hf[0] = hf[1] = hf[2] = 0.0;
+    }
+  }
+
+  tstamp[1] = __builtin_readcyclecounter();
+  const double* P = p.P;
+  const int ldp = p.ldp;
+  double chi2 = 0.0;
+  bool accept = false;
+  double yv = 0.0, zv[3] = {0.0, 0.0, 0.0};
+
+  if (feat_ok) {
+    // ----------------------------------------------------------------------------------------
+    // Phase A2: e = j P[clone(a), cal], d = c P[cal, cal], u = e + d ; publish rows to LDS
+    // ----------------------------------------------------------------------------------------
+    double u[14];
+    {
+      double e[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        e[k] = 0.0;
+        u[k] = 0.0;
+        if ((p.calmask >> k) & 1) {
+          const double* prow = P + (size_t)p.calcol[k] * ldp;
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) s = fma(jrow[l], prow[ida + l], s);
+          e[k] = s;
+          double dsum = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < 14; ++kk)
+            if ((p.calmask >> kk) & 1) dsum = fma(crow[kk], P[(size_t)p.calcol[kk] * ldp + p.calcol[k]], dsum);
+          u[k] = s + dsum;
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < 6; ++l) sJ[lane * 6 + l] = jrow[l];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        sC[lane * 14 + k] = crow[k];
+        sE[lane * 14 + k] = e[k];
+      }
+    }
+    __syncthreads();
+    tstamp[2] = __builtin_readcyclecounter();
+
+    // ----------------------------------------------------------------------------------------
+    // Phase B: row `lane` of B = H_x P H_x^T + I, lower triangle, packed in LDS
+    // ----------------------------------------------------------------------------------------
+    for (int b = 0; b < m; ++b) {
+      const int cb = cidx[b];
+      const int idb = p.clone_id[cb];
+      double t[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double* prow = P + (size_t)(idb + k) * ldp + ida;  // P[clone(b)+k][clone(a)+l] (symmetric)
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) s = fma(jrow[l], prow[l], s);
+        t[k] = s;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int col = 2 * b + rr;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s = fma(t[k], sJ[col * 6 + k], s);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) s = fma(u[k], sC[col * 14 + k], s);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) s = fma(crow[k], sE[col * 14 + k], s);
+        if (col <= lane) sB[tri(lane, col)] = s + (col == lane ? 1.0 : 0.0);
+      }
+    }
+    __syncthreads();
+    tstamp[3] = __builtin_readcyclecounter();
+
+    // ----------------------------------------------------------------------------------------
+    // Phase C: Cholesky of B with the row in registers, fused forward substitution of [r | H_f]
+    // ----------------------------------------------------------------------------------------
+    double arow[NR];
+    static_for<NR>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      double v = (k == lane) ? 1.0 : 0.0;
+      if (valid && k <= lane) v = sB[tri(lane, k)];
+      arow[k] = v;
+    });
+    __syncthreads();
+    double rh0 = res, rh1 = hf[0], rh2 = hf[1], rh3 = hf[2];
+    double* colbuf = sB;  // 2 x 64 doubles, alternating
+    bool spd = true;
+    static_for<NR>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k < n) {  // wave-uniform
+        const double dkk = readlane_f64(arow[k], k);
+        spd = spd && (dkk > 0.0);
+        const double inv = rsqrt_nr(dkk);
+        const double l = arow[k] * inv;  // column k of L (valid for lanes >= k)
+        double* cb = colbuf + (k & 1) * NR;
+        cb[lane] = l;
+        // forward substitution of the 4 right-hand sides
+        const double x0 = readlane_f64(rh0, k) * inv, x1 = readlane_f64(rh1, k) * inv;
+        const double x2 = readlane_f64(rh2, k) * inv, x3 = readlane_f64(rh3, k) * inv;
+        if (lane > k) {
+          rh0 = fma(-l, x0, rh0);
+          rh1 = fma(-l, x1, rh1);
+          rh2 = fma(-l, x2, rh2);
+          rh3 = fma(-l, x3, rh3);
+        } else if (lane == k) {
+          rh0 = x0;
+          rh1 = x1;
+          rh2 = x2;
+          rh3 = x3;
+        }
+        __syncthreads();
+        // trailing update of this lane's row: a[j] -= l_ik * l_jk
+        constexpr int jb0 = (k + 1) / 8;
+        static_for<8 - jb0>([&](auto jbc) {
+          constexpr int j0 = (jb0 + decltype(jbc)::value) * 8;
+          if (j0 < n) {  // wave-uniform
+            static_for<8>([&](auto jc) {
+              constexpr int j = j0 + decltype(jc)::value;
+              if constexpr (j > k) arow[j] = fma(-l, cb[j], arow[j]);
+            });
+          }
+        });
+      }
+    });
+    tstamp[4] = __builtin_readcyclecounter();
+    yv = valid ? rh0 : 0.0;
+    zv[0] = valid ? rh1 : 0.0;
+    zv[1] = valid ? rh2 : 0.0;
+    zv[2] = valid ? rh3 : 0.0;
+
+    // ----------------------------------------------------------------------------------------
+    // Phase D: chi2 = y^T y - (Z^T y)^T (Z^T Z)^-1 (Z^T y)      UpdaterMSCKF.cpp:739-764
+    // ----------------------------------------------------------------------------------------
+    double sums[10];
+    {
+      double v[16];
+      v[0] = yv * yv;
+      v[1] = zv[0] * yv;
+      v[2] = zv[1] * yv;
+      v[3] = zv[2] * yv;
+      v[4] = zv[0] * zv[0];
+      v[5] = zv[0] * zv[1];
+      v[6] = zv[0] * zv[2];
+      v[7] = zv[1] * zv[1];
+      v[8] = zv[1] * zv[2];
+      v[9] = zv[2] * zv[2];
+#pragma unroll
+      for (int k = 10; k < 16; ++k) v[k] = 0.0;
+      const double rsum = wave_transpose_reduce<16>(v);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) sums[k] = readlane_f64(rsum, reduce_owner_lane<16>(k));
+    }
+    {
+      const double l00 = sqrt(sums[4]);
+      const double l10 = sums[5] / l00, l20 = sums[6] / l00;
+      const double l11 = sqrt(sums[7] - l10 * l10);
+      const double l21 = (sums[8] - l20 * l10) / l11;
+      const double l22 = sqrt(sums[9] - l20 * l20 - l21 * l21);
+      const double w0 = sums[1] / l00;
+      const double w1 = (sums[2] - l10 * w0) / l11;
+      const double w2 = (sums[3] - l20 * w0 - l21 * w1) / l22;
+      chi2 = sums[0] - (w0 * w0 + w1 * w1 + w2 * w2);
+    }
+    const int dof = n - 3;
+    const double thr = p.chi2_mult * p.chi2_table[dof < OVP_CHI2_TABLE ? dof : OVP_CHI2_TABLE];
+    accept = spd && (chi2 <= thr);  // NaN (rank-deficient H_f) rejects
+  }
+  __syncthreads();
+  tstamp[5] = __builtin_readcyclecounter();
+
+  // ------------------------------------------------------------------------------------------
+  // Phase E: projector rows G = Q1^T H_x, g = Q1^T r  (Q1 by CholeskyQR2 on H_f), staged in LDS
+  // ------------------------------------------------------------------------------------------
+  const int ldg = p.ldg;
+  double* Gst = sB;  // 3 * ldg doubles (ldg <= OVP_LDG_MAX so that it fits in TRI)
+  for (int idx = lane; idx < 3 * ldg; idx += 64) Gst[idx] = 0.0;
+  __syncthreads();
+  if (accept) {
+    double q[3] = {hf[0], hf[1], hf[2]};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      double v[8];
+      v[0] = q[0] * q[0];
+      v[1] = q[0] * q[1];
+      v[2] = q[0] * q[2];
+      v[3] = q[1] * q[1];
+      v[4] = q[1] * q[2];
+      v[5] = q[2] * q[2];
+      v[6] = 0.0;
+      v[7] = 0.0;
+      const double rsum = wave_transpose_reduce<8>(v);
+      const double g00 = readlane_f64(rsum, reduce_owner_lane<8>(0)), g01 = readlane_f64(rsum, reduce_owner_lane<8>(1));
+      const double g02 = readlane_f64(rsum, reduce_owner_lane<8>(2)), g11 = readlane_f64(rsum, reduce_owner_lane<8>(3));
+      const double g12 = readlane_f64(rsum, reduce_owner_lane<8>(4)), g22 = readlane_f64(rsum, reduce_owner_lane<8>(5));
+      // R upper: R^T R = G
+      const double r00 = sqrt(g00), r01 = g01 / r00, r02 = g02 / r00;
+      const double r11 = sqrt(g11 - r01 * r01), r12 = (g12 - r01 * r02) / r11;
+      const double r22 = sqrt(g22 - r02 * r02 - r12 * r12);
+      const double a0 = q[0] / r00;
+      const double a1 = (q[1] - a0 * r01) / r11;
+      const double a2 = (q[2] - a0 * r02 - a1 * r12) / r22;
+      q[0] = a0;
+      q[1] = a1;
+      q[2] = a2;
+    }
+    // calibration columns and g: 3*14 + 3 = 45 wave sums in one transposed reduction
+    {
+      double v[64];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[t * 14 + k] = q[t] * crow[k];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) v[42 + t] = q[t] * res;
+#pragma unroll
+      for (int k = 45; k < 64; ++k) v[k] = 0.0;
+      const double rsum = wave_transpose_reduce<64>(v);
+      if (lane < 42) {
+        const int t = lane / 14, k = lane - 14 * t;
+        if ((p.calmask >> k) & 1) Gst[t * ldg + p.calcol[k]] = rsum;
+      } else if (lane < 45) {
+        Gst[(lane - 42) * ldg + p.n] = rsum;
+      }
+    }
+    // clone columns: sum of the two rows of the observation
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int l = 0; l < 6; ++l) {
+        double v = q[t] * jrow[l];
+        v += shfl_xor_f64(v, 1);
+        if (valid && r == 0) Gst[t * ldg + ida + l] = v;
+      }
+  }
+  __syncthreads();
+  tstamp[6] = __builtin_readcyclecounter();
+  {
+    double* gout = p.G + (size_t)3 * f * ldg;
+    for (int idx = lane; idx < 3 * ldg; idx += 64) gout[idx] = Gst[idx];
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // sparse rows for K2 (zero for rejected features / unobserved clones)
+  // ------------------------------------------------------------------------------------------
+  unsigned long long seen = 0ull;
+  if (accept) {
+    for (int b = 0; b < m; ++b) seen |= 1ull << cidx[b];
+    if (valid) {
+      double* ro = p.rec + (((size_t)ci * p.n_feats + f) * 2 + r) * OVP_REC;
+#pragma unroll
+      for (int l = 0; l < 6; ++l) ro[l] = jrow[l];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) ro[6 + k] = crow[k];
+      ro[20] = res;
+    }
+  }
+  for (int cc = 0; cc < p.n_clones; ++cc) {
+    if (!((seen >> cc) & 1ull)) {
+      double* ro = p.rec + (((size_t)cc * p.n_feats + f) * 2) * OVP_REC;
+      if (lane < 2 * OVP_REC) ro[lane] = 0.0;
+    }
+  }
+  tstamp[7] = __builtin_readcyclecounter();
+  if (p.dbg_cycles && lane == 0) {
+    for (int k = 0; k < 8; ++k) p.dbg_cycles[(size_t)f * 8 + k] = tstamp[k];
+  }
+  if (lane == 0) {
+    p.chi2[f] = chi2;
+    p.accept[f] = accept ? 1 : 0;
+  }
+}
+
+}  // namespace ovp
+
+extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream) {
+  if (p->n_feats <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ovp::k_feat_gate, dim3(p->n_feats), dim3(64), 0, stream, *p);
+  return hipGetLastError();
+}

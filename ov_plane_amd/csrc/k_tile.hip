@@ -1,0 +1,432 @@
+// K3 fast path: register-resident tile Cholesky + blocked forward substitution on v_mfma_f64_16x16x4_f64.
+//
+// A 200-300 dimensional factorization is latency bound, not FLOP bound: the 3 MFLOP of chol(210) are 10 us of one
+// CU's f64 rate, but every column step of a textbook kernel costs a barrier and a memory round trip.  Here the
+// whole lower triangle lives in the register file of ONE workgroup (8 waves x <=22 tiles of 16x16 f64 in MFMA
+// accumulator layout = up to 360 KB of the CU's 512 KB), panels are exchanged through LDS, and every step that
+// is not the 16x16 diagonal factorization is an MFMA:
+//   step k:  (a) owner publishes tile (k,k)             -> LDS
+//            (b) wave 0: lane-per-row Cholesky of the 16x16 block in registers (v_readlane broadcasts, no
+//                barriers) and its inverse  X = L_kk^-1 ; publishes L_kk and W = X^T
+//            (c) panel tiles (i,k) <- tile * W           (4 MFMA each), published to LDS
+//            (d) trailing tiles (i,j) -= L_ik L_jk^T      (4 MFMA each)
+// Three workgroup barriers per 16 columns instead of ~3 per column.
+// f64 MFMA operand layout (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// C/D reg v: row = (lane>>4) + 4 v, col = lane&15.
+#include "ovp_dev.h"
+#include "ovp_kernels.h"
+#include <utility>
+
+namespace ovp {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int... Is, class F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+__device__ __forceinline__ double rsqrt_nr2(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+static constexpr int TS = 17;        // LDS row pitch of a 16x16 tile (doubles)
+static constexpr int TSZ = 16 * TS;  // doubles per LDS tile
+static constexpr int TC_WAVES = 8;       // 1 factor wave + 7 tile waves
+static constexpr int TC_TILE_WAVES = 7;
+
+// multiply-accumulate of two LDS tiles in "row, k" form:  acc += sign * X[row][:] . Y[col][:]
+__device__ __forceinline__ double4_t mfma_xyT(const double* X, const double* Y, double4_t acc, double sign, int lc,
+                                              int lr) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const double a = sign * X[lc * TS + lr + 4 * s];
+    const double b = Y[lc * TS + lr + 4 * s];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// 16x16 diagonal block: Cholesky (lane r <-> row r) and inverse (lane c <-> column c of X = L^-1), one wave.
+__device__ __forceinline__ void diag_factor(double* Dbuf, double* Wbuf, double* dinv_out, int lane, int* flag) {
+  const int row = lane & 15;
+  double d[16];
+  double invd_mine = 0.0;  // lane c keeps 1 / L[c][c]
+  sfor<16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    d[c] = Dbuf[row * TS + c];
+  });
+  bool bad = false;
+  sfor<16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const double piv = readlane_f64(d[c], c);
+    bad = bad || !(piv > 0.0);
+    const double inv = rsqrt_nr2(piv);
+    if (row == c) invd_mine = inv;
+    const double l = d[c] * inv;
+    d[c] = l;
+    sfor<15 - c>([&](auto jc) {
+      constexpr int j = c + 1 + decltype(jc)::value;
+      const double ljc = readlane_f64(l, j);
+      d[j] = fma(-l, ljc, d[j]);
+    });
+  });
+  if (bad && lane == 0) *flag = 1;
+  if (lane < 16) {
+    sfor<16>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      Dbuf[row * TS + c] = (c <= row) ? d[c] : 0.0;  // L_kk, zero above the diagonal
+    });
+  }
+  double x[16];
+  sfor<16>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    double sum = (r == row) ? 1.0 : 0.0;
+    sfor<r>([&](auto sc2) {
+      constexpr int s2 = decltype(sc2)::value;
+      const double lrs = readlane_f64(d[s2], r);
+      sum = fma(-lrs, x[s2], sum);
+    });
+    x[r] = sum * readlane_f64(invd_mine, r);
+  });
+  if (lane < 16) {
+    sfor<16>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      Wbuf[row * TS + r] = x[r];  // W = X^T : W[c][r] = X[r][c]
+      if (dinv_out) dinv_out[r * 16 + row] = x[r];
+    });
+  }
+}
+
+// Wave 0 is the factor wave (owns no tiles, so the 16x16 factorization does not compete with the tile registers);
+// waves 1..TC_TILE_WAVES hold the tiles.  Both roles execute exactly three workgroup barriers per step.
+template <int MAXSLOT>
+__global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __restrict__ A, double* __restrict__ L,
+                                                           double* __restrict__ Dinv, int n, int ld,
+                                                           int* __restrict__ flag, int add_identity) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int nt = (n + 15) >> 4;
+  const int ntiles = nt * (nt + 1) / 2;
+  double* Dbuf = lds;
+  double* Wbuf = Dbuf + TSZ;
+  double* PB = Wbuf + TSZ;
+  double* SW = PB + nt * TSZ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+
+  if (wave == 0) {
+    for (int k = 0; k < nt; ++k) {
+      __syncthreads();  // B1: diagonal tile published
+      diag_factor(Dbuf, Wbuf, Dinv ? Dinv + (size_t)k * 256 : nullptr, lane, flag);
+      __syncthreads();  // B2: L_kk and W published
+      __syncthreads();  // B3: panel published
+    }
+  } else {
+    const int tw = wave - 1;
+    double* sw = SW + tw * TSZ;
+    double4_t tile[MAXSLOT];
+    int ti[MAXSLOT], tj[MAXSLOT];
+    // ---- load: tile index idx = slot*TILE_WAVES + tw, column-major over the lower tile triangle ----
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      const int idx = s * TC_TILE_WAVES + tw;
+      int i = -1, j = -1;
+      if (idx < ntiles) {
+        int jj = 0, start = 0;
+        while (start + (nt - jj) <= idx) {
+          start += nt - jj;
+          ++jj;
+        }
+        j = jj;
+        i = jj + (idx - start);
+      }
+      ti[s] = i;
+      tj[s] = j;
+      double4_t t = {0.0, 0.0, 0.0, 0.0};
+      if (i >= 0) {
+        const int c = 16 * j + lc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * i + lr + 4 * v;
+          double x = 0.0;
+          if (r < n && c < n) {
+            x = A[(size_t)r * ld + c];
+            if (add_identity && r == c) x += 1.0;
+          } else if (r == c) {
+            x = 1.0;  // identity padding keeps the padded matrix SPD
+          }
+          t[v] = x;
+        }
+      }
+      tile[s] = t;
+    });
+
+    for (int k = 0; k < nt; ++k) {
+      // (a) publish the diagonal tile
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (ti[s] == k && tj[s] == k) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Dbuf[(lr + 4 * v) * TS + lc] = tile[s][v];
+        }
+      });
+      __syncthreads();  // B1
+      __syncthreads();  // B2 (factor wave worked in between)
+      // (c) diagonal owner reloads L_kk; panel tiles <- tile * W, published to PB
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (tj[s] == k) {
+          if (ti[s] == k) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tile[s][v] = Dbuf[(lr + 4 * v) * TS + lc];
+          } else if (ti[s] > k) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sw[(lr + 4 * v) * TS + lc] = tile[s][v];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double a = sw[lc * TS + lr + 4 * q];
+              const double b = Wbuf[(lr + 4 * q) * TS + lc];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            tile[s] = acc;
+            double* pb = PB + ti[s] * TSZ;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pb[(lr + 4 * v) * TS + lc] = acc[v];
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      });
+      __syncthreads();  // B3
+      // (d) trailing update
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (tj[s] > k) tile[s] = mfma_xyT(PB + ti[s] * TSZ, PB + tj[s] * TSZ, tile[s], -1.0, lc, lr);
+      });
+      // no barrier here: (a) of the next step only writes Dbuf, which nobody reads in (d); PB is rewritten after B2
+    }
+    // ---- store L (lower) ----
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (ti[s] >= 0) {
+        const int c = 16 * tj[s] + lc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * ti[s] + lr + 4 * v;
+          if (r < n && c < n) L[(size_t)r * ld + c] = tile[s][v];
+        }
+      }
+    });
+  }
+  // zero the strict upper tile triangle (disjoint from the tiles stored above)
+  for (int idx = tid; idx < n * n; idx += TC_WAVES * 64) {
+    const int r = idx / n, c = idx - r * n;
+    if ((c >> 4) > (r >> 4)) L[(size_t)r * ld + c] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V = Lt^-1 * L^T  by blocked forward substitution; one workgroup (4 waves) per 16-column slab of V.
+//   V_i = Dinv_i ( (L^T)_i - sum_{k<i} Lt_ik V_k ),   Dinv_i = (Lt_ii)^-1 from k_tilechol.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Lt, const double* __restrict__ Dinv,
+                                                 const double* __restrict__ Lmat, double* __restrict__ V, int n,
+                                                 int ld) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int nt = (n + 15) >> 4;
+  const int cblk = blockIdx.x;  // column tile of V
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane >> 4, lc = lane & 15;
+  double* Vt = lds;                 // nt tiles: V_k row-major [kk][col]
+  double* red = Vt + nt * TSZ;      // 4 x 256 partial accumulators
+  double* tmp = red + 4 * 256;      // one tile
+  for (int i = 0; i < nt; ++i) {
+    // partial sums over k = wave, wave+4, ...
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = wave; k < i; k += 4) {
+      const double* vk = Vt + k * TSZ;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * i + lc, c = 16 * k + lr + 4 * q;
+        const double a = (r < n && c < n) ? Lt[(size_t)r * ld + c] : 0.0;
+        const double b = vk[(lr + 4 * q) * TS + lc];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[wave * 256 + (lr + 4 * v) * 16 + lc] = acc[v];
+    __syncthreads();
+    if (wave == 0) {
+      // rhs tile (i, cblk) of L^T: element [row][col] = L[16 cblk + col][16 i + row], zero if cblk < i
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = lr + 4 * v;
+        const int e = row * 16 + lc;
+        double sum = ((red[e] + red[256 + e]) + red[512 + e]) + red[768 + e];
+        const int gr = 16 * cblk + lc, gc = 16 * i + row;
+        if (cblk >= i && gr < n && gc < n) sum += Lmat[(size_t)gr * ld + gc];
+        tmp[row * TS + lc] = sum;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      double4_t vi = {0.0, 0.0, 0.0, 0.0};
+      const double* di = Dinv + (size_t)i * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = di[lc * 16 + lr + 4 * q];
+        const double b = tmp[(lr + 4 * q) * TS + lc];
+        vi = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, vi, 0, 0, 0);
+      }
+      double* vt = Vt + i * TSZ;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = lr + 4 * v;
+        vt[row * TS + lc] = vi[v];
+        const int gr = 16 * i + row, gc = 16 * cblk + lc;
+        if (gr < n && gc < n) V[(size_t)gr * ld + gc] = vi[v];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM, 4 waves per 16x16 output tile (split K, fixed-order LDS reduction), operands prefetched 4 k-steps deep.
+// C = op(A) op(B) (+ I); optional symmetric mode computes only tiles with bi >= bj and mirrors them.
+// ------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm4(int M, int N, int K, const double* __restrict__ A, int lda,
+                                               const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
+                                               int add_identity, int symmetric) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (symmetric && bj > bi) return;
+  const int i0 = bi * 16, j0 = bj * 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int ai = i0 + lc, bjj = j0 + lc;
+  // wave w takes k-steps w, w+4, ... (one k-step = 4 consecutive k)
+  const int nsteps = (K + 3) >> 2;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int st = wave; st < nsteps; st += 16) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 4 * (st + 4 * u) + lr;
+      av[u] = 0.0;
+      bv[u] = 0.0;
+      if (k < K && (st + 4 * u) < nsteps) {
+        if (ai < M) av[u] = TA ? A[(size_t)k * lda + ai] : A[(size_t)ai * lda + k];
+        if (bjj < N) bv[u] = TB ? B[(size_t)bjj * ldb + k] : B[(size_t)k * ldb + bjj];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  __shared__ double red[4][256];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) red[wave][(lr + 4 * v) * 16 + lc] = acc[v];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  const int gr = i0 + row, gc = j0 + col;
+  if (gr < M && gc < N) {
+    if (add_identity && gr == gc) sum += 1.0;
+    C[(size_t)gr * ldc + gc] = sum;
+    if (symmetric && bi != bj) C[(size_t)gc * ldc + gr] = sum;
+  }
+}
+
+// dx = P b (one wave per row), negative-diagonal flag
+__global__ __launch_bounds__(256) void k_dx_rows(const double* __restrict__ P, int n, int ldp,
+                                                  const double* __restrict__ b, double* __restrict__ dx,
+                                                  int* __restrict__ negdiag) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const double* pr = P + (size_t)row * ldp;
+  double s = 0.0;
+  for (int c = lane; c < n; c += 64) s = fma(pr[c], b[c], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    dx[row] = s;
+    if (pr[row] < 0.0) *negdiag = 1;
+  }
+}
+
+}  // namespace ovp
+
+extern "C" {
+
+// returns hipErrorInvalidValue when n is too large for the register-resident path (caller falls back)
+hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
+                               hipStream_t stream) {
+  const int nt = (n + 15) / 16;
+  const int ntiles = nt * (nt + 1) / 2;
+  const int slots = (ntiles + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
+  const size_t shmem = (size_t)(2 + nt + ovp::TC_WAVES) * ovp::TSZ * sizeof(double);
+  if (slots <= 15) {
+    hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, n, ld, flag,
+                       add_identity);
+  } else if (slots <= 25) {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)ovp::k_tilechol<25>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL((ovp::k_tilechol<25>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, n, ld, flag,
+                       add_identity);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
+                             hipStream_t stream) {
+  const int nt = (n + 15) / 16;
+  const size_t shmem = ((size_t)nt * ovp::TSZ + 4 * 256 + ovp::TSZ) * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)ovp::k_fwdsub, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), shmem, stream, Lt, Dinv, Lmat, V, n, ld);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
+                            int ldb, double* C, int ldc, int add_identity, int symmetric, hipStream_t stream) {
+  dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);
+  if (!transA && !transB)
+    hipLaunchKernelGGL((ovp::k_gemm4<false, false>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
+                       add_identity, symmetric);
+  else if (transA && !transB)
+    hipLaunchKernelGGL((ovp::k_gemm4<true, false>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
+                       add_identity, symmetric);
+  else if (!transA && transB)
+    hipLaunchKernelGGL((ovp::k_gemm4<false, true>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
+                       add_identity, symmetric);
+  else
+    hipLaunchKernelGGL((ovp::k_gemm4<true, true>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
+                       add_identity, symmetric);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_dx_rows, dim3((n + 3) / 4), dim3(256), 0, stream, P, n, ldp, b, dx, negdiag);
+  return hipGetLastError();
+}
+}

@@ -1,0 +1,762 @@
+// C-ABI shim of libovplane_hip.so (see include/ovplane_hip.h). Host-side orchestration only: every arithmetic
+// step of the update path runs in the gfx950 kernels of k_feat.hip / k_gram.hip / k_ekf.hip.
+#include "ovplane_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ovp_kernels.h"
+
+extern "C" {
+hipError_t ovp_launch_scatter_gram(const double* Acc, const double* bcc, int cols, const int* col_ids, double* Ab,
+                                   int lda, int n, hipStream_t stream);
+hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out, hipStream_t stream);
+hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, hipStream_t stream);
+hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, int n_old, int id, int sz,
+                                      hipStream_t stream);
+hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, const int* oldcol, int nold,
+                                const double* Phi, const double* Q, double* CPT, double* PCP, int* negdiag,
+                                hipStream_t stream);
+hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
+                               hipStream_t stream);
+hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
+                             hipStream_t stream);
+hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
+                            int ldb, double* C, int ldc, int add_identity, int symmetric, hipStream_t stream);
+hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
+                              hipStream_t stream);
+hipError_t ovp_launch_reduce_gram(const double* gramS, int n_clones, int n_chunks, double* gramR, hipStream_t stream);
+}
+
+static const int OVP_TILECHOL_NMAX = 288;  // register-resident factorization limit (22 tiles per wave)
+
+#define HIPCHK(x)                               \
+  do {                                          \
+    hipError_t _e = (x);                        \
+    if (_e != hipSuccess) return (int)_e;       \
+  } while (0)
+
+static inline int round_up(int v, int m) { return ((v + m - 1) / m) * m; }
+
+// ------------------------------------------------------------------------------------------------
+// chi-square 0.95 quantile (replaces boost::math::quantile(chi_squared(k), 0.95),
+// update/UpdaterMSCKF.cpp:59-62,749-750): regularised incomplete gamma + safeguarded Newton.
+// ------------------------------------------------------------------------------------------------
+static double gammap_reg(double a, double x) {
+  if (x <= 0) return 0.0;
+  const double gln = lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 100000; ++n) {
+      ap += 1.0;
+      del *= x / ap;
+      sum += del;
+      if (fabs(del) < fabs(sum) * 1e-17) break;
+    }
+    return sum * exp(-x + a * log(x) - gln);
+  }
+  double b = x + 1.0 - a, c = 1.0 / 1e-300, d = 1.0 / b, h = d;
+  for (int i = 1; i < 100000; ++i) {
+    const double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (fabs(d) < 1e-300) d = 1e-300;
+    c = b + an / c;
+    if (fabs(c) < 1e-300) c = 1e-300;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) < 1e-17) break;
+  }
+  return 1.0 - exp(-x + a * log(x) - gln) * h;
+}
+
+extern "C" double ovp_chi2_quantile_095(int dof) {
+  if (dof < 1) return 0.0;
+  const double p = 0.95, a = 0.5 * (double)dof;
+  const double z = 1.6448536269514722;
+  const double t = 1.0 - 2.0 / (9.0 * dof) + z * sqrt(2.0 / (9.0 * dof));
+  double x = 0.5 * dof * t * t * t;
+  if (x <= 0) x = 0.5;
+  double lo = 0.0, hi = 1e300;
+  for (int it = 0; it < 200; ++it) {
+    const double f = gammap_reg(a, x) - p;
+    if (f > 0) hi = x; else lo = x;
+    const double dens = exp((a - 1.0) * log(x) - x - lgamma(a));
+    double xn = x - f / dens;
+    if (!(xn > lo && xn < hi)) xn = (hi < 1e299) ? 0.5 * (lo + hi) : 2.0 * x;
+    if (fabs(xn - x) <= 1e-15 * fabs(xn)) {
+      x = xn;
+      break;
+    }
+    x = xn;
+  }
+  return 2.0 * x;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ovp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n_max = 0, c_max = 0, f_max = 0;
+  int n = 0, ld = 0;  // current covariance size, leading dimension of every n x n buffer
+  double *P = nullptr, *P_tmp = nullptr;
+  // state tables
+  double *clone_R = nullptr, *clone_p = nullptr, *clone_R_fej = nullptr, *clone_p_fej = nullptr;
+  int* clone_id = nullptr;
+  ovp::ColMap* colmap = nullptr;
+  double* chi2_table = nullptr;
+  ovp::FeatParams fp;
+  bool have_state = false, have_cov = false, have_batch = false;
+  // feature batch
+  float* uv = nullptr;
+  int *clone_idx = nullptr, *n_meas = nullptr;
+  double* p_FinG = nullptr;
+  int n_feats = 0, max_meas = 0;
+  // work buffers
+  double *G = nullptr, *rec = nullptr, *chi2 = nullptr;
+  unsigned char* accept = nullptr;
+  int ldg = 0;
+  double *gramS = nullptr, *gramR = nullptr, *part = nullptr, *Dinv = nullptr;
+  int n_chunks = 0, rows_per_chunk = 0, n_split = 0;
+  double* Ab = nullptr;  // (n_max+1) x ld
+  double *L = nullptr, *W1 = nullptr, *T = nullptr, *Lt = nullptr, *Y = nullptr;
+  double* dx = nullptr;
+  int* flags = nullptr;  // [0] not spd, [1] neg diag
+  double *Hd = nullptr, *Acc = nullptr, *bcc = nullptr, *resd = nullptr;  // dense-H path
+  size_t Hd_cap = 0, res_cap = 0;
+  int calib_id = -1, intr_id = -1;
+  long long* dbg_cycles = nullptr;
+  int* idbuf = nullptr;      // scratch ints (ids)
+  double* smallbuf = nullptr;  // scratch doubles (Phi, Q, CPT, PCP, marginal)
+  size_t small_cap = 0;
+  // pinned host staging
+  double *h_dx = nullptr, *h_chi2 = nullptr;
+  unsigned char* h_accept = nullptr;
+  int* h_flags = nullptr;
+  float last_ms[4] = {0, 0, 0, 0};
+  bool timed = false;
+  // dominant-kernel timer
+  bool ktimer = false;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+  double ktime_ms = 0.0;
+  int klaunches = 0;
+  bool kpending = false;
+};
+
+extern "C" const char* ovp_version(void) { return "ovplane_hip 0.1 (gfx950)"; }
+
+extern "C" const char* ovp_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case OVP_E_ARG: return "bad argument";
+    case OVP_E_CAPACITY: return "capacity exceeded";
+    case OVP_E_NOTSPD: return "matrix not positive definite";
+    case OVP_E_NEGDIAG: return "negative covariance diagonal";
+    case OVP_E_NODEVICE: return "no usable HIP device";
+    case OVP_E_STATE: return "call order violated";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown";
+  }
+}
+
+template <class T>
+static hipError_t dalloc(T** p, size_t count) {
+  return hipMalloc((void**)p, count * sizeof(T));
+}
+
+extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int n_feats_max, void* stream,
+                              ovp_ctx** out) {
+  if (!out || n_state_max < 1 || n_clones_max < 1 || n_clones_max > OVP_MAX_CLONES || n_feats_max < 1) return OVP_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return OVP_E_NODEVICE;
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OVP_E_NODEVICE;  // gfx950-only build, no fallback
+  ovp_ctx* c = new ovp_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->ev_t[i]));
+  HIPCHK(hipEventCreate(&c->ev_k0));
+  HIPCHK(hipEventCreate(&c->ev_k1));
+  c->n_max = n_state_max;
+  c->c_max = n_clones_max;
+  c->f_max = n_feats_max;
+  c->ld = round_up(n_state_max, 16);
+  c->ldg = round_up(n_state_max + 1, 16);
+  if (3 * c->ldg > 2080) return OVP_E_CAPACITY;  // K1 stages the projector rows in its 64x65/2 LDS triangle
+  const size_t nn = (size_t)(c->n_max + 1) * c->ld;
+  HIPCHK(dalloc(&c->P, nn));
+  HIPCHK(dalloc(&c->P_tmp, nn));
+  HIPCHK(dalloc(&c->Ab, nn));
+  HIPCHK(dalloc(&c->L, nn));
+  HIPCHK(dalloc(&c->W1, nn));
+  HIPCHK(dalloc(&c->T, nn));
+  HIPCHK(dalloc(&c->Lt, nn));
+  HIPCHK(dalloc(&c->Y, nn));
+  HIPCHK(dalloc(&c->dx, (size_t)c->n_max));
+  HIPCHK(dalloc(&c->flags, 4));
+  HIPCHK(dalloc(&c->clone_R, (size_t)9 * n_clones_max));
+  HIPCHK(dalloc(&c->clone_p, (size_t)3 * n_clones_max));
+  HIPCHK(dalloc(&c->clone_R_fej, (size_t)9 * n_clones_max));
+  HIPCHK(dalloc(&c->clone_p_fej, (size_t)3 * n_clones_max));
+  HIPCHK(dalloc(&c->clone_id, (size_t)n_clones_max));
+  HIPCHK(dalloc(&c->colmap, (size_t)c->n_max));
+  HIPCHK(dalloc(&c->chi2_table, (size_t)OVP_CHI2_TABLE + 1));
+  HIPCHK(dalloc(&c->uv, (size_t)n_feats_max * OVP_MAX_MEAS * 2));
+  HIPCHK(dalloc(&c->clone_idx, (size_t)n_feats_max * OVP_MAX_MEAS));
+  HIPCHK(dalloc(&c->n_meas, (size_t)n_feats_max));
+  HIPCHK(dalloc(&c->p_FinG, (size_t)n_feats_max * 3));
+  HIPCHK(dalloc(&c->G, (size_t)3 * n_feats_max * c->ldg));
+  HIPCHK(dalloc(&c->rec, (size_t)n_clones_max * n_feats_max * 2 * 21));
+  HIPCHK(dalloc(&c->chi2, (size_t)n_feats_max));
+  HIPCHK(dalloc(&c->accept, (size_t)n_feats_max));
+  // reduction geometry: fixed per context so the summation order (hence the result bits) is reproducible
+  c->rows_per_chunk = 512;
+  c->n_chunks = (2 * n_feats_max + c->rows_per_chunk - 1) / c->rows_per_chunk;
+  HIPCHK(dalloc(&c->gramS, (size_t)n_clones_max * c->n_chunks * OVP_GRAM_ELEMS));
+  HIPCHK(dalloc(&c->gramR, (size_t)n_clones_max * OVP_GRAM_ELEMS));
+  HIPCHK(dalloc(&c->Dinv, (size_t)(c->ld / 16 + 1) * 256));
+  c->n_split = (3 * n_feats_max + 511) / 512;
+  if (c->n_split < 1) c->n_split = 1;
+  if (c->n_split > 64) c->n_split = 64;
+  {
+    const int nt = c->ldg / 16;
+    HIPCHK(dalloc(&c->part, (size_t)c->n_split * (nt * (nt + 1) / 2) * 256));
+  }
+  HIPCHK(dalloc(&c->idbuf, (size_t)4 * c->n_max + 64));
+  c->small_cap = (size_t)4 * c->n_max * 64 + (size_t)c->n_max * c->n_max;
+  HIPCHK(dalloc(&c->smallbuf, c->small_cap));
+  HIPCHK(hipHostMalloc((void**)&c->h_dx, sizeof(double) * c->n_max));
+  HIPCHK(hipHostMalloc((void**)&c->h_chi2, sizeof(double) * n_feats_max));
+  HIPCHK(hipHostMalloc((void**)&c->h_accept, (size_t)n_feats_max));
+  HIPCHK(hipHostMalloc((void**)&c->h_flags, sizeof(int) * 4));
+  // chi2 table
+  {
+    std::vector<double> tab(OVP_CHI2_TABLE + 1, 0.0);
+    for (int k = 1; k <= OVP_CHI2_TABLE; ++k) tab[k] = ovp_chi2_quantile_095(k);
+    HIPCHK(hipMemcpy(c->chi2_table, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+  }
+  memset(&c->fp, 0, sizeof(c->fp));
+  *out = c;
+  return 0;
+}
+
+extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
+  if (!c) return OVP_E_ARG;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->stream2);
+  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->dx, c->flags, c->clone_R, c->clone_p,
+                 c->clone_R_fej, c->clone_p_fej, c->clone_id, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
+                 c->p_FinG, c->G, c->rec, c->chi2, c->accept, c->gramS, c->gramR, c->Dinv, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
+                 c->bcc, c->resd};
+  for (void* p : dev)
+    if (p) hipFree(p);
+  if (c->h_dx) hipHostFree(c->h_dx);
+  if (c->h_chi2) hipHostFree(c->h_chi2);
+  if (c->h_accept) hipHostFree(c->h_accept);
+  if (c->h_flags) hipHostFree(c->h_flags);
+  hipEventDestroy(c->ev_fork);
+  hipEventDestroy(c->ev_join);
+  for (int i = 0; i < 6; ++i) hipEventDestroy(c->ev_t[i]);
+  hipEventDestroy(c->ev_k0);
+  hipEventDestroy(c->ev_k1);
+  hipStreamDestroy(c->stream2);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int ovp_sync(ovp_ctx* c) {
+  if (!c) return OVP_E_ARG;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int ovp_cov_size(ovp_ctx* c) { return c ? c->n : OVP_E_ARG; }
+
+// ---- covariance residency ----------------------------------------------------------------------
+extern "C" int ovp_cov_upload(ovp_ctx* c, const double* P_host, int n, int ld) {
+  if (!c || !P_host || n < 1 || ld < n) return OVP_E_ARG;
+  if (n > c->n_max) return OVP_E_CAPACITY;
+  HIPCHK(hipMemcpy2DAsync(c->P, sizeof(double) * c->ld, P_host, sizeof(double) * ld, sizeof(double) * n, n,
+                          hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->n = n;
+  c->have_cov = true;
+  return 0;
+}
+extern "C" int ovp_cov_set_device(ovp_ctx* c, const double* P_dev, int n, int ld) {
+  if (!c || !P_dev || n < 1 || ld < n) return OVP_E_ARG;
+  if (n > c->n_max) return OVP_E_CAPACITY;
+  HIPCHK(hipMemcpy2DAsync(c->P, sizeof(double) * c->ld, P_dev, sizeof(double) * ld, sizeof(double) * n, n,
+                          hipMemcpyDeviceToDevice, c->stream));
+  c->n = n;
+  c->have_cov = true;
+  return 0;
+}
+extern "C" int ovp_cov_download(ovp_ctx* c, double* P_host, int n, int ld) {
+  if (!c || !P_host || n != c->n || ld < n) return OVP_E_ARG;
+  HIPCHK(hipMemcpy2DAsync(P_host, sizeof(double) * ld, c->P, sizeof(double) * c->ld, sizeof(double) * n, n,
+                          hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int ovp_cov_marginal(ovp_ctx* c, const int* ids, const int* sizes, int n_vars, double* out_host) {
+  if (!c || !ids || !sizes || !out_host || n_vars < 1) return OVP_E_ARG;
+  std::vector<int> cols;
+  for (int i = 0; i < n_vars; ++i)
+    for (int k = 0; k < sizes[i]; ++k) {
+      if (ids[i] + k >= c->n || ids[i] < 0) return OVP_E_ARG;
+      cols.push_back(ids[i] + k);
+    }
+  const int m = (int)cols.size();
+  if (m > c->n_max || (size_t)m * m > c->small_cap) return OVP_E_CAPACITY;
+  HIPCHK(hipMemcpyAsync(c->idbuf, cols.data(), sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(ovp_launch_gather_marginal(c->P, c->ld, c->idbuf, m, c->smallbuf, c->stream));
+  HIPCHK(hipMemcpyAsync(out_host, c->smallbuf, sizeof(double) * m * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- state tables ------------------------------------------------------------------------------
+static void quat_2_rot(const double q[4], double R[9]) {
+  // JPL: R = (2 q4^2 - 1) I - 2 q4 [qv]x + 2 qv qv^T  (ext quat_ops.h)
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double a = 2.0 * w * w - 1.0;
+  R[0] = a + 2.0 * x * x;
+  R[1] = 2.0 * w * z + 2.0 * x * y;
+  R[2] = -2.0 * w * y + 2.0 * x * z;
+  R[3] = -2.0 * w * z + 2.0 * y * x;
+  R[4] = a + 2.0 * y * y;
+  R[5] = 2.0 * w * x + 2.0 * y * z;
+  R[6] = 2.0 * w * y + 2.0 * z * x;
+  R[7] = -2.0 * w * x + 2.0 * z * y;
+  R[8] = a + 2.0 * z * z;
+}
+
+extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
+  if (!c || !st || !st->clone_q || !st->clone_p || !st->clone_q_fej || !st->clone_p_fej || !st->clone_id) return OVP_E_ARG;
+  if (st->n_clones < 1 || st->n_clones > c->c_max || st->n_state > c->n_max) return OVP_E_CAPACITY;
+  const int C = st->n_clones;
+  std::vector<double> R(9 * C), Rf(9 * C);
+  for (int i = 0; i < C; ++i) {
+    quat_2_rot(st->clone_q + 4 * i, &R[9 * i]);
+    quat_2_rot(st->clone_q_fej + 4 * i, &Rf[9 * i]);
+    if (st->clone_id[i] < 0 || st->clone_id[i] + 6 > st->n_state) return OVP_E_ARG;
+  }
+  HIPCHK(hipMemcpyAsync(c->clone_R, R.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->clone_R_fej, Rf.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->clone_p, st->clone_p, sizeof(double) * 3 * C, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->clone_p_fej, st->clone_p_fej, sizeof(double) * 3 * C, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->clone_id, st->clone_id, sizeof(int) * C, hipMemcpyHostToDevice, c->stream));
+  ovp::FeatParams& fp = c->fp;
+  fp.clone_R = c->clone_R;
+  fp.clone_p = c->clone_p;
+  fp.clone_R_fej = c->clone_R_fej;
+  fp.clone_p_fej = c->clone_p_fej;
+  fp.clone_id = c->clone_id;
+  fp.n_clones = C;
+  quat_2_rot(st->calib_q, fp.R_ItoC);
+  memcpy(fp.p_IinC, st->calib_p, sizeof(double) * 3);
+  memcpy(fp.intr, st->intrinsics, sizeof(double) * 8);
+  c->calib_id = st->calib_id;
+  c->intr_id = st->intr_id;
+  // column map for the assembly kernel (calibration columns are enabled per update via the opts)
+  std::vector<ovp::ColMap> cm(c->n_max);
+  for (auto& m : cm) m.kind = m.idx = m.off = m.pad = 0;
+  for (int i = 0; i < C; ++i)
+    for (int k = 0; k < 6; ++k) {
+      ovp::ColMap& m = cm[st->clone_id[i] + k];
+      m.kind = 1;
+      m.idx = i;
+      m.off = k;
+    }
+  if (st->calib_id >= 0 && st->calib_id + 6 <= st->n_state)
+    for (int k = 0; k < 6; ++k) {
+      ovp::ColMap& m = cm[st->calib_id + k];
+      m.kind = 2;
+      m.idx = k;
+    }
+  if (st->intr_id >= 0 && st->intr_id + 8 <= st->n_state)
+    for (int k = 0; k < 8; ++k) {
+      ovp::ColMap& m = cm[st->intr_id + k];
+      m.kind = 2;
+      m.idx = 6 + k;
+    }
+  HIPCHK(hipMemcpyAsync(c->colmap, cm.data(), sizeof(ovp::ColMap) * c->n_max, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->have_state = true;
+  return 0;
+}
+
+// ---- feature batch -----------------------------------------------------------------------------
+extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
+  if (!c || !b || b->n_feats < 0 || b->max_meas < 1 || b->max_meas > OVP_MAX_MEAS) return OVP_E_ARG;
+  if (b->n_feats > c->f_max) return OVP_E_CAPACITY;
+  const size_t F = (size_t)b->n_feats, M = (size_t)b->max_meas;
+  if (F) {
+    HIPCHK(hipMemcpyAsync(c->uv, b->uv, sizeof(float) * F * M * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->clone_idx, b->clone_idx, sizeof(int) * F * M, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->n_meas, b->n_meas, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->p_FinG, b->p_FinG, sizeof(double) * F * 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->fp.uv = c->uv;
+  c->fp.clone_idx = c->clone_idx;
+  c->fp.n_meas = c->n_meas;
+  c->fp.p_FinG = c->p_FinG;
+  c->n_feats = b->n_feats;
+  c->max_meas = b->max_meas;
+  c->have_batch = true;
+  return 0;
+}
+extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
+  if (!c || !b || b->n_feats < 0 || b->max_meas < 1 || b->max_meas > OVP_MAX_MEAS) return OVP_E_ARG;
+  if (b->n_feats > c->f_max) return OVP_E_CAPACITY;
+  c->fp.uv = b->uv;
+  c->fp.clone_idx = b->clone_idx;
+  c->fp.n_meas = b->n_meas;
+  c->fp.p_FinG = b->p_FinG;
+  c->n_feats = b->n_feats;
+  c->max_meas = b->max_meas;
+  c->have_batch = true;
+  return 0;
+}
+
+// ---- the update step ---------------------------------------------------------------------------
+static int chol_of_P(ovp_ctx* c, hipStream_t s) {
+  const int n = c->n, ld = c->ld;
+  if (n <= OVP_TILECHOL_NMAX) return (int)ovp_launch_tilechol(c->P, c->L, nullptr, n, ld, c->flags, 0, s);
+  return (int)ovp_launch_chol(c->P, c->L, n, ld, c->flags, 0, s);
+}
+
+static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
+  const int n = c->n, ld = c->ld;
+  if (!chol_p_done_on_stream2) {
+    int rc = chol_of_P(c, c->stream);
+    if (rc) return rc;
+  } else {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  }
+  const double* b = c->Ab + (size_t)n * ld;
+  if (n <= OVP_TILECHOL_NMAX) {
+    // W1 = A L ;  T = I + L^T W1 ;  Lt = chol(T) (+ inverses of its diagonal blocks)
+    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, c->stream));
+    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
+    HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, c->stream));
+    // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
+    HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, c->L, c->Y, n, ld, c->stream));
+    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->stream));
+    HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->stream));
+    return 0;
+  }
+  // large-state fallback: global-memory factorization
+  HIPCHK(ovp_launch_gemm(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, c->stream));
+  HIPCHK(ovp_launch_gemm(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, c->stream));
+  HIPCHK(ovp_launch_chol(c->T, c->Lt, n, ld, c->flags, 0, c->stream));
+  HIPCHK(ovp_launch_trsm_right_lt(c->L, c->Lt, c->Y, n, ld, c->stream));
+  HIPCHK(ovp_launch_cov_finish(c->Y, n, ld, b, c->P, ld, c->dx, c->flags + 1, c->stream));
+  return 0;
+}
+
+extern "C" int ovp_msckf_build_gate_gram_async(ovp_ctx* c, const ovp_update_opts* o) {
+  if (!c || !o) return OVP_E_ARG;
+  if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
+  if (c->fp.n_clones < 1) return OVP_E_STATE;
+  const int n = c->n, F = c->n_feats;
+  ovp::FeatParams& fp = c->fp;
+  fp.n_feats = F;
+  fp.max_meas = c->max_meas;
+  fp.do_fej = o->do_fej;
+  fp.calmask = (o->do_calib_camera_pose ? 0x3Fu : 0u) | (o->do_calib_camera_intrinsics ? (0xFFu << 6) : 0u);
+  for (int k = 0; k < 14; ++k) {
+    fp.calcol[k] = (k < 6) ? c->calib_id + k : c->intr_id + (k - 6);
+    if (!((fp.calmask >> k) & 1)) fp.calcol[k] = 0;
+    else if (fp.calcol[k] < 0 || fp.calcol[k] >= n) return OVP_E_ARG;
+  }
+  fp.white_px = 1.0 / o->sigma_px;
+  fp.chi2_mult = o->chi2_multiplier;
+  fp.chi2_table = c->chi2_table;
+  fp.P = c->P;
+  fp.n = n;
+  fp.ldp = c->ld;
+  fp.G = c->G;
+  fp.ldg = c->ldg;
+  fp.rec = c->rec;
+  fp.chi2 = c->chi2;
+  fp.accept = c->accept;
+  fp.dbg_cycles = c->dbg_cycles;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
+  // chol(P) does not depend on the measurements: run it beside K1/K2 on the second stream
+  HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  {
+    int rc = chol_of_P(c, c->stream2);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+  // K1
+  if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
+  HIPCHK(ovp_launch_feat_gate(&fp, c->stream));
+  if (c->ktimer) {
+    HIPCHK(hipEventRecord(c->ev_k1, c->stream));
+    c->kpending = true;
+  }
+  HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
+  // K2
+  const int used_chunks = F > 0 ? (2 * F + c->rows_per_chunk - 1) / c->rows_per_chunk : 0;
+  if (F > 0) {
+    HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, c->stream));
+    int nsplit = (3 * F + 511) / 512;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > c->n_split) nsplit = c->n_split;
+    HIPCHK(ovp_launch_syrk(c->G, 3 * F, c->ldg, n + 1, nsplit, c->part, c->stream));
+    HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, used_chunks, c->gramR, c->stream));
+    HIPCHK(ovp_launch_assemble(c->gramR, fp.n_clones, 1, c->part, nsplit, c->colmap, n, c->Ab, c->ld, c->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, c->stream));
+  }
+  HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
+  return 0;
+}
+
+extern "C" int ovp_gram_buffer(ovp_ctx* c, double** Ab_dev, int* n_rows, int* ld) {
+  if (!c || !Ab_dev) return OVP_E_ARG;
+  *Ab_dev = c->Ab;
+  if (n_rows) *n_rows = c->n + 1;
+  if (ld) *ld = c->ld;
+  return 0;
+}
+
+extern "C" int ovp_ekf_update_from_gram_async(ovp_ctx* c) {
+  if (!c) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  int rc = ekf_from_gram(c, true);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(c->ev_t[3], c->stream));
+  c->timed = true;
+  return 0;
+}
+
+extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* accepted_host, double* chi2_host,
+                                       ovp_update_info* info) {
+  if (!c) return OVP_E_ARG;
+  const int n = c->n, F = c->n_feats;
+  HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  if (F) {
+    HIPCHK(hipMemcpyAsync(c->h_accept, c->accept, (size_t)F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_chi2, c->chi2, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
+  if (accepted_host && F) memcpy(accepted_host, c->h_accept, (size_t)F);
+  if (chi2_host && F) memcpy(chi2_host, c->h_chi2, sizeof(double) * F);
+  if (c->timed) {
+    for (int i = 0; i < 3; ++i) hipEventElapsedTime(&c->last_ms[i], c->ev_t[i], c->ev_t[i + 1]);
+    hipEventElapsedTime(&c->last_ms[3], c->ev_t[0], c->ev_t[3]);
+    c->timed = false;
+  }
+  if (c->kpending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_k0, c->ev_k1) == hipSuccess) {
+      c->ktime_ms += ms;
+      c->klaunches += 1;
+    }
+    c->kpending = false;
+  }
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    std::vector<int> nm(F);
+    // n_meas may live in caller-owned device memory (bind_device); read it back for the row count
+    if (F) hipMemcpy(nm.data(), c->fp.n_meas, sizeof(int) * F, hipMemcpyDeviceToHost);
+    for (int f = 0; f < F; ++f)
+      if (c->h_accept[f]) {
+        info->n_accepted++;
+        info->n_rows += 2 * nm[f] - 3;
+      }
+    info->n_cols = 0;
+    info->not_spd = c->h_flags[0];
+    info->neg_diag = c->h_flags[1];
+  }
+  if (c->h_flags[0]) return OVP_E_NOTSPD;
+  if (c->h_flags[1]) return OVP_E_NEGDIAG;
+  return 0;
+}
+
+extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx_host, uint8_t* accepted_host,
+                                double* chi2_host, ovp_update_info* info) {
+  int rc = ovp_msckf_build_gate_gram_async(c, o);
+  if (rc) return rc;
+  rc = ovp_ekf_update_from_gram_async(c);
+  if (rc) return rc;
+  return ovp_msckf_fetch_results(c, dx_host, accepted_host, chi2_host, info);
+}
+
+// ---- StateHelper::EKFUpdate with a dense host H ------------------------------------------------
+extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int cols, int ld, const int* col_ids,
+                              const double* res_host, double* dx_host, ovp_update_info* info) {
+  if (!c || !H_host || !col_ids || !res_host || rows < 1 || cols < 1 || ld < rows) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  if (cols > c->n) return OVP_E_ARG;
+  const int n = c->n;
+  for (int j = 0; j < cols; ++j)
+    if (col_ids[j] < 0 || col_ids[j] >= n) return OVP_E_ARG;
+  const size_t need = (size_t)ld * cols;
+  if (need > c->Hd_cap) {
+    if (c->Hd) hipFree(c->Hd);
+    HIPCHK(dalloc(&c->Hd, need));
+    c->Hd_cap = need;
+  }
+  if ((size_t)rows > c->res_cap) {
+    if (c->resd) hipFree(c->resd);
+    HIPCHK(dalloc(&c->resd, (size_t)rows + 64));
+    c->res_cap = (size_t)rows + 64;
+  }
+  if (!c->Acc) HIPCHK(dalloc(&c->Acc, (size_t)c->n_max * c->n_max));
+  if (!c->bcc) HIPCHK(dalloc(&c->bcc, (size_t)c->n_max));
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  HIPCHK(hipMemcpyAsync(c->Hd, H_host, sizeof(double) * need, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->resd, res_host, sizeof(double) * rows, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->idbuf, col_ids, sizeof(int) * cols, hipMemcpyHostToDevice, c->stream));
+  // column-major H [rows x cols, ld] == row-major H^T [cols x rows, ld]:  A = H^T H, b = H^T r
+  HIPCHK(ovp_launch_gemm(0, 1, cols, cols, rows, c->Hd, ld, c->Hd, ld, c->Acc, cols, 0, c->stream));
+  HIPCHK(ovp_launch_gemm(0, 0, cols, 1, rows, c->Hd, ld, c->resd, 1, c->bcc, 1, 0, c->stream));
+  HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, c->stream));
+  HIPCHK(ovp_launch_scatter_gram(c->Acc, c->bcc, cols, c->idbuf, c->Ab, c->ld, n, c->stream));
+  int rc = ekf_from_gram(c, false);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->n_rows = rows;
+    info->n_cols = cols;
+    info->not_spd = c->h_flags[0];
+    info->neg_diag = c->h_flags[1];
+  }
+  if (c->h_flags[0]) return OVP_E_NOTSPD;
+  if (c->h_flags[1]) return OVP_E_NEGDIAG;
+  return 0;
+}
+
+// ---- propagation / clone / marginalise ---------------------------------------------------------
+extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const int* old_ids, const int* old_sizes,
+                                 int n_old, const double* Phi_host, const double* Q_host, int* neg_diag) {
+  if (!c || !old_ids || !old_sizes || !Phi_host || !Q_host || phi_size < 1 || n_old < 1) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  const int n = c->n;
+  if (new_start < 0 || new_start + phi_size > n || phi_size > 64) return OVP_E_ARG;
+  std::vector<int> oldcol;
+  for (int i = 0; i < n_old; ++i)
+    for (int k = 0; k < old_sizes[i]; ++k) {
+      if (old_ids[i] < 0 || old_ids[i] + k >= n) return OVP_E_ARG;
+      oldcol.push_back(old_ids[i] + k);
+    }
+  const int nold = (int)oldcol.size();
+  if (nold > 4 * c->n_max) return OVP_E_CAPACITY;
+  double* dPhi = c->smallbuf;
+  double* dQ = dPhi + (size_t)phi_size * nold;
+  double* dCPT = dQ + (size_t)phi_size * phi_size;
+  double* dPCP = dCPT + (size_t)n * phi_size;
+  if ((size_t)(dPCP + (size_t)phi_size * phi_size - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  HIPCHK(hipMemcpyAsync(c->idbuf, oldcol.data(), sizeof(int) * nold, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dPhi, Phi_host, sizeof(double) * phi_size * nold, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dQ, Q_host, sizeof(double) * phi_size * phi_size, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(ovp_launch_propagate(c->P, c->ld, n, new_start, phi_size, c->idbuf, nold, dPhi, dQ, dCPT, dPCP, c->flags + 1,
+                              c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (neg_diag) *neg_diag = c->h_flags[1];
+  return c->h_flags[1] ? OVP_E_NEGDIAG : 0;
+}
+
+extern "C" int ovp_cov_clone(ovp_ctx* c, int src_id, int size) {
+  if (!c || size < 1 || src_id < 0) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  if (src_id + size > c->n) return OVP_E_ARG;
+  if (c->n + size > c->n_max) return OVP_E_CAPACITY;
+  HIPCHK(ovp_launch_cov_clone(c->P, c->ld, c->n, src_id, size, c->stream));
+  c->n += size;
+  return 0;
+}
+
+extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
+  if (!c || size < 1 || id < 0) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  if (id + size > c->n) return OVP_E_ARG;
+  HIPCHK(ovp_launch_cov_marginalize(c->P, c->P_tmp, c->ld, c->n, id, size, c->stream));
+  double* t = c->P;
+  c->P = c->P_tmp;
+  c->P_tmp = t;
+  c->n -= size;
+  return 0;
+}
+
+// ---- diagnostics -------------------------------------------------------------------------------
+extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long max_bytes) {
+  if (!c || !name || !host) return OVP_E_ARG;
+  const size_t nn = (size_t)(c->n_max + 1) * c->ld * sizeof(double);
+  const void* src = nullptr;
+  size_t bytes = 0;
+  if (!strcmp(name, "A") || !strcmp(name, "Ab")) { src = c->Ab; bytes = nn; }
+  else if (!strcmp(name, "L")) { src = c->L; bytes = nn; }
+  else if (!strcmp(name, "T")) { src = c->T; bytes = nn; }
+  else if (!strcmp(name, "Lt")) { src = c->Lt; bytes = nn; }
+  else if (!strcmp(name, "Y")) { src = c->Y; bytes = nn; }
+  else if (!strcmp(name, "W1")) { src = c->W1; bytes = nn; }
+  else if (!strcmp(name, "P")) { src = c->P; bytes = nn; }
+  else if (!strcmp(name, "G")) { src = c->G; bytes = (size_t)3 * c->n_feats * c->ldg * sizeof(double); }
+  else if (!strcmp(name, "rec")) { src = c->rec; bytes = (size_t)c->fp.n_clones * c->n_feats * 2 * 21 * sizeof(double); }
+  else if (!strcmp(name, "chi2")) { src = c->chi2; bytes = (size_t)c->n_feats * sizeof(double); }
+  else if (!strcmp(name, "cycles_on")) {
+    if (!c->dbg_cycles && hipMalloc((void**)&c->dbg_cycles, (size_t)c->f_max * 8 * sizeof(long long)) != hipSuccess) return OVP_E_STATE;
+    return 0;
+  }
+  else if (!strcmp(name, "cycles")) { src = c->dbg_cycles; bytes = (size_t)c->n_feats * 8 * sizeof(long long); if (!src) return OVP_E_STATE; }
+  else return OVP_E_ARG;
+  if ((long)bytes > max_bytes) bytes = (size_t)max_bytes;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return OVP_E_STATE;
+  if (hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return OVP_E_STATE;
+  return (long)bytes;
+}
+
+extern "C" int ovp_last_timings(ovp_ctx* c, float* ms4) {
+  if (!c || !ms4) return OVP_E_ARG;
+  memcpy(ms4, c->last_ms, sizeof(float) * 4);
+  return 0;
+}
+
+extern "C" int ovp_kernel_timer(ovp_ctx* c, int enable, int reset, float* avg_ms_feat, int* n_launches) {
+  if (!c) return OVP_E_ARG;
+  if (avg_ms_feat) *avg_ms_feat = c->klaunches ? (float)(c->ktime_ms / c->klaunches) : 0.f;
+  if (n_launches) *n_launches = c->klaunches;
+  if (reset) {
+    c->ktime_ms = 0.0;
+    c->klaunches = 0;
+  }
+  c->ktimer = enable != 0;
+  return 0;
+}

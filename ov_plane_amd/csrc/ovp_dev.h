@@ -1,0 +1,71 @@
+// Device-side helpers shared by the gfx950 kernels of libovplane_hip.so (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OVP_WAVE 64
+#define OVP_REC 21  // per-row record: clone block (6) | calibration block (14) | residual (1)
+
+namespace ovp {
+
+// ---- cross-lane primitives (wave64) -----------------------------------------------------------
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  // ds_bpermute based exchange of a 64-bit value
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const int src = ((int)(threadIdx.x & 63) ^ mask) << 2;
+  lo = __builtin_amdgcn_ds_bpermute(src, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src, hi);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  // lane must be wave-uniform
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Transpose-reduce: every lane passes v[0..N) (N a power of two <= 64); on return element 0 of lane L holds
+// sum over all 64 lanes of v[k(L)], where k(L) = top log2(N) bits of the lane id (bit 5 most significant).
+// The remaining (64/N)-lane groups are then combined by a plain butterfly, so every lane of a group holds the
+// full sum.  Costs N-1 + log2(64/N) exchanges instead of 6*N.
+template <int H, int S>
+struct TransposeReduceStep {
+  template <int N>
+  static __device__ __forceinline__ void run(double (&v)[N], int lane) {
+    const bool up = (lane & S) != 0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double keep = up ? v[k + H] : v[k];
+      const double send = up ? v[k] : v[k + H];
+      v[k] = keep + shfl_xor_f64(send, S);
+    }
+    if constexpr (H > 1) TransposeReduceStep<H / 2, S / 2>::run(v, lane);
+  }
+};
+template <int N>
+__device__ __forceinline__ double wave_transpose_reduce(double (&v)[N]) {
+  static_assert(N >= 2 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two");
+  const int lane = threadIdx.x & 63;
+  TransposeReduceStep<N / 2, 32>::run(v, lane);
+  double r = v[0];
+#pragma unroll
+  for (int s = 32 / N; s >= 1; s >>= 1) r += shfl_xor_f64(r, s);
+  return r;
+}
+// lane that holds (after wave_transpose_reduce<N>) the sum of element k: any lane whose top bits equal k
+template <int N>
+__device__ __forceinline__ int reduce_owner_lane(int k) {
+  return k * (64 / N);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += shfl_xor_f64(v, s);
+  return v;
+}
+
+// index into a packed lower-triangular matrix (row i >= col j)
+__device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1)) / 2 + j; }
+
+}  // namespace ovp

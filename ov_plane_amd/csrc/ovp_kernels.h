@@ -1,0 +1,82 @@
+// Kernel parameter blocks and launch prototypes (internal to libovplane_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OVP_MAX_MEAS_DEV 32
+#define OVP_CHI2_TABLE 1024  // chi2_table[k] for k = 0..OVP_CHI2_TABLE (k=0 unused)
+#define OVP_MAX_CLONES 64
+#define OVP_GRAM_ELEMS 231   // 21*22/2: packed upper triangle of the per-clone 21x21 Gram
+
+namespace ovp {
+
+struct FeatParams {
+  // feature batch (device pointers)
+  const float* uv;
+  const int* clone_idx;
+  const int* n_meas;
+  const double* p_FinG;
+  int n_feats, max_meas;
+  // state tables (device pointers)
+  const double* clone_R;      // [C][9] row-major R_GtoI
+  const double* clone_p;      // [C][3]
+  const double* clone_R_fej;  // [C][9]
+  const double* clone_p_fej;  // [C][3]
+  const int* clone_id;        // [C]
+  int n_clones;
+  int do_fej;
+  double R_ItoC[9];
+  double p_IinC[3];
+  double intr[8];
+  int calcol[14];  // state column of calibration column k: k<6 extrinsics, k>=6 intrinsics
+  unsigned calmask;  // bit k set = calibration column k is estimated
+  double white_px, chi2_mult;
+  const double* chi2_table;
+  const double* P;
+  int n, ldp;
+  // outputs
+  double* G;  // [3*n_feats][ldg]: columns 0..n-1 = Q1^T H_x scattered to state columns, column n = Q1^T r
+  int ldg;
+  double* rec;  // [n_clones][n_feats][2][OVP_REC]
+  double* chi2;
+  unsigned char* accept;
+  long long* dbg_cycles;  // optional [n_feats][8] phase stamps (diagnostics)
+};
+
+// per-column description of the state used when assembling the information pair
+struct ColMap {
+  // kind: 0 = not involved, 1 = clone column, 2 = calibration column
+  int kind;
+  int idx;  // clone slot, or calibration column k (0..13)
+  int off;  // offset inside the clone block (0..5)
+  int pad;
+};
+
+}  // namespace ovp
+
+extern "C" {
+hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream);
+
+// K2a: per-clone structured Gram of the sparse rows. gramS [n_clones][n_chunks][OVP_GRAM_ELEMS]
+hipError_t ovp_launch_struct_gram(const double* rec, int n_clones, int n_feats, int rows_per_chunk, int n_chunks,
+                                  double* gramS, hipStream_t stream);
+// K2b: split-K lower-triangular SYRK of G ([rows][ldg]) with f64 MFMA. part [n_split][nt*(nt+1)/2][256]
+hipError_t ovp_launch_syrk(const double* G, int rows, int ldg, int ncols, int n_split, double* part,
+                           hipStream_t stream);
+// K2c: assemble A|b (Ab [(n+1)][lda], row n = b) from the structured Gram and the SYRK partials
+hipError_t ovp_launch_assemble(const double* gramS, int n_clones, int n_chunks, const double* part, int n_split,
+                               const ovp::ColMap* colmap, int n, double* Ab, int lda, hipStream_t stream);
+
+// K3 building blocks (all matrices row-major == column-major for symmetric ones; ld explicit)
+// blocked Cholesky of the n x n SPD matrix A into lower L (both [n][ld]); flag set to 1 on a non-positive pivot
+hipError_t ovp_launch_chol(const double* A, double* L, int n, int ld, int* flag, int add_identity,
+                           hipStream_t stream);
+// C[M][N] = alpha * op(A) * op(B) + beta_identity * I ; op = N or T; sizes given for the result
+hipError_t ovp_launch_gemm(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
+                           int ldb, double* C, int ldc, int add_identity, hipStream_t stream);
+// Y * Lt^T = L  ->  Y = L * Lt^-T  (row-wise forward substitution), all [n][ld]
+hipError_t ovp_launch_trsm_right_lt(const double* L, const double* Lt, double* Y, int n, int ld, hipStream_t stream);
+// P = Y Y^T (symmetric), dx = P * b, neg-diag flag
+hipError_t ovp_launch_cov_finish(const double* Y, int n, int ld, const double* b, double* P, int ldp, double* dx,
+                                 int* negdiag, hipStream_t stream);
+}

@@ -256,6 +256,7 @@ def make_scene(
     do_fej=True,
     calib=True,
     min_meas=5,
+    feat_seed=None,
 ):
     """Build one synthetic update-step input.
 
@@ -272,6 +273,8 @@ def make_scene(
       truth: dict of ground-truth quantities (for diagnostics only)
     """
     rng = np.random.default_rng(seed)
+    # features / measurement noise may use their own stream so that several ranks can share one filter state
+    frng = np.random.default_rng(1000003 + int(seed if feat_seed is None else feat_seed))
     n_in_state = int(round(n_planes * planes_in_state_frac))
     ids = state_layout(C, n_slam=n_slam, n_planes_in_state=n_in_state)
     N = ids["N"]
@@ -319,8 +322,8 @@ def make_scene(
     n_planar = min(F, n_planes * feats_per_plane)
     n_free = F - n_planar
     if ragged:
-        n_meas = rng.integers(min(min_meas, C), C + 1, size=F).astype(np.int32)
-        start = np.array([rng.integers(0, C - m + 1) for m in n_meas], dtype=np.int32)
+        n_meas = frng.integers(min(min_meas, C), C + 1, size=F).astype(np.int32)
+        start = np.array([frng.integers(0, C - m + 1) for m in n_meas], dtype=np.int32)
     else:
         n_meas = np.full(F, C, dtype=np.int32)
         start = np.zeros(F, dtype=np.int32)
@@ -332,12 +335,12 @@ def make_scene(
         lo, hi = int(start[f]), int(start[f] + n_meas[f])
         for _try in range(2000):
             if f < n_free:
-                depth = rng.uniform(2.0, 5.0)
-                cand = mid + np.array([depth, rng.uniform(-2.5, 2.5), rng.uniform(-1.4, 1.4)])
+                depth = frng.uniform(2.0, 5.0)
+                cand = mid + np.array([depth, frng.uniform(-2.5, 2.5), frng.uniform(-1.4, 1.4)])
             else:
                 k = (f - n_free) % n_planes
                 # random point on plane k near the viewing volume
-                base = mid + np.array([rng.uniform(1.8, 5.2), rng.uniform(-2.5, 2.5), rng.uniform(-1.4, 1.4)])
+                base = mid + np.array([frng.uniform(1.8, 5.2), frng.uniform(-2.5, 2.5), frng.uniform(-1.4, 1.4)])
                 cand = base - (planes_n[k] @ base - planes_d[k]) * planes_n[k]
             if visible(cand[None], lo, hi)[0] and (cand[0] - mid[0]) > 1.5:
                 break
@@ -388,7 +391,7 @@ def make_scene(
 
     # ---- measurements (truth + N(0, sigma_px)), stored as f32 ------------------------------------------
     uv_true, _ = project_all(p_f, R_true, p_true, R_ItoC_true, p_IinC_true, intr_true)
-    uv_noisy = uv_true + sigma_px * rng.standard_normal(uv_true.shape)
+    uv_noisy = uv_true + sigma_px * frng.standard_normal(uv_true.shape)
     uv = np.zeros((F, C, 2), dtype=np.float32)
     for f in range(F):
         m = int(n_meas[f])
@@ -400,7 +403,7 @@ def make_scene(
     for f in range(F):
         m = int(n_meas[f])
         uv_dense[f, start[f] : start[f] + m] = uv[f, :m].astype(np.float64)
-    p0 = p_f + 0.02 * np.linalg.norm(p_f - mid, axis=1, keepdims=True) * rng.standard_normal((F, 3))
+    p0 = p_f + 0.02 * np.linalg.norm(p_f - mid, axis=1, keepdims=True) * frng.standard_normal((F, 3))
     p_FinG = _triangulate_gn(p0, uv_dense, mask, R_est, clone_p, quat_2_rot(calib_q), calib_p, intr)
 
     # ---- plane estimates ------------------------------------------------------------------------------

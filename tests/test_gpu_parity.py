@@ -1,0 +1,208 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the oracle on identical seeded inputs.
+
+Tolerances (BASELINE.json north_star): |d state| <= 1e-6 ; covariance 1e-4 relative, measured as
+max_ij |dP_ij| / sqrt(P_ii P_jj) (correlation-normalised).  Observed errors are ~1e-10."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from ov_plane_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_DX = 1e-6
+TOL_P = 1e-4
+
+
+def _cases():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg.CASES
+
+
+def relP(Pa, Pb):
+    d = np.sqrt(np.abs(np.diag(Pb)))
+    return float((np.abs(Pa - Pb) / np.outer(d, d)).max())
+
+
+def run_gpu(capi, sc, feats=None, n_extra=0):
+    F = sc.F if feats is None else len(feats)
+    ctx = capi.Context(sc.N + n_extra, sc.C, max(F, 1))
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc, feats)
+    out = ctx.msckf_update(capi.opts_from_scene(sc))
+    out["P"] = ctx.cov_download()
+    out["ctx"] = ctx
+    return out
+
+
+@pytest.mark.parametrize("name", ["sim11", "ragged", "nocalib", "nofej", "gate_all", "c30"])
+def test_matches_committed_golden_vectors(hiplib, name):
+    sc = make_scene(**_cases()[name])
+    g = np.load(os.path.join(GOLD, "msckf_%s.npz" % name))
+    out = run_gpu(hiplib, sc)
+    assert (out["accepted"] == g["accepted"]).all()
+    assert np.abs(out["chi2"] - g["chi2"]).max() <= 1e-8 * max(1.0, np.abs(g["chi2"]).max())
+    assert np.abs(out["dx"] - g["dx"]).max() < TOL_DX
+    assert relP(out["P"], g["P"]) < TOL_P
+    assert out["info"].n_accepted == int(g["accepted"].sum())
+    out["ctx"].close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(C=11, F=150, seed=21, chi2_mult=1.0),
+    dict(C=5, F=33, seed=22, ragged=True, min_meas=2, chi2_mult=1.0),     # includes 2-observation features (dof 1)
+    dict(C=31, F=64, seed=23, chi2_mult=1.0),                               # max_clones+1 window
+    dict(C=12, F=90, seed=24, ragged=True, chi2_mult=0.6),                  # many rejections
+    dict(C=10, F=70, seed=25, chi2_mult=1.0, calib=False, do_fej=False),
+])
+def test_matches_oracle_on_fresh_scenes(hiplib, oracle, kw):
+    sc = make_scene(**kw)
+    ref = oracle.msckf_point_update(sc)
+    out = run_gpu(hiplib, sc)
+    # gate decisions: identical unless a feature sits within 1e-9 relative of its threshold
+    diff = np.where(out["accepted"] != ref["accepted"])[0]
+    assert len(diff) == 0, diff
+    assert np.abs(out["chi2"] - ref["chi2"]).max() <= 1e-8 * max(1.0, np.abs(ref["chi2"]).max())
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+    assert np.abs(out["P"] - out["P"].T).max() == 0.0
+    out["ctx"].close()
+
+
+def test_empty_and_all_rejected_batches(hiplib):
+    sc = make_scene(C=6, F=12, seed=31, chi2_mult=1e-9)  # everything fails the gate
+    out = run_gpu(hiplib, sc)
+    assert out["accepted"].sum() == 0
+    assert np.abs(out["dx"]).max() < 1e-12
+    assert relP(out["P"], sc.P) < 1e-10
+    out["ctx"].close()
+    # features with < 2 observations are dropped (UpdaterMSCKF.cpp:94-96)
+    sc = make_scene(C=6, F=10, seed=32, chi2_mult=1.0)
+    sc.n_meas[:] = 1
+    out = run_gpu(hiplib, sc)
+    assert out["accepted"].sum() == 0 and np.abs(out["dx"]).max() == 0.0
+    out["ctx"].close()
+
+
+def test_full_size_properties(hiplib):
+    """BASELINE config[1] size (30 clones x 2000 features): size-independent properties instead of the oracle."""
+    sc = make_scene(C=30, F=2000, seed=0, chi2_mult=1.0)
+    out = run_gpu(hiplib, sc)
+    P1 = out["P"]
+    assert out["accepted"].mean() > 0.9
+    assert np.abs(P1 - P1.T).max() == 0.0
+    w = np.linalg.eigvalsh(P1)
+    assert w.min() > 0
+    # information never decreases: P - P+ is PSD
+    wd = np.linalg.eigvalsh(sc.P - P1)
+    assert wd.min() > -1e-9 * np.abs(wd).max()
+    # information identity: P+^-1 - P^-1 = A  (A as accumulated on the device)
+    ctx = out["ctx"]
+    ld = ((sc.N + 15) // 16) * 16
+    Ab = ctx.debug_read("Ab", (sc.N + 1, ld))
+    A, b = Ab[: sc.N, : sc.N], Ab[sc.N, : sc.N]
+    assert np.abs(A - A.T).max() <= 1e-9 * np.abs(A).max()
+    lhs = P1 @ (np.linalg.inv(sc.P) + A)
+    assert np.abs(lhs - np.eye(sc.N)).max() < 1e-6
+    assert np.abs(out["dx"] - P1 @ b).max() < 1e-9
+    ctx.close()
+    # feature order does not matter (the stacked update is permutation invariant)
+    perm = np.random.default_rng(0).permutation(sc.F)
+    out2 = run_gpu(hiplib, sc, feats=perm)
+    assert (out2["accepted"] == out["accepted"][perm]).all()
+    assert np.abs(out2["dx"] - out["dx"]).max() < 1e-9
+    assert relP(out2["P"], P1) < 1e-8
+    out2["ctx"].close()
+    # splitting the batch: information adds, so two half-batch covariance updates == one full update
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    o = hiplib.opts_from_scene(sc)
+    o.chi2_multiplier = 1e12  # gate against the *prior* would differ in the second half; disable it here
+    ctx.batch_upload_scene(sc, np.arange(0, 1000))
+    ctx.msckf_update(o)
+    ctx.batch_upload_scene(sc, np.arange(1000, 2000))
+    ctx.msckf_update(o)
+    P_two = ctx.cov_download()
+    ctx.cov_upload(sc.P)
+    ctx.batch_upload_scene(sc)
+    ctx.msckf_update(o)
+    P_one = ctx.cov_download()
+    assert relP(P_two, P_one) < 1e-7
+    ctx.close()
+
+
+def test_dense_ekf_update_matches_reference_form(hiplib):
+    """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H."""
+    from oracle import np_ref
+
+    rng = np.random.default_rng(4)
+    sc = make_scene(C=6, F=4, seed=41)
+    order = [(int(sc.ids["clones"][1]), 6), (int(sc.ids["calib"]), 6), (0, 3)]
+    cols = np_ref.order_cols(order)
+    H = rng.standard_normal((9, len(cols))) * 30.0
+    res = rng.standard_normal(9)
+    Pn, dx = np_ref.ekf_update(sc.P, order, H, res)
+    ctx = hiplib.Context(sc.N, sc.C, 4)
+    ctx.cov_upload(sc.P)
+    dxg, info = ctx.ekf_update(H, cols, res)
+    Pg = ctx.cov_download()
+    assert np.abs(dxg - dx).max() < 1e-9
+    assert relP(Pg, Pn) < 1e-8
+    ctx.close()
+
+
+def test_covariance_bookkeeping(hiplib):
+    """propagate / clone / marginalise / marginal-gather against the restatement (StateHelper.cpp:41-119,231-396)."""
+    from oracle import np_ref
+
+    rng = np.random.default_rng(6)
+    sc = make_scene(C=5, F=4, seed=51)
+    N = sc.N
+    ctx = hiplib.Context(N + 12, sc.C + 2, 4)
+    ctx.cov_upload(sc.P)
+    Phi = np.eye(15) + 0.05 * rng.standard_normal((15, 15))
+    Qh = rng.standard_normal((15, 15)) * 1e-3
+    Q = Qh @ Qh.T
+    Pref = np_ref.ekf_propagation(sc.P, 0, 15, [(0, 15)], Phi, Q)
+    neg = ctx.cov_propagate(0, [0], [15], Phi, Q)
+    assert neg == 0
+    Pprop = ctx.cov_download()
+    assert np.abs(Pprop - Pref).max() < 1e-12 * max(1.0, np.abs(Pref).max())
+    Pref = Pprop  # the copies below must be bit-exact with respect to what is resident on the device
+    # clone the IMU pose (StateHelper::clone)
+    ctx.cov_clone(0, 6)
+    Pc = ctx.cov_download()
+    assert Pc.shape == (N + 6, N + 6)
+    assert np.abs(Pc[:N, :N] - Pref).max() == 0.0
+    assert np.abs(Pc[N:, N:] - Pref[:6, :6]).max() == 0.0
+    assert np.abs(Pc[:N, N:] - Pref[:, :6]).max() == 0.0 and np.abs(Pc[N:, :N] - Pref[:6, :]).max() == 0.0
+    # marginal covariance gather
+    ids = [int(sc.ids["clones"][2]), 16]
+    M = ctx.cov_marginal(ids, [6, 6])
+    cols = np_ref.order_cols([(ids[0], 6), (16, 6)])
+    assert np.abs(M - Pc[np.ix_(cols, cols)]).max() == 0.0
+    # marginalise the oldest clone
+    cid = int(sc.ids["clones"][0])
+    ctx.cov_marginalize(cid, 6)
+    Pm = ctx.cov_download()
+    keep = [i for i in range(N + 6) if not (cid <= i < cid + 6)]
+    assert np.abs(Pm - Pc[np.ix_(keep, keep)]).max() == 0.0
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_slam", [10, 25, 40])
+def test_larger_states_use_every_factorization_path(hiplib, oracle, n_slam):
+    """N = 30 + 6C + 3 n_slam: 240 (15-slot register-resident Cholesky), 285 (25-slot), 330 (global-memory fallback)."""
+    sc = make_scene(C=30, F=48, seed=61 + n_slam, n_slam=n_slam, chi2_mult=1.0)
+    ref = oracle.msckf_point_update(sc)
+    out = run_gpu(hiplib, sc)
+    assert (out["accepted"] == ref["accepted"]).all()
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+    out["ctx"].close()
