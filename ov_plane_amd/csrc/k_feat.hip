@@ -49,8 +49,9 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
   __shared__ __attribute__((aligned(16))) double sJ[NR * 6];
   __shared__ __attribute__((aligned(16))) double sC[NR * 14];
   __shared__ __attribute__((aligned(16))) double sE[NR * 14];
-  __shared__ __attribute__((aligned(16))) double sB[TRI];
+  __shared__ __attribute__((aligned(16))) double sB[TRI + 256];
 
+  double* sB2 = sB + 256;  // packed lower triangle of B (the first 256 doubles are scratch: P_cc, column buffers)
   const int a = lane >> 1, r = lane & 1;
   long long tstamp[8];
   tstamp[0] = __builtin_readcyclecounter();
@@ -182,23 +183,32 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
     // ----------------------------------------------------------------------------------------
     double u[14];
     {
+      // 14x14 calibration block of P: one coalesced gather per wave instead of 196 serialized scalar loads
+      double* sPcc = sB;  // 196 doubles, sB is not in use yet
+      for (int idx = lane; idx < 196; idx += 64) {
+        const int kk = idx / 14, k = idx - 14 * kk;
+        const bool on = ((p.calmask >> kk) & 1) && ((p.calmask >> k) & 1);
+        sPcc[idx] = on ? P[(size_t)p.calcol[kk] * ldp + p.calcol[k]] : 0.0;
+      }
       double e[14];
 #pragma unroll
       for (int k = 0; k < 14; ++k) {
         e[k] = 0.0;
-        u[k] = 0.0;
         if ((p.calmask >> k) & 1) {
           const double* prow = P + (size_t)p.calcol[k] * ldp;
           double s = 0.0;
 #pragma unroll
           for (int l = 0; l < 6; ++l) s = fma(jrow[l], prow[ida + l], s);
           e[k] = s;
-          double dsum = 0.0;
-#pragma unroll
-          for (int kk = 0; kk < 14; ++kk)
-            if ((p.calmask >> kk) & 1) dsum = fma(crow[kk], P[(size_t)p.calcol[kk] * ldp + p.calcol[k]], dsum);
-          u[k] = s + dsum;
         }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        double dsum = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) dsum = fma(crow[kk], sPcc[kk * 14 + k], dsum);
+        u[k] = e[k] + dsum;
       }
 #pragma unroll
       for (int l = 0; l < 6; ++l) sJ[lane * 6 + l] = jrow[l];
@@ -214,29 +224,46 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
     // ----------------------------------------------------------------------------------------
     // Phase B: row `lane` of B = H_x P H_x^T + I, lower triangle, packed in LDS
     // ----------------------------------------------------------------------------------------
-    for (int b = 0; b < m; ++b) {
-      const int cb = cidx[b];
-      const int idb = p.clone_id[cb];
-      double t[6];
+    {
+      double pn[36];  // P[clone(b)+k][clone(a)+l] for the next b
+      {
+        const int idb0 = p.clone_id[cidx[0]];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double* prow = P + (size_t)(idb + k) * ldp + ida;  // P[clone(b)+k][clone(a)+l] (symmetric)
-        double s = 0.0;
+        for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int l = 0; l < 6; ++l) s = fma(jrow[l], prow[l], s);
-        t[k] = s;
+          for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb0 + k) * ldp + ida + l];
       }
+      for (int b = 0; b < m; ++b) {
+        double pc[36];
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int col = 2 * b + rr;
-        double s = 0.0;
+        for (int q = 0; q < 36; ++q) pc[q] = pn[q];
+        if (b + 1 < m) {
+          const int idb1 = p.clone_id[cidx[b + 1]];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s = fma(t[k], sJ[col * 6 + k], s);
+          for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int k = 0; k < 14; ++k) s = fma(u[k], sC[col * 14 + k], s);
+            for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb1 + k) * ldp + ida + l];
+        }
+        double t[6];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) s = fma(crow[k], sE[col * 14 + k], s);
-        if (col <= lane) sB[tri(lane, col)] = s + (col == lane ? 1.0 : 0.0);
+        for (int k = 0; k < 6; ++k) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) sacc = fma(jrow[l], pc[6 * k + l], sacc);
+          t[k] = sacc;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int col = 2 * b + rr;
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s0 = fma(t[k], sJ[col * 6 + k], s0);
+#pragma unroll
+          for (int k = 0; k < 14; ++k) s1 = fma(u[k], sC[col * 14 + k], s1);
+#pragma unroll
+          for (int k = 0; k < 14; ++k) s0 = fma(crow[k], sE[col * 14 + k], s0);
+          if (col <= lane) sB2[tri(lane, col)] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+        }
       }
     }
     __syncthreads();
@@ -249,25 +276,34 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
     static_for<NR>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       double v = (k == lane) ? 1.0 : 0.0;
-      if (valid && k <= lane) v = sB[tri(lane, k)];
+      if (valid && k <= lane) v = sB2[tri(lane, k)];
       arow[k] = v;
     });
     __syncthreads();
     double rh0 = res, rh1 = hf[0], rh2 = hf[1], rh3 = hf[2];
-    double* colbuf = sB;  // 2 x 64 doubles, alternating
+    double* colbuf = sB;  // 2 x 64 doubles, alternating (scratch region, disjoint from the packed triangle)
     bool spd = true;
+    // look-ahead: the reciprocal square root of pivot k+1 is started as soon as column k is known, so the
+    // rsq/Newton chain overlaps the LDS broadcast and the trailing FMAs of step k.
+    double piv = readlane_f64(arow[0], 0);
+    double inv = rsqrt_nr(piv);
     static_for<NR>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       if (k < n) {  // wave-uniform
-        const double dkk = readlane_f64(arow[k], k);
-        spd = spd && (dkk > 0.0);
-        const double inv = rsqrt_nr(dkk);
+        spd = spd && (piv > 0.0);
         const double l = arow[k] * inv;  // column k of L (valid for lanes >= k)
+        const double inv_k = inv;
         double* cb = colbuf + (k & 1) * NR;
         cb[lane] = l;
+        if constexpr (k + 1 < NR) {
+          const double lk1 = readlane_f64(l, k + 1);
+          arow[k + 1] = fma(-l, lk1, arow[k + 1]);
+          piv = readlane_f64(arow[k + 1], k + 1);
+          inv = rsqrt_nr(piv);
+        }
         // forward substitution of the 4 right-hand sides
-        const double x0 = readlane_f64(rh0, k) * inv, x1 = readlane_f64(rh1, k) * inv;
-        const double x2 = readlane_f64(rh2, k) * inv, x3 = readlane_f64(rh3, k) * inv;
+        const double x0 = readlane_f64(rh0, k) * inv_k, x1 = readlane_f64(rh1, k) * inv_k;
+        const double x2 = readlane_f64(rh2, k) * inv_k, x3 = readlane_f64(rh3, k) * inv_k;
         if (lane > k) {
           rh0 = fma(-l, x0, rh0);
           rh1 = fma(-l, x1, rh1);
@@ -279,15 +315,14 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
           rh2 = x2;
           rh3 = x3;
         }
-        __syncthreads();
-        // trailing update of this lane's row: a[j] -= l_ik * l_jk
-        constexpr int jb0 = (k + 1) / 8;
+        // trailing update of this lane's row: a[j] -= l_ik * l_jk   (j = k+1 already done above)
+        constexpr int jb0 = (k + 2) / 8;
         static_for<8 - jb0>([&](auto jbc) {
           constexpr int j0 = (jb0 + decltype(jbc)::value) * 8;
           if (j0 < n) {  // wave-uniform
             static_for<8>([&](auto jc) {
               constexpr int j = j0 + decltype(jc)::value;
-              if constexpr (j > k) arow[j] = fma(-l, cb[j], arow[j]);
+              if constexpr (j > k + 1) arow[j] = fma(-l, cb[j], arow[j]);
             });
           }
         });
