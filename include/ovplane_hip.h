@@ -132,6 +132,29 @@ int ovp_ekf_update_from_gram_async(ovp_ctx *ctx);
 int ovp_msckf_fetch_results(ovp_ctx *ctx, double *dx_host, uint8_t *accepted_host, double *chi2_host,
                             ovp_update_info *info);
 
+/* Planes touched by an update (host pointers): plane k (0-based) has reference id k+1.
+ * plane_of_feat[f] = 0 for a free point, else the id of the plane feature f lies on (VioManager's feat2plane map,
+ * core/VioManager.cpp:516-533). cp / cp_fej: closest-point estimates (State::_features_PLANE value()/fej() for in-state
+ * planes, the PlaneFitting estimate otherwise, update/UpdaterMSCKF.cpp:467-475). plane_state_id[k] = Type::id() or -1. */
+typedef struct {
+  int n_planes;
+  const int *plane_of_feat;   /* [n_feats of the uploaded batch] */
+  const double *cp;           /* [n_planes*3] */
+  const double *cp_fej;       /* [n_planes*3] */
+  const int *plane_state_id;  /* [n_planes] */
+} ovp_plane_batch;
+
+/* UpdaterMSCKF::update, per-plane loop with MSCKF features (update/UpdaterMSCKF.cpp:411-649): for every plane in
+ * ascending id: point-on-plane Jacobians (update/UpdaterHelper.cpp:448-512), UpdaterPlane::nullspace_project_inplace /
+ * measurement_compress_inplace (update/UpdaterPlane.cpp:483-552), plane appended (in state) or projected out, plane-level
+ * chi2, StateHelper::EKFUpdate.  Planes are sequential: pose tables, calibration, in-state planes and P on the device are
+ * updated after every accepted plane.  Needs a batch given with ovp_batch_upload (features with 2..31 observations).
+ * Outputs (host, any may be NULL): dx_planes[n_planes*n_state] the correction of every plane (zeros if rejected / skipped)
+ * for the caller to apply in order with Type::update; plane_ok; plane_chi2; plane_dof (rows of the reference's test);
+ * feat_used[n_feats] = 1 for features consumed by an accepted plane (reference: to_delete + feature_vec_used). */
+int ovp_msckf_plane_update(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_plane_batch *planes, double *dx_planes,
+                           uint8_t *plane_ok, double *plane_chi2, int *plane_dof, uint8_t *feat_used);
+
 /* StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for a dense H handed over by the host
  * (UpdaterSLAM::update, StateHelper::initialize, merge_planes...): H is [rows x cols] column-major with leading
  * dimension ld, col_ids[cols] gives the state column of every H column, R = I. */

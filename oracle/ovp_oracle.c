@@ -748,3 +748,238 @@ int ovo_msckf_point_update(const ovo_opts *o, const ovo_state *st, const ovo_fea
   free(osz);
   return rows_c;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * ext Type::update: JPL left-multiplicative quaternions, additive vectors
+ * ------------------------------------------------------------------------------------------- */
+void ovo_apply_dx(const ovo_state *st, int n_planes, const int *plane_state_id, const double *dx, ovo_state_values *val) {
+  for (int i = 0; i < st->n_clones; ++i) {
+    const int id = st->clone_id[i];
+    ovo_quat_update(val->clone_q + 4 * i, dx + id);
+    for (int k = 0; k < 3; ++k) val->clone_p[3 * i + k] += dx[id + 3 + k];
+  }
+  if (st->calib_id >= 0) {
+    ovo_quat_update(val->calib_q, dx + st->calib_id);
+    for (int k = 0; k < 3; ++k) val->calib_p[k] += dx[st->calib_id + 3 + k];
+  }
+  if (st->intr_id >= 0)
+    for (int k = 0; k < 8; ++k) val->intrinsics[k] += dx[st->intr_id + k];
+  for (int p = 0; p < n_planes; ++p)
+    if (plane_state_id[p] >= 0)
+      for (int k = 0; k < 3; ++k) val->cp[3 * p + k] += dx[plane_state_id[p] + k];
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterMSCKF.cpp:411-649
+ * ------------------------------------------------------------------------------------------- */
+int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, const int *plane_of_feat,
+                           int n_planes, const double *cp_in, const double *cp_fej, const int *plane_state_id, double *P,
+                           ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows) {
+  const int n = st_in->n_state;
+  const int F = fb->n_feats;
+  const int mm = fb->max_meas;
+  for (int f = 0; f < F; ++f) used[f] = 0;
+  (void)cp_in; /* current estimates live in val->cp */
+  const int maxrows = 3 * mm + 1, maxcols = 6 * mm + 14 + 3;
+  double *H_f_tmp = (double *)malloc(sizeof(double) * (size_t)maxrows * 6);
+  double *H_f = (double *)malloc(sizeof(double) * (size_t)maxrows * 3);
+  double *H_cp = (double *)malloc(sizeof(double) * (size_t)maxrows * 3);
+  double *H_x_tmp = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *H_x = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *res = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  int *oid = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *osz = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *oid2 = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *osz2 = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *map_col = (int *)malloc(sizeof(int) * (size_t)n);
+  int *order_big_id = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8));
+  int *order_big_size = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8));
+  double *dx = (double *)malloc(sizeof(double) * (size_t)n);
+
+  for (int pl = 0; pl < n_planes; ++pl) {
+    const int planeid = pl + 1;
+    plane_ok[pl] = 0;
+    plane_chi2[pl] = 0.0;
+    plane_rows[pl] = 0;
+    const int is_slam_plane = plane_state_id[pl] >= 0;
+    /* features of this plane (MSCKF features only; UpdaterMSCKF.cpp:206-229) */
+    int nf = 0;
+    size_t max_meas = 0;
+    for (int f = 0; f < F; ++f)
+      if (plane_of_feat[f] == planeid && fb->n_meas[f] >= 2) {
+        ++nf;
+        max_meas += 3 * (size_t)fb->n_meas[f];
+      }
+    /* :316-317,396: a plane that is not in the state needs more than 3 features */
+    if (nf == 0 || (!is_slam_plane && nf < 4)) continue;
+    /* state tables at the current estimate (values change after every plane update, FEJ does not) */
+    ovo_state st = *st_in;
+    st.clone_q = val->clone_q;
+    st.clone_p = val->clone_p;
+    memcpy(st.calib_q, val->calib_q, sizeof(st.calib_q));
+    memcpy(st.calib_p, val->calib_p, sizeof(st.calib_p));
+    memcpy(st.intrinsics, val->intrinsics, sizeof(st.intrinsics));
+    /* :467-475 plane linearisation points */
+    const double *cpv = val->cp + 3 * pl;
+    const double *cpf = is_slam_plane ? (cp_fej + 3 * pl) : cpv;
+
+    double *res_big = (double *)calloc(max_meas, sizeof(double));
+    double *Hx_big = (double *)calloc(max_meas * (size_t)n, sizeof(double));
+    double *Hcp_big = (double *)calloc(max_meas * 3, sizeof(double));
+    for (int i = 0; i < n; ++i) map_col[i] = -1;
+    int n_order_big = 0;
+    size_t ct_jacob = 0, ct_meas = 0;
+
+    for (int f = 0; f < F; ++f) {
+      if (plane_of_feat[f] != planeid || fb->n_meas[f] < 2) continue;
+      int rows, cols, hfc, no;
+      ovo_feature_jacobian_full(o, &st, fb, f, o->sigma_constraint, planeid, cpv, cpf, plane_state_id[pl], H_f_tmp,
+                                H_x_tmp, res, &rows, &cols, &hfc, oid, osz, &no);
+      int no2 = 0, cols2 = 0;
+      if (is_slam_plane) {
+        /* :518-535 pull the plane columns out of H_x */
+        int ct_hx = 0, ct_new = 0;
+        for (int v = 0; v < no; ++v) {
+          if (oid[v] == plane_state_id[pl]) {
+            memcpy(H_cp, H_x_tmp + (size_t)ct_hx * rows, sizeof(double) * (size_t)rows * 3);
+          } else {
+            oid2[no2] = oid[v];
+            osz2[no2++] = osz[v];
+            memcpy(H_x + (size_t)ct_new * rows, H_x_tmp + (size_t)ct_hx * rows, sizeof(double) * (size_t)rows * osz[v]);
+            ct_new += osz[v];
+          }
+          ct_hx += osz[v];
+        }
+        cols2 = ct_new;
+        memcpy(H_f, H_f_tmp, sizeof(double) * (size_t)rows * 3);
+      } else {
+        /* :537-540 */
+        memcpy(H_cp, H_f_tmp + (size_t)3 * rows, sizeof(double) * (size_t)rows * 3);
+        memcpy(H_f, H_f_tmp, sizeof(double) * (size_t)rows * 3);
+        memcpy(H_x, H_x_tmp, sizeof(double) * (size_t)rows * cols);
+        cols2 = cols;
+        no2 = no;
+        memcpy(oid2, oid, sizeof(int) * no);
+        memcpy(osz2, osz, sizeof(int) * no);
+      }
+      /* :559 */
+      ovo_nullspace_project(H_f, rows, 3, H_x, cols2, H_cp, 3, res);
+      const int q = rows - 3;
+      /* :564-576 */
+      int ct_hx = 0;
+      for (int v = 0; v < no2; ++v) {
+        if (map_col[oid2[v]] < 0) {
+          map_col[oid2[v]] = (int)ct_jacob;
+          order_big_id[n_order_big] = oid2[v];
+          order_big_size[n_order_big++] = osz2[v];
+          ct_jacob += (size_t)osz2[v];
+        }
+        for (int cc = 0; cc < osz2[v]; ++cc)
+          for (int i = 0; i < q; ++i)
+            CM(Hx_big, max_meas, ct_meas + i, map_col[oid2[v]] + cc) = CM(H_x, rows, 3 + i, ct_hx + cc);
+        ct_hx += osz2[v];
+      }
+      for (int cc = 0; cc < 3; ++cc)
+        for (int i = 0; i < q; ++i) CM(Hcp_big, max_meas, ct_meas + i, cc) = CM(H_cp, rows, 3 + i, cc);
+      for (int i = 0; i < q; ++i) res_big[ct_meas + i] = res[3 + i];
+      ct_meas += (size_t)q;
+    }
+    /* :583-585 conservativeResize, :588 compress */
+    const size_t hcols = ct_jacob + (is_slam_plane ? 3 : 0);
+    double *Hc = (double *)malloc(sizeof(double) * ct_meas * (hcols ? hcols : 1));
+    for (size_t j = 0; j < ct_jacob; ++j) memcpy(Hc + j * ct_meas, Hx_big + j * max_meas, sizeof(double) * ct_meas);
+    double *Hcpc = (double *)malloc(sizeof(double) * ct_meas * 3);
+    for (size_t j = 0; j < 3; ++j) memcpy(Hcpc + j * ct_meas, Hcp_big + j * max_meas, sizeof(double) * ct_meas);
+    int rows_c = ovo_measurement_compress(Hc, (int)ct_meas, (int)ct_jacob, (int)ct_meas, Hcpc, 3, (int)ct_meas, res_big);
+    int rows_u = rows_c;
+    int row0 = 0; /* first row of the system handed to the chi2 test / update */
+    if (is_slam_plane) {
+      /* :593-600 append the plane columns */
+      for (size_t j = 0; j < 3; ++j) memcpy(Hc + (ct_jacob + j) * ct_meas, Hcpc + j * ct_meas, sizeof(double) * ct_meas);
+      order_big_id[n_order_big] = plane_state_id[pl];
+      order_big_size[n_order_big++] = 3;
+    } else {
+      /* :602-603 project the plane out of the (compressed) system: rows [0, rows_c) of leading dimension ct_meas */
+      /* work on a compact copy so that the Givens sweeps only see the retained rows */
+      double *Hx2 = (double *)malloc(sizeof(double) * (size_t)rows_c * (ct_jacob ? ct_jacob : 1));
+      double *Hcp2 = (double *)malloc(sizeof(double) * (size_t)rows_c * 3);
+      double *res2 = (double *)malloc(sizeof(double) * (size_t)rows_c);
+      for (size_t j = 0; j < ct_jacob; ++j)
+        for (int i = 0; i < rows_c; ++i) CM(Hx2, rows_c, i, j) = CM(Hc, ct_meas, i, j);
+      for (size_t j = 0; j < 3; ++j)
+        for (int i = 0; i < rows_c; ++i) CM(Hcp2, rows_c, i, j) = CM(Hcpc, ct_meas, i, j);
+      for (int i = 0; i < rows_c; ++i) res2[i] = res_big[i];
+      ovo_nullspace_project(Hcp2, rows_c, 3, Hx2, (int)ct_jacob, NULL, 0, res2);
+      rows_u = rows_c - 3;
+      row0 = 0;
+      for (size_t j = 0; j < ct_jacob; ++j)
+        for (int i = 0; i < rows_u; ++i) CM(Hc, ct_meas, i, j) = CM(Hx2, rows_c, 3 + i, j);
+      for (int i = 0; i < rows_u; ++i) res_big[i] = res2[3 + i];
+      free(Hx2);
+      free(Hcp2);
+      free(res2);
+    }
+    (void)row0;
+    /* :607-610 plane-level chi2 */
+    const int hc = (int)hcols;
+    double *Pm = (double *)malloc(sizeof(double) * (size_t)hc * hc);
+    ovo_marginal_cov(P, n, order_big_id, order_big_size, n_order_big, Pm);
+    double *HP = (double *)calloc((size_t)rows_u * hc, sizeof(double));
+    for (int k = 0; k < hc; ++k)
+      for (int j = 0; j < hc; ++j) {
+        const double pv = CM(Pm, hc, k, j);
+        for (int i = 0; i < rows_u; ++i) CM(HP, rows_u, i, j) += CM(Hc, ct_meas, i, k) * pv;
+      }
+    double *S = (double *)calloc((size_t)rows_u * rows_u, sizeof(double));
+    for (int i = 0; i < rows_u; ++i) CM(S, rows_u, i, i) = 1.0;
+    for (int k = 0; k < hc; ++k)
+      for (int j = 0; j < rows_u; ++j) {
+        const double hv = CM(Hc, ct_meas, j, k);
+        for (int i = 0; i < rows_u; ++i) CM(S, rows_u, i, j) += CM(HP, rows_u, i, k) * hv;
+      }
+    double chi2 = 0.0;
+    int fail = ovo_llt(S, rows_u, rows_u);
+    if (!fail) {
+      double *tmp = (double *)malloc(sizeof(double) * (size_t)rows_u);
+      memcpy(tmp, res_big, sizeof(double) * (size_t)rows_u);
+      llt_solve_vec(S, rows_u, rows_u, tmp);
+      for (int i = 0; i < rows_u; ++i) chi2 += res_big[i] * tmp[i];
+      free(tmp);
+    }
+    plane_chi2[pl] = chi2;
+    plane_rows[pl] = rows_u;
+    const double chi2_check = ovo_chi2_quantile_095(rows_u);
+    if (!fail && !(chi2 > o->chi2_multiplier * chi2_check)) {
+      /* :635-648 */
+      plane_ok[pl] = 1;
+      for (int f = 0; f < F; ++f)
+        if (plane_of_feat[f] == planeid && fb->n_meas[f] >= 2) used[f] = 1;
+      int neg = 0;
+      ovo_ekf_update(P, n, order_big_id, order_big_size, n_order_big, Hc, rows_u, (int)ct_meas, res_big, dx, &neg);
+      ovo_apply_dx(st_in, n_planes, plane_state_id, dx, val);
+    }
+    free(Pm);
+    free(HP);
+    free(S);
+    free(Hc);
+    free(Hcpc);
+    free(res_big);
+    free(Hx_big);
+    free(Hcp_big);
+  }
+  free(H_f_tmp);
+  free(H_f);
+  free(H_cp);
+  free(H_x_tmp);
+  free(H_x);
+  free(res);
+  free(oid);
+  free(osz);
+  free(oid2);
+  free(osz2);
+  free(map_col);
+  free(order_big_id);
+  free(order_big_size);
+  free(dx);
+  return 0;
+}

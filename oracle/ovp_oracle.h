@@ -106,6 +106,31 @@ int ovo_ekf_propagation(double *P, int n, int new_start, int phi_size, const int
 int ovo_msckf_point_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, double *P, double *dx,
                            uint8_t *accepted, double *chi2, double *timings);
 
+/* Mutable copy of the filter state the plane loop updates between planes (ext Type::update semantics). */
+typedef struct {
+  double *clone_q;   /* [n_clones*4] */
+  double *clone_p;   /* [n_clones*3] */
+  double calib_q[4];
+  double calib_p[3];
+  double intrinsics[8];
+  double *cp;        /* [n_planes*3] plane closest points (only in-state planes are updated) */
+} ovo_state_values;
+
+/* ext Type::update for every variable the path touches: clones (PoseJPL), calibration (PoseJPL), intrinsics (Vec),
+ * in-state planes (Vec).  FEJ values are never touched.  dx indexed by Type::id(). */
+void ovo_apply_dx(const ovo_state *st, int n_planes, const int *plane_state_id, const double *dx, ovo_state_values *val);
+
+/* update/UpdaterMSCKF.cpp:411-649: sequential per-plane updates with MSCKF features
+ * (get_feature_jacobian_full with plane rows, UpdaterPlane::nullspace_project_inplace, UpdaterPlane::measurement_compress_inplace,
+ *  plane appended (in state) or projected out (not in state), plane-level chi2, StateHelper::EKFUpdate).
+ * plane ids are 1..n_planes and processed in ascending order (std::map iteration); plane_of_feat[f] = 0 for free points.
+ * cp/cp_fej [n_planes*3]; plane_state_id[k] >= 0 when plane k+1 is in the state.
+ * On return: P and val updated, used[f] = 1 for features consumed by an accepted plane, plane_ok[k], plane_chi2[k],
+ * plane_rows[k] (rows entering the chi2 test). */
+int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat,
+                           int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
+                           ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows);
+
 #ifdef __cplusplus
 }
 #endif

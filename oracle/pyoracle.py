@@ -160,3 +160,48 @@ def msckf_point_update(sc, feats=None):
     rc = lib().ovo_msckf_point_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), _dp(dx),
                                       acc.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _dp(tim))
     return dict(dx=dx, P=np.ascontiguousarray(P), accepted=acc.astype(bool), chi2=chi2, rows_compressed=rc, timings=tim)
+
+
+class OvoStateValues(C.Structure):
+    _fields_ = [
+        ("clone_q", C.POINTER(C.c_double)),
+        ("clone_p", C.POINTER(C.c_double)),
+        ("calib_q", C.c_double * 4),
+        ("calib_p", C.c_double * 3),
+        ("intrinsics", C.c_double * 8),
+        ("cp", C.POINTER(C.c_double)),
+    ]
+
+
+def msckf_plane_update(sc, libpath=None):
+    """Runs ovo_msckf_plane_update on the scene's planar features.
+    Returns dict(P, state values after the plane loop, used[F], plane_ok, plane_chi2, plane_rows)."""
+    L = lib() if libpath is None else C.CDLL(libpath)
+    pk = Packed(sc)
+    n_planes = int(sc.cp.shape[0])
+    P = np.asfortranarray(sc.P.copy())
+    cq = np.ascontiguousarray(sc.clone_q.copy())
+    cpv = np.ascontiguousarray(sc.clone_p.copy())
+    cp = np.ascontiguousarray(sc.cp.copy())
+    cp_in = np.ascontiguousarray(sc.cp.copy())
+    cp_fej = np.ascontiguousarray(sc.cp_fej.copy())
+    psid = np.ascontiguousarray(sc.plane_state_id, dtype=np.int32)
+    pof = np.ascontiguousarray(sc.plane_id, dtype=np.int32)
+    val = OvoStateValues()
+    val.clone_q = _dp(cq)
+    val.clone_p = _dp(cpv)
+    val.calib_q[:] = list(sc.calib_q)
+    val.calib_p[:] = list(sc.calib_p)
+    val.intrinsics[:] = list(sc.intr)
+    val.cp = _dp(cp)
+    used = np.zeros(sc.F, dtype=np.uint8)
+    ok = np.zeros(max(n_planes, 1), dtype=np.uint8)
+    chi2 = np.zeros(max(n_planes, 1))
+    rows = np.zeros(max(n_planes, 1), dtype=np.int32)
+    u8 = C.POINTER(C.c_uint8)
+    L.ovo_msckf_plane_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(pof), C.c_int(n_planes),
+                             _dp(cp_in), _dp(cp_fej), _ip(psid), _dp(P), C.byref(val), used.ctypes.data_as(u8),
+                             ok.ctypes.data_as(u8), _dp(chi2), _ip(rows))
+    return dict(P=np.ascontiguousarray(P), clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
+                calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), cp=cp, used=used.astype(bool),
+                plane_ok=ok[:n_planes].astype(bool), plane_chi2=chi2[:n_planes], plane_rows=rows[:n_planes])

@@ -64,6 +64,16 @@ class FeatureBatch(C.Structure):
     ]
 
 
+class PlaneBatch(C.Structure):
+    _fields_ = [
+        ("n_planes", C.c_int),
+        ("plane_of_feat", C.c_void_p),
+        ("cp", C.c_void_p),
+        ("cp_fej", C.c_void_p),
+        ("plane_state_id", C.c_void_p),
+    ]
+
+
 class UpdateInfo(C.Structure):
     _fields_ = [
         ("n_accepted", C.c_int),
@@ -84,7 +94,7 @@ EXPORTS = [
     "ovp_batch_bind_device", "ovp_msckf_update", "ovp_msckf_build_gate_gram_async", "ovp_gram_buffer",
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
-    "ovp_last_timings", "ovp_kernel_timer",
+    "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update",
 ]
 
 
@@ -121,6 +131,8 @@ def lib():
         L.ovp_msckf_fetch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateInfo)]
         L.ovp_ekf_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(UpdateInfo)]
+        L.ovp_msckf_plane_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(PlaneBatch), C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ovp_cov_propagate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.POINTER(C.c_int)]
         L.ovp_cov_clone.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -293,6 +305,27 @@ class Context:
         if rc != 0 and raise_on_error:
             raise OvpError(rc, "ovp_msckf_fetch_results")
         return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
+
+    def plane_update(self, opts: UpdateOpts, plane_of_feat, cp, cp_fej, plane_state_id, raise_on_error=True):
+        """UpdaterMSCKF::update per-plane loop. Returns dict(dx [n_planes, n], ok, chi2, dof, used)."""
+        plane_of_feat = np.ascontiguousarray(plane_of_feat, dtype=np.int32)
+        cp = np.ascontiguousarray(cp, dtype=np.float64)
+        cp_fej = np.ascontiguousarray(cp_fej, dtype=np.float64)
+        sid = np.ascontiguousarray(plane_state_id, dtype=np.int32)
+        npl = int(sid.shape[0])
+        n = self.cov_size()
+        dx = np.zeros((max(npl, 1), n))
+        ok = np.zeros(max(npl, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(npl, 1))
+        dof = np.zeros(max(npl, 1), dtype=np.int32)
+        used = np.zeros(max(self.n_feats, 1), dtype=np.uint8)
+        pb = PlaneBatch(npl, plane_of_feat.ctypes.data, cp.ctypes.data, cp_fej.ctypes.data, sid.ctypes.data)
+        rc = lib().ovp_msckf_plane_update(self._h, C.byref(opts), C.byref(pb), dx.ctypes.data, ok.ctypes.data,
+                                          chi2.ctypes.data, dof.ctypes.data, used.ctypes.data)
+        if rc != 0 and raise_on_error:
+            raise OvpError(rc, "ovp_msckf_plane_update")
+        return dict(dx=dx[:npl], ok=ok[:npl].astype(bool), chi2=chi2[:npl], dof=dof[:npl],
+                    used=used[: self.n_feats].astype(bool), rc=rc)
 
     def ekf_update(self, H, col_ids, res):
         """StateHelper::EKFUpdate with a dense H (rows x cols) and per-column state ids."""

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Lt, const double* __restrict__ Dinv,
                                                  const double* __restrict__ Lmat, double* __restrict__ V, int n,
-                                                 int ld) {
+                                                 int ld, int dense) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int nt = (n + 15) >> 4;
   const int cblk = blockIdx.x;  // column tile of V
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Lt, c
         const int e = row * 16 + lc;
         double sum = ((red[e] + red[256 + e]) + red[512 + e]) + red[768 + e];
         const int gr = 16 * cblk + lc, gc = 16 * i + row;
-        if (cblk >= i && gr < n && gc < n) sum += Lmat[(size_t)gr * ld + gc];
+        if ((dense || cblk >= i) && gr < n && gc < n) sum += Lmat[(size_t)gr * ld + gc];
         tmp[row * TS + lc] = sum;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -394,7 +394,7 @@ hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, 
 }
 
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
-                             hipStream_t stream) {
+                             int dense, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   const size_t shmem = ((size_t)nt * ovp::TSZ + 4 * 256 + ovp::TSZ) * sizeof(double);
   static bool attr = false;
@@ -402,7 +402,7 @@ hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double*
     hipFuncSetAttribute((const void*)ovp::k_fwdsub, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), shmem, stream, Lt, Dinv, Lmat, V, n, ld);
+  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), shmem, stream, Lt, Dinv, Lmat, V, n, ld, dense);
   return hipGetLastError();
 }
 

@@ -25,12 +25,31 @@ hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, c
 hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
                                hipStream_t stream);
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
-                             hipStream_t stream);
+                             int dense, hipStream_t stream);
 hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
                             int ldb, double* C, int ldc, int add_identity, int symmetric, hipStream_t stream);
 hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
                               hipStream_t stream);
 hipError_t ovp_launch_reduce_gram(const double* gramS, int n_clones, int n_chunks, double* gramR, hipStream_t stream);
+hipError_t ovp_launch_plane_feat(const ovp::FeatParams* p, const ovp::PlaneParams* pp, int n_local, hipStream_t stream);
+hipError_t ovp_launch_reduce_cst(const double* cst, int nf, double* out, hipStream_t stream);
+hipError_t ovp_launch_assemble_ext(const double* gramR, int n_clones, const double* part, int n_split,
+                                   const ovp::ColMap* colmap, int n, int plane_sid, const double* cstsum, double* E,
+                                   int lde, hipStream_t stream);
+hipError_t ovp_launch_plane_reduce_to_state(const double* E, int lde, int n, int in_state, double* Ab, int lda,
+                                            const double* rr_in, double* scal, hipStream_t stream);
+hipError_t ovp_launch_normalize_reg(const double* Ab, int lda, int n, double eps, double* An, double* bn,
+                                    hipStream_t stream);
+hipError_t ovp_launch_range_energy(const double* Lr, const double* Dinv, const double* bn, int n, int ld, double tol,
+                                   double* scal, hipStream_t stream);
+hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const double* b, double* dx, double* scal,
+                                     hipStream_t stream);
+hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
+                                 int n_involved, double* res_out, hipStream_t stream);
+hipError_t ovp_launch_plane_commit(const double* res, const double* V, double* M, int n, int ld, const double* dx,
+                                   double* dx_out, double* clone_R, double* clone_p, const int* clone_id, int n_clones,
+                                   double* cal, int calib_id, int intr_id, double* cp, const int* plane_sid,
+                                   int n_planes, hipStream_t stream);
 }
 
 static const int OVP_TILECHOL_NMAX = 288;  // register-resident factorization limit (22 tiles per wave)
@@ -112,6 +131,7 @@ struct ovp_ctx {
   // state tables
   double *clone_R = nullptr, *clone_p = nullptr, *clone_R_fej = nullptr, *clone_p_fej = nullptr;
   int* clone_id = nullptr;
+  double* cal = nullptr;  // [20] camera extrinsics / intrinsics values
   ovp::ColMap* colmap = nullptr;
   double* chi2_table = nullptr;
   ovp::FeatParams fp;
@@ -135,6 +155,13 @@ struct ovp_ctx {
   size_t Hd_cap = 0, res_cap = 0;
   int calib_id = -1, intr_id = -1;
   long long* dbg_cycles = nullptr;
+  // plane path
+  std::vector<int> h_n_meas, h_clone_idx;  // host copies of the uploaded batch (plane grouping is host logic)
+  int *pl_featlist = nullptr, *pl_sid = nullptr;
+  double *pl_cp = nullptr, *pl_cp_fej = nullptr, *pl_cst = nullptr, *pl_cstsum = nullptr, *pl_E = nullptr;
+  double *pl_An = nullptr, *pl_bn = nullptr, *pl_Lr = nullptr, *pl_Dinv2 = nullptr, *pl_scal = nullptr;
+  double *pl_res = nullptr, *pl_dx = nullptr;
+  int pl_cap = 0;
   int* idbuf = nullptr;      // scratch ints (ids)
   double* smallbuf = nullptr;  // scratch doubles (Phi, Q, CPT, PCP, marginal)
   size_t small_cap = 0;
@@ -199,8 +226,8 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   c->c_max = n_clones_max;
   c->f_max = n_feats_max;
   c->ld = round_up(n_state_max, 16);
-  c->ldg = round_up(n_state_max + 1, 16);
-  if (3 * c->ldg > 2080) return OVP_E_CAPACITY;  // K1 stages the projector rows in its 64x65/2 LDS triangle
+  c->ldg = round_up(n_state_max + 4, 16);  // state columns | residual | 3 out-of-state plane columns
+  if (3 * c->ldg > 2080 || c->ldg > OVP_LDG_CAP) return OVP_E_CAPACITY;  // K1 stages the projector rows in its 64x65/2 LDS triangle
   const size_t nn = (size_t)(c->n_max + 1) * c->ld;
   HIPCHK(dalloc(&c->P, nn));
   HIPCHK(dalloc(&c->P_tmp, nn));
@@ -217,6 +244,7 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->clone_R_fej, (size_t)9 * n_clones_max));
   HIPCHK(dalloc(&c->clone_p_fej, (size_t)3 * n_clones_max));
   HIPCHK(dalloc(&c->clone_id, (size_t)n_clones_max));
+  HIPCHK(dalloc(&c->cal, (size_t)32));
   HIPCHK(dalloc(&c->colmap, (size_t)c->n_max));
   HIPCHK(dalloc(&c->chi2_table, (size_t)OVP_CHI2_TABLE + 1));
   HIPCHK(dalloc(&c->uv, (size_t)n_feats_max * OVP_MAX_MEAS * 2));
@@ -264,7 +292,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->stream2);
   void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->dx, c->flags, c->clone_R, c->clone_p,
-                 c->clone_R_fej, c->clone_p_fej, c->clone_id, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
+                 c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
                  c->p_FinG, c->G, c->rec, c->chi2, c->accept, c->gramS, c->gramR, c->Dinv, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd};
   for (void* p : dev)
@@ -374,9 +402,14 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
   fp.clone_p_fej = c->clone_p_fej;
   fp.clone_id = c->clone_id;
   fp.n_clones = C;
-  quat_2_rot(st->calib_q, fp.R_ItoC);
-  memcpy(fp.p_IinC, st->calib_p, sizeof(double) * 3);
-  memcpy(fp.intr, st->intrinsics, sizeof(double) * 8);
+  {
+    double cal[20];
+    quat_2_rot(st->calib_q, cal);
+    memcpy(cal + 9, st->calib_p, sizeof(double) * 3);
+    memcpy(cal + 12, st->intrinsics, sizeof(double) * 8);
+    HIPCHK(hipMemcpyAsync(c->cal, cal, sizeof(cal), hipMemcpyHostToDevice, c->stream));
+  }
+  fp.cal = c->cal;
   c->calib_id = st->calib_id;
   c->intr_id = st->intr_id;
   // column map for the assembly kernel (calibration columns are enabled per update via the opts)
@@ -419,6 +452,8 @@ extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
     HIPCHK(hipMemcpyAsync(c->p_FinG, b->p_FinG, sizeof(double) * F * 3, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
+  c->h_n_meas.assign(b->n_meas, b->n_meas + F);
+  c->h_clone_idx.assign(b->clone_idx, b->clone_idx + F * M);
   c->fp.uv = c->uv;
   c->fp.clone_idx = c->clone_idx;
   c->fp.n_meas = c->n_meas;
@@ -431,6 +466,8 @@ extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
 extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
   if (!c || !b || b->n_feats < 0 || b->max_meas < 1 || b->max_meas > OVP_MAX_MEAS) return OVP_E_ARG;
   if (b->n_feats > c->f_max) return OVP_E_CAPACITY;
+  c->h_n_meas.clear();
+  c->h_clone_idx.clear();
   c->fp.uv = b->uv;
   c->fp.clone_idx = b->clone_idx;
   c->fp.n_meas = b->n_meas;
@@ -463,7 +500,7 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
     HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
-    HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, c->L, c->Y, n, ld, c->stream));
+    HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->stream));
     HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->stream));
     return 0;
@@ -477,10 +514,25 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
   return 0;
 }
 
+static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o);
+static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F);
+
 extern "C" int ovp_msckf_build_gate_gram_async(ovp_ctx* c, const ovp_update_opts* o) {
   if (!c || !o) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->fp.n_clones < 1) return OVP_E_STATE;
+  const int n = c->n, F = c->n_feats;
+  {
+    int rc = fill_feat_params(c, o);
+    if (rc) return rc;
+  }
+  ovp::FeatParams& fp = c->fp;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
+  return ovp_build_gate_gram_tail(c, n, F);
+}
+
+static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   const int n = c->n, F = c->n_feats;
   ovp::FeatParams& fp = c->fp;
   fp.n_feats = F;
@@ -504,8 +556,11 @@ extern "C" int ovp_msckf_build_gate_gram_async(ovp_ctx* c, const ovp_update_opts
   fp.chi2 = c->chi2;
   fp.accept = c->accept;
   fp.dbg_cycles = c->dbg_cycles;
-  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
-  HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
+  return 0;
+}
+
+static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
+  ovp::FeatParams& fp = c->fp;
   // chol(P) does not depend on the measurements: run it beside K1/K2 on the second stream
   HIPCHK(hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -610,6 +665,167 @@ extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx
   rc = ovp_ekf_update_from_gram_async(c);
   if (rc) return rc;
   return ovp_msckf_fetch_results(c, dx_host, accepted_host, chi2_host, info);
+}
+
+// ---- UpdaterMSCKF::update, per-plane loop ------------------------------------------------------
+extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
+                                      uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
+  if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
+  if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
+  if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
+  const int n = c->n, ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
+  if (n > OVP_TILECHOL_NMAX) return OVP_E_CAPACITY;
+  if (feat_used) memset(feat_used, 0, (size_t)F);
+  if (NP == 0) return 0;
+  for (int k = 0; k < NP; ++k)
+    if (pb->plane_state_id[k] >= 0 && pb->plane_state_id[k] + 3 > n) return OVP_E_ARG;
+  int rc = fill_feat_params(c, o);
+  if (rc) return rc;
+  ovp::FeatParams fp = c->fp;
+  // ---- host-side grouping (update/UpdaterMSCKF.cpp:204-229) ----
+  struct PlaneJob { int pl, start, nf, rows_total, rows_u, n_involved, in_state, sid; double thr; };
+  std::vector<PlaneJob> jobs;
+  std::vector<int> featlist;
+  const int ncal = (o->do_calib_camera_pose ? 6 : 0) + (o->do_calib_camera_intrinsics ? 8 : 0);
+  int max_nf = 1;
+  for (int pl = 0; pl < NP; ++pl) {
+    PlaneJob j;
+    j.pl = pl;
+    j.start = (int)featlist.size();
+    j.nf = 0;
+    j.rows_total = 0;
+    j.sid = pb->plane_state_id[pl];
+    j.in_state = j.sid >= 0;
+    unsigned long long seen = 0ull;
+    for (int f = 0; f < F; ++f) {
+      if (pb->plane_of_feat[f] != pl + 1) continue;
+      const int m = c->h_n_meas[f];
+      if (m < 2) continue;
+      if (m > 31) return OVP_E_CAPACITY;  // 2m+1 rows must fit one wavefront
+      featlist.push_back(f);
+      j.nf++;
+      j.rows_total += 3 * m - 3;
+      for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
+    }
+    if (j.nf == 0 || (!j.in_state && j.nf < 4)) {  // update/UpdaterMSCKF.cpp:316-317,396
+      featlist.resize(j.start);
+      continue;
+    }
+    const int c_ref = 6 * __builtin_popcountll(seen) + ncal;
+    const int rows_c = j.rows_total > c_ref ? c_ref : j.rows_total;  // UpdaterPlane::measurement_compress_inplace
+    j.rows_u = j.in_state ? rows_c : rows_c - 3;
+    j.n_involved = c_ref + (j.in_state ? 3 : 0);
+    if (!j.in_state) j.rows_total -= 3;
+    if (j.rows_u < 1) {
+      featlist.resize(j.start);
+      continue;
+    }
+    j.thr = o->chi2_multiplier * ovp_chi2_quantile_095(j.rows_u);
+    if (j.nf > max_nf) max_nf = j.nf;
+    jobs.push_back(j);
+  }
+  // ---- device buffers ----
+  if (NP > c->pl_cap || !c->pl_E) {
+    void* olds[] = {c->pl_sid, c->pl_cp, c->pl_cp_fej, c->pl_res, c->pl_dx};
+    for (void* p : olds) if (p) hipFree(p);
+    const int cap = NP + 8;
+    HIPCHK(dalloc(&c->pl_sid, (size_t)cap));
+    HIPCHK(dalloc(&c->pl_cp, (size_t)3 * cap));
+    HIPCHK(dalloc(&c->pl_cp_fej, (size_t)3 * cap));
+    HIPCHK(dalloc(&c->pl_res, (size_t)4 * cap));
+    HIPCHK(dalloc(&c->pl_dx, (size_t)c->n_max * cap));
+    c->pl_cap = cap;
+    if (!c->pl_E) {
+      const size_t ne = (size_t)(c->n_max + 4) * c->ldg;
+      HIPCHK(dalloc(&c->pl_featlist, (size_t)c->f_max));
+      HIPCHK(dalloc(&c->pl_cst, (size_t)c->f_max * 10));
+      HIPCHK(dalloc(&c->pl_cstsum, 16));
+      HIPCHK(dalloc(&c->pl_E, ne));
+      HIPCHK(dalloc(&c->pl_An, (size_t)(c->n_max + 1) * ld));
+      HIPCHK(dalloc(&c->pl_bn, (size_t)c->n_max));
+      HIPCHK(dalloc(&c->pl_Lr, (size_t)(c->n_max + 1) * ld));
+      HIPCHK(dalloc(&c->pl_Dinv2, (size_t)(ld / 16 + 1) * 256));
+      HIPCHK(dalloc(&c->pl_scal, 8));
+    }
+  }
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemsetAsync(c->pl_res, 0, sizeof(double) * 4 * NP, s));
+  HIPCHK(hipMemsetAsync(c->pl_dx, 0, sizeof(double) * (size_t)n * NP, s));
+  HIPCHK(hipMemcpyAsync(c->pl_sid, pb->plane_state_id, sizeof(int) * NP, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->pl_cp, pb->cp, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->pl_cp_fej, pb->cp_fej, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, s));
+  if (!featlist.empty())
+    HIPCHK(hipMemcpyAsync(c->pl_featlist, featlist.data(), sizeof(int) * featlist.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // the host vectors above go out of scope before the copies would otherwise run
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  // factor of P, chained through the plane loop:  P = M M^T
+  if (!jobs.empty()) {
+    rc = chol_of_P(c, s);
+    if (rc) return rc;
+  }
+  double* Mf = c->L;
+  const int ldg = c->ldg;
+  for (const PlaneJob& j : jobs) {
+    ovp::PlaneParams pp;
+    pp.feat_list = c->pl_featlist + j.start;
+    pp.n_local = j.nf;
+    pp.plane = j.pl;
+    pp.in_state = j.in_state;
+    pp.plane_sid = j.sid;
+    pp.white_c = 1.0 / o->sigma_constraint;
+    pp.cp = c->pl_cp;
+    pp.cp_fej = c->pl_cp_fej;
+    pp.cst = c->pl_cst;
+    HIPCHK(ovp_launch_plane_feat(&fp, &pp, j.nf, s));
+    const int chunks = (2 * j.nf + c->rows_per_chunk - 1) / c->rows_per_chunk;
+    HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, j.nf, c->rows_per_chunk, chunks, c->gramS, s));
+    HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, chunks, c->gramR, s));
+    int nsplit = (3 * j.nf + 511) / 512;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > c->n_split) nsplit = c->n_split;
+    HIPCHK(ovp_launch_syrk(c->G, 3 * j.nf, ldg, n + 4, nsplit, c->part, s));
+    HIPCHK(ovp_launch_reduce_cst(c->pl_cst, j.nf, c->pl_cstsum, s));
+    HIPCHK(ovp_launch_assemble_ext(c->gramR, fp.n_clones, c->part, nsplit, c->colmap, n, j.sid, c->pl_cstsum, c->pl_E, ldg, s));
+    HIPCHK(ovp_launch_plane_reduce_to_state(c->pl_E, ldg, n, j.in_state, c->Ab, ld, c->pl_cstsum + 9, c->pl_scal, s));
+    // range part of the residual (regularised, diagonally normalised)
+    HIPCHK(ovp_launch_normalize_reg(c->Ab, ld, n, 1e-10, c->pl_An, c->pl_bn, s));
+    HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, n, ld, c->flags + 2, 0, s));
+    HIPCHK(ovp_launch_range_energy(c->pl_Lr, c->pl_Dinv2, c->pl_bn, n, ld, 1e-8, c->pl_scal, s));
+    // EKF update in information form with the chained factor
+    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
+    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
+    HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, s));
+    HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, Mf, c->Y, n, ld, 1, s));
+    HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
+    HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, j.thr, j.rows_total, j.rows_u, j.n_involved, c->pl_res + 4 * j.pl, s));
+    HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * j.pl, c->Y, Mf, n, ld, c->dx, c->pl_dx + (size_t)j.pl * n, c->clone_R,
+                                   c->clone_p, c->clone_id, fp.n_clones, c->cal, o->do_calib_camera_pose ? c->calib_id : -1,
+                                   o->do_calib_camera_intrinsics ? c->intr_id : -1, c->pl_cp, c->pl_sid, NP, s));
+  }
+  // P = M M^T
+  if (!jobs.empty()) HIPCHK(ovp_launch_gemm4(0, 1, n, n, n, Mf, ld, Mf, ld, c->P, ld, 0, 1, s));
+  // results
+  std::vector<double> res(4 * (size_t)NP, 0.0);
+  HIPCHK(hipMemcpyAsync(res.data(), c->pl_res, sizeof(double) * 4 * NP, hipMemcpyDeviceToHost, s));
+  std::vector<double> dxh;
+  if (dx_planes) HIPCHK(hipMemcpyAsync(dx_planes, c->pl_dx, sizeof(double) * (size_t)n * NP, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int pl = 0; pl < NP; ++pl) {
+    if (plane_ok) plane_ok[pl] = 0;
+    if (plane_chi2) plane_chi2[pl] = 0.0;
+    if (plane_dof) plane_dof[pl] = 0;
+  }
+  for (const PlaneJob& j : jobs) {
+    const bool ok = res[4 * j.pl + 1] > 0.5;
+    if (plane_ok) plane_ok[j.pl] = ok ? 1 : 0;
+    if (plane_chi2) plane_chi2[j.pl] = res[4 * j.pl];
+    if (plane_dof) plane_dof[j.pl] = j.rows_u;
+    if (ok && feat_used)
+      for (int k = 0; k < j.nf; ++k) feat_used[featlist[j.start + k]] = 1;
+  }
+  if (c->h_flags[0]) return OVP_E_NOTSPD;
+  return 0;
 }
 
 // ---- StateHelper::EKFUpdate with a dense host H ------------------------------------------------

@@ -7,6 +7,7 @@
 #define OVP_CHI2_TABLE 1024  // chi2_table[k] for k = 0..OVP_CHI2_TABLE (k=0 unused)
 #define OVP_MAX_CLONES 64
 #define OVP_GRAM_ELEMS 231   // 21*22/2: packed upper triangle of the per-clone 21x21 Gram
+#define OVP_LDG_CAP 704      // max leading dimension of the projector-row buffer G (LDS staging in the feature kernels)
 
 namespace ovp {
 
@@ -25,9 +26,7 @@ struct FeatParams {
   const int* clone_id;        // [C]
   int n_clones;
   int do_fej;
-  double R_ItoC[9];
-  double p_IinC[3];
-  double intr[8];
+  const double* cal;  // device: [0..8] R_ItoC row-major, [9..11] p_IinC, [12..19] fx fy cx cy k1 k2 p1 p2
   int calcol[14];  // state column of calibration column k: k<6 extrinsics, k>=6 intrinsics
   unsigned calmask;  // bit k set = calibration column k is estimated
   double white_px, chi2_mult;
@@ -41,6 +40,19 @@ struct FeatParams {
   double* chi2;
   unsigned char* accept;
   long long* dbg_cycles;  // optional [n_feats][8] phase stamps (diagnostics)
+};
+
+// per-plane arguments of the plane feature kernel
+struct PlaneParams {
+  const int* feat_list;  // [n_local] indices into the feature batch
+  int n_local;
+  int plane;             // 0-based plane slot
+  int in_state;          // plane is a state variable (State::_features_PLANE)
+  int plane_sid;         // its Type::id(), or -1
+  double white_c;        // 1 / sigma_constraint
+  const double* cp;      // [n_planes][3] current closest-point estimates
+  const double* cp_fej;  // [n_planes][3]
+  double* cst;           // [n_local][10] constraint-row moments
 };
 
 // per-column description of the state used when assembling the information pair
