@@ -170,6 +170,9 @@ int ovp_cov_propagate(ovp_ctx *ctx, int new_start, int phi_size, const int *old_
 int ovp_cov_clone(ovp_ctx *ctx, int src_id, int size);
 /* StateHelper::marginalize (state/StateHelper.cpp:276-344): removes rows/cols [id, id+size). */
 int ovp_cov_marginalize(ovp_ctx *ctx, int id, int size);
+/* StateHelper::augment_clone, time-offset part (state/StateHelper.cpp:613-624):
+ *   Cov[:, pose..pose+5] += Cov[:, dt] * dnc_dt^T ;  Cov[pose..pose+5, :] += dnc_dt * Cov[dt, :]   (in that order) */
+int ovp_cov_augment_dt(ovp_ctx *ctx, int pose_id, int dt_id, const double dnc_dt[6]);
 /* current covariance dimension */
 int ovp_cov_size(ovp_ctx *ctx);
 

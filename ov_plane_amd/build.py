@@ -28,3 +28,26 @@ def build_lib(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return OUT
+
+
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_SOURCES = ["ov_plane_host.cpp", "host_capi.cpp"]
+HOST_HEADERS = ["ov_plane_host.h", "ov_types.h"]
+HOST_OUT = os.path.join(_HERE, "libovplane_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """C++ host mirror of ov_plane's State / StateHelper / UpdaterMSCKF on top of the C-ABI (g++, links libovplane_hip.so)."""
+    build_lib(force=False, verbose=verbose)
+    stale = force or not os.path.exists(HOST_OUT)
+    if not stale:
+        t = os.path.getmtime(HOST_OUT)
+        stale = any(os.path.getmtime(os.path.join(HOST_DIR, f)) > t for f in HOST_SOURCES + HOST_HEADERS) or os.path.getmtime(OUT) > t
+    if not stale:
+        return HOST_OUT
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + HOST_DIR, "-I" + os.path.join(_HERE, "..", "include")] + \
+          [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] + ["-o", HOST_OUT, "-L" + _HERE, "-lovplane_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_OUT

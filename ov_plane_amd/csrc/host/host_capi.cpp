@@ -1,0 +1,137 @@
+// Harness entry point for the host mirror (tests only need a C symbol to drive the C++ classes from ctypes).
+// It builds an ov_plane::State the way VioManager would (clone by clone through StateHelper::augment_clone), installs the
+// given covariance, wraps the measurements in ov_core::Feature objects and calls UpdaterMSCKF::update.
+#include <cstring>
+
+#include "ov_plane_host.h"
+
+using namespace ov_plane;
+using namespace ov_type;
+
+extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
+                                     const double *clone_p_fej, const double *calib_q, const double *calib_p,
+                                     const double *intr, int n_planes_in_state, const double *cp_state,
+                                     const double *cp_state_fej, const size_t *plane_ids_state, int n_planes_out,
+                                     const double *cp_out, const size_t *plane_ids_out, int N, const double *P, int F, int M,
+                                     const float *uv, const int *clone_idx, const int *n_meas, const double *p_FinG,
+                                     const int *plane_of_feat /* reference plane id or 0 */, double sigma_px,
+                                     double chi2_mult, double sigma_c, int do_fej,
+                                     /* outputs */ double *out_clone_q, double *out_clone_p, double *out_calib_q,
+                                     double *out_calib_p, double *out_intr, double *out_cp_state, double *out_P,
+                                     unsigned char *feat_kept, unsigned char *feat_used, unsigned char *feat_deleted) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.use_plane_constraint = so.use_plane_constraint_msckf = true;
+  so.sigma_constraint = sigma_c;
+  so.max_state_size = N + 8;
+  so.max_features = F + 8;
+  auto state = std::make_shared<State>(so);
+  // calibration values
+  {
+    VectorXd v(7, 1);
+    for (int k = 0; k < 4; ++k) v(k) = calib_q[k];
+    for (int k = 0; k < 3; ++k) v(4 + k) = calib_p[k];
+    state->_calib_IMUtoCAM.at(0)->set_value(v);
+    state->_calib_IMUtoCAM.at(0)->set_fej(v);
+    VectorXd iv(8, 1);
+    for (int k = 0; k < 8; ++k) iv(k) = intr[k];
+    state->_cam_intrinsics.at(0)->set_value(iv);
+    state->_cam_intrinsics.at(0)->set_fej(iv);
+  }
+  // clones, oldest first, through the reference's own entry point
+  const double w0[3] = {0, 0, 0};
+  std::vector<double> times(C);
+  for (int i = 0; i < C; ++i) {
+    VectorXd v(7, 1), vf(7, 1);
+    for (int k = 0; k < 4; ++k) {
+      v(k) = clone_q[4 * i + k];
+      vf(k) = clone_q_fej[4 * i + k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      v(4 + k) = clone_p[3 * i + k];
+      vf(4 + k) = clone_p_fej[3 * i + k];
+    }
+    state->_imu->pose()->set_value(v);
+    state->_imu->pose()->set_fej(vf);
+    times[i] = 100.0 + 0.1 * i;
+    state->_timestamp = times[i];
+    StateHelper::augment_clone(state, w0);
+  }
+  // in-state planes: grow the state by cloning the 3-dof position block of the IMU (sizes match), then relabel the new
+  // variable's value; the covariance is overwritten below
+  std::vector<std::shared_ptr<Vec>> planes;
+  for (int k = 0; k < n_planes_in_state; ++k) {
+    std::shared_ptr<Type> t = StateHelper::clone(state, state->_imu->p());
+    auto pl = std::dynamic_pointer_cast<Vec>(t);
+    if (!pl) return -10;
+    VectorXd v(3, 1), vf(3, 1);
+    for (int a = 0; a < 3; ++a) {
+      v(a) = cp_state[3 * k + a];
+      vf(a) = cp_state_fej[3 * k + a];
+    }
+    pl->set_value(v);
+    pl->set_fej(vf);
+    state->_features_PLANE[plane_ids_state[k]] = pl;
+    planes.push_back(pl);
+  }
+  for (int k = 0; k < n_planes_out; ++k)
+    state->_plane_estimates_cp_inG[plane_ids_out[k]] = {cp_out[3 * k], cp_out[3 * k + 1], cp_out[3 * k + 2]};
+  if (state->max_covariance_size() != N) return -11;
+  {
+    std::vector<std::shared_ptr<Type>> order;
+    order.push_back(state->_imu);
+    order.push_back(state->_calib_dt_CAMtoIMU);
+    order.push_back(state->_calib_IMUtoCAM.at(0));
+    order.push_back(state->_cam_intrinsics.at(0));
+    for (auto &c : state->_clones_IMU) order.push_back(c.second);
+    for (auto &p : planes) order.push_back(p);
+    MatrixXd Pm(N, N);
+    memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+    StateHelper::set_initial_covariance(state, Pm, order);
+  }
+  // features
+  std::vector<std::shared_ptr<ov_core::Feature>> fv, fextra, fused;
+  std::map<size_t, size_t> feat2plane;
+  for (int f = 0; f < F; ++f) {
+    auto ft = std::make_shared<ov_core::Feature>();
+    ft->featid = 5000 + f;
+    for (int k = 0; k < n_meas[f]; ++k) {
+      ft->timestamps.push_back(times[clone_idx[(size_t)f * M + k]]);
+      ft->uvs.push_back(uv[((size_t)f * M + k) * 2]);
+      ft->uvs.push_back(uv[((size_t)f * M + k) * 2 + 1]);
+    }
+    memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+    if (plane_of_feat[f] > 0) feat2plane[ft->featid] = (size_t)plane_of_feat[f];
+    fv.push_back(ft);
+  }
+  std::vector<std::shared_ptr<ov_core::Feature>> all = fv;
+  UpdaterOptions uo;
+  uo.sigma_pix = sigma_px;
+  uo.chi2_multipler = chi2_mult;
+  ov_core::FeatureInitializerOptions fio;
+  UpdaterMSCKF updater(uo, fio);
+  updater.update(state, fv, fextra, fused, feat2plane);
+  // outputs
+  int i = 0;
+  for (auto &c : state->_clones_IMU) {
+    memcpy(out_clone_q + 4 * i, c.second->quat(), 4 * sizeof(double));
+    memcpy(out_clone_p + 3 * i, c.second->pos(), 3 * sizeof(double));
+    ++i;
+  }
+  memcpy(out_calib_q, state->_calib_IMUtoCAM.at(0)->quat(), 4 * sizeof(double));
+  memcpy(out_calib_p, state->_calib_IMUtoCAM.at(0)->pos(), 3 * sizeof(double));
+  memcpy(out_intr, state->_cam_intrinsics.at(0)->value().data(), 8 * sizeof(double));
+  for (int k = 0; k < n_planes_in_state; ++k) memcpy(out_cp_state + 3 * k, planes[k]->value().data(), 3 * sizeof(double));
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)N * N);
+  for (int f = 0; f < F; ++f) {
+    feat_kept[f] = 0;
+    feat_used[f] = 0;
+    feat_deleted[f] = all[f]->to_delete ? 1 : 0;
+  }
+  for (auto &ft : fv) feat_kept[ft->featid - 5000] = 1;
+  for (auto &ft : fused) feat_used[ft->featid - 5000] = 1;
+  return 0;
+}

@@ -1,0 +1,494 @@
+#include "ov_plane_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+using namespace ov_type;
+
+namespace ov_plane {
+
+#define PRINT_ERROR(...) fprintf(stderr, __VA_ARGS__)
+static void gpu_check(int rc, const char *what) {
+  if (rc == 0) return;
+  PRINT_ERROR("ov_plane(gpu): %s failed: %s\n", what, ovp_error_string(rc));
+  std::exit(EXIT_FAILURE);  // the reference treats every failure on this path as fatal (state/StateHelper.cpp:116-118,185-187)
+}
+
+// ---- state/State.cpp:33-102 -------------------------------------------------------------------
+State::State(StateOptions &options_) {
+  _options = options_;
+  int current_id = 0;
+  _imu = std::make_shared<IMU>();
+  _imu->set_local_id(current_id);
+  _variables.push_back(_imu);
+  current_id += _imu->size();
+  _calib_dt_CAMtoIMU = std::make_shared<Vec>(1);
+  if (_options.do_calib_camera_timeoffset) {
+    _calib_dt_CAMtoIMU->set_local_id(current_id);
+    _variables.push_back(_calib_dt_CAMtoIMU);
+    current_id += _calib_dt_CAMtoIMU->size();
+  }
+  for (int i = 0; i < _options.num_cameras; i++) {
+    auto pose = std::make_shared<PoseJPL>();
+    auto intrin = std::make_shared<Vec>(8);
+    _calib_IMUtoCAM.insert({(size_t)i, pose});
+    _cam_intrinsics.insert({(size_t)i, intrin});
+    if (_options.do_calib_camera_pose) {
+      pose->set_local_id(current_id);
+      _variables.push_back(pose);
+      current_id += pose->size();
+    }
+    if (_options.do_calib_camera_intrinsics) {
+      intrin->set_local_id(current_id);
+      _variables.push_back(intrin);
+      current_id += intrin->size();
+    }
+  }
+  // covariance priors (:85-101)
+  MatrixXd Cov = MatrixXd::Zero(current_id, current_id);
+  for (int i = 0; i < current_id; ++i) Cov(i, i) = 1e-3 * 1e-3;
+  if (_options.do_calib_camera_timeoffset) Cov(_calib_dt_CAMtoIMU->id(), _calib_dt_CAMtoIMU->id()) = 0.01 * 0.01;
+  if (_options.do_calib_camera_pose)
+    for (int i = 0; i < _options.num_cameras; i++) {
+      const int id = _calib_IMUtoCAM.at(i)->id();
+      for (int k = 0; k < 3; ++k) {
+        Cov(id + k, id + k) = 0.005 * 0.005;
+        Cov(id + 3 + k, id + 3 + k) = 0.01 * 0.01;
+      }
+    }
+  if (_options.do_calib_camera_intrinsics)
+    for (int i = 0; i < _options.num_cameras; i++) {
+      const int id = _cam_intrinsics.at(i)->id();
+      for (int k = 0; k < 4; ++k) {
+        Cov(id + k, id + k) = 1.0;
+        Cov(id + 4 + k, id + 4 + k) = 0.005 * 0.005;
+      }
+    }
+  gpu_check(ovp_ctx_create(0, _options.max_state_size, std::min(64, _options.max_clone_size + 2), _options.max_features, nullptr, &_gpu),
+            "ovp_ctx_create");
+  gpu_check(ovp_cov_upload(_gpu, Cov.data(), current_id, current_id), "ovp_cov_upload");
+}
+
+State::~State() {
+  if (_gpu) ovp_ctx_destroy(_gpu);
+}
+
+// ---- state/StateHelper.cpp:41-119 --------------------------------------------------------------
+void StateHelper::EKFPropagation(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &order_NEW,
+                                 const std::vector<std::shared_ptr<Type>> &order_OLD, const MatrixXd &Phi, const MatrixXd &Q) {
+  if (order_NEW.empty() || order_OLD.empty()) {
+    PRINT_ERROR("StateHelper::EKFPropagation() - Called with empty variable arrays!\n");
+    std::exit(EXIT_FAILURE);
+  }
+  int size_order_NEW = order_NEW.at(0)->size();
+  for (size_t i = 0; i < order_NEW.size() - 1; i++) {
+    if (order_NEW.at(i)->id() + order_NEW.at(i)->size() != order_NEW.at(i + 1)->id()) {
+      PRINT_ERROR("StateHelper::EKFPropagation() - Called with non-contiguous state elements!\n");
+      std::exit(EXIT_FAILURE);
+    }
+    size_order_NEW += order_NEW.at(i + 1)->size();
+  }
+  int size_order_OLD = 0;
+  std::vector<int> ids, sizes;
+  for (const auto &var : order_OLD) {
+    ids.push_back(var->id());
+    sizes.push_back(var->size());
+    size_order_OLD += var->size();
+  }
+  assert(size_order_NEW == Phi.rows() && size_order_OLD == Phi.cols());
+  assert(size_order_NEW == Q.cols() && size_order_NEW == Q.rows());
+  int neg = 0;
+  int rc = ovp_cov_propagate(state->_gpu, order_NEW.at(0)->id(), Phi.rows(), ids.data(), sizes.data(), (int)ids.size(), Phi.data(),
+                             Q.data(), &neg);
+  if (rc == OVP_E_NEGDIAG || neg) {
+    PRINT_ERROR("StateHelper::EKFPropagation() - negative covariance diagonal\n");
+    std::exit(EXIT_FAILURE);
+  }
+  gpu_check(rc, "ovp_cov_propagate");
+}
+
+// Cholesky of a small SPD host matrix (noise whitening when R != I)
+static bool host_llt(MatrixXd &A) {
+  const int n = A.rows();
+  for (int j = 0; j < n; ++j) {
+    double d = A(j, j);
+    for (int k = 0; k < j; ++k) d -= A(j, k) * A(j, k);
+    if (!(d > 0)) return false;
+    d = std::sqrt(d);
+    A(j, j) = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A(i, j);
+      for (int k = 0; k < j; ++k) s -= A(i, k) * A(j, k);
+      A(i, j) = s / d;
+    }
+  }
+  return true;
+}
+
+void StateHelper::apply_correction(std::shared_ptr<State> state, const double *dx) {
+  for (auto &var : state->_variables) {
+    VectorXd d(var->size(), 1);
+    for (int k = 0; k < var->size(); ++k) d(k) = dx[var->id() + k];
+    var->update(d);
+  }
+}
+
+// ---- state/StateHelper.cpp:121-202 -------------------------------------------------------------
+void StateHelper::EKFUpdate(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &H_order, const MatrixXd &H,
+                            const VectorXd &res, const MatrixXd &R) {
+  assert(res.rows() == R.rows());
+  assert(H.rows() == res.rows());
+  std::vector<int> col_ids;
+  for (const auto &v : H_order)
+    for (int k = 0; k < v->size(); ++k) col_ids.push_back(v->id() + k);
+  assert((int)col_ids.size() == H.cols());
+  // the device update assumes whitened noise (R = I, true for every caller on the MSCKF/plane path); whiten otherwise
+  bool identity = true;
+  for (int j = 0; j < R.cols() && identity; ++j)
+    for (int i = 0; i < R.rows(); ++i)
+      if (R(i, j) != (i == j ? 1.0 : 0.0)) {
+        identity = false;
+        break;
+      }
+  MatrixXd Hw = H;
+  VectorXd rw = res;
+  if (!identity) {
+    MatrixXd Lr = R;
+    if (!host_llt(Lr)) {
+      PRINT_ERROR("StateHelper::EKFUpdate() - measurement noise is not positive definite\n");
+      std::exit(EXIT_FAILURE);
+    }
+    const int m = H.rows();
+    for (int j = 0; j < H.cols(); ++j)
+      for (int i = 0; i < m; ++i) {
+        double s = Hw(i, j);
+        for (int k = 0; k < i; ++k) s -= Lr(i, k) * Hw(k, j);
+        Hw(i, j) = s / Lr(i, i);
+      }
+    for (int i = 0; i < m; ++i) {
+      double s = rw(i);
+      for (int k = 0; k < i; ++k) s -= Lr(i, k) * rw(k);
+      rw(i) = s / Lr(i, i);
+    }
+  }
+  const int n = ovp_cov_size(state->_gpu);
+  std::vector<double> dx(n, 0.0);
+  ovp_update_info info;
+  int rc = ovp_ekf_update(state->_gpu, Hw.data(), Hw.rows(), Hw.cols(), Hw.rows(), col_ids.data(), rw.data(), dx.data(), &info);
+  if (rc == OVP_E_NEGDIAG) {
+    PRINT_ERROR("StateHelper::EKFUpdate() - negative covariance diagonal\n");
+    std::exit(EXIT_FAILURE);
+  }
+  gpu_check(rc, "ovp_ekf_update");
+  apply_correction(state, dx.data());
+}
+
+// ---- state/StateHelper.cpp:204-229 -------------------------------------------------------------
+void StateHelper::set_initial_covariance(std::shared_ptr<State> state, const MatrixXd &covariance,
+                                         const std::vector<std::shared_ptr<Type>> &order) {
+  const int n = ovp_cov_size(state->_gpu);
+  MatrixXd Cov(n, n);
+  gpu_check(ovp_cov_download(state->_gpu, Cov.data(), n, n), "ovp_cov_download");
+  int i_index = 0;
+  for (size_t i = 0; i < order.size(); i++) {
+    int k_index = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+      for (int a = 0; a < order[i]->size(); ++a)
+        for (int b = 0; b < order[k]->size(); ++b) Cov(order[i]->id() + a, order[k]->id() + b) = covariance(i_index + a, k_index + b);
+      k_index += order[k]->size();
+    }
+    i_index += order[i]->size();
+  }
+  for (int j = 0; j < n; ++j)
+    for (int i = j + 1; i < n; ++i) Cov(i, j) = Cov(j, i);  // selfadjointView<Upper>
+  gpu_check(ovp_cov_upload(state->_gpu, Cov.data(), n, n), "ovp_cov_upload");
+}
+
+// ---- state/StateHelper.cpp:231-274 -------------------------------------------------------------
+MatrixXd StateHelper::get_marginal_covariance(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &small_variables) {
+  std::vector<int> ids, sizes;
+  int cov_size = 0;
+  for (const auto &v : small_variables) {
+    ids.push_back(v->id());
+    sizes.push_back(v->size());
+    cov_size += v->size();
+  }
+  MatrixXd Small_cov = MatrixXd::Zero(cov_size, cov_size);
+  gpu_check(ovp_cov_marginal(state->_gpu, ids.data(), sizes.data(), (int)ids.size(), Small_cov.data()), "ovp_cov_marginal");
+  return Small_cov;
+}
+
+MatrixXd StateHelper::get_full_covariance(std::shared_ptr<State> state) {
+  const int n = ovp_cov_size(state->_gpu);
+  MatrixXd full_cov = MatrixXd::Zero(n, n);
+  gpu_check(ovp_cov_download(state->_gpu, full_cov.data(), n, n), "ovp_cov_download");
+  return full_cov;
+}
+
+// ---- state/StateHelper.cpp:276-344 -------------------------------------------------------------
+void StateHelper::marginalize(std::shared_ptr<State> state, std::shared_ptr<Type> marg) {
+  if (std::find(state->_variables.begin(), state->_variables.end(), marg) == state->_variables.end()) {
+    PRINT_ERROR("StateHelper::marginalize() - Called on variable that is not in the state\n");
+    std::exit(EXIT_FAILURE);
+  }
+  const int marg_size = marg->size();
+  const int marg_id = marg->id();
+  gpu_check(ovp_cov_marginalize(state->_gpu, marg_id, marg_size), "ovp_cov_marginalize");
+  std::vector<std::shared_ptr<Type>> remaining_variables;
+  for (size_t i = 0; i < state->_variables.size(); i++) {
+    if (state->_variables.at(i) != marg) {
+      if (state->_variables.at(i)->id() > marg_id) state->_variables.at(i)->set_local_id(state->_variables.at(i)->id() - marg_size);
+      remaining_variables.push_back(state->_variables.at(i));
+    }
+  }
+  marg->set_local_id(-1);
+  state->_variables = remaining_variables;
+}
+
+// ---- state/StateHelper.cpp:346-396 -------------------------------------------------------------
+std::shared_ptr<Type> StateHelper::clone(std::shared_ptr<State> state, std::shared_ptr<Type> variable_to_clone) {
+  const int total_size = variable_to_clone->size();
+  const int new_loc = ovp_cov_size(state->_gpu);
+  std::shared_ptr<Type> new_clone = nullptr;
+  for (size_t k = 0; k < state->_variables.size(); k++) {
+    std::shared_ptr<Type> type_check = state->_variables.at(k)->check_if_subvariable(variable_to_clone);
+    if (state->_variables.at(k) == variable_to_clone) {
+      type_check = state->_variables.at(k);
+    } else if (type_check != variable_to_clone) {
+      continue;
+    }
+    const int old_loc = type_check->id();
+    gpu_check(ovp_cov_clone(state->_gpu, old_loc, total_size), "ovp_cov_clone");
+    new_clone = type_check->clone();
+    new_clone->set_local_id(new_loc);
+    break;
+  }
+  if (new_clone == nullptr) {
+    PRINT_ERROR("StateHelper::clone() - Called on variable is not in the state\n");
+    std::exit(EXIT_FAILURE);
+  }
+  state->_variables.push_back(new_clone);
+  return new_clone;
+}
+
+// ---- state/StateHelper.cpp:588-625 -------------------------------------------------------------
+void StateHelper::augment_clone(std::shared_ptr<State> state, const double last_w[3]) {
+  if (state->_clones_IMU.find(state->_timestamp) != state->_clones_IMU.end()) {
+    PRINT_ERROR("TRIED TO INSERT A CLONE AT THE SAME TIME AS AN EXISTING CLONE, EXITING!#!@#!@#\n");
+    std::exit(EXIT_FAILURE);
+  }
+  std::shared_ptr<Type> posetemp = StateHelper::clone(state, state->_imu->pose());
+  std::shared_ptr<PoseJPL> pose = std::dynamic_pointer_cast<PoseJPL>(posetemp);
+  if (pose == nullptr) {
+    PRINT_ERROR("INVALID OBJECT RETURNED FROM STATEHELPER CLONE, EXITING!#!@#!@#\n");
+    std::exit(EXIT_FAILURE);
+  }
+  state->_clones_IMU[state->_timestamp] = pose;
+  if (state->_options.do_calib_camera_timeoffset) {
+    double dnc_dt[6] = {last_w[0], last_w[1], last_w[2], state->_imu->vel()[0], state->_imu->vel()[1], state->_imu->vel()[2]};
+    gpu_check(ovp_cov_augment_dt(state->_gpu, pose->id(), state->_calib_dt_CAMtoIMU->id(), dnc_dt), "ovp_cov_augment_dt");
+  }
+}
+
+// ---- state/StateHelper.cpp:627-636 -------------------------------------------------------------
+void StateHelper::marginalize_old_clone(std::shared_ptr<State> state) {
+  if ((int)state->_clones_IMU.size() > state->_options.max_clone_size) {
+    double marginal_time = state->margtimestep();
+    assert(marginal_time != INFINITY);
+    StateHelper::marginalize(state, state->_clones_IMU.at(marginal_time));
+    state->_clones_IMU.erase(marginal_time);
+  }
+}
+
+// ---- update/UpdaterMSCKF.cpp ---------------------------------------------------------------------
+UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, ov_core::FeatureInitializerOptions &) : _options(options) {
+  _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
+  // the chi-square table (:59-62) lives inside libovplane_hip.so (ovp_chi2_quantile_095)
+}
+
+void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                          std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_extra,
+                          std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane) {
+  if (feature_vec.empty()) return;  // :70-71
+  (void)feature_vec_extra;          // extra on-plane features only feed the upstream plane fit (:218-228), out of scope
+
+  // :74-100  keep measurements at existing clone times, drop features with < 2 of them
+  std::map<double, int> clone_slot;
+  std::vector<std::shared_ptr<PoseJPL>> clones;
+  for (const auto &c : state->_clones_IMU) {
+    clone_slot[c.first] = (int)clones.size();
+    clones.push_back(c.second);
+  }
+  auto it0 = feature_vec.begin();
+  while (it0 != feature_vec.end()) {
+    auto &ft = **it0;
+    std::vector<float> uv2;
+    std::vector<double> ts2;
+    for (size_t k = 0; k < ft.timestamps.size(); ++k)
+      if (clone_slot.count(ft.timestamps[k])) {
+        ts2.push_back(ft.timestamps[k]);
+        uv2.push_back(ft.uvs[2 * k]);
+        uv2.push_back(ft.uvs[2 * k + 1]);
+      }
+    ft.timestamps = ts2;
+    ft.uvs = uv2;
+    if (ts2.size() < 2) {
+      ft.to_delete = true;
+      it0 = feature_vec.erase(it0);
+    } else {
+      it0++;
+    }
+  }
+  if (feature_vec.empty()) return;
+
+  // ---- pack the pose tables and the feature batch for the device ----
+  const int C = (int)clones.size();
+  std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
+  std::vector<int> cid(C);
+  for (int i = 0; i < C; ++i) {
+    memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
+    memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
+    memcpy(&cqf[4 * i], clones[i]->quat_fej(), 4 * sizeof(double));
+    memcpy(&cpf[3 * i], clones[i]->pos_fej(), 3 * sizeof(double));
+    cid[i] = clones[i]->id();
+  }
+  auto pack_tables = [&]() {
+    ovp_state_tables st;
+    st.n_state = ovp_cov_size(state->_gpu);
+    st.n_clones = C;
+    for (int i = 0; i < C; ++i) {  // values may have changed after the plane loop
+      memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
+      memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
+    }
+    st.clone_q = cq.data();
+    st.clone_p = cp.data();
+    st.clone_q_fej = cqf.data();
+    st.clone_p_fej = cpf.data();
+    st.clone_id = cid.data();
+    auto calib = state->_calib_IMUtoCAM.at(0);
+    auto intr = state->_cam_intrinsics.at(0);
+    memcpy(st.calib_q, calib->quat(), 4 * sizeof(double));
+    memcpy(st.calib_p, calib->pos(), 3 * sizeof(double));
+    st.calib_id = calib->id();
+    memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
+    st.intr_id = intr->id();
+    gpu_check(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
+  };
+  auto upload_batch = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv) {
+    const int F = (int)fv.size();
+    int M = 1;
+    for (auto &f : fv) M = std::max(M, (int)f->timestamps.size());
+    if (M > OVP_MAX_MEAS) {
+      PRINT_ERROR("UpdaterMSCKF::update() - more than %d observations per feature are not supported\n", OVP_MAX_MEAS);
+      std::exit(EXIT_FAILURE);
+    }
+    std::vector<float> uv((size_t)F * M * 2, 0.f);
+    std::vector<int> cidx((size_t)F * M, -1), nm(F);
+    std::vector<double> pf((size_t)F * 3);
+    for (int f = 0; f < F; ++f) {
+      nm[f] = (int)fv[f]->timestamps.size();
+      for (int k = 0; k < nm[f]; ++k) {
+        cidx[(size_t)f * M + k] = clone_slot.at(fv[f]->timestamps[k]);
+        uv[((size_t)f * M + k) * 2] = fv[f]->uvs[2 * k];
+        uv[((size_t)f * M + k) * 2 + 1] = fv[f]->uvs[2 * k + 1];
+      }
+      memcpy(&pf[3 * f], fv[f]->p_FinG, 3 * sizeof(double));
+    }
+    ovp_feature_batch fb{F, M, uv.data(), cidx.data(), nm.data(), pf.data()};
+    gpu_check(ovp_batch_upload(state->_gpu, &fb), "ovp_batch_upload");
+  };
+  ovp_update_opts o{_options.sigma_pix,
+                    _options.chi2_multipler,
+                    state->_options.sigma_constraint,
+                    state->_options.do_fej ? 1 : 0,
+                    state->_options.do_calib_camera_pose ? 1 : 0,
+                    state->_options.do_calib_camera_intrinsics ? 1 : 0,
+                    0};
+  pack_tables();
+
+  // ---- plane loop (:411-649) ----
+  std::set<size_t> features_used_already;
+  if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_msckf && !feat2plane.empty()) {
+    // planes that have an estimate: in the state, or handed over by the upstream fit
+    std::vector<size_t> plane_ids;
+    for (const auto &fp : feat2plane)
+      if (std::find(plane_ids.begin(), plane_ids.end(), fp.second) == plane_ids.end()) plane_ids.push_back(fp.second);
+    std::sort(plane_ids.begin(), plane_ids.end());  // std::map iteration order of plane_estimates_cp_inG (:413)
+    std::vector<size_t> used_planes;
+    for (size_t pid : plane_ids)
+      if (state->_features_PLANE.count(pid) || state->_plane_estimates_cp_inG.count(pid)) used_planes.push_back(pid);
+    if (!used_planes.empty()) {
+      const int NP = (int)used_planes.size();
+      std::vector<int> pof(feature_vec.size(), 0), sid(NP, -1);
+      std::vector<double> cpv(3 * NP), cpfej(3 * NP);
+      for (int k = 0; k < NP; ++k) {
+        const size_t pid = used_planes[k];
+        if (state->_features_PLANE.count(pid)) {
+          auto pl = state->_features_PLANE.at(pid);
+          sid[k] = pl->id();
+          for (int a = 0; a < 3; ++a) {
+            cpv[3 * k + a] = pl->value()(a);
+            cpfej[3 * k + a] = pl->fej()(a);
+          }
+        } else {
+          for (int a = 0; a < 3; ++a) cpv[3 * k + a] = cpfej[3 * k + a] = state->_plane_estimates_cp_inG.at(pid)[a];
+        }
+      }
+      for (size_t f = 0; f < feature_vec.size(); ++f) {
+        auto it = feat2plane.find(feature_vec[f]->featid);
+        if (it == feat2plane.end()) continue;
+        auto pos = std::find(used_planes.begin(), used_planes.end(), it->second);
+        if (pos != used_planes.end()) pof[f] = 1 + (int)(pos - used_planes.begin());
+      }
+      upload_batch(feature_vec);
+      const int n = ovp_cov_size(state->_gpu);
+      std::vector<double> dxp((size_t)NP * n, 0.0);
+      std::vector<uint8_t> pok(NP, 0), fused(feature_vec.size(), 0);
+      ovp_plane_batch pb{NP, pof.data(), cpv.data(), cpfej.data(), sid.data()};
+      gpu_check(ovp_msckf_plane_update(state->_gpu, &o, &pb, dxp.data(), pok.data(), nullptr, nullptr, fused.data()),
+                "ovp_msckf_plane_update");
+      for (int k = 0; k < NP; ++k)
+        if (pok[k]) StateHelper::apply_correction(state, &dxp[(size_t)k * n]);  // :648 per accepted plane, in order
+      for (size_t f = 0; f < feature_vec.size(); ++f)
+        if (fused[f]) {  // :640-644
+          feature_vec[f]->to_delete = true;
+          features_used_already.insert(feature_vec[f]->featid);
+          feature_vec_used.push_back(feature_vec[f]);
+        }
+    }
+  }
+
+  // :657-668 remove features already used
+  std::vector<std::shared_ptr<ov_core::Feature>> feature_vec_tmp;
+  for (auto const &feature : feature_vec)
+    if (features_used_already.find(feature->featid) == features_used_already.end()) feature_vec_tmp.push_back(feature);
+  feature_vec = feature_vec_tmp;
+  if (feature_vec.empty()) return;
+
+  // ---- point loop, gate, compression, update (:671-814) ----
+  if (!features_used_already.empty()) pack_tables();  // the plane loop moved the linearisation points
+  upload_batch(feature_vec);
+  const int n = ovp_cov_size(state->_gpu);
+  std::vector<double> dx(n, 0.0);
+  std::vector<uint8_t> ok(feature_vec.size(), 0);
+  ovp_update_info info;
+  int rc = ovp_msckf_update(state->_gpu, &o, dx.data(), ok.data(), nullptr, &info);
+  if (rc == OVP_E_NEGDIAG) {
+    PRINT_ERROR("StateHelper::EKFUpdate() - negative covariance diagonal\n");
+    std::exit(EXIT_FAILURE);
+  }
+  gpu_check(rc, "ovp_msckf_update");
+  // :755-757 rejected features are flagged and erased, :791-793 the rest is flagged as used
+  std::vector<std::shared_ptr<ov_core::Feature>> kept;
+  for (size_t f = 0; f < feature_vec.size(); ++f) {
+    feature_vec[f]->to_delete = true;
+    if (ok[f]) kept.push_back(feature_vec[f]);
+  }
+  feature_vec = kept;
+  if (info.n_accepted > 0) StateHelper::apply_correction(state, dx.data());
+}
+
+}  // namespace ov_plane

@@ -1,0 +1,114 @@
+// Host side of the drop-in: ov_plane's State / StateHelper / UpdaterMSCKF surface (same names, argument meaning and
+// error behaviour as the reference) implemented on top of the C-ABI of libovplane_hip.so.  The covariance
+// State::_Cov lives on the GPU; everything that is host scalar code in the reference (id bookkeeping, Type::update,
+// feature vector side effects) stays here.  Citations relative to /root/reference/ov_plane/src/.
+#pragma once
+#include <cmath>
+#include <map>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+#include "ov_types.h"
+#include "ovplane_hip.h"
+
+namespace ov_plane {
+
+// state/StateOptions.h:41-153 (fields read on this path)
+struct StateOptions {
+  bool do_fej = true;
+  bool do_calib_camera_pose = false;
+  bool do_calib_camera_intrinsics = false;
+  bool do_calib_camera_timeoffset = false;
+  int max_clone_size = 11;
+  int num_cameras = 1;
+  bool use_plane_constraint = false;
+  bool use_plane_constraint_msckf = false;
+  double sigma_constraint = 0.01;
+  // capacity of the device context (not in the reference: Eigen resizes dynamically)
+  int max_state_size = 320;
+  int max_features = 8192;
+};
+
+// update/UpdaterOptions.h:37-53
+struct UpdaterOptions {
+  double chi2_multipler = 5;
+  double sigma_pix = 1;
+  double sigma_pix_sq = 1;
+};
+
+class StateHelper;
+
+// state/State.h:48-135
+class State {
+public:
+  explicit State(StateOptions &options_);
+  ~State();
+  double margtimestep() {
+    double time = INFINITY;
+    for (const auto &clone_imu : _clones_IMU)
+      if (clone_imu.first < time) time = clone_imu.first;
+    return time;
+  }
+  int max_covariance_size() { return ovp_cov_size(_gpu); }
+
+  double _timestamp = -1;
+  StateOptions _options;
+  std::shared_ptr<ov_type::IMU> _imu;
+  std::map<double, std::shared_ptr<ov_type::PoseJPL>> _clones_IMU;
+  std::shared_ptr<ov_type::Vec> _calib_dt_CAMtoIMU;
+  std::unordered_map<size_t, std::shared_ptr<ov_type::PoseJPL>> _calib_IMUtoCAM;
+  std::unordered_map<size_t, std::shared_ptr<ov_type::Vec>> _cam_intrinsics;
+  std::unordered_map<size_t, std::shared_ptr<ov_type::Vec>> _features_PLANE;
+  // out-of-state plane estimates the caller obtained upstream (PlaneFitting, out of scope here; UpdaterMSCKF.cpp:319-400)
+  std::map<size_t, std::vector<double>> _plane_estimates_cp_inG;
+
+private:
+  friend class StateHelper;
+  friend class UpdaterMSCKF;
+  ovp_ctx *_gpu = nullptr;  // replaces Eigen::MatrixXd _Cov (state/State.h:130)
+  std::vector<std::shared_ptr<ov_type::Type>> _variables;
+};
+
+// state/StateHelper.h:82-243 (subset on the path)
+class StateHelper {
+public:
+  static void EKFPropagation(std::shared_ptr<State> state, const std::vector<std::shared_ptr<ov_type::Type>> &order_NEW,
+                             const std::vector<std::shared_ptr<ov_type::Type>> &order_OLD, const MatrixXd &Phi,
+                             const MatrixXd &Q);
+  static void EKFUpdate(std::shared_ptr<State> state, const std::vector<std::shared_ptr<ov_type::Type>> &H_order,
+                        const MatrixXd &H, const VectorXd &res, const MatrixXd &R);
+  static void set_initial_covariance(std::shared_ptr<State> state, const MatrixXd &covariance,
+                                     const std::vector<std::shared_ptr<ov_type::Type>> &order);
+  static MatrixXd get_marginal_covariance(std::shared_ptr<State> state,
+                                          const std::vector<std::shared_ptr<ov_type::Type>> &small_variables);
+  static MatrixXd get_full_covariance(std::shared_ptr<State> state);
+  static void marginalize(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> marg);
+  static std::shared_ptr<ov_type::Type> clone(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> variable_to_clone);
+  static void augment_clone(std::shared_ptr<State> state, const double last_w[3]);
+  static void marginalize_old_clone(std::shared_ptr<State> state);
+  // applies a correction to every active variable (the tail of EKFUpdate, state/StateHelper.cpp:190-193)
+  static void apply_correction(std::shared_ptr<State> state, const double *dx);
+
+private:
+  StateHelper() {}
+};
+
+// update/UpdaterMSCKF.h:49-91
+class UpdaterMSCKF {
+public:
+  UpdaterMSCKF(UpdaterOptions &options, ov_core::FeatureInitializerOptions &feat_init_options);
+  // Same contract as the reference for everything downstream of triangulation (update/UpdaterMSCKF.cpp:407-828):
+  // plane loop first (planes in state / estimates in state->_plane_estimates_cp_inG), then the point loop, chi2 gate,
+  // compression and EKF update.  feature_vec: rejected features are erased and every processed feature gets
+  // to_delete = true; features consumed by an accepted plane are appended to feature_vec_used.
+  // Features must already carry p_FinG (triangulation / plane refinement are upstream and out of scope).
+  void update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+              std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_extra,
+              std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane);
+
+protected:
+  UpdaterOptions _options;
+};
+
+}  // namespace ov_plane

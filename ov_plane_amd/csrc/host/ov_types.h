@@ -1,0 +1,297 @@
+// Minimal restatement of the open_vins ov_type classes the update path touches (ext ov_core/src/types/, not vendored
+// in the reference tree; semantics per SURVEY.md Appendix A): Type, Vec, JPLQuat, PoseJPL, IMU, Landmark.
+// Dense storage is ov_plane::DenseMatrix (same data()/rows()/cols()/operator() surface as Eigen::MatrixXd, which is
+// not installed here): switching the typedefs below to Eigen's types is the only change a build with Eigen needs.
+#pragma once
+#include <cassert>
+#include <cmath>
+#include <cstddef>
+#include <memory>
+#include <vector>
+
+namespace ov_plane {
+
+class DenseMatrix {  // column-major, like Eigen::MatrixXd
+public:
+  DenseMatrix() : r_(0), c_(0) {}
+  DenseMatrix(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
+  static DenseMatrix Zero(int r, int c) { return DenseMatrix(r, c); }
+  static DenseMatrix Identity(int r, int c) {
+    DenseMatrix m(r, c);
+    for (int i = 0; i < (r < c ? r : c); ++i) m(i, i) = 1.0;
+    return m;
+  }
+  int rows() const { return r_; }
+  int cols() const { return c_; }
+  double *data() { return d_.data(); }
+  const double *data() const { return d_.data(); }
+  double &operator()(int i, int j) { return d_[(size_t)j * r_ + i]; }
+  double operator()(int i, int j) const { return d_[(size_t)j * r_ + i]; }
+  double &operator()(int i) { return d_[i]; }
+  double operator()(int i) const { return d_[i]; }
+  void resize(int r, int c) {
+    r_ = r;
+    c_ = c;
+    d_.assign((size_t)r * c, 0.0);
+  }
+  DenseMatrix block(int i0, int j0, int nr, int nc) const {
+    DenseMatrix b(nr, nc);
+    for (int j = 0; j < nc; ++j)
+      for (int i = 0; i < nr; ++i) b(i, j) = (*this)(i0 + i, j0 + j);
+    return b;
+  }
+
+private:
+  int r_, c_;
+  std::vector<double> d_;
+};
+typedef DenseMatrix MatrixXd;
+typedef DenseMatrix VectorXd;  // n x 1
+
+}  // namespace ov_plane
+
+namespace ov_type {
+using ov_plane::MatrixXd;
+using ov_plane::VectorXd;
+
+// ---- ext quat_ops.h (JPL) ----
+inline void quat_2_Rot(const double q[4], double R[9]) {  // row-major
+  const double x = q[0], y = q[1], z = q[2], w = q[3], a = 2.0 * w * w - 1.0;
+  R[0] = a + 2 * x * x;
+  R[1] = 2 * w * z + 2 * x * y;
+  R[2] = -2 * w * y + 2 * x * z;
+  R[3] = -2 * w * z + 2 * y * x;
+  R[4] = a + 2 * y * y;
+  R[5] = 2 * w * x + 2 * y * z;
+  R[6] = 2 * w * y + 2 * z * x;
+  R[7] = -2 * w * x + 2 * z * y;
+  R[8] = a + 2 * z * z;
+}
+inline void quat_multiply(const double q[4], const double p[4], double o[4]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  double r[4] = {w * p[0] + z * p[1] - y * p[2] + x * p[3], -z * p[0] + w * p[1] + x * p[2] + y * p[3],
+                 y * p[0] - x * p[1] + w * p[2] + z * p[3], -x * p[0] - y * p[1] - z * p[2] + w * p[3]};
+  if (r[3] < 0)
+    for (double &v : r) v = -v;
+  const double n = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+  for (int k = 0; k < 4; ++k) o[k] = r[k] / n;
+}
+
+class Type {
+public:
+  explicit Type(int size) : _size(size) {}
+  virtual ~Type() {}
+  virtual void set_local_id(int new_id) { _id = new_id; }
+  int id() const { return _id; }
+  int size() const { return _size; }
+  virtual void update(const VectorXd &dx) = 0;
+  virtual const VectorXd &value() const { return _value; }
+  virtual const VectorXd &fej() const { return _fej; }
+  virtual void set_value(const VectorXd &v) { _value = v; }
+  virtual void set_fej(const VectorXd &v) { _fej = v; }
+  virtual std::shared_ptr<Type> clone() = 0;
+  virtual std::shared_ptr<Type> check_if_subvariable(const std::shared_ptr<Type> check) { return nullptr; }
+
+protected:
+  VectorXd _fej, _value;
+  int _id = -1;
+  int _size = -1;
+};
+
+class Vec : public Type {
+public:
+  explicit Vec(int dim) : Type(dim) {
+    _value = VectorXd::Zero(dim, 1);
+    _fej = VectorXd::Zero(dim, 1);
+  }
+  void update(const VectorXd &dx) override {
+    assert(dx.rows() == _size);
+    for (int i = 0; i < _size; ++i) _value(i) += dx(i);
+  }
+  std::shared_ptr<Type> clone() override {
+    auto c = std::make_shared<Vec>(_size);
+    c->set_value(value());
+    c->set_fej(fej());
+    return c;
+  }
+};
+
+class JPLQuat : public Type {
+public:
+  JPLQuat() : Type(3) {
+    VectorXd q0 = VectorXd::Zero(4, 1);
+    q0(3) = 1.0;
+    set_value(q0);
+    set_fej(q0);
+  }
+  void update(const VectorXd &dx) override {  // dq = quatnorm([dth/2, 1]); q <- dq (x) q
+    double dq[4] = {0.5 * dx(0), 0.5 * dx(1), 0.5 * dx(2), 1.0};
+    const double n = std::sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+    for (double &v : dq) v /= n;
+    double o[4];
+    quat_multiply(dq, _value.data(), o);
+    VectorXd nv(4, 1);
+    for (int k = 0; k < 4; ++k) nv(k) = o[k];
+    set_value(nv);
+  }
+  void set_value(const VectorXd &v) override {
+    _value = v;
+    quat_2_Rot(_value.data(), _R);
+  }
+  void set_fej(const VectorXd &v) override {
+    _fej = v;
+    quat_2_Rot(_fej.data(), _Rfej);
+  }
+  const double *Rot() const { return _R; }        // row-major 3x3
+  const double *Rot_fej() const { return _Rfej; }
+  std::shared_ptr<Type> clone() override {
+    auto c = std::make_shared<JPLQuat>();
+    c->set_value(value());
+    c->set_fej(fej());
+    return c;
+  }
+
+protected:
+  double _R[9], _Rfej[9];
+};
+
+class PoseJPL : public Type {
+public:
+  PoseJPL() : Type(6) {
+    _q = std::make_shared<JPLQuat>();
+    _p = std::make_shared<Vec>(3);
+    _value = VectorXd::Zero(7, 1);
+    _value(3) = 1.0;
+    _fej = _value;
+  }
+  void set_local_id(int new_id) override {
+    _id = new_id;
+    _q->set_local_id(new_id);
+    _p->set_local_id(new_id + (new_id != -1 ? 3 : 0));
+  }
+  void update(const VectorXd &dx) override {
+    VectorXd a(3, 1), b(3, 1);
+    for (int k = 0; k < 3; ++k) {
+      a(k) = dx(k);
+      b(k) = dx(3 + k);
+    }
+    _q->update(a);
+    _p->update(b);
+    sync_value();
+  }
+  void set_value(const VectorXd &v) override {
+    VectorXd q(4, 1), p(3, 1);
+    for (int k = 0; k < 4; ++k) q(k) = v(k);
+    for (int k = 0; k < 3; ++k) p(k) = v(4 + k);
+    _q->set_value(q);
+    _p->set_value(p);
+    _value = v;
+  }
+  void set_fej(const VectorXd &v) override {
+    VectorXd q(4, 1), p(3, 1);
+    for (int k = 0; k < 4; ++k) q(k) = v(k);
+    for (int k = 0; k < 3; ++k) p(k) = v(4 + k);
+    _q->set_fej(q);
+    _p->set_fej(p);
+    _fej = v;
+  }
+  const double *Rot() const { return _q->Rot(); }
+  const double *Rot_fej() const { return _q->Rot_fej(); }
+  const double *pos() const { return _p->value().data(); }
+  const double *pos_fej() const { return _p->fej().data(); }
+  const double *quat() const { return _q->value().data(); }
+  const double *quat_fej() const { return _q->fej().data(); }
+  std::shared_ptr<JPLQuat> q() { return _q; }
+  std::shared_ptr<Vec> p() { return _p; }
+  std::shared_ptr<Type> clone() override {
+    auto c = std::make_shared<PoseJPL>();
+    c->set_value(value());
+    c->set_fej(fej());
+    return c;
+  }
+  std::shared_ptr<Type> check_if_subvariable(const std::shared_ptr<Type> check) override {
+    if (check == _q) return _q;
+    if (check == _p) return _p;
+    return nullptr;
+  }
+
+protected:
+  void sync_value() {
+    for (int k = 0; k < 4; ++k) _value(k) = _q->value()(k);
+    for (int k = 0; k < 3; ++k) _value(4 + k) = _p->value()(k);
+  }
+  std::shared_ptr<JPLQuat> _q;
+  std::shared_ptr<Vec> _p;
+};
+
+class IMU : public Type {  // [q p v bg ba], error state 15
+public:
+  IMU() : Type(15) {
+    _pose = std::make_shared<PoseJPL>();
+    _v = std::make_shared<Vec>(3);
+    _bg = std::make_shared<Vec>(3);
+    _ba = std::make_shared<Vec>(3);
+    _value = VectorXd::Zero(16, 1);
+    _value(3) = 1.0;
+    _fej = _value;
+  }
+  void set_local_id(int new_id) override {
+    _id = new_id;
+    _pose->set_local_id(new_id);
+    _v->set_local_id(_pose->id() + (new_id != -1 ? _pose->size() : 0));
+    _bg->set_local_id(_v->id() + (new_id != -1 ? _v->size() : 0));
+    _ba->set_local_id(_bg->id() + (new_id != -1 ? _bg->size() : 0));
+  }
+  void update(const VectorXd &dx) override {
+    VectorXd a(6, 1), b(3, 1), c(3, 1), d(3, 1);
+    for (int k = 0; k < 6; ++k) a(k) = dx(k);
+    for (int k = 0; k < 3; ++k) {
+      b(k) = dx(6 + k);
+      c(k) = dx(9 + k);
+      d(k) = dx(12 + k);
+    }
+    _pose->update(a);
+    _v->update(b);
+    _bg->update(c);
+    _ba->update(d);
+  }
+  std::shared_ptr<PoseJPL> pose() { return _pose; }
+  std::shared_ptr<JPLQuat> q() { return _pose->q(); }
+  std::shared_ptr<Vec> p() { return _pose->p(); }
+  std::shared_ptr<Vec> v() { return _v; }
+  std::shared_ptr<Vec> bg() { return _bg; }
+  std::shared_ptr<Vec> ba() { return _ba; }
+  const double *vel() const { return _v->value().data(); }
+  std::shared_ptr<Type> clone() override {
+    auto c = std::make_shared<IMU>();
+    c->pose()->set_value(_pose->value());
+    c->pose()->set_fej(_pose->fej());
+    return c;
+  }
+  std::shared_ptr<Type> check_if_subvariable(const std::shared_ptr<Type> check) override {
+    if (check == _pose) return _pose;
+    if (check == _pose->check_if_subvariable(check)) return _pose->check_if_subvariable(check);
+    if (check == _v) return _v;
+    if (check == _bg) return _bg;
+    if (check == _ba) return _ba;
+    return nullptr;
+  }
+
+protected:
+  std::shared_ptr<PoseJPL> _pose;
+  std::shared_ptr<Vec> _v, _bg, _ba;
+};
+
+}  // namespace ov_type
+
+namespace ov_core {
+// subset of ext ov_core::Feature used by the updaters (mono: camera id 0)
+struct Feature {
+  size_t featid = 0;
+  bool to_delete = false;
+  std::vector<float> uvs;          // [2*k] raw pixels of camera 0 (reference: unordered_map<cam, vector<VectorXf>>)
+  std::vector<double> timestamps;  // [k] clone timestamps of camera 0
+  double p_FinG[3] = {0, 0, 0};
+};
+struct FeatureInitializerOptions {};
+}  // namespace ov_core

@@ -233,6 +233,23 @@ __global__ void k_prop_write(double* __restrict__ P, int ldp, int n, int start, 
   if (!inblk) P[(size_t)(start + j) * ldp + r] = v;
   if (inblk && (r - start) == j && v < 0.0) *negdiag = 1;
 }
+// StateHelper::augment_clone time-offset Jacobian, step 1 (columns) and step 2 (rows, reads the updated row dt)
+__global__ void k_augment_dt_cols(double* __restrict__ P, int ldp, int n, int pose, int dt, double d0, double d1, double d2,
+                                  double d3, double d4, double d5) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const double v = P[(size_t)r * ldp + dt];
+  const double d[6] = {d0, d1, d2, d3, d4, d5};
+  for (int k = 0; k < 6; ++k) P[(size_t)r * ldp + pose + k] += v * d[k];
+}
+__global__ void k_augment_dt_rows(double* __restrict__ P, int ldp, int n, int pose, int dt, double d0, double d1, double d2,
+                                  double d3, double d4, double d5) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const double v = P[(size_t)dt * ldp + c];
+  const double d[6] = {d0, d1, d2, d3, d4, d5};
+  for (int k = 0; k < 6; ++k) P[(size_t)(pose + k) * ldp + c] += d[k] * v;
+}
 __global__ void k_check_negdiag(const double* __restrict__ P, int ldp, int n, int* __restrict__ negdiag) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n && P[(size_t)r * ldp + r] < 0.0) *negdiag = 1;
@@ -301,6 +318,14 @@ hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, in
   if (n_new <= 0) return hipSuccess;
   hipLaunchKernelGGL(ovp::k_cov_marginalize, dim3((n_new + 127) / 128, n_new), dim3(128), 0, stream, src, dst, ld,
                      n_old, id, sz);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_augment_dt(double* P, int ldp, int n, int pose, int dt, const double* d, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_augment_dt_cols, dim3((n + 127) / 128), dim3(128), 0, stream, P, ldp, n, pose, dt, d[0], d[1], d[2],
+                     d[3], d[4], d[5]);
+  hipLaunchKernelGGL(ovp::k_augment_dt_rows, dim3((n + 127) / 128), dim3(128), 0, stream, P, ldp, n, pose, dt, d[0], d[1], d[2],
+                     d[3], d[4], d[5]);
   return hipGetLastError();
 }
 

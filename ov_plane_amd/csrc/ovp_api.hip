@@ -22,6 +22,7 @@ hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, in
 hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, const int* oldcol, int nold,
                                 const double* Phi, const double* Q, double* CPT, double* PCP, int* negdiag,
                                 hipStream_t stream);
+hipError_t ovp_launch_augment_dt(double* P, int ldp, int n, int pose, int dt, const double* d, hipStream_t stream);
 hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
                                hipStream_t stream);
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
@@ -928,6 +929,14 @@ extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
   c->P = c->P_tmp;
   c->P_tmp = t;
   c->n -= size;
+  return 0;
+}
+
+extern "C" int ovp_cov_augment_dt(ovp_ctx* c, int pose_id, int dt_id, const double dnc_dt[6]) {
+  if (!c || !dnc_dt) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  if (pose_id < 0 || pose_id + 6 > c->n || dt_id < 0 || dt_id >= c->n) return OVP_E_ARG;
+  HIPCHK(ovp_launch_augment_dt(c->P, c->ld, c->n, pose_id, dt_id, dnc_dt, c->stream));
   return 0;
 }
 

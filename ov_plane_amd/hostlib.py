@@ -1,0 +1,60 @@
+"""ctypes access to libovplane_host.so: the C++ host mirror of ov_plane's State / StateHelper / UpdaterMSCKF
+(ov_plane_amd/csrc/host/).  Only a harness symbol is exported; the classes themselves are C++."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovplane_host.so")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libovplane_host.so is not built (run __graft_entry__.build())")
+        C.CDLL(os.path.join(_HERE, "libovplane_hip.so"), mode=C.RTLD_GLOBAL)
+        _LIB = C.CDLL(LIB_PATH)
+    return _LIB
+
+
+def run_msckf_update(sc):
+    """Drives ov_plane::UpdaterMSCKF::update (C++ host classes over the C-ABI) on a synth.Scene."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    in_state = np.where(sc.plane_in_state)[0]
+    out_state = np.where(~sc.plane_in_state)[0]
+    ids_in = np.ascontiguousarray(in_state + 1, dtype=np.uint64)
+    ids_out = np.ascontiguousarray(out_state + 1, dtype=np.uint64)
+    cp_in, cpf_in, cp_out = f64(sc.cp[in_state]), f64(sc.cp_fej[in_state]), f64(sc.cp[out_state])
+    N, F, M = int(sc.N), int(sc.F), int(sc.uv.shape[1])
+    P = np.asfortranarray(sc.P)
+    uv = np.ascontiguousarray(sc.uv, dtype=np.float32)
+    cidx = np.ascontiguousarray(sc.clone_idx, dtype=np.int32)
+    nm = np.ascontiguousarray(sc.n_meas, dtype=np.int32)
+    pf = f64(sc.p_FinG)
+    pof = np.ascontiguousarray(sc.plane_id, dtype=np.int32)
+    o = sc.opts
+    out = dict(clone_q=np.zeros((sc.C, 4)), clone_p=np.zeros((sc.C, 3)), calib_q=np.zeros(4), calib_p=np.zeros(3),
+               intr=np.zeros(8), cp_state=np.zeros((max(len(in_state), 1), 3)), P=np.zeros((N, N)),
+               kept=np.zeros(F, dtype=np.uint8), used=np.zeros(F, dtype=np.uint8), deleted=np.zeros(F, dtype=np.uint8))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    cq, cp_, cqf, cpf = f64(sc.clone_q), f64(sc.clone_p), f64(sc.clone_q_fej), f64(sc.clone_p_fej)
+    calq, calp, intr = f64(sc.calib_q), f64(sc.calib_p), f64(sc.intr)
+    L.ovph_run_msckf_update.restype = C.c_int
+    rc = L.ovph_run_msckf_update(
+        C.c_int(sc.C), p(cq), p(cp_), p(cqf), p(cpf), p(calq), p(calp), p(intr), C.c_int(len(in_state)), p(cp_in), p(cpf_in),
+        p(ids_in), C.c_int(len(out_state)), p(cp_out), p(ids_out), C.c_int(N), p(P), C.c_int(F), C.c_int(M), p(uv), p(cidx),
+        p(nm), p(pf), p(pof), C.c_double(o["sigma_px"]), C.c_double(o["chi2_mult"]), C.c_double(o["sigma_c"]),
+        C.c_int(int(o["do_fej"])), p(out["clone_q"]), p(out["clone_p"]), p(out["calib_q"]), p(out["calib_p"]), p(out["intr"]),
+        p(out["cp_state"]), p(out["P"]), p(out["kept"]), p(out["used"]), p(out["deleted"]))
+    if rc != 0:
+        raise RuntimeError("ovph_run_msckf_update failed with %d" % rc)
+    out["cp_state"] = out["cp_state"][: len(in_state)]
+    for k in ("kept", "used", "deleted"):
+        out[k] = out[k].astype(bool)
+    return out

@@ -263,3 +263,63 @@ def test_plane_loop_matches_oracle(hiplib, oracle, kw):
     ratio = out["chi2"][sel] / ref["plane_chi2"][sel]
     assert np.all(ratio > 0.5) and np.all(ratio < 2.0), ratio
     ctx.close()
+
+
+def _oracle_full_update(oracle, sc):
+    """Reference flow of UpdaterMSCKF::update downstream of triangulation: plane loop, then the point loop on the
+    features the planes did not consume, at the state/covariance the plane loop left behind."""
+    from ov_plane_amd.synth import Scene
+
+    if sc.cp.shape[0] > 0:
+        pl = oracle.msckf_plane_update(sc)
+    else:
+        pl = dict(P=sc.P, clone_q=sc.clone_q, clone_p=sc.clone_p, calib_q=sc.calib_q, calib_p=sc.calib_p, intr=sc.intr,
+                  cp=sc.cp, used=np.zeros(sc.F, dtype=bool))
+    sc2 = Scene(sc)
+    for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
+        sc2[k] = pl[k]
+    rest = np.where(~pl["used"])[0]
+    pt = oracle.msckf_point_update(sc2, feats=rest)
+    from ov_plane_amd.synth import quat_boxplus
+
+    dx = pt["dx"]
+    cq, cpos = pl["clone_q"].copy(), pl["clone_p"].copy()
+    for i in range(sc.C):
+        cid = sc.ids["clones"][i]
+        cq[i] = quat_boxplus(cq[i], dx[cid:cid + 3])
+        cpos[i] = cpos[i] + dx[cid + 3:cid + 6]
+    cp = pl["cp"].copy()
+    for k in range(cp.shape[0]):
+        sid = sc.plane_state_id[k]
+        if sid >= 0:
+            cp[k] = cp[k] + dx[sid:sid + 3]
+    kept = np.zeros(sc.F, dtype=bool)
+    kept[rest[pt["accepted"]]] = True
+    return dict(P=pt["P"], clone_q=cq, clone_p=cpos, calib_q=quat_boxplus(pl["calib_q"], dx[16:19]),
+                calib_p=pl["calib_p"] + dx[19:22], intr=pl["intr"] + dx[22:30], cp=cp, used=pl["used"], kept=kept)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(C=11, F=120, seed=71, chi2_mult=1.0),                                           # points only
+    dict(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0),         # planes + points
+    dict(C=8, F=90, seed=73, n_planes=3, feats_per_plane=15, chi2_mult=99999.0, ragged=True),
+])
+def test_host_cpp_mirror_updater_msckf(hiplib, oracle, kw):
+    """ov_plane::UpdaterMSCKF::update / StateHelper (C++ host classes, ov_plane_amd/csrc/host) over the C-ABI vs the oracle,
+    including the feature-vector side effects (erase rejected, to_delete, feature_vec_used)."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_scene(**kw)
+    ref = _oracle_full_update(oracle, sc)
+    out = hostlib.run_msckf_update(sc)
+    assert (out["used"] == ref["used"]).all()
+    assert (out["kept"] == ref["kept"]).all()
+    assert out["deleted"].all()  # every processed feature is flagged (UpdaterMSCKF.cpp:641,756,791-793)
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(out["calib_p"] - ref["calib_p"]).max() < TOL_DX and np.abs(out["intr"] - ref["intr"]).max() < TOL_DX
+    if sc.plane_in_state.any():
+        assert np.abs(out["cp_state"] - ref["cp"][sc.plane_in_state]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
