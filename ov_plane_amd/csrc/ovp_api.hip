@@ -12,6 +12,7 @@
 
 #include "ovp_kernels.h"
 
+extern "C" int ovp_dbg_tilechol_skip;
 extern "C" {
 hipError_t ovp_launch_scatter_gram(const double* Acc, const double* bcc, int cols, const int* col_ids, double* Ab,
                                    int lda, int n, hipStream_t stream);
@@ -956,6 +957,25 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
   else if (!strcmp(name, "G")) { src = c->G; bytes = (size_t)3 * c->n_feats * c->ldg * sizeof(double); }
   else if (!strcmp(name, "rec")) { src = c->rec; bytes = (size_t)c->fp.n_clones * c->n_feats * 2 * 21 * sizeof(double); }
   else if (!strcmp(name, "chi2")) { src = c->chi2; bytes = (size_t)c->n_feats * sizeof(double); }
+  else if (!strncmp(name, "bench_chol", 10)) {
+    // diagnostics: average time of k_tilechol on the resident covariance; name = "bench_chol<skipmask>"
+    ovp_dbg_tilechol_skip = atoi(name + 10);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) ovp_launch_tilechol(c->P, c->L, c->Dinv, c->n, c->ld, c->flags + 3, 0, c->stream);
+    hipEventRecord(e0, c->stream);
+    for (int i = 0; i < 20; ++i) ovp_launch_tilechol(c->P, c->L, c->Dinv, c->n, c->ld, c->flags + 3, 0, c->stream);
+    hipEventRecord(e1, c->stream);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    ovp_dbg_tilechol_skip = 0;
+    *(double*)host = ms / 20.0;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 8;
+  }
   else if (!strcmp(name, "cycles_on")) {
     if (!c->dbg_cycles && hipMalloc((void**)&c->dbg_cycles, (size_t)c->f_max * 8 * sizeof(long long)) != hipSuccess) return OVP_E_STATE;
     return 0;

@@ -59,6 +59,16 @@ __device__ __forceinline__ int reduce_owner_lane(int k) {
   return k * (64 / N);
 }
 
+// broadcast of lane N of every 16-lane DPP row to all lanes of that row (row_share:N, gfx90a+): the value stays in
+// VGPRs, so unlike v_readlane there is no VALU -> SGPR -> VALU round trip on the dependent chain.
+template <int N>
+__device__ __forceinline__ double row_share_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + N, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + N, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += shfl_xor_f64(v, s);

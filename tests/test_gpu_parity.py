@@ -323,3 +323,48 @@ def test_host_cpp_mirror_updater_msckf(hiplib, oracle, kw):
     if sc.plane_in_state.any():
         assert np.abs(out["cp_state"] - ref["cp"][sc.plane_in_state]).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
+
+
+def test_rccl_allreduce_path_single_rank(hiplib, oracle):
+    """The sharded-update plumbing (zero-copy __cuda_array_interface__ view of the library's [A|b] buffer + RCCL
+    all_reduce on the context's stream) with a 1-rank nccl group: results must equal the plain update."""
+    import torch
+    import torch.distributed as dist
+
+    from ov_plane_amd.dist import sharded_update, shard_bounds
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
+    try:
+        sc = make_scene(C=9, F=64, seed=81, chi2_mult=1.0)
+        ref = oracle.msckf_point_update(sc)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ctx = hiplib.Context(sc.N, sc.C, sc.F, stream=stream.cuda_stream)
+            ctx.cov_upload(sc.P)
+            ctx.state_upload(sc)
+            lo, hi = shard_bounds(sc.F, 0, 1)
+            ctx.batch_upload_scene(sc, np.arange(lo, hi))
+            o = hiplib.opts_from_scene(sc)
+            # force the collective even though world_size == 1
+            ctx.build_gate_gram_async(o)
+            from ov_plane_amd.dist import DeviceBufferView
+
+            ptr, rows, ld = ctx.gram_buffer()
+            t = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
+            before = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            assert torch.equal(before, t)  # 1 rank: identity, and proves the view aliases the library buffer
+            ctx.ekf_update_from_gram_async()
+            out = ctx.fetch_results()
+            P = ctx.cov_download()
+        assert (out["accepted"] == ref["accepted"]).all()
+        assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX and relP(P, ref["P"]) < TOL_P
+        # and the packaged helper
+        with torch.cuda.stream(stream):
+            ctx.cov_upload(sc.P)
+            out2 = sharded_update(ctx, o)
+        assert np.abs(out2["dx"] - out["dx"]).max() == 0.0
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
