@@ -18,7 +18,11 @@
 namespace ovp {
 
 static constexpr int NR = 64;               // rows handled by one wave (2 * OVP_MAX_MEAS)
-static constexpr int TRI = NR * (NR + 1) / 2;
+static constexpr int LCOLS = 2112;           // packed column-major lower triangle with even row starts
+__device__ __forceinline__ int coff(int k) {  // offset of column k; element (i,k) lives at coff(k) + i - (k & ~1)
+  const int pr = k >> 1;
+  return 130 * pr - 2 * pr * pr + (k & 1) * (64 - 2 * pr);
+}
 
 // compile-time loop: guarantees that register arrays are only ever indexed by constants
 template <int... Is, class F>
@@ -39,7 +43,11 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
-__global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// one wave per block; LDS (38 KB) limits residency to 4 blocks per CU = 1 wave per SIMD, so let the allocator use the
+// whole register file instead of serialising loads through a single temporary
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_feat_gate(const FeatParams p) {
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
   const int m = p.n_meas[f];
@@ -48,9 +56,12 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
   __shared__ __attribute__((aligned(16))) double sJ[NR * 6];
   __shared__ __attribute__((aligned(16))) double sC[NR * 14];
   __shared__ __attribute__((aligned(16))) double sE[NR * 14];
-  __shared__ __attribute__((aligned(16))) double sB[TRI + 256];
+  // B = H_x P H_x^T + I, then its Cholesky factor, column-major: column k holds rows (k & ~1) .. 63 (even start keeps
+  // the 16-byte alignment of the broadcast reads), 2112 doubles; + 64 x 4 solved right-hand sides; + 256 scratch
+  __shared__ __attribute__((aligned(16))) double sL[LCOLS];
+  __shared__ __attribute__((aligned(16))) double sY[NR * 4];
+  __shared__ __attribute__((aligned(16))) double sB[256];
 
-  double* sB2 = sB + 256;  // packed lower triangle of B (the first 256 doubles are scratch: P_cc, column buffers)
   const int a = lane >> 1, r = lane & 1;
   long long tstamp[8];
   tstamp[0] = __builtin_readcyclecounter();
@@ -85,16 +96,29 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
         const bool on = ((p.calmask >> kk) & 1) && ((p.calmask >> k) & 1);
         sPcc[idx] = on ? P[(size_t)p.calcol[kk] * ldp + p.calcol[k]] : 0.0;
       }
+      // e = j P[clone(a), cal]: the two lanes of an observation need the same 14 x 6 block of P; each loads half
+      // (7 calibration rows) and the halves are exchanged with a DPP pair swap
       double e[14];
+      {
+        double mine[42];
 #pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        e[k] = 0.0;
-        if ((p.calmask >> k) & 1) {
-          const double* prow = P + (size_t)p.calcol[k] * ldp;
-          double s = 0.0;
+        for (int kk = 0; kk < 7; ++kk) {
+          const int crow_id = r ? p.calcol[kk + 7] : p.calcol[kk];
+          const double* prow = P + (size_t)crow_id * ldp + ida;
 #pragma unroll
-          for (int l = 0; l < 6; ++l) s = fma(jrow[l], prow[ida + l], s);
-          e[k] = s;
+          for (int l = 0; l < 6; ++l) mine[6 * kk + l] = prow[l];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+          double ea = 0.0, eb = 0.0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) {
+            const double other = swap_pair_f64(mine[6 * kk + l]);
+            ea = fma(jrow[l], mine[6 * kk + l], ea);
+            eb = fma(jrow[l], other, eb);
+          }
+          e[kk] = r ? eb : ea;
+          e[kk + 7] = r ? ea : eb;
         }
       }
       __syncthreads();
@@ -120,44 +144,63 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
     // Phase B: row `lane` of B = H_x P H_x^T + I, lower triangle, packed in LDS
     // ----------------------------------------------------------------------------------------
     {
-      double pn[36];  // P[clone(b)+k][clone(a)+l] for the next b
+      // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads rows 3r..3r+2
+      double pn[18];
       {
-        const int idb0 = p.clone_id[cidx[0]];
+        const int idb0 = __builtin_amdgcn_readlane(ida, 0);  // lane 2b already holds clone_id of observation b
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb0 + k) * ldp + ida + l];
+          for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb0 + 3 * r + k) * ldp + ida + l];
       }
       for (int b = 0; b < m; ++b) {
-        double pc[36];
+        double pc[18];
 #pragma unroll
-        for (int q = 0; q < 36; ++q) pc[q] = pn[q];
+        for (int q = 0; q < 18; ++q) pc[q] = pn[q];
         if (b + 1 < m) {
-          const int idb1 = p.clone_id[cidx[b + 1]];
+          const int idb1 = __builtin_amdgcn_readlane(ida, 2 * (b + 1));  // no dependent global loads in the loop
 #pragma unroll
-          for (int k = 0; k < 6; ++k)
+          for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb1 + k) * ldp + ida + l];
+            for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb1 + 3 * r + k) * ldp + ida + l];
         }
         double t[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          double sacc = 0.0;
+        for (int k = 0; k < 3; ++k) {
+          double ta = 0.0, tb = 0.0;
 #pragma unroll
-          for (int l = 0; l < 6; ++l) sacc = fma(jrow[l], pc[6 * k + l], sacc);
-          t[k] = sacc;
+          for (int l = 0; l < 6; ++l) {
+            const double other = swap_pair_f64(pc[6 * k + l]);
+            ta = fma(jrow[l], pc[6 * k + l], ta);
+            tb = fma(jrow[l], other, tb);
+          }
+          t[k] = r ? tb : ta;
+          t[k + 3] = r ? ta : tb;
+        }
+        // rows 2b, 2b+1 of [J | C | E] (wave-uniform addresses: LDS broadcasts), fetched as 16-byte vectors up front
+        double2_t vj[6], vc[14], ve[14];
+        {
+          const double2_t* pj = reinterpret_cast<const double2_t*>(sJ + 12 * b);
+          const double2_t* pcv = reinterpret_cast<const double2_t*>(sC + 28 * b);
+          const double2_t* pev = reinterpret_cast<const double2_t*>(sE + 28 * b);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) vj[q] = pj[q];
+#pragma unroll
+          for (int q = 0; q < 14; ++q) vc[q] = pcv[q];
+#pragma unroll
+          for (int q = 0; q < 14; ++q) ve[q] = pev[q];
         }
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const int col = 2 * b + rr;
           double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) s0 = fma(t[k], sJ[col * 6 + k], s0);
+          for (int k = 0; k < 6; ++k) s0 = fma(t[k], vj[(rr * 6 + k) >> 1][(rr * 6 + k) & 1], s0);
 #pragma unroll
-          for (int k = 0; k < 14; ++k) s1 = fma(u[k], sC[col * 14 + k], s1);
+          for (int k = 0; k < 14; ++k) s1 = fma(u[k], vc[(rr * 14 + k) >> 1][(rr * 14 + k) & 1], s1);
 #pragma unroll
-          for (int k = 0; k < 14; ++k) s0 = fma(crow[k], sE[col * 14 + k], s0);
-          if (col <= lane) sB2[tri(lane, col)] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+          for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[(rr * 14 + k) >> 1][(rr * 14 + k) & 1], s0);
+          if (lane >= 2 * b) sL[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
         }
       }
     }
@@ -167,63 +210,117 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
     // ----------------------------------------------------------------------------------------
     // Phase C: Cholesky of B with the row in registers, fused forward substitution of [r | H_f]
     // ----------------------------------------------------------------------------------------
-    double arow[NR];
-    static_for<NR>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      double v = (k == lane) ? 1.0 : 0.0;
-      if (valid && k <= lane) v = sB2[tri(lane, k)];
-      arow[k] = v;
-    });
-    __syncthreads();
+    // Left-looking, blocked by 16 columns: the block's 16 entries of this lane's row live in registers, the finished
+    // columns of L are read back from LDS (own element + 16-wide broadcast), so the code is a compact rolled loop
+    // (an earlier fully unrolled 64-step version was instruction-fetch bound).
     double rh0 = res, rh1 = hf[0], rh2 = hf[1], rh3 = hf[2];
-    double* colbuf = sB;  // 2 x 64 doubles, alternating (scratch region, disjoint from the packed triangle)
     bool spd = true;
-    // look-ahead: the reciprocal square root of pivot k+1 is started as soon as column k is known, so the
-    // rsq/Newton chain overlaps the LDS broadcast and the trailing FMAs of step k.
-    double piv = readlane_f64(arow[0], 0);
-    double inv = rsqrt_nr(piv);
-    static_for<NR>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      if (k < n) {  // wave-uniform
+    const int nblk = (n + 15) >> 4;
+    long long t_ll = 0, t_ib = 0;
+#pragma nounroll
+    for (int jb = 0; jb < nblk; ++jb) {
+      const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);  // scalar: lane selects below must not waterfall
+      double ab[16];
+      static_for<16>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int col = j0 + t;
+        double v = (col == lane) ? 1.0 : 0.0;                       // identity padding for rows/columns >= n
+        if (valid && col < n && lane >= (col & ~1)) v = sL[coff(col) + lane - (col & ~1)];
+        ab[t] = v;
+      });
+      long long tq0 = __builtin_readcyclecounter();
+      // update with the finished columns k < j0
+#pragma nounroll
+      for (int k = 0; k < j0; ++k) {
+        const int ck = coff(k) - (k & ~1);
+        double lik = sL[ck + lane];
+        if (lane < j0) lik = 0.0;  // rows of finished blocks are final (k < j0 <= lane also covers the upper triangle)
+        // L[j0 .. j0+15][k] and y_k: wave-uniform, 16-byte aligned (column starts are even) -> ds_read_b128 broadcasts
+        const double2_t* lj = reinterpret_cast<const double2_t*>(sL + ck + j0);
+        const double2_t* yk = reinterpret_cast<const double2_t*>(sY + 4 * k);
+        double2_t lv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lv[q] = lj[q];
+        const double2_t y01 = yk[0], y23 = yk[1];
+        static_for<16>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          ab[t] = fma(-lik, lv[t >> 1][t & 1], ab[t]);
+        });
+        const double lir = (lane < j0 + 16) ? lik : 0.0;  // right-hand sides: only the rows of this block
+        rh0 = fma(-lir, y01[0], rh0);
+        rh1 = fma(-lir, y01[1], rh1);
+        rh2 = fma(-lir, y23[0], rh2);
+        rh3 = fma(-lir, y23[1], rh3);
+      }
+      long long tq1 = __builtin_readcyclecounter();
+      t_ll += tq1 - tq0;
+      // factor the block: 16 right-looking steps inside the registers.  Column c of L is broadcast to the other rows
+      // through a small LDS buffer (one ds_write + a few 16-byte broadcast reads per step instead of 2 v_readlane per
+      // element); the next pivot is taken with a look-ahead so its rsq/Newton chain overlaps the LDS round trip.
+      double piv = readlane_f64(ab[0], j0);
+      double inv = rsqrt_nr(piv);
+      static_for<16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const int kg = j0 + c;  // global column, wave-uniform
         spd = spd && (piv > 0.0);
-        const double l = arow[k] * inv;  // column k of L (valid for lanes >= k)
-        const double inv_k = inv;
-        double* cb = colbuf + (k & 1) * NR;
+        const double inv_c = inv;
+        double l = ab[c] * inv_c;
+        if (lane < kg) l = 0.0;  // rows above the diagonal do not belong to column kg
+        ab[c] = l;
+        double* cb = sB + (c & 1) * NR;
         cb[lane] = l;
-        if constexpr (k + 1 < NR) {
-          const double lk1 = readlane_f64(l, k + 1);
-          arow[k + 1] = fma(-l, lk1, arow[k + 1]);
-          piv = readlane_f64(arow[k + 1], k + 1);
+        if constexpr (c + 1 < 16) {
+          const double l1 = readlane_f64(l, kg + 1);
+          ab[c + 1] = fma(-l, l1, ab[c + 1]);
+          piv = readlane_f64(ab[c + 1], kg + 1);
           inv = rsqrt_nr(piv);
         }
-        // forward substitution of the 4 right-hand sides
-        const double x0 = readlane_f64(rh0, k) * inv_k, x1 = readlane_f64(rh1, k) * inv_k;
-        const double x2 = readlane_f64(rh2, k) * inv_k, x3 = readlane_f64(rh3, k) * inv_k;
-        if (lane > k) {
+        const double x0 = readlane_f64(rh0, kg) * inv_c, x1 = readlane_f64(rh1, kg) * inv_c;
+        const double x2 = readlane_f64(rh2, kg) * inv_c, x3 = readlane_f64(rh3, kg) * inv_c;
+        if (lane > kg && lane < j0 + 16) {  // rows of later blocks receive this column through the left-looking pass
           rh0 = fma(-l, x0, rh0);
           rh1 = fma(-l, x1, rh1);
           rh2 = fma(-l, x2, rh2);
           rh3 = fma(-l, x3, rh3);
-        } else if (lane == k) {
+        } else if (lane == kg) {
           rh0 = x0;
           rh1 = x1;
           rh2 = x2;
           rh3 = x3;
         }
-        // trailing update of this lane's row: a[j] -= l_ik * l_jk   (j = k+1 already done above)
-        constexpr int jb0 = (k + 2) / 8;
-        static_for<8 - jb0>([&](auto jbc) {
-          constexpr int j0 = (jb0 + decltype(jbc)::value) * 8;
-          if (j0 < n) {  // wave-uniform
-            static_for<8>([&](auto jc) {
-              constexpr int j = j0 + decltype(jc)::value;
-              if constexpr (j > k + 1) arow[j] = fma(-l, cb[j], arow[j]);
-            });
-          }
-        });
+        if constexpr (c + 2 < 16) {
+          // l_(j0+j), j = c+2..15, read as aligned pairs starting at the even index <= c+2
+          constexpr int e0 = (c + 2) & ~1;
+          const double2_t* cbv = reinterpret_cast<const double2_t*>(cb + j0 + e0);
+          double2_t lv[(16 - e0) / 2];
+#pragma unroll
+          for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = cbv[q];
+          static_for<14 - c>([&](auto jc) {
+            constexpr int j = c + 2 + decltype(jc)::value;
+            ab[j] = fma(-l, lv[(j - e0) >> 1][(j - e0) & 1], ab[j]);
+          });
+        }
+      });
+      t_ib += __builtin_readcyclecounter() - tq1;
+      // publish the block's columns of L and the solved right-hand sides of its rows
+      static_for<16>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int col = j0 + t;
+        if (lane >= (col & ~1)) sL[coff(col) + lane - (col & ~1)] = ab[t];
+      });
+      if (lane >= j0 && lane < j0 + 16) {
+        sY[4 * lane + 0] = rh0;
+        sY[4 * lane + 1] = rh1;
+        sY[4 * lane + 2] = rh2;
+        sY[4 * lane + 3] = rh3;
       }
-    });
+      __syncthreads();
+    }
     tstamp[4] = __builtin_readcyclecounter();
+    if (p.dbg_cycles && lane == 0) {
+      p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f] = t_ll;
+      p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f + 1] = t_ib;
+    }
     yv = valid ? rh0 : 0.0;
     zv[0] = valid ? rh1 : 0.0;
     zv[1] = valid ? rh2 : 0.0;
@@ -273,7 +370,7 @@ __global__ __launch_bounds__(64) void k_feat_gate(const FeatParams p) {
   // Phase E: projector rows G = Q1^T H_x, g = Q1^T r  (Q1 by CholeskyQR2 on H_f), staged in LDS
   // ------------------------------------------------------------------------------------------
   const int ldg = p.ldg;
-  double* Gst = sB;  // 3 * ldg doubles (ldg <= OVP_LDG_MAX so that it fits in TRI)
+  double* Gst = sL;  // 3 * ldg doubles (ldg <= OVP_LDG_CAP = LCOLS / 3); the factor is no longer needed
   for (int idx = lane; idx < 3 * ldg; idx += 64) Gst[idx] = 0.0;
   __syncthreads();
   if (accept) {

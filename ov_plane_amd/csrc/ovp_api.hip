@@ -229,7 +229,7 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   c->f_max = n_feats_max;
   c->ld = round_up(n_state_max, 16);
   c->ldg = round_up(n_state_max + 4, 16);  // state columns | residual | 3 out-of-state plane columns
-  if (3 * c->ldg > 2080 || c->ldg > OVP_LDG_CAP) return OVP_E_CAPACITY;  // K1 stages the projector rows in its 64x65/2 LDS triangle
+  if (c->ldg > OVP_LDG_CAP) return OVP_E_CAPACITY;  // the feature kernels stage 3 projector rows in LDS  // K1 stages the projector rows in its 64x65/2 LDS triangle
   const size_t nn = (size_t)(c->n_max + 1) * c->ld;
   HIPCHK(dalloc(&c->P, nn));
   HIPCHK(dalloc(&c->P_tmp, nn));
@@ -977,10 +977,10 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
     return 8;
   }
   else if (!strcmp(name, "cycles_on")) {
-    if (!c->dbg_cycles && hipMalloc((void**)&c->dbg_cycles, (size_t)c->f_max * 8 * sizeof(long long)) != hipSuccess) return OVP_E_STATE;
+    if (!c->dbg_cycles && hipMalloc((void**)&c->dbg_cycles, (size_t)c->f_max * 10 * sizeof(long long)) != hipSuccess) return OVP_E_STATE;
     return 0;
   }
-  else if (!strcmp(name, "cycles")) { src = c->dbg_cycles; bytes = (size_t)c->n_feats * 8 * sizeof(long long); if (!src) return OVP_E_STATE; }
+  else if (!strcmp(name, "cycles")) { src = c->dbg_cycles; bytes = (size_t)c->n_feats * 10 * sizeof(long long); if (!src) return OVP_E_STATE; }
   else return OVP_E_ARG;
   if ((long)bytes > max_bytes) bytes = (size_t)max_bytes;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return OVP_E_STATE;

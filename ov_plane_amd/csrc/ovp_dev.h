@@ -69,6 +69,14 @@ __device__ __forceinline__ double row_share_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// exchange with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double swap_pair_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += shfl_xor_f64(v, s);
