@@ -173,6 +173,12 @@ int ovp_cov_marginalize(ovp_ctx *ctx, int id, int size);
 /* StateHelper::augment_clone, time-offset part (state/StateHelper.cpp:613-624):
  *   Cov[:, pose..pose+5] += Cov[:, dt] * dnc_dt^T ;  Cov[pose..pose+5, :] += dnc_dt * Cov[dt, :]   (in that order) */
 int ovp_cov_augment_dt(ovp_ctx *ctx, int pose_id, int dt_id, const double dnc_dt[6]);
+/* StateHelper::initialize_invertible, covariance part (state/StateHelper.cpp:520-573): appends a k-dimensional variable
+ * (k <= 6) at the end of the state.  H_R [k x cols] column-major (ld) with per-column state ids, H_Linv [k x k] and
+ * R [k x k] column-major (upper triangle of R read).  New cross-covariance = -P H_R^T H_Linv^T,
+ * new block = H_Linv (H_R P H_R^T + R) H_Linv^T.  The caller applies H_Linv * res to the new variable's value. */
+int ovp_cov_initialize_invertible(ovp_ctx *ctx, const double *H_R_host, int k, int cols, int ld, const int *col_ids,
+                                  const double *H_Linv_host, const double *R_host);
 /* current covariance dimension */
 int ovp_cov_size(ovp_ctx *ctx);
 

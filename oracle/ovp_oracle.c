@@ -983,3 +983,179 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_
   free(dx);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * state/StateHelper.cpp:398-586
+ * ------------------------------------------------------------------------------------------- */
+/* inverse of a small k x k matrix (col-major) by Gauss-Jordan with partial pivoting
+ * (the reference uses colPivHouseholderQr().inverse(), :564) */
+static int small_inverse(const double *A, int k, double *Ainv) {
+  double M[6 * 12];
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      M[i * 2 * k + j] = A[(size_t)j * k + i];
+      M[i * 2 * k + k + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < k; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < k; ++r)
+      if (fabs(M[r * 2 * k + c]) > fabs(M[piv * 2 * k + c])) piv = r;
+    if (M[piv * 2 * k + c] == 0.0) return -1;
+    if (piv != c)
+      for (int j = 0; j < 2 * k; ++j) {
+        double t = M[c * 2 * k + j];
+        M[c * 2 * k + j] = M[piv * 2 * k + j];
+        M[piv * 2 * k + j] = t;
+      }
+    const double d = M[c * 2 * k + c];
+    for (int j = 0; j < 2 * k; ++j) M[c * 2 * k + j] /= d;
+    for (int r = 0; r < k; ++r)
+      if (r != c) {
+        const double f = M[r * 2 * k + c];
+        for (int j = 0; j < 2 * k; ++j) M[r * 2 * k + j] -= f * M[c * 2 * k + j];
+      }
+  }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) Ainv[(size_t)j * k + i] = M[i * 2 * k + k + j];
+  return 0;
+}
+
+int ovo_initialize(double *P, int n_cap, int *n_io, const int *order_id, const int *order_size, int n_order, double *H_R,
+                   double *H_L, int rows, int k, double r_iso, double *res, double chi2_mult, int do_update,
+                   double *new_var_delta, double *dx, double *chi2_out, int *dof_out) {
+  const int n = *n_io;
+  int cols = 0;
+  for (int i = 0; i < n_order; ++i) cols += order_size[i];
+  if (k > 6 || rows < k || n + k > n_cap) return -1;
+  /* :434-446 Givens on H_L, applied to res and H_R */
+  for (int c = 0; c < k; ++c)
+    for (int m = rows - 1; m > c; --m) {
+      double cs, sn;
+      ovo_make_givens(CM(H_L, rows, m - 1, c), CM(H_L, rows, m, c), &cs, &sn);
+      rot_rows(H_L, rows, m - 1, c, k, cs, sn);
+      rot_rows(res, rows, m - 1, 0, 1, cs, sn);
+      rot_rows(H_R, rows, m - 1, 0, cols, cs, sn);
+    }
+  const int rup = rows - k;
+  int *gcol = (int *)malloc(sizeof(int) * (size_t)cols);
+  {
+    int t = 0;
+    for (int i = 0; i < n_order; ++i)
+      for (int q = 0; q < order_size[i]; ++q) gcol[t++] = order_id[i] + q;
+  }
+  /* :464-475 chi2 on the update part with the prior covariance, dof = res.rows() */
+  double chi2 = 0.0;
+  if (rup > 0) {
+    double *HP = (double *)calloc((size_t)rup * cols, sizeof(double));
+    for (int a = 0; a < cols; ++a)
+      for (int b = 0; b < cols; ++b) {
+        const double pv = CM(P, n_cap, gcol[a], gcol[b]);
+        for (int i = 0; i < rup; ++i) CM(HP, rup, i, b) += CM(H_R, rows, k + i, a) * pv;
+      }
+    double *S = (double *)calloc((size_t)rup * rup, sizeof(double));
+    for (int i = 0; i < rup; ++i) CM(S, rup, i, i) = r_iso;
+    for (int a = 0; a < cols; ++a)
+      for (int j = 0; j < rup; ++j) {
+        const double hv = CM(H_R, rows, k + j, a);
+        for (int i = 0; i < rup; ++i) CM(S, rup, i, j) += CM(HP, rup, i, a) * hv;
+      }
+    if (ovo_llt(S, rup, rup)) {
+      free(HP);
+      free(S);
+      free(gcol);
+      return -2;
+    }
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)rup);
+    for (int i = 0; i < rup; ++i) tmp[i] = res[k + i];
+    llt_solve_vec(S, rup, rup, tmp);
+    for (int i = 0; i < rup; ++i) chi2 += res[k + i] * tmp[i];
+    free(tmp);
+    free(HP);
+    free(S);
+  }
+  if (chi2_out) *chi2_out = chi2;
+  if (dof_out) *dof_out = rows;
+  if (chi2 > chi2_mult * ovo_chi2_quantile_095(rows)) {
+    free(gcol);
+    return 0;
+  }
+  /* initialize_invertible :520-581 with Hxinit = top k rows of H_R, H_finit = top k x k of H_L */
+  double *M_a = (double *)calloc((size_t)n * k, sizeof(double));
+  for (int j = 0; j < k; ++j)
+    for (int a = 0; a < cols; ++a) {
+      const double hv = CM(H_R, rows, j, a);
+      for (int r = 0; r < n; ++r) CM(M_a, n, r, j) += CM(P, n_cap, r, gcol[a]) * hv;
+    }
+  double Mm[36], HL[36], HLinv[36];
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      double s = (i == j) ? r_iso : 0.0;
+      for (int a = 0; a < cols; ++a) s += CM(H_R, rows, i, a) * CM(M_a, n, gcol[a], j);
+      Mm[(size_t)j * k + i] = s;
+      HL[(size_t)j * k + i] = CM(H_L, rows, i, j);
+    }
+  /* selfadjointView<Upper> of M */
+  for (int j = 0; j < k; ++j)
+    for (int i = j + 1; i < k; ++i) Mm[(size_t)j * k + i] = Mm[(size_t)i * k + j];
+  if (small_inverse(HL, k, HLinv)) {
+    free(M_a);
+    free(gcol);
+    return -3;
+  }
+  /* P_LL = H_Linv M H_Linv^T ; cross = -M_a H_Linv^T */
+  double T1[36], PLL[36];
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      double s = 0.0;
+      for (int a = 0; a < k; ++a) s += HLinv[(size_t)a * k + i] * Mm[(size_t)j * k + a];
+      T1[(size_t)j * k + i] = s;
+    }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      double s = 0.0;
+      for (int a = 0; a < k; ++a) s += T1[(size_t)a * k + i] * HLinv[(size_t)a * k + j];
+      PLL[(size_t)j * k + i] = s;
+    }
+  for (int r = 0; r < n; ++r)
+    for (int j = 0; j < k; ++j) {
+      double s = 0.0;
+      for (int a = 0; a < k; ++a) s += CM(M_a, n, r, a) * HLinv[(size_t)a * k + j];
+      CM(P, n_cap, r, n + j) = -s;
+      CM(P, n_cap, n + j, r) = -s;
+    }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) CM(P, n_cap, n + i, n + j) = PLL[(size_t)j * k + i];
+  for (int i = 0; i < k; ++i) {
+    double s = 0.0;
+    for (int a = 0; a < k; ++a) s += HLinv[(size_t)a * k + i] * res[a];
+    new_var_delta[i] = s; /* :577 */
+  }
+  free(M_a);
+  *n_io = n + k;
+  const int n2 = n + k;
+  for (int i = 0; i < n2; ++i) dx[i] = 0.0;
+  /* :483-485 update with the remaining rows (whitened: R = r_iso I) */
+  if (rup > 0 && do_update) {
+    /* compact copy of the update rows, whitened */
+    const double w = 1.0 / sqrt(r_iso);
+    double *Hup = (double *)malloc(sizeof(double) * (size_t)rup * cols);
+    double *rupv = (double *)malloc(sizeof(double) * (size_t)rup);
+    for (int a = 0; a < cols; ++a)
+      for (int i = 0; i < rup; ++i) CM(Hup, rup, i, a) = w * CM(H_R, rows, k + i, a);
+    for (int i = 0; i < rup; ++i) rupv[i] = w * res[k + i];
+    /* ovo_ekf_update works on a dense n2 x n2 matrix with leading dimension n2: repack */
+    double *Pd = (double *)malloc(sizeof(double) * (size_t)n2 * n2);
+    for (int j = 0; j < n2; ++j)
+      for (int i = 0; i < n2; ++i) CM(Pd, n2, i, j) = CM(P, n_cap, i, j);
+    int neg = 0;
+    ovo_ekf_update(Pd, n2, order_id, order_size, n_order, Hup, rup, rup, rupv, dx, &neg);
+    for (int j = 0; j < n2; ++j)
+      for (int i = 0; i < n2; ++i) CM(P, n_cap, i, j) = CM(Pd, n2, i, j);
+    for (int i = 0; i < k; ++i) new_var_delta[i] += dx[n + i];
+    free(Pd);
+    free(Hup);
+    free(rupv);
+  }
+  free(gcol);
+  return 1;
+}

@@ -131,6 +131,16 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st, const ovo_fea
                            int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
                            ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows);
 
+/* state/StateHelper.cpp:398-487 (initialize) + :489-586 (initialize_invertible), isotropic noise R = r_iso * I.
+ * H_R [rows x cols] (col-major, ld = rows) over the variables of `order`, H_L [rows x k] for the new variable (k <= 6),
+ * res [rows].  P is [n_cap x n_cap] storage holding the current n x n covariance (leading dimension n_cap); on success
+ * it becomes (n+k) x (n+k) and *n is updated.  new_value_update[k] receives H_L^-1 * res_init plus the EKF correction of
+ * the new variable; dx[n+k] the EKF correction of the remaining rows (zero when there is no update part).
+ * Returns 1 = initialised, 0 = chi2 rejected, <0 error.  chi2/dof of the test are returned when non-NULL. */
+int ovo_initialize(double *P, int n_cap, int *n, const int *order_id, const int *order_size, int n_order, double *H_R,
+                   double *H_L, int rows, int k, double r_iso, double *res, double chi2_mult, int do_update,
+                   double *new_var_delta, double *dx, double *chi2_out, int *dof_out);
+
 #ifdef __cplusplus
 }
 #endif

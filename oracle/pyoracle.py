@@ -205,3 +205,29 @@ def msckf_plane_update(sc, libpath=None):
     return dict(P=np.ascontiguousarray(P), clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
                 calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), cp=cp, used=used.astype(bool),
                 plane_ok=ok[:n_planes].astype(bool), plane_chi2=chi2[:n_planes], plane_rows=rows[:n_planes])
+
+
+def initialize(P, order, H_R, H_L, res, r_iso, chi2_mult, do_update=True):
+    """ovo_initialize. order = list of (id, size). Returns dict(ok, P (n+k), new_delta[k], dx[n+k], chi2, dof)."""
+    n = P.shape[0]
+    rows, k = H_L.shape
+    cap = n + k
+    Pc = np.zeros((cap, cap), order="F")
+    Pc[:n, :n] = P
+    oid = np.ascontiguousarray([o[0] for o in order], dtype=np.int32)
+    osz = np.ascontiguousarray([o[1] for o in order], dtype=np.int32)
+    HR = np.asfortranarray(H_R, dtype=np.float64).copy(order="F")
+    HL = np.asfortranarray(H_L, dtype=np.float64).copy(order="F")
+    r = np.ascontiguousarray(res, dtype=np.float64).copy()
+    nn = C.c_int(n)
+    nd = np.zeros(k)
+    dx = np.zeros(cap)
+    chi2 = C.c_double(0)
+    dof = C.c_int(0)
+    L = lib()
+    L.ovo_initialize.restype = C.c_int
+    rc = L.ovo_initialize(_dp(Pc), C.c_int(cap), C.byref(nn), _ip(oid), _ip(osz), C.c_int(len(order)), _dp(HR), _dp(HL),
+                          C.c_int(rows), C.c_int(k), C.c_double(r_iso), _dp(r), C.c_double(chi2_mult), C.c_int(int(do_update)),
+                          _dp(nd), _dp(dx), C.byref(chi2), C.byref(dof))
+    n2 = nn.value
+    return dict(ok=rc, P=np.ascontiguousarray(Pc[:n2, :n2]), new_delta=nd, dx=dx[:n2], chi2=chi2.value, dof=dof.value)

@@ -94,7 +94,7 @@ EXPORTS = [
     "ovp_batch_bind_device", "ovp_msckf_update", "ovp_msckf_build_gate_gram_async", "ovp_gram_buffer",
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
-    "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt",
+    "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible",
 ]
 
 

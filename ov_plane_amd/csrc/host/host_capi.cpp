@@ -135,3 +135,74 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   for (auto &ft : fused) feat_used[ft->featid - 5000] = 1;
   return 0;
 }
+
+
+// Harness for StateHelper::initialize: state with C clones + calibration, covariance P (N x N), a new Vec(k) variable.
+// order_ids[n_order] select the measuring variables by Type::id() (clones / calibration / intrinsics).
+extern "C" int ovph_run_initialize(int C, const double *clone_q, const double *clone_p, int N, const double *P, int n_order,
+                                   const int *order_ids, int rows, int cols, const double *H_R, int k, const double *H_L,
+                                   const double *res, double r_iso, double chi2_mult, const double *new_value0,
+                                   double *out_P /* (N+k)^2 */, double *out_new_value, double *out_clone_q,
+                                   double *out_clone_p, double *out_calib_p, double *out_intr) {
+  StateOptions so;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.max_state_size = N + 16;
+  so.max_features = 16;
+  auto state = std::make_shared<State>(so);
+  const double w0[3] = {0, 0, 0};
+  for (int i = 0; i < C; ++i) {
+    VectorXd v(7, 1);
+    for (int q = 0; q < 4; ++q) v(q) = clone_q[4 * i + q];
+    for (int q = 0; q < 3; ++q) v(4 + q) = clone_p[3 * i + q];
+    state->_imu->pose()->set_value(v);
+    state->_imu->pose()->set_fej(v);
+    state->_timestamp = 100.0 + 0.1 * i;
+    StateHelper::augment_clone(state, w0);
+  }
+  if (state->max_covariance_size() != N) return -11;
+  std::vector<std::shared_ptr<Type>> all;
+  all.push_back(state->_imu);
+  all.push_back(state->_calib_dt_CAMtoIMU);
+  all.push_back(state->_calib_IMUtoCAM.at(0));
+  all.push_back(state->_cam_intrinsics.at(0));
+  for (auto &c : state->_clones_IMU) all.push_back(c.second);
+  {
+    MatrixXd Pm(N, N);
+    memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+    StateHelper::set_initial_covariance(state, Pm, all);
+  }
+  std::vector<std::shared_ptr<Type>> H_order;
+  for (int i = 0; i < n_order; ++i) {
+    std::shared_ptr<Type> found;
+    for (auto &v : all)
+      if (v->id() == order_ids[i]) found = v;
+    if (!found) return -12;
+    H_order.push_back(found);
+  }
+  MatrixXd HR(rows, cols), HL(rows, k), R = MatrixXd::Zero(rows, rows);
+  VectorXd r(rows, 1);
+  memcpy(HR.data(), H_R, sizeof(double) * (size_t)rows * cols);
+  memcpy(HL.data(), H_L, sizeof(double) * (size_t)rows * k);
+  memcpy(r.data(), res, sizeof(double) * rows);
+  for (int i = 0; i < rows; ++i) R(i, i) = r_iso;
+  auto nv = std::make_shared<Vec>(k);
+  VectorXd v0(k, 1);
+  for (int i = 0; i < k; ++i) v0(i) = new_value0[i];
+  nv->set_value(v0);
+  nv->set_fej(v0);
+  const bool ok = StateHelper::initialize(state, nv, H_order, HR, HL, R, r, chi2_mult, true);
+  const int n2 = state->max_covariance_size();
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)n2 * n2);
+  memcpy(out_new_value, nv->value().data(), sizeof(double) * k);
+  int i = 0;
+  for (auto &c : state->_clones_IMU) {
+    memcpy(out_clone_q + 4 * i, c.second->quat(), 4 * sizeof(double));
+    memcpy(out_clone_p + 3 * i, c.second->pos(), 3 * sizeof(double));
+    ++i;
+  }
+  memcpy(out_calib_p, state->_calib_IMUtoCAM.at(0)->pos(), 3 * sizeof(double));
+  memcpy(out_intr, state->_cam_intrinsics.at(0)->value().data(), 8 * sizeof(double));
+  return ok ? 1 : 0;
+}

@@ -303,6 +303,174 @@ void StateHelper::marginalize_old_clone(std::shared_ptr<State> state) {
   }
 }
 
+// ---- Eigen pieces used by initialize ----------------------------------------
+static void make_givens(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0 ? 1.0 : -1.0;
+  } else if (std::fabs(p) > std::fabs(q)) {
+    double t = q / p, u = std::sqrt(1.0 + t * t);
+    if (p < 0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+  } else {
+    double t = p / q, u = std::sqrt(1.0 + t * t);
+    if (q < 0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+  }
+}
+static void rot_rows(MatrixXd &A, int r0, int c0, double c, double s) {
+  for (int j = c0; j < A.cols(); ++j) {
+    const double x = A(r0, j), y = A(r0 + 1, j);
+    A(r0, j) = c * x - s * y;
+    A(r0 + 1, j) = s * x + c * y;
+  }
+}
+static void check_isotropic(const MatrixXd &R, const char *who) {
+  assert(R.rows() == R.cols());
+  assert(R.rows() > 0);
+  for (int r = 0; r < R.rows(); r++)
+    for (int c = 0; c < R.cols(); c++) {
+      if (r == c && R(0, 0) != R(r, c)) {
+        PRINT_ERROR("StateHelper::%s() - Your noise is not isotropic!\n", who);
+        std::exit(EXIT_FAILURE);
+      } else if (r != c && R(r, c) != 0.0) {
+        PRINT_ERROR("StateHelper::%s() - Your noise is not diagonal!\n", who);
+        std::exit(EXIT_FAILURE);
+      }
+    }
+}
+static bool small_inverse(const MatrixXd &A, MatrixXd &Ainv) {  // replaces colPivHouseholderQr().inverse() (:564)
+  const int k = A.rows();
+  MatrixXd M(k, 2 * k);
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      M(i, j) = A(i, j);
+      M(i, k + j) = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < k; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < k; ++r)
+      if (std::fabs(M(r, c)) > std::fabs(M(piv, c))) piv = r;
+    if (M(piv, c) == 0.0) return false;
+    if (piv != c)
+      for (int j = 0; j < 2 * k; ++j) std::swap(M(c, j), M(piv, j));
+    const double d = M(c, c);
+    for (int j = 0; j < 2 * k; ++j) M(c, j) /= d;
+    for (int r = 0; r < k; ++r)
+      if (r != c) {
+        const double f = M(r, c);
+        for (int j = 0; j < 2 * k; ++j) M(r, j) -= f * M(c, j);
+      }
+  }
+  Ainv.resize(k, k);
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) Ainv(i, j) = M(i, k + j);
+  return true;
+}
+
+// ---- state/StateHelper.cpp:398-487 -------------------------------------------------------------
+bool StateHelper::initialize(std::shared_ptr<State> state, std::shared_ptr<Type> new_variable,
+                             const std::vector<std::shared_ptr<Type>> &H_order, MatrixXd &H_R, MatrixXd &H_L, MatrixXd &R,
+                             VectorXd &res, double chi_2_mult, bool do_update) {
+  if (std::find(state->_variables.begin(), state->_variables.end(), new_variable) != state->_variables.end()) {
+    PRINT_ERROR("StateHelper::initialize_invertible() - Called on variable that is already in the state\n");
+    std::exit(EXIT_FAILURE);
+  }
+  check_isotropic(R, "initialize");
+  const int new_var_size = new_variable->size();
+  assert(new_var_size == H_L.cols());
+  // :434-446 Givens split
+  for (int n = 0; n < H_L.cols(); ++n)
+    for (int m = H_L.rows() - 1; m > n; m--) {
+      double c, s;
+      make_givens(H_L(m - 1, n), H_L(m, n), c, s);
+      rot_rows(H_L, m - 1, n, c, s);
+      rot_rows(res, m - 1, 0, c, s);
+      rot_rows(H_R, m - 1, 0, c, s);
+    }
+  const int rows = H_R.rows(), cols = H_R.cols(), rup = rows - new_var_size;
+  MatrixXd Hxinit = H_R.block(0, 0, new_var_size, cols);
+  MatrixXd H_finit = H_L.block(0, 0, new_var_size, new_var_size);
+  VectorXd resinit = res.block(0, 0, new_var_size, 1);
+  MatrixXd Rinit = R.block(0, 0, new_var_size, new_var_size);
+  MatrixXd Hup = H_R.block(new_var_size, 0, rup, cols);
+  VectorXd resup = res.block(new_var_size, 0, rup, 1);
+  MatrixXd Rup = R.block(new_var_size, new_var_size, rup, rup);
+  // :464-475 Mahalanobis test of the update part against the prior, dof = res.rows()
+  double chi2 = 0.0;
+  if (rup > 0) {
+    MatrixXd P_up = get_marginal_covariance(state, H_order);
+    MatrixXd HP(rup, cols);
+    for (int a = 0; a < cols; ++a)
+      for (int b = 0; b < cols; ++b) {
+        const double pv = P_up(a, b);
+        for (int i = 0; i < rup; ++i) HP(i, b) += Hup(i, a) * pv;
+      }
+    MatrixXd S = Rup;
+    for (int a = 0; a < cols; ++a)
+      for (int j = 0; j < rup; ++j) {
+        const double hv = Hup(j, a);
+        for (int i = 0; i < rup; ++i) S(i, j) += HP(i, a) * hv;
+      }
+    if (!host_llt(S)) return false;
+    VectorXd tmp = resup;
+    for (int i = 0; i < rup; ++i) {
+      double s = tmp(i);
+      for (int k = 0; k < i; ++k) s -= S(i, k) * tmp(k);
+      tmp(i) = s / S(i, i);
+    }
+    for (int i = 0; i < rup; ++i) chi2 += tmp(i) * tmp(i);  // res^T S^-1 res = |L^-1 res|^2
+  }
+  const double chi2_check = ovp_chi2_quantile_095(res.rows());
+  if (chi2 > chi_2_mult * chi2_check) return false;
+  StateHelper::initialize_invertible(state, new_variable, H_order, Hxinit, H_finit, Rinit, resinit);
+  if (Hup.rows() > 0 && do_update) StateHelper::EKFUpdate(state, H_order, Hup, resup, Rup);
+  return true;
+}
+
+// ---- state/StateHelper.cpp:489-586 -------------------------------------------------------------
+void StateHelper::initialize_invertible(std::shared_ptr<State> state, std::shared_ptr<Type> new_variable,
+                                        const std::vector<std::shared_ptr<Type>> &H_order, const MatrixXd &H_R, const MatrixXd &H_L,
+                                        const MatrixXd &R, const VectorXd &res) {
+  if (std::find(state->_variables.begin(), state->_variables.end(), new_variable) != state->_variables.end()) {
+    PRINT_ERROR("StateHelper::initialize_invertible() - Called on variable that is already in the state\n");
+    std::exit(EXIT_FAILURE);
+  }
+  check_isotropic(R, "initialize_invertible");
+  assert(res.rows() == R.rows());
+  assert(H_L.rows() == res.rows());
+  assert(H_L.rows() == H_R.rows());
+  assert(H_L.rows() == H_L.cols());
+  assert(H_L.rows() == new_variable->size());
+  std::vector<int> col_ids;
+  for (const auto &v : H_order)
+    for (int k = 0; k < v->size(); ++k) col_ids.push_back(v->id() + k);
+  MatrixXd H_Linv;
+  if (!small_inverse(H_L, H_Linv)) {
+    PRINT_ERROR("StateHelper::initialize_invertible() - H_L is singular\n");
+    std::exit(EXIT_FAILURE);
+  }
+  const int oldSize = ovp_cov_size(state->_gpu);
+  gpu_check(ovp_cov_initialize_invertible(state->_gpu, H_R.data(), H_R.rows(), H_R.cols(), H_R.rows(), col_ids.data(), H_Linv.data(),
+                                          R.data()),
+            "ovp_cov_initialize_invertible");
+  // :577 new_variable->update(H_Linv * res)
+  VectorXd d(new_variable->size(), 1);
+  for (int i = 0; i < new_variable->size(); ++i) {
+    double s = 0.0;
+    for (int a = 0; a < H_Linv.cols(); ++a) s += H_Linv(i, a) * res(a);
+    d(i) = s;
+  }
+  new_variable->update(d);
+  new_variable->set_local_id(oldSize);
+  state->_variables.push_back(new_variable);
+}
+
 // ---- update/UpdaterMSCKF.cpp ---------------------------------------------------------------------
 UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, ov_core::FeatureInitializerOptions &) : _options(options) {
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);

@@ -87,6 +87,13 @@ public:
   static std::shared_ptr<ov_type::Type> clone(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> variable_to_clone);
   static void augment_clone(std::shared_ptr<State> state, const double last_w[3]);
   static void marginalize_old_clone(std::shared_ptr<State> state);
+  // state/StateHelper.h:172-173 / :188-190
+  static bool initialize(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> new_variable,
+                         const std::vector<std::shared_ptr<ov_type::Type>> &H_order, MatrixXd &H_R, MatrixXd &H_L, MatrixXd &R,
+                         VectorXd &res, double chi_2_mult, bool do_update = true);
+  static void initialize_invertible(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> new_variable,
+                                    const std::vector<std::shared_ptr<ov_type::Type>> &H_order, const MatrixXd &H_R,
+                                    const MatrixXd &H_L, const MatrixXd &R, const VectorXd &res);
   // applies a correction to every active variable (the tail of EKFUpdate, state/StateHelper.cpp:190-193)
   static void apply_correction(std::shared_ptr<State> state, const double *dx);
 

@@ -250,6 +250,61 @@ __global__ void k_augment_dt_rows(double* __restrict__ P, int ldp, int n, int po
   const double d[6] = {d0, d1, d2, d3, d4, d5};
   for (int k = 0; k < 6; ++k) P[(size_t)(pose + k) * ldp + c] += d[k] * v;
 }
+// StateHelper::initialize_invertible (state/StateHelper.cpp:520-573), k <= 6 new columns.
+// step 1: M_a[r][j] = sum_a P[r][cols[a]] * H_R[j][a]          (H_R row-major [k][ncols] on the device)
+__global__ void k_init_ma(const double* __restrict__ P, int ldp, int n, const int* __restrict__ cols, int ncols,
+                          const double* __restrict__ HR, int k, double* __restrict__ Ma) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < ncols; ++a) {
+    const double pv = P[(size_t)r * ldp + cols[a]];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (j < k) acc[j] = fma(pv, HR[(size_t)j * ncols + a], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    if (j < k) Ma[(size_t)r * 6 + j] = acc[j];
+}
+// step 2 (one workgroup): M = H_R M_a[cols] + R (upper triangle mirrored), P_LL = Hinv M Hinv^T,
+// P[0:n, n:n+k] = -M_a Hinv^T and its transpose.   Hinv, Rk are k x k row-major.
+__global__ __launch_bounds__(256) void k_init_write(double* __restrict__ P, int ldp, int n, const int* __restrict__ cols,
+                                                     int ncols, const double* __restrict__ HR, int k,
+                                                     const double* __restrict__ Ma, const double* __restrict__ Hinv,
+                                                     const double* __restrict__ Rk) {
+  __shared__ double M[36], PLL[36], Hi[36];
+  const int t = threadIdx.x;
+  if (t < k * k) {
+    const int i = t / k, j = t - i * k;
+    Hi[t] = Hinv[t];
+    const int ii = i <= j ? i : j, jj = i <= j ? j : i;  // selfadjointView<Upper>
+    double s = Rk[ii * k + jj];
+    for (int a = 0; a < ncols; ++a) s = fma(HR[(size_t)ii * ncols + a], Ma[(size_t)cols[a] * 6 + jj], s);
+    M[t] = s;
+  }
+  __syncthreads();
+  if (t < k * k) {
+    const int i = t / k, j = t - i * k;
+    double s = 0.0;
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b) s = fma(Hi[i * k + a] * M[a * k + b], Hi[j * k + b], s);
+    PLL[t] = s;
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * k; idx += 256) {
+    const int r = idx / k, j = idx - r * k;
+    double s = 0.0;
+    for (int a = 0; a < k; ++a) s = fma(Ma[(size_t)r * 6 + a], Hi[j * k + a], s);
+    P[(size_t)r * ldp + n + j] = -s;
+    P[(size_t)(n + j) * ldp + r] = -s;
+  }
+  if (t < k * k) {
+    const int i = t / k, j = t - i * k;
+    P[(size_t)(n + i) * ldp + n + j] = PLL[t];
+  }
+}
+
 __global__ void k_check_negdiag(const double* __restrict__ P, int ldp, int n, int* __restrict__ negdiag) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n && P[(size_t)r * ldp + r] < 0.0) *negdiag = 1;
@@ -318,6 +373,13 @@ hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, in
   if (n_new <= 0) return hipSuccess;
   hipLaunchKernelGGL(ovp::k_cov_marginalize, dim3((n_new + 127) / 128, n_new), dim3(128), 0, stream, src, dst, ld,
                      n_old, id, sz);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_init_invertible(double* P, int ldp, int n, const int* cols, int ncols, const double* HR, int k,
+                                      double* Ma, const double* Hinv, const double* Rk, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_init_ma, dim3((n + 127) / 128), dim3(128), 0, stream, P, ldp, n, cols, ncols, HR, k, Ma);
+  hipLaunchKernelGGL(ovp::k_init_write, dim3(1), dim3(256), 0, stream, P, ldp, n, cols, ncols, HR, k, Ma, Hinv, Rk);
   return hipGetLastError();
 }
 

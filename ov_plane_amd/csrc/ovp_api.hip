@@ -24,6 +24,8 @@ hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, c
                                 const double* Phi, const double* Q, double* CPT, double* PCP, int* negdiag,
                                 hipStream_t stream);
 hipError_t ovp_launch_augment_dt(double* P, int ldp, int n, int pose, int dt, const double* d, hipStream_t stream);
+hipError_t ovp_launch_init_invertible(double* P, int ldp, int n, const int* cols, int ncols, const double* HR, int k,
+                                      double* Ma, const double* Hinv, const double* Rk, hipStream_t stream);
 hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
                                hipStream_t stream);
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
@@ -930,6 +932,39 @@ extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
   c->P = c->P_tmp;
   c->P_tmp = t;
   c->n -= size;
+  return 0;
+}
+
+extern "C" int ovp_cov_initialize_invertible(ovp_ctx* c, const double* H_R, int k, int cols, int ld, const int* col_ids,
+                                             const double* H_Linv, const double* R) {
+  if (!c || !H_R || !col_ids || !H_Linv || !R || k < 1 || k > 6 || cols < 1 || ld < k) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  const int n = c->n;
+  if (n + k > c->n_max) return OVP_E_CAPACITY;
+  if (cols > c->n_max) return OVP_E_ARG;
+  for (int j = 0; j < cols; ++j)
+    if (col_ids[j] < 0 || col_ids[j] >= n) return OVP_E_ARG;
+  // device layout: H_R row-major [k][cols], Hinv / R row-major [k][k], M_a [n][6]
+  std::vector<double> hr((size_t)k * cols), hi((size_t)k * k), rk((size_t)k * k);
+  for (int i = 0; i < k; ++i)
+    for (int a = 0; a < cols; ++a) hr[(size_t)i * cols + a] = H_R[(size_t)a * ld + i];
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      hi[(size_t)i * k + j] = H_Linv[(size_t)j * k + i];
+      rk[(size_t)i * k + j] = R[(size_t)j * k + i];
+    }
+  double* dHR = c->smallbuf;
+  double* dHi = dHR + (size_t)k * cols;
+  double* dRk = dHi + 36;
+  double* dMa = dRk + 36;
+  if ((size_t)(dMa + (size_t)6 * n - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
+  HIPCHK(hipMemcpyAsync(dHR, hr.data(), sizeof(double) * hr.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dHi, hi.data(), sizeof(double) * hi.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dRk, rk.data(), sizeof(double) * rk.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->idbuf, col_ids, sizeof(int) * cols, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(ovp_launch_init_invertible(c->P, c->ld, n, c->idbuf, cols, dHR, k, dMa, dHi, dRk, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // host vectors above must outlive the copies
+  c->n = n + k;
   return 0;
 }
 

@@ -58,3 +58,31 @@ def run_msckf_update(sc):
     for k in ("kept", "used", "deleted"):
         out[k] = out[k].astype(bool)
     return out
+
+
+def run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, new_value0):
+    """Drives ov_plane::StateHelper::initialize (C++ host mirror) on the state of a synth.Scene (no planes / SLAM)."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N = int(sc.N)
+    rows, k = H_L.shape
+    cols = H_R.shape[1]
+    P = np.asfortranarray(sc.P)
+    HR = np.asfortranarray(H_R, dtype=np.float64)
+    HL = np.asfortranarray(H_L, dtype=np.float64)
+    r = f64(res)
+    oid = np.ascontiguousarray([o[0] for o in order], dtype=np.int32)
+    cq, cp_ = f64(sc.clone_q), f64(sc.clone_p)
+    v0 = f64(new_value0)
+    out = dict(P=np.zeros((N + k, N + k)), new_value=np.zeros(k), clone_q=np.zeros((sc.C, 4)), clone_p=np.zeros((sc.C, 3)),
+               calib_p=np.zeros(3), intr=np.zeros(8))
+    L.ovph_run_initialize.restype = C.c_int
+    rc = L.ovph_run_initialize(C.c_int(sc.C), p(cq), p(cp_), C.c_int(N), p(P), C.c_int(len(order)), p(oid), C.c_int(rows),
+                               C.c_int(cols), p(HR), C.c_int(k), p(HL), p(r), C.c_double(r_iso), C.c_double(chi2_mult), p(v0),
+                               p(out["P"]), p(out["new_value"]), p(out["clone_q"]), p(out["clone_p"]), p(out["calib_p"]),
+                               p(out["intr"]))
+    if rc < 0:
+        raise RuntimeError("ovph_run_initialize failed with %d" % rc)
+    out["ok"] = rc
+    return out

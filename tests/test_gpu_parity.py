@@ -368,3 +368,36 @@ def test_rccl_allreduce_path_single_rank(hiplib, oracle):
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("r_iso,chi2_mult,expect", [(1.0, 1e9, 1), (0.25, 1e9, 1), (1.0, 1e-9, 0)])
+def test_host_cpp_initialize_matches_oracle(hiplib, oracle, r_iso, chi2_mult, expect):
+    """StateHelper::initialize / initialize_invertible (state/StateHelper.cpp:398-586): Givens split, chi2 against the prior,
+    covariance augmentation on the device, EKF update with the remaining rows."""
+    from ov_plane_amd.build import build_host
+    from ov_plane_amd.synth import quat_boxplus
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    rng = np.random.default_rng(7)
+    sc = make_scene(C=6, F=4, seed=91)
+    # the synth layout has calibration at ids 16/22; the host State here does not estimate planes or SLAM features
+    order = [(int(sc.ids["clones"][1]), 6), (int(sc.ids["calib"]), 6), (int(sc.ids["clones"][4]), 6)]
+    rows, cols, k = 30, 18, 3
+    H_R = rng.standard_normal((rows, cols)) * 20.0
+    H_L = rng.standard_normal((rows, k)) * 5.0
+    res = rng.standard_normal(rows) * np.sqrt(r_iso)
+    v0 = np.array([1.0, -2.0, 3.0])
+    ref = oracle.initialize(sc.P, order, H_R, H_L, res, r_iso, chi2_mult)
+    out = hostlib.run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, v0)
+    assert out["ok"] == ref["ok"] == expect
+    if not expect:
+        return
+    assert relP(out["P"], ref["P"]) < TOL_P
+    assert np.abs(out["new_value"] - (v0 + ref["new_delta"])).max() < TOL_DX
+    dx = ref["dx"]
+    for i in range(sc.C):
+        cid = sc.ids["clones"][i]
+        assert np.abs(out["clone_p"][i] - (sc.clone_p[i] + dx[cid + 3:cid + 6])).max() < TOL_DX
+        assert np.abs(out["clone_q"][i] - quat_boxplus(sc.clone_q[i], dx[cid:cid + 3])).max() < TOL_DX
