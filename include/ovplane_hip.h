@@ -155,6 +155,17 @@ typedef struct {
 int ovp_msckf_plane_update(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_plane_batch *planes, double *dx_planes,
                            uint8_t *plane_ok, double *plane_chi2, int *plane_dof, uint8_t *feat_used);
 
+/* UpdaterPlane::init_vio_plane, core (update/UpdaterPlane.cpp:296-481): for every plane of the batch (none of them in the
+ * state; plane_state_id is ignored), in ascending id: stack the on-plane MSCKF features with sigma_c * const_init_multi,
+ * project out the feature, compress, StateHelper::initialize(plane, ..., const_init_chi2) = chi2 test of the part that
+ * does not involve the plane, covariance augmentation by 3 and EKF update with the remaining rows.
+ * Every accepted plane appends 3 columns to the state (new_ids[k] = its Type::id(), else -1); cp_new[3k..] is its
+ * initialised value; dx_planes[k*dx_stride ..] the correction of the pre-existing variables to apply with Type::update
+ * (dx_stride >= final state size).  Upstream triangulation / plane fitting is the caller's job. */
+int ovp_plane_init(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_plane_batch *planes, double const_init_multi,
+                   double const_init_chi2, double *dx_planes, int dx_stride, uint8_t *plane_ok, double *plane_chi2,
+                   int *plane_dof, int *new_ids, double *cp_new, uint8_t *feat_used);
+
 /* StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for a dense H handed over by the host
  * (UpdaterSLAM::update, StateHelper::initialize, merge_planes...): H is [rows x cols] column-major with leading
  * dimension ld, col_ids[cols] gives the state column of every H column, R = I. */

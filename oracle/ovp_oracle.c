@@ -1159,3 +1159,138 @@ int ovo_initialize(double *P, int n_cap, int *n_io, const int *order_id, const i
   free(gcol);
   return 1;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterPlane.cpp:296-481
+ * ------------------------------------------------------------------------------------------- */
+int ovo_plane_init(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, const int *plane_of_feat, int n_planes,
+                   const double *cp_in, double const_init_multi, double const_init_chi2, double *P, int n_cap, int *n_io,
+                   ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_dof,
+                   int *new_id, double *cp_out) {
+  const int F = fb->n_feats, mm = fb->max_meas;
+  for (int f = 0; f < F; ++f) used[f] = 0;
+  const int maxrows = 3 * mm + 1, maxcols = 6 * mm + 14 + 3;
+  double *H_f_tmp = (double *)malloc(sizeof(double) * (size_t)maxrows * 6);
+  double *H_f = (double *)malloc(sizeof(double) * (size_t)maxrows * 3);
+  double *H_cp = (double *)malloc(sizeof(double) * (size_t)maxrows * 3);
+  double *H_x = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *res = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  int *oid = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *osz = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
+  int *map_col = (int *)malloc(sizeof(int) * (size_t)n_cap);
+  int *order_big_id = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8));
+  int *order_big_size = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8));
+  double *dx = (double *)malloc(sizeof(double) * (size_t)n_cap);
+  for (int pl = 0; pl < n_planes; ++pl) {
+    const int planeid = pl + 1;
+    plane_ok[pl] = 0;
+    plane_chi2[pl] = 0.0;
+    plane_dof[pl] = 0;
+    new_id[pl] = -1;
+    for (int q = 0; q < 3; ++q) cp_out[3 * pl + q] = cp_in[3 * pl + q];
+    const int n = *n_io;
+    int nf = 0;
+    size_t max_meas = 0;
+    for (int f = 0; f < F; ++f)
+      if (plane_of_feat[f] == planeid && fb->n_meas[f] >= 2) {
+        ++nf;
+        max_meas += 3 * (size_t)fb->n_meas[f];
+      }
+    if (nf < 3) continue; /* :303 */
+    ovo_state st = *st_in;
+    st.n_state = n;
+    st.clone_q = val->clone_q;
+    st.clone_p = val->clone_p;
+    memcpy(st.calib_q, val->calib_q, sizeof(st.calib_q));
+    memcpy(st.calib_p, val->calib_p, sizeof(st.calib_p));
+    memcpy(st.intrinsics, val->intrinsics, sizeof(st.intrinsics));
+    const double *cpv = cp_in + 3 * pl; /* :344-347 plane linearisation point = the estimate, fej = value */
+    double *res_big = (double *)calloc(max_meas, sizeof(double));
+    double *Hx_big = (double *)calloc(max_meas * (size_t)n, sizeof(double));
+    double *Hcp_big = (double *)calloc(max_meas * 3, sizeof(double));
+    for (int i = 0; i < n_cap; ++i) map_col[i] = -1;
+    int n_order_big = 0;
+    size_t ct_jacob = 0, ct_meas = 0;
+    const double sigma_c = const_init_multi * o->sigma_constraint; /* :384 */
+    for (int f = 0; f < F; ++f) {
+      if (plane_of_feat[f] != planeid || fb->n_meas[f] < 2) continue;
+      int rows, cols, hfc, no;
+      ovo_feature_jacobian_full(o, &st, fb, f, sigma_c, planeid, cpv, cpv, -1, H_f_tmp, H_x, res, &rows, &cols, &hfc, oid, osz,
+                                &no);
+      memcpy(H_cp, H_f_tmp + (size_t)3 * rows, sizeof(double) * (size_t)rows * 3); /* :389 */
+      memcpy(H_f, H_f_tmp, sizeof(double) * (size_t)rows * 3);
+      ovo_nullspace_project(H_f, rows, 3, H_x, cols, H_cp, 3, res); /* :402 */
+      const int q = rows - 3;
+      int ct_hx = 0;
+      for (int v = 0; v < no; ++v) {
+        if (map_col[oid[v]] < 0) {
+          map_col[oid[v]] = (int)ct_jacob;
+          order_big_id[n_order_big] = oid[v];
+          order_big_size[n_order_big++] = osz[v];
+          ct_jacob += (size_t)osz[v];
+        }
+        for (int cc = 0; cc < osz[v]; ++cc)
+          for (int i = 0; i < q; ++i)
+            CM(Hx_big, max_meas, ct_meas + i, map_col[oid[v]] + cc) = CM(H_x, rows, 3 + i, ct_hx + cc);
+        ct_hx += osz[v];
+      }
+      for (int cc = 0; cc < 3; ++cc)
+        for (int i = 0; i < q; ++i) CM(Hcp_big, max_meas, ct_meas + i, cc) = CM(H_cp, rows, 3 + i, cc);
+      for (int i = 0; i < q; ++i) res_big[ct_meas + i] = res[3 + i];
+      ct_meas += (size_t)q;
+    }
+    /* :431-436 resize + compress */
+    double *Hc = (double *)malloc(sizeof(double) * ct_meas * (ct_jacob ? ct_jacob : 1));
+    for (size_t j = 0; j < ct_jacob; ++j) memcpy(Hc + j * ct_meas, Hx_big + j * max_meas, sizeof(double) * ct_meas);
+    double *Hcpc = (double *)malloc(sizeof(double) * ct_meas * 3);
+    for (size_t j = 0; j < 3; ++j) memcpy(Hcpc + j * ct_meas, Hcp_big + j * max_meas, sizeof(double) * ct_meas);
+    const int rows_c = ovo_measurement_compress(Hc, (int)ct_meas, (int)ct_jacob, (int)ct_meas, Hcpc, 3, (int)ct_meas, res_big);
+    /* compact (rows_c x .) copies for initialize */
+    double *HR = (double *)malloc(sizeof(double) * (size_t)rows_c * (ct_jacob ? ct_jacob : 1));
+    double *HL = (double *)malloc(sizeof(double) * (size_t)rows_c * 3);
+    double *rr = (double *)malloc(sizeof(double) * (size_t)rows_c);
+    for (size_t j = 0; j < ct_jacob; ++j)
+      for (int i = 0; i < rows_c; ++i) CM(HR, rows_c, i, j) = CM(Hc, ct_meas, i, j);
+    for (size_t j = 0; j < 3; ++j)
+      for (int i = 0; i < rows_c; ++i) CM(HL, rows_c, i, j) = CM(Hcpc, ct_meas, i, j);
+    for (int i = 0; i < rows_c; ++i) rr[i] = res_big[i];
+    double delta[3], chi2 = 0.0;
+    int dof = 0;
+    int nn = n;
+    const int ok = ovo_initialize(P, n_cap, &nn, order_big_id, order_big_size, n_order_big, HR, HL, rows_c, 3, 1.0, rr,
+                                  const_init_chi2, 1, delta, dx, &chi2, &dof); /* :446 */
+    plane_chi2[pl] = chi2;
+    plane_dof[pl] = dof;
+    if (ok == 1) {
+      plane_ok[pl] = 1;
+      new_id[pl] = n;
+      *n_io = nn;
+      for (int q = 0; q < 3; ++q) cp_out[3 * pl + q] = cp_in[3 * pl + q] + delta[q];
+      for (int f = 0; f < F; ++f)
+        if (plane_of_feat[f] == planeid && fb->n_meas[f] >= 2) used[f] = 1;
+      /* Type::update of the pre-existing variables with the EKF correction of the update rows */
+      int no_planes = 0;
+      ovo_apply_dx(st_in, no_planes, NULL, dx, val);
+    }
+    free(HR);
+    free(HL);
+    free(rr);
+    free(Hc);
+    free(Hcpc);
+    free(res_big);
+    free(Hx_big);
+    free(Hcp_big);
+  }
+  free(H_f_tmp);
+  free(H_f);
+  free(H_cp);
+  free(H_x);
+  free(res);
+  free(oid);
+  free(osz);
+  free(map_col);
+  free(order_big_id);
+  free(order_big_size);
+  free(dx);
+  return 0;
+}

@@ -131,6 +131,17 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st, const ovo_fea
                            int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
                            ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows);
 
+/* update/UpdaterPlane.cpp:296-481: core of UpdaterPlane::init_vio_plane for planes that already have an estimate
+ * (triangulation / RANSAC / Ceres refinement are upstream and out of scope): per plane, stack the on-plane MSCKF features
+ * with sigma_c * const_init_multi, nullspace-project the 3 feature columns, compress with H_cp carried, then
+ * StateHelper::initialize(plane, ..., const_init_chi2).  Planes are processed in ascending id; every success appends a
+ * 3-dof plane to the state (P grows inside its n_cap x n_cap storage) and updates `val`.
+ * Outputs per plane: ok, chi2, dof, new_id (Type::id() of the initialised plane or -1), cp_out[3] (its value). */
+int ovo_plane_init(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat, int n_planes,
+                   const double *cp_in, double const_init_multi, double const_init_chi2, double *P, int n_cap, int *n,
+                   ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_dof,
+                   int *new_id, double *cp_out);
+
 /* state/StateHelper.cpp:398-487 (initialize) + :489-586 (initialize_invertible), isotropic noise R = r_iso * I.
  * H_R [rows x cols] (col-major, ld = rows) over the variables of `order`, H_L [rows x k] for the new variable (k <= 6),
  * res [rows].  P is [n_cap x n_cap] storage holding the current n x n covariance (leading dimension n_cap); on success

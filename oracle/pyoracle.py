@@ -231,3 +231,41 @@ def initialize(P, order, H_R, H_L, res, r_iso, chi2_mult, do_update=True):
                           _dp(nd), _dp(dx), C.byref(chi2), C.byref(dof))
     n2 = nn.value
     return dict(ok=rc, P=np.ascontiguousarray(Pc[:n2, :n2]), new_delta=nd, dx=dx[:n2], chi2=chi2.value, dof=dof.value)
+
+
+def plane_init(sc, const_init_multi=5.0, const_init_chi2=1.0, n_extra=None):
+    """ovo_plane_init on every plane of the scene that is NOT in the state (scene must have planes_in_state_frac=0)."""
+    L = lib()
+    pk = Packed(sc)
+    n_planes = int(sc.cp.shape[0])
+    cap = sc.N + 3 * n_planes
+    P = np.zeros((cap, cap), order="F")
+    P[: sc.N, : sc.N] = sc.P
+    cq = np.ascontiguousarray(sc.clone_q.copy())
+    cpv = np.ascontiguousarray(sc.clone_p.copy())
+    cpdummy = np.zeros((max(n_planes, 1), 3))
+    val = OvoStateValues()
+    val.clone_q = _dp(cq)
+    val.clone_p = _dp(cpv)
+    val.calib_q[:] = list(sc.calib_q)
+    val.calib_p[:] = list(sc.calib_p)
+    val.intrinsics[:] = list(sc.intr)
+    val.cp = _dp(cpdummy)
+    cp_in = np.ascontiguousarray(sc.cp, dtype=np.float64)
+    pof = np.ascontiguousarray(sc.plane_id, dtype=np.int32)
+    used = np.zeros(sc.F, dtype=np.uint8)
+    ok = np.zeros(max(n_planes, 1), dtype=np.uint8)
+    chi2 = np.zeros(max(n_planes, 1))
+    dof = np.zeros(max(n_planes, 1), dtype=np.int32)
+    nid = np.zeros(max(n_planes, 1), dtype=np.int32)
+    cp_out = np.zeros((max(n_planes, 1), 3))
+    nn = C.c_int(sc.N)
+    u8 = C.POINTER(C.c_uint8)
+    L.ovo_plane_init(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(pof), C.c_int(n_planes), _dp(cp_in),
+                     C.c_double(const_init_multi), C.c_double(const_init_chi2), _dp(P), C.c_int(cap), C.byref(nn), C.byref(val),
+                     used.ctypes.data_as(u8), ok.ctypes.data_as(u8), _dp(chi2), _ip(dof), _ip(nid), _dp(cp_out))
+    n2 = nn.value
+    return dict(P=np.ascontiguousarray(P[:n2, :n2]), n=n2, clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
+                calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), used=used.astype(bool),
+                plane_ok=ok[:n_planes].astype(bool), plane_chi2=chi2[:n_planes], plane_dof=dof[:n_planes],
+                new_id=nid[:n_planes], cp=cp_out[:n_planes])

@@ -94,7 +94,7 @@ EXPORTS = [
     "ovp_batch_bind_device", "ovp_msckf_update", "ovp_msckf_build_gate_gram_async", "ovp_gram_buffer",
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
-    "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible",
+    "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
 ]
 
 
@@ -133,6 +133,9 @@ def lib():
                                      C.c_void_p, C.POINTER(UpdateInfo)]
         L.ovp_msckf_plane_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(PlaneBatch), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ovp_plane_init.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(PlaneBatch), C.c_double, C.c_double,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
         L.ovp_cov_propagate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.POINTER(C.c_int)]
         L.ovp_cov_clone.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -326,6 +329,27 @@ class Context:
             raise OvpError(rc, "ovp_msckf_plane_update")
         return dict(dx=dx[:npl], ok=ok[:npl].astype(bool), chi2=chi2[:npl], dof=dof[:npl],
                     used=used[: self.n_feats].astype(bool), rc=rc)
+
+    def plane_init(self, opts: UpdateOpts, plane_of_feat, cp, const_init_multi, const_init_chi2):
+        """UpdaterPlane::init_vio_plane core. Returns dict(dx [n_planes, stride], ok, chi2, dof, new_ids, cp, used)."""
+        plane_of_feat = np.ascontiguousarray(plane_of_feat, dtype=np.int32)
+        cp = np.ascontiguousarray(cp, dtype=np.float64)
+        npl = int(cp.shape[0])
+        sid = -np.ones(max(npl, 1), dtype=np.int32)
+        stride = self.n_state_max
+        dx = np.zeros((max(npl, 1), stride))
+        ok = np.zeros(max(npl, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(npl, 1))
+        dof = np.zeros(max(npl, 1), dtype=np.int32)
+        nid = np.zeros(max(npl, 1), dtype=np.int32)
+        cpn = np.zeros((max(npl, 1), 3))
+        used = np.zeros(max(self.n_feats, 1), dtype=np.uint8)
+        pb = PlaneBatch(npl, plane_of_feat.ctypes.data, cp.ctypes.data, cp.ctypes.data, sid.ctypes.data)
+        _chk(lib().ovp_plane_init(self._h, C.byref(opts), C.byref(pb), C.c_double(const_init_multi),
+                                  C.c_double(const_init_chi2), dx.ctypes.data, C.c_int(stride), ok.ctypes.data, chi2.ctypes.data,
+                                  dof.ctypes.data, nid.ctypes.data, cpn.ctypes.data, used.ctypes.data), "ovp_plane_init")
+        return dict(dx=dx[:npl], ok=ok[:npl].astype(bool), chi2=chi2[:npl], dof=dof[:npl], new_ids=nid[:npl], cp=cpn[:npl],
+                    used=used[: self.n_feats].astype(bool))
 
     def ekf_update(self, H, col_ids, res):
         """StateHelper::EKFUpdate with a dense H (rows x cols) and per-column state ids."""

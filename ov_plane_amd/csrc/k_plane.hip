@@ -527,9 +527,112 @@ __global__ __launch_bounds__(256) void k_plane_commit(const double* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Plane initialisation (UpdaterPlane::init_vio_plane -> StateHelper::initialize, update/UpdaterPlane.cpp:436-446,
+// state/StateHelper.cpp:398-586) in information form: with a flat prior on the new plane the joint posterior of
+// (x, cp) given the extended pair E = [[Exx Exc][Ecx Ecc]], [bx; bc] is
+//   Sigma_xx = P+ (already resident),  Sigma_xc = -P+ Z,  Sigma_cc = Ecc^-1 + Z^T P+ Z,  Z = Exc Ecc^-1,
+//   d cp = Ecc^-1 (bc - Ecx dx).
+// One workgroup; P already holds P+ (n x n); rows/columns n..n+2 are appended.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plane_init_augment(const double* __restrict__ E, int lde, int n,
+                                                             double* __restrict__ P, int ldp,
+                                                             const double* __restrict__ dx,
+                                                             double* __restrict__ out /* [3] d cp */) {
+  extern __shared__ double Z[];  // n x 3
+  __shared__ double Ai[9], red[256 * 3];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    const double a00 = E[(size_t)(n + 1) * lde + n + 1], a01 = E[(size_t)(n + 1) * lde + n + 2];
+    const double a02 = E[(size_t)(n + 1) * lde + n + 3], a11 = E[(size_t)(n + 2) * lde + n + 2];
+    const double a12 = E[(size_t)(n + 2) * lde + n + 3], a22 = E[(size_t)(n + 3) * lde + n + 3];
+    const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+    Ai[0] = c00 * id;
+    Ai[1] = c01 * id;
+    Ai[2] = c02 * id;
+    Ai[3] = Ai[1];
+    Ai[4] = (a00 * a22 - a02 * a02) * id;
+    Ai[5] = (a01 * a02 - a00 * a12) * id;
+    Ai[6] = Ai[2];
+    Ai[7] = Ai[5];
+    Ai[8] = (a00 * a11 - a01 * a01) * id;
+  }
+  __syncthreads();
+  for (int r = t; r < n; r += 256) {
+    const double x0 = E[(size_t)r * lde + n + 1], x1 = E[(size_t)r * lde + n + 2], x2 = E[(size_t)r * lde + n + 3];
+    Z[3 * r + 0] = x0 * Ai[0] + x1 * Ai[3] + x2 * Ai[6];
+    Z[3 * r + 1] = x0 * Ai[1] + x1 * Ai[4] + x2 * Ai[7];
+    Z[3 * r + 2] = x0 * Ai[2] + x1 * Ai[5] + x2 * Ai[8];
+  }
+  __syncthreads();
+  // Sigma_xc rows and the partial sums of Z^T Sigma_xc (3x3) and Ecx dx (3)
+  double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = t; r < n; r += 256) {
+    const double* pr = P + (size_t)r * ldp;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < n; ++c) {
+      const double pv = pr[c];
+      s0 = fma(pv, Z[3 * c + 0], s0);
+      s1 = fma(pv, Z[3 * c + 1], s1);
+      s2 = fma(pv, Z[3 * c + 2], s2);
+    }
+    const double v[3] = {-s0, -s1, -s2};
+    for (int k = 0; k < 3; ++k) {
+      P[(size_t)r * ldp + n + k] = v[k];
+      P[(size_t)(n + k) * ldp + r] = v[k];
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) acc[3 * i + j] += Z[3 * r + i] * v[j];
+    const double dxr = dx[r];
+    acc[9] += E[(size_t)r * lde + n + 1] * dxr;
+    acc[10] += E[(size_t)r * lde + n + 2] * dxr;
+    acc[11] += E[(size_t)r * lde + n + 3] * dxr;
+  }
+  __shared__ double tot[12];
+  for (int q = 0; q < 12; q += 3) {
+    red[t] = acc[q];
+    red[256 + t] = acc[q + 1];
+    red[512 + t] = acc[q + 2];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) {
+        red[t] += red[t + s];
+        red[256 + t] += red[256 + t + s];
+        red[512 + t] += red[512 + t + s];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      tot[q] = red[0];
+      tot[q + 1] = red[256];
+      tot[q + 2] = red[512];
+    }
+    __syncthreads();
+  }
+  if (t < 9) {
+    const int i = t / 3, j = t - 3 * i;
+    // Sigma_cc = Ecc^-1 - Z^T Sigma_xc  (symmetrised)
+    const double v = Ai[t] - 0.5 * (tot[3 * i + j] + tot[3 * j + i]);
+    P[(size_t)(n + i) * ldp + n + j] = v;
+  }
+  if (t < 3) {
+    const double b0 = E[(size_t)n * lde + n + 1] - tot[9], b1 = E[(size_t)n * lde + n + 2] - tot[10];
+    const double b2 = E[(size_t)n * lde + n + 3] - tot[11];
+    out[t] = Ai[3 * t] * b0 + Ai[3 * t + 1] * b1 + Ai[3 * t + 2] * b2;
+  }
+}
+
 }  // namespace ovp
 
 extern "C" {
+
+hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
+                                         hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_plane_init_augment, dim3(1), dim3(256), (size_t)3 * n * sizeof(double), stream, E, lde, n, P, ldp,
+                     dx, out);
+  return hipGetLastError();
+}
 
 hipError_t ovp_launch_plane_feat(const ovp::FeatParams* p, const ovp::PlaneParams* pp, int n_local,
                                  hipStream_t stream) {

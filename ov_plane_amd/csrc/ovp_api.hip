@@ -50,6 +50,8 @@ hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const doubl
                                      hipStream_t stream);
 hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
                                  int n_involved, double* res_out, hipStream_t stream);
+hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
+                                         hipStream_t stream);
 hipError_t ovp_launch_plane_commit(const double* res, const double* V, double* M, int n, int ld, const double* dx,
                                    double* dx_out, double* clone_R, double* clone_p, const int* clone_id, int n_clones,
                                    double* cal, int calib_id, int intr_id, double* cp, const int* plane_sid,
@@ -671,6 +673,81 @@ extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx
   return ovp_msckf_fetch_results(c, dx_host, accepted_host, chi2_host, info);
 }
 
+// device sequence shared by the plane update and the plane initialisation: feature kernel, Gram reduction, reduction to the
+// state columns, range-energy factorisation, information-form update with the factor Mf (P = Mf Mf^T), gate.
+// Leaves: V in c->Y, dx in c->dx, [chi2, ok, n_deg, pr] in c->pl_res + 4*pl, the extended Gram in c->pl_E.
+static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::FeatParams& fp, int pl, int start, int nf,
+                            int in_state, int sid, double white_c, const double* Mf, int factor_dense, double thr,
+                            int rows_total, int rows_u, int n_involved) {
+  const int n = c->n, ld = c->ld, ldg = c->ldg;
+  hipStream_t s = c->stream;
+  ovp::PlaneParams pp;
+  pp.feat_list = c->pl_featlist + start;
+  pp.n_local = nf;
+  pp.plane = pl;
+  pp.in_state = in_state;
+  pp.plane_sid = sid;
+  pp.white_c = white_c;
+  pp.cp = c->pl_cp;
+  pp.cp_fej = c->pl_cp_fej;
+  pp.cst = c->pl_cst;
+  ovp::FeatParams fpl = fp;
+  fpl.n = n;
+  fpl.P = c->P;
+  HIPCHK(ovp_launch_plane_feat(&fpl, &pp, nf, s));
+  const int chunks = (2 * nf + c->rows_per_chunk - 1) / c->rows_per_chunk;
+  HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, nf, c->rows_per_chunk, chunks, c->gramS, s));
+  HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, chunks, c->gramR, s));
+  int nsplit = (3 * nf + 511) / 512;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > c->n_split) nsplit = c->n_split;
+  HIPCHK(ovp_launch_syrk(c->G, 3 * nf, ldg, n + 4, nsplit, c->part, s));
+  HIPCHK(ovp_launch_reduce_cst(c->pl_cst, nf, c->pl_cstsum, s));
+  HIPCHK(ovp_launch_assemble_ext(c->gramR, fp.n_clones, c->part, nsplit, c->colmap, n, sid, c->pl_cstsum, c->pl_E, ldg, s));
+  HIPCHK(ovp_launch_plane_reduce_to_state(c->pl_E, ldg, n, in_state, c->Ab, ld, c->pl_cstsum + 9, c->pl_scal, s));
+  // range part of the residual (regularised, diagonally normalised)
+  HIPCHK(ovp_launch_normalize_reg(c->Ab, ld, n, 1e-10, c->pl_An, c->pl_bn, s));
+  HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, n, ld, c->flags + 2, 0, s));
+  HIPCHK(ovp_launch_range_energy(c->pl_Lr, c->pl_Dinv2, c->pl_bn, n, ld, 1e-8, c->pl_scal, s));
+  // EKF update in information form with the chained factor
+  HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
+  HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
+  HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, s));
+  HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
+  HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
+  HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_total, rows_u, n_involved, c->pl_res + 4 * pl, s));
+  return 0;
+}
+
+static int plane_buffers(ovp_ctx* c, int NP) {
+  const int ld = c->ld;
+  if (NP > c->pl_cap || !c->pl_E) {
+    void* olds[] = {c->pl_sid, c->pl_cp, c->pl_cp_fej, c->pl_res, c->pl_dx};
+    for (void* p : olds)
+      if (p) hipFree(p);
+    const int cap = NP + 8;
+    HIPCHK(dalloc(&c->pl_sid, (size_t)cap));
+    HIPCHK(dalloc(&c->pl_cp, (size_t)3 * cap));
+    HIPCHK(dalloc(&c->pl_cp_fej, (size_t)3 * cap));
+    HIPCHK(dalloc(&c->pl_res, (size_t)4 * cap));
+    HIPCHK(dalloc(&c->pl_dx, (size_t)c->n_max * cap));
+    c->pl_cap = cap;
+    if (!c->pl_E) {
+      const size_t ne = (size_t)(c->n_max + 4) * c->ldg;
+      HIPCHK(dalloc(&c->pl_featlist, (size_t)c->f_max));
+      HIPCHK(dalloc(&c->pl_cst, (size_t)c->f_max * 10));
+      HIPCHK(dalloc(&c->pl_cstsum, 16));
+      HIPCHK(dalloc(&c->pl_E, ne));
+      HIPCHK(dalloc(&c->pl_An, (size_t)(c->n_max + 1) * ld));
+      HIPCHK(dalloc(&c->pl_bn, (size_t)c->n_max));
+      HIPCHK(dalloc(&c->pl_Lr, (size_t)(c->n_max + 1) * ld));
+      HIPCHK(dalloc(&c->pl_Dinv2, (size_t)(ld / 16 + 1) * 256));
+      HIPCHK(dalloc(&c->pl_scal, 8));
+    }
+  }
+  return 0;
+}
+
 // ---- UpdaterMSCKF::update, per-plane loop ------------------------------------------------------
 extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
                                       uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
@@ -728,30 +805,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (j.nf > max_nf) max_nf = j.nf;
     jobs.push_back(j);
   }
-  // ---- device buffers ----
-  if (NP > c->pl_cap || !c->pl_E) {
-    void* olds[] = {c->pl_sid, c->pl_cp, c->pl_cp_fej, c->pl_res, c->pl_dx};
-    for (void* p : olds) if (p) hipFree(p);
-    const int cap = NP + 8;
-    HIPCHK(dalloc(&c->pl_sid, (size_t)cap));
-    HIPCHK(dalloc(&c->pl_cp, (size_t)3 * cap));
-    HIPCHK(dalloc(&c->pl_cp_fej, (size_t)3 * cap));
-    HIPCHK(dalloc(&c->pl_res, (size_t)4 * cap));
-    HIPCHK(dalloc(&c->pl_dx, (size_t)c->n_max * cap));
-    c->pl_cap = cap;
-    if (!c->pl_E) {
-      const size_t ne = (size_t)(c->n_max + 4) * c->ldg;
-      HIPCHK(dalloc(&c->pl_featlist, (size_t)c->f_max));
-      HIPCHK(dalloc(&c->pl_cst, (size_t)c->f_max * 10));
-      HIPCHK(dalloc(&c->pl_cstsum, 16));
-      HIPCHK(dalloc(&c->pl_E, ne));
-      HIPCHK(dalloc(&c->pl_An, (size_t)(c->n_max + 1) * ld));
-      HIPCHK(dalloc(&c->pl_bn, (size_t)c->n_max));
-      HIPCHK(dalloc(&c->pl_Lr, (size_t)(c->n_max + 1) * ld));
-      HIPCHK(dalloc(&c->pl_Dinv2, (size_t)(ld / 16 + 1) * 256));
-      HIPCHK(dalloc(&c->pl_scal, 8));
-    }
-  }
+  rc = plane_buffers(c, NP);
+  if (rc) return rc;
   hipStream_t s = c->stream;
   HIPCHK(hipMemsetAsync(c->pl_res, 0, sizeof(double) * 4 * NP, s));
   HIPCHK(hipMemsetAsync(c->pl_dx, 0, sizeof(double) * (size_t)n * NP, s));
@@ -768,40 +823,10 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (rc) return rc;
   }
   double* Mf = c->L;
-  const int ldg = c->ldg;
   for (const PlaneJob& j : jobs) {
-    ovp::PlaneParams pp;
-    pp.feat_list = c->pl_featlist + j.start;
-    pp.n_local = j.nf;
-    pp.plane = j.pl;
-    pp.in_state = j.in_state;
-    pp.plane_sid = j.sid;
-    pp.white_c = 1.0 / o->sigma_constraint;
-    pp.cp = c->pl_cp;
-    pp.cp_fej = c->pl_cp_fej;
-    pp.cst = c->pl_cst;
-    HIPCHK(ovp_launch_plane_feat(&fp, &pp, j.nf, s));
-    const int chunks = (2 * j.nf + c->rows_per_chunk - 1) / c->rows_per_chunk;
-    HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, j.nf, c->rows_per_chunk, chunks, c->gramS, s));
-    HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, chunks, c->gramR, s));
-    int nsplit = (3 * j.nf + 511) / 512;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > c->n_split) nsplit = c->n_split;
-    HIPCHK(ovp_launch_syrk(c->G, 3 * j.nf, ldg, n + 4, nsplit, c->part, s));
-    HIPCHK(ovp_launch_reduce_cst(c->pl_cst, j.nf, c->pl_cstsum, s));
-    HIPCHK(ovp_launch_assemble_ext(c->gramR, fp.n_clones, c->part, nsplit, c->colmap, n, j.sid, c->pl_cstsum, c->pl_E, ldg, s));
-    HIPCHK(ovp_launch_plane_reduce_to_state(c->pl_E, ldg, n, j.in_state, c->Ab, ld, c->pl_cstsum + 9, c->pl_scal, s));
-    // range part of the residual (regularised, diagonally normalised)
-    HIPCHK(ovp_launch_normalize_reg(c->Ab, ld, n, 1e-10, c->pl_An, c->pl_bn, s));
-    HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, n, ld, c->flags + 2, 0, s));
-    HIPCHK(ovp_launch_range_energy(c->pl_Lr, c->pl_Dinv2, c->pl_bn, n, ld, 1e-8, c->pl_scal, s));
-    // EKF update in information form with the chained factor
-    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
-    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
-    HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, s));
-    HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, Mf, c->Y, n, ld, 1, s));
-    HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
-    HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, j.thr, j.rows_total, j.rows_u, j.n_involved, c->pl_res + 4 * j.pl, s));
+    rc = plane_job_device(c, o, fp, j.pl, j.start, j.nf, j.in_state, j.sid, 1.0 / o->sigma_constraint, Mf, 1, j.thr, j.rows_total,
+                          j.rows_u, j.n_involved);
+    if (rc) return rc;
     HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * j.pl, c->Y, Mf, n, ld, c->dx, c->pl_dx + (size_t)j.pl * n, c->clone_R,
                                    c->clone_p, c->clone_id, fp.n_clones, c->cal, o->do_calib_camera_pose ? c->calib_id : -1,
                                    o->do_calib_camera_intrinsics ? c->intr_id : -1, c->pl_cp, c->pl_sid, NP, s));
@@ -829,6 +854,96 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       for (int k = 0; k < j.nf; ++k) feat_used[featlist[j.start + k]] = 1;
   }
   if (c->h_flags[0]) return OVP_E_NOTSPD;
+  return 0;
+}
+
+// ---- UpdaterPlane::init_vio_plane core ----------------------------------------------------------
+extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double const_init_multi,
+                              double const_init_chi2, double* dx_planes, int dx_stride, uint8_t* plane_ok, double* plane_chi2,
+                              int* plane_dof, int* new_ids, double* cp_new, uint8_t* feat_used) {
+  if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
+  if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
+  if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;
+  const int ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
+  if (feat_used) memset(feat_used, 0, (size_t)F);
+  for (int pl = 0; pl < NP; ++pl) {
+    if (plane_ok) plane_ok[pl] = 0;
+    if (plane_chi2) plane_chi2[pl] = 0.0;
+    if (plane_dof) plane_dof[pl] = 0;
+    if (new_ids) new_ids[pl] = -1;
+    if (cp_new) memcpy(cp_new + 3 * pl, pb->cp + 3 * pl, 3 * sizeof(double));
+    if (dx_planes) memset(dx_planes + (size_t)pl * dx_stride, 0, sizeof(double) * dx_stride);
+  }
+  if (NP == 0) return 0;
+  int rc = fill_feat_params(c, o);
+  if (rc) return rc;
+  rc = plane_buffers(c, NP);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const int ncal = (o->do_calib_camera_pose ? 6 : 0) + (o->do_calib_camera_intrinsics ? 8 : 0);
+  std::vector<int> sid(NP, -1);
+  HIPCHK(hipMemcpyAsync(c->pl_sid, sid.data(), sizeof(int) * NP, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->pl_cp, pb->cp, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->pl_cp_fej, pb->cp, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<double> res4(4), dxh(c->n_max), dcp(3);
+  for (int pl = 0; pl < NP; ++pl) {
+    const int n = c->n;
+    if (n > OVP_TILECHOL_NMAX || n + 3 > c->n_max) return OVP_E_CAPACITY;
+    std::vector<int> featlist;
+    int rows_total = 0;
+    unsigned long long seen = 0ull;
+    for (int f = 0; f < F; ++f) {
+      if (pb->plane_of_feat[f] != pl + 1) continue;
+      const int m = c->h_n_meas[f];
+      if (m < 2) continue;
+      if (m > 31) return OVP_E_CAPACITY;
+      featlist.push_back(f);
+      rows_total += 3 * m - 3;
+      for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
+    }
+    const int nf = (int)featlist.size();
+    if (nf < 3) continue;  // update/UpdaterPlane.cpp:303
+    const int c_ref = 6 * __builtin_popcountll(seen) + ncal;
+    const int rows_c = rows_total > c_ref ? c_ref : rows_total;
+    if (rows_c - 3 < 1) continue;
+    // the chi2 of StateHelper::initialize covers the rows that do not involve the plane, with dof = all rows (:471)
+    const double thr = const_init_chi2 * ovp_chi2_quantile_095(rows_c);
+    HIPCHK(hipMemcpyAsync(c->pl_featlist, featlist.data(), sizeof(int) * nf, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+    HIPCHK(hipMemsetAsync(c->pl_res + 4 * pl, 0, sizeof(double) * 4, s));
+    rc = chol_of_P(c, s);
+    if (rc) return rc;
+    ovp::FeatParams fp = c->fp;
+    rc = plane_job_device(c, o, fp, pl, 0, nf, 0, -1, 1.0 / (const_init_multi * o->sigma_constraint), c->L, 0, thr, rows_total - 3,
+                          rows_c - 3, c_ref);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(res4.data(), c->pl_res + 4 * pl, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->h_flags[0]) return OVP_E_NOTSPD;
+    if (plane_chi2) plane_chi2[pl] = res4[0];
+    if (plane_dof) plane_dof[pl] = rows_c;
+    if (res4[1] < 0.5) continue;  // chi2 rejected: StateHelper::initialize returns false
+    // accepted: P <- P+ = V^T V, append the plane, update the device tables like Type::update would
+    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, s));
+    HIPCHK(ovp_launch_plane_init_augment(c->pl_E, c->ldg, n, c->P, ld, c->dx, c->pl_scal + 4, s));
+    HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * pl, c->Y, c->W1 /* factor not chained here */, n, ld, c->dx,
+                                   c->pl_dx + (size_t)pl * c->n_max, c->clone_R, c->clone_p, c->clone_id, fp.n_clones, c->cal,
+                                   o->do_calib_camera_pose ? c->calib_id : -1, o->do_calib_camera_intrinsics ? c->intr_id : -1,
+                                   c->pl_cp, c->pl_sid, 0, s));
+    HIPCHK(hipMemcpyAsync(dxh.data(), c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(dcp.data(), c->pl_scal + 4, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->n = n + 3;
+    if (plane_ok) plane_ok[pl] = 1;
+    if (new_ids) new_ids[pl] = n;
+    if (cp_new)
+      for (int k = 0; k < 3; ++k) cp_new[3 * pl + k] = pb->cp[3 * pl + k] + dcp[k];
+    if (dx_planes) memcpy(dx_planes + (size_t)pl * dx_stride, dxh.data(), sizeof(double) * (n < dx_stride ? n : dx_stride));
+    if (feat_used)
+      for (int f : featlist) feat_used[f] = 1;
+  }
   return 0;
 }
 

@@ -401,3 +401,40 @@ def test_host_cpp_initialize_matches_oracle(hiplib, oracle, r_iso, chi2_mult, ex
         cid = sc.ids["clones"][i]
         assert np.abs(out["clone_p"][i] - (sc.clone_p[i] + dx[cid + 3:cid + 6])).max() < TOL_DX
         assert np.abs(out["clone_q"][i] - quat_boxplus(sc.clone_q[i], dx[cid:cid + 3])).max() < TOL_DX
+
+
+@pytest.mark.parametrize("kw,chi2", [
+    (dict(C=11, F=140, seed=15, n_planes=3, feats_per_plane=30, planes_in_state_frac=0.0, chi2_mult=1.0), 1e9),
+    (dict(C=8, F=80, seed=16, n_planes=2, feats_per_plane=25, planes_in_state_frac=0.0, chi2_mult=1.0, ragged=True), 1e9),
+])
+def test_plane_initialisation_matches_oracle(hiplib, oracle, kw, chi2):
+    """UpdaterPlane::init_vio_plane core (update/UpdaterPlane.cpp:296-481) -> StateHelper::initialize: every accepted plane
+    appends 3 columns; state correction, plane value and the augmented covariance against the restatement."""
+    sc = make_scene(**kw)
+    ref = oracle.plane_init(sc, const_init_multi=5.0, const_init_chi2=chi2)
+    ctx = hiplib.Context(sc.N + 3 * sc.cp.shape[0], sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_init(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, 5.0, chi2)
+    assert (out["ok"] == ref["plane_ok"]).all() and out["ok"].all()
+    assert (out["new_ids"] == ref["new_id"]).all()
+    assert (out["dof"] == ref["plane_dof"]).all()
+    assert (out["used"] == ref["used"]).all()
+    assert np.abs(out["cp"] - ref["cp"]).max() < TOL_DX
+    from ov_plane_amd.synth import quat_boxplus
+
+    cq, cpos, intr = sc.clone_q.copy(), sc.clone_p.copy(), sc.intr.copy()
+    for pl in range(sc.cp.shape[0]):
+        dx = out["dx"][pl]
+        for i in range(sc.C):
+            cid = sc.ids["clones"][i]
+            cq[i] = quat_boxplus(cq[i], dx[cid:cid + 3])
+            cpos[i] = cpos[i] + dx[cid + 3:cid + 6]
+        intr = intr + dx[22:30]
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX
+    P = ctx.cov_download()
+    assert P.shape == ref["P"].shape
+    assert relP(P, ref["P"]) < TOL_P
+    ctx.close()
