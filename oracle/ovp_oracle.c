@@ -265,7 +265,8 @@ int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_
   const int *cidx = fb->clone_idx + (size_t)f * fb->max_meas;
   const float *uv = fb->uv + (size_t)f * fb->max_meas * 2;
   const double *p_FinG = fb->p_FinG + (size_t)f * 3;
-  const double *p_FinG_fej = p_FinG; /* UpdaterMSCKF.cpp:499-500,721-722 */
+  /* MSCKF features: fej == value (UpdaterMSCKF.cpp:499-500,721-722); SLAM landmarks carry their first estimate */
+  const double *p_FinG_fej = fb->p_FinG_fej ? fb->p_FinG_fej + (size_t)f * 3 : p_FinG;
 
   /* column bookkeeping :205-277 */
   int n_order = 0, total_hx = 0;
@@ -1266,6 +1267,10 @@ int ovo_plane_init(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *f
       new_id[pl] = n;
       *n_io = nn;
       for (int q = 0; q < 3; ++q) cp_out[3 * pl + q] = cp_in[3 * pl + q] + delta[q];
+      /* planes initialised earlier in this call are state variables now and receive this update's correction */
+      for (int g = 0; g < pl; ++g)
+        if (new_id[g] >= 0)
+          for (int q = 0; q < 3; ++q) cp_out[3 * g + q] += dx[new_id[g] + q];
       for (int f = 0; f < F; ++f)
         if (plane_of_feat[f] == planeid && fb->n_meas[f] >= 2) used[f] = 1;
       /* Type::update of the pre-existing variables with the EKF correction of the update rows */
@@ -1291,6 +1296,194 @@ int ovo_plane_init(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *f
   free(map_col);
   free(order_big_id);
   free(order_big_size);
+  free(dx);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterSLAM.cpp:376-682
+ * ------------------------------------------------------------------------------------------- */
+static double chi2_of(const double *P, int n, const double *H, int rows, int cols, const int *oid, const int *osz, int no,
+                      const double *res) {
+  double *Pm = (double *)malloc(sizeof(double) * (size_t)cols * cols);
+  ovo_marginal_cov(P, n, oid, osz, no, Pm);
+  double *HP = (double *)calloc((size_t)rows * cols, sizeof(double));
+  for (int k = 0; k < cols; ++k)
+    for (int j = 0; j < cols; ++j) {
+      const double pv = CM(Pm, cols, k, j);
+      for (int i = 0; i < rows; ++i) CM(HP, rows, i, j) += CM(H, rows, i, k) * pv;
+    }
+  double *S = (double *)calloc((size_t)rows * rows, sizeof(double));
+  for (int i = 0; i < rows; ++i) CM(S, rows, i, i) = 1.0;
+  for (int k = 0; k < cols; ++k)
+    for (int j = 0; j < rows; ++j) {
+      const double hv = CM(H, rows, j, k);
+      for (int i = 0; i < rows; ++i) CM(S, rows, i, j) += CM(HP, rows, i, k) * hv;
+    }
+  double chi2 = 1e300;
+  if (!ovo_llt(S, rows, rows)) {
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)rows);
+    memcpy(tmp, res, sizeof(double) * (size_t)rows);
+    llt_solve_vec(S, rows, rows, tmp);
+    chi2 = 0.0;
+    for (int i = 0; i < rows; ++i) chi2 += res[i] * tmp[i];
+    free(tmp);
+  }
+  free(Pm);
+  free(HP);
+  free(S);
+  return chi2;
+}
+
+int ovo_slam_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *lm_id, const int *plane_of_feat,
+                    int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P, double *dx,
+                    uint8_t *accepted, double *chi2_out, uint8_t *fellback) {
+  const int n = st->n_state, F = fb->n_feats, mm = fb->max_meas;
+  size_t max_meas = 0;
+  for (int f = 0; f < F; ++f) max_meas += 3 * (size_t)fb->n_meas[f];
+  if (max_meas == 0) max_meas = 1;
+  double *res_big = (double *)calloc(max_meas, sizeof(double));
+  double *Hx_big = (double *)calloc(max_meas * (size_t)n, sizeof(double));
+  int *map_col = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) map_col[i] = -1;
+  int *obig_id = (int *)malloc(sizeof(int) * (size_t)(st->n_clones + F + 8));
+  int *obig_sz = (int *)malloc(sizeof(int) * (size_t)(st->n_clones + F + 8));
+  int n_obig = 0;
+  size_t ct_jacob = 0, ct_meas = 0;
+  const int maxrows = 3 * mm + 1, maxcols = 6 * mm + 14 + 3 + 3;
+  double *H_f = (double *)malloc(sizeof(double) * (size_t)maxrows * 6);
+  double *H_x = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *H_xf = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *res = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  int *oid = (int *)malloc(sizeof(int) * (size_t)(mm + 6));
+  int *osz = (int *)malloc(sizeof(int) * (size_t)(mm + 6));
+  for (int i = 0; i < n; ++i) dx[i] = 0.0;
+  for (int f = 0; f < F; ++f) {
+    accepted[f] = 0;
+    chi2_out[f] = 0.0;
+    fellback[f] = 0;
+    if (fb->n_meas[f] < 1) continue; /* :416-418 */
+    int planeid = 0, psid = -1;
+    const double *cpv = NULL, *cpf = NULL;
+    if (n_planes > 0 && plane_of_feat && plane_of_feat[f] > 0 && plane_state_id[plane_of_feat[f] - 1] >= 0) { /* :465-475 */
+      planeid = plane_of_feat[f];
+      psid = plane_state_id[planeid - 1];
+      cpv = cp + 3 * (planeid - 1);
+      cpf = cp_fej + 3 * (planeid - 1);
+    }
+    int rows = 0, cols = 0, hfc = 0, no = 0;
+    double chi2 = 0.0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      ovo_feature_jacobian_full(o, st, fb, f, o->sigma_constraint, planeid, cpv, cpf, psid, H_f, H_x, res, &rows, &cols, &hfc, oid,
+                                osz, &no);
+      /* :517-522 append the landmark columns */
+      memcpy(H_xf, H_x, sizeof(double) * (size_t)rows * cols);
+      memcpy(H_xf + (size_t)rows * cols, H_f, sizeof(double) * (size_t)rows * 3);
+      oid[no] = lm_id[f];
+      osz[no] = 3;
+      ++no;
+      cols += 3;
+      chi2 = chi2_of(P, n, H_xf, rows, cols, oid, osz, no, res); /* :529-532 */
+      const double thr = o->chi2_multiplier * ovo_chi2_quantile_095(rows);
+      if (planeid != 0 && chi2 > thr) { /* :547-553 fallback without the plane */
+        planeid = 0;
+        psid = -1;
+        fellback[f] = 1;
+        continue;
+      }
+      break;
+    }
+    chi2_out[f] = chi2;
+    if (chi2 > o->chi2_multiplier * ovo_chi2_quantile_095(rows)) continue; /* :596-619 */
+    accepted[f] = 1;
+    int ct_hx = 0;
+    for (int v = 0; v < no; ++v) {
+      if (map_col[oid[v]] < 0) {
+        map_col[oid[v]] = (int)ct_jacob;
+        obig_id[n_obig] = oid[v];
+        obig_sz[n_obig++] = osz[v];
+        ct_jacob += (size_t)osz[v];
+      }
+      for (int cc = 0; cc < osz[v]; ++cc)
+        for (int i = 0; i < rows; ++i) CM(Hx_big, max_meas, ct_meas + i, map_col[oid[v]] + cc) = CM(H_xf, rows, i, ct_hx + cc);
+      ct_hx += osz[v];
+    }
+    for (int i = 0; i < rows; ++i) res_big[ct_meas + i] = res[i];
+    ct_meas += (size_t)rows;
+  }
+  int rc = 0;
+  if (ct_meas >= 1) {
+    double *Hc = (double *)malloc(sizeof(double) * ct_meas * (ct_jacob ? ct_jacob : 1));
+    for (size_t j = 0; j < ct_jacob; ++j) memcpy(Hc + j * ct_meas, Hx_big + j * max_meas, sizeof(double) * ct_meas);
+    int neg = 0;
+    rc = ovo_ekf_update(P, n, obig_id, obig_sz, n_obig, Hc, (int)ct_meas, (int)ct_meas, res_big, dx, &neg); /* :673 */
+    free(Hc);
+  }
+  free(res_big);
+  free(Hx_big);
+  free(map_col);
+  free(obig_id);
+  free(obig_sz);
+  free(H_f);
+  free(H_x);
+  free(H_xf);
+  free(res);
+  free(oid);
+  free(osz);
+  return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterSLAM.cpp:204-364
+ * ------------------------------------------------------------------------------------------- */
+int ovo_slam_delayed_init(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, double *P, int n_cap, int *n_io,
+                          ovo_state_values *val, uint8_t *ok, double *chi2_out, int *new_id, double *p_out) {
+  const int F = fb->n_feats, mm = fb->max_meas;
+  const int maxrows = 3 * mm + 1, maxcols = 6 * mm + 14 + 3;
+  double *H_f = (double *)malloc(sizeof(double) * (size_t)maxrows * 6);
+  double *H_x = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *res = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  int *oid = (int *)malloc(sizeof(int) * (size_t)(mm + 6));
+  int *osz = (int *)malloc(sizeof(int) * (size_t)(mm + 6));
+  double *dx = (double *)malloc(sizeof(double) * (size_t)n_cap);
+  for (int f = 0; f < F; ++f) {
+    ok[f] = 0;
+    chi2_out[f] = 0.0;
+    new_id[f] = -1;
+    for (int q = 0; q < 3; ++q) p_out[3 * f + q] = fb->p_FinG[3 * f + q];
+    if (fb->n_meas[f] < 2) continue; /* :112-118 */
+    ovo_state st = *st_in;
+    st.n_state = *n_io;
+    st.clone_q = val->clone_q;
+    st.clone_p = val->clone_p;
+    memcpy(st.calib_q, val->calib_q, sizeof(st.calib_q));
+    memcpy(st.calib_p, val->calib_p, sizeof(st.calib_p));
+    memcpy(st.intrinsics, val->intrinsics, sizeof(st.intrinsics));
+    int rows, cols, hfc, no;
+    ovo_feature_jacobian_full(o, &st, fb, f, o->sigma_constraint, 0, NULL, NULL, -1, H_f, H_x, res, &rows, &cols, &hfc, oid, osz, &no);
+    double delta[3], chi2 = 0.0;
+    int dof = 0, nn = *n_io;
+    const int r = ovo_initialize(P, n_cap, &nn, oid, osz, no, H_x, H_f, rows, 3, 1.0, res, o->chi2_multiplier, 1, delta, dx, &chi2,
+                                 &dof); /* :304 */
+    chi2_out[f] = chi2;
+    if (r == 1) {
+      ok[f] = 1;
+      new_id[f] = *n_io;
+      *n_io = nn;
+      for (int q = 0; q < 3; ++q) p_out[3 * f + q] = fb->p_FinG[3 * f + q] + delta[q];
+      /* landmarks initialised earlier in this call are ordinary state variables now: the EKF update inside
+       * StateHelper::initialize corrects them too (Type::update through StateHelper::EKFUpdate) */
+      for (int g = 0; g < f; ++g)
+        if (new_id[g] >= 0)
+          for (int q = 0; q < 3; ++q) p_out[3 * g + q] += dx[new_id[g] + q];
+      ovo_apply_dx(st_in, 0, NULL, dx, val);
+    }
+  }
+  free(H_f);
+  free(H_x);
+  free(res);
+  free(oid);
+  free(osz);
   free(dx);
   return 0;
 }

@@ -59,6 +59,7 @@ typedef struct {
   const int *clone_idx;  /* [n_feats*max_meas]    index into the clone tables, -1 = padding */
   const int *n_meas;     /* [n_feats] */
   const double *p_FinG;  /* [n_feats*3]  linearisation point (fej == value for MSCKF feats) */
+  const double *p_FinG_fej; /* [n_feats*3] or NULL: first-estimate position of in-state (SLAM) landmarks */
 } ovo_feats;
 
 /* ---- small building blocks (exported so tests can pin them individually) ---------------------- */
@@ -131,12 +132,29 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st, const ovo_fea
                            int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
                            ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows);
 
+/* update/UpdaterSLAM.cpp:376-682 (GLOBAL_3D landmarks already in the state, no ArUco): per feature Jacobian with the
+ * landmark columns appended, optional point-on-plane rows for in-state planes with the no-plane fallback (:547-609),
+ * per-feature chi2, stacking in first-seen order, ONE StateHelper::EKFUpdate without compression.
+ * lm_id[f] = Type::id() of the landmark of feature f; plane arrays may be NULL (n_planes = 0).
+ * Outputs: dx[n], P in place, accepted[F], chi2[F], fellback[F] (plane constraint dropped for that feature). */
+int ovo_slam_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *lm_id, const int *plane_of_feat,
+                    int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P, double *dx,
+                    uint8_t *accepted, double *chi2, uint8_t *fellback);
+
+/* update/UpdaterSLAM.cpp:204-364 (core of delayed_init downstream of triangulation): features one by one,
+ * StateHelper::initialize(landmark, Hx_order, H_x, H_f, I, res, chi2_multipler); every success appends a 3-dof landmark,
+ * updates the state values (val) and P (n grows inside the n_cap storage).  new_id[f] = landmark id or -1,
+ * p_out[3f..] = landmark position at the end of the call (initial value + the corrections of later initialisations). */
+int ovo_slam_delayed_init(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, double *P, int n_cap, int *n,
+                          ovo_state_values *val, uint8_t *ok, double *chi2, int *new_id, double *p_out);
+
 /* update/UpdaterPlane.cpp:296-481: core of UpdaterPlane::init_vio_plane for planes that already have an estimate
  * (triangulation / RANSAC / Ceres refinement are upstream and out of scope): per plane, stack the on-plane MSCKF features
  * with sigma_c * const_init_multi, nullspace-project the 3 feature columns, compress with H_cp carried, then
  * StateHelper::initialize(plane, ..., const_init_chi2).  Planes are processed in ascending id; every success appends a
  * 3-dof plane to the state (P grows inside its n_cap x n_cap storage) and updates `val`.
- * Outputs per plane: ok, chi2, dof, new_id (Type::id() of the initialised plane or -1), cp_out[3] (its value). */
+ * Outputs per plane: ok, chi2, dof, new_id (Type::id() of the initialised plane or -1), cp_out[3] (its value at the end of
+ * the call, i.e. including the corrections it received from planes initialised after it). */
 int ovo_plane_init(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat, int n_planes,
                    const double *cp_in, double const_init_multi, double const_init_chi2, double *P, int n_cap, int *n,
                    ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_dof,

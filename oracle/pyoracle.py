@@ -50,6 +50,7 @@ class OvoFeats(C.Structure):
         ("clone_idx", C.POINTER(C.c_int)),
         ("n_meas", C.POINTER(C.c_int)),
         ("p_FinG", C.POINTER(C.c_double)),
+        ("p_FinG_fej", C.POINTER(C.c_double)),
     ]
 
 
@@ -120,6 +121,9 @@ class Packed:
         fb.clone_idx = _ip(self.clone_idx)
         fb.n_meas = _ip(self.n_meas)
         fb.p_FinG = _dp(self.p_FinG)
+        if "p_FinG_fej" in sc and sc["p_FinG_fej"] is not None:
+            self.p_FinG_fej = np.ascontiguousarray(sc["p_FinG_fej"][sel], dtype=np.float64)
+            fb.p_FinG_fej = _dp(self.p_FinG_fej)
         self.feats = fb
 
 
@@ -269,3 +273,54 @@ def plane_init(sc, const_init_multi=5.0, const_init_chi2=1.0, n_extra=None):
                 calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), used=used.astype(bool),
                 plane_ok=ok[:n_planes].astype(bool), plane_chi2=chi2[:n_planes], plane_dof=dof[:n_planes],
                 new_id=nid[:n_planes], cp=cp_out[:n_planes])
+
+
+def slam_update(sc, lm_id, use_planes=False):
+    """ovo_slam_update: features of the scene are observations of landmarks already in the state (ids lm_id[f])."""
+    L = lib()
+    pk = Packed(sc)
+    P = np.asfortranarray(sc.P.copy())
+    dx = np.zeros(sc.N)
+    acc = np.zeros(sc.F, dtype=np.uint8)
+    chi2 = np.zeros(sc.F)
+    fb = np.zeros(sc.F, dtype=np.uint8)
+    lm = np.ascontiguousarray(lm_id, dtype=np.int32)
+    u8 = C.POINTER(C.c_uint8)
+    npl = int(sc.cp.shape[0]) if use_planes else 0
+    pof = np.ascontiguousarray(sc.plane_id, dtype=np.int32)
+    cp = np.ascontiguousarray(sc.cp if npl else np.zeros((1, 3)), dtype=np.float64)
+    cpf = np.ascontiguousarray(sc.cp_fej if npl else np.zeros((1, 3)), dtype=np.float64)
+    sid = np.ascontiguousarray(sc.plane_state_id if npl else -np.ones(1), dtype=np.int32)
+    rc = L.ovo_slam_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(lm), _ip(pof), C.c_int(npl), _dp(cp),
+                           _dp(cpf), _ip(sid), _dp(P), _dp(dx), acc.ctypes.data_as(u8), _dp(chi2), fb.ctypes.data_as(u8))
+    return dict(rc=rc, P=np.ascontiguousarray(P), dx=dx, accepted=acc.astype(bool), chi2=chi2, fellback=fb.astype(bool))
+
+
+def slam_delayed_init(sc):
+    """ovo_slam_delayed_init on every feature of the scene (no planes)."""
+    L = lib()
+    pk = Packed(sc)
+    cap = sc.N + 3 * sc.F
+    P = np.zeros((cap, cap), order="F")
+    P[: sc.N, : sc.N] = sc.P
+    cq = np.ascontiguousarray(sc.clone_q.copy())
+    cpv = np.ascontiguousarray(sc.clone_p.copy())
+    dummy = np.zeros((1, 3))
+    val = OvoStateValues()
+    val.clone_q = _dp(cq)
+    val.clone_p = _dp(cpv)
+    val.calib_q[:] = list(sc.calib_q)
+    val.calib_p[:] = list(sc.calib_p)
+    val.intrinsics[:] = list(sc.intr)
+    val.cp = _dp(dummy)
+    ok = np.zeros(sc.F, dtype=np.uint8)
+    chi2 = np.zeros(sc.F)
+    nid = np.zeros(sc.F, dtype=np.int32)
+    pout = np.zeros((sc.F, 3))
+    nn = C.c_int(sc.N)
+    L.ovo_slam_delayed_init(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), C.c_int(cap), C.byref(nn),
+                            C.byref(val), ok.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _ip(nid), _dp(pout))
+    n2 = nn.value
+    return dict(P=np.ascontiguousarray(P[:n2, :n2]), n=n2, clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
+                calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), ok=ok.astype(bool), chi2=chi2, new_id=nid,
+                p=pout)

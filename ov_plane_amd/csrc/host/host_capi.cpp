@@ -206,3 +206,211 @@ extern "C" int ovph_run_initialize(int C, const double *clone_q, const double *c
   memcpy(out_intr, state->_cam_intrinsics.at(0)->value().data(), 8 * sizeof(double));
   return ok ? 1 : 0;
 }
+
+// ---- shared state construction for the SLAM / plane-init harnesses ----------------------------------
+namespace ov_plane {
+struct StateTestAccess {
+  static void replace_last_variable(std::shared_ptr<State> state, std::shared_ptr<Type> v) { state->_variables.back() = v; }
+};
+}  // namespace ov_plane
+
+namespace {
+struct HarnessState {
+  std::shared_ptr<State> state;
+  std::vector<double> times;
+  std::vector<std::shared_ptr<Landmark>> landmarks;
+  std::vector<std::shared_ptr<Vec>> planes;
+};
+
+// Order of the state: imu, dt, calib, intrinsics, clones (oldest first), SLAM landmarks, planes (= synth.state_layout).
+int build_harness_state(HarnessState &hs, StateOptions &so, int C, const double *clone_q, const double *clone_p,
+                        const double *clone_q_fej, const double *clone_p_fej, const double *calib_q, const double *calib_p,
+                        const double *intr, int n_slam, const double *slam_p, const double *slam_p_fej, int n_planes,
+                        const double *cp, const double *cp_fej, int N, const double *P) {
+  hs.state = std::make_shared<State>(so);
+  auto &state = hs.state;
+  VectorXd v(7, 1);
+  for (int k = 0; k < 4; ++k) v(k) = calib_q[k];
+  for (int k = 0; k < 3; ++k) v(4 + k) = calib_p[k];
+  state->_calib_IMUtoCAM.at(0)->set_value(v);
+  state->_calib_IMUtoCAM.at(0)->set_fej(v);
+  VectorXd iv(8, 1);
+  for (int k = 0; k < 8; ++k) iv(k) = intr[k];
+  state->_cam_intrinsics.at(0)->set_value(iv);
+  state->_cam_intrinsics.at(0)->set_fej(iv);
+  const double w0[3] = {0, 0, 0};
+  hs.times.resize(C);
+  for (int i = 0; i < C; ++i) {
+    VectorXd a(7, 1), af(7, 1);
+    for (int k = 0; k < 4; ++k) {
+      a(k) = clone_q[4 * i + k];
+      af(k) = clone_q_fej[4 * i + k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      a(4 + k) = clone_p[3 * i + k];
+      af(4 + k) = clone_p_fej[3 * i + k];
+    }
+    state->_imu->pose()->set_value(a);
+    state->_imu->pose()->set_fej(af);
+    hs.times[i] = 100.0 + 0.1 * i;
+    state->_timestamp = hs.times[i];
+    StateHelper::augment_clone(state, w0);
+  }
+  // 3-dof variables: grow the covariance through StateHelper::clone (the block is overwritten below), then swap the cloned
+  // Vec for the variable type the updaters expect at the same id
+  for (int k = 0; k < n_slam; ++k) {
+    std::shared_ptr<Type> t = StateHelper::clone(state, state->_imu->p());
+    auto lm = std::make_shared<Landmark>(3);
+    lm->set_local_id(t->id());
+    lm->_featid = 9000 + k;
+    lm->set_from_xyz(slam_p + 3 * k, false);
+    lm->set_from_xyz(slam_p_fej + 3 * k, true);
+    StateTestAccess::replace_last_variable(state, lm);
+    state->_features_SLAM[lm->_featid] = lm;
+    hs.landmarks.push_back(lm);
+  }
+  for (int k = 0; k < n_planes; ++k) {
+    auto pl = std::dynamic_pointer_cast<Vec>(StateHelper::clone(state, state->_imu->p()));
+    if (!pl) return -10;
+    VectorXd a(3, 1), af(3, 1);
+    for (int q = 0; q < 3; ++q) {
+      a(q) = cp[3 * k + q];
+      af(q) = cp_fej[3 * k + q];
+    }
+    pl->set_value(a);
+    pl->set_fej(af);
+    state->_features_PLANE[(size_t)(k + 1)] = pl;
+    hs.planes.push_back(pl);
+  }
+  if (state->max_covariance_size() != N) return -11;
+  std::vector<std::shared_ptr<Type>> order;
+  order.push_back(state->_imu);
+  order.push_back(state->_calib_dt_CAMtoIMU);
+  order.push_back(state->_calib_IMUtoCAM.at(0));
+  order.push_back(state->_cam_intrinsics.at(0));
+  for (auto &c : state->_clones_IMU) order.push_back(c.second);
+  for (auto &l : hs.landmarks) order.push_back(l);
+  for (auto &p : hs.planes) order.push_back(p);
+  MatrixXd Pm(N, N);
+  memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+  StateHelper::set_initial_covariance(state, Pm, order);
+  return 0;
+}
+
+std::vector<std::shared_ptr<ov_core::Feature>> make_features(const HarnessState &hs, int F, int M, const float *uv, const int *clone_idx,
+                                                             const int *n_meas, const double *p_FinG, size_t id0) {
+  std::vector<std::shared_ptr<ov_core::Feature>> fv;
+  for (int f = 0; f < F; ++f) {
+    auto ft = std::make_shared<ov_core::Feature>();
+    ft->featid = id0 + f;
+    for (int k = 0; k < n_meas[f]; ++k) {
+      ft->timestamps.push_back(hs.times[clone_idx[(size_t)f * M + k]]);
+      ft->uvs.push_back(uv[((size_t)f * M + k) * 2]);
+      ft->uvs.push_back(uv[((size_t)f * M + k) * 2 + 1]);
+    }
+    if (p_FinG) memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+    fv.push_back(ft);
+  }
+  return fv;
+}
+
+void export_state(const HarnessState &hs, double *out_clone_q, double *out_clone_p, double *out_calib_q, double *out_calib_p,
+                  double *out_intr, double *out_slam_p, double *out_cp, double *out_P, int *out_n) {
+  auto &state = hs.state;
+  int i = 0;
+  for (auto &c : state->_clones_IMU) {
+    memcpy(out_clone_q + 4 * i, c.second->quat(), 4 * sizeof(double));
+    memcpy(out_clone_p + 3 * i, c.second->pos(), 3 * sizeof(double));
+    ++i;
+  }
+  memcpy(out_calib_q, state->_calib_IMUtoCAM.at(0)->quat(), 4 * sizeof(double));
+  memcpy(out_calib_p, state->_calib_IMUtoCAM.at(0)->pos(), 3 * sizeof(double));
+  memcpy(out_intr, state->_cam_intrinsics.at(0)->value().data(), 8 * sizeof(double));
+  for (size_t k = 0; k < hs.landmarks.size(); ++k) memcpy(out_slam_p + 3 * k, hs.landmarks[k]->value().data(), 3 * sizeof(double));
+  for (size_t k = 0; k < hs.planes.size(); ++k) memcpy(out_cp + 3 * k, hs.planes[k]->value().data(), 3 * sizeof(double));
+  const int n2 = state->max_covariance_size();
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)n2 * n2);
+  *out_n = n2;
+}
+}  // namespace
+
+// mode 0: UpdaterSLAM::update (feature f observes landmark f, n_slam == F); mode 1: UpdaterSLAM::delayed_init (n_slam == 0,
+// out_new_p [F*3] / out_new_id [F] describe the landmarks that joined the state); mode 2: UpdaterPlane::init_vio_plane
+// (n_planes in-state planes must be 0; cp_out_est [n_planes_out*3] are the upstream plane estimates with ids 1..n).
+extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
+                                const double *clone_p_fej, const double *calib_q, const double *calib_p, const double *intr,
+                                int n_slam, const double *slam_p, const double *slam_p_fej, int n_planes, const double *cp,
+                                const double *cp_fej, int n_planes_out, const double *cp_out_est, int N, const double *P, int F,
+                                int M, const float *uv, const int *clone_idx, const int *n_meas, const double *p_FinG,
+                                const int *plane_of_feat, double sigma_px, double chi2_mult, double sigma_c, int do_fej,
+                                double const_init_multi, double const_init_chi2, int n_cap,
+                                /* outputs */ double *out_clone_q, double *out_clone_p, double *out_calib_q, double *out_calib_p,
+                                double *out_intr, double *out_slam_p, double *out_cp, double *out_P, int *out_n,
+                                unsigned char *feat_kept, unsigned char *feat_deleted, unsigned char *lm_should_marg,
+                                int *slam_to_plane, double *out_new_p, int *out_new_id) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.use_plane_constraint = so.use_plane_constraint_msckf = so.use_plane_constraint_slamu = so.use_plane_constraint_slamd = true;
+  so.sigma_constraint = sigma_c;
+  so.const_init_multi = const_init_multi;
+  so.const_init_chi2 = const_init_chi2;
+  so.max_state_size = n_cap;
+  so.max_features = F + 8;
+  HarnessState hs;
+  int rc = build_harness_state(hs, so, C, clone_q, clone_p, clone_q_fej, clone_p_fej, calib_q, calib_p, intr, n_slam, slam_p,
+                               slam_p_fej, n_planes, cp, cp_fej, N, P);
+  if (rc) return rc;
+  auto &state = hs.state;
+  const size_t id0 = (mode == 0) ? 9000 : 5000;
+  auto fv = make_features(hs, F, M, uv, clone_idx, n_meas, p_FinG, id0);
+  auto all = fv;
+  std::map<size_t, size_t> feat2plane;
+  for (int f = 0; f < F; ++f)
+    if (plane_of_feat && plane_of_feat[f] > 0) feat2plane[id0 + f] = (size_t)plane_of_feat[f];
+  UpdaterOptions uo, ua;
+  uo.sigma_pix = sigma_px;
+  uo.chi2_multipler = chi2_mult;
+  ua = uo;
+  ov_core::FeatureInitializerOptions fio;
+  if (mode == 0) {
+    UpdaterSLAM up(uo, ua, fio);
+    up.update(state, fv, feat2plane);
+  } else if (mode == 1) {
+    UpdaterSLAM up(uo, ua, fio);
+    up.delayed_init(state, fv, feat2plane);
+    for (int f = 0; f < F; ++f) {
+      out_new_id[f] = -1;
+      auto it = state->_features_SLAM.find(id0 + f);
+      if (it == state->_features_SLAM.end()) continue;
+      out_new_id[f] = it->second->id();
+      memcpy(out_new_p + 3 * f, it->second->value().data(), 3 * sizeof(double));
+    }
+  } else {
+    for (int k = 0; k < n_planes_out; ++k)
+      state->_plane_estimates_cp_inG[(size_t)(k + 1)] = {cp_out_est[3 * k], cp_out_est[3 * k + 1], cp_out_est[3 * k + 2]};
+    UpdaterPlane up(uo, fio);
+    std::vector<std::shared_ptr<ov_core::Feature>> used;
+    up.init_vio_plane(state, fv, used, feat2plane);
+    for (int k = 0; k < n_planes_out; ++k) {
+      out_new_id[k] = -1;
+      auto it = state->_features_PLANE.find((size_t)(k + 1));
+      if (it == state->_features_PLANE.end()) continue;
+      out_new_id[k] = it->second->id();
+      memcpy(out_new_p + 3 * k, it->second->value().data(), 3 * sizeof(double));
+    }
+  }
+  export_state(hs, out_clone_q, out_clone_p, out_calib_q, out_calib_p, out_intr, out_slam_p, out_cp, out_P, out_n);
+  for (int f = 0; f < F; ++f) {
+    feat_kept[f] = 0;
+    feat_deleted[f] = all[f]->to_delete ? 1 : 0;
+    slam_to_plane[f] = -1;
+    auto it = state->_features_SLAM_to_PLANE.find(id0 + f);
+    if (it != state->_features_SLAM_to_PLANE.end()) slam_to_plane[f] = (int)it->second;
+  }
+  for (auto &ft : fv) feat_kept[ft->featid - id0] = 1;
+  for (size_t k = 0; k < hs.landmarks.size(); ++k) lm_should_marg[k] = hs.landmarks[k]->should_marg ? 1 : 0;
+  return 0;
+}

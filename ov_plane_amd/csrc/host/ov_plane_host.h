@@ -24,7 +24,11 @@ struct StateOptions {
   int num_cameras = 1;
   bool use_plane_constraint = false;
   bool use_plane_constraint_msckf = false;
+  bool use_plane_constraint_slamu = false;
+  bool use_plane_constraint_slamd = false;
   double sigma_constraint = 0.01;
+  double const_init_multi = 1.0;
+  double const_init_chi2 = 1.0;
   // capacity of the device context (not in the reference: Eigen resizes dynamically)
   int max_state_size = 320;
   int max_features = 8192;
@@ -40,6 +44,8 @@ struct UpdaterOptions {
 class StateHelper;
 
 // state/State.h:48-135
+struct StateTestAccess;
+
 class State {
 public:
   explicit State(StateOptions &options_);
@@ -59,13 +65,17 @@ public:
   std::shared_ptr<ov_type::Vec> _calib_dt_CAMtoIMU;
   std::unordered_map<size_t, std::shared_ptr<ov_type::PoseJPL>> _calib_IMUtoCAM;
   std::unordered_map<size_t, std::shared_ptr<ov_type::Vec>> _cam_intrinsics;
+  std::unordered_map<size_t, std::shared_ptr<ov_type::Landmark>> _features_SLAM;
   std::unordered_map<size_t, std::shared_ptr<ov_type::Vec>> _features_PLANE;
+  std::unordered_map<size_t, size_t> _features_SLAM_to_PLANE;
   // out-of-state plane estimates the caller obtained upstream (PlaneFitting, out of scope here; UpdaterMSCKF.cpp:319-400)
   std::map<size_t, std::vector<double>> _plane_estimates_cp_inG;
 
 private:
   friend class StateHelper;
   friend class UpdaterMSCKF;
+  friend class UpdaterPlane;
+  friend struct StateTestAccess;  // host_capi.cpp harness: swaps a cloned Vec for a Landmark at the same id
   ovp_ctx *_gpu = nullptr;  // replaces Eigen::MatrixXd _Cov (state/State.h:130)
   std::vector<std::shared_ptr<ov_type::Type>> _variables;
 };
@@ -99,6 +109,54 @@ public:
 
 private:
   StateHelper() {}
+};
+
+// update/UpdaterHelper.h:55-157: host (dense) versions for the small SLAM / initialisation systems
+class UpdaterHelper {
+public:
+  struct UpdaterHelperFeature {  // update/UpdaterHelper.h:62-105, mono, GLOBAL_3D
+    size_t featid = 0;
+    std::vector<float> uvs;          // [2k]
+    std::vector<double> timestamps;  // [k]
+    double p_FinG[3] = {0, 0, 0}, p_FinG_fej[3] = {0, 0, 0};
+    size_t planeid = 0;
+    double cp_FinG[3] = {0, 0, 0}, cp_FinG_fej[3] = {0, 0, 0};
+  };
+  // update/UpdaterHelper.cpp:195-513
+  static void get_feature_jacobian_full(std::shared_ptr<State> state, UpdaterHelperFeature &feature, double sigma_px, double sigma_c,
+                                        MatrixXd &H_f, MatrixXd &H_x, VectorXd &res, std::vector<std::shared_ptr<ov_type::Type>> &x_order);
+  // update/UpdaterHelper.cpp:515-546
+  static void nullspace_project_inplace(MatrixXd &H_f, MatrixXd &H_x, VectorXd &res);
+  // update/UpdaterHelper.cpp:548-579
+  static void measurement_compress_inplace(MatrixXd &H_x, VectorXd &res);
+};
+
+// update/UpdaterSLAM.h:53-122
+class UpdaterSLAM {
+public:
+  UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_aruco, ov_core::FeatureInitializerOptions &feat_init_options);
+  // update/UpdaterSLAM.cpp:376-682 (landmarks already in the state)
+  void update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+              const std::map<size_t, size_t> &feat2plane);
+  // update/UpdaterSLAM.cpp:66-374, downstream of triangulation (features carry p_FinG)
+  void delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                    const std::map<size_t, size_t> &feat2plane);
+
+protected:
+  UpdaterOptions _options_slam, _options_aruco;
+};
+
+// update/UpdaterPlane.h:55-123
+class UpdaterPlane {
+public:
+  UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerOptions &feat_init_options);
+  // update/UpdaterPlane.cpp:61-481 downstream of triangulation / plane fitting: planes with an estimate in
+  // state->_plane_estimates_cp_inG that are not in the state yet are initialised from their on-plane MSCKF features.
+  void init_vio_plane(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                      std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane);
+
+protected:
+  UpdaterOptions _options;
 };
 
 // update/UpdaterMSCKF.h:49-91

@@ -1,0 +1,629 @@
+// Host mirrors of UpdaterHelper (dense Jacobians for the small SLAM systems), UpdaterSLAM and UpdaterPlane.
+// The covariance work goes to the device through StateHelper (EKFUpdate / initialize / get_marginal_covariance) or the
+// batched C-ABI calls; what stays here is what is host scalar code in the reference as well.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+#include "ov_plane_host.h"
+
+using namespace ov_type;
+
+namespace ov_plane {
+
+static void gpu_check2(int rc, const char *what) {
+  if (rc == 0) return;
+  fprintf(stderr, "ov_plane(gpu): %s failed: %s\n", what, ovp_error_string(rc));
+  std::exit(EXIT_FAILURE);
+}
+
+static inline void m3v(const double *A, const double *v, double *o) {
+  for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+static inline void m3m(const double *A, const double *B, double *C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static inline void skew3(const double *w, double *S) {
+  S[0] = 0;
+  S[1] = -w[2];
+  S[2] = w[1];
+  S[3] = w[2];
+  S[4] = 0;
+  S[5] = -w[0];
+  S[6] = -w[1];
+  S[7] = w[0];
+  S[8] = 0;
+}
+
+// ---- update/UpdaterHelper.cpp:195-513 (GLOBAL_3D, radtan, mono) ----------------------------------
+void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, UpdaterHelperFeature &feature, double sigma_px,
+                                              double sigma_c, MatrixXd &H_f, MatrixXd &H_x, VectorXd &res,
+                                              std::vector<std::shared_ptr<Type>> &x_order) {
+  const int total_meas = (int)feature.timestamps.size();
+  x_order.clear();
+  int total_hx = 0;
+  std::vector<std::pair<std::shared_ptr<Type>, int>> map_hx;
+  auto find_col = [&](const std::shared_ptr<Type> &v) {
+    for (auto &p : map_hx)
+      if (p.first == v) return p.second;
+    return -1;
+  };
+  std::shared_ptr<PoseJPL> calibration = state->_calib_IMUtoCAM.at(0);
+  std::shared_ptr<Vec> distortion = state->_cam_intrinsics.at(0);
+  if (state->_options.do_calib_camera_pose) {  // :216-220
+    map_hx.push_back({calibration, total_hx});
+    x_order.push_back(calibration);
+    total_hx += calibration->size();
+  }
+  if (state->_options.do_calib_camera_intrinsics) {  // :223-227
+    map_hx.push_back({distortion, total_hx});
+    x_order.push_back(distortion);
+    total_hx += distortion->size();
+  }
+  for (int m = 0; m < total_meas; m++) {  // :230-239
+    std::shared_ptr<PoseJPL> clone_Ci = state->_clones_IMU.at(feature.timestamps[m]);
+    if (find_col(clone_Ci) < 0) {
+      map_hx.push_back({clone_Ci, total_hx});
+      x_order.push_back(clone_Ci);
+      total_hx += clone_Ci->size();
+    }
+  }
+  const bool plane_in_state = (state->_features_PLANE.find(feature.planeid) != state->_features_PLANE.end());  // :269
+  if (feature.planeid != 0 && plane_in_state) {
+    std::shared_ptr<Vec> planecp = state->_features_PLANE.at(feature.planeid);
+    if (find_col(planecp) < 0) {
+      map_hx.push_back({planecp, total_hx});
+      x_order.push_back(planecp);
+      total_hx += planecp->size();
+    }
+  }
+  const double *p_FinG = feature.p_FinG;
+  const double *p_FinG_fej = feature.p_FinG_fej;
+  int c = 0;
+  int jacobsize = 3 + ((feature.planeid != 0 && !plane_in_state) ? 3 : 0);  // :310-311
+  int meassize = (feature.planeid != 0) ? (3 * total_meas) : (2 * total_meas);
+  if (total_meas == 0 && feature.planeid != 0) meassize = 1;
+  res = VectorXd::Zero(meassize, 1);
+  H_f = MatrixXd::Zero(meassize, jacobsize);
+  H_x = MatrixXd::Zero(meassize, total_hx);
+  const double white_px = 1.0 / sigma_px;
+  const double *R_ItoC = calibration->Rot();
+  const double *p_IinC = calibration->pos();
+  const double *v = distortion->value().data();
+  for (int m = 0; m < total_meas; m++) {
+    std::shared_ptr<PoseJPL> clone_Ii = state->_clones_IMU.at(feature.timestamps[m]);
+    const double *R_GtoIi = clone_Ii->Rot();
+    const double *p_IiinG = clone_Ii->pos();
+    double d[3] = {p_FinG[0] - p_IiinG[0], p_FinG[1] - p_IiinG[1], p_FinG[2] - p_IiinG[2]};
+    double p_FinIi[3], p_FinCi[3];
+    m3v(R_GtoIi, d, p_FinIi);
+    m3v(R_ItoC, p_FinIi, p_FinCi);
+    for (int k = 0; k < 3; ++k) p_FinCi[k] += p_IinC[k];
+    const double x = p_FinCi[0] / p_FinCi[2], y = p_FinCi[1] / p_FinCi[2];
+    // ext CamRadtan::distort_d (:365)
+    const double r2 = x * x + y * y, r4 = r2 * r2, g = 1 + v[4] * r2 + v[5] * r4;
+    const double x1 = x * g + 2 * v[6] * x * y + v[7] * (r2 + 2 * x * x);
+    const double y1 = y * g + v[6] * (r2 + 2 * y * y) + 2 * v[7] * x * y;
+    res(c) = white_px * ((double)feature.uvs[2 * m] - (v[0] * x1 + v[2]));
+    res(c + 1) = white_px * ((double)feature.uvs[2 * m + 1] - (v[1] * y1 + v[3]));
+    if (state->_options.do_fej) {  // :376-385
+      R_GtoIi = clone_Ii->Rot_fej();
+      p_IiinG = clone_Ii->pos_fej();
+      for (int k = 0; k < 3; ++k) d[k] = p_FinG_fej[k] - p_IiinG[k];
+      m3v(R_GtoIi, d, p_FinIi);
+      m3v(R_ItoC, p_FinIi, p_FinCi);
+      for (int k = 0; k < 3; ++k) p_FinCi[k] += p_IinC[k];
+    }
+    // ext CamRadtan::compute_distort_jacobian at the non-FEJ uv_norm (:389)
+    const double fx = v[0], fy = v[1], k1 = v[4], k2 = v[5], p1 = v[6], p2 = v[7];
+    double dz_dzn[4], dz_dzeta[16];
+    dz_dzn[0] = fx * (g + 2 * k1 * x * x + 4 * k2 * x * x * r2 + 2 * p1 * y + 6 * p2 * x);
+    dz_dzn[1] = fx * (2 * k1 * x * y + 4 * k2 * x * y * r2 + 2 * p1 * x + 2 * p2 * y);
+    dz_dzn[2] = fy * (2 * k1 * x * y + 4 * k2 * x * y * r2 + 2 * p1 * x + 2 * p2 * y);
+    dz_dzn[3] = fy * (g + 2 * k1 * y * y + 4 * k2 * y * y * r2 + 6 * p1 * y + 2 * p2 * x);
+    memset(dz_dzeta, 0, sizeof(dz_dzeta));
+    dz_dzeta[0] = x1;
+    dz_dzeta[2] = 1;
+    dz_dzeta[4] = fx * x * r2;
+    dz_dzeta[5] = fx * x * r4;
+    dz_dzeta[6] = 2 * fx * x * y;
+    dz_dzeta[7] = fx * (r2 + 2 * x * x);
+    dz_dzeta[9] = y1;
+    dz_dzeta[11] = 1;
+    dz_dzeta[12] = fy * y * r2;
+    dz_dzeta[13] = fy * y * r4;
+    dz_dzeta[14] = fy * (r2 + 2 * y * y);
+    dz_dzeta[15] = 2 * fy * x * y;
+    const double z = p_FinCi[2];
+    const double dzn_dpfc[6] = {1 / z, 0, -p_FinCi[0] / (z * z), 0, 1 / z, -p_FinCi[1] / (z * z)};
+    double dpfc_dpfg[9], sk[9], Rsk[9];
+    m3m(R_ItoC, R_GtoIi, dpfc_dpfg);
+    skew3(p_FinIi, sk);
+    m3m(R_ItoC, sk, Rsk);
+    double dz_dpfc[6], dz_dpfg[6];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) dz_dpfc[3 * i + j] = dz_dzn[2 * i] * dzn_dpfc[j] + dz_dzn[2 * i + 1] * dzn_dpfc[3 + j];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j)
+        dz_dpfg[3 * i + j] = dz_dpfc[3 * i] * dpfc_dpfg[j] + dz_dpfc[3 * i + 1] * dpfc_dpfg[3 + j] + dz_dpfc[3 * i + 2] * dpfc_dpfg[6 + j];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) H_f(c + i, j) = white_px * dz_dpfg[3 * i + j];  // :411
+    const int cc = find_col(clone_Ii);
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) {  // :414
+        H_x(c + i, cc + j) = white_px * (dz_dpfc[3 * i] * Rsk[j] + dz_dpfc[3 * i + 1] * Rsk[3 + j] + dz_dpfc[3 * i + 2] * Rsk[6 + j]);
+        H_x(c + i, cc + 3 + j) = -white_px * dz_dpfg[3 * i + j];
+      }
+    if (state->_options.do_calib_camera_pose) {  // :426-435
+      const double w[3] = {p_FinCi[0] - p_IinC[0], p_FinCi[1] - p_IinC[1], p_FinCi[2] - p_IinC[2]};
+      double skc[9];
+      skew3(w, skc);
+      const int ccal = find_col(calibration);
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) {
+          H_x(c + i, ccal + j) += white_px * (dz_dpfc[3 * i] * skc[j] + dz_dpfc[3 * i + 1] * skc[3 + j] + dz_dpfc[3 * i + 2] * skc[6 + j]);
+          H_x(c + i, ccal + 3 + j) += white_px * dz_dpfc[3 * i + j];
+        }
+    }
+    if (state->_options.do_calib_camera_intrinsics) {  // :438-440
+      const int cin = find_col(distortion);
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 8; ++j) H_x(c + i, cin + j) = white_px * dz_dzeta[8 * i + j];
+    }
+    c += 2;
+  }
+  if (feature.planeid != 0) {  // :448-512
+    const double white_c = 1.0 / sigma_c;
+    const int reps = (total_meas == 0) ? 1 : total_meas;
+    for (int rep = 0; rep < reps; ++rep) {
+      const double *cp = feature.cp_FinG;
+      double dd = std::sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+      double n[3] = {cp[0] / dd, cp[1] / dd, cp[2] / dd};
+      res(c) = white_c * (0.0 - (n[0] * p_FinG[0] + n[1] * p_FinG[1] + n[2] * p_FinG[2] - dd));
+      const double *lp = p_FinG;
+      if (state->_options.do_fej) {
+        lp = p_FinG_fej;
+        cp = feature.cp_FinG_fej;
+        dd = std::sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+        for (int k = 0; k < 3; ++k) n[k] = cp[k] / dd;
+      }
+      const double ndp = n[0] * lp[0] + n[1] * lp[1] + n[2] * lp[2];
+      for (int j = 0; j < 3; ++j) {
+        const double hcp = white_c * 1.0 / dd * (lp[j] - ndp * n[j] - dd * n[j]);
+        if (plane_in_state) H_x(c, find_col(state->_features_PLANE.at(feature.planeid)) + j) = hcp;
+        else H_f(c, jacobsize - 3 + j) = hcp;
+        H_f(c, j) = white_c * n[j];
+      }
+      c += 1;
+    }
+  }
+}
+
+static void givens(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0 ? 1.0 : -1.0;
+  } else if (std::fabs(p) > std::fabs(q)) {
+    double t = q / p, u = std::sqrt(1.0 + t * t);
+    if (p < 0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+  } else {
+    double t = p / q, u = std::sqrt(1.0 + t * t);
+    if (q < 0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+  }
+}
+static void rot2(MatrixXd &A, int r0, int c0, double c, double s) {
+  for (int j = c0; j < A.cols(); ++j) {
+    const double x = A(r0, j), y = A(r0 + 1, j);
+    A(r0, j) = c * x - s * y;
+    A(r0 + 1, j) = s * x + c * y;
+  }
+}
+
+// ---- update/UpdaterHelper.cpp:515-546 ------------------------------------------------------------
+void UpdaterHelper::nullspace_project_inplace(MatrixXd &H_f, MatrixXd &H_x, VectorXd &res) {
+  assert(H_f.rows() >= H_f.cols());
+  for (int n = 0; n < H_f.cols(); ++n)
+    for (int m = H_f.rows() - 1; m > n; m--) {
+      double c, s;
+      givens(H_f(m - 1, n), H_f(m, n), c, s);
+      rot2(H_f, m - 1, n, c, s);
+      rot2(H_x, m - 1, 0, c, s);
+      rot2(res, m - 1, 0, c, s);
+    }
+  H_x = H_x.block(H_f.cols(), 0, H_x.rows() - H_f.cols(), H_x.cols());
+  res = res.block(H_f.cols(), 0, res.rows() - H_f.cols(), res.cols());
+}
+
+// ---- update/UpdaterHelper.cpp:548-579 ------------------------------------------------------------
+void UpdaterHelper::measurement_compress_inplace(MatrixXd &H_x, VectorXd &res) {
+  if (H_x.rows() <= H_x.cols()) return;
+  for (int n = 0; n < H_x.cols(); n++)
+    for (int m = H_x.rows() - 1; m > n; m--) {
+      double c, s;
+      givens(H_x(m - 1, n), H_x(m, n), c, s);
+      rot2(H_x, m - 1, n, c, s);
+      rot2(res, m - 1, 0, c, s);
+    }
+  const int r = std::min(H_x.rows(), H_x.cols());
+  H_x = H_x.block(0, 0, r, H_x.cols());
+  res = res.block(0, 0, r, 1);
+}
+
+// ---- update/UpdaterSLAM.cpp ----------------------------------------------------------------------
+UpdaterSLAM::UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_aruco, ov_core::FeatureInitializerOptions &)
+    : _options_slam(options_slam), _options_aruco(options_aruco) {
+  _options_slam.sigma_pix_sq = std::pow(_options_slam.sigma_pix, 2);
+  _options_aruco.sigma_pix_sq = std::pow(_options_aruco.sigma_pix, 2);
+}
+
+static void clean_old_measurements(ov_core::Feature &ft, const std::map<double, std::shared_ptr<PoseJPL>> &clones) {
+  std::vector<float> uv2;
+  std::vector<double> ts2;
+  for (size_t k = 0; k < ft.timestamps.size(); ++k)
+    if (clones.count(ft.timestamps[k])) {
+      ts2.push_back(ft.timestamps[k]);
+      uv2.push_back(ft.uvs[2 * k]);
+      uv2.push_back(ft.uvs[2 * k + 1]);
+    }
+  ft.timestamps = ts2;
+  ft.uvs = uv2;
+}
+
+static double chi2_host(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &order, const MatrixXd &H, const VectorXd &res) {
+  MatrixXd P_marg = StateHelper::get_marginal_covariance(state, order);
+  const int rows = H.rows(), cols = H.cols();
+  MatrixXd HP(rows, cols);
+  for (int k = 0; k < cols; ++k)
+    for (int j = 0; j < cols; ++j) {
+      const double pv = P_marg(k, j);
+      for (int i = 0; i < rows; ++i) HP(i, j) += H(i, k) * pv;
+    }
+  MatrixXd S = MatrixXd::Identity(rows, rows);
+  for (int k = 0; k < cols; ++k)
+    for (int j = 0; j < rows; ++j) {
+      const double hv = H(j, k);
+      for (int i = 0; i < rows; ++i) S(i, j) += HP(i, k) * hv;
+    }
+  // LLT
+  for (int j = 0; j < rows; ++j) {
+    double d = S(j, j);
+    for (int k = 0; k < j; ++k) d -= S(j, k) * S(j, k);
+    if (!(d > 0)) return 1e300;
+    d = std::sqrt(d);
+    S(j, j) = d;
+    for (int i = j + 1; i < rows; ++i) {
+      double s = S(i, j);
+      for (int k = 0; k < j; ++k) s -= S(i, k) * S(j, k);
+      S(i, j) = s / d;
+    }
+  }
+  double chi2 = 0.0;
+  VectorXd y = res;
+  for (int i = 0; i < rows; ++i) {
+    double s = y(i);
+    for (int k = 0; k < i; ++k) s -= S(i, k) * y(k);
+    y(i) = s / S(i, i);
+    chi2 += y(i) * y(i);
+  }
+  return chi2;
+}
+
+void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                         const std::map<size_t, size_t> &feat2plane) {
+  if (feature_vec.empty()) return;
+  // :391-419
+  auto it0 = feature_vec.begin();
+  while (it0 != feature_vec.end()) {
+    clean_old_measurements(**it0, state->_clones_IMU);
+    if ((*it0)->timestamps.size() < 1) {
+      (*it0)->to_delete = true;
+      it0 = feature_vec.erase(it0);
+    } else {
+      it0++;
+    }
+  }
+  std::vector<std::pair<std::shared_ptr<Type>, size_t>> Hx_mapping;
+  std::vector<std::shared_ptr<Type>> Hx_order_big;
+  size_t ct_jacob = 0, ct_meas = 0;
+  struct Blk {
+    MatrixXd H;
+    VectorXd r;
+    std::vector<std::shared_ptr<Type>> order;
+  };
+  std::vector<Blk> blocks;
+  auto it2 = feature_vec.begin();
+  while (it2 != feature_vec.end()) {
+    std::shared_ptr<Landmark> landmark = state->_features_SLAM.at((*it2)->featid);
+    UpdaterHelper::UpdaterHelperFeature feat;
+    feat.featid = (*it2)->featid;
+    feat.uvs = (*it2)->uvs;
+    feat.timestamps = (*it2)->timestamps;
+    // :465-475
+    if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamu &&
+        feat2plane.find((*it2)->featid) != feat2plane.end() &&
+        state->_features_PLANE.find(feat2plane.at((*it2)->featid)) != state->_features_PLANE.end()) {
+      if (state->_features_SLAM_to_PLANE.find((*it2)->featid) == state->_features_SLAM_to_PLANE.end() ||
+          state->_features_SLAM_to_PLANE.at((*it2)->featid) != 0) {
+        feat.planeid = feat2plane.at((*it2)->featid);
+        auto pl = state->_features_PLANE.at(feat.planeid);
+        for (int k = 0; k < 3; ++k) {
+          feat.cp_FinG[k] = pl->value()(k);
+          feat.cp_FinG_fej[k] = pl->fej()(k);
+        }
+      }
+    }
+    landmark->get_xyz(false, feat.p_FinG);
+    landmark->get_xyz(true, feat.p_FinG_fej);
+    MatrixXd H_f, H_x, H_xf;
+    VectorXd res;
+    std::vector<std::shared_ptr<Type>> Hx_order, Hxf_order;
+    const double sigma_c = state->_options.sigma_constraint;
+    const double sigma_px = _options_slam.sigma_pix;
+    const double chi2_multipler = _options_slam.chi2_multipler;
+    auto build = [&]() {
+      UpdaterHelper::get_feature_jacobian_full(state, feat, sigma_px, sigma_c, H_f, H_x, res, Hx_order);
+      H_xf = MatrixXd(H_x.rows(), H_x.cols() + H_f.cols());  // :517-522
+      for (int j = 0; j < H_x.cols(); ++j)
+        for (int i = 0; i < H_x.rows(); ++i) H_xf(i, j) = H_x(i, j);
+      for (int j = 0; j < H_f.cols(); ++j)
+        for (int i = 0; i < H_x.rows(); ++i) H_xf(i, H_x.cols() + j) = H_f(i, j);
+      Hxf_order = Hx_order;
+      Hxf_order.push_back(landmark);
+    };
+    build();
+    double chi2 = chi2_host(state, Hxf_order, H_xf, res);  // :529-532
+    double chi2_check = ovp_chi2_quantile_095(res.rows());
+    if (feat.planeid != 0 && chi2 > chi2_multipler * chi2_check) {  // :547-609 fallback without the plane
+      feat.planeid = 0;
+      state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;
+      build();
+      chi2 = chi2_host(state, Hxf_order, H_xf, res);
+      chi2_check = ovp_chi2_quantile_095(res.rows());
+    }
+    if (chi2 > chi2_multipler * chi2_check) {  // :596-619
+      landmark->should_marg = true;
+      (*it2)->to_delete = true;
+      it2 = feature_vec.erase(it2);
+      continue;
+    }
+    if (feat.planeid != 0) state->_features_SLAM_to_PLANE[(*it2)->featid] = feat.planeid;  // :623-624
+    for (const auto &var : Hxf_order) {  // :634-646
+      bool found = false;
+      for (auto &p : Hx_mapping) found = found || (p.first == var);
+      if (!found) {
+        Hx_mapping.push_back({var, ct_jacob});
+        Hx_order_big.push_back(var);
+        ct_jacob += var->size();
+      }
+    }
+    blocks.push_back({H_xf, res, Hxf_order});
+    ct_meas += res.rows();
+    it2++;
+  }
+  for (size_t f = 0; f < feature_vec.size(); f++) feature_vec[f]->to_delete = true;  // :657-659
+  if (ct_meas < 1) return;
+  MatrixXd Hx_big = MatrixXd::Zero((int)ct_meas, (int)ct_jacob);
+  VectorXd res_big = VectorXd::Zero((int)ct_meas, 1);
+  int r0 = 0;
+  for (auto &b : blocks) {
+    int ct_hx = 0;
+    for (const auto &var : b.order) {
+      size_t col = 0;
+      for (auto &p : Hx_mapping)
+        if (p.first == var) col = p.second;
+      for (int j = 0; j < var->size(); ++j)
+        for (int i = 0; i < b.H.rows(); ++i) Hx_big(r0 + i, (int)col + j) = b.H(i, ct_hx + j);
+      ct_hx += var->size();
+    }
+    for (int i = 0; i < b.r.rows(); ++i) res_big(r0 + i) = b.r(i);
+    r0 += b.r.rows();
+  }
+  MatrixXd R_big = MatrixXd::Identity((int)ct_meas, (int)ct_meas);
+  StateHelper::EKFUpdate(state, Hx_order_big, Hx_big, res_big, R_big);  // :673
+}
+
+void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                               const std::map<size_t, size_t> &feat2plane) {
+  if (feature_vec.empty()) return;
+  // :80-118 clean, need >= 2 measurements
+  auto it0 = feature_vec.begin();
+  while (it0 != feature_vec.end()) {
+    clean_old_measurements(**it0, state->_clones_IMU);
+    if ((*it0)->timestamps.size() < 2) {
+      (*it0)->to_delete = true;
+      it0 = feature_vec.erase(it0);
+    } else {
+      it0++;
+    }
+  }
+  // (triangulation and the joint point/plane refinement :120-202 are upstream: features carry p_FinG)
+  auto it2 = feature_vec.begin();
+  while (it2 != feature_vec.end()) {
+    UpdaterHelper::UpdaterHelperFeature feat;
+    feat.featid = (*it2)->featid;
+    feat.uvs = (*it2)->uvs;
+    feat.timestamps = (*it2)->timestamps;
+    if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamd &&
+        feat2plane.find((*it2)->featid) != feat2plane.end() &&
+        state->_features_PLANE.find(feat2plane.at((*it2)->featid)) != state->_features_PLANE.end()) {
+      if (state->_features_SLAM_to_PLANE.find((*it2)->featid) == state->_features_SLAM_to_PLANE.end() ||
+          state->_features_SLAM_to_PLANE.at((*it2)->featid) != 0) {
+        feat.planeid = feat2plane.at((*it2)->featid);
+        auto pl = state->_features_PLANE.at(feat.planeid);
+        for (int k = 0; k < 3; ++k) {
+          feat.cp_FinG[k] = pl->value()(k);
+          feat.cp_FinG_fej[k] = pl->fej()(k);
+        }
+      }
+    }
+    memcpy(feat.p_FinG, (*it2)->p_FinG, sizeof(feat.p_FinG));
+    memcpy(feat.p_FinG_fej, (*it2)->p_FinG, sizeof(feat.p_FinG));
+    MatrixXd H_f, H_x;
+    VectorXd res;
+    std::vector<std::shared_ptr<Type>> Hx_order;
+    const double sigma_c = state->_options.sigma_constraint;
+    UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
+    auto landmark = std::make_shared<Landmark>(3);  // :289-296
+    landmark->_featid = feat.featid;
+    landmark->set_from_xyz(feat.p_FinG, false);
+    landmark->set_from_xyz(feat.p_FinG_fej, true);
+    MatrixXd R = MatrixXd::Identity(res.rows(), res.rows());
+    const double chi2_multipler = _options_slam.chi2_multipler;
+    if (StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler)) {  // :304
+      state->_features_SLAM.insert({(*it2)->featid, landmark});
+      (*it2)->to_delete = true;
+      if (feat.planeid != 0) state->_features_SLAM_to_PLANE[(*it2)->featid] = feat.planeid;
+      it2++;
+    } else if (feat.planeid != 0) {  // :310-359 fallback without the plane
+      feat.planeid = 0;
+      state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;
+      UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
+      R = MatrixXd::Identity(res.rows(), res.rows());
+      if (StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler)) {
+        state->_features_SLAM.insert({(*it2)->featid, landmark});
+        (*it2)->to_delete = true;
+        it2++;
+      } else {
+        (*it2)->to_delete = true;
+        it2 = feature_vec.erase(it2);
+      }
+    } else {
+      (*it2)->to_delete = true;
+      it2 = feature_vec.erase(it2);
+    }
+  }
+}
+
+// ---- update/UpdaterPlane.cpp ---------------------------------------------------------------------
+UpdaterPlane::UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerOptions &) : _options(options) {
+  _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
+}
+
+void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                                  std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used,
+                                  const std::map<size_t, size_t> &feat2plane) {
+  if (feature_vec.empty() || feat2plane.empty()) return;
+  // planes with an upstream estimate that are not in the state yet, ascending id (:297 iterates a std::map)
+  std::vector<size_t> todo;
+  for (const auto &pe : state->_plane_estimates_cp_inG)
+    if (state->_features_PLANE.find(pe.first) == state->_features_PLANE.end()) todo.push_back(pe.first);
+  if (todo.empty()) return;
+  std::map<double, int> clone_slot;
+  std::vector<std::shared_ptr<PoseJPL>> clones;
+  for (const auto &c : state->_clones_IMU) {
+    clone_slot[c.first] = (int)clones.size();
+    clones.push_back(c.second);
+  }
+  for (auto &f : feature_vec) clean_old_measurements(*f, state->_clones_IMU);
+  const int C = (int)clones.size(), F = (int)feature_vec.size();
+  std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
+  std::vector<int> cid(C);
+  for (int i = 0; i < C; ++i) {
+    memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
+    memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
+    memcpy(&cqf[4 * i], clones[i]->quat_fej(), 4 * sizeof(double));
+    memcpy(&cpf[3 * i], clones[i]->pos_fej(), 3 * sizeof(double));
+    cid[i] = clones[i]->id();
+  }
+  ovp_state_tables st;
+  st.n_state = ovp_cov_size(state->_gpu);
+  st.n_clones = C;
+  st.clone_q = cq.data();
+  st.clone_p = cp.data();
+  st.clone_q_fej = cqf.data();
+  st.clone_p_fej = cpf.data();
+  st.clone_id = cid.data();
+  auto calib = state->_calib_IMUtoCAM.at(0);
+  auto intr = state->_cam_intrinsics.at(0);
+  memcpy(st.calib_q, calib->quat(), 4 * sizeof(double));
+  memcpy(st.calib_p, calib->pos(), 3 * sizeof(double));
+  st.calib_id = calib->id();
+  memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
+  st.intr_id = intr->id();
+  gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
+  int M = 1;
+  for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
+  std::vector<float> uv((size_t)F * M * 2, 0.f);
+  std::vector<int> cidx((size_t)F * M, -1), nm(F), pof(F, 0);
+  std::vector<double> pf((size_t)F * 3);
+  for (int f = 0; f < F; ++f) {
+    nm[f] = (int)feature_vec[f]->timestamps.size();
+    for (int k = 0; k < nm[f]; ++k) {
+      cidx[(size_t)f * M + k] = clone_slot.at(feature_vec[f]->timestamps[k]);
+      uv[((size_t)f * M + k) * 2] = feature_vec[f]->uvs[2 * k];
+      uv[((size_t)f * M + k) * 2 + 1] = feature_vec[f]->uvs[2 * k + 1];
+    }
+    memcpy(&pf[3 * f], feature_vec[f]->p_FinG, 3 * sizeof(double));
+    auto it = feat2plane.find(feature_vec[f]->featid);
+    if (it != feat2plane.end()) {
+      auto pos = std::find(todo.begin(), todo.end(), it->second);
+      if (pos != todo.end()) pof[f] = 1 + (int)(pos - todo.begin());
+    }
+  }
+  ovp_feature_batch fb{F, M, uv.data(), cidx.data(), nm.data(), pf.data()};
+  gpu_check2(ovp_batch_upload(state->_gpu, &fb), "ovp_batch_upload");
+  const int NP = (int)todo.size();
+  std::vector<double> cpv(3 * NP), cpn(3 * NP);
+  std::vector<int> sid(NP, -1), nid(NP, -1);
+  for (int k = 0; k < NP; ++k)
+    for (int a = 0; a < 3; ++a) cpv[3 * k + a] = state->_plane_estimates_cp_inG.at(todo[k])[a];
+  ovp_update_opts o{_options.sigma_pix,
+                    _options.chi2_multipler,
+                    state->_options.sigma_constraint,
+                    state->_options.do_fej ? 1 : 0,
+                    state->_options.do_calib_camera_pose ? 1 : 0,
+                    state->_options.do_calib_camera_intrinsics ? 1 : 0,
+                    0};
+  const int stride = state->_options.max_state_size;
+  std::vector<double> dxp((size_t)NP * stride, 0.0);
+  std::vector<uint8_t> pok(NP, 0), fused(F, 0);
+  ovp_plane_batch pb{NP, pof.data(), cpv.data(), cpv.data(), sid.data()};
+  gpu_check2(ovp_plane_init(state->_gpu, &o, &pb, state->_options.const_init_multi, state->_options.const_init_chi2, dxp.data(), stride,
+                            pok.data(), nullptr, nullptr, nid.data(), cpn.data(), fused.data()),
+             "ovp_plane_init");
+  for (int k = 0; k < NP; ++k) {
+    if (!pok[k]) continue;
+    // Type::update of the variables that existed before this plane, then the plane itself joins the state (:441-449)
+    for (auto &var : state->_variables) {
+      VectorXd d(var->size(), 1);
+      for (int a = 0; a < var->size(); ++a) d(a) = dxp[(size_t)k * stride + var->id() + a];
+      var->update(d);
+    }
+    auto plane = std::make_shared<Vec>(3);
+    VectorXd v(3, 1), vf(3, 1);
+    for (int a = 0; a < 3; ++a) {
+      v(a) = cpn[3 * k + a];
+      vf(a) = cpv[3 * k + a];
+    }
+    plane->set_value(v);
+    plane->set_fej(vf);
+    plane->set_local_id(nid[k]);
+    state->_variables.push_back(plane);
+    state->_features_PLANE.insert({todo[k], plane});
+  }
+  // :459-475 features consumed by an initialised plane leave the MSCKF vector
+  auto it = feature_vec.begin();
+  size_t f = 0;
+  while (it != feature_vec.end()) {
+    if (fused[f]) {
+      (*it)->to_delete = true;
+      feature_vec_used.push_back(*it);
+      it = feature_vec.erase(it);
+    } else {
+      it++;
+    }
+    ++f;
+  }
+}
+
+}  // namespace ov_plane

@@ -282,6 +282,24 @@ protected:
   std::shared_ptr<Vec> _v, _bg, _ba;
 };
 
+// ext ov_type::Landmark (GLOBAL_3D only here: value == xyz); fields used by UpdaterSLAM
+class Landmark : public Vec {
+public:
+  explicit Landmark(int dim) : Vec(dim) {}
+  size_t _featid = 0;
+  bool should_marg = false;
+  void get_xyz(bool getfej, double out[3]) const {
+    const VectorXd &v = getfej ? fej() : value();
+    for (int k = 0; k < 3; ++k) out[k] = v(k);
+  }
+  void set_from_xyz(const double p[3], bool isfej) {
+    VectorXd v(3, 1);
+    for (int k = 0; k < 3; ++k) v(k) = p[k];
+    if (isfej) set_fej(v);
+    else set_value(v);
+  }
+};
+
 }  // namespace ov_type
 
 namespace ov_core {

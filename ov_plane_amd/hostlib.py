@@ -86,3 +86,62 @@ def run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, new_value0):
         raise RuntimeError("ovph_run_initialize failed with %d" % rc)
     out["ok"] = rc
     return out
+
+
+def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0):
+    """Drives the C++ host mirrors on a synth scene.
+
+    mode "slam_update": UpdaterSLAM::update on a synth.make_slam_scene (feature f observes landmark f);
+    mode "slam_delayed_init": UpdaterSLAM::delayed_init on a plain scene (every feature is a landmark candidate);
+    mode "plane_init": UpdaterPlane::init_vio_plane on a scene whose planes are all out of the state.
+    """
+    L = lib()
+    m = {"slam_update": 0, "slam_delayed_init": 1, "plane_init": 2}[mode]
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N, F, M = int(sc.N), int(sc.F), int(sc.uv.shape[1])
+    n_slam = F if m == 0 else 0
+    n_pl_total = int(sc.cp.shape[0])
+    n_pl_in = n_pl_total if m == 0 else 0
+    n_pl_out = n_pl_total if m == 2 else 0
+    n_cap = N + 3 * F + 3 * n_pl_total + 8
+    dummy = np.zeros((1, 3))
+    slam_p = f64(sc.slam_p if n_slam else dummy)
+    slam_pf = f64(sc["p_FinG_fej"] if n_slam else dummy)
+    cp = f64(sc.cp if n_pl_total else dummy)
+    cpf = f64(sc.cp_fej if n_pl_total else dummy)
+    P = np.asfortranarray(sc.P)
+    uv = np.ascontiguousarray(sc.uv, dtype=np.float32)
+    cidx = np.ascontiguousarray(sc.clone_idx, dtype=np.int32)
+    nm = np.ascontiguousarray(sc.n_meas, dtype=np.int32)
+    pf = f64(sc.p_FinG)
+    pof = np.ascontiguousarray(sc.plane_id, dtype=np.int32)
+    o = sc.opts
+    nout = max(F, n_pl_total, 1)
+    out = dict(clone_q=np.zeros((sc.C, 4)), clone_p=np.zeros((sc.C, 3)), calib_q=np.zeros(4), calib_p=np.zeros(3),
+               intr=np.zeros(8), slam_p=np.zeros((max(n_slam, 1), 3)), cp=np.zeros((max(n_pl_in, 1), 3)),
+               P=np.zeros((n_cap, n_cap)), n=np.zeros(1, dtype=np.int32), kept=np.zeros(F, dtype=np.uint8),
+               deleted=np.zeros(F, dtype=np.uint8), should_marg=np.zeros(max(n_slam, 1), dtype=np.uint8),
+               slam_to_plane=np.zeros(F, dtype=np.int32), new_p=np.zeros((nout, 3)), new_id=np.zeros(nout, dtype=np.int32))
+    cq, cp_, cqf, cpf_ = f64(sc.clone_q), f64(sc.clone_p), f64(sc.clone_q_fej), f64(sc.clone_p_fej)
+    calq, calp, intr = f64(sc.calib_q), f64(sc.calib_p), f64(sc.intr)
+    L.ovph_run_updater.restype = C.c_int
+    rc = L.ovph_run_updater(
+        C.c_int(m), C.c_int(sc.C), p(cq), p(cp_), p(cqf), p(cpf_), p(calq), p(calp), p(intr), C.c_int(n_slam), p(slam_p),
+        p(slam_pf), C.c_int(n_pl_in), p(cp), p(cpf), C.c_int(n_pl_out), p(cp), C.c_int(N), p(P), C.c_int(F), C.c_int(M), p(uv),
+        p(cidx), p(nm), p(pf), p(pof), C.c_double(o["sigma_px"]), C.c_double(o["chi2_mult"]), C.c_double(o["sigma_c"]),
+        C.c_int(int(o["do_fej"])), C.c_double(const_init_multi), C.c_double(const_init_chi2), C.c_int(n_cap),
+        p(out["clone_q"]), p(out["clone_p"]), p(out["calib_q"]), p(out["calib_p"]), p(out["intr"]), p(out["slam_p"]),
+        p(out["cp"]), p(out["P"]), p(out["n"]), p(out["kept"]), p(out["deleted"]), p(out["should_marg"]),
+        p(out["slam_to_plane"]), p(out["new_p"]), p(out["new_id"]))
+    if rc != 0:
+        raise RuntimeError("ovph_run_updater failed with %d" % rc)
+    n2 = int(out["n"][0])
+    out["n"] = n2
+    out["P"] = np.ascontiguousarray(out["P"].reshape(-1)[: n2 * n2].reshape(n2, n2).T)
+    out["slam_p"] = out["slam_p"][:n_slam]
+    out["cp"] = out["cp"][:n_pl_in]
+    out["should_marg"] = out["should_marg"][:n_slam].astype(bool)
+    for k in ("kept", "deleted"):
+        out[k] = out[k].astype(bool)
+    return out

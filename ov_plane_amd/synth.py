@@ -463,3 +463,34 @@ def make_scene(
         truth=dict(R=R_true, p=p_true, p_f=p_f, cp=cp_true, err=err),
     )
     return sc
+
+
+def make_slam_scene(C=11, n_slam=12, seed=0, n_planes=0, ragged=True, outliers=0, wrong_plane=0, **kw):
+    """Scene whose F = n_slam features are new observations of SLAM landmarks that are already in the state.
+
+    Landmark f sits at state id ids["slam"][f]; its estimate is truth - err[id:id+3] (consistent with P), its first
+    estimate is the value plus a small perturbation.  With n_planes > 0 every plane is in the state and the landmarks are
+    spread over the planes (plane_id[f] > 0 for all of them).  The last `outliers` landmarks get gross pixel noise (the
+    chi2 gate rejects them with and without the plane rows); the first `wrong_plane` landmarks are associated with a plane
+    they do not lie on (the plane rows fail the gate, the no-plane fallback of UpdaterSLAM.cpp:547-609 passes).
+    """
+    fpp = (n_slam + max(n_planes, 1) - 1) // max(n_planes, 1)
+    sc = make_scene(C=C, F=n_slam, seed=seed, ragged=ragged, n_slam=n_slam, n_planes=n_planes, feats_per_plane=fpp,
+                    planes_in_state_frac=1.0, min_meas=min(3, C), **kw)
+    rng = np.random.default_rng(77 + seed)
+    err = sc.truth["err"]
+    p = np.zeros((n_slam, 3))
+    for f in range(n_slam):
+        i = sc.ids["slam"][f]
+        p[f] = sc.truth["p_f"][f] - err[i : i + 3]
+    sc["p_FinG"] = p
+    sc["p_FinG_fej"] = p + 1e-3 * rng.standard_normal(p.shape)
+    sc["slam_p"] = p.copy()
+    sc["lm_id"] = np.asarray(sc.ids["slam"], dtype=np.int32)
+    for f in range(min(outliers, n_slam)):
+        m = int(sc.n_meas[n_slam - 1 - f])
+        sc.uv[n_slam - 1 - f, :m] += (25.0 * rng.standard_normal((m, 2))).astype(np.float32)
+    if n_planes > 1:
+        for f in range(min(wrong_plane, n_slam)):
+            sc.plane_id[f] = 1 + (int(sc.plane_id[f]) % n_planes)
+    return sc

@@ -421,12 +421,14 @@ def test_plane_initialisation_matches_oracle(hiplib, oracle, kw, chi2):
     assert (out["new_ids"] == ref["new_id"]).all()
     assert (out["dof"] == ref["plane_dof"]).all()
     assert (out["used"] == ref["used"]).all()
-    assert np.abs(out["cp"] - ref["cp"]).max() < TOL_DX
     from ov_plane_amd.synth import quat_boxplus
 
     cq, cpos, intr = sc.clone_q.copy(), sc.clone_p.copy(), sc.intr.copy()
+    cp_end = out["cp"].copy()   # value at initialisation; later planes correct it like any other state variable
     for pl in range(sc.cp.shape[0]):
         dx = out["dx"][pl]
+        for g in range(pl):
+            cp_end[g] += dx[out["new_ids"][g]:out["new_ids"][g] + 3]
         for i in range(sc.C):
             cid = sc.ids["clones"][i]
             cq[i] = quat_boxplus(cq[i], dx[cid:cid + 3])
@@ -434,7 +436,100 @@ def test_plane_initialisation_matches_oracle(hiplib, oracle, kw, chi2):
         intr = intr + dx[22:30]
     assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
     assert np.abs(intr - ref["intr"]).max() < TOL_DX
+    assert np.abs(cp_end - ref["cp"]).max() < TOL_DX
     P = ctx.cov_download()
     assert P.shape == ref["P"].shape
     assert relP(P, ref["P"]) < TOL_P
     ctx.close()
+
+
+def _apply_dx_to_scene(sc, dx):
+    from ov_plane_amd.synth import quat_boxplus
+
+    cq, cp = sc.clone_q.copy(), sc.clone_p.copy()
+    for i in range(sc.C):
+        cid = sc.ids["clones"][i]
+        cq[i] = quat_boxplus(cq[i], dx[cid:cid + 3])
+        cp[i] = cp[i] + dx[cid + 3:cid + 6]
+    return cq, cp, sc.intr + dx[22:30]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(C=11, n_slam=12, seed=3, outliers=2),
+    dict(C=11, n_slam=14, seed=4, n_planes=3, outliers=2, wrong_plane=3),   # plane rows + no-plane fallback
+    dict(C=6, n_slam=5, seed=5, do_fej=False),
+])
+def test_host_cpp_mirror_updater_slam_update(hiplib, oracle, kw):
+    """ov_plane::UpdaterSLAM::update (update/UpdaterSLAM.cpp:376-682): per-landmark chi2 over the marginal covariance from the
+    device, optional point-on-plane rows with the no-plane fallback, one StateHelper::EKFUpdate on the device."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import make_slam_scene
+
+    sc = make_slam_scene(**kw)
+    use_planes = kw.get("n_planes", 0) > 0
+    ref = oracle.slam_update(sc, sc.lm_id, use_planes=use_planes)
+    out = hostlib.run_updater(sc, "slam_update")
+    assert (out["should_marg"] == ~ref["accepted"]).all()
+    assert (out["kept"] == ref["accepted"]).all() and out["deleted"].all()
+    if use_planes:
+        assert ref["fellback"].any()
+        # _features_SLAM_to_PLANE: 0 once the plane was dropped for a landmark, the plane id when it was used
+        exp = np.where(ref["fellback"], 0, np.where(ref["accepted"], sc.plane_id, -1))
+        assert (out["slam_to_plane"] == exp).all()
+    cq, cp, intr = _apply_dx_to_scene(sc, ref["dx"])
+    assert np.abs(out["clone_p"] - cp).max() < TOL_DX and np.abs(out["clone_q"] - cq).max() < TOL_DX
+    assert np.abs(out["intr"] - intr).max() < TOL_DX
+    lm = sc.slam_p + ref["dx"][sc.ids["slam"][0]:sc.ids["slam"][0] + 3 * sc.F].reshape(-1, 3)
+    assert np.abs(out["slam_p"] - lm).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+
+
+@pytest.mark.parametrize("kw", [
+    dict(C=11, F=8, seed=5, ragged=True),
+    dict(C=8, F=6, seed=6, ragged=True, chi2_mult=0.6),   # two candidates fail the gate
+])
+def test_host_cpp_mirror_updater_slam_delayed_init(hiplib, oracle, kw):
+    """ov_plane::UpdaterSLAM::delayed_init downstream of triangulation (update/UpdaterSLAM.cpp:204-364): one
+    StateHelper::initialize per feature, the state grows by 3 for every accepted landmark."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_scene(**kw)
+    ref = oracle.slam_delayed_init(sc)
+    out = hostlib.run_updater(sc, "slam_delayed_init")
+    assert out["n"] == ref["n"]
+    assert ((out["new_id"][:sc.F] >= 0) == ref["ok"]).all()
+    assert (out["new_id"][:sc.F] == ref["new_id"]).all()
+    ok = ref["ok"]
+    assert ok.any()
+    assert np.abs(out["new_p"][:sc.F][ok] - ref["p"][ok]).max() < TOL_DX
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(out["intr"] - ref["intr"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+    assert (out["kept"] == ok).all() and out["deleted"].all()
+
+
+def test_host_cpp_mirror_updater_plane_init(hiplib, oracle):
+    """ov_plane::UpdaterPlane::init_vio_plane (update/UpdaterPlane.cpp:296-481) over ovp_plane_init."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_scene(C=11, F=90, seed=33, n_planes=2, feats_per_plane=30, planes_in_state_frac=0.0, chi2_mult=1.0)
+    ref = oracle.plane_init(sc, const_init_multi=5.0, const_init_chi2=1.0)
+    out = hostlib.run_updater(sc, "plane_init", 5.0, 1.0)
+    assert ref["plane_ok"].all()
+    assert out["n"] == ref["n"]
+    assert (out["new_id"][:2] == ref["new_id"]).all()
+    assert np.abs(out["new_p"][:2] - ref["cp"]).max() < TOL_DX
+    assert (out["kept"] == ~ref["used"]).all()
+    assert (out["deleted"] == ref["used"]).all()
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(out["intr"] - ref["intr"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
