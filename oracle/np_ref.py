@@ -363,3 +363,174 @@ def msckf_point_update(sc, feats=None, use_qr=False):
     Hc, rc = measurement_compress_inplace(Hx_big, res_big, use_qr=use_qr)
     Pn, dx = ekf_update(P, order_big, Hc, rc)
     return dict(dx=dx, P=Pn, accepted=accepted, chi2=chi2s, rows=rows, H=Hc, res=rc, order=order_big)
+
+
+# ---- state/Propagator.cpp (a11), independent matrix-form restatement used to cross-check the C oracle ----------------
+def _skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def _exp_so3(w):
+    th = np.linalg.norm(w)
+    S = _skew(w)
+    if th < 1e-7:
+        return np.eye(3) + S + 0.5 * S @ S
+    return np.eye(3) + np.sin(th) / th * S + (1 - np.cos(th)) / th**2 * S @ S
+
+
+def _jl_so3(w):
+    th = np.linalg.norm(w)
+    if th < 1e-6:
+        return np.eye(3)
+    a = w / th
+    return np.sin(th) / th * np.eye(3) + (1 - np.sin(th) / th) * np.outer(a, a) + (1 - np.cos(th)) / th * _skew(a)
+
+
+def _Omega(w):
+    O = np.zeros((4, 4))
+    O[:3, :3] = -_skew(w)
+    O[:3, 3] = w
+    O[3, :3] = -w
+    return O
+
+
+def _quatnorm(q):
+    q = -q if q[3] < 0 else q
+    return q / np.linalg.norm(q)
+
+
+def _quat_mul(q, p):
+    from ov_plane_amd.synth import quat_multiply
+    return quat_multiply(q, p)
+
+
+def _q2R(q):
+    from ov_plane_amd.synth import quat_2_rot
+    return quat_2_rot(q)
+
+
+def select_imu_readings(imu, t0, t1):
+    """Propagator.cpp:227-341 on rows (t, wm, am)."""
+    def interp(a, b, t):
+        lam = (t - a[0]) / (b[0] - a[0])
+        return np.concatenate([[t], (1 - lam) * a[1:] + lam * b[1:]])
+
+    out = []
+    n = len(imu)
+    for i in range(n - 1):
+        a, b = imu[i], imu[i + 1]
+        if b[0] > t0 and a[0] < t0:
+            out.append(interp(a, b, t0))
+            continue
+        if a[0] >= t0 and b[0] <= t1:
+            out.append(a.copy())
+            continue
+        if b[0] > t1:
+            if a[0] > t1 and i == 0:
+                break
+            elif a[0] > t1:
+                out.append(interp(imu[i - 1], a, t1))
+            else:
+                out.append(a.copy())
+            if out[-1][0] != t1:
+                out.append(interp(a, b, t1))
+            break
+    i = 0
+    while i < len(out) - 1:
+        if abs(out[i + 1][0] - out[i][0]) < 1e-12:
+            out.pop(i)
+            continue
+        i += 1
+    return np.array(out).reshape(-1, 7)
+
+
+def predict_mean(x, po, dt, w1, a1, w2, a2):
+    g = np.array([0, 0, po["gravity_mag"]])
+    q0, p0, v0 = x["q"], x["p"], x["v"]
+    if not po["use_rk4"]:
+        w, a = (0.5 * (w1 + w2), 0.5 * (a1 + a2)) if po["imu_avg"] else (w1, a1)
+        wn = np.linalg.norm(w)
+        R = _q2R(q0)
+        if wn > 1e-20:
+            bigO = np.cos(0.5 * wn * dt) * np.eye(4) + np.sin(0.5 * wn * dt) / wn * _Omega(w)
+        else:
+            bigO = np.eye(4) + 0.5 * dt * _Omega(w)
+        return _quatnorm(bigO @ q0), v0 + R.T @ a * dt - g * dt, p0 + v0 * dt + 0.5 * R.T @ a * dt * dt - 0.5 * g * dt * dt
+    wal, aj = (w2 - w1) / dt, (a2 - a1) / dt
+    dq0 = np.array([0, 0, 0, 1.0])
+    ks = []
+    dq, vv = dq0, v0
+    for s, (frac, adv) in enumerate([(0.0, 0.0), (0.5, 0.5), (0.5, 0.5), (1.0, 1.0)]):
+        w, a = w1 + adv * wal * dt, a1 + adv * aj * dt
+        if s > 0:
+            dq = _quatnorm(dq0 + frac * ks[-1][0])
+            vv = v0 + frac * ks[-1][2]
+        R = _q2R(_quat_mul(dq, q0))
+        ks.append((0.5 * _Omega(w) @ dq * dt, vv * dt, (R.T @ a - g) * dt))
+    c = [1 / 6, 1 / 3, 1 / 3, 1 / 6]
+    dqf = _quatnorm(dq0 + sum(ci * k[0] for ci, k in zip(c, ks)))
+    return _quat_mul(dqf, q0), v0 + sum(ci * k[2] for ci, k in zip(c, ks)), p0 + sum(ci * k[1] for ci, k in zip(c, ks))
+
+
+def predict_and_compute(x, po, minus, plus):
+    """Propagator.cpp:343-454.  Returns (x_new, F, Qd)."""
+    dt = plus[0] - minus[0]
+    w1, a1 = minus[1:4] - x["bg"], minus[4:7] - x["ba"]
+    w2, a2 = plus[1:4] - x["bg"], plus[4:7] - x["ba"]
+    nq, nv, npos = predict_mean(x, po, dt, w1, a1, w2, a2)
+    g = np.array([0, 0, po["gravity_mag"]])
+    F = np.zeros((15, 15))
+    G = np.zeros((15, 12))
+    th, p, v, bg, ba = slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 12), slice(12, 15)
+    Jr = _jl_so3(w1 * dt)   # Jr(-w dt) = Jl(w dt)
+    I = np.eye(3)
+    if po["do_fej"]:
+        Rf = _q2R(x["q_fej"])
+        dR = _q2R(nq) @ Rf.T
+        F[th, th] = dR
+        F[th, bg] = -dR @ Jr * dt
+        F[v, th] = -_skew(nv - x["v_fej"] + g * dt) @ Rf.T
+        F[v, ba] = -Rf.T * dt
+        F[p, th] = -_skew(npos - x["p_fej"] - x["v_fej"] * dt + 0.5 * g * dt * dt) @ Rf.T
+        F[p, ba] = -0.5 * Rf.T * dt * dt
+        G[th, 0:3] = -dR @ Jr * dt
+        G[v, 3:6] = -Rf.T * dt
+        G[p, 3:6] = -0.5 * Rf.T * dt * dt
+    else:
+        R = _q2R(x["q"])
+        E = _exp_so3(-w1 * dt)
+        F[th, th] = E
+        F[th, bg] = -E @ Jr * dt
+        F[v, th] = -R.T @ _skew(a1 * dt)
+        F[v, ba] = -R.T * dt
+        F[p, th] = -0.5 * R.T @ _skew(a1 * dt * dt)
+        F[p, ba] = -0.5 * R.T * dt * dt
+        G[th, 0:3] = -E @ Jr * dt
+        G[v, 3:6] = -R.T * dt
+        G[p, 3:6] = -0.5 * R.T * dt * dt
+    F[bg, bg] = F[v, v] = F[ba, ba] = F[p, p] = I
+    F[p, v] = I * dt
+    G[bg, 6:9] = I
+    G[ba, 9:12] = I
+    Qc = np.diag(np.repeat([po["sigma_w"]**2 / dt, po["sigma_a"]**2 / dt, po["sigma_wb"]**2 * dt, po["sigma_ab"]**2 * dt], 3))
+    Qd = G @ Qc @ G.T
+    Qd = 0.5 * (Qd + Qd.T)
+    xn = dict(x)
+    xn.update(q=nq, p=npos, v=nv, q_fej=nq, p_fej=npos, v_fej=nv, bg_fej=x["bg"], ba_fej=x["ba"])
+    return xn, F, Qd
+
+
+def propagate_summed(x, po, imu, t0, t1):
+    sel = select_imu_readings(imu, t0, t1)
+    Phi, Qs = np.eye(15), np.zeros((15, 15))
+    for i in range(len(sel) - 1):
+        x, F, Qd = predict_and_compute(x, po, sel[i], sel[i + 1])
+        Phi = F @ Phi
+        Qs = F @ Qs @ F.T + Qd
+        Qs = 0.5 * (Qs + Qs.T)
+    last_w = np.zeros(3)
+    if len(sel) > 1:
+        last_w = sel[-2][1:4] - x["bg"]
+    elif len(sel) == 1:
+        last_w = sel[-1][1:4] - x["bg"]
+    return dict(x=x, Phi=Phi, Q=Qs, last_w=last_w, n_sel=len(sel))

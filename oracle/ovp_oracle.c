@@ -1487,3 +1487,356 @@ int ovo_slam_delayed_init(const ovo_opts *o, const ovo_state *st_in, const ovo_f
   free(dx);
   return 0;
 }
+
+/* ================================================================================================================
+ * state/Propagator.cpp restatement (a11): IMU reading selection, mean integration, Phi / Qd accumulation.
+ * ext quat_ops.h pieces: Omega, exp_so3, Jr_so3, quatnorm.
+ * ============================================================================================================== */
+static void pr_exp_so3(const double w[3], double R[9]) {
+  double S[9], S2[9];
+  skew3(w, S);
+  mat3_mul(S, S, S2);
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double A, B;
+  if (th < 1e-7) {
+    A = 1.0;
+    B = 0.5;
+  } else {
+    A = sin(th) / th;
+    B = (1.0 - cos(th)) / (th * th);
+  }
+  for (int i = 0; i < 9; ++i) R[i] = A * S[i] + B * S2[i];
+  R[0] += 1.0;
+  R[4] += 1.0;
+  R[8] += 1.0;
+}
+
+static void pr_jl_so3(const double w[3], double J[9]) {
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (th < 1e-6) {
+    for (int i = 0; i < 9; ++i) J[i] = 0.0;
+    J[0] = J[4] = J[8] = 1.0;
+    return;
+  }
+  const double a[3] = {w[0] / th, w[1] / th, w[2] / th};
+  double S[9];
+  skew3(a, S);
+  const double s = sin(th) / th, c = (1.0 - cos(th)) / th;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) J[3 * i + j] = (i == j ? s : 0.0) + (1.0 - s) * a[i] * a[j] + c * S[3 * i + j];
+}
+
+static void pr_jr_so3(const double w[3], double J[9]) {
+  const double m[3] = {-w[0], -w[1], -w[2]};
+  pr_jl_so3(m, J);
+}
+
+/* Omega(w) q : [[-skew(w), w], [-w^T, 0]] applied to q (JPL) */
+static void pr_omega_mul(const double w[3], const double q[4], double o[4]) {
+  o[0] = w[2] * q[1] - w[1] * q[2] + w[0] * q[3];
+  o[1] = -w[2] * q[0] + w[0] * q[2] + w[1] * q[3];
+  o[2] = w[1] * q[0] - w[0] * q[1] + w[2] * q[3];
+  o[3] = -w[0] * q[0] - w[1] * q[1] - w[2] * q[2];
+}
+
+static void pr_quatnorm(double q[4]) {
+  if (q[3] < 0)
+    for (int k = 0; k < 4; ++k) q[k] = -q[k];
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) q[k] /= n;
+}
+
+/* Propagator.cpp:571-591 (interpolate_data): linear in time */
+static void pr_interp(const double *a, const double *b, double t, double *o) {
+  const double lambda = (t - a[0]) / (b[0] - a[0]);
+  o[0] = t;
+  for (int k = 1; k < 7; ++k) o[k] = (1.0 - lambda) * a[k] + lambda * b[k];
+}
+
+/* Propagator.cpp:227-341.  imu [n x 7] rows = (t, wm, am).  Returns the number of selected readings (out [cap x 7]). */
+int ovo_select_imu_readings(const double *imu, int n, double time0, double time1, double *out, int cap) {
+  int m = 0;
+  if (n == 0) return 0;
+  for (int i = 0; i + 1 < n; ++i) {
+    const double *a = imu + 7 * i, *b = imu + 7 * (i + 1);
+    if (b[0] > time0 && a[0] < time0) { /* :246-252 start of the period: split */
+      if (m < cap) pr_interp(a, b, time0, out + 7 * m);
+      ++m;
+      continue;
+    }
+    if (a[0] >= time0 && b[0] <= time1) { /* :257-261 middle */
+      if (m < cap) memcpy(out + 7 * m, a, 7 * sizeof(double));
+      ++m;
+      continue;
+    }
+    if (b[0] > time1) { /* :268-296 end of the period */
+      if (a[0] > time1 && i == 0) {
+        break;
+      } else if (a[0] > time1) {
+        if (m < cap) pr_interp(imu + 7 * (i - 1), a, time1, out + 7 * m);
+        ++m;
+      } else {
+        if (m < cap) memcpy(out + 7 * m, a, 7 * sizeof(double));
+        ++m;
+      }
+      if (m <= cap && out[7 * (m - 1)] != time1) {
+        if (m < cap) pr_interp(a, b, time1, out + 7 * m);
+        ++m;
+      }
+      break;
+    }
+  }
+  if (m == 0) return 0;
+  if (m > cap) return -1;
+  for (int i = 0; i + 1 < m; ++i) /* :316-325 zero dt */
+    if (fabs(out[7 * (i + 1)] - out[7 * i]) < 1e-12) {
+      memmove(out + 7 * i, out + 7 * (i + 1), sizeof(double) * 7 * (size_t)(m - i - 1));
+      --m;
+      --i;
+    }
+  return m;
+}
+
+/* Propagator.cpp:456-488 */
+static void pr_mean_discrete(const ovo_imu_state *x, const ovo_prop_opts *po, double dt, const double *w1, const double *a1,
+                             const double *w2, const double *a2, double *nq, double *nv, double *np) {
+  double w[3], a[3];
+  for (int k = 0; k < 3; ++k) {
+    w[k] = po->imu_avg ? 0.5 * (w1[k] + w2[k]) : w1[k];
+    a[k] = po->imu_avg ? 0.5 * (a1[k] + a2[k]) : a1[k];
+  }
+  const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double R[9], Oq[4];
+  ovo_quat_2_rot(x->q, R);
+  pr_omega_mul(w, x->q, Oq);
+  double ca, cb;
+  if (wn > 1e-20) {
+    ca = cos(0.5 * wn * dt);
+    cb = 1.0 / wn * sin(0.5 * wn * dt);
+  } else {
+    ca = 1.0;
+    cb = 0.5 * dt;
+  }
+  for (int k = 0; k < 4; ++k) nq[k] = ca * x->q[k] + cb * Oq[k];
+  pr_quatnorm(nq);
+  double Rta[3]; /* R^T a */
+  for (int i = 0; i < 3; ++i) Rta[i] = R[i] * a[0] + R[3 + i] * a[1] + R[6 + i] * a[2];
+  const double g[3] = {0.0, 0.0, po->gravity_mag};
+  for (int i = 0; i < 3; ++i) {
+    nv[i] = x->v[i] + Rta[i] * dt - g[i] * dt;
+    np[i] = x->p[i] + x->v[i] * dt + 0.5 * Rta[i] * dt * dt - 0.5 * g[i] * dt * dt;
+  }
+}
+
+/* Propagator.cpp:490-569 */
+static void pr_mean_rk4(const ovo_imu_state *x, const ovo_prop_opts *po, double dt, const double *w1, const double *a1,
+                        const double *w2, const double *a2, double *nq, double *nv, double *np) {
+  double w[3], a[3], wal[3], aj[3];
+  for (int k = 0; k < 3; ++k) {
+    w[k] = w1[k];
+    a[k] = a1[k];
+    wal[k] = (w2[k] - w1[k]) / dt;
+    aj[k] = (a2[k] - a1[k]) / dt;
+  }
+  const double g[3] = {0.0, 0.0, po->gravity_mag};
+  double dq[4][4] = {{0, 0, 0, 1}}, kq[4][4], kp[4][3], kv[4][3], vs[3];
+  for (int s = 0; s < 4; ++s) {
+    if (s == 1 || s == 3)
+      for (int k = 0; k < 3; ++k) {
+        w[k] += 0.5 * wal[k] * dt;
+        a[k] += 0.5 * aj[k] * dt;
+      }
+    if (s > 0) {
+      const double f = (s == 3) ? 1.0 : 0.5;
+      for (int k = 0; k < 4; ++k) dq[s][k] = dq[0][k] + f * kq[s - 1][k];
+      pr_quatnorm(dq[s]);
+      for (int k = 0; k < 3; ++k) vs[k] = x->v[k] + f * kv[s - 1][k];
+    } else {
+      for (int k = 0; k < 3; ++k) vs[k] = x->v[k];
+    }
+    double qd[4], qq[4], R[9];
+    pr_omega_mul(w, dq[s], qd);
+    quat_multiply(dq[s], x->q, qq);
+    ovo_quat_2_rot(qq, R);
+    for (int k = 0; k < 4; ++k) kq[s][k] = 0.5 * qd[k] * dt;
+    for (int i = 0; i < 3; ++i) {
+      kp[s][i] = vs[i] * dt;
+      kv[s][i] = (R[i] * a[0] + R[3 + i] * a[1] + R[6 + i] * a[2] - g[i]) * dt;
+    }
+  }
+  double dqf[4];
+  for (int k = 0; k < 4; ++k)
+    dqf[k] = dq[0][k] + (1.0 / 6.0) * kq[0][k] + (1.0 / 3.0) * kq[1][k] + (1.0 / 3.0) * kq[2][k] + (1.0 / 6.0) * kq[3][k];
+  pr_quatnorm(dqf);
+  quat_multiply(dqf, x->q, nq);
+  for (int i = 0; i < 3; ++i) {
+    np[i] = x->p[i] + (1.0 / 6.0) * kp[0][i] + (1.0 / 3.0) * kp[1][i] + (1.0 / 3.0) * kp[2][i] + (1.0 / 6.0) * kp[3][i];
+    nv[i] = x->v[i] + (1.0 / 6.0) * kv[0][i] + (1.0 / 3.0) * kv[1][i] + (1.0 / 3.0) * kv[2][i] + (1.0 / 6.0) * kv[3][i];
+  }
+}
+
+#define F15(i, j) F[(size_t)(j) * 15 + (i)]
+#define G15(i, j) G[(size_t)(j) * 15 + (i)]
+static void set33(double *M, int ld, int r0, int c0, const double *B /* row-major */, double s) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[(size_t)(c0 + j) * ld + r0 + i] = s * B[3 * i + j];
+}
+
+/* Propagator.cpp:343-454; x is advanced (value and FEJ := propagated value, :447-453). F, Qd col-major 15x15. */
+void ovo_predict_and_compute(ovo_imu_state *x, const ovo_prop_opts *po, const double *minus, const double *plus, double *F,
+                             double *Qd) {
+  memset(F, 0, sizeof(double) * 225);
+  memset(Qd, 0, sizeof(double) * 225);
+  const double dt = plus[0] - minus[0];
+  double w1[3], a1[3], w2[3], a2[3];
+  for (int k = 0; k < 3; ++k) {
+    w1[k] = minus[1 + k] - x->bg[k];
+    a1[k] = minus[4 + k] - x->ba[k];
+    w2[k] = plus[1 + k] - x->bg[k];
+    a2[k] = plus[4 + k] - x->ba[k];
+  }
+  double nq[4], nv[3], np[3];
+  if (po->use_rk4)
+    pr_mean_rk4(x, po, dt, w1, a1, w2, a2, nq, nv, np);
+  else
+    pr_mean_discrete(x, po, dt, w1, a1, w2, a2, nq, nv, np);
+  const int th = 0, p = 3, v = 6, bg = 9, ba = 12;
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double g[3] = {0.0, 0.0, po->gravity_mag};
+  double G[15 * 12];
+  memset(G, 0, sizeof(G));
+  double mw[3] = {-w1[0] * dt, -w1[1] * dt, -w1[2] * dt}, Jr[9];
+  pr_jr_so3(mw, Jr);
+  if (po->do_fej) { /* :379-409 */
+    double Rfej[9], Rn[9], RfT[9], dR[9], T[9], S[9], ST[9], a[3];
+    ovo_quat_2_rot(x->q_fej, Rfej);
+    ovo_quat_2_rot(nq, Rn);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) RfT[3 * i + j] = Rfej[3 * j + i];
+    mat3_mul(Rn, RfT, dR);
+    set33(F, 15, th, th, dR, 1.0);
+    mat3_mul(dR, Jr, T);
+    set33(F, 15, th, bg, T, -dt);
+    set33(F, 15, bg, bg, I3, 1.0);
+    for (int k = 0; k < 3; ++k) a[k] = nv[k] - x->v_fej[k] + g[k] * dt;
+    skew3(a, S);
+    mat3_mul(S, RfT, ST);
+    set33(F, 15, v, th, ST, -1.0);
+    set33(F, 15, v, v, I3, 1.0);
+    set33(F, 15, v, ba, RfT, -dt);
+    set33(F, 15, ba, ba, I3, 1.0);
+    for (int k = 0; k < 3; ++k) a[k] = np[k] - x->p_fej[k] - x->v_fej[k] * dt + 0.5 * g[k] * dt * dt;
+    skew3(a, S);
+    mat3_mul(S, RfT, ST);
+    set33(F, 15, p, th, ST, -1.0);
+    set33(F, 15, p, v, I3, dt);
+    set33(F, 15, p, ba, RfT, -0.5 * dt * dt);
+    set33(F, 15, p, p, I3, 1.0);
+    set33(G, 15, th, 0, T, -dt);
+    set33(G, 15, v, 3, RfT, -dt);
+    set33(G, 15, p, 3, RfT, -0.5 * dt * dt);
+    set33(G, 15, bg, 6, I3, 1.0);
+    set33(G, 15, ba, 9, I3, 1.0);
+  } else { /* :411-432 */
+    double R[9], RT[9], E[9], T[9], S[9], RS[9], a[3];
+    ovo_quat_2_rot(x->q, R);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) RT[3 * i + j] = R[3 * j + i];
+    pr_exp_so3(mw, E);
+    set33(F, 15, th, th, E, 1.0);
+    mat3_mul(E, Jr, T);
+    set33(F, 15, th, bg, T, -dt);
+    set33(F, 15, bg, bg, I3, 1.0);
+    for (int k = 0; k < 3; ++k) a[k] = a1[k] * dt;
+    skew3(a, S);
+    mat3_mul(RT, S, RS);
+    set33(F, 15, v, th, RS, -1.0);
+    set33(F, 15, v, v, I3, 1.0);
+    set33(F, 15, v, ba, RT, -dt);
+    set33(F, 15, ba, ba, I3, 1.0);
+    for (int k = 0; k < 3; ++k) a[k] = a1[k] * dt * dt;
+    skew3(a, S);
+    mat3_mul(RT, S, RS);
+    set33(F, 15, p, th, RS, -0.5);
+    set33(F, 15, p, v, I3, dt);
+    set33(F, 15, p, ba, RT, -0.5 * dt * dt);
+    set33(F, 15, p, p, I3, 1.0);
+    set33(G, 15, th, 0, T, -dt);
+    set33(G, 15, v, 3, RT, -dt);
+    set33(G, 15, p, 3, RT, -0.5 * dt * dt);
+    set33(G, 15, bg, 6, I3, 1.0);
+    set33(G, 15, ba, 9, I3, 1.0);
+  }
+  /* :437-445 Qd = G Qc G^T, symmetrised */
+  const double qc[4] = {po->sigma_w * po->sigma_w / dt, po->sigma_a * po->sigma_a / dt, po->sigma_wb * po->sigma_wb * dt,
+                        po->sigma_ab * po->sigma_ab * dt};
+  double T2[225];
+  for (int i = 0; i < 15; ++i)
+    for (int j = 0; j < 15; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 12; ++k) s += G15(i, k) * qc[k / 3] * G15(j, k);
+      T2[(size_t)j * 15 + i] = s;
+    }
+  for (int i = 0; i < 15; ++i)
+    for (int j = 0; j < 15; ++j) Qd[(size_t)j * 15 + i] = 0.5 * (T2[(size_t)j * 15 + i] + T2[(size_t)i * 15 + j]);
+  /* :447-453 */
+  memcpy(x->q, nq, sizeof(nq));
+  memcpy(x->p, np, sizeof(np));
+  memcpy(x->v, nv, sizeof(nv));
+  memcpy(x->q_fej, nq, sizeof(nq));
+  memcpy(x->p_fej, np, sizeof(np));
+  memcpy(x->v_fej, nv, sizeof(nv));
+  memcpy(x->bg_fej, x->bg, sizeof(x->bg));
+  memcpy(x->ba_fej, x->ba, sizeof(x->ba));
+}
+
+/* Propagator.cpp:37-126 up to (not including) the covariance call: returns Phi_summed, Qd_summed (col-major 15x15),
+ * the propagated IMU state and last_w.  The caller applies ovo_ekf_propagation with order {imu} and clones. */
+int ovo_propagate_summed(ovo_imu_state *x, const ovo_prop_opts *po, const double *imu, int n_imu, double time0, double time1,
+                         double *Phi, double *Qs, double *last_w, int *n_sel) {
+  const int cap = n_imu + 4;
+  double *sel = (double *)malloc(sizeof(double) * 7 * (size_t)cap);
+  const int m = ovo_select_imu_readings(imu, n_imu, time0, time1, sel, cap);
+  if (m < 0) {
+    free(sel);
+    return -1;
+  }
+  memset(Phi, 0, sizeof(double) * 225);
+  memset(Qs, 0, sizeof(double) * 225);
+  for (int i = 0; i < 15; ++i) Phi[(size_t)i * 15 + i] = 1.0;
+  double F[225], Qdi[225], T[225], T2[225];
+  for (int k = 0; k < 3; ++k) last_w[k] = 0.0;
+  /* last_w uses the bias BEFORE... the bias is not propagated, so any time works (:110-114) */
+  if (m > 1) {
+    for (int i = 0; i + 1 < m; ++i) {
+      ovo_predict_and_compute(x, po, sel + 7 * i, sel + 7 * (i + 1), F, Qdi);
+      for (int r = 0; r < 15; ++r) /* Phi = F Phi */
+        for (int c = 0; c < 15; ++c) {
+          double s = 0.0;
+          for (int k = 0; k < 15; ++k) s += F[(size_t)k * 15 + r] * Phi[(size_t)c * 15 + k];
+          T[(size_t)c * 15 + r] = s;
+        }
+      memcpy(Phi, T, sizeof(T));
+      for (int r = 0; r < 15; ++r) /* T = F Qs */
+        for (int c = 0; c < 15; ++c) {
+          double s = 0.0;
+          for (int k = 0; k < 15; ++k) s += F[(size_t)k * 15 + r] * Qs[(size_t)c * 15 + k];
+          T[(size_t)c * 15 + r] = s;
+        }
+      for (int r = 0; r < 15; ++r) /* T2 = T F^T + Qdi */
+        for (int c = 0; c < 15; ++c) {
+          double s = 0.0;
+          for (int k = 0; k < 15; ++k) s += T[(size_t)k * 15 + r] * F[(size_t)k * 15 + c];
+          T2[(size_t)c * 15 + r] = s + Qdi[(size_t)c * 15 + r];
+        }
+      for (int r = 0; r < 15; ++r)
+        for (int c = 0; c < 15; ++c) Qs[(size_t)c * 15 + r] = 0.5 * (T2[(size_t)c * 15 + r] + T2[(size_t)r * 15 + c]);
+    }
+    for (int k = 0; k < 3; ++k) last_w[k] = sel[7 * (m - 2) + 1 + k] - x->bg[k];
+  } else if (m == 1) {
+    for (int k = 0; k < 3; ++k) last_w[k] = sel[1 + k] - x->bg[k];
+  }
+  *n_sel = m;
+  free(sel);
+  return 0;
+}

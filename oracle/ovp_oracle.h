@@ -170,6 +170,29 @@ int ovo_initialize(double *P, int n_cap, int *n, const int *order_id, const int 
                    double *H_L, int rows, int k, double r_iso, double *res, double chi2_mult, int do_update,
                    double *new_var_delta, double *dx, double *chi2_out, int *dof_out);
 
+/* ---- state/Propagator.cpp (a11) ------------------------------------------------------------------------------- */
+typedef struct {
+  double q[4], p[3], v[3], bg[3], ba[3];                 /* State::_imu value (JPL q_GtoI, p_IinG, v_IinG, biases) */
+  double q_fej[4], p_fej[3], v_fej[3], bg_fej[3], ba_fej[3];
+} ovo_imu_state;
+
+typedef struct {
+  double sigma_w, sigma_a, sigma_wb, sigma_ab; /* NoiseManager (continuous-time) */
+  double gravity_mag;                          /* _gravity = (0, 0, gravity_mag) */
+  int use_rk4;                                 /* StateOptions::use_rk4_integration */
+  int imu_avg;                                 /* StateOptions::imu_avg */
+  int do_fej;
+} ovo_prop_opts;
+
+/* Propagator.cpp:227-341: readings [n x 7] = (t, wm xyz, am xyz) -> the split / interpolated set covering [time0, time1]. */
+int ovo_select_imu_readings(const double *imu, int n, double time0, double time1, double *out, int cap);
+/* Propagator.cpp:343-454: one IMU interval; advances x, returns F and Qd (col-major 15 x 15, error order th p v bg ba). */
+void ovo_predict_and_compute(ovo_imu_state *x, const ovo_prop_opts *po, const double *minus, const double *plus, double *F,
+                             double *Qd);
+/* Propagator.cpp:37-118: Phi_summed / Qd_summed over the selected readings, propagated mean, last_w (:110-114). */
+int ovo_propagate_summed(ovo_imu_state *x, const ovo_prop_opts *po, const double *imu, int n_imu, double time0, double time1,
+                         double *Phi, double *Qs, double *last_w, int *n_sel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,3 +324,57 @@ def slam_delayed_init(sc):
     return dict(P=np.ascontiguousarray(P[:n2, :n2]), n=n2, clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
                 calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), ok=ok.astype(bool), chi2=chi2, new_id=nid,
                 p=pout)
+
+
+# ---- state/Propagator.cpp (a11) ----------------------------------------------------------------------------------
+class OvoImuState(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("p", C.c_double * 3), ("v", C.c_double * 3), ("bg", C.c_double * 3),
+                ("ba", C.c_double * 3), ("q_fej", C.c_double * 4), ("p_fej", C.c_double * 3), ("v_fej", C.c_double * 3),
+                ("bg_fej", C.c_double * 3), ("ba_fej", C.c_double * 3)]
+
+
+class OvoPropOpts(C.Structure):
+    _fields_ = [("sigma_w", C.c_double), ("sigma_a", C.c_double), ("sigma_wb", C.c_double), ("sigma_ab", C.c_double),
+                ("gravity_mag", C.c_double), ("use_rk4", C.c_int), ("imu_avg", C.c_int), ("do_fej", C.c_int)]
+
+
+IMU_KEYS = ("q", "p", "v", "bg", "ba", "q_fej", "p_fej", "v_fej", "bg_fej", "ba_fej")
+
+
+def _imu_struct(x):
+    s = OvoImuState()
+    for k in IMU_KEYS:
+        getattr(s, k)[:] = [float(a) for a in x[k]]
+    return s
+
+
+def _prop_opts(po):
+    return OvoPropOpts(po["sigma_w"], po["sigma_a"], po["sigma_wb"], po["sigma_ab"], po["gravity_mag"], int(po["use_rk4"]),
+                       int(po["imu_avg"]), int(po["do_fej"]))
+
+
+def select_imu_readings(imu, time0, time1):
+    L = lib()
+    imu = np.ascontiguousarray(imu, dtype=np.float64)
+    out = np.zeros((imu.shape[0] + 4, 7))
+    L.ovo_select_imu_readings.restype = C.c_int
+    m = L.ovo_select_imu_readings(_dp(imu), C.c_int(imu.shape[0]), C.c_double(time0), C.c_double(time1), _dp(out),
+                                  C.c_int(out.shape[0]))
+    return out[:max(m, 0)].copy()
+
+
+def propagate_summed(x, po, imu, time0, time1):
+    """ovo_propagate_summed: x = dict of IMU_KEYS, po = dict of OvoPropOpts fields, imu [n,7] = (t, wm, am)."""
+    L = lib()
+    s = _imu_struct(x)
+    o = _prop_opts(po)
+    imu = np.ascontiguousarray(imu, dtype=np.float64)
+    Phi = np.zeros((15, 15), order="F")
+    Q = np.zeros((15, 15), order="F")
+    lw = np.zeros(3)
+    n = C.c_int(0)
+    L.ovo_propagate_summed.restype = C.c_int
+    rc = L.ovo_propagate_summed(C.byref(s), C.byref(o), _dp(imu), C.c_int(imu.shape[0]), C.c_double(time0), C.c_double(time1),
+                                _dp(Phi), _dp(Q), _dp(lw), C.byref(n))
+    xo = {k: np.array(getattr(s, k)[:]) for k in IMU_KEYS}
+    return dict(rc=rc, x=xo, Phi=np.ascontiguousarray(Phi), Q=np.ascontiguousarray(Q), last_w=lw, n_sel=n.value)

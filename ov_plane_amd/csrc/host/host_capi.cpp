@@ -414,3 +414,81 @@ extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const do
   for (size_t k = 0; k < hs.landmarks.size(); ++k) lm_should_marg[k] = hs.landmarks[k]->should_marg ? 1 : 0;
   return 0;
 }
+
+// Propagator::propagate_and_clone harness: state with C clones (+ calibration), IMU state x16 / x16_fej, covariance P,
+// n_imu readings rows (t, wm, am).  state->_timestamp = t_state, camera time offset dt_cam_imu; propagates to `timestamp`.
+extern "C" int ovph_run_propagate(int C, const double *clone_q, const double *clone_p, const double *imu_x16, const double *imu_x16_fej,
+                                  double calib_dt, int N, const double *P, int n_imu, const double *imu, double t_state,
+                                  double timestamp, const double *sigmas4 /* w a wb ab */, double gravity_mag, int use_rk4,
+                                  int imu_avg, int do_fej,
+                                  /* outputs */ double *out_x16, double *out_x16_fej, double *out_Phi, double *out_Qd, double *out_last_w,
+                                  double *out_P /* (N+6)^2 */, double *out_new_clone7) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C + 1;
+  so.use_rk4_integration = use_rk4 != 0;
+  so.imu_avg = imu_avg != 0;
+  so.max_state_size = N + 16;
+  so.max_features = 16;
+  auto state = std::make_shared<State>(so);
+  const double w0[3] = {0, 0, 0};
+  for (int i = 0; i < C; ++i) {
+    VectorXd v(7, 1);
+    for (int q = 0; q < 4; ++q) v(q) = clone_q[4 * i + q];
+    for (int q = 0; q < 3; ++q) v(4 + q) = clone_p[3 * i + q];
+    state->_imu->pose()->set_value(v);
+    state->_imu->pose()->set_fej(v);
+    state->_timestamp = t_state - 0.1 * (C - i);
+    StateHelper::augment_clone(state, w0);
+  }
+  if (state->max_covariance_size() != N) return -11;
+  VectorXd x(16, 1), xf(16, 1), dtv(1, 1);
+  for (int k = 0; k < 16; ++k) {
+    x(k) = imu_x16[k];
+    xf(k) = imu_x16_fej[k];
+  }
+  state->_imu->set_value(x);
+  state->_imu->set_fej(xf);
+  dtv(0) = calib_dt;
+  state->_calib_dt_CAMtoIMU->set_value(dtv);
+  state->_calib_dt_CAMtoIMU->set_fej(dtv);
+  state->_timestamp = t_state;
+  std::vector<std::shared_ptr<Type>> all;
+  all.push_back(state->_imu);
+  all.push_back(state->_calib_dt_CAMtoIMU);
+  all.push_back(state->_calib_IMUtoCAM.at(0));
+  all.push_back(state->_cam_intrinsics.at(0));
+  for (auto &c : state->_clones_IMU) all.push_back(c.second);
+  MatrixXd Pm(N, N);
+  memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+  StateHelper::set_initial_covariance(state, Pm, all);
+  NoiseManager nm;
+  nm.sigma_w = sigmas4[0];
+  nm.sigma_a = sigmas4[1];
+  nm.sigma_wb = sigmas4[2];
+  nm.sigma_ab = sigmas4[3];
+  Propagator prop(nm, gravity_mag);
+  for (int i = 0; i < n_imu; ++i) {
+    ov_core::ImuData d;
+    d.timestamp = imu[7 * i];
+    for (int k = 0; k < 3; ++k) {
+      d.wm[k] = imu[7 * i + 1 + k];
+      d.am[k] = imu[7 * i + 4 + k];
+    }
+    prop.feed_imu(d);
+  }
+  prop.propagate_and_clone(state, timestamp);
+  memcpy(out_x16, state->_imu->value().data(), 16 * sizeof(double));
+  memcpy(out_x16_fej, state->_imu->fej().data(), 16 * sizeof(double));
+  memcpy(out_Phi, prop.last_Phi(), 225 * sizeof(double));
+  memcpy(out_Qd, prop.last_Qd(), 225 * sizeof(double));
+  memcpy(out_last_w, prop.last_w(), 3 * sizeof(double));
+  const int n2 = state->max_covariance_size();
+  if (n2 != N + 6) return -12;
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)n2 * n2);
+  auto nc = state->_clones_IMU.at(timestamp);
+  memcpy(out_new_clone7, nc->value().data(), 7 * sizeof(double));
+  return 0;
+}

@@ -5,6 +5,7 @@
 #pragma once
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <unordered_map>
 #include <vector>
@@ -20,6 +21,8 @@ struct StateOptions {
   bool do_calib_camera_pose = false;
   bool do_calib_camera_intrinsics = false;
   bool do_calib_camera_timeoffset = false;
+  bool imu_avg = false;
+  bool use_rk4_integration = true;
   int max_clone_size = 11;
   int num_cameras = 1;
   bool use_plane_constraint = false;
@@ -174,6 +177,46 @@ public:
 
 protected:
   UpdaterOptions _options;
+};
+
+// utils/NoiseManager.h:36-79 (continuous-time IMU noise densities; *_2 are filled by the Propagator constructor)
+struct NoiseManager {
+  double sigma_w = 1.6968e-04, sigma_w_2 = 0;
+  double sigma_wb = 1.9393e-05, sigma_wb_2 = 0;
+  double sigma_a = 2.0000e-3, sigma_a_2 = 0;
+  double sigma_ab = 3.0000e-03, sigma_ab_2 = 0;
+};
+
+// state/Propagator.h:47-230.  Mean integration and the 15x15 Phi / Qd accumulation are host scalar code as in the
+// reference; the covariance step goes to the device through StateHelper::EKFPropagation + augment_clone.
+class Propagator {
+public:
+  Propagator(NoiseManager noises, double gravity_mag);
+  void feed_imu(const ov_core::ImuData &message, double oldest_time = -1);                    // Propagator.h:70-87
+  void propagate_and_clone(std::shared_ptr<State> state, double timestamp);                  // Propagator.cpp:37-126
+  static std::vector<ov_core::ImuData> select_imu_readings(const std::vector<ov_core::ImuData> &imu_data, double time0,
+                                                           double time1, bool warn = true);  // Propagator.cpp:227-341
+  static ov_core::ImuData interpolate_data(const ov_core::ImuData &imu_1, const ov_core::ImuData &imu_2, double timestamp);
+  // F, Qd: column-major 15 x 15 in the IMU error order [th p v bg ba]
+  void predict_and_compute(std::shared_ptr<State> state, const ov_core::ImuData &data_minus, const ov_core::ImuData &data_plus,
+                           double F[225], double Qd[225]);                                    // Propagator.cpp:343-454
+  // last summed transition / noise (diagnostics and tests)
+  const double *last_Phi() const { return _Phi; }
+  const double *last_Qd() const { return _Qs; }
+  const double *last_w() const { return _last_w; }
+
+protected:
+  void predict_mean_discrete(std::shared_ptr<State> state, double dt, const double w1[3], const double a1[3], const double w2[3],
+                             const double a2[3], double new_q[4], double new_v[3], double new_p[3]);  // :456-488
+  void predict_mean_rk4(std::shared_ptr<State> state, double dt, const double w1[3], const double a1[3], const double w2[3],
+                        const double a2[3], double new_q[4], double new_v[3], double new_p[3]);       // :490-569
+  double last_prop_time_offset = 0.0;
+  bool have_last_prop_time_offset = false;
+  NoiseManager _noises;
+  std::vector<ov_core::ImuData> imu_data;
+  std::mutex imu_data_mtx;
+  double _gravity[3];
+  double _Phi[225], _Qs[225], _last_w[3];
 };
 
 }  // namespace ov_plane

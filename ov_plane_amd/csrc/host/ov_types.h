@@ -262,6 +262,32 @@ public:
   std::shared_ptr<Vec> bg() { return _bg; }
   std::shared_ptr<Vec> ba() { return _ba; }
   const double *vel() const { return _v->value().data(); }
+  const double *Rot() const { return _pose->Rot(); }
+  const double *Rot_fej() const { return _pose->Rot_fej(); }
+  const double *quat() const { return _pose->quat(); }
+  const double *quat_fej() const { return _pose->quat_fej(); }
+  const double *pos() const { return _pose->pos(); }
+  const double *pos_fej() const { return _pose->pos_fej(); }
+  const double *vel_fej() const { return _v->fej().data(); }
+  const double *bias_g() const { return _bg->value().data(); }
+  const double *bias_a() const { return _ba->value().data(); }
+  // 16-vector [q p v bg ba] like ext ov_type::IMU::set_value / set_fej
+  void set_value(const VectorXd &x) override {
+    split(x, true);
+    _value = x;
+  }
+  void set_fej(const VectorXd &x) override {
+    split(x, false);
+    _fej = x;
+  }
+  const VectorXd &value() const override {
+    gather(true);
+    return _value;
+  }
+  const VectorXd &fej() const override {
+    gather(false);
+    return _fej;
+  }
   std::shared_ptr<Type> clone() override {
     auto c = std::make_shared<IMU>();
     c->pose()->set_value(_pose->value());
@@ -278,6 +304,37 @@ public:
   }
 
 protected:
+  void split(const VectorXd &x, bool val) {
+    VectorXd a(7, 1), b(3, 1), c(3, 1), d(3, 1);
+    for (int k = 0; k < 7; ++k) a(k) = x(k);
+    for (int k = 0; k < 3; ++k) {
+      b(k) = x(7 + k);
+      c(k) = x(10 + k);
+      d(k) = x(13 + k);
+    }
+    if (val) {
+      _pose->set_value(a);
+      _v->set_value(b);
+      _bg->set_value(c);
+      _ba->set_value(d);
+    } else {
+      _pose->set_fej(a);
+      _v->set_fej(b);
+      _bg->set_fej(c);
+      _ba->set_fej(d);
+    }
+  }
+  void gather(bool val) const {  // sub-variables are updated individually (IMU::update), the composite is rebuilt on read
+    VectorXd &o = val ? const_cast<VectorXd &>(_value) : const_cast<VectorXd &>(_fej);
+    const VectorXd &a = val ? _pose->value() : _pose->fej(), &b = val ? _v->value() : _v->fej();
+    const VectorXd &c = val ? _bg->value() : _bg->fej(), &d = val ? _ba->value() : _ba->fej();
+    for (int k = 0; k < 7; ++k) o(k) = a(k);
+    for (int k = 0; k < 3; ++k) {
+      o(7 + k) = b(k);
+      o(10 + k) = c(k);
+      o(13 + k) = d(k);
+    }
+  }
   std::shared_ptr<PoseJPL> _pose;
   std::shared_ptr<Vec> _v, _bg, _ba;
 };
@@ -312,4 +369,10 @@ struct Feature {
   double p_FinG[3] = {0, 0, 0};
 };
 struct FeatureInitializerOptions {};
+// ext ov_core::ImuData (utils/sensor_data.h)
+struct ImuData {
+  double timestamp = 0.0;
+  double wm[3] = {0, 0, 0};  // angular velocity (rad/s)
+  double am[3] = {0, 0, 0};  // linear acceleration (m/s^2)
+};
 }  // namespace ov_core

@@ -145,3 +145,32 @@ def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0):
     for k in ("kept", "deleted"):
         out[k] = out[k].astype(bool)
     return out
+
+
+def run_propagate(sc, x, imu, t_state, timestamp, calib_dt, po):
+    """Drives ov_plane::Propagator::propagate_and_clone (C++ host mirror; covariance on the device) on the clone window and
+    covariance of a synth scene (no planes / SLAM) with IMU state x (dict: q p v bg ba + *_fej) and readings imu [n,7]."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N = int(sc.N)
+    x16 = f64(np.concatenate([x["q"], x["p"], x["v"], x["bg"], x["ba"]]))
+    x16f = f64(np.concatenate([x["q_fej"], x["p_fej"], x["v_fej"], x["bg_fej"], x["ba_fej"]]))
+    P = np.asfortranarray(sc.P)
+    imu = f64(imu)
+    sig = f64([po["sigma_w"], po["sigma_a"], po["sigma_wb"], po["sigma_ab"]])
+    cq, cp_ = f64(sc.clone_q), f64(sc.clone_p)
+    out = dict(x16=np.zeros(16), x16_fej=np.zeros(16), Phi=np.zeros((15, 15)), Q=np.zeros((15, 15)), last_w=np.zeros(3),
+               P=np.zeros((N + 6, N + 6)), new_clone=np.zeros(7))
+    L.ovph_run_propagate.restype = C.c_int
+    rc = L.ovph_run_propagate(C.c_int(sc.C), p(cq), p(cp_), p(x16), p(x16f), C.c_double(calib_dt), C.c_int(N), p(P),
+                              C.c_int(imu.shape[0]), p(imu), C.c_double(t_state), C.c_double(timestamp), p(sig),
+                              C.c_double(po["gravity_mag"]), C.c_int(int(po["use_rk4"])), C.c_int(int(po["imu_avg"])),
+                              C.c_int(int(po["do_fej"])), p(out["x16"]), p(out["x16_fej"]), p(out["Phi"]), p(out["Q"]),
+                              p(out["last_w"]), p(out["P"]), p(out["new_clone"]))
+    if rc != 0:
+        raise RuntimeError("ovph_run_propagate failed with %d" % rc)
+    out["Phi"] = np.ascontiguousarray(out["Phi"].T)   # column-major on the C++ side
+    out["Q"] = np.ascontiguousarray(out["Q"].T)
+    out["P"] = np.ascontiguousarray(out["P"].T)
+    return out

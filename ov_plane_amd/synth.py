@@ -494,3 +494,52 @@ def make_slam_scene(C=11, n_slam=12, seed=0, n_planes=0, ragged=True, outliers=0
         for f in range(min(wrong_plane, n_slam)):
             sc.plane_id[f] = 1 + (int(sc.plane_id[f]) % n_planes)
     return sc
+
+
+def _rotz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def _roty(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1.0, 0], [-s, 0, c]])
+
+
+def make_imu_scenario(seed=0, rate=400.0, t_state=100.0, dt_cam=0.1, t_off=0.004, fej_perturb=1e-3, low_rate=False):
+    """IMU state + a stream of inertial readings around one camera interval (imitating Simulator's 400 Hz IMU / 10 Hz
+    camera, config/sim/estimator_config.yaml:177-178).  Returns (x, imu, time0, time1):
+      x    dict q p v bg ba (+ *_fej first estimates)
+      imu  [n,7] rows (t, wm xyz, am xyz); readings neither start nor end on time0/time1, so both ends are interpolated
+      time0 = t_state + t_off, time1 = t_state + dt_cam + t_off  (Propagator.cpp:67-68)
+    `low_rate` produces a stream slower than the camera (exercises the CASE 3.1 branch of select_imu_readings).
+    """
+    rng = np.random.default_rng(4242 + seed)
+    q = rot_2_quat(_rotz(0.3 * rng.standard_normal()) @ _roty(0.1 * rng.standard_normal()))
+    x = dict(q=q, p=rng.uniform(-2, 2, 3), v=np.array([0.8, 0.2, -0.05]) + 0.1 * rng.standard_normal(3),
+             bg=1e-3 * rng.standard_normal(3), ba=1e-2 * rng.standard_normal(3))
+    x["q_fej"] = quat_boxplus(x["q"], fej_perturb * rng.standard_normal(3))
+    x["p_fej"] = x["p"] + fej_perturb * rng.standard_normal(3)
+    x["v_fej"] = x["v"] + fej_perturb * rng.standard_normal(3)
+    x["bg_fej"] = x["bg"].copy()
+    x["ba_fej"] = x["ba"].copy()
+    time0, time1 = t_state + t_off, t_state + dt_cam + t_off
+    if low_rate:
+        ts = time0 - 0.013 + np.arange(0, 6) * 0.07
+    else:
+        ts = time0 - 0.0113 + np.arange(0, int((dt_cam + 0.03) * rate)) / rate
+    R = quat_2_rot(x["q"])
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    imu = np.zeros((len(ts), 7))
+    imu[:, 0] = ts
+    for k in range(3):
+        imu[:, 1 + k] = 0.35 * np.sin(2 * np.pi * 0.7 * (ts - ts[0]) + ph[k]) + x["bg"][k]
+        imu[:, 4 + k] = 0.6 * np.sin(2 * np.pi * 1.1 * (ts - ts[0]) + ph[3 + k]) + x["ba"][k]
+    imu[:, 4:7] += R @ np.array([0, 0, 9.81])
+    imu[:, 1:4] += 1.7e-4 * np.sqrt(rate) * rng.standard_normal((len(ts), 3))
+    imu[:, 4:7] += 2.0e-3 * np.sqrt(rate) * rng.standard_normal((len(ts), 3))
+    return x, imu, time0, time1
+
+
+PROP_OPTS = dict(sigma_w=1.6968e-04, sigma_a=2.0000e-3, sigma_wb=1.9393e-05, sigma_ab=3.0000e-03, gravity_mag=9.81,
+                 use_rk4=True, imu_avg=False, do_fej=True)

@@ -533,3 +533,46 @@ def test_host_cpp_mirror_updater_plane_init(hiplib, oracle):
     assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
     assert np.abs(out["intr"] - ref["intr"]).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
+
+
+@pytest.mark.parametrize("mode", [dict(use_rk4=1, do_fej=1, imu_avg=0), dict(use_rk4=0, do_fej=0, imu_avg=1),
+                                  dict(use_rk4=1, do_fej=1, imu_avg=0, low_rate=True)])
+def test_host_cpp_mirror_propagator(hiplib, oracle, mode):
+    """ov_plane::Propagator::propagate_and_clone (state/Propagator.cpp:37-126): host Phi/Qd accumulation vs the oracle, then
+    StateHelper::EKFPropagation + augment_clone (with the time-offset Jacobian, StateHelper.cpp:613-624) on the device P."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import PROP_OPTS, make_imu_scenario
+    from oracle import np_ref
+
+    mode = dict(mode)
+    low = mode.pop("low_rate", False)
+    sc = make_scene(C=6, F=4, seed=91)
+    t_off = 0.004
+    x, imu, t0, t1 = make_imu_scenario(7, t_state=100.0, dt_cam=0.1, t_off=t_off, low_rate=low)
+    po = dict(PROP_OPTS, **mode)
+    ref = oracle.propagate_summed(x, po, imu, t0, t1)
+    out = hostlib.run_propagate(sc, x, imu, 100.0, 100.1, t_off, po)
+    assert np.abs(out["Phi"] - ref["Phi"]).max() < 1e-12
+    assert np.abs(out["Q"] - ref["Q"]).max() < 1e-12 * np.abs(ref["Q"]).max()
+    assert np.abs(out["last_w"] - ref["last_w"]).max() < 1e-14
+    xr = ref["x"]
+    x16 = np.concatenate([xr["q"], xr["p"], xr["v"], xr["bg"], xr["ba"]])
+    assert np.abs(out["x16"] - x16).max() < 1e-12 and np.abs(out["x16_fej"] - x16).max() < 1e-12
+    assert np.abs(out["new_clone"] - x16[:7]).max() < 1e-12
+    # covariance: EKFPropagation over the IMU block, clone of the pose, time-offset augmentation
+    N = sc.N
+    Pp = np_ref.ekf_propagation(sc.P, 0, 15, [(0, 15)], ref["Phi"], ref["Q"])
+    Pc = np.zeros((N + 6, N + 6))
+    Pc[:N, :N] = Pp
+    Pc[N:, :N] = Pp[:6, :]
+    Pc[:N, N:] = Pp[:, :6]
+    Pc[N:, N:] = Pp[:6, :6]
+    dnc = np.concatenate([ref["last_w"], xr["v"]])
+    col = Pc[:, 15].copy()
+    Pc[:, N:] += np.outer(col, dnc)
+    row = Pc[15, :].copy()
+    Pc[N:, :] += np.outer(dnc, row)
+    assert relP(out["P"], Pc) < 1e-10

@@ -239,3 +239,73 @@ def test_plane_rows_are_mergeable_and_constraint_matches_ceres_factor():
         _, _, r1, _ = np_ref.feature_jacobian_full(sc, f, cp=cpk, plane_state_id=-1, planeid=1)
         num = -(r1[2 * m] - res[2 * m]) / eps
         assert abs(num - H_f[2 * m, 3 + k]) < 1e-4 * max(1.0, abs(H_f[2 * m, 3 + k]))
+
+
+# ---- Propagator (a11) ----------------------------------------------------------------------------------------------
+def _prop_cases():
+    for seed in range(2):
+        for rk4 in (0, 1):
+            for fej in (0, 1):
+                for avg in (0, 1):
+                    for low in (False, True):
+                        yield seed, rk4, fej, avg, low
+
+
+def test_propagator_c_restatement_equals_independent_numpy():
+    """Phi_summed / Qd_summed / propagated mean / last_w / reading selection (state/Propagator.cpp:37-118,227-341,343-569):
+    the C oracle against the matrix-form numpy restatement written separately, every integration and Jacobian mode."""
+    from ov_plane_amd.synth import PROP_OPTS, make_imu_scenario
+    from oracle import np_ref, pyoracle
+
+    for seed, rk4, fej, avg, low in _prop_cases():
+        x, imu, t0, t1 = make_imu_scenario(seed, low_rate=low)
+        o = dict(PROP_OPTS, use_rk4=rk4, do_fej=fej, imu_avg=avg)
+        a = pyoracle.propagate_summed(x, o, imu, t0, t1)
+        b = np_ref.propagate_summed(x, o, imu, t0, t1)
+        sa, sb = pyoracle.select_imu_readings(imu, t0, t1), np_ref.select_imu_readings(imu, t0, t1)
+        assert sa.shape == sb.shape and np.abs(sa - sb).max() < 1e-12
+        assert sa[0, 0] == t0 and sa[-1, 0] == t1 and (np.diff(sa[:, 0]) > 0).all()
+        assert a["n_sel"] == b["n_sel"] >= 2
+        assert np.abs(a["Phi"] - b["Phi"]).max() < 1e-11
+        assert np.abs(a["Q"] - b["Q"]).max() < 1e-11 * np.abs(b["Q"]).max()
+        assert max(np.abs(a["x"][k] - b["x"][k]).max() for k in a["x"]) < 1e-11
+        assert np.abs(a["last_w"] - b["last_w"]).max() < 1e-14
+        assert np.abs(a["Q"] - a["Q"].T).max() == 0.0 and np.linalg.eigvalsh(a["Q"]).min() > -1e-18
+
+
+def test_propagator_transition_matrix_is_the_jacobian_of_the_mean_integration():
+    """Finite differences of the discrete mean integration (Propagator.cpp:456-488) with the JPL left-multiplicative
+    error state against F of predict_and_compute (:411-432); and the FEJ form (:379-409) reduces to the same matrix when
+    the first estimates equal the values."""
+    from ov_plane_amd.synth import PROP_OPTS, make_imu_scenario, quat_boxplus, quat_multiply
+    from oracle import np_ref
+
+    x, imu, t0, t1 = make_imu_scenario(3)
+    o = dict(PROP_OPTS, use_rk4=0, do_fej=0, imu_avg=0)
+    minus, plus = imu[5], imu[6]
+    xn, F, _ = np_ref.predict_and_compute(x, o, minus, plus)
+
+    def perturb(x, e):
+        y = dict(x)
+        y["q"] = quat_boxplus(x["q"], e[0:3])
+        y["p"], y["v"], y["bg"], y["ba"] = x["p"] + e[3:6], x["v"] + e[6:9], x["bg"] + e[9:12], x["ba"] + e[12:15]
+        return y
+
+    def err(y, ynom):
+        qi = ynom["q"] * np.array([-1, -1, -1, 1.0])
+        dq = quat_multiply(y["q"], qi)
+        return np.concatenate([2 * dq[:3] / dq[3], y["p"] - ynom["p"], y["v"] - ynom["v"], y["bg"] - ynom["bg"],
+                               y["ba"] - ynom["ba"]])
+
+    eps = 1e-6
+    Ffd = np.zeros((15, 15))
+    for k in range(15):
+        e = np.zeros(15)
+        e[k] = eps
+        yp, _, _ = np_ref.predict_and_compute(perturb(x, e), o, minus, plus)
+        ym, _, _ = np_ref.predict_and_compute(perturb(x, -e), o, minus, plus)
+        Ffd[:, k] = (err(yp, xn) - err(ym, xn)) / (2 * eps)
+    assert np.abs(F - Ffd).max() < 2e-8
+    xf = dict(x, q_fej=x["q"], p_fej=x["p"], v_fej=x["v"])
+    _, Ffej, _ = np_ref.predict_and_compute(xf, dict(o, do_fej=1), minus, plus)
+    assert np.abs(Ffej - F).max() < 1e-12
