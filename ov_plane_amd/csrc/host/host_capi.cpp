@@ -492,3 +492,83 @@ extern "C" int ovph_run_propagate(int C, const double *clone_q, const double *cl
   memcpy(out_new_clone7, nc->value().data(), 7 * sizeof(double));
   return 0;
 }
+
+// StateHelper::marginalize_slam + merge_planes_and_marginalize harness.  State: clones, n_slam landmarks (should_marg flags),
+// n_planes in-state planes (ids 1..n).  merge_pairs [n_pairs x 2] = (old id, new id); active_planes = ids observed by features.
+// Outputs: final P / n, for every plane id 1..n+8 its Type::id() (or -1) and value, landmark ids (or -1).
+extern "C" int ovph_run_state_maintenance(int C, const double *clone_q, const double *clone_p, const double *calib_q,
+                                          const double *calib_p, const double *intr, int n_slam, const double *slam_p,
+                                          const unsigned char *should_marg, int n_planes, const double *cp, int N, const double *P,
+                                          int n_pairs, const int *merge_pairs, int n_active, const int *active_planes,
+                                          double sigma_plane_merge, double plane_merge_chi2, double plane_merge_deg_max,
+                                          double *out_P, int *out_n, int *out_plane_state_id /* [n_planes+8] */,
+                                          double *out_plane_cp /* [(n_planes+8)*3] */, int *out_slam_state_id,
+                                          int *out_slam_to_plane) {
+  StateOptions so;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.use_plane_constraint = true;
+  so.sigma_plane_merge = sigma_plane_merge;
+  so.plane_merge_chi2 = plane_merge_chi2;
+  so.plane_merge_deg_max = plane_merge_deg_max;
+  so.max_state_size = N + 8;
+  so.max_features = 16;
+  HarnessState hs;
+  int rc = build_harness_state(hs, so, C, clone_q, clone_p, clone_q, clone_p, calib_q, calib_p, intr, n_slam, slam_p, slam_p,
+                               n_planes, cp, cp, N, P);
+  if (rc) return rc;
+  auto &state = hs.state;
+  for (int k = 0; k < n_slam; ++k) {
+    hs.landmarks[k]->should_marg = should_marg[k] != 0;
+    state->_features_SLAM_to_PLANE[hs.landmarks[k]->_featid] = 1;
+  }
+  StateHelper::marginalize_slam(state);
+  std::map<size_t, size_t> feat2plane;
+  for (int k = 0; k < n_active; ++k) feat2plane[7000 + k] = (size_t)active_planes[k];
+  std::map<size_t, std::set<size_t>> plane2oldplane;
+  for (int k = 0; k < n_pairs; ++k) plane2oldplane[(size_t)merge_pairs[2 * k + 1]].insert((size_t)merge_pairs[2 * k]);
+  StateHelper::merge_planes_and_marginalize(state, feat2plane, plane2oldplane);
+  const int n2 = state->max_covariance_size();
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)n2 * n2);
+  *out_n = n2;
+  for (int k = 0; k < n_planes + 8; ++k) {
+    out_plane_state_id[k] = -1;
+    auto it = state->_features_PLANE.find((size_t)(k + 1));
+    if (it == state->_features_PLANE.end()) continue;
+    out_plane_state_id[k] = it->second->id();
+    memcpy(out_plane_cp + 3 * k, it->second->value().data(), 3 * sizeof(double));
+  }
+  for (int k = 0; k < n_slam; ++k) {
+    auto it = state->_features_SLAM.find(hs.landmarks[k]->_featid);
+    out_slam_state_id[k] = (it == state->_features_SLAM.end()) ? -1 : it->second->id();
+    out_slam_to_plane[k] = state->_features_SLAM_to_PLANE.count(hs.landmarks[k]->_featid) ? 1 : 0;
+  }
+  return 0;
+}
+
+// UpdaterPlane::nullspace_project_inplace / measurement_compress_inplace and the UpdaterHelper twins on dense inputs
+// (column-major).  Returns the number of rows left; outputs overwrite the leading rows of the inputs (ld unchanged).
+extern "C" int ovph_run_plane_givens(int op /* 0 nullspace, 1 compress */, int rows, int hf_cols, double *H_f, int cols,
+                                     double *H_x, int cp_cols, double *H_cp, double *res) {
+  MatrixXd Hf(rows, std::max(hf_cols, 1)), Hx(rows, cols), Hcp(rows, std::max(cp_cols, 1));
+  VectorXd r(rows, 1);
+  if (hf_cols) memcpy(Hf.data(), H_f, sizeof(double) * (size_t)rows * hf_cols);
+  memcpy(Hx.data(), H_x, sizeof(double) * (size_t)rows * cols);
+  if (cp_cols) memcpy(Hcp.data(), H_cp, sizeof(double) * (size_t)rows * cp_cols);
+  memcpy(r.data(), res, sizeof(double) * rows);
+  if (op == 0) {
+    if (cp_cols) UpdaterPlane::nullspace_project_inplace(Hf, Hx, Hcp, r);
+    else UpdaterHelper::nullspace_project_inplace(Hf, Hx, r);
+  } else {
+    if (cp_cols) UpdaterPlane::measurement_compress_inplace(Hx, Hcp, r);
+    else UpdaterHelper::measurement_compress_inplace(Hx, r);
+  }
+  const int ro = Hx.rows();
+  for (int j = 0; j < cols; ++j)
+    for (int i = 0; i < ro; ++i) H_x[(size_t)j * rows + i] = Hx(i, j);
+  for (int j = 0; j < cp_cols; ++j)
+    for (int i = 0; i < ro; ++i) H_cp[(size_t)j * rows + i] = Hcp(i, j);
+  for (int i = 0; i < ro; ++i) res[i] = r(i);
+  return ro;
+}

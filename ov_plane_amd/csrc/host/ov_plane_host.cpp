@@ -303,6 +303,110 @@ void StateHelper::marginalize_old_clone(std::shared_ptr<State> state) {
   }
 }
 
+// ---- state/StateHelper.cpp:638-652 -------------------------------------------------------------
+void StateHelper::marginalize_slam(std::shared_ptr<State> state) {
+  auto it0 = state->_features_SLAM.begin();
+  while (it0 != state->_features_SLAM.end()) {
+    if ((*it0).second->should_marg && (int)(*it0).first > 4 * state->_options.max_aruco_features) {
+      StateHelper::marginalize(state, (*it0).second);
+      state->_features_SLAM_to_PLANE.erase((*it0).first);
+      it0 = state->_features_SLAM.erase(it0);
+    } else {
+      it0++;
+    }
+  }
+}
+
+// ---- state/StateHelper.cpp:654-776 -------------------------------------------------------------
+void StateHelper::merge_planes_and_marginalize(std::shared_ptr<State> state, const std::map<size_t, size_t> &feat2plane,
+                                               const std::map<size_t, std::set<size_t>> &plane2oldplane) {
+  if (state->_features_PLANE.empty()) return;
+  auto it5 = state->_features_PLANE.begin();
+  while (it5 != state->_features_PLANE.end()) {
+    const size_t planeid = (*it5).first;
+    int planeid_new = -1;
+    bool in_state = false;
+    for (auto const &planeset : plane2oldplane) {
+      if (planeset.second.find(planeid) != planeset.second.end()) {
+        planeid_new = (int)planeset.first;
+        in_state = (state->_features_PLANE.find(planeset.first) != state->_features_PLANE.end());
+      }
+    }
+    if (planeid_new == -1 || (int)planeid == planeid_new) {
+      it5++;
+      continue;
+    }
+    if (!in_state) {  // the surviving id is not a state variable: the old variable simply takes the new id
+      state->_features_PLANE.insert({(size_t)planeid_new, state->_features_PLANE.at(planeid)});
+      it5 = state->_features_PLANE.erase(it5);
+      continue;
+    }
+    auto plane_new = state->_features_PLANE.at((size_t)planeid_new);
+    auto plane_old = state->_features_PLANE.at(planeid);
+    double cn[3], co[3], nn = 0, no = 0, dot = 0;
+    for (int k = 0; k < 3; ++k) {
+      cn[k] = plane_new->value()(k);
+      co[k] = plane_old->value()(k);
+      nn += cn[k] * cn[k];
+      no += co[k] * co[k];
+    }
+    nn = std::sqrt(nn);
+    no = std::sqrt(no);
+    for (int k = 0; k < 3; ++k) dot += (cn[k] / nn) * (co[k] / no);
+    const double norm_angle = (180.0 / M_PI) * std::acos(dot);
+    // 3 rows: cp_new - cp_old = 0 with sigma_plane_merge
+    const double white_c = 1.0 / state->_options.sigma_plane_merge;
+    VectorXd res(3, 1);
+    MatrixXd H = MatrixXd::Zero(3, 6);
+    for (int k = 0; k < 3; ++k) {
+      res(k) = white_c * (0.0 - (cn[k] - co[k]));
+      H(k, k) = white_c;
+      H(k, 3 + k) = -white_c;
+    }
+    std::vector<std::shared_ptr<Type>> H_order = {plane_new, plane_old};
+    MatrixXd R = MatrixXd::Identity(3, 3);
+    // S = H P_marg H^T + R is 3x3: (Pnn - Pno - Pon + Poo) / sigma^2 + I
+    MatrixXd P_marg = StateHelper::get_marginal_covariance(state, H_order);
+    double S[9], L[9] = {0};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        S[3 * i + j] = white_c * white_c * (P_marg(i, j) - P_marg(i, 3 + j) - P_marg(3 + i, j) + P_marg(3 + i, 3 + j)) + (i == j ? 1.0 : 0.0);
+    for (int j = 0; j < 3; ++j) {  // LLT
+      double d = S[3 * j + j];
+      for (int k = 0; k < j; ++k) d -= L[3 * j + k] * L[3 * j + k];
+      L[3 * j + j] = std::sqrt(d);
+      for (int i = j + 1; i < 3; ++i) {
+        double s = S[3 * i + j];
+        for (int k = 0; k < j; ++k) s -= L[3 * i + k] * L[3 * j + k];
+        L[3 * i + j] = s / L[3 * j + j];
+      }
+    }
+    double y[3], chi2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      double s = res(i);
+      for (int k = 0; k < i; ++k) s -= L[3 * i + k] * y[k];
+      y[i] = s / L[3 * i + i];
+      chi2 += y[i] * y[i];
+    }
+    const double chi2_check = state->_options.plane_merge_chi2 * ovp_chi2_quantile_095(3);
+    if (chi2 < chi2_check && norm_angle < state->_options.plane_merge_deg_max) StateHelper::EKFUpdate(state, H_order, H, res, R);
+    StateHelper::marginalize(state, plane_old);
+    it5 = state->_features_PLANE.erase(it5);
+  }
+  // planes without any observing feature leave the state
+  std::set<size_t> active_planes;
+  for (auto const &featpair : feat2plane) active_planes.insert(featpair.second);
+  it5 = state->_features_PLANE.begin();
+  while (it5 != state->_features_PLANE.end()) {
+    if (active_planes.find((*it5).first) == active_planes.end()) {
+      StateHelper::marginalize(state, (*it5).second);
+      it5 = state->_features_PLANE.erase(it5);
+    } else {
+      it5++;
+    }
+  }
+}
+
 // ---- Eigen pieces used by initialize ----------------------------------------
 static void make_givens(double p, double q, double &c, double &s) {
   if (q == 0.0) {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <map>
 #include <mutex>
+#include <set>
 #include <memory>
 #include <unordered_map>
 #include <vector>
@@ -32,6 +33,11 @@ struct StateOptions {
   double sigma_constraint = 0.01;
   double const_init_multi = 1.0;
   double const_init_chi2 = 1.0;
+  int max_slam_features = 25;
+  int max_aruco_features = 1024;
+  double sigma_plane_merge = 0.001;
+  double plane_merge_chi2 = 1.00;
+  double plane_merge_deg_max = 1.00;
   // capacity of the device context (not in the reference: Eigen resizes dynamically)
   int max_state_size = 320;
   int max_features = 8192;
@@ -100,6 +106,11 @@ public:
   static std::shared_ptr<ov_type::Type> clone(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> variable_to_clone);
   static void augment_clone(std::shared_ptr<State> state, const double last_w[3]);
   static void marginalize_old_clone(std::shared_ptr<State> state);
+  static void marginalize_slam(std::shared_ptr<State> state);  // state/StateHelper.cpp:638-652
+  // state/StateHelper.cpp:654-776: planes whose id was re-assigned by the tracker are merged into their new id (a 3-row
+  // EKF update cp_new - cp_old = 0 gated by chi2 and the angle between the normals), planes nobody observes are dropped
+  static void merge_planes_and_marginalize(std::shared_ptr<State> state, const std::map<size_t, size_t> &feat2plane,
+                                           const std::map<size_t, std::set<size_t>> &plane2oldplane);
   // state/StateHelper.h:172-173 / :188-190
   static bool initialize(std::shared_ptr<State> state, std::shared_ptr<ov_type::Type> new_variable,
                          const std::vector<std::shared_ptr<ov_type::Type>> &H_order, MatrixXd &H_R, MatrixXd &H_L, MatrixXd &R,
@@ -157,6 +168,9 @@ public:
   // state->_plane_estimates_cp_inG that are not in the state yet are initialised from their on-plane MSCKF features.
   void init_vio_plane(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                       std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane);
+  // update/UpdaterPlane.cpp:483-517 / :519-552: the UpdaterHelper operations with the plane Jacobian H_cp carried along
+  static void nullspace_project_inplace(MatrixXd &H_f, MatrixXd &H_x, MatrixXd &H_cp, VectorXd &res);
+  static void measurement_compress_inplace(MatrixXd &H_x, MatrixXd &H_cp, VectorXd &res);
 
 protected:
   UpdaterOptions _options;

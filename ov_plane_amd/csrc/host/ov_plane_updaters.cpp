@@ -509,6 +509,39 @@ UpdaterPlane::UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerO
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
 }
 
+void UpdaterPlane::nullspace_project_inplace(MatrixXd &H_f, MatrixXd &H_x, MatrixXd &H_cp, VectorXd &res) {
+  assert(H_f.rows() >= H_f.cols());
+  for (int n = 0; n < H_f.cols(); ++n)
+    for (int m = H_f.rows() - 1; m > n; m--) {
+      double c, s;
+      givens(H_f(m - 1, n), H_f(m, n), c, s);
+      rot2(H_f, m - 1, n, c, s);
+      rot2(H_x, m - 1, 0, c, s);
+      rot2(H_cp, m - 1, 0, c, s);
+      rot2(res, m - 1, 0, c, s);
+    }
+  const int k = H_f.cols();
+  H_x = H_x.block(k, 0, H_x.rows() - k, H_x.cols());
+  H_cp = H_cp.block(k, 0, H_cp.rows() - k, H_cp.cols());
+  res = res.block(k, 0, res.rows() - k, res.cols());
+}
+
+void UpdaterPlane::measurement_compress_inplace(MatrixXd &H_x, MatrixXd &H_cp, VectorXd &res) {
+  if (H_x.rows() <= H_x.cols()) return;
+  for (int n = 0; n < H_x.cols(); n++)
+    for (int m = H_x.rows() - 1; m > n; m--) {
+      double c, s;
+      givens(H_x(m - 1, n), H_x(m, n), c, s);
+      rot2(H_x, m - 1, n, c, s);
+      rot2(H_cp, m - 1, 0, c, s);
+      rot2(res, m - 1, 0, c, s);
+    }
+  const int r = std::min(H_x.rows(), H_x.cols());
+  H_x = H_x.block(0, 0, r, H_x.cols());
+  H_cp = H_cp.block(0, 0, r, H_cp.cols());
+  res = res.block(0, 0, r, 1);
+}
+
 void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                                   std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used,
                                   const std::map<size_t, size_t> &feat2plane) {

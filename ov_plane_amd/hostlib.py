@@ -174,3 +174,53 @@ def run_propagate(sc, x, imu, t_state, timestamp, calib_dt, po):
     out["Q"] = np.ascontiguousarray(out["Q"].T)
     out["P"] = np.ascontiguousarray(out["P"].T)
     return out
+
+
+def run_state_maintenance(sc, should_marg, merge_pairs, active_planes, sigma_plane_merge=0.001, plane_merge_chi2=1.0,
+                          plane_merge_deg_max=1.0):
+    """StateHelper::marginalize_slam followed by merge_planes_and_marginalize on a make_slam_scene-like state
+    (n_slam landmarks + all planes in the state)."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N = int(sc.N)
+    n_slam, n_pl = int(sc.slam_p.shape[0]), int(sc.cp.shape[0])
+    P = np.asfortranarray(sc.P)
+    sm = np.ascontiguousarray(should_marg, dtype=np.uint8)
+    mp = np.ascontiguousarray(np.asarray(merge_pairs, dtype=np.int32).reshape(-1, 2))
+    ap = np.ascontiguousarray(active_planes, dtype=np.int32)
+    out = dict(P=np.zeros((N, N)), n=np.zeros(1, dtype=np.int32), plane_id=np.zeros(n_pl + 8, dtype=np.int32),
+               plane_cp=np.zeros((n_pl + 8, 3)), slam_id=np.zeros(max(n_slam, 1), dtype=np.int32),
+               slam_to_plane=np.zeros(max(n_slam, 1), dtype=np.int32))
+    cq, cp_, calq, calp, intr = f64(sc.clone_q), f64(sc.clone_p), f64(sc.calib_q), f64(sc.calib_p), f64(sc.intr)
+    slam_p, cp = f64(sc.slam_p if n_slam else np.zeros((1, 3))), f64(sc.cp if n_pl else np.zeros((1, 3)))
+    L.ovph_run_state_maintenance.restype = C.c_int
+    rc = L.ovph_run_state_maintenance(
+        C.c_int(sc.C), p(cq), p(cp_), p(calq), p(calp), p(intr), C.c_int(n_slam), p(slam_p), p(sm), C.c_int(n_pl), p(cp),
+        C.c_int(N), p(P), C.c_int(mp.shape[0]), p(mp), C.c_int(len(ap)), p(ap), C.c_double(sigma_plane_merge),
+        C.c_double(plane_merge_chi2), C.c_double(plane_merge_deg_max), p(out["P"]), p(out["n"]), p(out["plane_id"]),
+        p(out["plane_cp"]), p(out["slam_id"]), p(out["slam_to_plane"]))
+    if rc != 0:
+        raise RuntimeError("ovph_run_state_maintenance failed with %d" % rc)
+    n2 = int(out["n"][0])
+    out["n"] = n2
+    out["P"] = np.ascontiguousarray(out["P"].reshape(-1)[: n2 * n2].reshape(n2, n2).T)
+    out["slam_id"] = out["slam_id"][:n_slam]
+    out["slam_to_plane"] = out["slam_to_plane"][:n_slam]
+    return out
+
+
+def run_plane_givens(op, H_f, H_x, H_cp, res):
+    """UpdaterPlane / UpdaterHelper ::nullspace_project_inplace (op 0) or ::measurement_compress_inplace (op 1) of the C++
+    host mirror on dense matrices; H_cp None selects the UpdaterHelper version."""
+    L = lib()
+    rows, cols = H_x.shape
+    Hx = np.asfortranarray(H_x, dtype=np.float64).copy(order="F")
+    Hf = np.asfortranarray(H_f if H_f is not None else np.zeros((rows, 1)), dtype=np.float64).copy(order="F")
+    Hc = np.asfortranarray(H_cp if H_cp is not None else np.zeros((rows, 1)), dtype=np.float64).copy(order="F")
+    r = np.ascontiguousarray(res, dtype=np.float64).copy()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L.ovph_run_plane_givens.restype = C.c_int
+    ro = L.ovph_run_plane_givens(C.c_int(op), C.c_int(rows), C.c_int(0 if H_f is None else H_f.shape[1]), p(Hf), C.c_int(cols),
+                                 p(Hx), C.c_int(0 if H_cp is None else H_cp.shape[1]), p(Hc), p(r))
+    return Hx[:ro].copy(), (Hc[:ro].copy() if H_cp is not None else None), r[:ro].copy()

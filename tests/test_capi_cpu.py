@@ -61,3 +61,37 @@ def test_struct_layouts_match_header(hiplib):
     assert C.sizeof(hiplib.UpdateInfo) == 32
     assert C.sizeof(hiplib.FeatureBatch) == 40
     assert C.sizeof(hiplib.StateTables) == 8 + 5 * 8 + 7 * 8 + 8 + 8 * 8 + 8
+
+
+def test_host_givens_operations_match_restatement():
+    """UpdaterHelper / UpdaterPlane ::nullspace_project_inplace and ::measurement_compress_inplace of the C++ host mirror
+    (update/UpdaterHelper.cpp:515-579, update/UpdaterPlane.cpp:483-552) are pure host arithmetic: checked here without a GPU
+    against the numpy restatement of the same rotation sequence."""
+    import numpy as np
+
+    from ov_plane_amd.build import build_host
+    from oracle import np_ref
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    rng = np.random.default_rng(12)
+    rows, cols = 33, 14
+    H_f, H_x, H_cp, res = (rng.standard_normal((rows, 3)), rng.standard_normal((rows, cols)), rng.standard_normal((rows, 3)),
+                           rng.standard_normal(rows))
+    # nullspace, with and without the plane Jacobian
+    Hx, Hcp, r = hostlib.run_plane_givens(0, H_f, H_x, H_cp, res)
+    eHx, er, eHcp = np_ref.nullspace_project_inplace(H_f, H_x, res, H_cp)
+    assert Hx.shape == (rows - 3, cols)
+    assert max(np.abs(Hx - eHx).max(), np.abs(Hcp - eHcp).max(), np.abs(r - er).max()) < 1e-13
+    Hx2, _, r2 = hostlib.run_plane_givens(0, H_f, H_x, None, res)
+    assert max(np.abs(Hx2 - eHx).max(), np.abs(r2 - er).max()) < 1e-13
+    # compression
+    Hx, Hcp, r = hostlib.run_plane_givens(1, None, H_x, H_cp, res)
+    eHx, er, eHcp = np_ref.measurement_compress_inplace(H_x, res, H_cp)
+    assert Hx.shape == (cols, cols)
+    assert max(np.abs(Hx - eHx).max(), np.abs(Hcp - eHcp).max(), np.abs(r - er).max()) < 1e-13
+    assert np.abs(Hx.T @ Hx - H_x.T @ H_x).max() < 1e-12
+    # rows <= cols: untouched (UpdaterHelper.cpp:551-552)
+    Hx, _, r = hostlib.run_plane_givens(1, None, H_x[:10], None, res[:10])
+    assert Hx.shape == (10, cols) and np.abs(Hx - H_x[:10]).max() == 0.0 and np.abs(r - res[:10]).max() == 0.0

@@ -576,3 +576,61 @@ def test_host_cpp_mirror_propagator(hiplib, oracle, mode):
     row = Pc[15, :].copy()
     Pc[N:, :] += np.outer(dnc, row)
     assert relP(out["P"], Pc) < 1e-10
+
+
+def test_host_cpp_mirror_state_maintenance(hiplib, oracle):
+    """StateHelper::marginalize_slam (state/StateHelper.cpp:638-652) and merge_planes_and_marginalize (:654-776): landmark
+    removal, a plane-merge EKF update (cp_new - cp_old = 0) with its chi2 / angle gate, relabelling of an out-of-state
+    target id and removal of unobserved planes, all on the device covariance."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import make_slam_scene
+    from oracle import np_ref
+
+    sc = make_slam_scene(C=6, n_slam=5, seed=8, n_planes=4)
+    # plane 2 is a re-detection of plane 1: same plane up to a small error that is consistent with the covariance
+    i1, i2 = int(sc.plane_state_id[0]), int(sc.plane_state_id[1])
+    P = sc.P.copy()
+    P[i2:i2 + 3, :] = P[i1:i1 + 3, :]
+    P[:, i2:i2 + 3] = P[:, i1:i1 + 3]
+    P[i2:i2 + 3, i2:i2 + 3] = P[i1:i1 + 3, i1:i1 + 3] + 1e-6 * np.eye(3)
+    sc["P"] = P
+    sc.cp[1] = sc.cp[0] + np.array([4e-4, -3e-4, 2e-4])
+    should_marg = np.array([0, 1, 0, 1, 0], dtype=np.uint8)
+    # plane 2 -> 1 (both in state: merge update), plane 3 -> 9 (9 not in state: relabel), plane 4 unobserved (dropped)
+    out = hostlib.run_state_maintenance(sc, should_marg, [(2, 1), (3, 9)], [1, 9])
+    # ---- expected ----
+    keep = np.ones(sc.N, dtype=bool)
+    for k in np.where(should_marg)[0]:
+        keep[sc.ids["slam"][k]:sc.ids["slam"][k] + 3] = False
+    newid = np.cumsum(keep) - 1
+    Pe = P[np.ix_(keep, keep)]
+    j1, j2 = int(newid[i1]), int(newid[i2])
+    wc = 1.0 / 0.001
+    H = np.hstack([wc * np.eye(3), -wc * np.eye(3)])
+    res = wc * (0.0 - (sc.cp[0] - sc.cp[1]))
+    order = [(j1, 3), (j2, 3)]
+    Pm = np_ref.get_marginal_covariance(Pe, order)
+    S = H @ Pm @ H.T + np.eye(3)
+    chi2 = float(res @ np.linalg.solve(S, res))
+    assert chi2 < np_ref.chi2_095(3)        # the merge passes its gate in this scenario
+    Pe, dx = np_ref.ekf_update(Pe, order, H, res)
+    cp1 = sc.cp[0] + dx[j1:j1 + 3]
+    cp3 = sc.cp[2] + dx[int(newid[sc.plane_state_id[2]]):int(newid[sc.plane_state_id[2]]) + 3]
+    keep2 = np.ones(Pe.shape[0], dtype=bool)
+    keep2[j2:j2 + 3] = False
+    j4 = int(newid[sc.plane_state_id[3]])
+    keep2[j4:j4 + 3] = False
+    Pe = Pe[np.ix_(keep2, keep2)]
+    assert out["n"] == Pe.shape[0] == sc.N - 6 - 6
+    assert relP(out["P"], Pe) < 1e-9
+    newid2 = np.cumsum(keep2) - 1
+    assert out["plane_id"][0] == newid2[j1] and out["plane_id"][1] == -1 and out["plane_id"][2] == -1
+    assert out["plane_id"][3] == -1 and out["plane_id"][8] == newid2[int(newid[sc.plane_state_id[2]])]
+    assert np.abs(out["plane_cp"][0] - cp1).max() < TOL_DX and np.abs(out["plane_cp"][8] - cp3).max() < TOL_DX
+    assert (out["slam_id"] >= 0).tolist() == [True, False, True, False, True]
+    assert out["slam_to_plane"].tolist() == [1, 0, 1, 0, 1]
+    exp_ids = [int(newid2[newid[sc.ids["slam"][k]]]) for k in (0, 2, 4)]
+    assert out["slam_id"][[0, 2, 4]].tolist() == exp_ids
