@@ -87,9 +87,11 @@ def main():
 
     C, F = args.clones, args.feats
     sc = make_scene(C=C, F=F, seed=0, feat_seed=100 + rank, chi2_mult=1.0)
-    stream = torch.cuda.Stream()
+    # the library creates its own stream pair (CU-partitioned, see ovp_ctx_create); torch work of this process (the RCCL
+    # all_reduce for N > 1, the device copy of P) is ordered on the same stream through an ExternalStream view
+    ctx = capi.Context(sc.N, sc.C, sc.F, device=local_rank)
+    stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", local_rank))
     with torch.cuda.stream(stream):
-        ctx = capi.Context(sc.N, sc.C, sc.F, device=local_rank, stream=stream.cuda_stream)
         ctx.state_upload(sc)
         ctx.batch_upload_scene(sc)  # inputs resident in HBM before the timed region
         P0 = torch.from_numpy(np.ascontiguousarray(sc.P)).to("cuda")

@@ -86,10 +86,12 @@ typedef struct {
 } ovp_update_info;
 
 /* ---- context --------------------------------------------------------------------------------- */
-/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to create one. */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create its own. */
 int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int n_feats_max, void *stream, ovp_ctx **out);
 int ovp_ctx_destroy(ovp_ctx *ctx);
 int ovp_sync(ovp_ctx *ctx);
+/* the hipStream_t all work of the context is ordered on (to enqueue a collective between the staged calls) */
+int ovp_ctx_stream(ovp_ctx *ctx, void **stream);
 const char *ovp_version(void);
 const char *ovp_error_string(int code);
 

@@ -95,6 +95,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
+    "ovp_ctx_stream",
 ]
 
 
@@ -365,6 +366,12 @@ class Context:
 
     def sync(self):
         _chk(lib().ovp_sync(self._h), "ovp_sync")
+
+    def stream_handle(self):
+        """hipStream_t (as int) the context orders its work on; wrap it with torch.cuda.ExternalStream for collectives."""
+        s = C.c_void_p()
+        _chk(lib().ovp_ctx_stream(self._h, C.byref(s)), "ovp_ctx_stream")
+        return int(s.value or 0)
 
     def timings_ms(self):
         t = np.zeros(4, dtype=np.float32)

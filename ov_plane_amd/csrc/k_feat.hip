@@ -18,7 +18,7 @@
 namespace ovp {
 
 static constexpr int NR = 64;               // rows handled by one wave (2 * OVP_MAX_MEAS)
-static constexpr int LCOLS = 2112;           // packed column-major lower triangle with even row starts
+static constexpr int LCOLS = OVP_BSCR;          // packed column-major lower triangle with even row starts
 __device__ __forceinline__ int coff(int k) {  // offset of column k; element (i,k) lives at coff(k) + i - (k & ~1)
   const int pr = k >> 1;
   return 130 * pr - 2 * pr * pr + (k & 1) * (64 - 2 * pr);
@@ -45,26 +45,46 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// one wave per block; LDS (38 KB) limits residency to 4 blocks per CU = 1 wave per SIMD, so let the allocator use the
-// whole register file instead of serialising loads through a single temporary
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_feat_gate(const FeatParams p) {
+// phase stamps (s_memtime) for the "cycles" debug read: compiled in only with -DOVP_K1_STAMPS (they cost 20 VGPRs)
+#ifdef OVP_K1_STAMPS
+#define OVP_STAMP_DECL long long tstamp[8]
+#define OVP_STAMP(i) tstamp[i] = __builtin_readcyclecounter()
+#define OVP_STAMP_ONLY(...) __VA_ARGS__
+#else
+#define OVP_STAMP_DECL
+#define OVP_STAMP(i)
+#define OVP_STAMP_ONLY(...)
+#endif
+
+// One wave per block.  LDS budget is exactly 160 KB / 8 = 20480 B per block so that 8 blocks (2 waves per SIMD) are
+// resident per CU and one feature's dependent chains (the Cholesky) overlap another's:
+//   phases A2/B:  rows of [J | C | E] (64 x 34 doubles, wave-uniform broadcast operands)          17408 B
+//   phases C-E :  the factor L (packed lower triangle, 2112 doubles) in the SAME bytes            16896 B
+//   all phases :  solved right-hand sides (64 x 4) + column exchange buffer (2 x 64)               3072 B
+// B itself (written column by column in phase B, consumed block by block in phase C by the lane that wrote it) goes
+// through a per-feature scratch in device memory: 16.9 KB per feature, 2.2 MB per XCD in flight = L2-resident.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_gate(const FeatParams p) {
+  // the feature waves outrank the (latency-bound, one-workgroup) chol(P) that runs beside them on the side stream: on the
+  // SIMDs both share, an equal-priority Cholesky wave stretches the slowest feature block - and the kernel - by 40 %
+  __builtin_amdgcn_s_setprio(3);
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
   const int m = p.n_meas[f];
   const int n = 2 * m;
 
-  __shared__ __attribute__((aligned(16))) double sJ[NR * 6];
-  __shared__ __attribute__((aligned(16))) double sC[NR * 14];
-  __shared__ __attribute__((aligned(16))) double sE[NR * 14];
-  // B = H_x P H_x^T + I, then its Cholesky factor, column-major: column k holds rows (k & ~1) .. 63 (even start keeps
-  // the 16-byte alignment of the broadcast reads), 2112 doubles; + 64 x 4 solved right-hand sides; + 256 scratch
-  __shared__ __attribute__((aligned(16))) double sL[LCOLS];
-  __shared__ __attribute__((aligned(16))) double sY[NR * 4];
-  __shared__ __attribute__((aligned(16))) double sB[256];
+  __shared__ __attribute__((aligned(16))) double smem[2560];
+  double* const sJ = smem;                 // [64][6]
+  double* const sC = smem + NR * 6;        // [64][14]
+  double* const sE = sC + NR * 14;         // [64][14]   (ends at 2176)
+  double* const sL = smem;                 // [LCOLS] factor, valid from phase C on (aliases sJ/sC/sE)
+  double* const sY = smem + 2176;          // [64][4]
+  double* const sB = sY + NR * 4;          // [2][64]
+  static_assert(LCOLS <= 2176, "factor must fit in the [J|C|E] region");
+  double* const Bg = p.Bscr + (size_t)f * LCOLS;  // B = H_x P H_x^T + I, packed like sL
 
   const int a = lane >> 1, r = lane & 1;
-  long long tstamp[8];
-  tstamp[0] = __builtin_readcyclecounter();
+  OVP_STAMP_DECL;
+  OVP_STAMP(0);
   const bool valid = lane < n;
   const bool feat_ok = (m >= 2) && (m <= OVP_MAX_MEAS_DEV);  // UpdaterMSCKF.cpp:94-96
   const int* cidx = p.clone_idx + (size_t)f * p.max_meas;
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   // ------------------------------------------------------------------------------------------
   double jrow[6], crow[14], hf[3], res;
   build_bearing_row(p, f, a, r, valid, ci, jrow, crow, hf, res);
-  tstamp[1] = __builtin_readcyclecounter();
+  OVP_STAMP(1);
   const double* P = p.P;
   const int ldp = p.ldp;
   double chi2 = 0.0;
@@ -90,7 +110,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     double u[14];
     {
       // 14x14 calibration block of P: one coalesced gather per wave instead of 196 serialized scalar loads
-      double* sPcc = sB;  // 196 doubles, sB is not in use yet
+      double* sPcc = sY;  // 196 doubles in the sY|sB region, which is not in use yet
       for (int idx = lane; idx < 196; idx += 64) {
         const int kk = idx / 14, k = idx - 14 * kk;
         const bool on = ((p.calmask >> kk) & 1) && ((p.calmask >> k) & 1);
@@ -122,13 +142,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         }
       }
       __syncthreads();
+      // u = e + c P_cc, one row of P_cc (7 x ds_read_b128 broadcasts) at a time; the scheduling barrier keeps the
+      // compiler from hoisting all 98 reads (392 VGPRs) in front of the FMAs
 #pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        double dsum = 0.0;
+      for (int k = 0; k < 14; ++k) u[k] = e[k];
+      static_for<14>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        const double2_t* prow = reinterpret_cast<const double2_t*>(sPcc + kk * 14);
+        double2_t pv[7];
 #pragma unroll
-        for (int kk = 0; kk < 14; ++kk) dsum = fma(crow[kk], sPcc[kk * 14 + k], dsum);
-        u[k] = e[k] + dsum;
-      }
+        for (int q = 0; q < 7; ++q) pv[q] = prow[q];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) u[k] = fma(crow[kk], pv[k >> 1][k & 1], u[k]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // pin u here: otherwise the FMAs are sunk behind the barrier into phase B and all of P_cc stays live in registers
+#pragma unroll
+      for (int k = 0; k < 14; ++k) asm volatile("" : "+v"(u[k]));
 #pragma unroll
       for (int l = 0; l < 6; ++l) sJ[lane * 6 + l] = jrow[l];
 #pragma unroll
@@ -138,7 +168,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       }
     }
     __syncthreads();
-    tstamp[2] = __builtin_readcyclecounter();
+    OVP_STAMP(2);
 
     // ----------------------------------------------------------------------------------------
     // Phase B: row `lane` of B = H_x P H_x^T + I, lower triangle, packed in LDS
@@ -177,35 +207,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
           t[k] = r ? tb : ta;
           t[k + 3] = r ? ta : tb;
         }
-        // rows 2b, 2b+1 of [J | C | E] (wave-uniform addresses: LDS broadcasts), fetched as 16-byte vectors up front
-        double2_t vj[6], vc[14], ve[14];
-        {
-          const double2_t* pj = reinterpret_cast<const double2_t*>(sJ + 12 * b);
-          const double2_t* pcv = reinterpret_cast<const double2_t*>(sC + 28 * b);
-          const double2_t* pev = reinterpret_cast<const double2_t*>(sE + 28 * b);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) vj[q] = pj[q];
-#pragma unroll
-          for (int q = 0; q < 14; ++q) vc[q] = pcv[q];
-#pragma unroll
-          for (int q = 0; q < 14; ++q) ve[q] = pev[q];
-        }
+        // rows 2b, 2b+1 of [J | C | E] (wave-uniform addresses: LDS broadcasts), fetched as 16-byte vectors, one row at a
+        // time: with two waves per SIMD the other wave covers the LDS latency and the registers stay under 256
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const int col = 2 * b + rr;
+          double2_t vj[3], vc[7], ve[7];
+          {
+            const double2_t* pj = reinterpret_cast<const double2_t*>(sJ + 12 * b + 6 * rr);
+            const double2_t* pcv = reinterpret_cast<const double2_t*>(sC + 28 * b + 14 * rr);
+            const double2_t* pev = reinterpret_cast<const double2_t*>(sE + 28 * b + 14 * rr);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vj[q] = pj[q];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) vc[q] = pcv[q];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) ve[q] = pev[q];
+          }
           double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) s0 = fma(t[k], vj[(rr * 6 + k) >> 1][(rr * 6 + k) & 1], s0);
+          for (int k = 0; k < 6; ++k) s0 = fma(t[k], vj[k >> 1][k & 1], s0);
 #pragma unroll
-          for (int k = 0; k < 14; ++k) s1 = fma(u[k], vc[(rr * 14 + k) >> 1][(rr * 14 + k) & 1], s1);
+          for (int k = 0; k < 14; ++k) s1 = fma(u[k], vc[k >> 1][k & 1], s1);
 #pragma unroll
-          for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[(rr * 14 + k) >> 1][(rr * 14 + k) & 1], s0);
-          if (lane >= 2 * b) sL[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+          for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[k >> 1][k & 1], s0);
+          if (lane >= 2 * b) Bg[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
         }
       }
     }
     __syncthreads();
-    tstamp[3] = __builtin_readcyclecounter();
+    OVP_STAMP(3);
 
     // ----------------------------------------------------------------------------------------
     // Phase C: Cholesky of B with the row in registers, fused forward substitution of [r | H_f]
@@ -216,7 +247,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     double rh0 = res, rh1 = hf[0], rh2 = hf[1], rh3 = hf[2];
     bool spd = true;
     const int nblk = (n + 15) >> 4;
-    long long t_ll = 0, t_ib = 0;
+    OVP_STAMP_ONLY(long long t_ll = 0, t_ib = 0;)
 #pragma nounroll
     for (int jb = 0; jb < nblk; ++jb) {
       const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);  // scalar: lane selects below must not waterfall
@@ -225,10 +256,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         constexpr int t = decltype(tc)::value;
         const int col = j0 + t;
         double v = (col == lane) ? 1.0 : 0.0;                       // identity padding for rows/columns >= n
-        if (valid && col < n && lane >= (col & ~1)) v = sL[coff(col) + lane - (col & ~1)];
+        if (valid && col < n && lane >= (col & ~1)) v = Bg[coff(col) + lane - (col & ~1)];
         ab[t] = v;
       });
-      long long tq0 = __builtin_readcyclecounter();
+      OVP_STAMP_ONLY(long long tq0 = __builtin_readcyclecounter();)
       // update with the finished columns k < j0
 #pragma nounroll
       for (int k = 0; k < j0; ++k) {
@@ -252,8 +283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         rh2 = fma(-lir, y23[0], rh2);
         rh3 = fma(-lir, y23[1], rh3);
       }
-      long long tq1 = __builtin_readcyclecounter();
-      t_ll += tq1 - tq0;
+      OVP_STAMP_ONLY(long long tq1 = __builtin_readcyclecounter(); t_ll += tq1 - tq0;)
       // factor the block: 16 right-looking steps inside the registers.  Column c of L is broadcast to the other rows
       // through a small LDS buffer (one ds_write + a few 16-byte broadcast reads per step instead of 2 v_readlane per
       // element); the next pivot is taken with a look-ahead so its rsq/Newton chain overlaps the LDS round trip.
@@ -301,7 +331,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
           });
         }
       });
-      t_ib += __builtin_readcyclecounter() - tq1;
+      OVP_STAMP_ONLY(t_ib += __builtin_readcyclecounter() - tq1;)
       // publish the block's columns of L and the solved right-hand sides of its rows
       static_for<16>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
@@ -316,11 +346,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       }
       __syncthreads();
     }
-    tstamp[4] = __builtin_readcyclecounter();
-    if (p.dbg_cycles && lane == 0) {
+    OVP_STAMP(4);
+    OVP_STAMP_ONLY(if (p.dbg_cycles && lane == 0) {
       p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f] = t_ll;
       p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f + 1] = t_ib;
-    }
+    })
     yv = valid ? rh0 : 0.0;
     zv[0] = valid ? rh1 : 0.0;
     zv[1] = valid ? rh2 : 0.0;
@@ -364,7 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     accept = spd && (chi2 <= thr);  // NaN (rank-deficient H_f) rejects
   }
   __syncthreads();
-  tstamp[5] = __builtin_readcyclecounter();
+  OVP_STAMP(5);
 
   // ------------------------------------------------------------------------------------------
   // Phase E: projector rows G = Q1^T H_x, g = Q1^T r  (Q1 by CholeskyQR2 on H_f), staged in LDS
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       }
   }
   __syncthreads();
-  tstamp[6] = __builtin_readcyclecounter();
+  OVP_STAMP(6);
   {
     double* gout = p.G + (size_t)3 * f * ldg;
     for (int idx = lane; idx < 3 * ldg; idx += 64) gout[idx] = Gst[idx];
@@ -458,10 +488,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       if (lane < 2 * OVP_REC) ro[lane] = 0.0;
     }
   }
-  tstamp[7] = __builtin_readcyclecounter();
-  if (p.dbg_cycles && lane == 0) {
+  OVP_STAMP(7);
+  OVP_STAMP_ONLY(if (p.dbg_cycles && lane == 0) {
     for (int k = 0; k < 8; ++k) p.dbg_cycles[(size_t)f * 8 + k] = tstamp[k];
-  }
+  })
   if (lane == 0) {
     p.chi2[f] = chi2;
     p.accept[f] = accept ? 1 : 0;

@@ -5,17 +5,18 @@
 // whole lower triangle lives in the register file of ONE workgroup (8 waves x <=22 tiles of 16x16 f64 in MFMA
 // accumulator layout = up to 360 KB of the CU's 512 KB), panels are exchanged through LDS, and every step that
 // is not the 16x16 diagonal factorization is an MFMA:
-//   step k:  (a) owner publishes tile (k,k)             -> LDS
+//   step k:  (a) owner publishes tile (k,k)             -> LDS  (already during the trailing phase of step k-1)
 //            (b) wave 0: lane-per-row Cholesky of the 16x16 block in registers (v_readlane broadcasts, no
 //                barriers) and its inverse  X = L_kk^-1 ; publishes L_kk and W = X^T
 //            (c) panel tiles (i,k) <- tile * W           (4 MFMA each), published to LDS
 //            (d) trailing tiles (i,j) -= L_ik L_jk^T      (4 MFMA each)
-// Three workgroup barriers per 16 columns instead of ~3 per column.
+// Two workgroup barriers per 16 columns instead of ~3 per column.
 // f64 MFMA operand layout (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // C/D reg v: row = (lane>>4) + 4 v, col = lane&15.
 #include "ovp_dev.h"
 #include "ovp_kernels.h"
 #include <utility>
+#include <cstdlib>
 
 namespace ovp {
 
@@ -29,6 +30,9 @@ template <int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
   sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
+
+// opaque use + redefinition of a value: keeps the optimizer from sinking / hoisting the computation across this point
+__device__ __forceinline__ void pin_vgpr(double& v) { asm volatile("" : "+v"(v)); }
 
 __device__ __forceinline__ double rsqrt_nr2(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -55,18 +59,21 @@ __device__ __forceinline__ double4_t mfma_xyT(const double* X, const double* Y, 
   return acc;
 }
 
-// 16x16 diagonal block: Cholesky and inverse in ONE sweep, lane r <-> row r of both L and X = L^-1 (the four 16-lane
-// DPP rows of the wave run identical copies).  The inverse is obtained by carrying the identity as right-hand side
-// through the elimination (row c of X is final after step c and only has c+1 non-zeros), so it adds independent FMAs to
-// every step instead of the 120-long dependent chain of a separate forward substitution.  Broadcasts are v_readlane
-// (measured faster here than DPP row_share: 3.9 vs 4.8 us per block).
-__device__ __forceinline__ void diag_factor(double* Dbuf, double* Wbuf, double* dinv_out, int lane, int* flag) {
+// 16x16 diagonal block, one wave.
+//  (1) Cholesky with lane r <-> row r (the four 16-lane DPP rows run identical copies): right-looking, the column just
+//      finished is broadcast with v_readlane (measured faster here than DPP row_share or an LDS round trip), the next
+//      pivot is taken first so that its rsq/Newton chain overlaps the rest of the step.
+//  (2) X = L^-1 with lane c <-> COLUMN c of X: sixteen independent forward substitutions, the entries of L are
+//      wave-uniform operands (16-byte LDS broadcasts from a column-major copy written in (1)), so the inverse costs
+//      136 lane-local FMAs and no cross-lane traffic (carrying the identity through (1) took 2 v_readlane per FMA).
+// Outputs: Dbuf = L_kk (zero above the diagonal), Wbuf = X^T (the MFMA B-operand of the panel solve), dinv_out = X.
+__device__ __forceinline__ void diag_factor(double* Dbuf, double* Wbuf, double* Sbuf, double* dinv_out, int lane,
+                                            int* flag) {
   const int row = lane & 15;
-  double d[16], x[16];
+  double d[16];
   sfor<16>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     d[c] = Dbuf[row * TS + c];
-    x[c] = (c == row) ? 1.0 : 0.0;
   });
   bool bad = false;
   double piv = readlane_f64(d[0], 0);
@@ -77,39 +84,84 @@ __device__ __forceinline__ void diag_factor(double* Dbuf, double* Wbuf, double* 
     const double inv_c = inv;
     const double l = d[c] * inv_c;  // column c of L for rows >= c
     d[c] = l;
-    // look-ahead: next pivot first, so that its rsq/Newton chain overlaps the rest of this step
+    // column-major copy for (2) with 1 / L_cc on the diagonal; rows < c are never read
+    if (lane < 16) Sbuf[c * 16 + row] = (row == c) ? inv_c : l;
     if constexpr (c + 1 < 16) {
       const double l1 = readlane_f64(l, c + 1);
       d[c + 1] = fma(-l, l1, d[c + 1]);
       piv = readlane_f64(d[c + 1], c + 1);
       inv = rsqrt_nr2(piv);
     }
-    sfor<(c + 2 < 16) ? (14 - c) : 0>([&](auto jc) {
-      constexpr int j = c + 2 + decltype(jc)::value;
-      const double ljc = readlane_f64(l, j);
-      d[j] = fma(-l, ljc, d[j]);
-    });
-    // row c of X: scale by 1/l_cc ; rows below: x_i -= l_ic * x_c   (x_c has non-zeros in columns 0..c only)
-    sfor<c + 1>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const double xc = readlane_f64(x[k], c) * inv_c;
-      if (row == c) x[k] = xc;
-      else if (row > c) x[k] = fma(-l, xc, x[k]);
-    });
+    if constexpr (c + 2 < 16) {
+      // L[j][c], j = c+2..15, come back from the column-major copy as 16-byte LDS broadcasts (operands in VGPRs: the
+      // v_readlane form needs 2 SGPRs per element and spills the scalar file)
+      constexpr int e0 = (c + 2) & ~1;
+      typedef double dbl2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const dbl2* col = reinterpret_cast<const dbl2*>(Sbuf + c * 16 + e0);
+      dbl2 lv[(16 - e0) / 2];
+#pragma unroll
+      for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = col[q];
+      sfor<14 - c>([&](auto jc) {
+        constexpr int j = c + 2 + decltype(jc)::value;
+        d[j] = fma(-l, lv[(j - e0) >> 1][(j - e0) & 1], d[j]);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one column at a time
   });
   if (bad && lane == 0) *flag = 1;
   if (lane < 16) {
     sfor<16>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      Dbuf[row * TS + c] = (c <= row) ? d[c] : 0.0;  // L_kk, zero above the diagonal
-      Wbuf[c * TS + row] = x[c];                      // W = X^T : W[c][r] = X[r][c]
-      if (dinv_out) dinv_out[row * 16 + c] = x[c];    // X row-major
+      Dbuf[row * TS + c] = (c <= row) ? d[c] : 0.0;
+    });
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // Sbuf written by lanes 0..15 of this wave, read by all below
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // (2) column `row` of X:  x_m = e_m / L_mm after eliminating rows 0..m-1;  x_i -= L_im x_m  for i > m
+  double x[16];
+  int rowv = row;
+  asm volatile("" : "+v"(rowv));  // opaque: keeps the 16 identity selects out of the (loop-invariant) spill area
+  sfor<16>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    x[i] = (i == rowv) ? 1.0 : 0.0;
+  });
+  sfor<16>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int e0 = m & ~1;  // aligned pairs starting at the even index <= m (the diagonal slot holds 1 / L_mm)
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const dbl2* col = reinterpret_cast<const dbl2*>(Sbuf + m * 16 + e0);
+    dbl2 lv[(16 - e0) / 2];
+#pragma unroll
+    for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = col[q];
+    const double xm = x[m] * lv[(m - e0) >> 1][(m - e0) & 1];
+    x[m] = xm;
+    sfor<15 - m>([&](auto ic) {
+      constexpr int i = m + 1 + decltype(ic)::value;
+      x[i] = fma(-lv[(i - e0) >> 1][(i - e0) & 1], xm, x[i]);
+    });
+    // one column of broadcast reads at a time: the optimizer otherwise hoists all 64 of them, or sinks the FMAs into the
+    // `lane < 16` block below, and spills either way
+    sfor<16 - m>([&](auto ic) {
+      constexpr int i = m + decltype(ic)::value;
+      pin_vgpr(x[i]);
+    });
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  if (lane < 16) {
+    sfor<16>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      Wbuf[row * TS + r] = x[r];                       // W = X^T : W[c][r] = X[r][c], lane = c
+      if (dinv_out) dinv_out[r * 16 + row] = x[r];     // X row-major
     });
   }
 }
 
 // Wave 0 is the factor wave (owns no tiles, so the 16x16 factorization does not compete with the tile registers);
-// waves 1..TC_TILE_WAVES hold the tiles.  Both roles execute exactly three workgroup barriers per step.
+// waves 1..TC_TILE_WAVES hold the tiles.  Both roles execute exactly two workgroup barriers per step.
 template <int MAXSLOT>
 __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __restrict__ A, double* __restrict__ L,
                                                            double* __restrict__ Dinv, int n, int ld,
@@ -121,16 +173,26 @@ __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __rest
   double* Wbuf = Dbuf + TSZ;
   double* PB = Wbuf + TSZ;
   double* SW = PB + nt * TSZ;
+  double* Sbuf = SW + TC_TILE_WAVES * TSZ;        // 256 doubles: column-major L_kk for the inverse (factor wave only)
+  int* rdy = reinterpret_cast<int*>(Sbuf + 256);  // diagonal tile k is in Dbuf once *rdy >= k + 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
+  if (dbg_skip & 32) return;  // diagnostics: launch overhead only
+  if (tid == 0) *rdy = 0;
+  __syncthreads();
 
+  // Look-ahead: the diagonal tile of step k+1 is brought up to date FIRST in the trailing phase of step k and handed to
+  // the factor wave through an LDS flag, so its 16x16 factorization (the longest serial piece of a step) runs while the
+  // tile waves finish the rest of the trailing update.  Two workgroup barriers per step:
+  //   B2(k): L_kk / W published (factor wave -> tile waves)      B3(k): panel published (tile waves -> tile waves)
   if (wave == 0) {
     for (int k = 0; k < nt; ++k) {
-      __syncthreads();  // B1: diagonal tile published
-      if (!(dbg_skip & 1)) diag_factor(Dbuf, Wbuf, Dinv ? Dinv + (size_t)k * 256 : nullptr, lane, flag);
-      __syncthreads();  // B2: L_kk and W published
-      __syncthreads();  // B3: panel published
+      while (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (!(dbg_skip & 1)) diag_factor(Dbuf, Wbuf, Sbuf, Dinv ? Dinv + (size_t)k * 256 : nullptr, lane, flag);
+      __syncthreads();  // B2
+      __syncthreads();  // B3
     }
   } else {
     const int tw = wave - 1;
@@ -138,51 +200,62 @@ __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __rest
     double4_t tile[MAXSLOT];
     int ti[MAXSLOT], tj[MAXSLOT];
     // ---- load: tile index idx = slot*TILE_WAVES + tw, column-major over the lower tile triangle ----
+    // (i, j) of consecutive slots are found incrementally on the scalar unit (they depend on the wave index only; as
+    // SGPRs they also make the per-step "is this a panel / trailing / diagonal tile" tests scalar branches).  Loads
+    // are branch-free - out-of-range elements read a clamped address and are replaced by the identity padding - so all
+    // of a wave's tiles are in flight together.
+    const int nfull = n >> 4;  // tiles with index < nfull need no range checks
+    int jj = 0, cstart = 0;    // current tile column and the index of its first tile
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       const int idx = s * TC_TILE_WAVES + tw;
       int i = -1, j = -1;
       if (idx < ntiles) {
-        int jj = 0, start = 0;
-        while (start + (nt - jj) <= idx) {
-          start += nt - jj;
+        while (cstart + (nt - jj) <= idx) {
+          cstart += nt - jj;
           ++jj;
         }
         j = jj;
-        i = jj + (idx - start);
+        i = jj + (idx - cstart);
       }
+      i = __builtin_amdgcn_readfirstlane(i);
+      j = __builtin_amdgcn_readfirstlane(j);
       ti[s] = i;
       tj[s] = j;
       double4_t t = {0.0, 0.0, 0.0, 0.0};
-      if (i >= 0) {
+      if (i >= 0 && (dbg_skip & 8)) {
+        if (i == j) t[0] = (lc == lr) ? 4.0 : 0.0, t[1] = (lc == lr + 4) ? 4.0 : 0.0, t[2] = (lc == lr + 8) ? 4.0 : 0.0,
+                    t[3] = (lc == lr + 12) ? 4.0 : 0.0;
+      } else if (i >= 0) {
         const int c = 16 * j + lc;
+        const int cc = c < n ? c : n - 1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int r = 16 * i + lr + 4 * v;
-          double x = 0.0;
-          if (r < n && c < n) {
-            x = A[(size_t)r * ld + c];
-            if (add_identity && r == c) x += 1.0;
-          } else if (r == c) {
-            x = 1.0;  // identity padding keeps the padded matrix SPD
-          }
+          const int rc = r < n ? r : n - 1;
+          double x = A[(size_t)rc * ld + cc];
+          if (i >= nfull) x = (r < n && c < n) ? x : 0.0;  // i >= j: a partial tile is always in the last tile row
+          if (r == c) x = (r < n) ? (add_identity ? x + 1.0 : x) : 1.0;  // identity padding keeps the matrix SPD
           t[v] = x;
         }
       }
       tile[s] = t;
     });
 
-    for (int k = 0; k < nt; ++k) {
-      // (a) publish the diagonal tile
-      sfor<MAXSLOT>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (ti[s] == k && tj[s] == k) {
+    // hands the (up to date) diagonal tile kk to the factor wave
+    auto publish_diag = [&](const double4_t& t, int kk) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) Dbuf[(lr + 4 * v) * TS + lc] = tile[s][v];
-        }
-      });
-      __syncthreads();  // B1
-      __syncthreads();  // B2 (factor wave worked in between)
+      for (int v = 0; v < 4; ++v) Dbuf[(lr + 4 * v) * TS + lc] = t[v];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(rdy, kk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (ti[s] == 0 && tj[s] == 0) publish_diag(tile[s], 0);
+    });
+
+    for (int k = 0; k < nt; ++k) {
+      __syncthreads();  // B2: L_kk in Dbuf, W = L_kk^-T in Wbuf
       // (c) diagonal owner reloads L_kk; panel tiles <- tile * W, published to PB
       sfor<MAXSLOT>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -211,30 +284,47 @@ __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __rest
           }
         }
       });
-      __syncthreads();  // B3
-      // (d) trailing update
+      __syncthreads();  // B3: panel k in PB (Dbuf / Wbuf of step k are dead from here on)
+      // (d) trailing update, next diagonal tile first
       sfor<MAXSLOT>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if (tj[s] > k && !(dbg_skip & 4)) tile[s] = mfma_xyT(PB + ti[s] * TSZ, PB + tj[s] * TSZ, tile[s], -1.0, lc, lr);
+        if (ti[s] == k + 1 && tj[s] == k + 1) {
+          if (!(dbg_skip & 4)) tile[s] = mfma_xyT(PB + ti[s] * TSZ, PB + tj[s] * TSZ, tile[s], -1.0, lc, lr);
+          publish_diag(tile[s], k + 1);
+        }
       });
-      // no barrier here: (a) of the next step only writes Dbuf, which nobody reads in (d); PB is rewritten after B2
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (tj[s] > k && !(ti[s] == k + 1 && tj[s] == k + 1) && !(dbg_skip & 4))
+          tile[s] = mfma_xyT(PB + ti[s] * TSZ, PB + tj[s] * TSZ, tile[s], -1.0, lc, lr);
+      });
+      // PB is rewritten only after B2 of the next step, which every wave reaches after its trailing update
     }
-    // ---- store L (lower) ----
+    // ---- store L (lower); the mirrored tile of the strict upper triangle is zero ----
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      if (ti[s] >= 0) {
+      if (ti[s] >= 0 && !(dbg_skip & 16)) {
         const int c = 16 * tj[s] + lc;
+        const int c2 = 16 * ti[s] + lc;
+        if (ti[s] < nfull) {  // interior tile (j <= i < nfull): no range checks
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int r = 16 * ti[s] + lr + 4 * v;
-          if (r < n && c < n) L[(size_t)r * ld + c] = tile[s][v];
-        }
-        if (ti[s] != tj[s]) {  // mirrored tile of the strict upper triangle is zero
-          const int c2 = 16 * ti[s] + lc;
+          for (int v = 0; v < 4; ++v) L[(size_t)(16 * ti[s] + lr + 4 * v) * ld + c] = tile[s][v];
+          if (ti[s] != tj[s]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) L[(size_t)(16 * tj[s] + lr + 4 * v) * ld + c2] = 0.0;
+          }
+        } else {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int r2 = 16 * tj[s] + lr + 4 * v;
-            if (r2 < n && c2 < n) L[(size_t)r2 * ld + c2] = 0.0;
+            const int r = 16 * ti[s] + lr + 4 * v;
+            if (r < n && c < n) L[(size_t)r * ld + c] = tile[s][v];
+          }
+          if (ti[s] != tj[s]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int r2 = 16 * tj[s] + lr + 4 * v;
+              if (r2 < n && c2 < n) L[(size_t)r2 * ld + c2] = 0.0;
+            }
           }
         }
       }
@@ -381,8 +471,9 @@ hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, 
   const int nt = (n + 15) / 16;
   const int ntiles = nt * (nt + 1) / 2;
   const int slots = (ntiles + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
-  const size_t shmem = (size_t)(2 + nt + ovp::TC_WAVES) * ovp::TSZ * sizeof(double);
-  if (slots <= 15) {
+  const size_t shmem = ((size_t)(2 + nt + ovp::TC_WAVES) * ovp::TSZ + 256) * sizeof(double) + 16;
+  static const bool force25 = getenv("OVP_TC_FORCE25") != nullptr;  // diagnostics: cost of the per-slot tests
+  if (slots <= 15 && !force25) {
     hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, n, ld, flag,
                        add_identity, ovp_dbg_tilechol_skip);
   } else if (slots <= 25) {

@@ -148,7 +148,7 @@ struct ovp_ctx {
   double* p_FinG = nullptr;
   int n_feats = 0, max_meas = 0;
   // work buffers
-  double *G = nullptr, *rec = nullptr, *chi2 = nullptr;
+  double *G = nullptr, *rec = nullptr, *chi2 = nullptr, *Bscr = nullptr;
   unsigned char* accept = nullptr;
   int ldg = 0;
   double *gramS = nullptr, *gramR = nullptr, *part = nullptr, *Dinv = nullptr;
@@ -175,6 +175,8 @@ struct ovp_ctx {
   double *h_dx = nullptr, *h_chi2 = nullptr;
   unsigned char* h_accept = nullptr;
   int* h_flags = nullptr;
+  void *res_block = nullptr, *h_res_block = nullptr;  // [flags | dx | chi2 | accept], device and pinned host
+  size_t res_bytes = 0;
   float last_ms[4] = {0, 0, 0, 0};
   bool timed = false;
   // dominant-kernel timer
@@ -216,6 +218,9 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OVP_E_NODEVICE;  // gfx950-only build, no fallback
   ovp_ctx* c = new ovp_ctx();
   c->device = device;
+  // Two streams: the main one carries K1/K2/K3, the side stream the measurement-independent chol(P).  (Pinning the side
+  // stream to one CU with hipExtStreamCreateWithCUMask was tried: the driver keeps CU masks symmetric across shader
+  // engines, so removing one CU from the main stream removes 32 and K1 drops below one block per feature.)
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -243,8 +248,15 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->T, nn));
   HIPCHK(dalloc(&c->Lt, nn));
   HIPCHK(dalloc(&c->Y, nn));
-  HIPCHK(dalloc(&c->dx, (size_t)c->n_max));
-  HIPCHK(dalloc(&c->flags, 4));
+  // results of an update live in ONE block [flags 4 x i32 | dx n_max | chi2 f_max | accept f_max] so that
+  // ovp_msckf_fetch_results is a single device-to-host copy (four small copies cost ~5 us each)
+  c->res_bytes = 16 + sizeof(double) * ((size_t)c->n_max + n_feats_max) + (size_t)n_feats_max;
+  HIPCHK(hipMalloc((void**)&c->res_block, c->res_bytes));
+  HIPCHK(hipMemset(c->res_block, 0, c->res_bytes));
+  c->flags = (int*)c->res_block;
+  c->dx = (double*)((char*)c->res_block + 16);
+  c->chi2 = c->dx + c->n_max;
+  c->accept = (unsigned char*)(c->chi2 + n_feats_max);
   HIPCHK(dalloc(&c->clone_R, (size_t)9 * n_clones_max));
   HIPCHK(dalloc(&c->clone_p, (size_t)3 * n_clones_max));
   HIPCHK(dalloc(&c->clone_R_fej, (size_t)9 * n_clones_max));
@@ -258,9 +270,8 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->n_meas, (size_t)n_feats_max));
   HIPCHK(dalloc(&c->p_FinG, (size_t)n_feats_max * 3));
   HIPCHK(dalloc(&c->G, (size_t)3 * n_feats_max * c->ldg));
+  HIPCHK(dalloc(&c->Bscr, (size_t)n_feats_max * OVP_BSCR));
   HIPCHK(dalloc(&c->rec, (size_t)n_clones_max * n_feats_max * 2 * 21));
-  HIPCHK(dalloc(&c->chi2, (size_t)n_feats_max));
-  HIPCHK(dalloc(&c->accept, (size_t)n_feats_max));
   // reduction geometry: fixed per context so the summation order (hence the result bits) is reproducible
   c->rows_per_chunk = 512;
   c->n_chunks = (2 * n_feats_max + c->rows_per_chunk - 1) / c->rows_per_chunk;
@@ -277,10 +288,11 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->idbuf, (size_t)4 * c->n_max + 64));
   c->small_cap = (size_t)4 * c->n_max * 64 + (size_t)c->n_max * c->n_max;
   HIPCHK(dalloc(&c->smallbuf, c->small_cap));
-  HIPCHK(hipHostMalloc((void**)&c->h_dx, sizeof(double) * c->n_max));
-  HIPCHK(hipHostMalloc((void**)&c->h_chi2, sizeof(double) * n_feats_max));
-  HIPCHK(hipHostMalloc((void**)&c->h_accept, (size_t)n_feats_max));
-  HIPCHK(hipHostMalloc((void**)&c->h_flags, sizeof(int) * 4));
+  HIPCHK(hipHostMalloc((void**)&c->h_res_block, c->res_bytes));  // pinned mirror of res_block
+  c->h_flags = (int*)c->h_res_block;
+  c->h_dx = (double*)((char*)c->h_res_block + 16);
+  c->h_chi2 = c->h_dx + c->n_max;
+  c->h_accept = (unsigned char*)(c->h_chi2 + n_feats_max);
   // chi2 table
   {
     std::vector<double> tab(OVP_CHI2_TABLE + 1, 0.0);
@@ -297,16 +309,13 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->stream2);
-  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->dx, c->flags, c->clone_R, c->clone_p,
+  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
-                 c->p_FinG, c->G, c->rec, c->chi2, c->accept, c->gramS, c->gramR, c->Dinv, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
+                 c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd};
   for (void* p : dev)
     if (p) hipFree(p);
-  if (c->h_dx) hipHostFree(c->h_dx);
-  if (c->h_chi2) hipHostFree(c->h_chi2);
-  if (c->h_accept) hipHostFree(c->h_accept);
-  if (c->h_flags) hipHostFree(c->h_flags);
+  if (c->h_res_block) hipHostFree(c->h_res_block);
   hipEventDestroy(c->ev_fork);
   hipEventDestroy(c->ev_join);
   for (int i = 0; i < 6; ++i) hipEventDestroy(c->ev_t[i]);
@@ -321,6 +330,12 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
 extern "C" int ovp_sync(ovp_ctx* c) {
   if (!c) return OVP_E_ARG;
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int ovp_ctx_stream(ovp_ctx* c, void** stream) {
+  if (!c || !stream) return OVP_E_ARG;
+  *stream = (void*)c->stream;
   return 0;
 }
 
@@ -557,6 +572,7 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   fp.n = n;
   fp.ldp = c->ld;
   fp.G = c->G;
+  fp.Bscr = c->Bscr;
   fp.ldg = c->ldg;
   fp.rec = c->rec;
   fp.chi2 = c->chi2;
@@ -567,20 +583,35 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
 
 static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   ovp::FeatParams& fp = c->fp;
-  // chol(P) does not depend on the measurements: run it beside K1/K2 on the second stream
-  HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-  HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  {
+  // chol(P) does not depend on the measurements, so it runs on the side stream - but beside K2, not beside K1: K1 keeps
+  // every SIMD of the chip busy with two feature waves, and the CU that also hosts the eight Cholesky waves finishes its
+  // feature blocks ~40 % later, which is the kernel's duration (measured: K1 112 -> 157 us).
+  // OVP_OVERLAP_MODE: 0 = no overlap, 1 = beside K1 (old behaviour), 2 (default) = beside K2.
+  static const int overlap_mode = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 2;
+  if (overlap_mode == 1) {
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     int rc = chol_of_P(c, c->stream2);
     if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
   }
-  HIPCHK(hipEventRecord(c->ev_join, c->stream2));
   // K1
   if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
   HIPCHK(ovp_launch_feat_gate(&fp, c->stream));
   if (c->ktimer) {
     HIPCHK(hipEventRecord(c->ev_k1, c->stream));
     c->kpending = true;
+  }
+  if (overlap_mode == 2) {
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    int rc = chol_of_P(c, c->stream2);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+  } else if (overlap_mode == 0) {
+    int rc = chol_of_P(c, c->stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_join, c->stream));
   }
   HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
   // K2
@@ -622,12 +653,11 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
                                        ovp_update_info* info) {
   if (!c) return OVP_E_ARG;
   const int n = c->n, F = c->n_feats;
-  HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  if (F) {
-    HIPCHK(hipMemcpyAsync(c->h_accept, c->accept, (size_t)F, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_chi2, c->chi2, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream));
+  {
+    // one copy up to the end of the accept flags in use
+    const size_t used = (size_t)((char*)c->accept - (char*)c->res_block) + (size_t)F;
+    HIPCHK(hipMemcpyAsync(c->h_res_block, c->res_block, used, hipMemcpyDeviceToHost, c->stream));
   }
-  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
   if (accepted_host && F) memcpy(accepted_host, c->h_accept, (size_t)F);

@@ -7,6 +7,7 @@
 #define OVP_CHI2_TABLE 1024  // chi2_table[k] for k = 0..OVP_CHI2_TABLE (k=0 unused)
 #define OVP_MAX_CLONES 64
 #define OVP_GRAM_ELEMS 231   // 21*22/2: packed upper triangle of the per-clone 21x21 Gram
+#define OVP_BSCR 2112        // doubles of per-feature scratch for B (k_feat.hip LCOLS)
 #define OVP_LDG_CAP 704      // max leading dimension of the projector-row buffer G (LDS staging in the feature kernels)
 
 namespace ovp {
@@ -36,6 +37,7 @@ struct FeatParams {
   // outputs
   double* G;  // [3*n_feats][ldg]: columns 0..n-1 = Q1^T H_x scattered to state columns, column n = Q1^T r
   int ldg;
+  double* Bscr;  // [n_feats][OVP_BSCR] scratch: per-feature B = H_x P H_x^T + I (packed lower triangle)
   double* rec;  // [n_clones][n_feats][2][OVP_REC]
   double* chi2;
   unsigned char* accept;
