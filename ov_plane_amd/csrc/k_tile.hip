@@ -164,8 +164,9 @@ __device__ __forceinline__ void diag_factor(double* Dbuf, double* Wbuf, double* 
 // waves 1..TC_TILE_WAVES hold the tiles.  Both roles execute exactly two workgroup barriers per step.
 template <int MAXSLOT>
 __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __restrict__ A, double* __restrict__ L,
-                                                           double* __restrict__ Dinv, int n, int ld,
-                                                           int* __restrict__ flag, int add_identity, int dbg_skip) {
+                                                           double* __restrict__ Dinv, double* __restrict__ Lpack, int n,
+                                                           int ld, int* __restrict__ flag, int add_identity,
+                                                           int dbg_skip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int nt = (n + 15) >> 4;
   const int ntiles = nt * (nt + 1) / 2;
@@ -306,6 +307,11 @@ __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __rest
       if (ti[s] >= 0 && !(dbg_skip & 16)) {
         const int c = 16 * tj[s] + lc;
         const int c2 = 16 * ti[s] + lc;
+        if (Lpack) {  // tile-packed copy, column-major inside the tile = coalesced MFMA A-operand reads in k_fwdsub
+          double* pk = Lpack + (size_t)(s * TC_TILE_WAVES + tw) * 256;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) pk[lc * 16 + lr + 4 * v] = tile[s][v];
+        }
         if (ti[s] < nfull) {  // interior tile (j <= i < nfull): no range checks
 #pragma unroll
           for (int v = 0; v < 4; ++v) L[(size_t)(16 * ti[s] + lr + 4 * v) * ld + c] = tile[s][v];
@@ -333,68 +339,100 @@ __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// V = Lt^-1 * L^T  by blocked forward substitution; one workgroup (4 waves) per 16-column slab of V.
-//   V_i = Dinv_i ( (L^T)_i - sum_{k<i} Lt_ik V_k ),   Dinv_i = (Lt_ii)^-1 from k_tilechol.
+// V = Lt^-1 * M  (M = L^T in the plain update) by blocked forward substitution, right-looking; one workgroup (4 waves)
+// per 16-column slab of V.  Wave w owns the tile rows i = w, w+4, ... of the slab and keeps their accumulators
+//   acc_i = M_i - sum_{k<i, k done} Lt_ik V_k
+// in MFMA C layout, which is also the B-operand layout, so the diagonal solve  V_k = Dinv_k acc_k  (Dinv_k = Lt_kk^-1 from
+// k_tilechol) needs no data movement at all.  Per step: the owner of row k multiplies, publishes V_k to LDS (double
+// buffered), ONE barrier, every wave updates its rows i > k - row k+1 first, whose owner then carries on with the next
+// diagonal solve while the others finish.  Lt comes tile-packed (Ltp, column-major tiles = coalesced A operands) and is
+// prefetched one step ahead; nothing on the dependent chain touches global memory.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Lt, const double* __restrict__ Dinv,
+static constexpr int FW_ROWS = 5;  // tile rows per wave: nt <= 20
+
+__global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, const double* __restrict__ Dinv,
                                                  const double* __restrict__ Lmat, double* __restrict__ V, int n,
                                                  int ld, int dense) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ __attribute__((aligned(16))) double vt[2][TSZ];
   const int nt = (n + 15) >> 4;
   const int cblk = blockIdx.x;  // column tile of V
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
-  double* Vt = lds;                 // nt tiles: V_k row-major [kk][col]
-  double* red = Vt + nt * TSZ;      // 4 x 256 partial accumulators
-  double* tmp = red + 4 * 256;      // one tile
-  for (int i = 0; i < nt; ++i) {
-    // partial sums over k = wave, wave+4, ...
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k = wave; k < i; k += 4) {
-      const double* vk = Vt + k * TSZ;
+  auto tile_index = [&](int i, int k) { return k * nt - (k * (k - 1)) / 2 + (i - k); };
+
+  // accumulators = right-hand side tiles: element [row][col] of tile i is M[16 i + row][16 cblk + col];
+  // for M = L^T (dense == 0) that is L[16 cblk + col][16 i + row], zero for i > cblk
+  double4_t acc[FW_ROWS], a_cur[FW_ROWS], a_nxt[FW_ROWS];
+  sfor<FW_ROWS>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    const int i = wave + 4 * r;
+    double4_t t = {0.0, 0.0, 0.0, 0.0};
+    if (i < nt && (dense || i <= cblk)) {
+      const int gr = 16 * cblk + lc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 16 * i + lc, c = 16 * k + lr + 4 * q;
-        const double a = (r < n && c < n) ? Lt[(size_t)r * ld + c] : 0.0;
-        const double b = vk[(lr + 4 * q) * TS + lc];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc, 0, 0, 0);
+      for (int v = 0; v < 4; ++v) {
+        const int gc = 16 * i + lr + 4 * v;
+        if (gr < n && gc < n) t[v] = Lmat[(size_t)gr * ld + gc];
       }
     }
+    acc[r] = t;
+    a_cur[r] = double4_t{0.0, 0.0, 0.0, 0.0};
+    a_nxt[r] = double4_t{0.0, 0.0, 0.0, 0.0};
+  });
+  // A operands of step 0: tiles (i, 0), i > 0
+  auto prefetch = [&](double4_t (&dst)[FW_ROWS], int k) {
+    sfor<FW_ROWS>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const int i = wave + 4 * r;
+      if (i < nt && i > k && k < nt) {
+        const double* tp = Ltp + (size_t)tile_index(i, k) * 256;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) red[wave * 256 + (lr + 4 * v) * 16 + lc] = acc[v];
-    __syncthreads();
-    if (wave == 0) {
-      // rhs tile (i, cblk) of L^T: element [row][col] = L[16 cblk + col][16 i + row], zero if cblk < i
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = lr + 4 * v;
-        const int e = row * 16 + lc;
-        double sum = ((red[e] + red[256 + e]) + red[512 + e]) + red[768 + e];
-        const int gr = 16 * cblk + lc, gc = 16 * i + row;
-        if ((dense || cblk >= i) && gr < n && gc < n) sum += Lmat[(size_t)gr * ld + gc];
-        tmp[row * TS + lc] = sum;
+        for (int q = 0; q < 4; ++q) dst[r][q] = tp[q * 64 + lane];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    });
+  };
+  prefetch(a_cur, 0);
+
+  for (int k = 0; k < nt; ++k) {
+    double* vk = vt[k & 1];
+    // diagonal solve by the owner of row k
+    if ((k & 3) == wave) {
+      const double* di = Dinv + (size_t)k * 256;
+      double dq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dq[q] = di[lc * 16 + lr + 4 * q];
       double4_t vi = {0.0, 0.0, 0.0, 0.0};
-      const double* di = Dinv + (size_t)i * 256;
+      sfor<FW_ROWS>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if (wave + 4 * r == k) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double a = di[lc * 16 + lr + 4 * q];
-        const double b = tmp[(lr + 4 * q) * TS + lc];
-        vi = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, vi, 0, 0, 0);
-      }
-      double* vt = Vt + i * TSZ;
+          for (int q = 0; q < 4; ++q) vi = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[q], acc[r][q], vi, 0, 0, 0);
+        }
+      });
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = lr + 4 * v;
-        vt[row * TS + lc] = vi[v];
-        const int gr = 16 * i + row, gc = 16 * cblk + lc;
+        vk[row * TS + lc] = vi[v];
+        const int gr = 16 * k + row, gc = 16 * cblk + lc;
         if (gr < n && gc < n) V[(size_t)gr * ld + gc] = vi[v];
       }
     }
+    prefetch(a_nxt, k + 1);
     __syncthreads();
+    // trailing update of the rows i > k (increasing i: row k+1 first)
+    double b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = vk[(lr + 4 * q) * TS + lc];
+    sfor<FW_ROWS>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const int i = wave + 4 * r;
+      if (i < nt && i > k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][q], b[q], acc[r], 0, 0, 0);
+      }
+      a_cur[r] = a_nxt[r];
+    });
   }
 }
 
@@ -466,40 +504,35 @@ extern "C" {
 
 // returns hipErrorInvalidValue when n is too large for the register-resident path (caller falls back)
 extern "C" { int ovp_dbg_tilechol_skip = 0; }
-hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
-                               hipStream_t stream) {
+hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag,
+                               int add_identity, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   const int ntiles = nt * (nt + 1) / 2;
   const int slots = (ntiles + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
   const size_t shmem = ((size_t)(2 + nt + ovp::TC_WAVES) * ovp::TSZ + 256) * sizeof(double) + 16;
   static const bool force25 = getenv("OVP_TC_FORCE25") != nullptr;  // diagnostics: cost of the per-slot tests
   if (slots <= 15 && !force25) {
-    hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, n, ld, flag,
-                       add_identity, ovp_dbg_tilechol_skip);
+    hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
+                       flag, add_identity, ovp_dbg_tilechol_skip);
   } else if (slots <= 25) {
     static bool attr = false;
     if (!attr) {
       hipFuncSetAttribute((const void*)ovp::k_tilechol<25>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       attr = true;
     }
-    hipLaunchKernelGGL((ovp::k_tilechol<25>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, n, ld, flag,
-                       add_identity, ovp_dbg_tilechol_skip);
+    hipLaunchKernelGGL((ovp::k_tilechol<25>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
+                       flag, add_identity, ovp_dbg_tilechol_skip);
   } else {
     return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
+hipError_t ovp_launch_fwdsub(const double* Ltp, const double* Dinv, const double* Lmat, double* V, int n, int ld,
                              int dense, hipStream_t stream) {
   const int nt = (n + 15) / 16;
-  const size_t shmem = ((size_t)nt * ovp::TSZ + 4 * 256 + ovp::TSZ) * sizeof(double);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)ovp::k_fwdsub, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr = true;
-  }
-  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), shmem, stream, Lt, Dinv, Lmat, V, n, ld, dense);
+  if (nt > 4 * ovp::FW_ROWS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), 0, stream, Ltp, Dinv, Lmat, V, n, ld, dense);
   return hipGetLastError();
 }
 

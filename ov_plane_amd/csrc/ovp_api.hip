@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "ovp_kernels.h"
@@ -26,7 +27,7 @@ hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, c
 hipError_t ovp_launch_augment_dt(double* P, int ldp, int n, int pose, int dt, const double* d, hipStream_t stream);
 hipError_t ovp_launch_init_invertible(double* P, int ldp, int n, const int* cols, int ncols, const double* HR, int k,
                                       double* Ma, const double* Hinv, const double* Rk, hipStream_t stream);
-hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, int n, int ld, int* flag, int add_identity,
+hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag, int add_identity,
                                hipStream_t stream);
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
                              int dense, hipStream_t stream);
@@ -151,7 +152,7 @@ struct ovp_ctx {
   double *G = nullptr, *rec = nullptr, *chi2 = nullptr, *Bscr = nullptr;
   unsigned char* accept = nullptr;
   int ldg = 0;
-  double *gramS = nullptr, *gramR = nullptr, *part = nullptr, *Dinv = nullptr;
+  double *gramS = nullptr, *gramR = nullptr, *part = nullptr, *Dinv = nullptr, *Ltp = nullptr;
   int n_chunks = 0, rows_per_chunk = 0, n_split = 0;
   double* Ab = nullptr;  // (n_max+1) x ld
   double *L = nullptr, *W1 = nullptr, *T = nullptr, *Lt = nullptr, *Y = nullptr;
@@ -176,6 +177,11 @@ struct ovp_ctx {
   unsigned char* h_accept = nullptr;
   int* h_flags = nullptr;
   void *res_block = nullptr, *h_res_block = nullptr;  // [flags | dx | chi2 | accept], device and pinned host
+  void* h_res_block_dev = nullptr;                    // device address of the pinned block
+  volatile unsigned* h_seq = nullptr;                 // sequence word behind it (written last by k_publish_results)
+  unsigned seq = 0;
+  std::vector<int> h_nmeas;                           // host copy of n_meas of the current batch (row count of `info`)
+  bool h_nmeas_valid = false;
   size_t res_bytes = 0;
   float last_ms[4] = {0, 0, 0, 0};
   bool timed = false;
@@ -278,6 +284,10 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->gramS, (size_t)n_clones_max * c->n_chunks * OVP_GRAM_ELEMS));
   HIPCHK(dalloc(&c->gramR, (size_t)n_clones_max * OVP_GRAM_ELEMS));
   HIPCHK(dalloc(&c->Dinv, (size_t)(c->ld / 16 + 1) * 256));
+  {
+    const size_t ntm = (size_t)c->ld / 16 + 1;
+    HIPCHK(dalloc(&c->Ltp, ntm * (ntm + 1) / 2 * 256));  // tile-packed factor for k_fwdsub
+  }
   c->n_split = (3 * n_feats_max + 511) / 512;
   if (c->n_split < 1) c->n_split = 1;
   if (c->n_split > 64) c->n_split = 64;
@@ -288,7 +298,10 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->idbuf, (size_t)4 * c->n_max + 64));
   c->small_cap = (size_t)4 * c->n_max * 64 + (size_t)c->n_max * c->n_max;
   HIPCHK(dalloc(&c->smallbuf, c->small_cap));
-  HIPCHK(hipHostMalloc((void**)&c->h_res_block, c->res_bytes));  // pinned mirror of res_block
+  HIPCHK(hipHostMalloc((void**)&c->h_res_block, c->res_bytes + 64, hipHostMallocMapped));  // pinned mirror of res_block
+  memset(c->h_res_block, 0, c->res_bytes + 64);
+  HIPCHK(hipHostGetDevicePointer(&c->h_res_block_dev, c->h_res_block, 0));
+  c->h_seq = (volatile unsigned*)((char*)c->h_res_block + ((c->res_bytes + 15) & ~(size_t)15));
   c->h_flags = (int*)c->h_res_block;
   c->h_dx = (double*)((char*)c->h_res_block + 16);
   c->h_chi2 = c->h_dx + c->n_max;
@@ -311,7 +324,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   hipStreamSynchronize(c->stream2);
   void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
-                 c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
+                 c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd};
   for (void* p : dev)
     if (p) hipFree(p);
@@ -331,6 +344,18 @@ extern "C" int ovp_sync(ovp_ctx* c) {
   if (!c) return OVP_E_ARG;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+// Results go to the host without a copy command: the last kernel of an update writes the result block into mapped pinned
+// memory and then a sequence number; ovp_msckf_fetch_results spins on that word (a hipMemcpyAsync + hipStreamSynchronize
+// pair costs ~25 us of launch, blit and wake-up latency per update, this ~5).
+__global__ __launch_bounds__(1024) void k_publish_results(const unsigned long long* __restrict__ src,
+                                                         unsigned long long* __restrict__ dst, int words,
+                                                         volatile unsigned* seq_host, unsigned seq) {
+  for (int i = threadIdx.x; i < words; i += 1024) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *seq_host = seq;
 }
 
 extern "C" int ovp_ctx_stream(ovp_ctx* c, void** stream) {
@@ -474,6 +499,8 @@ extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   c->h_n_meas.assign(b->n_meas, b->n_meas + F);
+  c->h_nmeas.assign(b->n_meas, b->n_meas + F);
+  c->h_nmeas_valid = true;
   c->h_clone_idx.assign(b->clone_idx, b->clone_idx + F * M);
   c->fp.uv = c->uv;
   c->fp.clone_idx = c->clone_idx;
@@ -488,6 +515,7 @@ extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
   if (!c || !b || b->n_feats < 0 || b->max_meas < 1 || b->max_meas > OVP_MAX_MEAS) return OVP_E_ARG;
   if (b->n_feats > c->f_max) return OVP_E_CAPACITY;
   c->h_n_meas.clear();
+  c->h_nmeas_valid = false;  // read back lazily (once) if a caller asks for ovp_update_info
   c->h_clone_idx.clear();
   c->fp.uv = b->uv;
   c->fp.clone_idx = b->clone_idx;
@@ -502,7 +530,7 @@ extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
 // ---- the update step ---------------------------------------------------------------------------
 static int chol_of_P(ovp_ctx* c, hipStream_t s) {
   const int n = c->n, ld = c->ld;
-  if (n <= OVP_TILECHOL_NMAX) return (int)ovp_launch_tilechol(c->P, c->L, nullptr, n, ld, c->flags, 0, s);
+  if (n <= OVP_TILECHOL_NMAX) return (int)ovp_launch_tilechol(c->P, c->L, nullptr, nullptr, n, ld, c->flags, 0, s);
   return (int)ovp_launch_chol(c->P, c->L, n, ld, c->flags, 0, s);
 }
 
@@ -519,9 +547,9 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
     // W1 = A L ;  T = I + L^T W1 ;  Lt = chol(T) (+ inverses of its diagonal blocks)
     HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
-    HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, c->stream));
+    HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, c->Ltp, n, ld, c->flags, 0, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
-    HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
+    HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->stream));
     HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->stream));
     return 0;
@@ -547,8 +575,7 @@ extern "C" int ovp_msckf_build_gate_gram_async(ovp_ctx* c, const ovp_update_opts
     int rc = fill_feat_params(c, o);
     if (rc) return rc;
   }
-  ovp::FeatParams& fp = c->fp;
-  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  // (the flag words were cleared by the previous ovp_msckf_fetch_results, or at creation)
   HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
   return ovp_build_gate_gram_tail(c, n, F);
 }
@@ -602,12 +629,15 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
     HIPCHK(hipEventRecord(c->ev_k1, c->stream));
     c->kpending = true;
   }
+  // K2 runs on the side stream in mode 2 (it is the shorter of the two branches: the join below then never stalls the
+  // main stream, and the cross-queue wake-up latency sits at the START of the side branch, off the critical path)
+  hipStream_t s2k = c->stream;
   if (overlap_mode == 2) {
     HIPCHK(hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    int rc = chol_of_P(c, c->stream2);
+    s2k = c->stream2;
+    int rc = chol_of_P(c, c->stream);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
   } else if (overlap_mode == 0) {
     int rc = chol_of_P(c, c->stream);
     if (rc) return rc;
@@ -617,15 +647,20 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // K2
   const int used_chunks = F > 0 ? (2 * F + c->rows_per_chunk - 1) / c->rows_per_chunk : 0;
   if (F > 0) {
-    HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, c->stream));
+    HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, s2k));
     int nsplit = (3 * F + 511) / 512;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > c->n_split) nsplit = c->n_split;
-    HIPCHK(ovp_launch_syrk(c->G, 3 * F, c->ldg, n + 1, nsplit, c->part, c->stream));
-    HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, used_chunks, c->gramR, c->stream));
-    HIPCHK(ovp_launch_assemble(c->gramR, fp.n_clones, 1, c->part, nsplit, c->colmap, n, c->Ab, c->ld, c->stream));
+    HIPCHK(ovp_launch_syrk(c->G, 3 * F, c->ldg, n + 1, nsplit, c->part, s2k));
+    HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, used_chunks, c->gramR, s2k));
+    HIPCHK(ovp_launch_assemble(c->gramR, fp.n_clones, 1, c->part, nsplit, c->colmap, n, c->Ab, c->ld, s2k));
   } else {
-    HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, c->stream));
+    HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, s2k));
+  }
+  if (overlap_mode == 2) {
+    // the Gram pair must be complete on the main stream when this call returns (the caller may all-reduce it there)
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   }
   HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
   return 0;
@@ -654,11 +689,26 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
   if (!c) return OVP_E_ARG;
   const int n = c->n, F = c->n_feats;
   {
-    // one copy up to the end of the accept flags in use
     const size_t used = (size_t)((char*)c->accept - (char*)c->res_block) + (size_t)F;
-    HIPCHK(hipMemcpyAsync(c->h_res_block, c->res_block, used, hipMemcpyDeviceToHost, c->stream));
+    const int words = (int)((used + 7) / 8);
+    const unsigned seq = ++c->seq;
+    hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)c->res_block,
+                       (unsigned long long*)c->h_res_block_dev, words, (volatile unsigned*)((char*)c->h_res_block_dev +
+                       ((char*)c->h_seq - (char*)c->h_res_block)), seq);
+    HIPCHK(hipGetLastError());
+    // flags for the next update are cleared behind the publication, off the next update's critical path
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n((const unsigned*)c->h_seq, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        HIPCHK(hipStreamSynchronize(c->stream));  // error path: surface a fault instead of spinning forever
+        if (__atomic_load_n((const unsigned*)c->h_seq, __ATOMIC_ACQUIRE) != seq) return OVP_E_STATE;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
   if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
   if (accepted_host && F) memcpy(accepted_host, c->h_accept, (size_t)F);
   if (chi2_host && F) memcpy(chi2_host, c->h_chi2, sizeof(double) * F);
@@ -677,13 +727,16 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
   }
   if (info) {
     memset(info, 0, sizeof(*info));
-    std::vector<int> nm(F);
-    // n_meas may live in caller-owned device memory (bind_device); read it back for the row count
-    if (F) hipMemcpy(nm.data(), c->fp.n_meas, sizeof(int) * F, hipMemcpyDeviceToHost);
+    // n_meas may live in caller-owned device memory (bind_device): read it back once per batch for the row count
+    if (F && !c->h_nmeas_valid) {
+      c->h_nmeas.resize(F);
+      HIPCHK(hipMemcpy(c->h_nmeas.data(), c->fp.n_meas, sizeof(int) * F, hipMemcpyDeviceToHost));
+      c->h_nmeas_valid = true;
+    }
     for (int f = 0; f < F; ++f)
       if (c->h_accept[f]) {
         info->n_accepted++;
-        info->n_rows += 2 * nm[f] - 3;
+        info->n_rows += 2 * c->h_nmeas[f] - 3;
       }
     info->n_cols = 0;
     info->not_spd = c->h_flags[0];
@@ -737,13 +790,13 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   HIPCHK(ovp_launch_plane_reduce_to_state(c->pl_E, ldg, n, in_state, c->Ab, ld, c->pl_cstsum + 9, c->pl_scal, s));
   // range part of the residual (regularised, diagonally normalised)
   HIPCHK(ovp_launch_normalize_reg(c->Ab, ld, n, 1e-10, c->pl_An, c->pl_bn, s));
-  HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, n, ld, c->flags + 2, 0, s));
+  HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, nullptr, n, ld, c->flags + 2, 0, s));
   HIPCHK(ovp_launch_range_energy(c->pl_Lr, c->pl_Dinv2, c->pl_bn, n, ld, 1e-8, c->pl_scal, s));
   // EKF update in information form with the chained factor
   HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
-  HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, n, ld, c->flags, 0, s));
-  HIPCHK(ovp_launch_fwdsub(c->Lt, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
+  HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, c->Ltp, n, ld, c->flags, 0, s));
+  HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
   HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
   HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_total, rows_u, n_involved, c->pl_res + 4 * pl, s));
   return 0;
@@ -1143,9 +1196,9 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) ovp_launch_tilechol(c->P, c->L, c->Dinv, c->n, c->ld, c->flags + 3, 0, c->stream);
+    for (int i = 0; i < 3; ++i) ovp_launch_tilechol(c->P, c->L, c->Dinv, c->Ltp, c->n, c->ld, c->flags + 3, 0, c->stream);
     hipEventRecord(e0, c->stream);
-    for (int i = 0; i < 20; ++i) ovp_launch_tilechol(c->P, c->L, c->Dinv, c->n, c->ld, c->flags + 3, 0, c->stream);
+    for (int i = 0; i < 20; ++i) ovp_launch_tilechol(c->P, c->L, c->Dinv, c->Ltp, c->n, c->ld, c->flags + 3, 0, c->stream);
     hipEventRecord(e1, c->stream);
     hipEventSynchronize(e1);
     float ms = 0.f;
