@@ -172,8 +172,8 @@ def main():
             "config": {"workload": "%d clones, %d MSCKF point feats per GPU, 0 planes, calib on (N=%d)" % (C, F, sc.N),
                        "clones": C, "feats_per_gpu": F, "state_dim": int(sc.N),
                        "accepted": int(out["accepted"].sum()), "parallelism": "feature-shard x%d" % world},
-            "stage_ms": {"build_gate": float(stage_ms[0]), "gram": float(stage_ms[1]), "ekf": float(stage_ms[2]),
-                         "gpu_total": float(stage_ms[3])},
+            "stage_ms": {"k1_build_project_gate": float(stage_ms[0]),
+                         "cholP_beside_gram_then_ekf": float(stage_ms[2]), "gpu_total": float(stage_ms[3])},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

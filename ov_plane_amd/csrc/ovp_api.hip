@@ -349,13 +349,14 @@ extern "C" int ovp_sync(ovp_ctx* c) {
 // Results go to the host without a copy command: the last kernel of an update writes the result block into mapped pinned
 // memory and then a sequence number; ovp_msckf_fetch_results spins on that word (a hipMemcpyAsync + hipStreamSynchronize
 // pair costs ~25 us of launch, blit and wake-up latency per update, this ~5).
-__global__ __launch_bounds__(1024) void k_publish_results(const unsigned long long* __restrict__ src,
+__global__ __launch_bounds__(1024) void k_publish_results(unsigned long long* __restrict__ src,
                                                          unsigned long long* __restrict__ dst, int words,
                                                          volatile unsigned* seq_host, unsigned seq) {
   for (int i = threadIdx.x; i < words; i += 1024) dst[i] = src[i];
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) *seq_host = seq;
+  if (threadIdx.x < 2) src[threadIdx.x] = 0ull;  // the four flag words, cleared for the next update
 }
 
 extern "C" int ovp_ctx_stream(ovp_ctx* c, void** stream) {
@@ -576,7 +577,6 @@ extern "C" int ovp_msckf_build_gate_gram_async(ovp_ctx* c, const ovp_update_opts
     if (rc) return rc;
   }
   // (the flag words were cleared by the previous ovp_msckf_fetch_results, or at creation)
-  HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
   return ovp_build_gate_gram_tail(c, n, F);
 }
 
@@ -602,8 +602,9 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   fp.Bscr = c->Bscr;
   fp.ldg = c->ldg;
   fp.rec = c->rec;
-  fp.chi2 = c->chi2;
-  fp.accept = c->accept;
+  // per-feature results straight into the pinned host block (same layout as res_block): they cross PCIe while K1 runs
+  fp.chi2 = (double*)((char*)c->h_res_block_dev + ((char*)c->chi2 - (char*)c->res_block));
+  fp.accept = (unsigned char*)c->h_res_block_dev + ((char*)c->accept - (char*)c->res_block);
   fp.dbg_cycles = c->dbg_cycles;
   return 0;
 }
@@ -622,28 +623,32 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_join, c->stream2));
   }
-  // K1
+  // K1.  Events on the main stream are kept to a minimum (each one costs microseconds between dependent kernels): with
+  // the kernel timer on, ev_k0 / ev_k1 bracket K1 and ev_k1 doubles as the fork point; otherwise one untimed fork event.
   if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
   HIPCHK(ovp_launch_feat_gate(&fp, c->stream));
+  hipEvent_t fork_ev = c->ev_fork;
   if (c->ktimer) {
-    HIPCHK(hipEventRecord(c->ev_k1, c->stream));
+    fork_ev = c->ev_k1;
     c->kpending = true;
   }
   // K2 runs on the side stream in mode 2 (it is the shorter of the two branches: the join below then never stalls the
   // main stream, and the cross-queue wake-up latency sits at the START of the side branch, off the critical path)
   hipStream_t s2k = c->stream;
   if (overlap_mode == 2) {
-    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    HIPCHK(hipEventRecord(fork_ev, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, fork_ev, 0));
     s2k = c->stream2;
     int rc = chol_of_P(c, c->stream);
     if (rc) return rc;
-  } else if (overlap_mode == 0) {
-    int rc = chol_of_P(c, c->stream);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_join, c->stream));
+  } else {
+    if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k1, c->stream));
+    if (overlap_mode == 0) {
+      int rc = chol_of_P(c, c->stream);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(c->ev_join, c->stream));
+    }
   }
-  HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
   // K2
   const int used_chunks = F > 0 ? (2 * F + c->rows_per_chunk - 1) / c->rows_per_chunk : 0;
   if (F > 0) {
@@ -662,7 +667,6 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
     HIPCHK(hipEventRecord(c->ev_join, c->stream2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   }
-  HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
   return 0;
 }
 
@@ -679,8 +683,10 @@ extern "C" int ovp_ekf_update_from_gram_async(ovp_ctx* c) {
   if (!c->have_cov) return OVP_E_STATE;
   int rc = ekf_from_gram(c, true);
   if (rc) return rc;
-  HIPCHK(hipEventRecord(c->ev_t[3], c->stream));
-  c->timed = true;
+  if (c->ktimer) {
+    HIPCHK(hipEventRecord(c->ev_t[3], c->stream));
+    c->timed = true;
+  }
   return 0;
 }
 
@@ -689,15 +695,13 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
   if (!c) return OVP_E_ARG;
   const int n = c->n, F = c->n_feats;
   {
-    const size_t used = (size_t)((char*)c->accept - (char*)c->res_block) + (size_t)F;
-    const int words = (int)((used + 7) / 8);
+    // [flags | dx] go through the publish kernel; chi2 / accept were written into the pinned block by K1 itself
+    const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
     const unsigned seq = ++c->seq;
-    hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)c->res_block,
+    hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(1024), 0, c->stream, (unsigned long long*)c->res_block,
                        (unsigned long long*)c->h_res_block_dev, words, (volatile unsigned*)((char*)c->h_res_block_dev +
                        ((char*)c->h_seq - (char*)c->h_res_block)), seq);
     HIPCHK(hipGetLastError());
-    // flags for the next update are cleared behind the publication, off the next update's critical path
-    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n((const unsigned*)c->h_seq, __ATOMIC_ACQUIRE) != seq) {
@@ -713,8 +717,12 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
   if (accepted_host && F) memcpy(accepted_host, c->h_accept, (size_t)F);
   if (chi2_host && F) memcpy(chi2_host, c->h_chi2, sizeof(double) * F);
   if (c->timed) {
-    for (int i = 0; i < 3; ++i) hipEventElapsedTime(&c->last_ms[i], c->ev_t[i], c->ev_t[i + 1]);
-    hipEventElapsedTime(&c->last_ms[3], c->ev_t[0], c->ev_t[3]);
+    // stage times while the kernel timer is on: [0] K1, [1] unused (K2 runs beside chol(P)), [2] chol(P) || K2 and the EKF
+    // update, [3] total from the start of K1
+    hipEventElapsedTime(&c->last_ms[0], c->ev_k0, c->ev_k1);
+    c->last_ms[1] = 0.f;
+    hipEventElapsedTime(&c->last_ms[2], c->ev_k1, c->ev_t[3]);
+    hipEventElapsedTime(&c->last_ms[3], c->ev_k0, c->ev_t[3]);
     c->timed = false;
   }
   if (c->kpending) {
@@ -1189,7 +1197,13 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
   else if (!strcmp(name, "P")) { src = c->P; bytes = nn; }
   else if (!strcmp(name, "G")) { src = c->G; bytes = (size_t)3 * c->n_feats * c->ldg * sizeof(double); }
   else if (!strcmp(name, "rec")) { src = c->rec; bytes = (size_t)c->fp.n_clones * c->n_feats * 2 * 21 * sizeof(double); }
-  else if (!strcmp(name, "chi2")) { src = c->chi2; bytes = (size_t)c->n_feats * sizeof(double); }
+  else if (!strcmp(name, "chi2")) {
+    hipStreamSynchronize(c->stream);
+    bytes = (size_t)c->n_feats * sizeof(double);
+    if ((long)bytes > max_bytes) bytes = (size_t)max_bytes;
+    memcpy(host, c->h_chi2, bytes);
+    return (int)bytes;
+  }
   else if (!strncmp(name, "bench_chol", 10)) {
     // diagnostics: average time of k_tilechol on the resident covariance; name = "bench_chol<skipmask>"
     ovp_dbg_tilechol_skip = atoi(name + 10);
