@@ -174,26 +174,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // Phase B: row `lane` of B = H_x P H_x^T + I, lower triangle, packed in LDS
     // ----------------------------------------------------------------------------------------
     {
-      // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads rows 3r..3r+2
-      double pn[18];
-      {
-        const int idb0 = __builtin_amdgcn_readlane(ida, 0);  // lane 2b already holds clone_id of observation b
+      // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads rows 3r..3r+2.
+      // The block of observation b+1 is fetched while b is processed; the loop is unrolled by two over a pair of
+      // buffers so that the prefetch needs no register copies.
+      const int rowoff = 3 * r * ldp + ida;  // 32-bit element offsets: (idb + 3r + k) * ldp + ida + l < 2^31
+      auto fetch = [&](double (&dst)[18], int b) {
+        const int idb = __builtin_amdgcn_readlane(ida, 2 * b);  // lane 2b holds clone_id of observation b
+        const double* src = P + (idb * ldp + rowoff);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb0 + 3 * r + k) * ldp + ida + l];
-      }
-      for (int b = 0; b < m; ++b) {
-        double pc[18];
-#pragma unroll
-        for (int q = 0; q < 18; ++q) pc[q] = pn[q];
-        if (b + 1 < m) {
-          const int idb1 = __builtin_amdgcn_readlane(ida, 2 * (b + 1));  // no dependent global loads in the loop
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int l = 0; l < 6; ++l) pn[6 * k + l] = P[(size_t)(idb1 + 3 * r + k) * ldp + ida + l];
-        }
+          for (int l = 0; l < 6; ++l) dst[6 * k + l] = src[k * ldp + l];
+      };
+      auto column_pair = [&](const double (&pc)[18], double (&pn)[18], int b) {
+        if (b + 1 < m) fetch(pn, b + 1);
         double t[6];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -233,6 +227,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[k >> 1][k & 1], s0);
           if (lane >= 2 * b) Bg[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
         }
+      };
+      double bufA[18], bufB[18];
+      fetch(bufA, 0);
+      for (int b = 0; b < m; b += 2) {
+        column_pair(bufA, bufB, b);
+        if (b + 1 < m) column_pair(bufB, bufA, b + 1);
       }
     }
     __syncthreads();
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       });
       OVP_STAMP_ONLY(long long tq0 = __builtin_readcyclecounter();)
       // update with the finished columns k < j0
+      int ck = 0;  // coff(k) - (k & ~1), advanced incrementally: +64-k after an even column, +63-k after an odd one
 #pragma nounroll
-      for (int k = 0; k < j0; ++k) {
-        const int ck = coff(k) - (k & ~1);
+      for (int k = 0; k < j0; ck += 64 - k - (k & 1), ++k) {
         double lik = sL[ck + lane];
         if (lane < j0) lik = 0.0;  // rows of finished blocks are final (k < j0 <= lane also covers the upper triangle)
         // L[j0 .. j0+15][k] and y_k: wave-uniform, 16-byte aligned (column starts are even) -> ds_read_b128 broadcasts

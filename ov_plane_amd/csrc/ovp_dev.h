@@ -72,8 +72,9 @@ __device__ __forceinline__ double row_share_f64(double v) {
 // exchange with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ double swap_pair_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+  // old = 0 with bound_ctrl: every lane is written, so no copy of the source into the destination is needed first
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
