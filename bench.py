@@ -139,22 +139,40 @@ def main():
         alg = algorithmic_flops_per_feature(m) * F
         exe = executed_flops_per_feature(m) * F
         k_s = max(k_ms, 1e-9) * 1e-3
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this
+        # process); only quoted when the workload is the one the passes were taken on
+        traffic, traffic_note = None, None
+        tp = os.path.join(_ROOT, "profiles", "r01_e_hbm_traffic_pmc.json")
+        if os.path.exists(tp) and (C, F, world) == (30, 2000, 1):
+            with open(tp) as fh:
+                kern = json.load(fh)["kernels"]
+            k1 = [v for k, v in kern.items() if "k_feat_gate" in k]
+            if k1:
+                # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies wide coalesced reads at half their bytes -> x2 as the
+                # upper bound; WRITE_SIZE taken as reported
+                traffic = (2.0 * k1[0]["FETCH_SIZE_KB_avg_per_launch"] + k1[0]["WRITE_SIZE_KB_avg_per_launch"]) * 1024.0
+                traffic_note = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_e_hbm_traffic_pmc.json "
+                                "(separate --pmc passes); mostly the materialised B scratch (34 MB), sparse rows (23 MB) "
+                                "and projector rows (10 MB) written for K2 - 1 TB/s, not the bound")
         roofline = {
             "bound": "mfma",
-            "kernel": "k_feat_gate (per-feature build + nullspace projection + chi2 gate)",
+            "kernel": "k_feat_gate (per-feature build + nullspace projection + chi2 gate), f64 vector ALU",
             "achieved": alg / k_s / 1e12,
             "peak": F64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": alg / k_s / 1e12 / F64_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
             "avg_launch_ms": k_ms,
             "launches_timed": k_n,
             "algorithmic_flops_per_launch": alg,
             "executed_flops_per_launch": exe,
             "achieved_executed": exe / k_s / 1e12,
             "frac_executed": exe / k_s / 1e12 / F64_PEAK_TFLOPS,
-            "note": "achieved = SURVEY 8(d) reference-algorithm FLOPs / launch time; the structured kernel issues "
-                    "~11x fewer FLOPs (executed_*), see DESIGN.md",
+            "note": "achieved/frac use the SURVEY 8(d) reference-algorithm FLOPs (5.77 MFLOP per feature) as the contract "
+                    "asks; the Gram-form kernel issues 9x fewer FLOPs, so that rate can exceed the hardware peak - the "
+                    "hardware utilisation is frac_executed (the kernel is VALU-issue bound: DPP exchanges, LDS "
+                    "broadcasts and readlanes around the f64 FMAs, DESIGN.md section 5)",
         }
         line = {
             "metric": "MSCKF update-step features/sec at %d clones" % C,

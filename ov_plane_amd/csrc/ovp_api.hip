@@ -541,7 +541,8 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
     int rc = chol_of_P(c, c->stream);
     if (rc) return rc;
   } else {
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    static const bool nojoin = getenv("OVP_DBG_NOJOIN") != nullptr;
+    if (!nojoin) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   }
   const double* b = c->Ab + (size_t)n * ld;
   if (n <= OVP_TILECHOL_NMAX) {
@@ -665,7 +666,8 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   if (overlap_mode == 2) {
     // the Gram pair must be complete on the main stream when this call returns (the caller may all-reduce it there)
     HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    static const bool nojoin = getenv("OVP_DBG_NOJOIN") != nullptr;  // timing experiment only (results are wrong)
+    if (!nojoin) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   }
   return 0;
 }
