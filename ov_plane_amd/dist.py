@@ -27,14 +27,17 @@ class DeviceBufferView:
 def sharded_update(ctx, opts, group=None):
     """One update step on a rank that already holds its shard (ctx.batch_*), the shared pose tables and P.
 
-    Returns ctx.fetch_results().  `ctx` must have been created on the current torch stream."""
+    The all-reduce is enqueued on the stream the context orders its work on (ovp_ctx_stream), wrapped as a
+    torch.cuda.ExternalStream, so that it runs between the two halves of the staged update without a host sync.
+    Returns ctx.fetch_results()."""
     import torch
     import torch.distributed as dist
 
     ctx.build_gate_gram_async(opts)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         ptr, rows, ld = ctx.gram_buffer()
-        t = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_handle())):
+            t = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     ctx.ekf_update_from_gram_async()
     return ctx.fetch_results()

@@ -366,6 +366,20 @@ def test_rccl_allreduce_path_single_rank(hiplib, oracle):
             out2 = sharded_update(ctx, o)
         assert np.abs(out2["dx"] - out["dx"]).max() == 0.0
         ctx.close()
+        # library-owned streams (what bench.py uses): the collective goes on ovp_ctx_stream through an ExternalStream
+        ctx2 = hiplib.Context(sc.N, sc.C, sc.F)
+        ctx2.cov_upload(sc.P)
+        ctx2.state_upload(sc)
+        ctx2.batch_upload_scene(sc)
+        ctx2.build_gate_gram_async(o)
+        ptr, rows, ld = ctx2.gram_buffer()
+        with torch.cuda.stream(torch.cuda.ExternalStream(ctx2.stream_handle())):
+            t2 = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
+            dist.all_reduce(t2, op=dist.ReduceOp.SUM)
+        ctx2.ekf_update_from_gram_async()
+        out3 = ctx2.fetch_results()
+        assert np.abs(out3["dx"] - out["dx"]).max() == 0.0 and (out3["accepted"] == out["accepted"]).all()
+        ctx2.close()
     finally:
         dist.destroy_process_group()
 
