@@ -514,6 +514,9 @@ hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double*
   if (slots <= 15 && !force25) {
     hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
                        flag, add_identity, ovp_dbg_tilechol_skip);
+  } else if (slots <= 18 && !force25) {  // N <= 240: still without register spills
+    hipLaunchKernelGGL((ovp::k_tilechol<18>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
+                       flag, add_identity, ovp_dbg_tilechol_skip);
   } else if (slots <= 25) {
     static bool attr = false;
     if (!attr) {

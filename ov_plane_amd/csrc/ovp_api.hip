@@ -798,16 +798,22 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   HIPCHK(ovp_launch_reduce_cst(c->pl_cst, nf, c->pl_cstsum, s));
   HIPCHK(ovp_launch_assemble_ext(c->gramR, fp.n_clones, c->part, nsplit, c->colmap, n, sid, c->pl_cstsum, c->pl_E, ldg, s));
   HIPCHK(ovp_launch_plane_reduce_to_state(c->pl_E, ldg, n, in_state, c->Ab, ld, c->pl_cstsum + 9, c->pl_scal, s));
-  // range part of the residual (regularised, diagonally normalised)
-  HIPCHK(ovp_launch_normalize_reg(c->Ab, ld, n, 1e-10, c->pl_An, c->pl_bn, s));
-  HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, nullptr, n, ld, c->flags + 2, 0, s));
-  HIPCHK(ovp_launch_range_energy(c->pl_Lr, c->pl_Dinv2, c->pl_bn, n, ld, 1e-8, c->pl_scal, s));
+  // range part of the residual (regularised, diagonally normalised): its own Cholesky, independent of the update's -
+  // side stream, joined before the gate (the two write different words of pl_scal)
+  hipStream_t s2 = c->stream2;
+  HIPCHK(hipEventRecord(c->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+  HIPCHK(ovp_launch_normalize_reg(c->Ab, ld, n, 1e-10, c->pl_An, c->pl_bn, s2));
+  HIPCHK(ovp_launch_tilechol(c->pl_An, c->pl_Lr, c->pl_Dinv2, nullptr, n, ld, c->flags + 2, 0, s2));
+  HIPCHK(ovp_launch_range_energy(c->pl_Lr, c->pl_Dinv2, c->pl_bn, n, ld, 1e-8, c->pl_scal, s2));
+  HIPCHK(hipEventRecord(c->ev_join, s2));
   // EKF update in information form with the chained factor
   HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
   HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, c->Ltp, n, ld, c->flags, 0, s));
   HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
   HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
+  HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
   HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_total, rows_u, n_involved, c->pl_res + 4 * pl, s));
   return 0;
 }
