@@ -482,20 +482,42 @@ __global__ __launch_bounds__(256) void k_gemm4(int M, int N, int K, const double
   }
 }
 
-// dx = P b (one wave per row), negative-diagonal flag
+// dx = P b (one wave per row), negative-diagonal flag.  Optionally the LAST block to finish (ticket counter) publishes the
+// result block [flags | dx] = `pub_words` 8-byte words into mapped pinned host memory, then the sequence word the host
+// spins on, and clears the flags and the ticket for the next update - the update then ends without a separate publish launch.
 __global__ __launch_bounds__(256) void k_dx_rows(const double* __restrict__ P, int n, int ldp,
                                                   const double* __restrict__ b, double* __restrict__ dx,
-                                                  int* __restrict__ negdiag) {
+                                                  int* __restrict__ negdiag, unsigned* __restrict__ ticket,
+                                                  unsigned long long* __restrict__ res_block,
+                                                  unsigned long long* __restrict__ host_block, int pub_words,
+                                                  volatile unsigned* seq_host, unsigned seq) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= n) return;
-  const double* pr = P + (size_t)row * ldp;
-  double s = 0.0;
-  for (int c = lane; c < n; c += 64) s = fma(pr[c], b[c], s);
-  s = wave_sum(s);
-  if (lane == 0) {
-    dx[row] = s;
-    if (pr[row] < 0.0) *negdiag = 1;
+  if (row < n) {
+    const double* pr = P + (size_t)row * ldp;
+    double s = 0.0;
+    for (int c = lane; c < n; c += 64) s = fma(pr[c], b[c], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      dx[row] = s;
+      if (pr[row] < 0.0) *negdiag = 1;
+    }
   }
+  if (!ticket) return;
+  __shared__ unsigned last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  for (int i = threadIdx.x; i < pub_words; i += 256) host_block[i] = __builtin_nontemporal_load(res_block + i);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *seq_host = seq;
+    *ticket = 0u;
+  }
+  if (threadIdx.x < 2) res_block[threadIdx.x] = 0ull;  // the four flag words, cleared for the next update
 }
 
 }  // namespace ovp
@@ -558,8 +580,11 @@ hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const d
 }
 
 hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
-                              hipStream_t stream) {
-  hipLaunchKernelGGL(ovp::k_dx_rows, dim3((n + 3) / 4), dim3(256), 0, stream, P, n, ldp, b, dx, negdiag);
+                              unsigned* ticket, void* res_block, void* host_block, int pub_words, void* seq_host,
+                              unsigned seq, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_dx_rows, dim3((n + 3) / 4), dim3(256), 0, stream, P, n, ldp, b, dx, negdiag, ticket,
+                     (unsigned long long*)res_block, (unsigned long long*)host_block, pub_words,
+                     (volatile unsigned*)seq_host, seq);
   return hipGetLastError();
 }
 }

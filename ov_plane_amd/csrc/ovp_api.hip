@@ -34,6 +34,8 @@ hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double*
 hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
                             int ldb, double* C, int ldc, int add_identity, int symmetric, hipStream_t stream);
 hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
+                              unsigned* ticket, void* res_block, void* host_block, int pub_words, void* seq_host,
+                              unsigned seq,
                               hipStream_t stream);
 hipError_t ovp_launch_reduce_gram(const double* gramS, int n_clones, int n_chunks, double* gramR, hipStream_t stream);
 hipError_t ovp_launch_plane_feat(const ovp::FeatParams* p, const ovp::PlaneParams* pp, int n_local, hipStream_t stream);
@@ -179,7 +181,9 @@ struct ovp_ctx {
   void *res_block = nullptr, *h_res_block = nullptr;  // [flags | dx | chi2 | accept], device and pinned host
   void* h_res_block_dev = nullptr;                    // device address of the pinned block
   volatile unsigned* h_seq = nullptr;                 // sequence word behind it (written last by k_publish_results)
-  unsigned seq = 0;
+  unsigned seq = 0, pub_seq = 0;
+  bool pub_pending = false;      // the running update publishes its results itself (k_dx_rows)
+  unsigned* ticket = nullptr;    // block counter of the publishing kernel
   std::vector<int> h_nmeas;                           // host copy of n_meas of the current batch (row count of `info`)
   bool h_nmeas_valid = false;
   size_t res_bytes = 0;
@@ -298,6 +302,8 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->idbuf, (size_t)4 * c->n_max + 64));
   c->small_cap = (size_t)4 * c->n_max * 64 + (size_t)c->n_max * c->n_max;
   HIPCHK(dalloc(&c->smallbuf, c->small_cap));
+  HIPCHK(hipMalloc((void**)&c->ticket, 16));
+  HIPCHK(hipMemset(c->ticket, 0, 16));
   HIPCHK(hipHostMalloc((void**)&c->h_res_block, c->res_bytes + 64, hipHostMallocMapped));  // pinned mirror of res_block
   memset(c->h_res_block, 0, c->res_bytes + 64);
   HIPCHK(hipHostGetDevicePointer(&c->h_res_block_dev, c->h_res_block, 0));
@@ -322,7 +328,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->stream2);
-  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->clone_R, c->clone_p,
+  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
                  c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd};
@@ -535,7 +541,7 @@ static int chol_of_P(ovp_ctx* c, hipStream_t s) {
   return (int)ovp_launch_chol(c->P, c->L, n, ld, c->flags, 0, s);
 }
 
-static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
+static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish = false) {
   const int n = c->n, ld = c->ld;
   if (!chol_p_done_on_stream2) {
     int rc = chol_of_P(c, c->stream);
@@ -553,7 +559,16 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2) {
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->stream));
-    HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->stream));
+    if (publish) {
+      // the last block of the dx kernel also publishes [flags | dx] to the pinned host block (no separate launch)
+      const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
+      c->pub_seq = ++c->seq;
+      HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->ticket, c->res_block, c->h_res_block_dev, words,
+                                (char*)c->h_res_block_dev + ((char*)c->h_seq - (char*)c->h_res_block), c->pub_seq, c->stream));
+      c->pub_pending = true;
+    } else {
+      HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, c->stream));
+    }
     return 0;
   }
   // large-state fallback: global-memory factorization
@@ -683,7 +698,7 @@ extern "C" int ovp_gram_buffer(ovp_ctx* c, double** Ab_dev, int* n_rows, int* ld
 extern "C" int ovp_ekf_update_from_gram_async(ovp_ctx* c) {
   if (!c) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
-  int rc = ekf_from_gram(c, true);
+  int rc = ekf_from_gram(c, true, true);
   if (rc) return rc;
   if (c->ktimer) {
     HIPCHK(hipEventRecord(c->ev_t[3], c->stream));
@@ -697,13 +712,18 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
   if (!c) return OVP_E_ARG;
   const int n = c->n, F = c->n_feats;
   {
-    // [flags | dx] go through the publish kernel; chi2 / accept were written into the pinned block by K1 itself
-    const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
-    const unsigned seq = ++c->seq;
-    hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(1024), 0, c->stream, (unsigned long long*)c->res_block,
-                       (unsigned long long*)c->h_res_block_dev, words, (volatile unsigned*)((char*)c->h_res_block_dev +
-                       ((char*)c->h_seq - (char*)c->h_res_block)), seq);
-    HIPCHK(hipGetLastError());
+    // [flags | dx] are published by the last block of the dx kernel (or, on the fallback path, by a publish kernel);
+    // chi2 / accept were written into the pinned block by K1 itself
+    unsigned seq = c->pub_seq;
+    if (!c->pub_pending) {
+      const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
+      seq = ++c->seq;
+      hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(1024), 0, c->stream, (unsigned long long*)c->res_block,
+                         (unsigned long long*)c->h_res_block_dev, words, (volatile unsigned*)((char*)c->h_res_block_dev +
+                         ((char*)c->h_seq - (char*)c->h_res_block)), seq);
+      HIPCHK(hipGetLastError());
+    }
+    c->pub_pending = false;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n((const unsigned*)c->h_seq, __ATOMIC_ACQUIRE) != seq) {
@@ -719,6 +739,7 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
   if (accepted_host && F) memcpy(accepted_host, c->h_accept, (size_t)F);
   if (chi2_host && F) memcpy(chi2_host, c->h_chi2, sizeof(double) * F);
   if (c->timed) {
+    hipEventSynchronize(c->ev_t[3]);  // recorded behind the publishing kernel: may trail the sequence word by a moment
     // stage times while the kernel timer is on: [0] K1, [1] unused (K2 runs beside chol(P)), [2] chol(P) || K2 and the EKF
     // update, [3] total from the start of K1
     hipEventElapsedTime(&c->last_ms[0], c->ev_k0, c->ev_k1);
