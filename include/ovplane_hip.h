@@ -134,6 +134,22 @@ int ovp_ekf_update_from_gram_async(ovp_ctx *ctx);
 int ovp_msckf_fetch_results(ovp_ctx *ctx, double *dx_host, uint8_t *accepted_host, double *chi2_host,
                             ovp_update_info *info);
 
+/* ext ov_core::FeatureInitializerOptions (open_vins ov_core/src/feat/FeatureInitializerOptions.h; not in the reference tree) */
+typedef struct {
+  int refine_features; /* run single_gaussnewton after the linear triangulation (UpdaterMSCKF.cpp:153-155) */
+  int max_runs;
+  double init_lamda, max_lamda, min_dx, min_dcost, lam_mult;
+  double min_dist, max_dist, max_baseline, max_cond_number;
+} ovp_triang_opts;
+void ovp_triang_defaults(ovp_triang_opts *o);
+
+/* ext FeatureInitializer::single_triangulation (+ single_gaussnewton) for every feature of the uploaded batch, against the
+ * camera poses of the clones (update/UpdaterMSCKF.cpp:120-166; same block in UpdaterSLAM.cpp:129-144, UpdaterPlane.cpp:139-164).
+ * uv_norm [n_feats*max_meas*2] f32 (host) = Feature::uvs_norm in the layout of ovp_feature_batch::uv.  The positions become
+ * the linearisation points of the batch on the device (the next update uses them) and are returned in p_FinG_out
+ * [n_feats*3] (host, may be NULL); ok[f] = 0 where the reference erases the feature.  Needs ovp_state_upload and a batch. */
+int ovp_triangulate(ovp_ctx *ctx, const ovp_triang_opts *opts, const float *uv_norm, double *p_FinG_out, uint8_t *ok);
+
 /* Planes touched by an update (host pointers): plane k (0-based) has reference id k+1.
  * plane_of_feat[f] = 0 for a free point, else the id of the plane feature f lies on (VioManager's feat2plane map,
  * core/VioManager.cpp:516-533). cp / cp_fej: closest-point estimates (State::_features_PLANE value()/fej() for in-state

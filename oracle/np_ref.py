@@ -534,3 +534,89 @@ def propagate_summed(x, po, imu, t0, t1):
     elif len(sel) == 1:
         last_w = sel[-1][1:4] - x["bg"]
     return dict(x=x, Phi=Phi, Q=Qs, last_w=last_w, n_sel=len(sel))
+
+
+# ---- ext FeatureInitializer, independent matrix-form restatement -----------------------------------------
+def triangulate_feature(sc, f, refine=True, opts=None):
+    """single_triangulation + single_gaussnewton of feature f of a synth scene (mono).  Returns (ok, p_FinG)."""
+    o = dict(max_runs=5, init_lamda=1e-3, max_lamda=1e10, min_dx=1e-6, min_dcost=1e-6, lam_mult=10.0, min_dist=0.10,
+             max_dist=60.0, max_baseline=40.0, max_cond_number=10000.0)
+    if opts:
+        o.update(opts)
+    m = int(sc.n_meas[f])
+    if m < 2:
+        return False, np.zeros(3)
+    R_ItoC = _q2R(sc.calib_q)
+    cams = []
+    for k in range(m):
+        ci = int(sc.clone_idx[f, k])
+        R_GtoC = R_ItoC @ _q2R(sc.clone_q[ci])
+        cams.append((R_GtoC, sc.clone_p[ci] - R_GtoC.T @ sc.calib_p))
+    R_GtoA, p_AinG = cams[-1]
+    uvn = sc.uv_norm[f, :m]
+    A, b, rel = np.zeros((3, 3)), np.zeros(3), []
+    for k in range(m):
+        R_GtoCi, p_CiinG = cams[k]
+        R_AtoCi = R_GtoCi @ R_GtoA.T
+        p_CiinA = R_GtoA @ (p_CiinG - p_AinG)
+        rel.append((R_AtoCi, p_CiinA, -R_AtoCi @ p_CiinA))
+        bi = R_AtoCi.T @ np.array([float(uvn[k, 0]), float(uvn[k, 1]), 1.0])
+        bi /= np.linalg.norm(bi)
+        Ai = _skew(bi).T @ _skew(bi)
+        A += Ai
+        b += Ai @ p_CiinA
+    pA = np.linalg.solve(A, b)
+    sv = np.linalg.svd(A, compute_uv=False)
+    if sv[0] / sv[-1] > o["max_cond_number"] or pA[2] < o["min_dist"] or pA[2] > o["max_dist"] or np.isnan(pA).any():
+        return False, np.zeros(3)
+
+    def cost(al, be, rho):
+        e = 0.0
+        for k in range(m):
+            R, _, pAC = rel[k]
+            h = R @ np.array([al, be, 1.0]) + rho * pAC
+            z = np.array([h[0] / h[2], h[1] / h[2]]).astype(np.float32)
+            r = uvn[k] - z
+            e += float(np.sqrt(r[0] * r[0] + r[1] * r[1])) ** 2
+        return e
+
+    if refine:
+        rho, al, be = 1.0 / pA[2], pA[0] / pA[2], pA[1] / pA[2]
+        lam, eps, runs, recompute = o["init_lamda"], 1e4, 0, True
+        cost_old = cost(al, be, rho)
+        Hess, grad = np.zeros((3, 3)), np.zeros(3)
+        while runs < o["max_runs"] and lam < o["max_lamda"] and eps > o["min_dx"]:
+            if recompute:
+                Hess[:] = 0
+                grad[:] = 0
+                for k in range(m):
+                    R, _, pAC = rel[k]
+                    h = R @ np.array([al, be, 1.0]) + rho * pAC
+                    H = np.array([[(R[0, 0] * h[2] - h[0] * R[2, 0]), (R[0, 1] * h[2] - h[0] * R[2, 1]), (pAC[0] * h[2] - h[0] * pAC[2])],
+                                  [(R[1, 0] * h[2] - h[1] * R[2, 0]), (R[1, 1] * h[2] - h[1] * R[2, 1]), (pAC[1] * h[2] - h[1] * pAC[2])]]) / h[2]**2
+                    z = np.array([h[0] / h[2], h[1] / h[2]]).astype(np.float32)
+                    r = (uvn[k] - z).astype(np.float64)
+                    grad += H.T @ r
+                    Hess += H.T @ H
+            Hl = Hess.copy()
+            Hl[np.diag_indices(3)] *= (1.0 + lam)
+            dx = np.linalg.solve(Hl, grad)
+            c = cost(al + dx[0], be + dx[1], rho + dx[2])
+            if c <= cost_old and (cost_old - c) / cost_old < o["min_dcost"]:
+                al, be, rho = al + dx[0], be + dx[1], rho + dx[2]
+                break
+            if c <= cost_old:
+                recompute, cost_old = True, c
+                al, be, rho = al + dx[0], be + dx[1], rho + dx[2]
+                runs += 1
+                lam /= o["lam_mult"]
+                eps = np.linalg.norm(dx)
+            else:
+                recompute = False
+                lam *= o["lam_mult"]
+        pA = np.array([al / rho, be / rho, 1.0 / rho])
+        u = pA / np.linalg.norm(pA)
+        base = max(np.linalg.norm(r[1] - (r[1] @ u) * u) for r in rel)
+        if pA[2] < o["min_dist"] or pA[2] > o["max_dist"] or np.linalg.norm(pA) / base > o["max_baseline"]:
+            return False, np.zeros(3)
+    return True, R_GtoA.T @ pA + p_AinG

@@ -1840,3 +1840,259 @@ int ovo_propagate_summed(ovo_imu_state *x, const ovo_prop_opts *po, const double
   free(sel);
   return 0;
 }
+
+/* ================================================================================================================
+ * ext ov_core::FeatureInitializer::single_triangulation + single_gaussnewton, as called from
+ * update/UpdaterMSCKF.cpp:120-166 (camera clone poses :123-135, mono).  The source is NOT in /root/reference (open_vins
+ * ov_core/src/feat/FeatureInitializer.cpp @ 74a63cf): this is a restatement of the published algorithm from memory -
+ * PARITY UNPINNED against the real implementation.  Kept faithful to what is remembered of its arithmetic: sequential sums
+ * over the measurements, residuals of the refinement formed in single precision (Eigen::Matrix<float,2,1>).
+ * ============================================================================================================== */
+static void tri_sym3_eig(const double A[9], double ev[3]) { /* cyclic Jacobi on a symmetric 3x3, eigenvalues only */
+  double a[9];
+  memcpy(a, A, sizeof(a));
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = fabs(a[1]) + fabs(a[2]) + fabs(a[5]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = a[3 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) { /* columns p,q */
+          const double akp = a[3 * k + p], akq = a[3 * k + q];
+          a[3 * k + p] = c * akp - s * akq;
+          a[3 * k + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) { /* rows p,q */
+          const double apk = a[3 * p + k], aqk = a[3 * q + k];
+          a[3 * p + k] = c * apk - s * aqk;
+          a[3 * q + k] = s * apk + c * aqk;
+        }
+      }
+  }
+  ev[0] = a[0];
+  ev[1] = a[4];
+  ev[2] = a[8];
+}
+
+/* x = A^-1 b for a 3x3 system, Gaussian elimination with full pivoting (the reference uses colPivHouseholderQr; both are
+ * backward stable, the solutions agree to a few ulp) */
+static int tri_solve3(const double A[9], const double b[3], double x[3]) {
+  double m[12];
+  int perm[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) m[4 * i + j] = A[3 * i + j];
+    m[4 * i + 3] = b[i];
+  }
+  for (int k = 0; k < 3; ++k) {
+    int pi = k, pj = k;
+    double best = -1.0;
+    for (int i = k; i < 3; ++i)
+      for (int j = k; j < 3; ++j)
+        if (fabs(m[4 * i + j]) > best) {
+          best = fabs(m[4 * i + j]);
+          pi = i;
+          pj = j;
+        }
+    if (!(best > 0.0)) return 1;
+    if (pi != k)
+      for (int j = 0; j < 4; ++j) {
+        const double t = m[4 * k + j];
+        m[4 * k + j] = m[4 * pi + j];
+        m[4 * pi + j] = t;
+      }
+    if (pj != k) {
+      for (int i = 0; i < 3; ++i) {
+        const double t = m[4 * i + k];
+        m[4 * i + k] = m[4 * i + pj];
+        m[4 * i + pj] = t;
+      }
+      const int t = perm[k];
+      perm[k] = perm[pj];
+      perm[pj] = t;
+    }
+    for (int i = k + 1; i < 3; ++i) {
+      const double f = m[4 * i + k] / m[4 * k + k];
+      for (int j = k; j < 4; ++j) m[4 * i + j] -= f * m[4 * k + j];
+    }
+  }
+  double y[3];
+  for (int i = 2; i >= 0; --i) {
+    double s = m[4 * i + 3];
+    for (int j = i + 1; j < 3; ++j) s -= m[4 * i + j] * y[j];
+    y[i] = s / m[4 * i + i];
+  }
+  for (int i = 0; i < 3; ++i) x[perm[i]] = y[i];
+  return 0;
+}
+
+typedef struct {
+  double R_AtoC[9], p_CinA[3], p_AinC[3];
+} tri_rel;
+
+static double tri_cost(const tri_rel *rel, const float *uvn, int m, double alpha, double beta, double rho) {
+  double err = 0.0;
+  for (int k = 0; k < m; ++k) {
+    const double *R = rel[k].R_AtoC, *p = rel[k].p_AinC;
+    const double hi1 = R[0] * alpha + R[1] * beta + R[2] + rho * p[0];
+    const double hi2 = R[3] * alpha + R[4] * beta + R[5] + rho * p[1];
+    const double hi3 = R[6] * alpha + R[7] * beta + R[8] + rho * p[2];
+    const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+    const float r0 = uvn[2 * k] - z0, r1 = uvn[2 * k + 1] - z1;
+    const float nrm = sqrtf(r0 * r0 + r1 * r1);
+    err += (double)nrm * (double)nrm;
+  }
+  return err;
+}
+
+void ovo_triang_defaults(ovo_triang_opts *o) {
+  o->refine_features = 1;
+  o->max_runs = 5;
+  o->init_lamda = 1e-3;
+  o->max_lamda = 1e10;
+  o->min_dx = 1e-6;
+  o->min_dcost = 1e-6;
+  o->lam_mult = 10.0;
+  o->min_dist = 0.10;
+  o->max_dist = 60.0;
+  o->max_baseline = 40.0;
+  o->max_cond_number = 10000.0;
+}
+
+int ovo_triangulate(const ovo_triang_opts *o, const ovo_state *st, const ovo_feats *fb, const float *uv_norm,
+                    double *p_FinG_out, uint8_t *ok) {
+  const int F = fb->n_feats, M = fb->max_meas, C = st->n_clones;
+  /* camera poses of the clones, update/UpdaterMSCKF.cpp:123-135 */
+  double *Rc = (double *)malloc(sizeof(double) * 9 * (size_t)C), *pc = (double *)malloc(sizeof(double) * 3 * (size_t)C);
+  double R_ItoC[9];
+  ovo_quat_2_rot(st->calib_q, R_ItoC);
+  for (int i = 0; i < C; ++i) {
+    double R_GtoI[9];
+    ovo_quat_2_rot(st->clone_q + 4 * i, R_GtoI);
+    mat3_mul(R_ItoC, R_GtoI, Rc + 9 * i);
+    for (int a = 0; a < 3; ++a) /* p_CinG = p_IinG - R_GtoC^T p_IinC */
+      pc[3 * i + a] = st->clone_p[3 * i + a] - (Rc[9 * i + a] * st->calib_p[0] + Rc[9 * i + 3 + a] * st->calib_p[1] +
+                                                 Rc[9 * i + 6 + a] * st->calib_p[2]);
+  }
+  tri_rel *rel = (tri_rel *)malloc(sizeof(tri_rel) * (size_t)M);
+  for (int f = 0; f < F; ++f) {
+    ok[f] = 0;
+    for (int a = 0; a < 3; ++a) p_FinG_out[3 * f + a] = 0.0;
+    const int m = fb->n_meas[f];
+    if (m < 2) continue;
+    const int *ci = fb->clone_idx + (size_t)f * M;
+    const float *uvn = uv_norm + (size_t)f * M * 2;
+    /* anchor = last measurement of the (only) camera */
+    const double *R_GtoA = Rc + 9 * ci[m - 1], *p_AinG = pc + 3 * ci[m - 1];
+    double A[9] = {0}, b[3] = {0};
+    for (int k = 0; k < m; ++k) {
+      const double *R_GtoCi = Rc + 9 * ci[k], *p_CiinG = pc + 3 * ci[k];
+      tri_rel *r = rel + k;
+      for (int i = 0; i < 3; ++i) /* R_AtoCi = R_GtoCi R_GtoA^T */
+        for (int j = 0; j < 3; ++j)
+          r->R_AtoC[3 * i + j] = R_GtoCi[3 * i] * R_GtoA[3 * j] + R_GtoCi[3 * i + 1] * R_GtoA[3 * j + 1] + R_GtoCi[3 * i + 2] * R_GtoA[3 * j + 2];
+      const double d[3] = {p_CiinG[0] - p_AinG[0], p_CiinG[1] - p_AinG[1], p_CiinG[2] - p_AinG[2]};
+      mat3_vec(R_GtoA, d, r->p_CinA);
+      double t[3];
+      mat3_vec(r->R_AtoC, r->p_CinA, t);
+      for (int a = 0; a < 3; ++a) r->p_AinC[a] = -t[a];
+      /* bearing in the anchor frame */
+      const double bc[3] = {(double)uvn[2 * k], (double)uvn[2 * k + 1], 1.0};
+      double bi[3];
+      for (int a = 0; a < 3; ++a) bi[a] = r->R_AtoC[a] * bc[0] + r->R_AtoC[3 + a] * bc[1] + r->R_AtoC[6 + a] * bc[2];
+      const double nb = sqrt(bi[0] * bi[0] + bi[1] * bi[1] + bi[2] * bi[2]);
+      for (int a = 0; a < 3; ++a) bi[a] /= nb;
+      double S[9], Ai[9];
+      skew3(bi, S);
+      for (int i = 0; i < 3; ++i) /* Ai = S^T S */
+        for (int j = 0; j < 3; ++j) Ai[3 * i + j] = S[i] * S[j] + S[3 + i] * S[3 + j] + S[6 + i] * S[6 + j];
+      for (int i = 0; i < 9; ++i) A[i] += Ai[i];
+      for (int i = 0; i < 3; ++i) b[i] += Ai[3 * i] * r->p_CinA[0] + Ai[3 * i + 1] * r->p_CinA[1] + Ai[3 * i + 2] * r->p_CinA[2];
+    }
+    double pA[3], ev[3];
+    if (tri_solve3(A, b, pA)) continue;
+    tri_sym3_eig(A, ev);
+    double emax = fmax(ev[0], fmax(ev[1], ev[2])), emin = fmin(ev[0], fmin(ev[1], ev[2]));
+    const double condA = emax / emin;
+    const double nrm0 = sqrt(pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2]);
+    if (fabs(condA) > o->max_cond_number || pA[2] < o->min_dist || pA[2] > o->max_dist || isnan(nrm0)) continue;
+    if (o->refine_features) {
+      double rho = 1.0 / pA[2], alpha = pA[0] / pA[2], beta = pA[1] / pA[2];
+      double lam = o->init_lamda, eps = 10000.0;
+      int runs = 0, recompute = 1;
+      double Hess[9] = {0}, grad[3] = {0};
+      double cost_old = tri_cost(rel, uvn, m, alpha, beta, rho);
+      while (runs < o->max_runs && lam < o->max_lamda && eps > o->min_dx) {
+        if (recompute) {
+          memset(Hess, 0, sizeof(Hess));
+          memset(grad, 0, sizeof(grad));
+          for (int k = 0; k < m; ++k) {
+            const double *R = rel[k].R_AtoC, *p = rel[k].p_AinC;
+            const double hi1 = R[0] * alpha + R[1] * beta + R[2] + rho * p[0];
+            const double hi2 = R[3] * alpha + R[4] * beta + R[5] + rho * p[1];
+            const double hi3 = R[6] * alpha + R[7] * beta + R[8] + rho * p[2];
+            const double h32 = hi3 * hi3;
+            const double H[6] = {(R[0] * hi3 - hi1 * R[6]) / h32, (R[1] * hi3 - hi1 * R[7]) / h32, (p[0] * hi3 - hi1 * p[2]) / h32,
+                                 (R[3] * hi3 - hi2 * R[6]) / h32, (R[4] * hi3 - hi2 * R[7]) / h32, (p[1] * hi3 - hi2 * p[2]) / h32};
+            const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+            const double r0 = (double)(uvn[2 * k] - z0), r1 = (double)(uvn[2 * k + 1] - z1);
+            for (int i = 0; i < 3; ++i) {
+              grad[i] += H[i] * r0 + H[3 + i] * r1;
+              for (int j = 0; j < 3; ++j) Hess[3 * i + j] += H[i] * H[j] + H[3 + i] * H[3 + j];
+            }
+          }
+        }
+        double Hl[9], dx[3];
+        memcpy(Hl, Hess, sizeof(Hl));
+        for (int i = 0; i < 3; ++i) Hl[4 * i] *= (1.0 + lam);
+        if (tri_solve3(Hl, grad, dx)) break;
+        const double cost = tri_cost(rel, uvn, m, alpha + dx[0], beta + dx[1], rho + dx[2]);
+        if (cost <= cost_old && (cost_old - cost) / cost_old < o->min_dcost) {
+          alpha += dx[0];
+          beta += dx[1];
+          rho += dx[2];
+          eps = 0;
+          break;
+        }
+        if (cost <= cost_old) {
+          recompute = 1;
+          cost_old = cost;
+          alpha += dx[0];
+          beta += dx[1];
+          rho += dx[2];
+          runs++;
+          lam = lam / o->lam_mult;
+          eps = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+        } else {
+          recompute = 0;
+          lam = lam * o->lam_mult;
+          continue;
+        }
+      }
+      pA[0] = alpha / rho;
+      pA[1] = beta / rho;
+      pA[2] = 1.0 / rho;
+      /* largest baseline orthogonal to the bearing of the feature */
+      const double np = sqrt(pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2]);
+      double base_line_max = 0.0;
+      for (int k = 0; k < m; ++k) {
+        const double *c = rel[k].p_CinA;
+        const double along = (c[0] * pA[0] + c[1] * pA[1] + c[2] * pA[2]) / np;
+        const double n2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2] - along * along;
+        const double bl = n2 > 0.0 ? sqrt(n2) : 0.0;
+        if (bl > base_line_max) base_line_max = bl;
+      }
+      if (pA[2] < o->min_dist || pA[2] > o->max_dist || (np / base_line_max) > o->max_baseline || isnan(np)) continue;
+    }
+    for (int a = 0; a < 3; ++a)
+      p_FinG_out[3 * f + a] = R_GtoA[a] * pA[0] + R_GtoA[3 + a] * pA[1] + R_GtoA[6 + a] * pA[2] + p_AinG[a];
+    ok[f] = 1;
+  }
+  free(rel);
+  free(Rc);
+  free(pc);
+  return 0;
+}

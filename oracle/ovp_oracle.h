@@ -193,6 +193,18 @@ void ovo_predict_and_compute(ovo_imu_state *x, const ovo_prop_opts *po, const do
 int ovo_propagate_summed(ovo_imu_state *x, const ovo_prop_opts *po, const double *imu, int n_imu, double time0, double time1,
                          double *Phi, double *Qs, double *last_w, int *n_sel);
 
+/* ---- ext ov_core::FeatureInitializer (source not in the reference tree - restated from memory) ------- */
+typedef struct {
+  int refine_features, max_runs;
+  double init_lamda, max_lamda, min_dx, min_dcost, lam_mult, min_dist, max_dist, max_baseline, max_cond_number;
+} ovo_triang_opts;
+void ovo_triang_defaults(ovo_triang_opts *o); /* ext FeatureInitializerOptions defaults */
+/* single_triangulation (+ single_gaussnewton when refine_features) of every feature of the batch against the camera poses of
+ * the clones (update/UpdaterMSCKF.cpp:123-166).  uv_norm [n_feats*max_meas*2] f32 = Feature::uvs_norm.  p_FinG_out
+ * [n_feats*3], ok[f] = 0 where the reference drops the feature. */
+int ovo_triangulate(const ovo_triang_opts *o, const ovo_state *st, const ovo_feats *fb, const float *uv_norm,
+                    double *p_FinG_out, uint8_t *ok);
+
 #ifdef __cplusplus
 }
 #endif

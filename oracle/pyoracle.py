@@ -378,3 +378,33 @@ def propagate_summed(x, po, imu, time0, time1):
                                 _dp(Phi), _dp(Q), _dp(lw), C.byref(n))
     xo = {k: np.array(getattr(s, k)[:]) for k in IMU_KEYS}
     return dict(rc=rc, x=xo, Phi=np.ascontiguousarray(Phi), Q=np.ascontiguousarray(Q), last_w=lw, n_sel=n.value)
+
+
+# ---- ext FeatureInitializer ---------------------------------------------------------------------------
+class OvoTriangOpts(C.Structure):
+    _fields_ = [("refine_features", C.c_int), ("max_runs", C.c_int), ("init_lamda", C.c_double), ("max_lamda", C.c_double),
+                ("min_dx", C.c_double), ("min_dcost", C.c_double), ("lam_mult", C.c_double), ("min_dist", C.c_double),
+                ("max_dist", C.c_double), ("max_baseline", C.c_double), ("max_cond_number", C.c_double)]
+
+
+def triang_defaults(**over):
+    o = OvoTriangOpts()
+    lib().ovo_triang_defaults(C.byref(o))
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
+
+
+def triangulate(sc, opts=None, feats=None):
+    """ovo_triangulate: single_triangulation + single_gaussnewton of every feature of the scene from sc.uv_norm."""
+    L = lib()
+    pk = Packed(sc, feats)
+    o = opts if opts is not None else triang_defaults()
+    sel = np.arange(sc.F) if feats is None else np.asarray(feats)
+    uvn = np.ascontiguousarray(sc.uv_norm[sel], dtype=np.float32)
+    F = len(sel)
+    p = np.zeros((F, 3))
+    ok = np.zeros(F, dtype=np.uint8)
+    L.ovo_triangulate(C.byref(o), C.byref(pk.state), C.byref(pk.feats), uvn.ctypes.data_as(C.POINTER(C.c_float)), _dp(p),
+                      ok.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return dict(p_FinG=p, ok=ok.astype(bool))

@@ -95,7 +95,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream",
+    "ovp_ctx_stream", "ovp_triang_defaults", "ovp_triangulate",
 ]
 
 
@@ -144,6 +144,10 @@ def lib():
         L.ovp_cov_size.argtypes = [C.c_void_p]
         L.ovp_last_timings.argtypes = [C.c_void_p, C.c_void_p]
         L.ovp_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.ovp_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.ovp_triang_defaults.argtypes = [C.POINTER(TriangOpts)]
+        L.ovp_triang_defaults.restype = None
+        L.ovp_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -157,6 +161,20 @@ def opts_from_scene(sc) -> UpdateOpts:
     o = sc.opts
     return UpdateOpts(o["sigma_px"], o["chi2_mult"], o["sigma_c"], int(o["do_fej"]), int(o["do_calib_pose"]),
                       int(o["do_calib_intr"]), 0)
+
+
+class TriangOpts(C.Structure):
+    _fields_ = [("refine_features", C.c_int), ("max_runs", C.c_int), ("init_lamda", C.c_double), ("max_lamda", C.c_double),
+                ("min_dx", C.c_double), ("min_dcost", C.c_double), ("lam_mult", C.c_double), ("min_dist", C.c_double),
+                ("max_dist", C.c_double), ("max_baseline", C.c_double), ("max_cond_number", C.c_double)]
+
+
+def triang_defaults(**over):
+    o = TriangOpts()
+    lib().ovp_triang_defaults(C.byref(o))
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
 
 
 class Context:
@@ -363,6 +381,16 @@ class Context:
         _chk(lib().ovp_ekf_update(self._h, H.ctypes.data, H.shape[0], H.shape[1], H.shape[0], col_ids.ctypes.data,
                                   res.ctypes.data, dx.ctypes.data, C.byref(info)), "ovp_ekf_update")
         return dx, info
+
+    def triangulate(self, uv_norm, opts=None):
+        """ovp_triangulate on the uploaded batch; returns dict(p_FinG [F,3], ok [F])."""
+        o = opts if opts is not None else triang_defaults()
+        uvn = np.ascontiguousarray(uv_norm, dtype=np.float32)
+        F = self.n_feats
+        p = np.zeros((max(F, 1), 3))
+        ok = np.zeros(max(F, 1), dtype=np.uint8)
+        _chk(lib().ovp_triangulate(self._h, C.byref(o), uvn.ctypes.data, p.ctypes.data, ok.ctypes.data), "ovp_triangulate")
+        return dict(p_FinG=p[:F], ok=ok[:F].astype(bool))
 
     def sync(self):
         _chk(lib().ovp_sync(self._h), "ovp_sync")

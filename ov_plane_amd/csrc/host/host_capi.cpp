@@ -8,6 +8,11 @@
 using namespace ov_plane;
 using namespace ov_type;
 
+// When set, the next ovph_run_msckf_update hands the features over with normalised measurements and NO position, i.e. the
+// updater triangulates them itself (update/UpdaterMSCKF.cpp:120-166) before the update.
+static const float *g_uv_norm = nullptr;
+extern "C" void ovph_set_uv_norm(const float *uv_norm /* [F][M][2] or NULL */) { g_uv_norm = uv_norm; }
+
 extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
                                      const double *clone_p_fej, const double *calib_q, const double *calib_p,
                                      const double *intr, int n_planes_in_state, const double *cp_state,
@@ -102,7 +107,14 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
       ft->uvs.push_back(uv[((size_t)f * M + k) * 2]);
       ft->uvs.push_back(uv[((size_t)f * M + k) * 2 + 1]);
     }
-    memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+    if (g_uv_norm) {
+      for (int k = 0; k < n_meas[f]; ++k) {
+        ft->uvs_norm.push_back(g_uv_norm[((size_t)f * M + k) * 2]);
+        ft->uvs_norm.push_back(g_uv_norm[((size_t)f * M + k) * 2 + 1]);
+      }
+    } else {
+      memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+    }
     if (plane_of_feat[f] > 0) feat2plane[ft->featid] = (size_t)plane_of_feat[f];
     fv.push_back(ft);
   }
@@ -113,6 +125,7 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   ov_core::FeatureInitializerOptions fio;
   UpdaterMSCKF updater(uo, fio);
   updater.update(state, fv, fextra, fused, feat2plane);
+  g_uv_norm = nullptr;
   // outputs
   int i = 0;
   for (auto &c : state->_clones_IMU) {

@@ -576,7 +576,8 @@ void StateHelper::initialize_invertible(std::shared_ptr<State> state, std::share
 }
 
 // ---- update/UpdaterMSCKF.cpp ---------------------------------------------------------------------
-UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, ov_core::FeatureInitializerOptions &) : _options(options) {
+UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, ov_core::FeatureInitializerOptions &feat_init_options)
+    : _options(options), _featinit(feat_init_options) {
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
   // the chi-square table (:59-62) lives inside libovplane_hip.so (ovp_chi2_quantile_095)
 }
@@ -597,16 +598,22 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   auto it0 = feature_vec.begin();
   while (it0 != feature_vec.end()) {
     auto &ft = **it0;
-    std::vector<float> uv2;
+    std::vector<float> uv2, uvn2;
     std::vector<double> ts2;
+    const bool has_norm = ft.uvs_norm.size() == ft.uvs.size();
     for (size_t k = 0; k < ft.timestamps.size(); ++k)
       if (clone_slot.count(ft.timestamps[k])) {
         ts2.push_back(ft.timestamps[k]);
         uv2.push_back(ft.uvs[2 * k]);
         uv2.push_back(ft.uvs[2 * k + 1]);
+        if (has_norm) {
+          uvn2.push_back(ft.uvs_norm[2 * k]);
+          uvn2.push_back(ft.uvs_norm[2 * k + 1]);
+        }
       }
     ft.timestamps = ts2;
     ft.uvs = uv2;
+    ft.uvs_norm = uvn2;
     if (ts2.size() < 2) {
       ft.to_delete = true;
       it0 = feature_vec.erase(it0);
@@ -680,6 +687,50 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
                     state->_options.do_calib_camera_intrinsics ? 1 : 0,
                     0};
   pack_tables();
+
+  // ---- :120-166 triangulate (+ refine) the features that arrive with normalised measurements; failures are erased ----
+  {
+    bool any_norm = false;
+    for (auto &f : feature_vec) any_norm = any_norm || (!f->uvs_norm.empty() && f->uvs_norm.size() == f->uvs.size());
+    if (any_norm) {
+      upload_batch(feature_vec);
+      const int F = (int)feature_vec.size();
+      int M = 1;
+      for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
+      std::vector<float> uvn((size_t)F * M * 2, 0.f);
+      for (int f = 0; f < F; ++f)
+        for (size_t k = 0; k < feature_vec[f]->uvs_norm.size(); ++k) uvn[(size_t)f * M * 2 + k] = feature_vec[f]->uvs_norm[k];
+      ovp_triang_opts to;
+      to.refine_features = _featinit.refine_features ? 1 : 0;
+      to.max_runs = _featinit.max_runs;
+      to.init_lamda = _featinit.init_lamda;
+      to.max_lamda = _featinit.max_lamda;
+      to.min_dx = _featinit.min_dx;
+      to.min_dcost = _featinit.min_dcost;
+      to.lam_mult = _featinit.lam_mult;
+      to.min_dist = _featinit.min_dist;
+      to.max_dist = _featinit.max_dist;
+      to.max_baseline = _featinit.max_baseline;
+      to.max_cond_number = _featinit.max_cond_number;
+      std::vector<double> pf((size_t)F * 3);
+      std::vector<uint8_t> okv(F, 0);
+      gpu_check(ovp_triangulate(state->_gpu, &to, uvn.data(), pf.data(), okv.data()), "ovp_triangulate");
+      size_t f = 0;
+      auto it1 = feature_vec.begin();
+      while (it1 != feature_vec.end()) {
+        const bool had_norm = !(*it1)->uvs_norm.empty();
+        if (had_norm && !okv[f]) {
+          (*it1)->to_delete = true;  // :161-165
+          it1 = feature_vec.erase(it1);
+        } else {
+          if (had_norm) memcpy((*it1)->p_FinG, &pf[3 * f], 3 * sizeof(double));
+          it1++;
+        }
+        ++f;
+      }
+      if (feature_vec.empty()) return;
+    }
+  }
 
   // ---- plane loop (:411-649) ----
   std::set<size_t> features_used_already;

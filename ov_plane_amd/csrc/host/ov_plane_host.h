@@ -191,6 +191,7 @@ public:
 
 protected:
   UpdaterOptions _options;
+  ov_core::FeatureInitializerOptions _featinit;  // reference: std::shared_ptr<ov_core::FeatureInitializer> initializer_feat
 };
 
 // utils/NoiseManager.h:36-79 (continuous-time IMU noise densities; *_2 are filled by the Propagator constructor)

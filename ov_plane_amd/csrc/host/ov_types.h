@@ -365,10 +365,18 @@ struct Feature {
   size_t featid = 0;
   bool to_delete = false;
   std::vector<float> uvs;          // [2*k] raw pixels of camera 0 (reference: unordered_map<cam, vector<VectorXf>>)
+  std::vector<float> uvs_norm;     // [2*k] undistorted normalised coordinates (filled by the tracker); empty = p_FinG is given
   std::vector<double> timestamps;  // [k] clone timestamps of camera 0
   double p_FinG[3] = {0, 0, 0};
 };
-struct FeatureInitializerOptions {};
+// ext ov_core::FeatureInitializerOptions (feat/FeatureInitializerOptions.h), defaults of open_vins
+struct FeatureInitializerOptions {
+  bool triangulate_1d = false;  // only the 3-d triangulation is built (every shipped config uses it)
+  bool refine_features = true;
+  int max_runs = 5;
+  double init_lamda = 1e-3, max_lamda = 1e10, min_dx = 1e-6, min_dcost = 1e-6, lam_mult = 10;
+  double min_dist = 0.10, max_dist = 60, max_baseline = 40, max_cond_number = 10000;
+};
 // ext ov_core::ImuData (utils/sensor_data.h)
 struct ImuData {
   double timestamp = 0.0;

@@ -153,6 +153,8 @@ struct ovp_ctx {
   // work buffers
   double *G = nullptr, *rec = nullptr, *chi2 = nullptr, *Bscr = nullptr;
   unsigned char* accept = nullptr;
+  float* uvn = nullptr;            // normalised measurements for ovp_triangulate (allocated on first use)
+  unsigned char* tri_ok = nullptr;
   int ldg = 0;
   double *gramS = nullptr, *gramR = nullptr, *part = nullptr, *Dinv = nullptr, *Ltp = nullptr;
   int n_chunks = 0, rows_per_chunk = 0, n_split = 0;
@@ -328,7 +330,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->stream2);
-  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->clone_R, c->clone_p,
+  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
                  c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd};
@@ -490,6 +492,60 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
   HIPCHK(hipMemcpyAsync(c->colmap, cm.data(), sizeof(ovp::ColMap) * c->n_max, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->have_state = true;
+  return 0;
+}
+
+// ---- triangulation ----------------------------------------------------------------
+extern "C" void ovp_triang_defaults(ovp_triang_opts* o) {
+  if (!o) return;
+  o->refine_features = 1;
+  o->max_runs = 5;
+  o->init_lamda = 1e-3;
+  o->max_lamda = 1e10;
+  o->min_dx = 1e-6;
+  o->min_dcost = 1e-6;
+  o->lam_mult = 10.0;
+  o->min_dist = 0.10;
+  o->max_dist = 60.0;
+  o->max_baseline = 40.0;
+  o->max_cond_number = 10000.0;
+}
+
+extern "C" int ovp_triangulate(ovp_ctx* c, const ovp_triang_opts* o, const float* uv_norm, double* p_FinG_out, uint8_t* ok) {
+  if (!c || !o || !uv_norm || !ok) return OVP_E_ARG;
+  if (!c->have_state || !c->have_batch) return OVP_E_STATE;
+  const size_t F = (size_t)c->n_feats, M = (size_t)c->max_meas;
+  if (F == 0) return 0;
+  if (!c->uvn) HIPCHK(hipMalloc((void**)&c->uvn, sizeof(float) * (size_t)c->f_max * OVP_MAX_MEAS * 2));
+  if (!c->tri_ok) HIPCHK(hipMalloc((void**)&c->tri_ok, (size_t)c->f_max));
+  HIPCHK(hipMemcpyAsync(c->uvn, uv_norm, sizeof(float) * F * M * 2, hipMemcpyHostToDevice, c->stream));
+  ovp::TriParams tp;
+  tp.uvn = c->uvn;
+  tp.clone_idx = c->fp.clone_idx;
+  tp.n_meas = c->fp.n_meas;
+  tp.n_feats = (int)F;
+  tp.max_meas = (int)M;
+  tp.clone_R = c->clone_R;
+  tp.clone_p = c->clone_p;
+  tp.cal = c->cal;
+  tp.refine_features = o->refine_features;
+  tp.max_runs = o->max_runs;
+  tp.init_lamda = o->init_lamda;
+  tp.max_lamda = o->max_lamda;
+  tp.min_dx = o->min_dx;
+  tp.min_dcost = o->min_dcost;
+  tp.lam_mult = o->lam_mult;
+  tp.min_dist = o->min_dist;
+  tp.max_dist = o->max_dist;
+  tp.max_baseline = o->max_baseline;
+  tp.max_cond_number = o->max_cond_number;
+  tp.p_FinG = c->p_FinG;  // the library's own buffer even when the batch was bound to caller memory
+  tp.ok = c->tri_ok;
+  HIPCHK(ovp_launch_triangulate(&tp, c->stream));
+  c->fp.p_FinG = c->p_FinG;
+  if (p_FinG_out) HIPCHK(hipMemcpyAsync(p_FinG_out, c->p_FinG, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ok, c->tri_ok, F, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -44,6 +44,21 @@ struct FeatParams {
   long long* dbg_cycles;  // optional [n_feats][8] phase stamps (diagnostics)
 };
 
+// arguments of the triangulation kernel (ext FeatureInitializerOptions + the feature batch + the clone tables)
+struct TriParams {
+  const float* uvn;  // [n_feats][max_meas][2] normalised measurements (Feature::uvs_norm)
+  const int* clone_idx;
+  const int* n_meas;
+  int n_feats, max_meas;
+  const double* clone_R;  // [C][9] row-major R_GtoI (current estimates)
+  const double* clone_p;  // [C][3]
+  const double* cal;      // [0..8] R_ItoC, [9..11] p_IinC
+  int refine_features, max_runs;
+  double init_lamda, max_lamda, min_dx, min_dcost, lam_mult, min_dist, max_dist, max_baseline, max_cond_number;
+  double* p_FinG;         // [n_feats][3] out
+  unsigned char* ok;      // [n_feats] out
+};
+
 // per-plane arguments of the plane feature kernel
 struct PlaneParams {
   const int* feat_list;  // [n_local] indices into the feature batch
@@ -70,6 +85,7 @@ struct ColMap {
 
 extern "C" {
 hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream);
+hipError_t ovp_launch_triangulate(const ovp::TriParams* p, hipStream_t stream);
 
 // K2a: per-clone structured Gram of the sparse rows. gramS [n_clones][n_chunks][OVP_GRAM_ELEMS]
 hipError_t ovp_launch_struct_gram(const double* rec, int n_clones, int n_feats, int rows_per_chunk, int n_chunks,

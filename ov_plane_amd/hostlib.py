@@ -22,9 +22,12 @@ def lib():
     return _LIB
 
 
-def run_msckf_update(sc):
-    """Drives ov_plane::UpdaterMSCKF::update (C++ host classes over the C-ABI) on a synth.Scene."""
+def run_msckf_update(sc, triangulate=False):
+    """Drives ov_plane::UpdaterMSCKF::update (C++ host classes over the C-ABI) on a synth.Scene.
+    triangulate=True: the features carry uvs_norm and no position; the updater triangulates them first."""
     L = lib()
+    uvn = np.ascontiguousarray(sc.uv_norm, dtype=np.float32) if triangulate else None
+    L.ovph_set_uv_norm(uvn.ctypes.data_as(C.c_void_p) if triangulate else None)
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
     in_state = np.where(sc.plane_in_state)[0]
     out_state = np.where(~sc.plane_in_state)[0]

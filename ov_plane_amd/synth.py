@@ -131,6 +131,23 @@ def project_all(p_f, R_GtoI, p_IinG, R_ItoC, p_IinC, intr):
     return np.stack([u, v], axis=-1), z
 
 
+def radtan_undistort(u, v, intr, iters=30):
+    """Inverse of the radtan model by fixed-point iteration (what the tracker's undistort_cv does before a feature's
+    uvs_norm are stored, ext ov_core CamRadtan / cv::undistortPoints).  u, v arrays of raw pixels -> normalised coordinates."""
+    fx, fy, cx, cy, k1, k2, p1, p2 = [float(a) for a in intr]
+    x0 = (np.asarray(u, dtype=np.float64) - cx) / fx
+    y0 = (np.asarray(v, dtype=np.float64) - cy) / fy
+    x, y = x0.copy(), y0.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        g = 1 + k1 * r2 + k2 * r2 * r2
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (x0 - dx) / g
+        y = (y0 - dy) / g
+    return x, y
+
+
 # ----------------------------------------------------------------------------------------------
 # scene container
 # ----------------------------------------------------------------------------------------------
@@ -397,6 +414,14 @@ def make_scene(
         m = int(n_meas[f])
         uv[f, :m] = uv_noisy[f, start[f] : start[f] + m].astype(np.float32)
 
+    # normalised measurements as the tracker stores them (undistorted with the current intrinsics estimate, f32)
+    uv_norm = np.zeros((F, C, 2), dtype=np.float32)
+    xn, yn = radtan_undistort(uv[..., 0].astype(np.float64), uv[..., 1].astype(np.float64), intr)
+    uv_norm[..., 0] = xn.astype(np.float32)
+    uv_norm[..., 1] = yn.astype(np.float32)
+    for f in range(F):
+        uv_norm[f, int(n_meas[f]):] = 0.0
+
     # ---- linearisation points: GN triangulation with the *estimated* poses ----------------------------
     R_est = np.array([quat_2_rot(q) for q in clone_q])
     uv_dense = np.zeros((F, C, 2))
@@ -443,6 +468,7 @@ def make_scene(
         intr=intr,
         P=P,
         uv=uv,
+        uv_norm=uv_norm,
         clone_idx=clone_idx,
         n_meas=n_meas,
         p_FinG=p_FinG,

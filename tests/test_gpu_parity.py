@@ -648,3 +648,70 @@ def test_host_cpp_mirror_state_maintenance(hiplib, oracle):
     assert out["slam_to_plane"].tolist() == [1, 0, 1, 0, 1]
     exp_ids = [int(newid2[newid[sc.ids["slam"][k]]]) for k in (0, 2, 4)]
     assert out["slam_id"][[0, 2, 4]].tolist() == exp_ids
+
+
+@pytest.mark.parametrize("kw,refine", [
+    (dict(C=11, F=200, seed=3, ragged=True, min_meas=2), 1),
+    (dict(C=30, F=300, seed=4), 1),
+    (dict(C=8, F=120, seed=5, ragged=True, min_meas=2), 0),
+])
+def test_triangulation_matches_oracle(hiplib, oracle, kw, refine):
+    """ext FeatureInitializer::single_triangulation + single_gaussnewton on the device (SURVEY 8f rank 1) against the
+    restatement: same features kept / dropped, positions identical up to rounding (sums in the reference's order, no FMA
+    contraction, single-precision residuals), and the triangulated batch feeds the update like the scene's own points."""
+    sc = make_scene(**kw)
+    ref = oracle.triangulate(sc, oracle.triang_defaults(refine_features=refine))
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.triangulate(sc.uv_norm, hiplib.triang_defaults(refine_features=refine))
+    assert (out["ok"] == ref["ok"]).all()
+    assert ref["ok"].sum() > 0.8 * sc.F and ((~ref["ok"]).any() or not kw.get("ragged", False))
+    ok = ref["ok"]
+    assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < 1e-11
+    # the linearisation points now on the device are the triangulated ones: update with them == oracle update with them
+    from ov_plane_amd.synth import Scene
+
+    sc2 = Scene(sc)
+    sc2["p_FinG"] = np.where(ok[:, None], ref["p_FinG"], sc.p_FinG)
+    keep = np.where(ok)[0]
+    ref_u = oracle.msckf_point_update(sc2, feats=keep)
+    # device: same batch, rejected features masked out by a 1-observation count (dropped like UpdaterMSCKF.cpp:94-96)
+    ctx.batch_upload_scene(sc2, keep)
+    o = hiplib.opts_from_scene(sc)
+    upd = ctx.msckf_update(o)
+    assert (upd["accepted"] == ref_u["accepted"]).all()
+    assert np.abs(upd["dx"] - ref_u["dx"]).max() < TOL_DX
+    ctx.close()
+
+
+def test_host_cpp_mirror_updater_msckf_triangulates_first(hiplib, oracle):
+    """UpdaterMSCKF::update handed features WITHOUT positions (uvs_norm only): triangulation + refinement on the device
+    (update/UpdaterMSCKF.cpp:120-166), failures erased with to_delete, then the usual update on the survivors."""
+    from ov_plane_amd.build import build_host
+
+    build_host(force=False)
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import Scene, quat_boxplus
+
+    sc = make_scene(C=11, F=150, seed=3, ragged=True, min_meas=2, chi2_mult=1.0)
+    tri = oracle.triangulate(sc)
+    assert (~tri["ok"]).any()
+    keep = np.where(tri["ok"])[0]
+    sc2 = Scene(sc)
+    sc2["p_FinG"] = np.where(tri["ok"][:, None], tri["p_FinG"], sc.p_FinG)
+    ref = oracle.msckf_point_update(sc2, feats=keep)
+    out = hostlib.run_msckf_update(sc, triangulate=True)
+    exp_kept = np.zeros(sc.F, dtype=bool)
+    exp_kept[keep[ref["accepted"]]] = True
+    assert (out["kept"] == exp_kept).all()
+    assert out["deleted"].all()
+    dx = ref["dx"]
+    cq, cp = sc.clone_q.copy(), sc.clone_p.copy()
+    for i in range(sc.C):
+        cid = sc.ids["clones"][i]
+        cq[i] = quat_boxplus(cq[i], dx[cid:cid + 3])
+        cp[i] = cp[i] + dx[cid + 3:cid + 6]
+    assert np.abs(out["clone_p"] - cp).max() < TOL_DX and np.abs(out["clone_q"] - cq).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
