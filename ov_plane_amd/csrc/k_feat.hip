@@ -14,6 +14,7 @@
 // Q1 an orthonormal basis of range(H_f).  The kernel emits the sparse rows (rec) and G|g; K2 reduces them.
 #include "ovp_feat_model.h"
 #include <utility>
+#include <cstdlib>
 
 namespace ovp {
 
@@ -63,6 +64,16 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 //   all phases :  solved right-hand sides (64 x 4) + column exchange buffer (2 x 64)               3072 B
 // B itself (written column by column in phase B, consumed block by block in phase C by the lane that wrote it) goes
 // through a per-feature scratch in device memory: 16.9 KB per feature, 2.2 MB per XCD in flight = L2-resident.
+//
+// BORDERED (features with at most 30 observations, n + 4 <= 64): the four right-hand sides [r | H_f] ride along as four extra
+// ROWS n..n+3 of the matrix being factorized.  The forward substitution then is the factorization's own row update (no
+// per-column v_readlane / select code for right-hand sides), the sums y^T y, Z^T y, Z^T Z of the gate appear as the (negated)
+// Schur complement in the 4x4 corner, and the left-looking update of a 16-column block against the finished columns is a
+// product of LDS-resident panels - v_mfma_f64_16x16x4_f64 - instead of a 20-FMA-per-column scalar loop.  The variant
+// without the border keeps the all-VALU path for 31 / 32 observations.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <bool BORDERED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_gate(const FeatParams p) {
   // the feature waves outrank the (latency-bound, one-workgroup) chol(P) that runs beside them on the side stream: on the
   // SIMDs both share, an equal-priority Cholesky wave stretches the slowest feature block - and the kernel - by 40 %
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           for (int k = 0; k < 14; ++k) s1 = fma(u[k], vc[k >> 1][k & 1], s1);
 #pragma unroll
           for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[k >> 1][k & 1], s0);
-          if (lane >= 2 * b) Bg[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+          if (lane >= 2 * b && (!BORDERED || lane < n)) Bg[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
         }
       };
       double bufA[18], bufB[18];
@@ -233,6 +244,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int b = 0; b < m; b += 2) {
         column_pair(bufA, bufB, b);
         if (b + 1 < m) column_pair(bufB, bufA, b + 1);
+      }
+      if constexpr (BORDERED) {
+        // border rows n..n+3 of column `lane`: r, H_f(:,0..2) of measurement row `lane`
+        if (valid) {
+          double* cj = Bg + coff(lane) - (lane & ~1) + n;
+          cj[0] = res;
+          cj[1] = hf[0];
+          cj[2] = hf[1];
+          cj[3] = hf[2];
+        }
       }
     }
     __syncthreads();
@@ -244,139 +265,258 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // Left-looking, blocked by 16 columns: the block's 16 entries of this lane's row live in registers, the finished
     // columns of L are read back from LDS (own element + 16-wide broadcast), so the code is a compact rolled loop
     // (an earlier fully unrolled 64-step version was instruction-fetch bound).
-    double rh0 = res, rh1 = hf[0], rh2 = hf[1], rh3 = hf[2];
     bool spd = true;
-    const int nblk = (n + 15) >> 4;
-    OVP_STAMP_ONLY(long long t_ll = 0, t_ib = 0;)
+    double sums[10];
+    if constexpr (BORDERED) {
+      const int nb4 = n + 4;                      // rows of the bordered matrix
+      const bool brow = lane < nb4;               // this lane holds one of them
+      const int nblk = (nb4 + 15) >> 4;
+      const int lr = lane >> 4, lc = lane & 15;   // MFMA operand coordinates
+      double* const sT = sY;                       // 16 x 17 transpose scratch (sY | sB region, 3 KB)
 #pragma nounroll
-    for (int jb = 0; jb < nblk; ++jb) {
-      const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);  // scalar: lane selects below must not waterfall
-      double ab[16];
-      static_for<16>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int col = j0 + t;
-        double v = (col == lane) ? 1.0 : 0.0;                       // identity padding for rows/columns >= n
-        if (valid && col < n && lane >= (col & ~1)) v = Bg[coff(col) + lane - (col & ~1)];
-        ab[t] = v;
-      });
-      OVP_STAMP_ONLY(long long tq0 = __builtin_readcyclecounter();)
-      // update with the finished columns k < j0
-      int ck = 0;  // coff(k) - (k & ~1), advanced incrementally: +64-k after an even column, +63-k after an odd one
-#pragma nounroll
-      for (int k = 0; k < j0; ck += 64 - k - (k & 1), ++k) {
-        double lik = sL[ck + lane];
-        if (lane < j0) lik = 0.0;  // rows of finished blocks are final (k < j0 <= lane also covers the upper triangle)
-        // L[j0 .. j0+15][k] and y_k: wave-uniform, 16-byte aligned (column starts are even) -> ds_read_b128 broadcasts
-        const double2_t* lj = reinterpret_cast<const double2_t*>(sL + ck + j0);
-        const double2_t* yk = reinterpret_cast<const double2_t*>(sY + 4 * k);
-        double2_t lv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lv[q] = lj[q];
-        const double2_t y01 = yk[0], y23 = yk[1];
+      for (int jb = 0; jb < nblk; ++jb) {
+        const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);
+        double ab[16];
         static_for<16>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
-          ab[t] = fma(-lik, lv[t >> 1][t & 1], ab[t]);
+          const int col = j0 + t;
+          double v = 0.0;  // upper triangle, the 4x4 corner and the padding start at zero
+          if (brow && col < n && lane >= (col & ~1)) v = Bg[coff(col) + lane - (col & ~1)];
+          ab[t] = v;
         });
-        const double lir = (lane < j0 + 16) ? lik : 0.0;  // right-hand sides: only the rows of this block
-        rh0 = fma(-lir, y01[0], rh0);
-        rh1 = fma(-lir, y01[1], rh1);
-        rh2 = fma(-lir, y23[0], rh2);
-        rh3 = fma(-lir, y23[1], rh3);
-      }
-      OVP_STAMP_ONLY(long long tq1 = __builtin_readcyclecounter(); t_ll += tq1 - tq0;)
-      // factor the block: 16 right-looking steps inside the registers.  Column c of L is broadcast to the other rows
-      // through a small LDS buffer (one ds_write + a few 16-byte broadcast reads per step instead of 2 v_readlane per
-      // element); the next pivot is taken with a look-ahead so its rsq/Newton chain overlaps the LDS round trip.
-      double piv = readlane_f64(ab[0], j0);
-      double inv = rsqrt_nr(piv);
-      static_for<16>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const int kg = j0 + c;  // global column, wave-uniform
-        spd = spd && (piv > 0.0);
-        const double inv_c = inv;
-        double l = ab[c] * inv_c;
-        if (lane < kg) l = 0.0;  // rows above the diagonal do not belong to column kg
-        ab[c] = l;
-        double* cb = sB + (c & 1) * NR;
-        cb[lane] = l;
-        if constexpr (c + 1 < 16) {
-          const double l1 = readlane_f64(l, kg + 1);
-          ab[c + 1] = fma(-l, l1, ab[c + 1]);
-          piv = readlane_f64(ab[c + 1], kg + 1);
-          inv = rsqrt_nr(piv);
-        }
-        const double x0 = readlane_f64(rh0, kg) * inv_c, x1 = readlane_f64(rh1, kg) * inv_c;
-        const double x2 = readlane_f64(rh2, kg) * inv_c, x3 = readlane_f64(rh3, kg) * inv_c;
-        if (lane > kg && lane < j0 + 16) {  // rows of later blocks receive this column through the left-looking pass
-          rh0 = fma(-l, x0, rh0);
-          rh1 = fma(-l, x1, rh1);
-          rh2 = fma(-l, x2, rh2);
-          rh3 = fma(-l, x3, rh3);
-        } else if (lane == kg) {
-          rh0 = x0;
-          rh1 = x1;
-          rh2 = x2;
-          rh3 = x3;
-        }
-        if constexpr (c + 2 < 16) {
-          // l_(j0+j), j = c+2..15, read as aligned pairs starting at the even index <= c+2
-          constexpr int e0 = (c + 2) & ~1;
-          const double2_t* cbv = reinterpret_cast<const double2_t*>(cb + j0 + e0);
-          double2_t lv[(16 - e0) / 2];
+        if (jb > 0) {
+          // left-looking update of rows >= j0, columns j0..j0+15 with the finished columns 0..j0-1:
+          //   D[rt] = L[16 rt .. 16 rt + 15][0 .. j0) * L[j0 .. j0 + 15][0 .. j0)^T     (one 16 x 16 tile per row tile rt >= jb)
+          // A operand: lane -> (row lc of the tile, column kk + lr); B operand: (row j0 + lc, column kk + lr).
+          double4_t acc[4];
 #pragma unroll
-          for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = cbv[q];
-          static_for<14 - c>([&](auto jc) {
-            constexpr int j = c + 2 + decltype(jc)::value;
-            ab[j] = fma(-l, lv[(j - e0) >> 1][(j - e0) & 1], ab[j]);
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = double4_t{0.0, 0.0, 0.0, 0.0};
+          int col = lr;                              // column kk + lr of this lane
+          int ck = coff(col) - (col & ~1);           // its offset; four columns further: + 248 - 4 col
+          const int kend = j0 < n ? j0 : n;          // only factor columns (< n) contribute, never the corner columns
+#pragma nounroll
+          for (int kk = 0; kk < kend; kk += 4) {
+            const double bv = (col < n) ? sL[ck + j0 + lc] : 0.0;
+            double av[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) av[rt] = (rt >= jb) ? sL[ck + 16 * rt + lc] : 0.0;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+              if (rt >= jb) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv, acc[rt], 0, 0, 0);
+            ck += 248 - 4 * col;
+            col += 4;
+          }
+          // C layout (row lr + 4 v, column lc) -> row-per-lane through a 16 x 17 LDS tile, one row tile at a time
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            if (rt >= jb) {
+#pragma unroll
+              for (int v = 0; v < 4; ++v) sT[(lr + 4 * v) * 17 + lc] = acc[rt][v];
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              if ((lane >> 4) == rt) {
+                static_for<16>([&](auto tc) {
+                  constexpr int t = decltype(tc)::value;
+                  ab[t] -= sT[lc * 17 + t];
+                });
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+        // factor the block's columns < n (right-looking inside the registers, column exchange through LDS); the border
+        // rows take part like any other row, the corner columns are never pivots
+        double piv = readlane_f64(ab[0], j0);
+        double inv = rsqrt_nr(piv);
+        static_for<16>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          const int kg = j0 + c;  // global column, wave-uniform
+          if (kg < n) {
+            spd = spd && (piv > 0.0);
+            double l = ab[c] * inv;
+            if (lane < kg) l = 0.0;  // rows above the diagonal do not belong to column kg
+            ab[c] = l;
+            double* cb = sB + (c & 1) * NR;
+            cb[lane] = l;
+            if constexpr (c + 1 < 16) {
+              const double l1 = readlane_f64(l, kg + 1);
+              ab[c + 1] = fma(-l, l1, ab[c + 1]);
+              piv = readlane_f64(ab[c + 1], kg + 1);
+              inv = rsqrt_nr(piv);
+            }
+            if constexpr (c + 2 < 16) {
+              constexpr int e0 = (c + 2) & ~1;
+              const double2_t* cbv = reinterpret_cast<const double2_t*>(cb + j0 + e0);
+              double2_t lv[(16 - e0) / 2];
+#pragma unroll
+              for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = cbv[q];
+              static_for<14 - c>([&](auto jc) {
+                constexpr int j = c + 2 + decltype(jc)::value;
+                ab[j] = fma(-l, lv[(j - e0) >> 1][(j - e0) & 1], ab[j]);
+              });
+            }
+          }
+        });
+        // publish the block (factor columns, and for the last block the corner)
+        static_for<16>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          const int col = j0 + t;
+          if (lane >= (col & ~1)) sL[coff(col) + lane - (col & ~1)] = ab[t];
+        });
+        __syncthreads();
+      }
+      // corner (rows / columns n..n+3) = -[y Z]^T [y Z]: sums[0] = y^T y, [1..3] = Z^T y, [4..9] = Z^T Z (upper by rows)
+      {
+        auto corner = [&](int q, int qq) {  // q >= qq
+          const int col = n + qq;
+          return -sL[coff(col) + (n + q) - (col & ~1)];
+        };
+        sums[0] = corner(0, 0);
+        sums[1] = corner(1, 0);
+        sums[2] = corner(2, 0);
+        sums[3] = corner(3, 0);
+        sums[4] = corner(1, 1);
+        sums[5] = corner(2, 1);
+        sums[6] = corner(3, 1);
+        sums[7] = corner(2, 2);
+        sums[8] = corner(3, 2);
+        sums[9] = corner(3, 3);
+      }
+      OVP_STAMP(4);
+    } else {
+      double rh0 = res, rh1 = hf[0], rh2 = hf[1], rh3 = hf[2];
+      const int nblk = (n + 15) >> 4;
+      OVP_STAMP_ONLY(long long t_ll = 0, t_ib = 0;)
+#pragma nounroll
+      for (int jb = 0; jb < nblk; ++jb) {
+        const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);  // scalar: lane selects below must not waterfall
+        double ab[16];
+        static_for<16>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          const int col = j0 + t;
+          double v = (col == lane) ? 1.0 : 0.0;                       // identity padding for rows/columns >= n
+          if (valid && col < n && lane >= (col & ~1)) v = Bg[coff(col) + lane - (col & ~1)];
+          ab[t] = v;
+        });
+        OVP_STAMP_ONLY(long long tq0 = __builtin_readcyclecounter();)
+        // update with the finished columns k < j0
+        int ck = 0;  // coff(k) - (k & ~1), advanced incrementally: +64-k after an even column, +63-k after an odd one
+#pragma nounroll
+        for (int k = 0; k < j0; ck += 64 - k - (k & 1), ++k) {
+          double lik = sL[ck + lane];
+          if (lane < j0) lik = 0.0;  // rows of finished blocks are final (k < j0 <= lane also covers the upper triangle)
+          // L[j0 .. j0+15][k] and y_k: wave-uniform, 16-byte aligned (column starts are even) -> ds_read_b128 broadcasts
+          const double2_t* lj = reinterpret_cast<const double2_t*>(sL + ck + j0);
+          const double2_t* yk = reinterpret_cast<const double2_t*>(sY + 4 * k);
+          double2_t lv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) lv[q] = lj[q];
+          const double2_t y01 = yk[0], y23 = yk[1];
+          static_for<16>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            ab[t] = fma(-lik, lv[t >> 1][t & 1], ab[t]);
           });
+          const double lir = (lane < j0 + 16) ? lik : 0.0;  // right-hand sides: only the rows of this block
+          rh0 = fma(-lir, y01[0], rh0);
+          rh1 = fma(-lir, y01[1], rh1);
+          rh2 = fma(-lir, y23[0], rh2);
+          rh3 = fma(-lir, y23[1], rh3);
         }
-      });
-      OVP_STAMP_ONLY(t_ib += __builtin_readcyclecounter() - tq1;)
-      // publish the block's columns of L and the solved right-hand sides of its rows
-      static_for<16>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int col = j0 + t;
-        if (lane >= (col & ~1)) sL[coff(col) + lane - (col & ~1)] = ab[t];
-      });
-      if (lane >= j0 && lane < j0 + 16) {
-        sY[4 * lane + 0] = rh0;
-        sY[4 * lane + 1] = rh1;
-        sY[4 * lane + 2] = rh2;
-        sY[4 * lane + 3] = rh3;
+        OVP_STAMP_ONLY(long long tq1 = __builtin_readcyclecounter(); t_ll += tq1 - tq0;)
+        // factor the block: 16 right-looking steps inside the registers.  Column c of L is broadcast to the other rows
+        // through a small LDS buffer (one ds_write + a few 16-byte broadcast reads per step instead of 2 v_readlane per
+        // element); the next pivot is taken with a look-ahead so its rsq/Newton chain overlaps the LDS round trip.
+        double piv = readlane_f64(ab[0], j0);
+        double inv = rsqrt_nr(piv);
+        static_for<16>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          const int kg = j0 + c;  // global column, wave-uniform
+          spd = spd && (piv > 0.0);
+          const double inv_c = inv;
+          double l = ab[c] * inv_c;
+          if (lane < kg) l = 0.0;  // rows above the diagonal do not belong to column kg
+          ab[c] = l;
+          double* cb = sB + (c & 1) * NR;
+          cb[lane] = l;
+          if constexpr (c + 1 < 16) {
+            const double l1 = readlane_f64(l, kg + 1);
+            ab[c + 1] = fma(-l, l1, ab[c + 1]);
+            piv = readlane_f64(ab[c + 1], kg + 1);
+            inv = rsqrt_nr(piv);
+          }
+          const double x0 = readlane_f64(rh0, kg) * inv_c, x1 = readlane_f64(rh1, kg) * inv_c;
+          const double x2 = readlane_f64(rh2, kg) * inv_c, x3 = readlane_f64(rh3, kg) * inv_c;
+          if (lane > kg && lane < j0 + 16) {  // rows of later blocks receive this column through the left-looking pass
+            rh0 = fma(-l, x0, rh0);
+            rh1 = fma(-l, x1, rh1);
+            rh2 = fma(-l, x2, rh2);
+            rh3 = fma(-l, x3, rh3);
+          } else if (lane == kg) {
+            rh0 = x0;
+            rh1 = x1;
+            rh2 = x2;
+            rh3 = x3;
+          }
+          if constexpr (c + 2 < 16) {
+            // l_(j0+j), j = c+2..15, read as aligned pairs starting at the even index <= c+2
+            constexpr int e0 = (c + 2) & ~1;
+            const double2_t* cbv = reinterpret_cast<const double2_t*>(cb + j0 + e0);
+            double2_t lv[(16 - e0) / 2];
+#pragma unroll
+            for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = cbv[q];
+            static_for<14 - c>([&](auto jc) {
+              constexpr int j = c + 2 + decltype(jc)::value;
+              ab[j] = fma(-l, lv[(j - e0) >> 1][(j - e0) & 1], ab[j]);
+            });
+          }
+        });
+        OVP_STAMP_ONLY(t_ib += __builtin_readcyclecounter() - tq1;)
+        // publish the block's columns of L and the solved right-hand sides of its rows
+        static_for<16>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          const int col = j0 + t;
+          if (lane >= (col & ~1)) sL[coff(col) + lane - (col & ~1)] = ab[t];
+        });
+        if (lane >= j0 && lane < j0 + 16) {
+          sY[4 * lane + 0] = rh0;
+          sY[4 * lane + 1] = rh1;
+          sY[4 * lane + 2] = rh2;
+          sY[4 * lane + 3] = rh3;
+        }
+        __syncthreads();
       }
-      __syncthreads();
-    }
-    OVP_STAMP(4);
-    OVP_STAMP_ONLY(if (p.dbg_cycles && lane == 0) {
-      p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f] = t_ll;
-      p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f + 1] = t_ib;
-    })
-    yv = valid ? rh0 : 0.0;
-    zv[0] = valid ? rh1 : 0.0;
-    zv[1] = valid ? rh2 : 0.0;
-    zv[2] = valid ? rh3 : 0.0;
+      OVP_STAMP(4);
+      OVP_STAMP_ONLY(if (p.dbg_cycles && lane == 0) {
+        p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f] = t_ll;
+        p.dbg_cycles[(size_t)p.n_feats * 8 + 2 * f + 1] = t_ib;
+      })
+      yv = valid ? rh0 : 0.0;
+      zv[0] = valid ? rh1 : 0.0;
+      zv[1] = valid ? rh2 : 0.0;
+      zv[2] = valid ? rh3 : 0.0;
 
-    // ----------------------------------------------------------------------------------------
-    // Phase D: chi2 = y^T y - (Z^T y)^T (Z^T Z)^-1 (Z^T y)      UpdaterMSCKF.cpp:739-764
-    // ----------------------------------------------------------------------------------------
-    double sums[10];
-    {
-      double v[16];
-      v[0] = yv * yv;
-      v[1] = zv[0] * yv;
-      v[2] = zv[1] * yv;
-      v[3] = zv[2] * yv;
-      v[4] = zv[0] * zv[0];
-      v[5] = zv[0] * zv[1];
-      v[6] = zv[0] * zv[2];
-      v[7] = zv[1] * zv[1];
-      v[8] = zv[1] * zv[2];
-      v[9] = zv[2] * zv[2];
+      // ----------------------------------------------------------------------------------------
+      // Phase D: chi2 = y^T y - (Z^T y)^T (Z^T Z)^-1 (Z^T y)      UpdaterMSCKF.cpp:739-764
+      // ----------------------------------------------------------------------------------------
+      {
+        double v[16];
+        v[0] = yv * yv;
+        v[1] = zv[0] * yv;
+        v[2] = zv[1] * yv;
+        v[3] = zv[2] * yv;
+        v[4] = zv[0] * zv[0];
+        v[5] = zv[0] * zv[1];
+        v[6] = zv[0] * zv[2];
+        v[7] = zv[1] * zv[1];
+        v[8] = zv[1] * zv[2];
+        v[9] = zv[2] * zv[2];
 #pragma unroll
-      for (int k = 10; k < 16; ++k) v[k] = 0.0;
-      const double rsum = wave_transpose_reduce<16>(v);
+        for (int k = 10; k < 16; ++k) v[k] = 0.0;
+        const double rsum = wave_transpose_reduce<16>(v);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) sums[k] = readlane_f64(rsum, reduce_owner_lane<16>(k));
+        for (int k = 0; k < 10; ++k) sums[k] = readlane_f64(rsum, reduce_owner_lane<16>(k));
+      }
     }
     {
       const double l00 = sqrt(sums[4]);
@@ -502,6 +642,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream) {
   if (p->n_feats <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ovp::k_feat_gate, dim3(p->n_feats), dim3(64), 0, stream, *p);
+  if (p->max_meas <= 30 && !getenv("OVP_K1_LEGACY"))
+    hipLaunchKernelGGL(ovp::k_feat_gate<true>, dim3(p->n_feats), dim3(64), 0, stream, *p);
+  else
+    hipLaunchKernelGGL(ovp::k_feat_gate<false>, dim3(p->n_feats), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
