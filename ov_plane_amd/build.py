@@ -23,7 +23,8 @@ def build_lib(force=False, verbose=False):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I" + os.path.join(_HERE, "..", "include")] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+           "-I" + os.path.join(_HERE, "..", "include")] + os.environ.get("OVP_EXTRA_HIPCC_FLAGS", "").split() + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

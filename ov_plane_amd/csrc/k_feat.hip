@@ -192,10 +192,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       auto fetch = [&](double (&dst)[18], int b) {
         const int idb = __builtin_amdgcn_readlane(ida, 2 * b);  // lane 2b holds clone_id of observation b
         const double* src = P + (idb * ldp + rowoff);
+        // only the rows of the lower triangle (lane >= 2b) use the block: phase B is bound by the 64 B/clk of the vector
+        // memory path (9 KB of 6x6 blocks per wave and observation), inactive lanes cost nothing there
+        if (lane >= 2 * b && valid) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+          for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int l = 0; l < 6; ++l) dst[6 * k + l] = src[k * ldp + l];
+            for (int l = 0; l < 6; ++l) dst[6 * k + l] = src[k * ldp + l];
+        }
       };
       auto column_pair = [&](const double (&pc)[18], double (&pn)[18], int b) {
         if (b + 1 < m) fetch(pn, b + 1);
