@@ -195,7 +195,9 @@ int ovp_ekf_update(ovp_ctx *ctx, const double *H_host, int rows, int cols, int l
 int ovp_cov_propagate(ovp_ctx *ctx, int new_start, int phi_size, const int *old_ids, const int *old_sizes, int n_old,
                       const double *Phi_host, const double *Q_host, int *neg_diag);
 
-/* StateHelper::clone (state/StateHelper.cpp:346-396): appends a copy of [src_id, src_id+size) at the end. */
+/* StateHelper::clone (state/StateHelper.cpp:346-396): appends a copy of [src_id, src_id+size) at the end.  The diagonal of
+ * the new block is stored 1e-11 (relative) above the copied value: an exact copy leaves P singular, and the update path
+ * factors P.  A covariance handed to ovp_cov_upload / ovp_cov_set_device must be positive definite. */
 int ovp_cov_clone(ovp_ctx *ctx, int src_id, int size);
 /* StateHelper::marginalize (state/StateHelper.cpp:276-344): removes rows/cols [id, id+size). */
 int ovp_cov_marginalize(ovp_ctx *ctx, int id, int size);

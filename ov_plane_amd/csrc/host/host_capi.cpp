@@ -585,3 +585,133 @@ extern "C" int ovph_run_plane_givens(int op /* 0 nullspace, 1 compress */, int r
   for (int i = 0; i < ro; ++i) res[i] = r(i);
   return ro;
 }
+
+// Closed loop over several camera frames with the reference's own call order (core/VioManager.cpp:348 propagate_and_clone,
+// :670 UpdaterMSCKF::update, :864-866 marginalize_old_clone): state with C clones, IMU state, covariance P (N = 30 + 6 C).
+// Frame k: propagate + clone to frame_time[k], update with that frame's features (slots index the C+1 clones of the window,
+// oldest first; positions given), marginalize the oldest clone.  Outputs the final filter state and covariance.
+extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
+                                 const double *clone_p_fej, const double *calib_q, const double *calib_p, const double *intr,
+                                 const double *imu_x16, const double *imu_x16_fej, double calib_dt, int N, const double *P,
+                                 int n_imu, const double *imu, double t_state, const double *sigmas4, double gravity_mag,
+                                 int use_rk4, int do_fej, int K, const double *frame_time, const int *feat_offset /* [K+1] */,
+                                 int M, const float *uv, const int *clone_slot, const int *n_meas, const double *p_FinG,
+                                 double sigma_px, double chi2_mult,
+                                 /* outputs */ double *out_clone_q, double *out_clone_p, double *out_x16, double *out_calib_q,
+                                 double *out_calib_p, double *out_intr, double *out_dt, double *out_P, int *n_kept_per_frame) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.use_rk4_integration = use_rk4 != 0;
+  so.max_state_size = N + 16;
+  so.max_features = 4096;
+  auto state = std::make_shared<State>(so);
+  {
+    VectorXd v(7, 1);
+    for (int k = 0; k < 4; ++k) v(k) = calib_q[k];
+    for (int k = 0; k < 3; ++k) v(4 + k) = calib_p[k];
+    state->_calib_IMUtoCAM.at(0)->set_value(v);
+    state->_calib_IMUtoCAM.at(0)->set_fej(v);
+    VectorXd iv(8, 1);
+    for (int k = 0; k < 8; ++k) iv(k) = intr[k];
+    state->_cam_intrinsics.at(0)->set_value(iv);
+    state->_cam_intrinsics.at(0)->set_fej(iv);
+  }
+  const double w0[3] = {0, 0, 0};
+  for (int i = 0; i < C; ++i) {
+    VectorXd a(7, 1), af(7, 1);
+    for (int k = 0; k < 4; ++k) {
+      a(k) = clone_q[4 * i + k];
+      af(k) = clone_q_fej[4 * i + k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      a(4 + k) = clone_p[3 * i + k];
+      af(4 + k) = clone_p_fej[3 * i + k];
+    }
+    state->_imu->pose()->set_value(a);
+    state->_imu->pose()->set_fej(af);
+    state->_timestamp = t_state - 0.1 * (C - i);
+    StateHelper::augment_clone(state, w0);
+  }
+  if (state->max_covariance_size() != N) return -11;
+  VectorXd x(16, 1), xf(16, 1), dtv(1, 1);
+  for (int k = 0; k < 16; ++k) {
+    x(k) = imu_x16[k];
+    xf(k) = imu_x16_fej[k];
+  }
+  state->_imu->set_value(x);
+  state->_imu->set_fej(xf);
+  dtv(0) = calib_dt;
+  state->_calib_dt_CAMtoIMU->set_value(dtv);
+  state->_calib_dt_CAMtoIMU->set_fej(dtv);
+  state->_timestamp = t_state;
+  {
+    std::vector<std::shared_ptr<Type>> all;
+    all.push_back(state->_imu);
+    all.push_back(state->_calib_dt_CAMtoIMU);
+    all.push_back(state->_calib_IMUtoCAM.at(0));
+    all.push_back(state->_cam_intrinsics.at(0));
+    for (auto &c : state->_clones_IMU) all.push_back(c.second);
+    MatrixXd Pm(N, N);
+    memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+    StateHelper::set_initial_covariance(state, Pm, all);
+  }
+  NoiseManager nm;
+  nm.sigma_w = sigmas4[0];
+  nm.sigma_a = sigmas4[1];
+  nm.sigma_wb = sigmas4[2];
+  nm.sigma_ab = sigmas4[3];
+  Propagator prop(nm, gravity_mag);
+  for (int i = 0; i < n_imu; ++i) {
+    ov_core::ImuData d;
+    d.timestamp = imu[7 * i];
+    for (int k = 0; k < 3; ++k) {
+      d.wm[k] = imu[7 * i + 1 + k];
+      d.am[k] = imu[7 * i + 4 + k];
+    }
+    prop.feed_imu(d);
+  }
+  UpdaterOptions uo;
+  uo.sigma_pix = sigma_px;
+  uo.chi2_multipler = chi2_mult;
+  ov_core::FeatureInitializerOptions fio;
+  UpdaterMSCKF updater(uo, fio);
+  std::map<size_t, size_t> feat2plane;
+  for (int k = 0; k < K; ++k) {
+    prop.propagate_and_clone(state, frame_time[k]);  // VioManager.cpp:348
+    std::vector<double> times;
+    for (auto &c : state->_clones_IMU) times.push_back(c.first);
+    std::vector<std::shared_ptr<ov_core::Feature>> fv, fextra, fused;
+    for (int f = feat_offset[k]; f < feat_offset[k + 1]; ++f) {
+      auto ft = std::make_shared<ov_core::Feature>();
+      ft->featid = 1000 + f;
+      for (int q = 0; q < n_meas[f]; ++q) {
+        ft->timestamps.push_back(times.at(clone_slot[(size_t)f * M + q]));
+        ft->uvs.push_back(uv[((size_t)f * M + q) * 2]);
+        ft->uvs.push_back(uv[((size_t)f * M + q) * 2 + 1]);
+      }
+      memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+      fv.push_back(ft);
+    }
+    updater.update(state, fv, fextra, fused, feat2plane);  // VioManager.cpp:670
+    n_kept_per_frame[k] = (int)fv.size();
+    StateHelper::marginalize_old_clone(state);  // VioManager.cpp:864-866
+  }
+  int i = 0;
+  for (auto &c : state->_clones_IMU) {
+    memcpy(out_clone_q + 4 * i, c.second->quat(), 4 * sizeof(double));
+    memcpy(out_clone_p + 3 * i, c.second->pos(), 3 * sizeof(double));
+    ++i;
+  }
+  if (i != C) return -13;
+  memcpy(out_x16, state->_imu->value().data(), 16 * sizeof(double));
+  memcpy(out_calib_q, state->_calib_IMUtoCAM.at(0)->quat(), 4 * sizeof(double));
+  memcpy(out_calib_p, state->_calib_IMUtoCAM.at(0)->pos(), 3 * sizeof(double));
+  memcpy(out_intr, state->_cam_intrinsics.at(0)->value().data(), 8 * sizeof(double));
+  *out_dt = state->_calib_dt_CAMtoIMU->value()(0);
+  if (state->max_covariance_size() != N) return -12;
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)N * N);
+  return 0;
+}

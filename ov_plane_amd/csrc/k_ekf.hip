@@ -189,7 +189,13 @@ __global__ void k_cov_clone(double* __restrict__ P, int ldp, int n_old, int src,
     P[(size_t)r * ldp + n_old + k] = P[(size_t)r * ldp + src + k];
     P[(size_t)(n_old + k) * ldp + r] = P[(size_t)(src + k) * ldp + r];
   } else {
-    P[(size_t)r * ldp + n_old + k] = P[(size_t)(src + (r - n_old)) * ldp + src + k];
+    double v = P[(size_t)(src + (r - n_old)) * ldp + src + k];
+    // The clone is an exact copy, so P is only positive SEMI-definite from here until a propagation puts process noise on
+    // the source - but every update of this path factors P (P+ = L (I + L^T A L)^-1 L^T, L L^T = P).  The diagonal of the
+    // new block is therefore stored as (1 + 1e-11) x the copied value: the zero-variance directions get a pivot four orders
+    // of magnitude above the rounding noise of the Schur complement, seven orders below the tolerance of the path (1e-4).
+    if (r - n_old == k) v *= (1.0 + OVP_CLONE_JITTER);
+    P[(size_t)r * ldp + n_old + k] = v;
   }
 }
 

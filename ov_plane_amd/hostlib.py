@@ -227,3 +227,57 @@ def run_plane_givens(op, H_f, H_x, H_cp, res):
     ro = L.ovph_run_plane_givens(C.c_int(op), C.c_int(rows), C.c_int(0 if H_f is None else H_f.shape[1]), p(Hf), C.c_int(cols),
                                  p(Hx), C.c_int(0 if H_cp is None else H_cp.shape[1]), p(Hc), p(r))
     return Hx[:ro].copy(), (Hc[:ro].copy() if H_cp is not None else None), r[:ro].copy()
+
+
+def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0):
+    """Closed loop over several frames through the C++ host mirror (Propagator::propagate_and_clone ->
+    UpdaterMSCKF::update -> StateHelper::marginalize_old_clone per frame).
+
+    init: dict(C, N, clone_q, clone_p, clone_q_fej, clone_p_fej, calib_q, calib_p, intr, x (IMU dict), dt, P, t_state)
+    frames: list of dict(uv [F,M,2] f32, slot [F,M] int32 (index into the C+1 clones of the window), n_meas [F], p_FinG [F,3])
+    """
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    Cn, N = int(init["C"]), int(init["N"])
+    x = init["x"]
+    x16 = f64(np.concatenate([x["q"], x["p"], x["v"], x["bg"], x["ba"]]))
+    x16f = f64(np.concatenate([x["q_fej"], x["p_fej"], x["v_fej"], x["bg_fej"], x["ba_fej"]]))
+    M = max(int(fr["uv"].shape[1]) for fr in frames)
+    offs = np.zeros(len(frames) + 1, dtype=np.int32)
+    uv_l, slot_l, nm_l, pf_l = [], [], [], []
+    for k, fr in enumerate(frames):
+        F = int(fr["uv"].shape[0])
+        offs[k + 1] = offs[k] + F
+        uvp = np.zeros((F, M, 2), dtype=np.float32)
+        uvp[:, : fr["uv"].shape[1]] = fr["uv"]
+        sl = -np.ones((F, M), dtype=np.int32)
+        sl[:, : fr["slot"].shape[1]] = fr["slot"]
+        uv_l.append(uvp)
+        slot_l.append(sl)
+        nm_l.append(np.asarray(fr["n_meas"], dtype=np.int32))
+        pf_l.append(np.asarray(fr["p_FinG"], dtype=np.float64))
+    uv = np.ascontiguousarray(np.concatenate(uv_l), dtype=np.float32)
+    slot = np.ascontiguousarray(np.concatenate(slot_l), dtype=np.int32)
+    nm = np.ascontiguousarray(np.concatenate(nm_l), dtype=np.int32)
+    pf = f64(np.concatenate(pf_l))
+    P = np.asfortranarray(init["P"])
+    imu = f64(imu)
+    ft = f64(frame_time)
+    sig = f64([po["sigma_w"], po["sigma_a"], po["sigma_wb"], po["sigma_ab"]])
+    cq, cp_, cqf, cpf = f64(init["clone_q"]), f64(init["clone_p"]), f64(init["clone_q_fej"]), f64(init["clone_p_fej"])
+    calq, calp, intr = f64(init["calib_q"]), f64(init["calib_p"]), f64(init["intr"])
+    out = dict(clone_q=np.zeros((Cn, 4)), clone_p=np.zeros((Cn, 3)), x16=np.zeros(16), calib_q=np.zeros(4), calib_p=np.zeros(3),
+               intr=np.zeros(8), dt=np.zeros(1), P=np.zeros((N, N)), kept=np.zeros(len(frames), dtype=np.int32))
+    L.ovph_run_sequence.restype = C.c_int
+    rc = L.ovph_run_sequence(
+        C.c_int(Cn), p(cq), p(cp_), p(cqf), p(cpf), p(calq), p(calp), p(intr), p(x16), p(x16f), C.c_double(init["dt"]),
+        C.c_int(N), p(P), C.c_int(imu.shape[0]), p(imu), C.c_double(init["t_state"]), p(sig), C.c_double(po["gravity_mag"]),
+        C.c_int(int(po["use_rk4"])), C.c_int(int(po["do_fej"])), C.c_int(len(frames)), p(ft), p(offs), C.c_int(M), p(uv),
+        p(slot), p(nm), p(pf), C.c_double(sigma_px), C.c_double(chi2_mult), p(out["clone_q"]), p(out["clone_p"]), p(out["x16"]),
+        p(out["calib_q"]), p(out["calib_p"]), p(out["intr"]), p(out["dt"]), p(out["P"]), p(out["kept"]))
+    if rc != 0:
+        raise RuntimeError("ovph_run_sequence failed with %d" % rc)
+    out["P"] = np.ascontiguousarray(out["P"].T)
+    out["dt"] = float(out["dt"][0])
+    return out

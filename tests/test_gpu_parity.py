@@ -180,7 +180,9 @@ def test_covariance_bookkeeping(hiplib):
     Pc = ctx.cov_download()
     assert Pc.shape == (N + 6, N + 6)
     assert np.abs(Pc[:N, :N] - Pref).max() == 0.0
-    assert np.abs(Pc[N:, N:] - Pref[:6, :6]).max() == 0.0
+    blk = Pref[:6, :6].copy()
+    blk[np.diag_indices(6)] *= (1.0 + 1e-11)   # the clone's own diagonal carries the documented 1e-11 inflation
+    assert np.abs(Pc[N:, N:] - blk).max() <= 1e-16 * np.abs(blk).max()
     assert np.abs(Pc[:N, N:] - Pref[:, :6]).max() == 0.0 and np.abs(Pc[N:, :N] - Pref[:6, :]).max() == 0.0
     # marginal covariance gather
     ids = [int(sc.ids["clones"][2]), 16]
@@ -715,3 +717,113 @@ def test_host_cpp_mirror_updater_msckf_triangulates_first(hiplib, oracle):
         cp[i] = cp[i] + dx[cid + 3:cid + 6]
     assert np.abs(out["clone_p"] - cp).max() < TOL_DX and np.abs(out["clone_q"] - cq).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
+
+
+def test_closed_loop_over_frames_matches_oracle(hiplib, oracle):
+    """Four camera frames in the reference's call order (core/VioManager.cpp:348 propagate_and_clone, :670 UpdaterMSCKF::update,
+    :864-866 marginalize_old_clone) through the C++ host mirror with the covariance resident on the device, against the
+    same loop composed from the oracle pieces: ids shift after every marginalization, the new clone carries the time-offset
+    Jacobian, IMU / dt / calibration / intrinsics receive every update."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import (PROP_OPTS, Scene, make_imu_scenario, project_all, quat_2_rot, quat_boxplus,
+                                    state_layout)
+    from oracle import np_ref
+
+    Cn, K, dtc, t_off = 6, 4, 0.1, 0.004
+    sc0 = make_scene(C=Cn, F=4, seed=71)
+    rng = np.random.default_rng(5)
+    x, _, _, _ = make_imu_scenario(9, t_state=100.0, dt_cam=dtc, t_off=t_off)
+    x = dict(x)
+    x["q"], x["p"] = sc0.clone_q[-1].copy(), sc0.clone_p[-1].copy()      # the IMU sits at the newest clone
+    x["q_fej"], x["p_fej"] = x["q"].copy(), x["p"].copy()
+    x["v"] = np.array([0.3, 0.6, 0.0])
+    x["v_fej"] = x["v"].copy()
+    # one IMU stream for all frames (smooth body rates, specific force ~ gravity in the initial attitude)
+    ts = 100.0 + t_off - 0.0113 + np.arange(0, int((K * dtc + 0.04) * 400)) / 400.0
+    imu = np.zeros((len(ts), 7))
+    imu[:, 0] = ts
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    for a in range(3):
+        imu[:, 1 + a] = 0.2 * np.sin(2 * np.pi * 0.5 * (ts - ts[0]) + ph[a])
+        imu[:, 4 + a] = 0.3 * np.sin(2 * np.pi * 0.8 * (ts - ts[0]) + ph[3 + a])
+    imu[:, 4:7] += quat_2_rot(x["q"]) @ np.array([0, 0, 9.81])
+    po = dict(PROP_OPTS, use_rk4=1, do_fej=1, imu_avg=0)
+    frame_time = 100.0 + dtc * np.arange(1, K + 1)
+    init = dict(C=Cn, N=sc0.N, clone_q=sc0.clone_q, clone_p=sc0.clone_p, clone_q_fej=sc0.clone_q_fej,
+                clone_p_fej=sc0.clone_p_fej, calib_q=sc0.calib_q, calib_p=sc0.calib_p, intr=sc0.intr, x=x, dt=t_off, P=sc0.P,
+                t_state=100.0)
+
+    # ---- oracle loop (also generates the measurements of every frame from the state it has reached) ----
+    cq, cp = sc0.clone_q.copy(), sc0.clone_p.copy()
+    cqf, cpf = sc0.clone_q_fej.copy(), sc0.clone_p_fej.copy()
+    calq, calp, intr, dt_est, P = sc0.calib_q.copy(), sc0.calib_p.copy(), sc0.intr.copy(), t_off, sc0.P.copy()
+    xs = {k: np.array(v, dtype=np.float64) for k, v in x.items()}
+    last_off, t_state, frames = t_off, 100.0, []
+    N = sc0.N
+    for k in range(K):
+        pr = oracle.propagate_summed(xs, po, imu, t_state + last_off, frame_time[k] + dt_est)
+        xs = pr["x"]
+        P = np_ref.ekf_propagation(P, 0, 15, [(0, 15)], pr["Phi"], pr["Q"])
+        Pc = np.zeros((N + 6, N + 6))
+        Pc[:N, :N] = P
+        Pc[N:, :N] = P[:6, :]
+        Pc[:N, N:] = P[:, :6]
+        Pc[N:, N:] = P[:6, :6]
+        dnc = np.concatenate([pr["last_w"], xs["v"]])
+        col = Pc[:, 15].copy()
+        Pc[:, N:] += np.outer(col, dnc)
+        row = Pc[15, :].copy()
+        Pc[N:, :] += np.outer(dnc, row)
+        cq, cp = np.vstack([cq, xs["q"]]), np.vstack([cp, xs["p"]])
+        cqf, cpf = np.vstack([cqf, xs["q"]]), np.vstack([cpf, xs["p"]])
+        last_off, t_state = dt_est, frame_time[k]
+        # measurements of this frame: points in front of the middle camera of the window, seen by >= 3 consecutive clones
+        Cw, F = Cn + 1, 40
+        Rw = np.array([quat_2_rot(q) for q in cq])
+        R_ItoC = quat_2_rot(calq)
+        mid = Cw // 2
+        Rc_mid = R_ItoC @ Rw[mid]
+        pc_mid = cp[mid] - Rc_mid.T @ calp
+        pts_c = np.stack([rng.uniform(-1.0, 1.0, F), rng.uniform(-0.6, 0.6, F), rng.uniform(2.5, 5.0, F)], axis=1)
+        pts = (Rc_mid.T @ pts_c.T).T + pc_mid
+        uv_all, z = project_all(pts, Rw, cp, R_ItoC, calp, intr)
+        assert (z > 0.5).all()
+        nm = rng.integers(3, Cw + 1, size=F).astype(np.int32)
+        st = np.array([rng.integers(0, Cw - m + 1) for m in nm])
+        uv = np.zeros((F, Cw, 2), dtype=np.float32)
+        slot = -np.ones((F, Cw), dtype=np.int32)
+        for f in range(F):
+            slot[f, :nm[f]] = np.arange(st[f], st[f] + nm[f])
+            uv[f, :nm[f]] = (uv_all[f, st[f]:st[f] + nm[f]] + rng.standard_normal((nm[f], 2))).astype(np.float32)
+        pf = pts + 0.02 * rng.standard_normal(pts.shape)
+        frames.append(dict(uv=uv, slot=slot, n_meas=nm, p_FinG=pf))
+        sck = Scene(C=Cw, F=F, N=N + 6, ids=state_layout(Cw), clone_q=cq, clone_p=cp, clone_q_fej=cqf, clone_p_fej=cpf,
+                    calib_q=calq, calib_p=calp, intr=intr, P=Pc, uv=uv, clone_idx=slot, n_meas=nm, p_FinG=pf,
+                    opts=dict(sigma_px=1.0, sigma_c=0.05, chi2_mult=1.0, do_fej=True, do_calib_pose=True, do_calib_intr=True))
+        up = oracle.msckf_point_update(sck)
+        dx = up["dx"]
+        new = np_ref.apply_dx(sck, dx)
+        cq, cp, calq, calp, intr = new["clone_q"], new["clone_p"], new["calib_q"], new["calib_p"], new["intr"]
+        xs = dict(xs)
+        xs["q"] = quat_boxplus(xs["q"], dx[0:3])
+        xs["p"], xs["v"] = xs["p"] + dx[3:6], xs["v"] + dx[6:9]
+        xs["bg"], xs["ba"] = xs["bg"] + dx[9:12], xs["ba"] + dx[12:15]
+        dt_est = dt_est + dx[15]
+        # marginalize the oldest clone
+        keep = np.ones(N + 6, dtype=bool)
+        keep[30:36] = False
+        P = up["P"][np.ix_(keep, keep)]
+        cq, cp, cqf, cpf = cq[1:], cp[1:], cqf[1:], cpf[1:]
+        frames[-1]["n_acc"] = int(up["accepted"].sum())
+
+    out = hostlib.run_sequence(init, imu, frame_time, frames, po)
+    assert out["kept"].tolist() == [fr["n_acc"] for fr in frames] and min(out["kept"]) > 20
+    x16 = np.concatenate([xs["q"], xs["p"], xs["v"], xs["bg"], xs["ba"]])
+    assert np.abs(out["x16"] - x16).max() < TOL_DX
+    assert np.abs(out["clone_p"] - cp).max() < TOL_DX and np.abs(out["clone_q"] - cq).max() < TOL_DX
+    assert np.abs(out["calib_p"] - calp).max() < TOL_DX and np.abs(out["intr"] - intr).max() < TOL_DX
+    assert abs(out["dt"] - dt_est) < TOL_DX
+    assert relP(out["P"], P) < TOL_P
