@@ -827,3 +827,52 @@ def test_closed_loop_over_frames_matches_oracle(hiplib, oracle):
     assert np.abs(out["calib_p"] - calp).max() < TOL_DX and np.abs(out["intr"] - intr).max() < TOL_DX
     assert abs(out["dt"] - dt_est) < TOL_DX
     assert relP(out["P"], P) < TOL_P
+
+
+def _golden_mod():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg
+
+
+def test_widened_rows_match_committed_golden_vectors(hiplib):
+    """Device results against the committed restatement outputs (tests/golden/wide_*.npz) without the oracle in the loop:
+    triangulation, the plane loop and the plane initialisation."""
+    mg = _golden_mod()
+    # triangulation
+    sc = make_scene(**mg.WIDE["triangulate"])
+    g = np.load(os.path.join(GOLD, "wide_triangulate.npz"))
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.triangulate(sc.uv_norm)
+    assert (out["ok"] == g["ok"]).all()
+    assert np.abs(out["p_FinG"][g["ok"]] - g["p_FinG"][g["ok"]]).max() < 1e-11
+    ctx.close()
+    # plane loop
+    sc = make_scene(**mg.WIDE["plane_loop"])
+    g = np.load(os.path.join(GOLD, "wide_plane_loop.npz"))
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert (out["ok"] == g["plane_ok"]).all() and (out["used"] == g["used"]).all()
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - g["clone_p"]).max() < TOL_DX and np.abs(cq - g["clone_q"]).max() < TOL_DX
+    assert np.abs(cp - g["cp"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), g["P"]) < TOL_P
+    ctx.close()
+    # plane initialisation
+    sc = make_scene(**mg.WIDE["plane_init"])
+    g = np.load(os.path.join(GOLD, "wide_plane_init.npz"))
+    ctx = hiplib.Context(sc.N + 3 * sc.cp.shape[0], sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_init(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, 5.0, 1.0)
+    assert (out["ok"] == g["plane_ok"]).all() and (out["new_ids"] == g["new_id"]).all() and (out["used"] == g["used"]).all()
+    assert relP(ctx.cov_download(), g["P"]) < TOL_P
+    ctx.close()

@@ -170,6 +170,27 @@ def test_oracle_reproduces_committed_fixtures(oracle):
         assert np.abs(r["P"] - g["P"]).max() < 1e-13
 
 
+def test_oracle_reproduces_committed_fixtures_of_the_widened_rows(oracle):
+    """Plane loop, plane initialisation, SLAM update / delayed initialisation, Propagator and triangulation: the oracle
+    must keep reproducing the committed restatement outputs (guards the checker itself against silent edits)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    for name in mg.WIDE_NAMES:
+        got = mg.wide_outputs(name)
+        g = np.load(os.path.join(GOLD, "wide_%s.npz" % name))
+        assert set(g.files) == set(got), name
+        for k in g.files:
+            a, b = np.asarray(got[k]), g[k]
+            assert a.shape == b.shape, (name, k)
+            if a.dtype == bool or np.issubdtype(a.dtype, np.integer):
+                assert (a == b).all(), (name, k)
+            else:
+                assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), (name, k)
+
+
 def test_propagation_restatement_is_consistent():
     rng = np.random.default_rng(8)
     n = 20
