@@ -142,23 +142,24 @@ def main():
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this
         # process); only quoted when the workload is the one the passes were taken on
         traffic, traffic_note = None, None
-        tp = os.path.join(_ROOT, "profiles", "r01_f_hbm_traffic_pmc.json")
+        tp = os.path.join(_ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")
         if os.path.exists(tp) and (C, F, world) == (30, 2000, 1):
             with open(tp) as fh:
                 kern = json.load(fh)["kernels"]
-            k1 = [v for k, v in kern.items() if "k_feat_gate" in k]
+            k1 = [v for k, v in kern.items() if "k_feat_chol" in k or "k_feat_gate" in k]
             if k1:
                 # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies wide coalesced reads at half their bytes -> x2 as the
                 # upper bound; WRITE_SIZE taken as reported
                 traffic = (2.0 * k1[0]["FETCH_SIZE_KB_avg_per_launch"] + k1[0]["WRITE_SIZE_KB_avg_per_launch"]) * 1024.0
-                traffic_note = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_f_hbm_traffic_pmc.json "
+                traffic_note = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_g_hbm_traffic_pmc.json "
                                 "(separate --pmc passes); mostly the materialised B scratch (34 MB), sparse rows (23 MB) "
                                 "and projector rows (10 MB) written for K2 - 1 TB/s, not the bound")
         roofline = {
             "bound": "mfma",
-            "kernel": "k_feat_gate (per-feature build + nullspace projection + chi2 gate), f64 vector ALU",
+            "kernel": "k_feat_chol (per-feature build + nullspace projection + chi2 gate on 255 CUs; chol(P) rides on the 256th), f64 vector ALU",
             "achieved": alg / k_s / 1e12,
             "peak": F64_PEAK_TFLOPS,
+            "peak_measured": 59.5,  # v_fma_f64 microbenchmark on this part (scratch/fma64.hip); f64 MFMA: 35-47
             "unit": "TFLOP/s",
             "frac": alg / k_s / 1e12 / F64_PEAK_TFLOPS,
             "traffic": traffic,
@@ -191,7 +192,7 @@ def main():
                        "clones": C, "feats_per_gpu": F, "state_dim": int(sc.N),
                        "accepted": int(out["accepted"].sum()), "parallelism": "feature-shard x%d" % world},
             "stage_ms": {"k1_build_project_gate": float(stage_ms[0]),
-                         "cholP_beside_gram_then_ekf": float(stage_ms[2]), "gpu_total": float(stage_ms[3])},
+                         "gram_then_ekf": float(stage_ms[2]), "gpu_total": float(stage_ms[3])},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -13,6 +13,7 @@
 // information pair is  Hp^T Hp = H_x^T H_x - G^T G,  Hp^T rp = H_x^T r - G^T g  with  G = Q1^T H_x, g = Q1^T r,
 // Q1 an orthonormal basis of range(H_f).  The kernel emits the sparse rows (rec) and G|g; K2 reduces them.
 #include "ovp_feat_model.h"
+#include "k_tile_body.h"
 #include <utility>
 #include <cstdlib>
 
@@ -73,17 +74,22 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // without the border keeps the all-VALU path for 31 / 32 observations.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Synchronisation inside one feature wave: LDS traffic of a wave is in order, so only the compiler (and the outstanding-
+// counter waits of the fences) have to be told.  A real s_barrier would couple the eight independent feature waves of a
+// fused workgroup.
+#define OVP_WSYNC()                                          \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+  } while (0)
+
+// The work of one wave on feature f; smem = this wave's 20480 bytes of LDS.
 template <bool BORDERED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_gate(const FeatParams p) {
-  // the feature waves outrank the (latency-bound, one-workgroup) chol(P) that runs beside them on the side stream: on the
-  // SIMDs both share, an equal-priority Cholesky wave stretches the slowest feature block - and the kernel - by 40 %
-  __builtin_amdgcn_s_setprio(3);
-  const int f = blockIdx.x;
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void feat_body(const FeatParams& p, const int f, const int lane, double* const smem) {
   const int m = p.n_meas[f];
   const int n = 2 * m;
 
-  __shared__ __attribute__((aligned(16))) double smem[2560];
   double* const sJ = smem;                 // [64][6]
   double* const sC = smem + NR * 6;        // [64][14]
   double* const sE = sC + NR * 14;         // [64][14]   (ends at 2176)
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           e[kk + 7] = r ? ea : eb;
         }
       }
-      __syncthreads();
+      OVP_WSYNC();
       // u = e + c P_cc, one row of P_cc (7 x ds_read_b128 broadcasts) at a time; the scheduling barrier keeps the
       // compiler from hoisting all 98 reads (392 VGPRs) in front of the FMAs
 #pragma unroll
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         sE[lane * 14 + k] = e[k];
       }
     }
-    __syncthreads();
+    OVP_WSYNC();
     OVP_STAMP(2);
 
     // ----------------------------------------------------------------------------------------
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       }
     }
-    __syncthreads();
+    OVP_WSYNC();
     OVP_STAMP(3);
 
     // ----------------------------------------------------------------------------------------
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           const int col = j0 + t;
           if (lane >= (col & ~1)) sL[coff(col) + lane - (col & ~1)] = ab[t];
         });
-        __syncthreads();
+        OVP_WSYNC();
       }
       // corner (rows / columns n..n+3) = -[y Z]^T [y Z]: sums[0] = y^T y, [1..3] = Z^T y, [4..9] = Z^T Z (upper by rows)
       {
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           sY[4 * lane + 2] = rh2;
           sY[4 * lane + 3] = rh3;
         }
-        __syncthreads();
+        OVP_WSYNC();
       }
       OVP_STAMP(4);
       OVP_STAMP_ONLY(if (p.dbg_cycles && lane == 0) {
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double thr = p.chi2_mult * p.chi2_table[dof < OVP_CHI2_TABLE ? dof : OVP_CHI2_TABLE];
     accept = spd && (chi2 <= thr);  // NaN (rank-deficient H_f) rejects
   }
-  __syncthreads();
+  OVP_WSYNC();
   OVP_STAMP(5);
 
   // ------------------------------------------------------------------------------------------
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int ldg = p.ldg;
   double* Gst = sL;  // 3 * ldg doubles (ldg <= OVP_LDG_CAP = LCOLS / 3); the factor is no longer needed
   for (int idx = lane; idx < 3 * ldg; idx += 64) Gst[idx] = 0.0;
-  __syncthreads();
+  OVP_WSYNC();
   if (accept) {
     double q[3] = {hf[0], hf[1], hf[2]};
 #pragma unroll
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (valid && r == 0) Gst[t * ldg + ida + l] = v;
       }
   }
-  __syncthreads();
+  OVP_WSYNC();
   OVP_STAMP(6);
   {
     double* gout = p.G + (size_t)3 * f * ldg;
@@ -642,6 +648,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+template <bool BORDERED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_gate(const FeatParams p) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) double smem[2560];
+  feat_body<BORDERED>(p, blockIdx.x, threadIdx.x, smem);
+}
+
+// Fused launch: workgroup 0 factorizes P (chol(P) does not depend on the measurements, but its eight latency-bound waves
+// must not share SIMDs with feature waves: beside a one-wave-per-block K1 they stretch the slowest feature block - and the
+// kernel - by 40 %; CU masks are kept symmetric per shader engine by the driver, so a side stream cannot be pinned to one
+// CU either).  Every workgroup asks for all 160 KB of LDS, hence owns a CU: workgroup 0 has one to itself, the others run
+// eight feature waves (two per SIMD, 20 KB of LDS each) exactly as the one-wave blocks did.  Feature f is handled by wave
+// f / nwg of workgroup 1 + f % nwg, so small batches spread one wave per SIMD before they double up.
+template <int MAXSLOT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_chol(const FeatParams p,
+                                                                                             const CholJob c) {
+  __shared__ __attribute__((aligned(16))) double smem[8 * 2560];
+  static_assert(tilechol_lds_doubles(OVP_TC_MAX_TILES) <= 8 * 2560, "chol(P) must fit in the workgroup's LDS");
+  if (blockIdx.x == 0) {
+    tilechol_body<MAXSLOT>(c.A, c.L, c.Dinv, c.Lpack, c.n, c.ld, c.flag, 0, 0, smem);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x - 1;
+  const int f = wave * nwg + (blockIdx.x - 1);
+  if (f >= p.n_feats) return;
+  __builtin_amdgcn_s_setprio(3);
+  feat_body<true>(p, f, threadIdx.x & 63, smem + wave * 2560);
+}
+
 }  // namespace ovp
 
 extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream) {
@@ -650,5 +686,27 @@ extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t
     hipLaunchKernelGGL(ovp::k_feat_gate<true>, dim3(p->n_feats), dim3(64), 0, stream, *p);
   else
     hipLaunchKernelGGL(ovp::k_feat_gate<false>, dim3(p->n_feats), dim3(64), 0, stream, *p);
+  return hipGetLastError();
+}
+
+// 1 if ovp_launch_feat_chol can take this batch / matrix (otherwise: ovp_launch_feat_gate + ovp_launch_tilechol)
+extern "C" int ovp_feat_chol_supported(const ovp::FeatParams* p, int n) {
+  static const bool off = getenv("OVP_K1_UNFUSED") != nullptr || getenv("OVP_K1_LEGACY") != nullptr;
+  const int nt = (n + 15) >> 4;
+  return !off && p->n_feats > 0 && p->max_meas <= 30 && nt <= OVP_TC_MAX_TILES;
+}
+
+extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c, hipStream_t stream) {
+  const int F = p->n_feats;
+  const int cus = 255;  // feature workgroups of one round (256 CUs, one of them factorizes)
+  const int nwg = F <= cus ? F : (F <= 8 * cus ? cus : (F + 7) / 8);
+  const int nt = (c->n + 15) >> 4;
+  const int slots = (nt * (nt + 1) / 2 + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
+  if (slots <= 15)
+    hipLaunchKernelGGL(ovp::k_feat_chol<15>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+  else if (slots <= 18)
+    hipLaunchKernelGGL(ovp::k_feat_chol<18>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+  else
+    hipLaunchKernelGGL(ovp::k_feat_chol<25>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
   return hipGetLastError();
 }

@@ -10,6 +10,7 @@
 //                           ^ dense rank-3F downdate                          (k_syrk, v_mfma_f64_16x16x4_f64)
 #include "ovp_dev.h"
 #include "ovp_kernels.h"
+#include <cstdlib>
 
 namespace ovp {
 
@@ -116,6 +117,172 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ G, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2ab: both Gram products in ONE launch, both on v_mfma_f64_16x16x4_f64 (k_struct_gram / k_syrk above are the first
+// versions, kept for the plane path's small batches and as cross-checks).
+//   blocks [0, n_struct):   (chunk, slot) of the structured part: X = rec[slot] rows of the chunk, 21 columns padded to two
+//                           16-column groups, three tiles of X^T X, emitted in the packed 231-element layout of k_struct_gram
+//   blocks [n_struct, ..):  (macro tile, split) of the dense downdate G^T G: a 64 x 64 macro tile = 4 x 4 MFMA tiles held in
+//                           registers by every wave (one operand load feeds four MFMAs: 8 loads per 16 MFMAs instead of the
+//                           2 per MFMA that made k_syrk L2-bandwidth bound), the four waves split the rows of the block and
+//                           are summed through LDS in a fixed order.
+// A 16 x 16 x 4 f64 MFMA occupies its SIMD for 64 cycles, so the whole product is ~10 K cycles per SIMD when spread evenly:
+// the launch is sized for one or two blocks per CU.
+// ------------------------------------------------------------------------------------------------
+struct GramPairJob {
+  const double* rec;
+  int n_feats, n_clones, rows_per_chunk, n_chunks;
+  double* gramS;
+  const double* G;
+  int rows, ldg, nt16, n_macro_rows, n_split, rows_per_split, ntile;
+  double* part;
+};
+
+__global__ __launch_bounds__(256) void k_gram_pair(const GramPairJob j) {
+  __shared__ __attribute__((aligned(16))) double red[4][4][256];  // [wave][tile of the round][element]  32 KB
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kk = lane >> 4, ij = lane & 15;
+  const int n_struct = j.n_chunks * j.n_clones;
+  if ((int)blockIdx.x < n_struct) {
+    const int slot = blockIdx.x / j.n_chunks, chunk = blockIdx.x - slot * j.n_chunks;
+    const int total_rows = 2 * j.n_feats;
+    const int r0 = chunk * j.rows_per_chunk;
+    const int r1 = min(r0 + j.rows_per_chunk, total_rows);
+    const double* X = j.rec + (size_t)slot * total_rows * OVP_REC;
+    const bool hi_ok = 16 + ij < OVP_REC;  // second column group: columns 16..20
+    double4_t a00 = {0.0, 0.0, 0.0, 0.0}, a10 = a00, a11 = a00;
+    // raw loads from clamped addresses; rows past the chunk and the padding columns are zeroed when the operand is USED
+    // (a select right behind the load would make every load a synchronous one)
+    auto load = [&](int k0, double& x0, double& x1) {
+      const int row = k0 + kk;
+      const double* src = X + (size_t)(row < r1 ? row : r0) * OVP_REC + ij;
+      x0 = src[0];
+      x1 = src[hi_ok ? 16 : 0];
+    };
+    // all of the wave's rows are requested before the first MFMA (a step is only 3 MFMAs, far less than a memory round
+    // trip): SG_STEPS steps of 4 rows per wave and pass
+    constexpr int SG_STEPS = 8;
+    for (int kb = r0 + 4 * wave; kb < r1; kb += 16 * SG_STEPS) {
+      double x0[SG_STEPS], x1[SG_STEPS];
+#pragma unroll
+      for (int d = 0; d < SG_STEPS; ++d) load(kb + 16 * d, x0[d], x1[d]);
+#pragma unroll
+      for (int d = 0; d < SG_STEPS; ++d) {
+        if (kb + 16 * d < r1) {
+          const bool ok = kb + 16 * d + kk < r1;
+          const double u0 = ok ? x0[d] : 0.0;
+          const double u1 = (ok && hi_ok) ? x1[d] : 0.0;
+          a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, a00, 0, 0, 0);
+          a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u0, a10, 0, 0, 0);
+          a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u1, a11, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = (kk + 4 * v) * 16 + ij;
+      red[wave][0][e] = a00[v];
+      red[wave][1][e] = a10[v];
+      red[wave][2][e] = a11[v];
+    }
+    __syncthreads();
+    if (t < OVP_GRAM_ELEMS) {
+      int p = 0, q = 0, rem = t;
+      for (int pp = 0; pp < OVP_REC; ++pp) {
+        const int len = OVP_REC - pp;
+        if (rem < len) {
+          p = pp;
+          q = pp + rem;
+          break;
+        }
+        rem -= len;
+      }
+      // element (p, q), p <= q, = entry (row q, column p) of the lower tile triangle
+      const int tl = (q >> 4) + (p >> 4);  // (0,0) -> 0, (1,0) -> 1, (1,1) -> 2
+      const int e = (q & 15) * 16 + (p & 15);
+      j.gramS[((size_t)slot * j.n_chunks + chunk) * OVP_GRAM_ELEMS + t] =
+          ((red[0][tl][e] + red[1][tl][e]) + red[2][tl][e]) + red[3][tl][e];
+    }
+    return;
+  }
+  // ---- dense part ----
+  const int b = blockIdx.x - n_struct;
+  const int macro = b / j.n_split, split = b - macro * j.n_split;
+  int mi = 0;
+  while ((mi + 1) * (mi + 2) / 2 <= macro) ++mi;
+  const int mj = macro - mi * (mi + 1) / 2;
+  const int k_begin = split * j.rows_per_split;
+  const int k_end = min(k_begin + j.rows_per_split, j.rows);
+  const bool diag = (mi == mj);
+  // live tiles (wave-uniform): tile row a = 4 mi + ia, tile column bb = 4 mj + ib, both < nt16, a >= bb
+  auto live = [&](int ia, int ib) { return 4 * mi + ia < j.nt16 && 4 * mj + ib < j.nt16 && (!diag || ia >= ib); };
+  double4_t acc[4][4];
+#pragma unroll
+  for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) acc[ia][ib] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int cI = 64 * mi + ij, cJ = 64 * mj + ij;
+  // raw loads from clamped addresses (live tiles only touch columns < 16 nt16 <= ldg); rows past the block are zeroed in
+  // the B operand when it is used - a select right behind the load would make every load a synchronous one
+  auto load = [&](int k0, double (&av)[4], double (&bv)[4]) {
+    const int row = k0 + kk;
+    const double* src = j.G + (size_t)(row < k_end ? row : k_begin) * j.ldg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ca = cI + 16 * q, cb = cJ + 16 * q;
+      av[q] = src[ca < j.ldg ? ca : 0];
+      bv[q] = src[cb < j.ldg ? cb : 0];
+    }
+  };
+  // operand ring: the loads of DEPTH steps are in flight while one step's sixteen MFMAs execute
+  constexpr int DEPTH = 4;
+  double ra[DEPTH][4], rb[DEPTH][4];
+  int k0 = k_begin + 4 * wave;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(k0 + 16 * d, ra[d], rb[d]);
+  for (; k0 < k_end; k0 += 16 * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (k0 + 16 * d < k_end) {
+        const bool ok = k0 + 16 * d + kk < k_end;
+        double bz[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bz[q] = ok ? rb[d][q] : 0.0;
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib)
+            if (live(ia, ib))
+              acc[ia][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[d][ia], bz[ib], acc[ia][ib], 0, 0, 0);
+      }
+      load(k0 + 16 * (d + DEPTH), ra[d], rb[d]);
+    }
+  }
+  // four rounds of four tiles: waves -> LDS -> fixed-order sum -> part[split][tile][256]
+#pragma unroll
+  for (int ia = 0; ia < 4; ++ia) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      if (live(ia, ib)) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][ib][(kk + 4 * v) * 16 + ij] = acc[ia][ib][v];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      if (live(ia, ib)) {
+        const int a = 4 * mi + ia, bb = 4 * mj + ib;
+        const int tile = a * (a + 1) / 2 + bb;
+        j.part[((size_t)split * j.ntile + tile) * 256 + t] =
+            ((red[0][ib][t] + red[1][ib][t]) + red[2][ib][t]) + red[3][ib][t];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2c: assemble Ab[(n+1)][lda]: rows 0..n-1 = A (full symmetric), row n = b.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int gram_index(int p, int q) {  // packed upper triangle of 21x21, p <= q
@@ -175,8 +342,18 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gra
     const int tile = ti * (ti + 1) / 2 + tj;
     const int e = (I & 15) * 16 + (J & 15);
     double d = 0.0;
-#pragma unroll 4
-    for (int sp = 0; sp < n_split; ++sp) d += part[((size_t)sp * ntile + tile) * 256 + e];
+    // fixed order, eight loads in flight
+    const double* pp = part + (size_t)tile * 256 + e;
+    const size_t st = (size_t)ntile * 256;
+    int sp = 0;
+    for (; sp + 8 <= n_split; sp += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(sp + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d += v[u];
+    }
+    for (; sp < n_split; ++sp) d += pp[(size_t)sp * st];
     s -= d;
   }
   Ab[(size_t)r * lda + c] = s;
@@ -218,6 +395,51 @@ hipError_t ovp_launch_syrk(const double* G, int rows, int ldg, int ncols, int n_
   int rps = (rows + n_split - 1) / n_split;
   rps = ((rps + 15) / 16) * 16;
   hipLaunchKernelGGL(ovp::k_syrk, dim3(ntile, n_split), dim3(256), 0, stream, G, rows, ldg, n_split, rps, part);
+  return hipGetLastError();
+}
+
+// both Gram products of K2 in one launch; *n_split_used tells the assemble kernel how many partials to sum
+hipError_t ovp_launch_gram_pair(const double* rec, int n_clones, int n_feats, int rows_per_chunk, int n_chunks,
+                                double* gramS, const double* G, int rows, int ldg, int ncols, int n_split_cap,
+                                double* part, int* n_split_used, hipStream_t stream) {
+  ovp::GramPairJob j;
+  j.rec = rec;
+  j.n_feats = n_feats;
+  j.n_clones = n_clones;
+  j.rows_per_chunk = rows_per_chunk;
+  j.n_chunks = n_chunks;
+  j.gramS = gramS;
+  j.G = G;
+  j.rows = rows;
+  j.ldg = ldg;
+  j.nt16 = (ncols + 15) / 16;
+  if (16 * j.nt16 > ldg) return hipErrorInvalidValue;
+  j.n_macro_rows = (j.nt16 + 3) / 4;
+  j.ntile = j.nt16 * (j.nt16 + 1) / 2;
+  const int n_macro = j.n_macro_rows * (j.n_macro_rows + 1) / 2;
+  int ns = (256 + n_macro / 2) / n_macro;  // about one dense block per CU
+  const int by_rows = rows / 64;           // at least four steps per wave
+  if (ns > by_rows) ns = by_rows;
+  if (ns > n_split_cap) ns = n_split_cap;
+  if (ns < 1) ns = 1;
+  int rps = (rows + ns - 1) / ns;
+  rps = ((rps + 15) / 16) * 16;
+  ns = (rows + rps - 1) / rps;
+  j.n_split = ns;
+  j.rows_per_split = rps;
+  j.part = part;
+  *n_split_used = ns;
+  static const int dbg = getenv("OVP_DBG_GRAM") ? atoi(getenv("OVP_DBG_GRAM")) : 0;  // timing experiments (wrong results)
+  if (dbg == 1) {
+    hipLaunchKernelGGL(ovp::k_gram_pair, dim3(n_chunks * n_clones), dim3(256), 0, stream, j);
+    return hipGetLastError();
+  }
+  if (dbg == 2) {
+    j.n_chunks = 0;
+    hipLaunchKernelGGL(ovp::k_gram_pair, dim3(n_macro * ns), dim3(256), 0, stream, j);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(ovp::k_gram_pair, dim3(n_chunks * n_clones + n_macro * ns), dim3(256), 0, stream, j);
   return hipGetLastError();
 }
 

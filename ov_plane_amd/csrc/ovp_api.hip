@@ -185,6 +185,7 @@ struct ovp_ctx {
   volatile unsigned* h_seq = nullptr;                 // sequence word behind it (written last by k_publish_results)
   unsigned seq = 0, pub_seq = 0;
   bool pub_pending = false;      // the running update publishes its results itself (k_dx_rows)
+  bool need_join = false;     // chol(P) / K2 of the current update finish on stream2 (ev_join) rather than on the main stream
   unsigned* ticket = nullptr;    // block counter of the publishing kernel
   std::vector<int> h_nmeas;                           // host copy of n_meas of the current batch (row count of `info`)
   bool h_nmeas_valid = false;
@@ -285,7 +286,7 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(dalloc(&c->Bscr, (size_t)n_feats_max * OVP_BSCR));
   HIPCHK(dalloc(&c->rec, (size_t)n_clones_max * n_feats_max * 2 * 21));
   // reduction geometry: fixed per context so the summation order (hence the result bits) is reproducible
-  c->rows_per_chunk = 512;
+  c->rows_per_chunk = 128;  // 32 rows = 8 MFMA steps per wave of k_gram_pair
   c->n_chunks = (2 * n_feats_max + c->rows_per_chunk - 1) / c->rows_per_chunk;
   HIPCHK(dalloc(&c->gramS, (size_t)n_clones_max * c->n_chunks * OVP_GRAM_ELEMS));
   HIPCHK(dalloc(&c->gramR, (size_t)n_clones_max * OVP_GRAM_ELEMS));
@@ -294,7 +295,7 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
     const size_t ntm = (size_t)c->ld / 16 + 1;
     HIPCHK(dalloc(&c->Ltp, ntm * (ntm + 1) / 2 * 256));  // tile-packed factor for k_fwdsub
   }
-  c->n_split = (3 * n_feats_max + 511) / 512;
+  c->n_split = (3 * n_feats_max + 63) / 64;  // split-K partials of the dense Gram product (k_gram_pair: ~256 blocks)
   if (c->n_split < 1) c->n_split = 1;
   if (c->n_split > 64) c->n_split = 64;
   {
@@ -604,7 +605,7 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     if (rc) return rc;
   } else {
     static const bool nojoin = getenv("OVP_DBG_NOJOIN") != nullptr;
-    if (!nojoin) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (!nojoin && c->need_join) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   }
   const double* b = c->Ab + (size_t)n * ld;
   if (n <= OVP_TILECHOL_NMAX) {
@@ -683,11 +684,16 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
 
 static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   ovp::FeatParams& fp = c->fp;
-  // chol(P) does not depend on the measurements, so it runs on the side stream - but beside K2, not beside K1: K1 keeps
-  // every SIMD of the chip busy with two feature waves, and the CU that also hosts the eight Cholesky waves finishes its
-  // feature blocks ~40 % later, which is the kernel's duration (measured: K1 112 -> 157 us).
-  // OVP_OVERLAP_MODE: 0 = no overlap, 1 = beside K1 (old behaviour), 2 (default) = beside K2.
-  static const int overlap_mode = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 2;
+  // chol(P) does not depend on the measurements.  Default (mode 3): it rides in workgroup 0 of the fused feature kernel, on a
+  // CU of its own, and is hidden behind the features; K2 follows on the main stream and nothing forks or joins.
+  // Beside a one-wave-per-block K1 it must NOT run: K1 keeps every SIMD busy with two feature waves, and the CU that also
+  // hosts the eight Cholesky waves finishes its feature blocks ~40 % later, which is the kernel's duration (K1 112 -> 157 us).
+  // OVP_OVERLAP_MODE: 0 = no overlap, 1 = side stream beside K1, 2 = main stream after K1 with K2 beside it on the side
+  // stream (the fallback when the fused kernel cannot take the batch), 3 (default) = fused.
+  static const int overlap_env = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 3;
+  int overlap_mode = overlap_env;
+  if (overlap_mode == 3 && !(c->n <= OVP_TILECHOL_NMAX && ovp_feat_chol_supported(&fp, c->n))) overlap_mode = 2;
+  c->need_join = (overlap_mode == 1 || overlap_mode == 2);
   if (overlap_mode == 1) {
     HIPCHK(hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -698,7 +704,12 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // K1.  Events on the main stream are kept to a minimum (each one costs microseconds between dependent kernels): with
   // the kernel timer on, ev_k0 / ev_k1 bracket K1 and ev_k1 doubles as the fork point; otherwise one untimed fork event.
   if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
-  HIPCHK(ovp_launch_feat_gate(&fp, c->stream));
+  if (overlap_mode == 3) {
+    ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags};
+    HIPCHK(ovp_launch_feat_chol(&fp, &cj, c->stream));
+  } else {
+    HIPCHK(ovp_launch_feat_gate(&fp, c->stream));
+  }
   hipEvent_t fork_ev = c->ev_fork;
   if (c->ktimer) {
     fork_ev = c->ev_k1;
@@ -724,11 +735,17 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // K2
   const int used_chunks = F > 0 ? (2 * F + c->rows_per_chunk - 1) / c->rows_per_chunk : 0;
   if (F > 0) {
-    HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, s2k));
     int nsplit = (3 * F + 511) / 512;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > c->n_split) nsplit = c->n_split;
-    HIPCHK(ovp_launch_syrk(c->G, 3 * F, c->ldg, n + 1, nsplit, c->part, s2k));
+    static const bool k2_split = getenv("OVP_K2_SPLIT") != nullptr;  // first version: two VALU / narrow-tile launches
+    if (k2_split) {
+      HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, s2k));
+      HIPCHK(ovp_launch_syrk(c->G, 3 * F, c->ldg, n + 1, nsplit, c->part, s2k));
+    } else {
+      HIPCHK(ovp_launch_gram_pair(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, c->G, 3 * F, c->ldg,
+                                  n + 1, c->n_split, c->part, &nsplit, s2k));
+    }
     HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, used_chunks, c->gramR, s2k));
     HIPCHK(ovp_launch_assemble(c->gramR, fp.n_clones, 1, c->part, nsplit, c->colmap, n, c->Ab, c->ld, s2k));
   } else {

@@ -8,10 +8,22 @@
 #define OVP_MAX_CLONES 64
 #define OVP_GRAM_ELEMS 231   // 21*22/2: packed upper triangle of the per-clone 21x21 Gram
 #define OVP_CLONE_JITTER 1e-11  // relative inflation of the diagonal of a cloned covariance block (k_cov_clone)
+#define OVP_TC_MAX_TILES 18  // tile rows the register-resident Cholesky handles (N <= 288)
 #define OVP_BSCR 2112        // doubles of per-feature scratch for B (k_feat.hip LCOLS)
 #define OVP_LDG_CAP 704      // max leading dimension of the projector-row buffer G (LDS staging in the feature kernels)
 
 namespace ovp {
+
+// chol(P) riding in workgroup 0 of the fused feature kernel (k_feat.hip): A = L L^T, Dinv = inverse diagonal blocks,
+// Lpack = tile-packed factor (see k_tile.hip)
+struct CholJob {
+  const double* A;
+  double* L;
+  double* Dinv;
+  double* Lpack;
+  int n, ld;
+  int* flag;
+};
 
 struct FeatParams {
   // feature batch (device pointers)
@@ -86,12 +98,17 @@ struct ColMap {
 
 extern "C" {
 hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream);
+int ovp_feat_chol_supported(const ovp::FeatParams* p, int n);
+hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c, hipStream_t stream);
 hipError_t ovp_launch_triangulate(const ovp::TriParams* p, hipStream_t stream);
 
 // K2a: per-clone structured Gram of the sparse rows. gramS [n_clones][n_chunks][OVP_GRAM_ELEMS]
 hipError_t ovp_launch_struct_gram(const double* rec, int n_clones, int n_feats, int rows_per_chunk, int n_chunks,
                                   double* gramS, hipStream_t stream);
 // K2b: split-K lower-triangular SYRK of G ([rows][ldg]) with f64 MFMA. part [n_split][nt*(nt+1)/2][256]
+hipError_t ovp_launch_gram_pair(const double* rec, int n_clones, int n_feats, int rows_per_chunk, int n_chunks,
+                                double* gramS, const double* G, int rows, int ldg, int ncols, int n_split_cap,
+                                double* part, int* n_split_used, hipStream_t stream);
 hipError_t ovp_launch_syrk(const double* G, int rows, int ldg, int ncols, int n_split, double* part,
                            hipStream_t stream);
 // K2c: assemble A|b (Ab [(n+1)][lda], row n = b) from the structured Gram and the SYRK partials
