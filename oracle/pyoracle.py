@@ -56,8 +56,8 @@ class OvoFeats(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libovp_oracle.so")
-    src = os.path.join(_HERE, "ovp_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ovp_oracle.c", "ovp_oracle.h", "ovp_planefit.c", "ovp_planefit.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -408,3 +408,120 @@ def triangulate(sc, opts=None, feats=None):
     L.ovo_triangulate(C.byref(o), C.byref(pk.state), C.byref(pk.feats), uvn.ctypes.data_as(C.POINTER(C.c_float)), _dp(p),
                       ok.ctypes.data_as(C.POINTER(C.c_uint8)))
     return dict(p_FinG=p, ok=ok.astype(bool))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plane fitting (oracle/ovp_planefit.c)
+# ------------------------------------------------------------------------------------------------------------------
+class OvoMt(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+class OvoPlaneOpt(C.Structure):
+    _fields_ = [
+        ("n_feats", C.c_int),
+        ("p_FinG", C.POINTER(C.c_double)),
+        ("obs_start", C.POINTER(C.c_int)),
+        ("n_obs", C.POINTER(C.c_int)),
+        ("uv_norm", C.POINTER(C.c_double)),
+        ("R_GtoC", C.POINTER(C.c_double)),
+        ("p_CinG", C.POINTER(C.c_double)),
+        ("cp", C.c_double * 3),
+        ("sigma_px_norm", C.c_double),
+        ("sigma_c", C.c_double),
+        ("fix_plane", C.c_int),
+        ("R_GtoI", C.c_double * 9),
+        ("p_IinG", C.c_double * 3),
+        ("R_ItoC", C.c_double * 9),
+        ("p_IinC", C.c_double * 3),
+    ]
+
+
+def mt_values(seed, count):
+    L = lib()
+    L.ovo_mt_next.restype = C.c_uint32
+    g = OvoMt()
+    L.ovo_mt_seed(C.byref(g), C.c_uint32(seed))
+    return [int(L.ovo_mt_next(C.byref(g))) for _ in range(count)]
+
+
+def shuffles(seed, n, rounds, variant):
+    """`rounds` consecutive std::shuffle calls of 0..n-1 with one std::mt19937(seed), as plane_fitting does."""
+    L = lib()
+    g = OvoMt()
+    L.ovo_mt_seed(C.byref(g), C.c_uint32(seed))
+    out = []
+    for _ in range(rounds):
+        v = np.arange(n, dtype=np.int32)
+        L.ovo_shuffle(_ip(v), C.c_int(n), C.byref(g), C.c_int(variant))
+        out.append(v.copy())
+    return np.array(out)
+
+
+def fit_plane(pts, cond_thresh=1e9, cond_check=True):
+    L = lib()
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    abcd = np.zeros(4)
+    ok = L.ovo_fit_plane(_dp(pts), C.c_int(len(pts)), C.c_double(cond_thresh), C.c_int(int(cond_check)), _dp(abcd))
+    return bool(ok), abcd
+
+
+def plane_fitting(pts, min_inlier_num, max_cond, variant=0):
+    L = lib()
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    n = len(pts)
+    abcd = np.zeros(4)
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    cnt = C.c_int(0)
+    ok = L.ovo_plane_fitting(_dp(pts), C.c_int(n), C.c_int(min_inlier_num), C.c_double(max_cond), C.c_int(variant), _dp(abcd),
+                             inl.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(cnt))
+    return dict(ok=bool(ok), abcd=abcd, inlier=inl[:n].astype(bool), n_inliers=int(cnt.value))
+
+
+def _planeopt_struct(pb):
+    keep = {k: np.ascontiguousarray(pb[k], dtype=np.float64) for k in ("p_FinG", "uv_norm", "R_GtoC", "p_CinG")}
+    keep["obs_start"] = np.ascontiguousarray(pb["obs_start"], dtype=np.int32)
+    keep["n_obs"] = np.ascontiguousarray(pb["n_obs"], dtype=np.int32)
+    s = OvoPlaneOpt()
+    s.n_feats = int(pb["n_feats"])
+    s.p_FinG = _dp(keep["p_FinG"])
+    s.obs_start = _ip(keep["obs_start"])
+    s.n_obs = _ip(keep["n_obs"])
+    s.uv_norm = _dp(keep["uv_norm"])
+    s.R_GtoC = _dp(keep["R_GtoC"])
+    s.p_CinG = _dp(keep["p_CinG"])
+    s.cp = (C.c_double * 3)(*np.asarray(pb["cp"], dtype=np.float64))
+    s.sigma_px_norm = float(pb["sigma_px_norm"])
+    s.sigma_c = float(pb["sigma_c"])
+    s.fix_plane = int(bool(pb["fix_plane"]))
+    s.R_GtoI = (C.c_double * 9)(*np.asarray(pb["R_GtoI"], dtype=np.float64).reshape(-1))
+    s.p_IinG = (C.c_double * 3)(*np.asarray(pb["p_IinG"], dtype=np.float64))
+    s.R_ItoC = (C.c_double * 9)(*np.asarray(pb["R_ItoC"], dtype=np.float64).reshape(-1))
+    s.p_IinC = (C.c_double * 3)(*np.asarray(pb["p_IinC"], dtype=np.float64))
+    return s, keep
+
+
+def optimize_plane(pb):
+    L = lib()
+    s, keep = _planeopt_struct(pb)
+    nf = int(pb["n_feats"])
+    cp = np.zeros(3)
+    p = np.zeros((max(nf, 1), 3))
+    kept = np.zeros(max(nf, 1), dtype=np.uint8)
+    nk, it = C.c_int(0), C.c_int(0)
+    ok = L.ovo_optimize_plane(C.byref(s), _dp(cp), _dp(p), kept.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(nk), C.byref(it))
+    return dict(ok=bool(ok), cp=cp, p_FinG=p[:nf], kept=kept[:nf].astype(bool), n_kept=int(nk.value), iterations=int(it.value))
+
+
+def planeopt_cost(pb, p_FinG, cp, grad=False):
+    L = lib()
+    L.ovo_planeopt_cost.restype = C.c_double
+    s, keep = _planeopt_struct(pb)
+    p_FinG = np.ascontiguousarray(p_FinG, dtype=np.float64)
+    cp = np.ascontiguousarray(cp, dtype=np.float64)
+    if not grad:
+        return float(L.ovo_planeopt_cost(C.byref(s), _dp(p_FinG), _dp(cp), None, None))
+    gp = np.zeros_like(p_FinG)
+    gc = np.zeros(3)
+    c = float(L.ovo_planeopt_cost(C.byref(s), _dp(p_FinG), _dp(cp), _dp(gp), _dp(gc)))
+    return c, gp, gc

@@ -569,3 +569,72 @@ def make_imu_scenario(seed=0, rate=400.0, t_state=100.0, dt_cam=0.1, t_off=0.004
 
 PROP_OPTS = dict(sigma_w=1.6968e-04, sigma_a=2.0000e-3, sigma_wb=1.9393e-05, sigma_ab=3.0000e-03, gravity_mag=9.81,
                  use_rk4=True, imu_avg=False, do_fej=True)
+
+
+def make_planefit_problem(seed=0, n_feats=24, n_obs=9, n_slam=0, ragged=True, outliers=0, px_noise=0.25, sigma_px=1.0,
+                          focal=458.0, pt_noise=0.02, cp_noise=0.01, fix_plane=False, sigma_c=0.05):
+    """Inputs of one PlaneFitting::plane_fitting / optimize_plane call (track_plane/PlaneFitting.cpp:84-514): points of one
+    plane seen from a short camera trajectory.  Camera poses are the clonesCAM entries (R_GtoC, p_CinG); uv_norm are
+    normalised image coordinates (Feature::uvs_norm); features without observations play the SLAM features.
+    """
+    rng = np.random.default_rng(seed)
+    # plane: unit normal roughly facing the cameras, 3-4 m away
+    nrm = np.array([0.2, 0.1, 1.0]) + 0.2 * rng.standard_normal(3)
+    nrm /= np.linalg.norm(nrm)
+    dist = 3.5 + 0.5 * rng.random()
+    cp_true = nrm * dist
+    # orthonormal basis of the plane
+    a = np.cross(nrm, [1.0, 0.0, 0.0])
+    a /= np.linalg.norm(a)
+    b = np.cross(nrm, a)
+    nf = n_feats
+    st = rng.uniform(-1.2, 1.2, size=(nf, 2))
+    p_true = cp_true[None, :] + st[:, :1] * a[None, :] + st[:, 1:] * b[None, :]
+    for k in range(outliers):
+        p_true[nf - 1 - k] += nrm * (0.25 + 0.1 * k) * (1 if k % 2 else -1)
+    # cameras: looking along +z of the global frame with small rotations, moving sideways
+    Rs, ps = [], []
+    for k in range(n_obs):
+        ang = 0.03 * (k - n_obs / 2) + 0.01 * rng.standard_normal()
+        R = rotz(0.02 * rng.standard_normal()) @ roty(ang) @ rotx(0.01 * rng.standard_normal())
+        Rs.append(R)
+        ps.append(np.array([0.08 * k - 0.3, 0.02 * np.sin(k), 0.01 * k]) + 0.01 * rng.standard_normal(3))
+    Rs, ps = np.array(Rs), np.array(ps)
+    n_obs_f = np.full(nf, n_obs, dtype=np.int32)
+    if ragged:
+        n_obs_f = rng.integers(max(3, n_obs // 2), n_obs + 1, size=nf).astype(np.int32)
+    if n_slam:
+        n_obs_f[:n_slam] = 0
+    obs_start = np.zeros(nf, dtype=np.int32)
+    obs_start[1:] = np.cumsum(n_obs_f)[:-1]
+    tot = int(n_obs_f.sum())
+    uv = np.zeros((tot, 2))
+    Ro = np.zeros((tot, 9))
+    po = np.zeros((tot, 3))
+    # the tracker is better than the sigma the filter assumes (whitened residuals << 1): with residuals at the Cauchy
+    # scale the reweighted Gauss-Newton iteration converges too slowly for the 12 iterations optimize_plane allows
+    sig_n = sigma_px / focal
+    act_n = px_noise / focal
+    for f in range(nf):
+        first = int(rng.integers(0, n_obs - n_obs_f[f] + 1)) if n_obs_f[f] else 0
+        for k in range(n_obs_f[f]):
+            c = first + k
+            pc = Rs[c] @ (p_true[f] - ps[c])
+            o = obs_start[f] + k
+            uv[o] = np.float32(pc[:2] / pc[2] + act_n * rng.standard_normal(2))  # stored as f32 in the reference
+            Ro[o] = Rs[c].reshape(-1)
+            po[o] = ps[c]
+    # estimates as a triangulation leaves them: mostly wrong along the viewing ray, little across it
+    ray = p_true - ps[n_obs // 2][None, :]
+    ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+    p0 = p_true + pt_noise * rng.standard_normal((nf, 1)) * ray + 0.1 * pt_noise * rng.standard_normal((nf, 3))
+    if n_slam:
+        p0[:n_slam] = p_true[:n_slam] + 0.005 * rng.standard_normal((n_slam, 3))
+    cp0 = cp_true + cp_noise * rng.standard_normal(3)
+    return Scene(
+        n_feats=nf, p_FinG=np.ascontiguousarray(p0), obs_start=obs_start, n_obs=n_obs_f, uv_norm=np.ascontiguousarray(uv),
+        R_GtoC=np.ascontiguousarray(Ro), p_CinG=np.ascontiguousarray(po), cp=cp0, cp_true=cp_true, p_true=p_true,
+        sigma_px_norm=float(sig_n), sigma_c=float(sigma_c), fix_plane=bool(fix_plane),
+        # current IMU pose / extrinsics: identity extrinsics, the last camera
+        R_GtoI=Rs[-1].copy(), p_IinG=ps[-1].copy(), R_ItoC=np.eye(3), p_IinC=np.zeros(3),
+    )
