@@ -216,6 +216,49 @@ int ovp_cov_size(ovp_ctx *ctx);
 /* 0.95 chi-square quantile used by the gate (boost::math::quantile, update/UpdaterMSCKF.cpp:59-62) */
 double ovp_chi2_quantile_095(int dof);
 
+/* ---- plane fitting -------------------------------------------------------------------------------
+ * PlaneFitting::plane_fitting (track_plane/PlaneFitting.cpp:84-199) for a batch of planes: RANSAC with the reference's fixed
+ * parameters (5-point sets, 200 iterations, 80 % inliers, 5 cm, std::mt19937(8888) + std::shuffle) followed by the refit on the
+ * inlier set.  Plane k owns the points [feat_start[k], feat_start[k+1]).  shuffle_variant selects which libstdc++ the
+ * hypothesis sets mimic: 0 = GCC <= 10 (the reference's Ubuntu 18.04 / 20.04), 1 = GCC >= 11.
+ * Outputs: abcd [n_planes*4] (unit normal, offset), inlier [n_points] (-> feats = best_inliers, :190), ok [n_planes]. */
+typedef struct {
+  int n_planes;
+  const int *feat_start;  /* [n_planes + 1] */
+  const double *p_FinG;   /* [n_points*3] Feature::p_FinG */
+  int min_inlier_num;     /* StateOptions::plane_msckf_min_feat / plane_init_min_feat */
+  double max_cond;        /* StateOptions::plane_msckf_max_cond / plane_init_max_cond */
+  int shuffle_variant;
+} ovp_planefit_batch;
+int ovp_plane_fitting(ovp_ctx *ctx, const ovp_planefit_batch *batch, double *abcd, uint8_t *inlier, uint8_t *ok);
+
+/* PlaneFitting::optimize_plane (track_plane/PlaneFitting.cpp:201-514) for a batch of planes: joint refinement of the plane's
+ * closest point and its features over reprojection + point-on-plane factors (ceres/Factor_PointOnPlane.cpp) under
+ * CauchyLoss(1), Ceres' dogleg trust-region loop with its default options and at most 12 iterations, then the inlier tests of
+ * :456-498.  Observations of feature f are [obs_start[f], obs_start[f] + n_obs[f]); n_obs = 0 marks a SLAM feature (kept
+ * constant, :274-279).  R_GtoC / p_CinG are the clonesCAM poses of every observation, uv_norm the normalised measurements.
+ * Outputs per plane: cp_out (input value when the call fails), ok, iterations; per feature: p_out (refined position if kept,
+ * else the input), kept (-> feats = inliers, :511).  At most 256 features per plane. */
+typedef struct {
+  int n_planes;
+  const int *feat_start;    /* [n_planes + 1] */
+  const double *p_FinG;     /* [n_feats*3] */
+  const int *obs_start;     /* [n_feats] */
+  const int *n_obs;         /* [n_feats] */
+  int n_obs_total;
+  const double *uv_norm;    /* [n_obs_total*2] */
+  const double *R_GtoC;     /* [n_obs_total*9] row-major */
+  const double *p_CinG;     /* [n_obs_total*3] */
+  const double *cp;         /* [n_planes*3] initial closest points */
+  const uint8_t *fix_plane; /* [n_planes] plane is in the state: keep cp constant */
+  double sigma_px_norm;     /* sigma_pix / focal length (update/UpdaterMSCKF.cpp:271-272) */
+  double sigma_c;           /* StateOptions::sigma_constraint */
+  double R_GtoI[9], p_IinG[3]; /* current IMU pose (stateI) */
+  double R_ItoC[9], p_IinC[3]; /* camera extrinsics (calib0) */
+} ovp_planeopt_batch;
+int ovp_plane_optimize(ovp_ctx *ctx, const ovp_planeopt_batch *batch, double *cp_out, double *p_out, uint8_t *kept,
+                       uint8_t *ok, int *iterations);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* copies an internal device buffer to host for tests: name in {"A","b","L","T","Lt","Y","G","rec","chi2",
  * "gramS","syrk"}; returns the byte count copied (or <0). */

@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ovp_api.hip", "k_feat.hip", "k_gram.hip", "k_ekf.hip", "k_tile.hip", "k_plane.hip", "k_triang.hip"]
+SOURCES = ["ovp_api.hip", "k_feat.hip", "k_gram.hip", "k_ekf.hip", "k_tile.hip", "k_plane.hip", "k_triang.hip", "k_planefit.hip"]
 HEADERS = ["ovp_dev.h", "ovp_kernels.h", "ovp_feat_model.h", os.path.join("..", "..", "include", "ovplane_hip.h")]
 OUT = os.path.join(_HERE, "libovplane_hip.so")
 
@@ -32,7 +32,7 @@ def build_lib(force=False, verbose=False):
 
 
 HOST_DIR = os.path.join(CSRC, "host")
-HOST_SOURCES = ["ov_plane_host.cpp", "ov_plane_updaters.cpp", "ov_plane_propagator.cpp", "host_capi.cpp"]
+HOST_SOURCES = ["ov_plane_host.cpp", "ov_plane_updaters.cpp", "ov_plane_propagator.cpp", "ov_plane_planefit.cpp", "host_capi.cpp"]
 HOST_HEADERS = ["ov_plane_host.h", "ov_types.h"]
 HOST_OUT = os.path.join(_HERE, "libovplane_host.so")
 

@@ -88,6 +88,20 @@ class UpdateInfo(C.Structure):
 _LIB = None
 
 # every symbol include/ovplane_hip.h declares (checked by the CPU test-suite)
+class PlaneFitBatch(C.Structure):
+    _fields_ = [("n_planes", C.c_int), ("feat_start", C.POINTER(C.c_int)), ("p_FinG", C.POINTER(C.c_double)),
+                ("min_inlier_num", C.c_int), ("max_cond", C.c_double), ("shuffle_variant", C.c_int)]
+
+
+class PlaneOptBatch(C.Structure):
+    _fields_ = [("n_planes", C.c_int), ("feat_start", C.POINTER(C.c_int)), ("p_FinG", C.POINTER(C.c_double)),
+                ("obs_start", C.POINTER(C.c_int)), ("n_obs", C.POINTER(C.c_int)), ("n_obs_total", C.c_int),
+                ("uv_norm", C.POINTER(C.c_double)), ("R_GtoC", C.POINTER(C.c_double)), ("p_CinG", C.POINTER(C.c_double)),
+                ("cp", C.POINTER(C.c_double)), ("fix_plane", C.POINTER(C.c_ubyte)), ("sigma_px_norm", C.c_double),
+                ("sigma_c", C.c_double), ("R_GtoI", C.c_double * 9), ("p_IinG", C.c_double * 3),
+                ("R_ItoC", C.c_double * 9), ("p_IinC", C.c_double * 3)]
+
+
 EXPORTS = [
     "ovp_ctx_create", "ovp_ctx_destroy", "ovp_sync", "ovp_version", "ovp_error_string", "ovp_cov_upload",
     "ovp_cov_download", "ovp_cov_set_device", "ovp_cov_marginal", "ovp_state_upload", "ovp_batch_upload",
@@ -95,7 +109,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream", "ovp_triang_defaults", "ovp_triangulate",
+    "ovp_ctx_stream", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
 ]
 
 
@@ -148,6 +162,9 @@ def lib():
         L.ovp_triang_defaults.argtypes = [C.POINTER(TriangOpts)]
         L.ovp_triang_defaults.restype = None
         L.ovp_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangOpts), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ovp_plane_fitting.argtypes = [C.c_void_p, C.POINTER(PlaneFitBatch), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ovp_plane_optimize.argtypes = [C.c_void_p, C.POINTER(PlaneOptBatch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -391,6 +408,66 @@ class Context:
         ok = np.zeros(max(F, 1), dtype=np.uint8)
         _chk(lib().ovp_triangulate(self._h, C.byref(o), uvn.ctypes.data, p.ctypes.data, ok.ctypes.data), "ovp_triangulate")
         return dict(p_FinG=p[:F], ok=ok[:F].astype(bool))
+
+    def plane_fitting(self, feat_start, p_FinG, min_inlier_num, max_cond, shuffle_variant=0):
+        """ovp_plane_fitting: RANSAC + refit for a batch of planes; returns dict(abcd [P,4], inlier [F], ok [P])."""
+        fs = np.ascontiguousarray(feat_start, dtype=np.int32)
+        pts = np.ascontiguousarray(p_FinG, dtype=np.float64)
+        P = len(fs) - 1
+        b = PlaneFitBatch(P, fs.ctypes.data_as(C.POINTER(C.c_int)), pts.ctypes.data_as(C.POINTER(C.c_double)),
+                          int(min_inlier_num), float(max_cond), int(shuffle_variant))
+        abcd = np.zeros((max(P, 1), 4))
+        inl = np.zeros(max(len(pts), 1), dtype=np.uint8)
+        ok = np.zeros(max(P, 1), dtype=np.uint8)
+        _chk(lib().ovp_plane_fitting(self._h, C.byref(b), abcd.ctypes.data, inl.ctypes.data, ok.ctypes.data),
+             "ovp_plane_fitting")
+        return dict(abcd=abcd[:P], inlier=inl[: len(pts)].astype(bool), ok=ok[:P].astype(bool))
+
+    def plane_optimize(self, problems):
+        """ovp_plane_optimize on a list of per-plane problems (dicts as ov_plane_amd.synth.make_planefit_problem returns;
+        sigma / pose fields are taken from the first).  Returns a list of dict(ok, cp, p_FinG, kept, iterations)."""
+        P = len(problems)
+        fs = np.zeros(P + 1, dtype=np.int32)
+        for k, pb in enumerate(problems):
+            fs[k + 1] = fs[k] + int(pb["n_feats"])
+        p0 = np.ascontiguousarray(np.concatenate([np.asarray(pb["p_FinG"], dtype=np.float64).reshape(-1, 3) for pb in problems]))
+        n_obs = np.ascontiguousarray(np.concatenate([np.asarray(pb["n_obs"], dtype=np.int32) for pb in problems]))
+        obs_start = np.zeros(len(n_obs), dtype=np.int32)
+        obs_start[1:] = np.cumsum(n_obs)[:-1]
+        cat = lambda key, w: np.ascontiguousarray(
+            np.concatenate([np.asarray(pb[key], dtype=np.float64).reshape(-1, w) for pb in problems]))
+        uv, Rc, pc = cat("uv_norm", 2), cat("R_GtoC", 9), cat("p_CinG", 3)
+        cp = np.ascontiguousarray(np.array([pb["cp"] for pb in problems], dtype=np.float64))
+        fix = np.ascontiguousarray(np.array([1 if pb["fix_plane"] else 0 for pb in problems], dtype=np.uint8))
+        b = PlaneOptBatch()
+        b.n_planes = P
+        b.feat_start = fs.ctypes.data_as(C.POINTER(C.c_int))
+        b.p_FinG = p0.ctypes.data_as(C.POINTER(C.c_double))
+        b.obs_start = obs_start.ctypes.data_as(C.POINTER(C.c_int))
+        b.n_obs = n_obs.ctypes.data_as(C.POINTER(C.c_int))
+        b.n_obs_total = int(n_obs.sum())
+        b.uv_norm = uv.ctypes.data_as(C.POINTER(C.c_double))
+        b.R_GtoC = Rc.ctypes.data_as(C.POINTER(C.c_double))
+        b.p_CinG = pc.ctypes.data_as(C.POINTER(C.c_double))
+        b.cp = cp.ctypes.data_as(C.POINTER(C.c_double))
+        b.fix_plane = fix.ctypes.data_as(C.POINTER(C.c_ubyte))
+        f = problems[0]
+        b.sigma_px_norm = float(f["sigma_px_norm"])
+        b.sigma_c = float(f["sigma_c"])
+        b.R_GtoI = (C.c_double * 9)(*np.asarray(f["R_GtoI"], dtype=np.float64).reshape(-1))
+        b.p_IinG = (C.c_double * 3)(*np.asarray(f["p_IinG"], dtype=np.float64))
+        b.R_ItoC = (C.c_double * 9)(*np.asarray(f["R_ItoC"], dtype=np.float64).reshape(-1))
+        b.p_IinC = (C.c_double * 3)(*np.asarray(f["p_IinC"], dtype=np.float64))
+        F = int(fs[-1])
+        cp_out = np.zeros((P, 3))
+        p_out = np.zeros((max(F, 1), 3))
+        kept = np.zeros(max(F, 1), dtype=np.uint8)
+        ok = np.zeros(P, dtype=np.uint8)
+        its = np.zeros(P, dtype=np.int32)
+        _chk(lib().ovp_plane_optimize(self._h, C.byref(b), cp_out.ctypes.data, p_out.ctypes.data, kept.ctypes.data,
+                                      ok.ctypes.data, its.ctypes.data), "ovp_plane_optimize")
+        return [dict(ok=bool(ok[k]), cp=cp_out[k].copy(), p_FinG=p_out[fs[k]:fs[k + 1]].copy(),
+                     kept=kept[fs[k]:fs[k + 1]].astype(bool), iterations=int(its[k])) for k in range(P)]
 
     def sync(self):
         _chk(lib().ovp_sync(self._h), "ovp_sync")

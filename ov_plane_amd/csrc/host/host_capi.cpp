@@ -12,6 +12,15 @@ using namespace ov_type;
 // updater triangulates them itself (update/UpdaterMSCKF.cpp:120-166) before the update.
 static const float *g_uv_norm = nullptr;
 extern "C" void ovph_set_uv_norm(const float *uv_norm /* [F][M][2] or NULL */) { g_uv_norm = uv_norm; }
+// next ovph_run_msckf_update: no plane estimates are handed over, UpdaterMSCKF::update runs plane_fitting / optimize_plane itself
+static int g_fit_planes = 0, g_fit_min_feat = 20, g_fit_variant = 0;
+static double g_fit_max_cond = 100.0;
+extern "C" void ovph_set_plane_fit(int enable, int min_feat, double max_cond, int shuffle_variant) {
+  g_fit_planes = enable;
+  g_fit_min_feat = min_feat;
+  g_fit_max_cond = max_cond;
+  g_fit_variant = shuffle_variant;
+}
 
 extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
                                      const double *clone_p_fej, const double *calib_q, const double *calib_p,
@@ -30,6 +39,11 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   so.max_clone_size = C;
   so.use_plane_constraint = so.use_plane_constraint_msckf = true;
   so.sigma_constraint = sigma_c;
+  if (g_fit_planes) {
+    so.plane_msckf_min_feat = g_fit_min_feat;
+    so.plane_msckf_max_cond = g_fit_max_cond;
+    so.planefit_shuffle_variant = g_fit_variant;
+  }
   so.max_state_size = N + 8;
   so.max_features = F + 8;
   auto state = std::make_shared<State>(so);
@@ -81,8 +95,9 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
     state->_features_PLANE[plane_ids_state[k]] = pl;
     planes.push_back(pl);
   }
-  for (int k = 0; k < n_planes_out; ++k)
-    state->_plane_estimates_cp_inG[plane_ids_out[k]] = {cp_out[3 * k], cp_out[3 * k + 1], cp_out[3 * k + 2]};
+  if (!g_fit_planes)  // otherwise UpdaterMSCKF::update fits / refines the planes itself (UpdaterMSCKF.cpp:196-400)
+    for (int k = 0; k < n_planes_out; ++k)
+      state->_plane_estimates_cp_inG[plane_ids_out[k]] = {cp_out[3 * k], cp_out[3 * k + 1], cp_out[3 * k + 2]};
   if (state->max_covariance_size() != N) return -11;
   {
     std::vector<std::shared_ptr<Type>> order;
@@ -126,6 +141,7 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   UpdaterMSCKF updater(uo, fio);
   updater.update(state, fv, fextra, fused, feat2plane);
   g_uv_norm = nullptr;
+  g_fit_planes = 0;
   // outputs
   int i = 0;
   for (auto &c : state->_clones_IMU) {

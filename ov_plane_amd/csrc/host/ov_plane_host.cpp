@@ -70,9 +70,11 @@ State::State(StateOptions &options_) {
   gpu_check(ovp_ctx_create(0, _options.max_state_size, std::min(64, _options.max_clone_size + 2), _options.max_features, nullptr, &_gpu),
             "ovp_ctx_create");
   gpu_check(ovp_cov_upload(_gpu, Cov.data(), current_id, current_id), "ovp_cov_upload");
+  PlaneFitting::bind(_gpu, _options.planefit_shuffle_variant);
 }
 
 State::~State() {
+  if (PlaneFitting::bound() == _gpu) PlaneFitting::bind(nullptr, 0);
   if (_gpu) ovp_ctx_destroy(_gpu);
 }
 
@@ -586,7 +588,6 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
                           std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_extra,
                           std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane) {
   if (feature_vec.empty()) return;  // :70-71
-  (void)feature_vec_extra;          // extra on-plane features only feed the upstream plane fit (:218-228), out of scope
 
   // :74-100  keep measurements at existing clone times, drop features with < 2 of them
   std::map<double, int> clone_slot;
@@ -732,17 +733,132 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     }
   }
 
+  // ---- :196-400 plane linearisation points ----
+  // Planes in the state: their features are refined against the (fixed) plane.  Other planes: RANSAC fit of the triangulated
+  // points, then joint refinement of plane and points; a plane that fails either step is skipped this frame.  Runs when the
+  // on-plane features carry normalised measurements (the tracker's uvs_norm) and the caller has not handed estimates over in
+  // state->_plane_estimates_cp_inG (the pre-fitted entry point used when the fit happens elsewhere).
+  std::map<size_t, std::vector<double>> plane_estimates = state->_plane_estimates_cp_inG;
+  std::set<size_t> fitted_planes;       // planes whose feature set went through the fit below
+  std::set<size_t> plane_feat_kept;     // their surviving features (plane_feats.at(planeid) of :421)
+  if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_msckf && !feat2plane.empty() &&
+      state->_plane_estimates_cp_inG.empty()) {
+    std::map<size_t, std::vector<std::shared_ptr<ov_core::Feature>>> plane_feats;  // :198
+    bool all_norm = true;
+    auto collect = [&](std::vector<std::shared_ptr<ov_core::Feature>> &vec) {  // :206-228
+      for (auto &feat : vec) {
+        auto it = feat2plane.find(feat->featid);
+        if (it == feat2plane.end()) continue;
+        all_norm = all_norm && (feat->uvs_norm.size() == 2 * feat->timestamps.size());
+        plane_feats[it->second].push_back(feat);
+      }
+    };
+    collect(feature_vec);
+    {  // :101-118 the extra features get the same clean-up as the main vector
+      auto itx = feature_vec_extra.begin();
+      while (itx != feature_vec_extra.end()) {
+        auto &ft = **itx;
+        std::vector<float> uv2, uvn2;
+        std::vector<double> ts2;
+        const bool has_norm = ft.uvs_norm.size() == ft.uvs.size();
+        for (size_t k = 0; k < ft.timestamps.size(); ++k)
+          if (clone_slot.count(ft.timestamps[k])) {
+            ts2.push_back(ft.timestamps[k]);
+            uv2.push_back(ft.uvs[2 * k]);
+            uv2.push_back(ft.uvs[2 * k + 1]);
+            if (has_norm) {
+              uvn2.push_back(ft.uvs_norm[2 * k]);
+              uvn2.push_back(ft.uvs_norm[2 * k + 1]);
+            }
+          }
+        ft.timestamps = ts2;
+        ft.uvs = uv2;
+        ft.uvs_norm = uvn2;
+        if (ts2.size() < 2) itx = feature_vec_extra.erase(itx);
+        else itx++;
+      }
+    }
+    collect(feature_vec_extra);
+    if (all_norm && !plane_feats.empty()) {
+      // :232-252 SLAM features of planes that are not in the state take part in the fit as constants
+      if (state->_options.use_plane_constraint_slamu) {
+        for (auto &lm : state->_features_SLAM) {
+          auto it = feat2plane.find(lm.first);
+          if (it == feat2plane.end() || state->_features_PLANE.count(it->second)) continue;
+          auto bad = state->_features_SLAM_to_PLANE.find(lm.first);
+          if (bad != state->_features_SLAM_to_PLANE.end() && bad->second == 0) continue;
+          auto fp = std::make_shared<ov_core::Feature>();
+          fp->featid = lm.first;
+          lm.second->get_xyz(false, fp->p_FinG);
+          plane_feats[it->second].push_back(fp);
+        }
+      }
+      // camera poses of the clones (:122-141): R_GtoCi = R_ItoC R_GtoIi, p_CiinG = p_IiinG - R_GtoCi^T p_IinC
+      PlaneFitting::ClonesCam clones_cam;
+      auto calib = state->_calib_IMUtoCAM.at(0);
+      for (const auto &cl : state->_clones_IMU) {
+        PlaneFitting::ClonePose cpose;
+        const double *Ri = cl.second->Rot(), *Rc = calib->Rot(), *pi = cl.second->pos(), *pc = calib->pos();
+        for (int i = 0; i < 3; ++i)
+          for (int k = 0; k < 3; ++k) cpose.R[3 * i + k] = Rc[3 * i] * Ri[k] + Rc[3 * i + 1] * Ri[3 + k] + Rc[3 * i + 2] * Ri[6 + k];
+        for (int i = 0; i < 3; ++i)
+          cpose.p[i] = pi[i] - (cpose.R[i] * pc[0] + cpose.R[3 + i] * pc[1] + cpose.R[6 + i] * pc[2]);
+        clones_cam[0][cl.first] = cpose;
+      }
+      const double focal_length = state->_cam_intrinsics.at(0)->value()(0);  // :269-272
+      const double sigma_px_norm = _options.sigma_pix / focal_length;
+      const double sigma_c = state->_options.sigma_constraint;
+      double stateI[7], calib0[7];
+      memcpy(stateI, state->_imu->quat(), 4 * sizeof(double));
+      memcpy(stateI + 4, state->_imu->pos(), 3 * sizeof(double));
+      memcpy(calib0, calib->quat(), 4 * sizeof(double));
+      memcpy(calib0 + 4, calib->pos(), 3 * sizeof(double));
+      for (auto &fp : plane_feats) {  // :262-401, std::map order
+        const size_t pid = fp.first;
+        fitted_planes.insert(pid);
+        auto &feats = fp.second;
+        double cp[3];
+        if (state->_features_PLANE.count(pid)) {  // :265-316
+          auto pl = state->_features_PLANE.at(pid);
+          for (int a = 0; a < 3; ++a) cp[a] = pl->value()(a);
+          if (state->_options.use_refine_plane_feat &&
+              !PlaneFitting::optimize_plane(feats, cp, clones_cam, sigma_px_norm, sigma_c, true, stateI, calib0))
+            continue;
+        } else {
+          if (feats.size() < 4) continue;  // :320-321
+          double abcd[4];
+          if (!PlaneFitting::plane_fitting(feats, abcd, state->_options.plane_msckf_min_feat, state->_options.plane_msckf_max_cond))
+            continue;  // :325-327
+          for (int a = 0; a < 3; ++a) cp[a] = -abcd[a] * abcd[3];  // :352
+          if (state->_options.use_refine_plane_feat &&
+              !PlaneFitting::optimize_plane(feats, cp, clones_cam, sigma_px_norm, sigma_c, false, stateI, calib0))
+            continue;  // :355-357
+          bool has_msckf_feat = false;  // :384-392
+          for (auto &ft : feats) has_msckf_feat = has_msckf_feat || !state->_features_SLAM.count(ft->featid);
+          if (!has_msckf_feat || feats.size() < 4) continue;  // :395-396
+        }
+        plane_estimates[pid] = {cp[0], cp[1], cp[2]};
+        for (auto &ft : feats) plane_feat_kept.insert(ft->featid);
+      }
+      // on-plane extra features that survived join the batch of the plane loop (plane_feats.at(planeid), :421)
+      for (auto &ft : feature_vec_extra)
+        if (plane_feat_kept.count(ft->featid) && plane_estimates.count(feat2plane.at(ft->featid))) feature_vec.push_back(ft);
+    }
+  }
+
   // ---- plane loop (:411-649) ----
   std::set<size_t> features_used_already;
   if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_msckf && !feat2plane.empty()) {
-    // planes that have an estimate: in the state, or handed over by the upstream fit
+    // planes that have an estimate: in the state (when no fit ran), fitted above, or handed over by the caller
     std::vector<size_t> plane_ids;
     for (const auto &fp : feat2plane)
       if (std::find(plane_ids.begin(), plane_ids.end(), fp.second) == plane_ids.end()) plane_ids.push_back(fp.second);
     std::sort(plane_ids.begin(), plane_ids.end());  // std::map iteration order of plane_estimates_cp_inG (:413)
     std::vector<size_t> used_planes;
-    for (size_t pid : plane_ids)
-      if (state->_features_PLANE.count(pid) || state->_plane_estimates_cp_inG.count(pid)) used_planes.push_back(pid);
+    for (size_t pid : plane_ids) {
+      const bool in_state = state->_features_PLANE.count(pid) > 0;
+      if (fitted_planes.empty() ? (in_state || plane_estimates.count(pid)) : plane_estimates.count(pid) > 0) used_planes.push_back(pid);
+    }
     if (!used_planes.empty()) {
       const int NP = (int)used_planes.size();
       std::vector<int> pof(feature_vec.size(), 0), sid(NP, -1);
@@ -757,12 +873,13 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
             cpfej[3 * k + a] = pl->fej()(a);
           }
         } else {
-          for (int a = 0; a < 3; ++a) cpv[3 * k + a] = cpfej[3 * k + a] = state->_plane_estimates_cp_inG.at(pid)[a];
+          for (int a = 0; a < 3; ++a) cpv[3 * k + a] = cpfej[3 * k + a] = plane_estimates.at(pid)[a];
         }
       }
       for (size_t f = 0; f < feature_vec.size(); ++f) {
         auto it = feat2plane.find(feature_vec[f]->featid);
         if (it == feat2plane.end()) continue;
+        if (fitted_planes.count(it->second) && !plane_feat_kept.count(feature_vec[f]->featid)) continue;  // not an inlier of the fit
         auto pos = std::find(used_planes.begin(), used_planes.end(), it->second);
         if (pos != used_planes.end()) pof[f] = 1 + (int)(pos - used_planes.begin());
       }

@@ -38,6 +38,13 @@ struct StateOptions {
   double sigma_plane_merge = 0.001;
   double plane_merge_chi2 = 1.00;
   double plane_merge_deg_max = 1.00;
+  bool use_refine_plane_feat = true;   // StateOptions.h: refine on-plane features and the plane with optimize_plane
+  bool use_groundtruths = false;
+  int plane_msckf_min_feat = 20;       // plane_fitting: minimum inliers (MSCKF planes), StateOptions.h:147
+  double plane_msckf_max_cond = 100.0; //                 condition number limit of the 5-point solve, :150
+  int plane_init_min_feat = 20;        // :141
+  double plane_init_max_cond = 100.0;  // :144
+  int planefit_shuffle_variant = 0;    // which libstdc++ the RANSAC permutations mimic (0: GCC <= 10, 1: GCC >= 11); not in the reference
   // capacity of the device context (not in the reference: Eigen resizes dynamically)
   int max_state_size = 320;
   int max_features = 8192;
@@ -51,6 +58,41 @@ struct UpdaterOptions {
 };
 
 class StateHelper;
+
+// track_plane/PlaneFitting.h:43-104.  Static like the reference; the device context of the most recently constructed State is
+// used (the reference has no such notion: Eigen / Ceres run on the caller's thread).
+class PlaneFitting {
+public:
+  // ext ov_core::FeatureInitializer::ClonePose: camera orientation R_GtoC and position p_CinG
+  struct ClonePose {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double p[3] = {0, 0, 0};
+    const double *Rot() const { return R; }
+    const double *pos() const { return p; }
+  };
+  typedef std::unordered_map<size_t, std::unordered_map<double, ClonePose>> ClonesCam;
+
+  static bool fit_plane(const std::vector<std::shared_ptr<ov_core::Feature>> &feats, double abcd[4], double cond_thresh = 200.0,
+                        bool cond_check = true);
+  static double point_to_plane_distance(const double point[3], const double abcd[4]) {
+    return point[0] * abcd[0] + point[1] * abcd[1] + point[2] * abcd[2] + abcd[3];
+  }
+  static bool plane_fitting(std::vector<std::shared_ptr<ov_core::Feature>> &feats, double plane_abcd[4], int min_inlier_num,
+                            double max_plane_solver_condition_number);
+  // stateI = [q_GtoI (JPL), p_IinG], calib0 = [q_ItoC, p_IinC]
+  static bool optimize_plane(std::vector<std::shared_ptr<ov_core::Feature>> &feats, double cp_inG[3], ClonesCam &clonesCAM,
+                             double sigma_px_norm, double sigma_c, bool fix_plane, const double stateI[7], const double calib0[7]);
+  // batched forms the updaters use: one launch for all planes
+  static void bind(ovp_ctx *gpu, int shuffle_variant) {
+    _gpu = gpu;
+    _variant = shuffle_variant;
+  }
+  static ovp_ctx *bound() { return _gpu; }
+
+private:
+  static ovp_ctx *_gpu;
+  static int _variant;
+};
 
 // state/State.h:48-135
 struct StateTestAccess;

@@ -22,10 +22,15 @@ def lib():
     return _LIB
 
 
-def run_msckf_update(sc, triangulate=False):
+def run_msckf_update(sc, triangulate=False, fit_planes=None):
     """Drives ov_plane::UpdaterMSCKF::update (C++ host classes over the C-ABI) on a synth.Scene.
-    triangulate=True: the features carry uvs_norm and no position; the updater triangulates them first."""
+    triangulate=True: the features carry uvs_norm and no position; the updater triangulates them first.
+    fit_planes=dict(min_feat, max_cond, variant): no plane estimates are handed over - the updater fits the planes that are
+    not in the state (PlaneFitting::plane_fitting) and refines planes and on-plane features (optimize_plane) itself."""
     L = lib()
+    if fit_planes is not None:
+        L.ovph_set_plane_fit.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
+        L.ovph_set_plane_fit(1, int(fit_planes["min_feat"]), float(fit_planes["max_cond"]), int(fit_planes.get("variant", 0)))
     uvn = np.ascontiguousarray(sc.uv_norm, dtype=np.float32) if triangulate else None
     L.ovph_set_uv_norm(uvn.ctypes.data_as(C.c_void_p) if triangulate else None)
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731

@@ -274,6 +274,8 @@ def make_scene(
     calib=True,
     min_meas=5,
     feat_seed=None,
+    px_noise=None,
+    err_scale=0.85,
 ):
     """Build one synthetic update-step input.
 
@@ -379,7 +381,7 @@ def make_scene(
     Lc = np.linalg.cholesky(P)
     # the filter is made slightly conservative (true error = 0.85 sigma) so that ~95 % of the features pass
     # the 0.95 chi-square gate at chi2_mult = 1 despite second-order effects
-    err = 0.85 * (Lc @ rng.standard_normal(N))
+    err = err_scale * (Lc @ rng.standard_normal(N))
 
     clone_q = np.zeros((C, 4))
     clone_p = np.zeros((C, 3))
@@ -408,7 +410,8 @@ def make_scene(
 
     # ---- measurements (truth + N(0, sigma_px)), stored as f32 ------------------------------------------
     uv_true, _ = project_all(p_f, R_true, p_true, R_ItoC_true, p_IinC_true, intr_true)
-    uv_noisy = uv_true + sigma_px * frng.standard_normal(uv_true.shape)
+    # px_noise: the tracker's actual noise when it differs from the sigma the filter assumes
+    uv_noisy = uv_true + (sigma_px if px_noise is None else px_noise) * frng.standard_normal(uv_true.shape)
     uv = np.zeros((F, C, 2), dtype=np.float32)
     for f in range(F):
         m = int(n_meas[f])

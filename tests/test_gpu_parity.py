@@ -876,3 +876,149 @@ def test_widened_rows_match_committed_golden_vectors(hiplib):
     assert (out["ok"] == g["plane_ok"]).all() and (out["new_ids"] == g["new_id"]).all() and (out["used"] == g["used"]).all()
     assert relP(ctx.cov_download(), g["P"]) < TOL_P
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plane fitting: PlaneFitting::plane_fitting / optimize_plane on the device against the restatement
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [0, 1])
+def test_plane_fitting_matches_oracle(hiplib, oracle, variant):
+    from ov_plane_amd.synth import make_planefit_problem
+
+    probs = [make_planefit_problem(seed=s, n_feats=nf, outliers=o) for s, nf, o in
+             [(1, 24, 3), (2, 40, 6), (3, 12, 0), (4, 9, 2), (5, 64, 10), (6, 130, 20)]]
+    pts = [pb["p_FinG"] for pb in probs]
+    rng = np.random.default_rng(0)
+    pts.append(probs[0]["p_FinG"][:4])                                  # fewer than min_inlier_num (:97-100)
+    pts.append(probs[0]["p_FinG"][:1] + 1e-3 * np.arange(8)[:, None])   # no five points 5 cm apart (:138-141)
+    pts.append(rng.uniform(-2, 2, (30, 3)) + [0, 0, 5])                 # scattered: no valid inlier set
+    fs = np.r_[0, np.cumsum([len(p) for p in pts])]
+    ctx = hiplib.Context(32, 2, 4)
+    out = ctx.plane_fitting(fs, np.concatenate(pts), 5, 200.0, variant)
+    n_ok = 0
+    for k, p in enumerate(pts):
+        ref = oracle.plane_fitting(p, 5, 200.0, variant)
+        assert bool(out["ok"][k]) == ref["ok"], k
+        inl = out["inlier"][fs[k]:fs[k + 1]]
+        assert (inl == ref["inlier"]).all(), k
+        if ref["ok"]:
+            n_ok += 1
+            assert np.abs(out["abcd"][k] - ref["abcd"]).max() < 1e-9
+    assert n_ok == 5  # (4, 9, 2): seven inliers are not more than 80 % of nine
+    ctx.close()
+
+
+def test_plane_optimize_matches_oracle(hiplib, oracle):
+    """One launch over a batch of planes: free and fixed planes, SLAM features, a plane that does not converge within the 12
+    iterations, one with too few features, one whose estimate is off.  Same success flags and iteration counts as the
+    restated Ceres loop, same kept sets, values equal to rounding."""
+    from ov_plane_amd.synth import make_planefit_problem
+
+    specs = [dict(seed=11, n_feats=10, n_obs=6), dict(seed=12, n_feats=16, n_obs=8, n_slam=2),
+             dict(seed=13, n_feats=8, n_obs=5, fix_plane=True), dict(seed=14, n_feats=5, n_obs=7, n_slam=1, fix_plane=True),
+             dict(seed=15, n_feats=30, n_obs=11, n_slam=3), dict(seed=16, n_feats=100, n_obs=11, ragged=True),
+             dict(seed=12, n_feats=16, n_obs=8, px_noise=1.0),       # NO_CONVERGENCE
+             dict(seed=21, n_feats=3),                               # too few features
+             dict(seed=23, n_feats=1, fix_plane=True, cp_noise=0.0, pt_noise=0.005),
+             dict(seed=24, n_feats=40, n_obs=9, px_noise=0.5, outliers=4)]
+    probs = [make_planefit_problem(**s) for s in specs]
+    bad = make_planefit_problem(seed=22, n_feats=10, fix_plane=True)
+    bad["cp"] = bad["cp"] * 1.2
+    probs.append(bad)
+    for pb in probs[1:]:  # the batch shares the current camera pose and the sigmas
+        for key in ("R_GtoI", "p_IinG", "R_ItoC", "p_IinC", "sigma_px_norm", "sigma_c"):
+            pb[key] = probs[0][key]
+    ctx = hiplib.Context(32, 2, 4)
+    outs = ctx.plane_optimize(probs)
+    n_ok = 0
+    for k, (pb, out) in enumerate(zip(probs, outs)):
+        ref = oracle.optimize_plane(pb)
+        assert out["ok"] == ref["ok"], k
+        assert out["iterations"] == ref["iterations"], (k, out["iterations"], ref["iterations"])
+        assert (out["kept"] == ref["kept"]).all(), k
+        assert np.abs(out["cp"] - ref["cp"]).max() < 1e-9, k
+        assert np.abs(out["p_FinG"] - ref["p_FinG"]).max() < 1e-9, k
+        n_ok += int(ref["ok"])
+    assert n_ok >= 7 and not outs[6]["ok"] and not outs[7]["ok"] and not outs[-1]["ok"]
+    ctx.close()
+
+
+def test_host_cpp_mirror_updater_msckf_fits_planes_first(hiplib, oracle):
+    """UpdaterMSCKF::update with nothing pre-computed (update/UpdaterMSCKF.cpp:120-400): triangulation, then for every plane
+    the refinement against the in-state plane or RANSAC fit + joint refinement, then the plane loop on the surviving on-plane
+    features and the point loop on the rest - composed here from the oracle pieces in the reference's order."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import Scene, quat_2_rot
+
+    fit = dict(min_feat=5, max_cond=200.0, variant=0)
+    # a filter whose window is accurate relative to the pixel sigma (as after a second of tracking): with reprojection
+    # residuals at the Cauchy scale optimize_plane does not converge within its 12 iterations and every plane is skipped
+    sc = make_scene(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0, px_noise=0.25, err_scale=0.05)
+    tri = oracle.triangulate(sc)
+    ok = tri["ok"]
+    p_tri = np.where(ok[:, None], tri["p_FinG"], sc.p_FinG)
+    R_ItoC, p_IinC = quat_2_rot(sc.calib_q), sc.calib_p
+    Rc = np.array([R_ItoC @ quat_2_rot(sc.clone_q[i]) for i in range(sc.C)])
+    pc = np.array([sc.clone_p[i] - Rc[i].T @ p_IinC for i in range(sc.C)])
+    uvn = np.asarray(sc.uv_norm, dtype=np.float32)
+    sc2 = Scene(sc)
+    sc2["p_FinG"] = p_tri.copy()
+    sc2["plane_id"] = sc.plane_id.copy()
+    sc2["cp"] = sc.cp.copy()
+    n_est = 0
+    for k in range(sc.cp.shape[0]):
+        feats = np.where((sc.plane_id == k + 1) & ok)[0]
+
+        def problem(sel, cp, fixp):
+            n_obs = sc.n_meas[sel].astype(np.int32)
+            rows = [(f, j) for f in sel for j in range(sc.n_meas[f])]
+            ci = np.array([sc.clone_idx[f, j] for f, j in rows], dtype=int)
+            return dict(n_feats=len(sel), p_FinG=sc2["p_FinG"][sel], n_obs=n_obs,
+                        obs_start=np.r_[0, np.cumsum(n_obs)[:-1]].astype(np.int32),
+                        uv_norm=np.array([uvn[f, j] for f, j in rows], dtype=np.float64).reshape(-1, 2),
+                        R_GtoC=Rc[ci].reshape(-1, 9), p_CinG=pc[ci], cp=cp, fix_plane=fixp,
+                        sigma_px_norm=sc.opts["sigma_px"] / sc.intr[0], sigma_c=sc.opts["sigma_c"],
+                        R_GtoI=quat_2_rot(sc.clone_q[-1]), p_IinG=sc.clone_p[-1], R_ItoC=R_ItoC, p_IinC=p_IinC)
+
+        keep, cp = None, None
+        if sc.plane_in_state[k]:
+            res = oracle.optimize_plane(problem(feats, sc.cp[k], True))
+            if res["ok"]:
+                keep, cp = feats[res["kept"]], sc.cp[k]
+        elif len(feats) >= 4:
+            fitr = oracle.plane_fitting(sc2["p_FinG"][feats], fit["min_feat"], fit["max_cond"], fit["variant"])
+            if fitr["ok"]:
+                sel = feats[fitr["inlier"]]
+                res = oracle.optimize_plane(problem(sel, -fitr["abcd"][:3] * fitr["abcd"][3], False))
+                if res["ok"] and res["n_kept"] >= 4:
+                    keep, cp = sel[res["kept"]], res["cp"]
+        drop = feats if keep is None else np.setdiff1d(feats, keep)
+        sc2["plane_id"][drop] = 0  # not part of the plane update: ordinary MSCKF features of the point loop
+        if keep is not None:
+            n_est += 1
+            sc2["p_FinG"][keep] = res["p_FinG"][res["kept"]]
+            if not sc.plane_in_state[k]:
+                sc2["cp"][k] = cp
+                sc2["cp_fej"][k] = cp
+    assert n_est >= 2  # the scenario exercises both kinds of planes
+    sc2["plane_id"][~ok] = 0
+    good = np.where(ok)[0]
+    # plane loop + point loop of the oracle on the surviving features
+    sub = Scene(sc2)
+    for key in ("uv", "clone_idx", "n_meas", "p_FinG", "plane_id"):
+        sub[key] = sc2[key][good]
+    sub["F"] = len(good)
+    ref = _oracle_full_update(oracle, sub)
+    out = hostlib.run_msckf_update(sc, triangulate=True, fit_planes=fit)
+    exp_used = np.zeros(sc.F, dtype=bool)
+    exp_used[good[ref["used"]]] = True
+    exp_kept = np.zeros(sc.F, dtype=bool)
+    exp_kept[good[ref["kept"]]] = True
+    assert (out["used"] == exp_used).all() and exp_used.sum() > 20
+    assert (out["kept"] == exp_kept).all()
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(out["cp_state"] - ref["cp"][sc.plane_in_state]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
