@@ -337,7 +337,14 @@ std::vector<std::shared_ptr<ov_core::Feature>> make_features(const HarnessState 
       ft->uvs.push_back(uv[((size_t)f * M + k) * 2]);
       ft->uvs.push_back(uv[((size_t)f * M + k) * 2 + 1]);
     }
-    if (p_FinG) memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+    if (g_uv_norm) {  // features as the tracker hands them over: normalised measurements, no position yet
+      for (int k = 0; k < n_meas[f]; ++k) {
+        ft->uvs_norm.push_back(g_uv_norm[((size_t)f * M + k) * 2]);
+        ft->uvs_norm.push_back(g_uv_norm[((size_t)f * M + k) * 2 + 1]);
+      }
+    } else if (p_FinG) {
+      memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+    }
     fv.push_back(ft);
   }
   return fv;
@@ -386,6 +393,11 @@ extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const do
   so.sigma_constraint = sigma_c;
   so.const_init_multi = const_init_multi;
   so.const_init_chi2 = const_init_chi2;
+  if (g_fit_planes) {
+    so.plane_init_min_feat = g_fit_min_feat;
+    so.plane_init_max_cond = g_fit_max_cond;
+    so.planefit_shuffle_variant = g_fit_variant;
+  }
   so.max_state_size = n_cap;
   so.max_features = F + 8;
   HarnessState hs;
@@ -418,11 +430,14 @@ extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const do
       memcpy(out_new_p + 3 * f, it->second->value().data(), 3 * sizeof(double));
     }
   } else {
-    for (int k = 0; k < n_planes_out; ++k)
-      state->_plane_estimates_cp_inG[(size_t)(k + 1)] = {cp_out_est[3 * k], cp_out_est[3 * k + 1], cp_out_est[3 * k + 2]};
+    if (!g_fit_planes)  // otherwise init_vio_plane triangulates, fits and refines itself (UpdaterPlane.cpp:76-290)
+      for (int k = 0; k < n_planes_out; ++k)
+        state->_plane_estimates_cp_inG[(size_t)(k + 1)] = {cp_out_est[3 * k], cp_out_est[3 * k + 1], cp_out_est[3 * k + 2]};
     UpdaterPlane up(uo, fio);
     std::vector<std::shared_ptr<ov_core::Feature>> used;
     up.init_vio_plane(state, fv, used, feat2plane);
+    g_fit_planes = 0;
+    g_uv_norm = nullptr;
     for (int k = 0; k < n_planes_out; ++k) {
       out_new_id[k] = -1;
       auto it = state->_features_PLANE.find((size_t)(k + 1));

@@ -38,6 +38,7 @@ struct StateOptions {
   double sigma_plane_merge = 0.001;
   double plane_merge_chi2 = 1.00;
   double plane_merge_deg_max = 1.00;
+  int max_msckf_plane = 20;            // StateOptions.h:123
   bool use_refine_plane_feat = true;   // StateOptions.h: refine on-plane features and the plane with optimize_plane
   bool use_groundtruths = false;
   int plane_msckf_min_feat = 20;       // plane_fitting: minimum inliers (MSCKF planes), StateOptions.h:147
@@ -206,8 +207,9 @@ protected:
 class UpdaterPlane {
 public:
   UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerOptions &feat_init_options);
-  // update/UpdaterPlane.cpp:61-481 downstream of triangulation / plane fitting: planes with an estimate in
-  // state->_plane_estimates_cp_inG that are not in the state yet are initialised from their on-plane MSCKF features.
+  // update/UpdaterPlane.cpp:61-481.  Without estimates in state->_plane_estimates_cp_inG the planes that are not in the state
+  // are triangulated, fitted and refined here (:76-290) and then initialised from their surviving on-plane MSCKF features;
+  // with estimates (pre-fitted entry point) only the initialisation runs.
   void init_vio_plane(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                       std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane);
   // update/UpdaterPlane.cpp:483-517 / :519-552: the UpdaterHelper operations with the plane Jacobian H_cp carried along
@@ -216,6 +218,7 @@ public:
 
 protected:
   UpdaterOptions _options;
+  ov_core::FeatureInitializerOptions _featinit;
 };
 
 // update/UpdaterMSCKF.h:49-91

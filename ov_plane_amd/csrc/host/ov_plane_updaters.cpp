@@ -267,16 +267,22 @@ UpdaterSLAM::UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_a
 }
 
 static void clean_old_measurements(ov_core::Feature &ft, const std::map<double, std::shared_ptr<PoseJPL>> &clones) {
-  std::vector<float> uv2;
+  std::vector<float> uv2, uvn2;
   std::vector<double> ts2;
+  const bool has_norm = ft.uvs_norm.size() == ft.uvs.size();
   for (size_t k = 0; k < ft.timestamps.size(); ++k)
     if (clones.count(ft.timestamps[k])) {
       ts2.push_back(ft.timestamps[k]);
       uv2.push_back(ft.uvs[2 * k]);
       uv2.push_back(ft.uvs[2 * k + 1]);
+      if (has_norm) {
+        uvn2.push_back(ft.uvs_norm[2 * k]);
+        uvn2.push_back(ft.uvs_norm[2 * k + 1]);
+      }
     }
   ft.timestamps = ts2;
   ft.uvs = uv2;
+  ft.uvs_norm = uvn2;
 }
 
 static double chi2_host(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &order, const MatrixXd &H, const VectorXd &res) {
@@ -505,7 +511,8 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
 }
 
 // ---- update/UpdaterPlane.cpp ---------------------------------------------------------------------
-UpdaterPlane::UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerOptions &) : _options(options) {
+UpdaterPlane::UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerOptions &feat_init_options)
+    : _options(options), _featinit(feat_init_options) {
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
 }
 
@@ -546,19 +553,13 @@ void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std:
                                   std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used,
                                   const std::map<size_t, size_t> &feat2plane) {
   if (feature_vec.empty() || feat2plane.empty()) return;
-  // planes with an upstream estimate that are not in the state yet, ascending id (:297 iterates a std::map)
-  std::vector<size_t> todo;
-  for (const auto &pe : state->_plane_estimates_cp_inG)
-    if (state->_features_PLANE.find(pe.first) == state->_features_PLANE.end()) todo.push_back(pe.first);
-  if (todo.empty()) return;
   std::map<double, int> clone_slot;
   std::vector<std::shared_ptr<PoseJPL>> clones;
   for (const auto &c : state->_clones_IMU) {
     clone_slot[c.first] = (int)clones.size();
     clones.push_back(c.second);
   }
-  for (auto &f : feature_vec) clean_old_measurements(*f, state->_clones_IMU);
-  const int C = (int)clones.size(), F = (int)feature_vec.size();
+  const int C = (int)clones.size();
   std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
   std::vector<int> cid(C);
   for (int i = 0; i < C; ++i) {
@@ -584,27 +585,148 @@ void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std:
   memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
   st.intr_id = intr->id();
   gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
-  int M = 1;
-  for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
-  std::vector<float> uv((size_t)F * M * 2, 0.f);
-  std::vector<int> cidx((size_t)F * M, -1), nm(F), pof(F, 0);
-  std::vector<double> pf((size_t)F * 3);
-  for (int f = 0; f < F; ++f) {
-    nm[f] = (int)feature_vec[f]->timestamps.size();
-    for (int k = 0; k < nm[f]; ++k) {
-      cidx[(size_t)f * M + k] = clone_slot.at(feature_vec[f]->timestamps[k]);
-      uv[((size_t)f * M + k) * 2] = feature_vec[f]->uvs[2 * k];
-      uv[((size_t)f * M + k) * 2 + 1] = feature_vec[f]->uvs[2 * k + 1];
+  auto upload = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv, int &M_out) {
+    const int Fn = (int)fv.size();
+    int Mx = 1;
+    for (auto &f : fv) Mx = std::max(Mx, (int)f->timestamps.size());
+    std::vector<float> uvb((size_t)Fn * Mx * 2, 0.f);
+    std::vector<int> cidxb((size_t)Fn * Mx, -1), nmb(Fn);
+    std::vector<double> pfb((size_t)Fn * 3);
+    for (int f = 0; f < Fn; ++f) {
+      nmb[f] = (int)fv[f]->timestamps.size();
+      for (int k = 0; k < nmb[f]; ++k) {
+        cidxb[(size_t)f * Mx + k] = clone_slot.at(fv[f]->timestamps[k]);
+        uvb[((size_t)f * Mx + k) * 2] = fv[f]->uvs[2 * k];
+        uvb[((size_t)f * Mx + k) * 2 + 1] = fv[f]->uvs[2 * k + 1];
+      }
+      memcpy(&pfb[3 * f], fv[f]->p_FinG, 3 * sizeof(double));
     }
-    memcpy(&pf[3 * f], feature_vec[f]->p_FinG, 3 * sizeof(double));
+    ovp_feature_batch fbb{Fn, Mx, uvb.data(), cidxb.data(), nmb.data(), pfb.data()};
+    gpu_check2(ovp_batch_upload(state->_gpu, &fbb), "ovp_batch_upload");
+    M_out = Mx;
+  };
+
+  // planes to initialise, ascending id (:297 iterates a std::map), and the features each of them may use
+  std::vector<size_t> todo;
+  std::set<size_t> fit_kept;  // features that survived plane_fitting / optimize_plane (fit path only)
+  bool fitted = false;
+  if (!state->_plane_estimates_cp_inG.empty()) {
+    // pre-fitted entry point: the caller ran the fit (or owns better estimates)
+    for (const auto &pe : state->_plane_estimates_cp_inG)
+      if (state->_features_PLANE.find(pe.first) == state->_features_PLANE.end()) todo.push_back(pe.first);
+    for (auto &f : feature_vec) clean_old_measurements(*f, state->_clones_IMU);
+  } else {
+    fitted = true;
+    // :76-107 on-plane features of planes that are not in the state, with at least two measurements in the window
+    std::vector<std::shared_ptr<ov_core::Feature>> valid;
+    auto it0 = feature_vec.begin();
+    while (it0 != feature_vec.end()) {
+      auto fp = feat2plane.find((*it0)->featid);
+      if (fp == feat2plane.end() || state->_features_PLANE.count(fp->second)) {
+        clean_old_measurements(**it0, state->_clones_IMU);  // (the batch below needs window measurements only)
+        it0++;
+        continue;
+      }
+      clean_old_measurements(**it0, state->_clones_IMU);
+      if ((*it0)->timestamps.size() < 2) {
+        it0 = feature_vec.erase(it0);
+      } else {
+        valid.push_back(*it0);
+        it0++;
+      }
+    }
+    // :126-149 triangulate + refine; failures only leave the candidate set
+    bool any_norm = false;
+    for (auto &f : valid) any_norm = any_norm || (!f->uvs_norm.empty() && f->uvs_norm.size() == f->uvs.size());
+    if (any_norm && !valid.empty()) {
+      int Mv = 1;
+      upload(valid, Mv);
+      const int Fv = (int)valid.size();
+      std::vector<float> uvn((size_t)Fv * Mv * 2, 0.f);
+      for (int f = 0; f < Fv; ++f)
+        for (size_t k = 0; k < valid[f]->uvs_norm.size(); ++k) uvn[(size_t)f * Mv * 2 + k] = valid[f]->uvs_norm[k];
+      ovp_triang_opts to;
+      to.refine_features = _featinit.refine_features ? 1 : 0;
+      to.max_runs = _featinit.max_runs;
+      to.init_lamda = _featinit.init_lamda;
+      to.max_lamda = _featinit.max_lamda;
+      to.min_dx = _featinit.min_dx;
+      to.min_dcost = _featinit.min_dcost;
+      to.lam_mult = _featinit.lam_mult;
+      to.min_dist = _featinit.min_dist;
+      to.max_dist = _featinit.max_dist;
+      to.max_baseline = _featinit.max_baseline;
+      to.max_cond_number = _featinit.max_cond_number;
+      std::vector<double> pfv((size_t)Fv * 3);
+      std::vector<uint8_t> okv(Fv, 0);
+      gpu_check2(ovp_triangulate(state->_gpu, &to, uvn.data(), pfv.data(), okv.data()), "ovp_triangulate");
+      std::vector<std::shared_ptr<ov_core::Feature>> good;
+      for (int f = 0; f < Fv; ++f) {
+        const bool had_norm = !valid[f]->uvs_norm.empty();
+        if (had_norm && !okv[f]) continue;
+        if (had_norm) memcpy(valid[f]->p_FinG, &pfv[3 * f], 3 * sizeof(double));
+        good.push_back(valid[f]);
+      }
+      valid = good;
+    }
+    // :167-176 shortest tracks first (std::sort like the reference: the order of equal tracks is libstdc++'s)
+    std::sort(valid.begin(), valid.end(), [](const std::shared_ptr<ov_core::Feature> &a, const std::shared_ptr<ov_core::Feature> &b) {
+      return a->timestamps.size() < b->timestamps.size();
+    });
+    // :179-196
+    std::map<size_t, size_t> plane_feat_count;
+    std::map<size_t, std::vector<std::shared_ptr<ov_core::Feature>>> plane_feats;
+    for (auto &feat : valid) {
+      const size_t planeid = feat2plane.at(feat->featid);
+      if ((int)plane_feat_count[planeid] > state->_options.max_msckf_plane) continue;
+      plane_feat_count[planeid]++;
+      plane_feats[planeid].push_back(feat);
+    }
+    // :221-290 initial guess of every plane: RANSAC fit, then joint refinement with its features
+    PlaneFitting::ClonesCam clones_cam;
+    for (const auto &cl : state->_clones_IMU) {
+      PlaneFitting::ClonePose cpose;
+      const double *Ri = cl.second->Rot(), *Rc = calib->Rot(), *pi = cl.second->pos(), *pc = calib->pos();
+      for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) cpose.R[3 * i + k] = Rc[3 * i] * Ri[k] + Rc[3 * i + 1] * Ri[3 + k] + Rc[3 * i + 2] * Ri[6 + k];
+      for (int i = 0; i < 3; ++i) cpose.p[i] = pi[i] - (cpose.R[i] * pc[0] + cpose.R[3 + i] * pc[1] + cpose.R[6 + i] * pc[2]);
+      clones_cam[0][cl.first] = cpose;
+    }
+    const double sigma_px_norm = _options.sigma_pix / intr->value()(0);
+    double stateI[7], calib0[7];
+    memcpy(stateI, state->_imu->quat(), 4 * sizeof(double));
+    memcpy(stateI + 4, state->_imu->pos(), 3 * sizeof(double));
+    memcpy(calib0, calib->quat(), 4 * sizeof(double));
+    memcpy(calib0 + 4, calib->pos(), 3 * sizeof(double));
+    for (auto &fp : plane_feats) {
+      bool all_norm = true;
+      for (auto &ft : fp.second) all_norm = all_norm && (ft->uvs_norm.size() == 2 * ft->timestamps.size());
+      if (!all_norm) continue;  // optimize_plane needs the normalised measurements
+      double abcd[4];
+      if (!PlaneFitting::plane_fitting(fp.second, abcd, state->_options.plane_init_min_feat, state->_options.plane_init_max_cond)) continue;
+      double cp0[3] = {-abcd[0] * abcd[3], -abcd[1] * abcd[3], -abcd[2] * abcd[3]};
+      if (!PlaneFitting::optimize_plane(fp.second, cp0, clones_cam, sigma_px_norm, state->_options.sigma_constraint, false, stateI, calib0))
+        continue;
+      state->_plane_estimates_cp_inG[fp.first] = {cp0[0], cp0[1], cp0[2]};
+      todo.push_back(fp.first);
+      for (auto &ft : fp.second) fit_kept.insert(ft->featid);
+    }
+  }
+  if (todo.empty()) {
+    if (fitted) state->_plane_estimates_cp_inG.clear();
+    return;
+  }
+  const int F = (int)feature_vec.size();
+  int M = 1;
+  upload(feature_vec, M);
+  std::vector<int> pof(F, 0);
+  for (int f = 0; f < F; ++f) {
     auto it = feat2plane.find(feature_vec[f]->featid);
     if (it != feat2plane.end()) {
       auto pos = std::find(todo.begin(), todo.end(), it->second);
-      if (pos != todo.end()) pof[f] = 1 + (int)(pos - todo.begin());
+      if (pos != todo.end() && (!fitted || fit_kept.count(feature_vec[f]->featid))) pof[f] = 1 + (int)(pos - todo.begin());
     }
   }
-  ovp_feature_batch fb{F, M, uv.data(), cidx.data(), nm.data(), pf.data()};
-  gpu_check2(ovp_batch_upload(state->_gpu, &fb), "ovp_batch_upload");
   const int NP = (int)todo.size();
   std::vector<double> cpv(3 * NP), cpn(3 * NP);
   std::vector<int> sid(NP, -1), nid(NP, -1);
@@ -644,6 +766,7 @@ void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std:
     state->_variables.push_back(plane);
     state->_features_PLANE.insert({todo[k], plane});
   }
+  if (fitted) state->_plane_estimates_cp_inG.clear();  // the fit path's estimates are local to this call (:220)
   // :459-475 features consumed by an initialised plane leave the MSCKF vector
   auto it = feature_vec.begin();
   size_t f = 0;

@@ -96,8 +96,10 @@ def run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, new_value0):
     return out
 
 
-def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0):
+def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=None):
     """Drives the C++ host mirrors on a synth scene.
+    fit_planes=dict(min_feat, max_cond, variant) (mode "plane_init" only): the features carry normalised measurements and
+    no position, no plane estimates are handed over - init_vio_plane triangulates, fits and refines itself.
 
     mode "slam_update": UpdaterSLAM::update on a synth.make_slam_scene (feature f observes landmark f);
     mode "slam_delayed_init": UpdaterSLAM::delayed_init on a plain scene (every feature is a landmark candidate);
@@ -105,6 +107,13 @@ def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0):
     """
     L = lib()
     m = {"slam_update": 0, "slam_delayed_init": 1, "plane_init": 2}[mode]
+    uvn_keep = None
+    if fit_planes is not None:
+        assert m == 2
+        uvn_keep = np.ascontiguousarray(sc.uv_norm, dtype=np.float32)
+        L.ovph_set_uv_norm(uvn_keep.ctypes.data_as(C.c_void_p))
+        L.ovph_set_plane_fit.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
+        L.ovph_set_plane_fit(1, int(fit_planes["min_feat"]), float(fit_planes["max_cond"]), int(fit_planes.get("variant", 0)))
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     N, F, M = int(sc.N), int(sc.F), int(sc.uv.shape[1])

@@ -1022,3 +1022,65 @@ def test_host_cpp_mirror_updater_msckf_fits_planes_first(hiplib, oracle):
     assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
     assert np.abs(out["cp_state"] - ref["cp"][sc.plane_in_state]).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
+
+
+def test_host_cpp_mirror_plane_init_fits_planes_first(hiplib, oracle):
+    """UpdaterPlane::init_vio_plane with nothing pre-computed (update/UpdaterPlane.cpp:76-481): triangulation of the on-plane
+    candidates, RANSAC fit + joint refinement per plane, then the initialisation from the surviving features.  Sixteen
+    candidates keep the reference's std::sort by track length a stable insertion sort."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import Scene, quat_2_rot
+
+    fit = dict(min_feat=5, max_cond=200.0, variant=0)
+    sc = make_scene(C=10, F=16, seed=34, n_planes=2, feats_per_plane=8, planes_in_state_frac=0.0, chi2_mult=1.0,
+                    px_noise=0.25, err_scale=0.05)
+    assert (sc.plane_id > 0).all()
+    tri = oracle.triangulate(sc)
+    ok = tri["ok"]
+    R_ItoC, p_IinC = quat_2_rot(sc.calib_q), sc.calib_p
+    Rc = np.array([R_ItoC @ quat_2_rot(sc.clone_q[i]) for i in range(sc.C)])
+    pc = np.array([sc.clone_p[i] - Rc[i].T @ p_IinC for i in range(sc.C)])
+    uvn = np.asarray(sc.uv_norm, dtype=np.float32)
+    sc2 = Scene(sc)
+    sc2["p_FinG"] = np.where(ok[:, None], tri["p_FinG"], sc.p_FinG)
+    sc2["plane_id"] = sc.plane_id.copy()
+    sc2["cp"] = sc.cp.copy()
+    order = np.argsort(sc.n_meas, kind="stable")  # :167-176
+    n_est = 0
+    for k in range(2):
+        feats = np.array([f for f in order if sc.plane_id[f] == k + 1 and ok[f]], dtype=int)
+        keep = None
+        fitr = oracle.plane_fitting(sc2["p_FinG"][feats], fit["min_feat"], fit["max_cond"], fit["variant"])
+        if fitr["ok"]:
+            sel = feats[fitr["inlier"]]
+            n_obs = sc.n_meas[sel].astype(np.int32)
+            rows = [(f, j) for f in sel for j in range(sc.n_meas[f])]
+            ci = np.array([sc.clone_idx[f, j] for f, j in rows], dtype=int)
+            pb = dict(n_feats=len(sel), p_FinG=sc2["p_FinG"][sel], n_obs=n_obs,
+                      obs_start=np.r_[0, np.cumsum(n_obs)[:-1]].astype(np.int32),
+                      uv_norm=np.array([uvn[f, j] for f, j in rows], dtype=np.float64).reshape(-1, 2),
+                      R_GtoC=Rc[ci].reshape(-1, 9), p_CinG=pc[ci], cp=-fitr["abcd"][:3] * fitr["abcd"][3], fix_plane=False,
+                      sigma_px_norm=sc.opts["sigma_px"] / sc.intr[0], sigma_c=sc.opts["sigma_c"],
+                      R_GtoI=quat_2_rot(sc.clone_q[-1]), p_IinG=sc.clone_p[-1], R_ItoC=R_ItoC, p_IinC=p_IinC)
+            res = oracle.optimize_plane(pb)
+            if res["ok"]:
+                keep = sel[res["kept"]]
+                sc2["p_FinG"][keep] = res["p_FinG"][res["kept"]]
+                sc2["cp"][k] = res["cp"]
+                sc2["cp_fej"][k] = res["cp"]
+                n_est += 1
+        drop = np.where(sc.plane_id == k + 1)[0] if keep is None else np.setdiff1d(np.where(sc.plane_id == k + 1)[0], keep)
+        sc2["plane_id"][drop] = 0
+    assert n_est == 2
+    ref = oracle.plane_init(sc2, const_init_multi=5.0, const_init_chi2=1.0)
+    out = hostlib.run_updater(sc, "plane_init", 5.0, 1.0, fit_planes=fit)
+    assert ref["plane_ok"].all()
+    assert out["n"] == ref["n"]
+    assert (out["new_id"][:2] == ref["new_id"]).all()
+    assert np.abs(out["new_p"][:2] - ref["cp"]).max() < TOL_DX
+    assert (out["deleted"] == ref["used"]).all()
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
