@@ -746,3 +746,118 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
   memcpy(out_P, Pn.data(), sizeof(double) * (size_t)N * N);
   return 0;
 }
+
+
+// ---- on-disk formats (ov_plane_io.h) ---------------------------------------------------------------------------------
+#include "ov_plane_io.h"
+
+#include <fstream>
+#include <sstream>
+
+// no device needed: timing CSV (header + one row) into buf; returns the length
+extern "C" int ovph_format_timing(int use_plane, int max_slam, const double *vals9, char *buf, int cap) {
+  ov_plane::StateOptions so;
+  so.use_plane_constraint = use_plane != 0;
+  so.max_slam_features = max_slam;
+  ov_plane::TimingRecord r;
+  r.timestamp_inI = vals9[0];
+  r.track = vals9[1];
+  r.prop = vals9[2];
+  r.planeinit = vals9[3];
+  r.msckf = vals9[4];
+  r.slam_update = vals9[5];
+  r.slam_delay = vals9[6];
+  r.marg = vals9[7];
+  r.total = vals9[8];
+  std::ostringstream os;
+  ov_plane::write_timing_header(os, so);
+  ov_plane::write_timing_row(os, so, r);
+  const std::string s = os.str();
+  if ((int)s.size() + 1 > cap) return -1;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
+// no device needed: returns the number of poses (<= cap) copied to out [cap][8], or -1
+extern "C" int ovph_load_trajectory(const char *path, double *out, int cap) {
+  std::vector<std::array<double, 8>> poses;
+  if (!ov_plane::load_trajectory(path, poses)) return -1;
+  const int n = std::min((int)poses.size(), cap);
+  for (int i = 0; i < n; ++i) memcpy(out + 8 * i, poses[i].data(), 8 * sizeof(double));
+  return (int)poses.size();
+}
+
+// no device needed: reads every frame of `in` with the C++ reader and writes it back to `out` with the C++ writer
+extern "C" int ovph_trace_copy(const char *in, const char *out) {
+  std::ifstream is(in, std::ios::binary);
+  std::ofstream os(out, std::ios::binary);
+  if (!is.is_open() || !os.is_open()) return -1;
+  int n = 0;
+  ov_plane::FrameTrace f;
+  while (is.peek() != EOF) {
+    if (!ov_plane::read_frame_trace(is, f, n == 0)) return -2;
+    if (!ov_plane::write_frame_trace(os, f, n == 0)) return -3;
+    ++n;
+  }
+  return n;
+}
+
+// needs the device: a state as ovph_run_msckf_update builds it (no planes), one line of each of the three files
+extern "C" int ovph_format_state_files(int C, const double *clone_q, const double *clone_p, const double *calib_q, const double *calib_p,
+                                       const double *intr, int N, const double *P, double timestamp, double dt, int with_gt,
+                                       char *est, char *sd, char *gt, int cap) {
+  using namespace ov_plane;
+  StateOptions so;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.max_state_size = N + 8;
+  so.max_features = 16;
+  auto state = std::make_shared<State>(so);
+  {
+    VectorXd v(7, 1);
+    for (int k = 0; k < 4; ++k) v(k) = calib_q[k];
+    for (int k = 0; k < 3; ++k) v(4 + k) = calib_p[k];
+    state->_calib_IMUtoCAM.at(0)->set_value(v);
+    VectorXd iv(8, 1);
+    for (int k = 0; k < 8; ++k) iv(k) = intr[k];
+    state->_cam_intrinsics.at(0)->set_value(iv);
+    VectorXd d(1, 1);
+    d(0) = dt;
+    state->_calib_dt_CAMtoIMU->set_value(d);
+  }
+  const double w0[3] = {0, 0, 0};
+  for (int i = 0; i < C; ++i) {
+    VectorXd v(7, 1);
+    for (int k = 0; k < 4; ++k) v(k) = clone_q[4 * i + k];
+    for (int k = 0; k < 3; ++k) v(4 + k) = clone_p[3 * i + k];
+    state->_imu->pose()->set_value(v);
+    state->_timestamp = 100.0 + 0.1 * i;
+    StateHelper::augment_clone(state, w0);
+  }
+  state->_timestamp = timestamp;
+  if (state->max_covariance_size() != N) return -11;
+  {
+    std::vector<std::shared_ptr<Type>> order;
+    order.push_back(state->_imu);
+    order.push_back(state->_calib_dt_CAMtoIMU);
+    order.push_back(state->_calib_IMUtoCAM.at(0));
+    order.push_back(state->_cam_intrinsics.at(0));
+    for (auto &c : state->_clones_IMU) order.push_back(c.second);
+    MatrixXd Pm(N, N);
+    memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+    StateHelper::set_initial_covariance(state, Pm, order);
+  }
+  SimTruth sim;
+  for (int k = 0; k < 17; ++k) sim.state_gt[k] = 0.5 + 0.125 * k;
+  sim.calib_camimu_dt = 0.0123456;
+  for (int k = 0; k < 8; ++k) sim.intrinsics[k] = intr[k] + 1.0;
+  for (int k = 0; k < 7; ++k) sim.extrinsics[k] = 0.1 * (k + 1);
+  std::ostringstream oe, os, og;
+  ROSVisualizerHelper::sim_save_total_state_to_file(state, with_gt ? &sim : nullptr, oe, os, og);
+  const std::string a = oe.str(), b = os.str(), c = og.str();
+  if ((int)a.size() + 1 > cap || (int)b.size() + 1 > cap || (int)c.size() + 1 > cap) return -1;
+  memcpy(est, a.c_str(), a.size() + 1);
+  memcpy(sd, b.c_str(), b.size() + 1);
+  memcpy(gt, c.c_str(), c.size() + 1);
+  return 0;
+}

@@ -86,3 +86,9 @@ if __name__ == "__main__":
     for name in WIDE_NAMES:
         np.savez_compressed(os.path.join(HERE, "wide_%s.npz" % name), **wide_outputs(name))
         print("wide", name)
+    # a replayable frame in the binary trace format (ov_plane_amd/trace.py): inputs + the oracle's outputs
+    from ov_plane_amd import trace
+
+    sc = make_scene(seed=3, C=6, F=40, chi2_mult=1.0)
+    trace.write_frames(os.path.join(HERE, "trace_c6.ovptrc"), [trace.frame_from_scene(sc, pyoracle.msckf_point_update(sc), 103.0)])
+    print("trace_c6.ovptrc")

@@ -1,0 +1,79 @@
+"""On-disk formats that need no device: timing CSV, trajectory input, per-frame binary trace."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ov_plane_amd import trace
+from ov_plane_amd.synth import make_scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def host():
+    from ov_plane_amd.build import build_host, build_lib
+
+    build_lib()
+    build_host()
+    from ov_plane_amd import hostlib
+
+    return hostlib.lib()
+
+
+@pytest.mark.parametrize("use_plane,max_slam", [(1, 25), (0, 25), (1, 0), (0, 0)])
+def test_timing_csv_matches_the_reference_layout(host, use_plane, max_slam):
+    # core/VioManager.cpp:110-118 (header) and :911-927 (rows): 15 digits for the time stamp, 5 for the durations
+    v = np.array([1403715273.262142, 0.0123456, 0.00034, 0.0021, 0.0305, 0.0041, 0.0007, 0.0012, 0.0522])
+    buf = C.create_string_buffer(1024)
+    n = host.ovph_format_timing(use_plane, max_slam, v.ctypes.data_as(C.c_void_p), buf, 1024)
+    assert n > 0
+    head = "# timestamp (sec),tracking,propagation," + ("plane init," if use_plane else "") + "msckf update," + (
+        "slam update,slam delayed," if max_slam > 0 else "") + "re-tri & marg,total\n"
+    cols = ["%.15f" % v[0], "%.5f" % v[1], "%.5f" % v[2]] + (["%.5f" % v[3]] if use_plane else []) + ["%.5f" % v[4]] + (
+        ["%.5f" % v[5], "%.5f" % v[6]] if max_slam > 0 else []) + ["%.5f" % v[7], "%.5f" % v[8]]
+    assert buf.value.decode() == head + ",".join(cols) + "\n"
+
+
+def test_trajectory_loader(host, tmp_path):
+    p = tmp_path / "traj.txt"
+    rows = np.array([[1550864017.67095, -5.69716, 0.818541, 1.01392, -0.708047, -0.037029, -0.704376, 0.033938],
+                     [1550864017.72091, -5.69707, 0.818426, 1.01395, -0.708236, -0.037202, -0.704173, 0.034032]])
+    with open(p, "w") as fh:
+        fh.write("# timestamp(s) tx ty tz qx qy qz qw\n")  # header of data/udel_arl_short.txt
+        for r in rows:
+            fh.write("%.5f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n" % tuple(r))
+    out = np.zeros((4, 8))
+    n = host.ovph_load_trajectory(str(p).encode(), out.ctypes.data_as(C.c_void_p), 4)
+    assert n == 2 and np.allclose(out[:2], rows, atol=1e-9)
+    assert host.ovph_load_trajectory(b"/nonexistent", out.ctypes.data_as(C.c_void_p), 4) == -1
+
+
+def test_frame_trace_roundtrip_python_and_cpp(host, oracle, tmp_path):
+    frames = []
+    for seed, kw in [(3, dict(C=6, F=40)), (4, dict(C=5, F=17, ragged=True, min_meas=2))]:
+        sc = make_scene(seed=seed, chi2_mult=1.0, **kw)
+        ref = oracle.msckf_point_update(sc)
+        frames.append(trace.frame_from_scene(sc, outputs=ref, timestamp=100.0 + seed))
+    frames.append(trace.frame_from_scene(make_scene(seed=5, C=4, F=9)))  # inputs only
+    a, b = tmp_path / "a.ovptrc", tmp_path / "b.ovptrc"
+    trace.write_frames(a, frames)
+    assert host.ovph_trace_copy(str(a).encode(), str(b).encode()) == 3
+    assert open(a, "rb").read() == open(b, "rb").read()  # the C++ reader + writer reproduce the file byte for byte
+    back = trace.read_frames(b)
+    for f, g in zip(frames, back):
+        assert set(f) == set(g)
+        for k in f:
+            assert np.array_equal(np.asarray(f[k]), np.asarray(g[k])), k
+
+
+def test_committed_trace_fixture_holds_the_oracle_outputs(oracle):
+    """tests/golden/trace_c6.ovptrc (written by tests/golden/make_golden.py) is a replayable frame: its recorded outputs are
+    the oracle's on the recorded inputs."""
+    f = trace.read_frames(os.path.join(GOLD, "trace_c6.ovptrc"))[0]
+    sc = make_scene(seed=3, C=6, F=40, chi2_mult=1.0)
+    ref = oracle.msckf_point_update(sc)
+    assert np.array_equal(f["uv"], sc.uv) and np.allclose(f["P"], sc.P, atol=0)
+    assert (f["accepted"].astype(bool) == ref["accepted"]).all()
+    assert np.abs(f["dx"] - ref["dx"]).max() < 1e-12 and np.abs(f["P_after"] - ref["P"]).max() < 1e-12

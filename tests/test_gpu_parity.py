@@ -1084,3 +1084,62 @@ def test_host_cpp_mirror_plane_init_fits_planes_first(hiplib, oracle):
     assert (out["deleted"] == ref["used"]).all()
     assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# on-disk formats
+# ------------------------------------------------------------------------------------------------------------------
+def test_committed_trace_frame_replays_on_the_device(hiplib):
+    """tests/golden/trace_c6.ovptrc: a frame in the binary trace format with the oracle's outputs; replaying its inputs
+    through the C-ABI gives those outputs (the offline comparison a frame recorded next to the reference would get)."""
+    from ov_plane_amd import trace
+
+    f = trace.read_frames(os.path.join(GOLD, "trace_c6.ovptrc"))[0]
+    sc = trace.scene_from_frame(f)
+    out = run_gpu(hiplib, sc)
+    assert (out["accepted"] == f["accepted"].astype(bool)).all()
+    assert np.abs(out["chi2"] - f["chi2"]).max() <= 1e-8 * max(1.0, np.abs(f["chi2"]).max())
+    assert np.abs(out["dx"] - f["dx"]).max() < TOL_DX
+    assert relP(out["P"], f["P_after"]) < TOL_P
+    out["ctx"].close()
+
+
+@pytest.mark.parametrize("with_gt", [0, 1])
+def test_state_files_match_the_reference_layout(hiplib, with_gt):
+    """ROSVisualizerHelper::sim_save_total_state_to_file (ros/ROSVisualizerHelper.cpp:152-302): one line of the estimate,
+    standard-deviation and groundtruth files each, with the reference's precisions (5 / 6 / 7 / 0 digits)."""
+    import ctypes as C
+
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    L = hostlib.lib()
+    sc = make_scene(C=5, F=4, seed=9)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    cq, cp, calq, calp, intr, P = f64(sc.clone_q), f64(sc.clone_p), f64(sc.calib_q), f64(sc.calib_p), f64(sc.intr), np.asfortranarray(sc.P)
+    est, sd, gt = (C.create_string_buffer(4096) for _ in range(3))
+    ts, dt = 1403715273.262142, 0.0041234567
+    rc = L.ovph_format_state_files(C.c_int(sc.C), p(cq), p(cp), p(calq), p(calp), p(intr), C.c_int(sc.N), p(P), C.c_double(ts),
+                                   C.c_double(dt), C.c_int(with_gt), est, sd, gt, C.c_int(4096))
+    assert rc == 0
+    gt_dt = 0.0123456
+    t_out = ts + (gt_dt if with_gt else dt)  # :160 / :169: the groundtruth offset stamps all three files in simulation
+    six = lambda v: " ".join("%.6f" % x for x in v)  # noqa: E731
+    # the IMU sits at the last clone that was pushed; velocity and biases are the State's initial zeros
+    imu = np.r_[sc.clone_q[-1], sc.clone_p[-1], np.zeros(9)]
+    exp_est = "%.5f %s %.7f 1 %s %s \n" % (t_out, six(imu), dt, six(sc.intr), six(np.r_[sc.calib_q, sc.calib_p]))
+    assert est.value.decode() == exp_est
+    s = np.sqrt(np.diag(sc.P))
+    ids = sc.ids
+    exp_sd = "%.5f %s %.6f 1 %s %s \n" % (t_out, six(s[0:15]), s[15], six(s[ids["intr"]:ids["intr"] + 8]),
+                                         six(s[ids["calib"]:ids["calib"] + 6]))
+    assert sd.value.decode() == exp_sd
+    if with_gt:
+        g = 0.5 + 0.125 * np.arange(17)
+        exp_gt = "%.5f %s %.7f 1 %s %s \n" % (g[0], six(g[1:]), gt_dt, six(sc.intr + 1.0), six(0.1 * np.arange(1, 8)))
+        assert gt.value.decode() == exp_gt
+    else:
+        assert gt.value.decode() == ""
