@@ -59,6 +59,8 @@ def test_matches_committed_golden_vectors(hiplib, name):
     dict(C=31, F=64, seed=23, chi2_mult=1.0),                               # max_clones+1 window
     dict(C=12, F=90, seed=24, ragged=True, chi2_mult=0.6),                  # many rejections
     dict(C=10, F=70, seed=25, chi2_mult=1.0, calib=False, do_fej=False),
+    dict(C=7, F=2300, seed=26, ragged=True, min_meas=3, chi2_mult=1.0),     # more features than one round of the fused K1 launch (2040)
+    dict(C=9, F=700, seed=27, chi2_mult=1.0),                                # several waves per workgroup, not all eight
 ])
 def test_matches_oracle_on_fresh_scenes(hiplib, oracle, kw):
     sc = make_scene(**kw)
