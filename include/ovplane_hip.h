@@ -160,6 +160,14 @@ typedef struct {
   const double *cp;           /* [n_planes*3] */
   const double *cp_fej;       /* [n_planes*3] */
   const int *plane_state_id;  /* [n_planes] */
+  /* SLAM landmarks that lie on planes which are NOT in the state (update/UpdaterMSCKF.cpp:232-252), ovp_msckf_plane_update
+   * only: each contributes one point-on-plane row whose feature Jacobian stays in the landmark's three state columns
+   * (:545-552).  n_slam = 0 / NULL pointers when there are none. */
+  int n_slam;
+  const int *slam_plane;      /* [n_slam] 1-based plane slot */
+  const int *slam_state_id;   /* [n_slam] Type::id() of the landmark */
+  const double *slam_p;       /* [n_slam*3] Landmark::get_xyz(false) */
+  const double *slam_p_fej;   /* [n_slam*3] Landmark::get_xyz(true) */
 } ovp_plane_batch;
 
 /* UpdaterMSCKF::update, per-plane loop with MSCKF features (update/UpdaterMSCKF.cpp:411-649): for every plane in

@@ -776,6 +776,18 @@ void ovo_apply_dx(const ovo_state *st, int n_planes, const int *plane_state_id, 
 int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, const int *plane_of_feat,
                            int n_planes, const double *cp_in, const double *cp_fej, const int *plane_state_id, double *P,
                            ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows) {
+  return ovo_msckf_plane_update_slam(o, st_in, fb, plane_of_feat, n_planes, cp_in, cp_fej, plane_state_id, P, val, used, plane_ok,
+                                     plane_chi2, plane_rows, 0, NULL, NULL, NULL, NULL);
+}
+
+/* The same with the SLAM landmarks that lie on planes which are NOT in the state (update/UpdaterMSCKF.cpp:232-252): such a
+ * feature has no measurements here, it contributes ONE point-on-plane row (update/UpdaterHelper.cpp:503-505) whose feature
+ * Jacobian goes to the landmark's state columns instead of being projected away (:545-552).  slam_p is updated in place after
+ * every accepted plane (the landmarks are state variables). */
+int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, const int *plane_of_feat,
+                                int n_planes, const double *cp_in, const double *cp_fej, const int *plane_state_id, double *P,
+                                ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows,
+                                int n_slam, const int *slam_plane, const int *slam_id, double *slam_p, const double *slam_p_fej) {
   const int n = st_in->n_state;
   const int F = fb->n_feats;
   const int mm = fb->max_meas;
@@ -793,8 +805,8 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_
   int *oid2 = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
   int *osz2 = (int *)malloc(sizeof(int) * (size_t)(mm + 4));
   int *map_col = (int *)malloc(sizeof(int) * (size_t)n);
-  int *order_big_id = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8));
-  int *order_big_size = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8));
+  int *order_big_id = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8 + n_slam));
+  int *order_big_size = (int *)malloc(sizeof(int) * (size_t)(st_in->n_clones + 8 + n_slam));
   double *dx = (double *)malloc(sizeof(double) * (size_t)n);
 
   for (int pl = 0; pl < n_planes; ++pl) {
@@ -811,8 +823,13 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_
         ++nf;
         max_meas += 3 * (size_t)fb->n_meas[f];
       }
-    /* :316-317,396: a plane that is not in the state needs more than 3 features */
-    if (nf == 0 || (!is_slam_plane && nf < 4)) continue;
+    int ns = 0; /* SLAM landmarks on this plane: only planes outside the state collect them (:240-241) */
+    if (!is_slam_plane)
+      for (int q = 0; q < n_slam; ++q)
+        if (slam_plane[q] == planeid) ++ns;
+    max_meas += (size_t)ns;
+    /* :316-317,384-396: a plane that is not in the state needs more than 3 features, at least one of them an MSCKF one */
+    if (nf == 0 || (!is_slam_plane && nf + ns < 4)) continue;
     /* state tables at the current estimate (values change after every plane update, FEJ does not) */
     ovo_state st = *st_in;
     st.clone_q = val->clone_q;
@@ -884,6 +901,34 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_
         for (int i = 0; i < q; ++i) CM(Hcp_big, max_meas, ct_meas + i, cc) = CM(H_cp, rows, 3 + i, cc);
       for (int i = 0; i < q; ++i) res_big[ct_meas + i] = res[3 + i];
       ct_meas += (size_t)q;
+    }
+    /* SLAM landmarks of this plane: one constraint row each, landmark columns kept (:545-552) */
+    for (int q = 0; q < n_slam && !is_slam_plane; ++q) {
+      if (slam_plane[q] != planeid) continue;
+      const double white_c = 1.0 / o->sigma_constraint;
+      const double *pv = slam_p + 3 * q;
+      const double *pj = o->do_fej ? slam_p_fej + 3 * q : pv; /* UpdaterHelper.cpp:467-477 */
+      const double *cj = o->do_fej ? cpf : cpv;
+      double d = sqrt(cpv[0] * cpv[0] + cpv[1] * cpv[1] + cpv[2] * cpv[2]);
+      double nv[3] = {cpv[0] / d, cpv[1] / d, cpv[2] / d};
+      const double r = white_c * (0.0 - ((nv[0] * pv[0] + nv[1] * pv[1] + nv[2] * pv[2]) - d));
+      d = sqrt(cj[0] * cj[0] + cj[1] * cj[1] + cj[2] * cj[2]);
+      nv[0] = cj[0] / d;
+      nv[1] = cj[1] / d;
+      nv[2] = cj[2] / d;
+      const double np = nv[0] * pj[0] + nv[1] * pj[1] + nv[2] * pj[2];
+      if (map_col[slam_id[q]] < 0) {
+        map_col[slam_id[q]] = (int)ct_jacob;
+        order_big_id[n_order_big] = slam_id[q];
+        order_big_size[n_order_big++] = 3;
+        ct_jacob += 3;
+      }
+      for (int cc = 0; cc < 3; ++cc) {
+        CM(Hx_big, max_meas, ct_meas, map_col[slam_id[q]] + cc) = white_c * nv[cc];
+        CM(Hcp_big, max_meas, ct_meas, cc) = white_c * 1.0 / d * (pj[cc] - np * nv[cc] - d * nv[cc]);
+      }
+      res_big[ct_meas] = r;
+      ct_meas += 1;
     }
     /* :583-585 conservativeResize, :588 compress */
     const size_t hcols = ct_jacob + (is_slam_plane ? 3 : 0);
@@ -958,6 +1003,8 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_
       int neg = 0;
       ovo_ekf_update(P, n, order_big_id, order_big_size, n_order_big, Hc, rows_u, (int)ct_meas, res_big, dx, &neg);
       ovo_apply_dx(st_in, n_planes, plane_state_id, dx, val);
+      for (int q = 0; q < n_slam; ++q) /* ext Vec::update of every landmark */
+        for (int a = 0; a < 3; ++a) slam_p[3 * q + a] += dx[slam_id[q] + a];
     }
     free(Pm);
     free(HP);

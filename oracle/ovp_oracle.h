@@ -131,6 +131,12 @@ void ovo_apply_dx(const ovo_state *st, int n_planes, const int *plane_state_id, 
 int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat,
                            int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
                            ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows);
+/* + SLAM landmarks on planes that are not in the state (update/UpdaterMSCKF.cpp:232-252): slam_plane [n_slam] 1-based plane,
+ * slam_id [n_slam] Type::id(), slam_p [n_slam*3] values (updated in place), slam_p_fej [n_slam*3] */
+int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat,
+                                int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
+                                ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows,
+                                int n_slam, const int *slam_plane, const int *slam_id, double *slam_p, const double *slam_p_fej);
 
 /* update/UpdaterSLAM.cpp:376-682 (GLOBAL_3D landmarks already in the state, no ArUco): per feature Jacobian with the
  * landmark columns appended, optional point-on-plane rows for in-state planes with the no-plane fallback (:547-609),

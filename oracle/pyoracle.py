@@ -177,9 +177,10 @@ class OvoStateValues(C.Structure):
     ]
 
 
-def msckf_plane_update(sc, libpath=None):
+def msckf_plane_update(sc, libpath=None, slam=None):
     """Runs ovo_msckf_plane_update on the scene's planar features.
-    Returns dict(P, state values after the plane loop, used[F], plane_ok, plane_chi2, plane_rows)."""
+    slam = dict(plane [k] 1-based, id [k], p [k,3], p_fej [k,3]): SLAM landmarks lying on out-of-state planes.
+    Returns dict(P, state values after the plane loop, used[F], plane_ok, plane_chi2, plane_rows[, slam_p])."""
     L = lib() if libpath is None else C.CDLL(libpath)
     pk = Packed(sc)
     n_planes = int(sc.cp.shape[0])
@@ -203,12 +204,21 @@ def msckf_plane_update(sc, libpath=None):
     chi2 = np.zeros(max(n_planes, 1))
     rows = np.zeros(max(n_planes, 1), dtype=np.int32)
     u8 = C.POINTER(C.c_uint8)
-    L.ovo_msckf_plane_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(pof), C.c_int(n_planes),
-                             _dp(cp_in), _dp(cp_fej), _ip(psid), _dp(P), C.byref(val), used.ctypes.data_as(u8),
-                             ok.ctypes.data_as(u8), _dp(chi2), _ip(rows))
-    return dict(P=np.ascontiguousarray(P), clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
-                calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), cp=cp, used=used.astype(bool),
-                plane_ok=ok[:n_planes].astype(bool), plane_chi2=chi2[:n_planes], plane_rows=rows[:n_planes])
+    ns = 0 if slam is None else len(slam["id"])
+    s_pl = np.ascontiguousarray(slam["plane"] if ns else [0], dtype=np.int32)
+    s_id = np.ascontiguousarray(slam["id"] if ns else [0], dtype=np.int32)
+    s_p = np.ascontiguousarray(np.array(slam["p"], dtype=np.float64).copy() if ns else np.zeros((1, 3)))
+    s_pf = np.ascontiguousarray(np.array(slam["p_fej"], dtype=np.float64) if ns else np.zeros((1, 3)))
+    L.ovo_msckf_plane_update_slam(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(pof), C.c_int(n_planes),
+                                  _dp(cp_in), _dp(cp_fej), _ip(psid), _dp(P), C.byref(val), used.ctypes.data_as(u8),
+                                  ok.ctypes.data_as(u8), _dp(chi2), _ip(rows), C.c_int(ns), _ip(s_pl), _ip(s_id), _dp(s_p),
+                                  _dp(s_pf))
+    out = dict(P=np.ascontiguousarray(P), clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
+               calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), cp=cp, used=used.astype(bool),
+               plane_ok=ok[:n_planes].astype(bool), plane_chi2=chi2[:n_planes], plane_rows=rows[:n_planes])
+    if ns:
+        out["slam_p"] = s_p
+    return out
 
 
 def initialize(P, order, H_R, H_L, res, r_iso, chi2_mult, do_update=True):

@@ -71,6 +71,11 @@ class PlaneBatch(C.Structure):
         ("cp", C.c_void_p),
         ("cp_fej", C.c_void_p),
         ("plane_state_id", C.c_void_p),
+        ("n_slam", C.c_int),
+        ("slam_plane", C.c_void_p),
+        ("slam_state_id", C.c_void_p),
+        ("slam_p", C.c_void_p),
+        ("slam_p_fej", C.c_void_p),
     ]
 
 
@@ -345,8 +350,9 @@ class Context:
             raise OvpError(rc, "ovp_msckf_fetch_results")
         return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
 
-    def plane_update(self, opts: UpdateOpts, plane_of_feat, cp, cp_fej, plane_state_id, raise_on_error=True):
-        """UpdaterMSCKF::update per-plane loop. Returns dict(dx [n_planes, n], ok, chi2, dof, used)."""
+    def plane_update(self, opts: UpdateOpts, plane_of_feat, cp, cp_fej, plane_state_id, raise_on_error=True, slam=None):
+        """UpdaterMSCKF::update per-plane loop. Returns dict(dx [n_planes, n], ok, chi2, dof, used).
+        slam = dict(plane [k] 1-based, id [k], p [k,3], p_fej [k,3]): SLAM landmarks lying on out-of-state planes."""
         plane_of_feat = np.ascontiguousarray(plane_of_feat, dtype=np.int32)
         cp = np.ascontiguousarray(cp, dtype=np.float64)
         cp_fej = np.ascontiguousarray(cp_fej, dtype=np.float64)
@@ -359,6 +365,14 @@ class Context:
         dof = np.zeros(max(npl, 1), dtype=np.int32)
         used = np.zeros(max(self.n_feats, 1), dtype=np.uint8)
         pb = PlaneBatch(npl, plane_of_feat.ctypes.data, cp.ctypes.data, cp_fej.ctypes.data, sid.ctypes.data)
+        if slam is not None and len(slam["id"]):
+            s_pl = np.ascontiguousarray(slam["plane"], dtype=np.int32)
+            s_id = np.ascontiguousarray(slam["id"], dtype=np.int32)
+            s_p = np.ascontiguousarray(slam["p"], dtype=np.float64)
+            s_pf = np.ascontiguousarray(slam["p_fej"], dtype=np.float64)
+            pb.n_slam = len(s_id)
+            pb.slam_plane, pb.slam_state_id = s_pl.ctypes.data, s_id.ctypes.data
+            pb.slam_p, pb.slam_p_fej = s_p.ctypes.data, s_pf.ctypes.data
         rc = lib().ovp_msckf_plane_update(self._h, C.byref(opts), C.byref(pb), dx.ctypes.data, ok.ctypes.data,
                                           chi2.ctypes.data, dof.ctypes.data, used.ctypes.data)
         if rc != 0 and raise_on_error:

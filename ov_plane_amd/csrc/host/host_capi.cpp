@@ -15,6 +15,9 @@ extern "C" void ovph_set_uv_norm(const float *uv_norm /* [F][M][2] or NULL */) {
 // next ovph_run_msckf_update: no plane estimates are handed over, UpdaterMSCKF::update runs plane_fitting / optimize_plane itself
 static int g_fit_planes = 0, g_fit_min_feat = 20, g_fit_variant = 0;
 static double g_fit_max_cond = 100.0;
+// mode 3 of ovph_run_updater: plane of every SLAM landmark (0 = none)
+static const int *g_slam_plane = nullptr;
+extern "C" void ovph_set_slam_planes(const int *plane_of_landmark) { g_slam_plane = plane_of_landmark; }
 extern "C" void ovph_set_plane_fit(int enable, int min_feat, double max_cond, int shuffle_variant) {
   g_fit_planes = enable;
   g_fit_min_feat = min_feat;
@@ -371,6 +374,9 @@ void export_state(const HarnessState &hs, double *out_clone_q, double *out_clone
 }
 }  // namespace
 
+// mode 3: UpdaterMSCKF::update on a state that also holds SLAM landmarks (ids 9000 + k, planes from ovph_set_slam_planes) and
+// n_planes in-state planes (ids 1..n_planes); the features carry normalised measurements, the updater triangulates, fits and
+// refines (ovph_set_plane_fit must be on).
 // mode 0: UpdaterSLAM::update (feature f observes landmark f, n_slam == F); mode 1: UpdaterSLAM::delayed_init (n_slam == 0,
 // out_new_p [F*3] / out_new_id [F] describe the landmarks that joined the state); mode 2: UpdaterPlane::init_vio_plane
 // (n_planes in-state planes must be 0; cp_out_est [n_planes_out*3] are the upstream plane estimates with ids 1..n).
@@ -394,8 +400,8 @@ extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const do
   so.const_init_multi = const_init_multi;
   so.const_init_chi2 = const_init_chi2;
   if (g_fit_planes) {
-    so.plane_init_min_feat = g_fit_min_feat;
-    so.plane_init_max_cond = g_fit_max_cond;
+    so.plane_init_min_feat = so.plane_msckf_min_feat = g_fit_min_feat;
+    so.plane_init_max_cond = so.plane_msckf_max_cond = g_fit_max_cond;
     so.planefit_shuffle_variant = g_fit_variant;
   }
   so.max_state_size = n_cap;
@@ -416,6 +422,29 @@ extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const do
   uo.chi2_multipler = chi2_mult;
   ua = uo;
   ov_core::FeatureInitializerOptions fio;
+  if (mode == 3) {
+    for (int k = 0; k < n_slam && g_slam_plane; ++k)
+      if (g_slam_plane[k] > 0) feat2plane[9000 + k] = (size_t)g_slam_plane[k];
+    UpdaterMSCKF up(uo, fio);
+    std::vector<std::shared_ptr<ov_core::Feature>> fextra, fused;
+    up.update(state, fv, fextra, fused, feat2plane);
+    g_fit_planes = 0;
+    g_uv_norm = nullptr;
+    g_slam_plane = nullptr;
+    std::set<size_t> left;
+    for (auto &ft : fv) left.insert(ft->featid);
+    export_state(hs, out_clone_q, out_clone_p, out_calib_q, out_calib_p, out_intr, out_slam_p, out_cp, out_P, out_n);
+    for (int f = 0; f < F; ++f) {
+      feat_kept[f] = left.count(id0 + f) ? 1 : 0;
+      feat_deleted[f] = all[f]->to_delete ? 1 : 0;
+      slam_to_plane[f] = -1;
+    }
+    for (int k = 0; k < n_slam && k < F; ++k) {
+      auto it = state->_features_SLAM_to_PLANE.find(9000 + k);
+      if (it != state->_features_SLAM_to_PLANE.end()) slam_to_plane[k] = (int)it->second;
+    }
+    return 0;
+  }
   if (mode == 0) {
     UpdaterSLAM up(uo, ua, fio);
     up.update(state, fv, feat2plane);

@@ -741,6 +741,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   std::map<size_t, std::vector<double>> plane_estimates = state->_plane_estimates_cp_inG;
   std::set<size_t> fitted_planes;       // planes whose feature set went through the fit below
   std::set<size_t> plane_feat_kept;     // their surviving features (plane_feats.at(planeid) of :421)
+  std::map<size_t, std::vector<size_t>> plane_slam_kept;  // SLAM landmarks among them (planes outside the state only)
   if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_msckf && !feat2plane.empty() &&
       state->_plane_estimates_cp_inG.empty()) {
     std::map<size_t, std::vector<std::shared_ptr<ov_core::Feature>>> plane_feats;  // :198
@@ -838,7 +839,10 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
           if (!has_msckf_feat || feats.size() < 4) continue;  // :395-396
         }
         plane_estimates[pid] = {cp[0], cp[1], cp[2]};
-        for (auto &ft : feats) plane_feat_kept.insert(ft->featid);
+        for (auto &ft : feats) {
+          plane_feat_kept.insert(ft->featid);
+          if (ft->timestamps.empty() && state->_features_SLAM.count(ft->featid)) plane_slam_kept[pid].push_back(ft->featid);
+        }
       }
       // on-plane extra features that survived join the batch of the plane loop (plane_feats.at(planeid), :421)
       for (auto &ft : feature_vec_extra)
@@ -888,10 +892,40 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       std::vector<double> dxp((size_t)NP * n, 0.0);
       std::vector<uint8_t> pok(NP, 0), fused(feature_vec.size(), 0);
       ovp_plane_batch pb{NP, pof.data(), cpv.data(), cpfej.data(), sid.data()};
-      gpu_check(ovp_msckf_plane_update(state->_gpu, &o, &pb, dxp.data(), pok.data(), nullptr, nullptr, fused.data()),
+      // SLAM landmarks lying on planes that are not in the state: one constraint row each inside that plane's update (:454-552)
+      std::vector<int> s_plane, s_id;
+      std::vector<size_t> s_featid;
+      std::vector<double> s_p, s_pf;
+      for (int k = 0; k < NP; ++k) {
+        auto itp = plane_slam_kept.find(used_planes[k]);
+        if (itp == plane_slam_kept.end() || sid[k] >= 0) continue;
+        for (size_t fid : itp->second) {
+          auto lm = state->_features_SLAM.at(fid);
+          double v[3], vf[3];
+          lm->get_xyz(false, v);
+          lm->get_xyz(true, vf);
+          s_plane.push_back(k + 1);
+          s_id.push_back(lm->id());
+          s_featid.push_back(fid);
+          s_p.insert(s_p.end(), v, v + 3);
+          s_pf.insert(s_pf.end(), vf, vf + 3);
+        }
+      }
+      pb.n_slam = (int)s_id.size();
+      pb.slam_plane = s_plane.data();
+      pb.slam_state_id = s_id.data();
+      pb.slam_p = s_p.data();
+      pb.slam_p_fej = s_pf.data();
+      std::vector<int> pdof(NP, 0);
+      gpu_check(ovp_msckf_plane_update(state->_gpu, &o, &pb, dxp.data(), pok.data(), nullptr, pdof.data(), fused.data()),
                 "ovp_msckf_plane_update");
       for (int k = 0; k < NP; ++k)
         if (pok[k]) StateHelper::apply_correction(state, &dxp[(size_t)k * n]);  // :648 per accepted plane, in order
+      for (size_t q = 0; q < s_id.size(); ++q) {  // :626-639
+        const int k = s_plane[q] - 1;
+        if (pok[k]) state->_features_SLAM_to_PLANE[s_featid[q]] = used_planes[k];
+        else if (pdof[k] > 0) state->_features_SLAM_to_PLANE[s_featid[q]] = 0;  // the plane ran and failed its chi2 test
+      }
       for (size_t f = 0; f < feature_vec.size(); ++f)
         if (fused[f]) {  // :640-644
           feature_vec[f]->to_delete = true;

@@ -272,6 +272,62 @@ __global__ __launch_bounds__(256) void k_assemble_ext(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// SLAM landmarks on a plane that is not in the state (update/UpdaterMSCKF.cpp:232-252, :545-552): one point-on-plane row per
+// landmark (update/UpdaterHelper.cpp:448-505), added to the extended pair E over [state | residual | plane]:
+//   h = [ w n^T at the landmark's columns | w/d (p - (n.p) n - d n)^T at the plane's ],  r = -w (n.p - d)
+// Jacobians at the first estimates when do_fej.  One workgroup, the rows one after the other (there are a handful).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_plane_slam_rows(double* __restrict__ E, int lde, int n, int plane1, int n_slam,
+                                                         const int* __restrict__ slam_plane, const int* __restrict__ slam_id,
+                                                         const double* __restrict__ slam_p, const double* __restrict__ slam_p_fej,
+                                                         const double* __restrict__ cp, const double* __restrict__ cp_fej,
+                                                         double white_c, int do_fej, double* __restrict__ cstsum) {
+  __shared__ double h[7];
+  __shared__ int col[7];
+  const int t = threadIdx.x;
+  for (int q = 0; q < n_slam; ++q) {
+    if (slam_plane[q] != plane1) continue;  // uniform
+    if (t == 0) {
+      const double* pv = slam_p + 3 * q;
+      const double* pj = do_fej ? slam_p_fej + 3 * q : pv;
+      const double* cj = do_fej ? cp_fej : cp;
+      double d = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+      double nv[3] = {cp[0] / d, cp[1] / d, cp[2] / d};
+      const double r = white_c * (0.0 - ((nv[0] * pv[0] + nv[1] * pv[1] + nv[2] * pv[2]) - d));
+      d = sqrt(cj[0] * cj[0] + cj[1] * cj[1] + cj[2] * cj[2]);
+      nv[0] = cj[0] / d;
+      nv[1] = cj[1] / d;
+      nv[2] = cj[2] / d;
+      const double np = nv[0] * pj[0] + nv[1] * pj[1] + nv[2] * pj[2];
+      for (int k = 0; k < 3; ++k) {
+        h[k] = white_c * nv[k];
+        h[3 + k] = white_c * 1.0 / d * (pj[k] - np * nv[k] - d * nv[k]);
+        col[k] = slam_id[q] + k;
+        col[3 + k] = n + 1 + k;
+      }
+      h[6] = r;
+      col[6] = n;
+      cstsum[9] += r * r;
+    }
+    __syncthreads();
+    if (t < 49) {
+      const int i = t / 7, k = t - 7 * i;
+      if (!(i == 6 && k == 6)) E[(size_t)col[i] * lde + col[k]] += h[i] * h[k];
+    }
+    __syncthreads();
+  }
+}
+
+// landmarks are state variables: ext Vec::update after an accepted plane
+__global__ void k_plane_commit_slam(const double* __restrict__ res, const double* __restrict__ dx, int n_slam,
+                                    const int* __restrict__ slam_id, double* __restrict__ slam_p) {
+  if (!(res[1] > 0.5)) return;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_slam) return;
+  for (int k = 0; k < 3; ++k) slam_p[3 * q + k] += dx[slam_id[q] + k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // E -> Ab (n+1 rows): in-state plane: copy; out-of-state: Schur complement on columns n+1..n+3
 // (== UpdaterHelper::nullspace_project_inplace(Hcp_big, Hx_big, res_big), update/UpdaterMSCKF.cpp:603).
 // scal[0] = projected residual energy rr (input: cstsum[9] + bearing energy is folded by the caller).
@@ -682,6 +738,20 @@ hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double th
                      res_out);
   return hipGetLastError();
 }
+hipError_t ovp_launch_plane_slam_rows(double* E, int lde, int n, int plane1, int n_slam, const int* slam_plane, const int* slam_id,
+                                      const double* slam_p, const double* slam_p_fej, const double* cp, const double* cp_fej,
+                                      double white_c, int do_fej, double* cstsum, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_plane_slam_rows, dim3(1), dim3(64), 0, stream, E, lde, n, plane1, n_slam, slam_plane, slam_id, slam_p,
+                     slam_p_fej, cp, cp_fej, white_c, do_fej, cstsum);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_plane_commit_slam(const double* res, const double* dx, int n_slam, const int* slam_id, double* slam_p,
+                                        hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_plane_commit_slam, dim3((n_slam + 63) / 64), dim3(64), 0, stream, res, dx, n_slam, slam_id, slam_p);
+  return hipGetLastError();
+}
+
 hipError_t ovp_launch_plane_commit(const double* res, const double* V, double* M, int n, int ld, const double* dx,
                                    double* dx_out, double* clone_R, double* clone_p, const int* clone_id, int n_clones,
                                    double* cal, int calib_id, int intr_id, double* cp, const int* plane_sid,

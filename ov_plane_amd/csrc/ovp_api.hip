@@ -55,6 +55,11 @@ hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double th
                                  int n_involved, double* res_out, hipStream_t stream);
 hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
                                          hipStream_t stream);
+hipError_t ovp_launch_plane_slam_rows(double* E, int lde, int n, int plane1, int n_slam, const int* slam_plane, const int* slam_id,
+                                      const double* slam_p, const double* slam_p_fej, const double* cp, const double* cp_fej,
+                                      double white_c, int do_fej, double* cstsum, hipStream_t stream);
+hipError_t ovp_launch_plane_commit_slam(const double* res, const double* dx, int n_slam, const int* slam_id, double* slam_p,
+                                        hipStream_t stream);
 hipError_t ovp_launch_plane_commit(const double* res, const double* V, double* M, int n, int ld, const double* dx,
                                    double* dx_out, double* clone_R, double* clone_p, const int* clone_id, int n_clones,
                                    double* cal, int calib_id, int intr_id, double* cp, const int* plane_sid,
@@ -173,6 +178,10 @@ struct ovp_ctx {
   double *pl_An = nullptr, *pl_bn = nullptr, *pl_Lr = nullptr, *pl_Dinv2 = nullptr, *pl_scal = nullptr;
   double *pl_res = nullptr, *pl_dx = nullptr;
   int pl_cap = 0;
+  // SLAM landmarks on out-of-state planes (ovp_msckf_plane_update): [plane | id] ints and [p | p_fej] doubles
+  int *pl_slam_i = nullptr;
+  double *pl_slam_d = nullptr;
+  int pl_slam_cap = 0, pl_n_slam = 0;
   int* idbuf = nullptr;      // scratch ints (ids)
   double* smallbuf = nullptr;  // scratch doubles (Phi, Q, CPT, PCP, marginal)
   size_t small_cap = 0;
@@ -334,7 +343,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
                  c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
-                 c->bcc, c->resd};
+                 c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -891,6 +900,10 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   HIPCHK(ovp_launch_syrk(c->G, 3 * nf, ldg, n + 4, nsplit, c->part, s));
   HIPCHK(ovp_launch_reduce_cst(c->pl_cst, nf, c->pl_cstsum, s));
   HIPCHK(ovp_launch_assemble_ext(c->gramR, fp.n_clones, c->part, nsplit, c->colmap, n, sid, c->pl_cstsum, c->pl_E, ldg, s));
+  if (!in_state && c->pl_n_slam > 0)  // landmarks lying on this plane: one constraint row each (UpdaterMSCKF.cpp:545-552)
+    HIPCHK(ovp_launch_plane_slam_rows(c->pl_E, ldg, n, pl + 1, c->pl_n_slam, c->pl_slam_i, c->pl_slam_i + c->pl_slam_cap,
+                                      c->pl_slam_d, c->pl_slam_d + 3 * (size_t)c->pl_slam_cap, c->pl_cp + 3 * pl,
+                                      c->pl_cp_fej + 3 * pl, white_c, fp.do_fej, c->pl_cstsum, s));
   HIPCHK(ovp_launch_plane_reduce_to_state(c->pl_E, ldg, n, in_state, c->Ab, ld, c->pl_cstsum + 9, c->pl_scal, s));
   // range part of the residual (regularised, diagonally normalised): its own Cholesky, independent of the update's -
   // side stream, joined before the gate (the two write different words of pl_scal)
@@ -953,6 +966,10 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (NP == 0) return 0;
   for (int k = 0; k < NP; ++k)
     if (pb->plane_state_id[k] >= 0 && pb->plane_state_id[k] + 3 > n) return OVP_E_ARG;
+  const int n_slam = pb->n_slam > 0 ? pb->n_slam : 0;
+  if (n_slam > 0 && (!pb->slam_plane || !pb->slam_state_id || !pb->slam_p || !pb->slam_p_fej)) return OVP_E_ARG;
+  for (int q = 0; q < n_slam; ++q)
+    if (pb->slam_state_id[q] < 0 || pb->slam_state_id[q] + 3 > n || pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP) return OVP_E_ARG;
   int rc = fill_feat_params(c, o);
   if (rc) return rc;
   ovp::FeatParams fp = c->fp;
@@ -981,11 +998,16 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       j.rows_total += 3 * m - 3;
       for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
     }
-    if (j.nf == 0 || (!j.in_state && j.nf < 4)) {  // update/UpdaterMSCKF.cpp:316-317,396
+    int ns_pl = 0;  // SLAM landmarks on this (out-of-state) plane: one row and three involved columns each
+    if (!j.in_state)
+      for (int q = 0; q < n_slam; ++q)
+        if (pb->slam_plane[q] == pl + 1) ++ns_pl;
+    if (j.nf == 0 || (!j.in_state && j.nf + ns_pl < 4)) {  // update/UpdaterMSCKF.cpp:316-317,384-396
       featlist.resize(j.start);
       continue;
     }
-    const int c_ref = 6 * __builtin_popcountll(seen) + ncal;
+    j.rows_total += ns_pl;
+    const int c_ref = 6 * __builtin_popcountll(seen) + ncal + 3 * ns_pl;
     const int rows_c = j.rows_total > c_ref ? c_ref : j.rows_total;  // UpdaterPlane::measurement_compress_inplace
     j.rows_u = j.in_state ? rows_c : rows_c - 3;
     j.n_involved = c_ref + (j.in_state ? 3 : 0);
@@ -1008,6 +1030,20 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   HIPCHK(hipMemcpyAsync(c->pl_cp_fej, pb->cp_fej, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, s));
   if (!featlist.empty())
     HIPCHK(hipMemcpyAsync(c->pl_featlist, featlist.data(), sizeof(int) * featlist.size(), hipMemcpyHostToDevice, s));
+  c->pl_n_slam = n_slam;
+  if (n_slam > 0) {
+    if (n_slam > c->pl_slam_cap) {
+      if (c->pl_slam_i) hipFree(c->pl_slam_i);
+      if (c->pl_slam_d) hipFree(c->pl_slam_d);
+      c->pl_slam_cap = n_slam + 16;
+      HIPCHK(hipMalloc((void**)&c->pl_slam_i, sizeof(int) * 2 * (size_t)c->pl_slam_cap));
+      HIPCHK(dalloc(&c->pl_slam_d, (size_t)6 * c->pl_slam_cap));
+    }
+    HIPCHK(hipMemcpyAsync(c->pl_slam_i, pb->slam_plane, sizeof(int) * n_slam, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->pl_slam_i + c->pl_slam_cap, pb->slam_state_id, sizeof(int) * n_slam, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->pl_slam_d, pb->slam_p, sizeof(double) * 3 * n_slam, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->pl_slam_d + 3 * (size_t)c->pl_slam_cap, pb->slam_p_fej, sizeof(double) * 3 * n_slam, hipMemcpyHostToDevice, s));
+  }
   HIPCHK(hipStreamSynchronize(s));  // the host vectors above go out of scope before the copies would otherwise run
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
   // factor of P, chained through the plane loop:  P = M M^T
@@ -1023,7 +1059,10 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * j.pl, c->Y, Mf, n, ld, c->dx, c->pl_dx + (size_t)j.pl * n, c->clone_R,
                                    c->clone_p, c->clone_id, fp.n_clones, c->cal, o->do_calib_camera_pose ? c->calib_id : -1,
                                    o->do_calib_camera_intrinsics ? c->intr_id : -1, c->pl_cp, c->pl_sid, NP, s));
+    if (n_slam > 0)
+      HIPCHK(ovp_launch_plane_commit_slam(c->pl_res + 4 * j.pl, c->dx, n_slam, c->pl_slam_i + c->pl_slam_cap, c->pl_slam_d, s));
   }
+  c->pl_n_slam = 0;
   // P = M M^T
   if (!jobs.empty()) HIPCHK(ovp_launch_gemm4(0, 1, n, n, n, Mf, ld, Mf, ld, c->P, ld, 0, 1, s));
   // results
@@ -1068,6 +1107,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
     if (dx_planes) memset(dx_planes + (size_t)pl * dx_stride, 0, sizeof(double) * dx_stride);
   }
   if (NP == 0) return 0;
+  c->pl_n_slam = 0;
   int rc = fill_feat_params(c, o);
   if (rc) return rc;
   rc = plane_buffers(c, NP);

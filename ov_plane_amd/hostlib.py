@@ -96,7 +96,7 @@ def run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, new_value0):
     return out
 
 
-def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=None):
+def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=None, slam=None):
     """Drives the C++ host mirrors on a synth scene.
     fit_planes=dict(min_feat, max_cond, variant) (mode "plane_init" only): the features carry normalised measurements and
     no position, no plane estimates are handed over - init_vio_plane triangulates, fits and refines itself.
@@ -106,10 +106,12 @@ def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=
     mode "plane_init": UpdaterPlane::init_vio_plane on a scene whose planes are all out of the state.
     """
     L = lib()
-    m = {"slam_update": 0, "slam_delayed_init": 1, "plane_init": 2}[mode]
+    # "msckf_fit": UpdaterMSCKF::update on a state with SLAM landmarks (slam = dict(p [k,3], p_fej [k,3], plane [k]); the
+    # scene must have n_slam = k landmark columns) and the scene's in-state planes; needs fit_planes
+    m = {"slam_update": 0, "slam_delayed_init": 1, "plane_init": 2, "msckf_fit": 3}[mode]
     uvn_keep = None
     if fit_planes is not None:
-        assert m == 2
+        assert m in (2, 3)
         uvn_keep = np.ascontiguousarray(sc.uv_norm, dtype=np.float32)
         L.ovph_set_uv_norm(uvn_keep.ctypes.data_as(C.c_void_p))
         L.ovph_set_plane_fit.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
@@ -125,6 +127,15 @@ def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=
     dummy = np.zeros((1, 3))
     slam_p = f64(sc.slam_p if n_slam else dummy)
     slam_pf = f64(sc["p_FinG_fej"] if n_slam else dummy)
+    slam_pl_keep = None
+    if m == 3:
+        assert fit_planes is not None and slam is not None
+        n_slam = len(slam["plane"])
+        n_pl_in = int(np.sum(sc.plane_in_state))
+        assert sc.plane_in_state[:n_pl_in].all()
+        slam_p, slam_pf = f64(slam["p"]), f64(slam["p_fej"])
+        slam_pl_keep = np.ascontiguousarray(slam["plane"], dtype=np.int32)
+        L.ovph_set_slam_planes(slam_pl_keep.ctypes.data_as(C.c_void_p))
     cp = f64(sc.cp if n_pl_total else dummy)
     cpf = f64(sc.cp_fej if n_pl_total else dummy)
     P = np.asfortranarray(sc.P)

@@ -641,3 +641,21 @@ def make_planefit_problem(seed=0, n_feats=24, n_obs=9, n_slam=0, ragged=True, ou
         # current IMU pose / extrinsics: identity extrinsics, the last camera
         R_GtoI=Rs[-1].copy(), p_IinG=ps[-1].copy(), R_ItoC=np.eye(3), p_IinC=np.zeros(3),
     )
+
+
+def slam_rows_on_planes(sc, k_rows, seed=1):
+    """SLAM landmarks of a make_scene(n_slam=..., n_planes=...) state placed on its out-of-state planes: the extra rows of
+    the MSCKF plane update (update/UpdaterMSCKF.cpp:232-252).  Returns dict(plane [k] 1-based, id [k], p [k,3], p_fej [k,3])."""
+    rng = np.random.default_rng(seed)
+    out_planes = np.where(~sc.plane_in_state)[0]
+    pl = np.array([out_planes[q % len(out_planes)] for q in range(k_rows)], dtype=np.int32)
+    p = np.zeros((k_rows, 3))
+    truth = sc.get("truth", {})
+    for q in range(k_rows):
+        cp = truth["cp"][pl[q]] if "cp" in truth else sc.cp[pl[q]]  # the true plane: estimates of it may be centimetres off
+        d = np.linalg.norm(cp)
+        nrm = cp / d
+        x = sc.slam_p[q]
+        p[q] = x - (nrm @ x - d) * nrm + 0.01 * rng.standard_normal(3)
+    return dict(plane=pl + 1, id=np.asarray(sc.ids["slam"][:k_rows], dtype=np.int32), p=p,
+                p_fej=p + 1e-3 * rng.standard_normal((k_rows, 3)))

@@ -269,13 +269,13 @@ def test_plane_loop_matches_oracle(hiplib, oracle, kw):
     ctx.close()
 
 
-def _oracle_full_update(oracle, sc):
+def _oracle_full_update(oracle, sc, slam=None):
     """Reference flow of UpdaterMSCKF::update downstream of triangulation: plane loop, then the point loop on the
     features the planes did not consume, at the state/covariance the plane loop left behind."""
     from ov_plane_amd.synth import Scene
 
     if sc.cp.shape[0] > 0:
-        pl = oracle.msckf_plane_update(sc)
+        pl = oracle.msckf_plane_update(sc, slam=slam)
     else:
         pl = dict(P=sc.P, clone_q=sc.clone_q, clone_p=sc.clone_p, calib_q=sc.calib_q, calib_p=sc.calib_p, intr=sc.intr,
                   cp=sc.cp, used=np.zeros(sc.F, dtype=bool))
@@ -299,8 +299,48 @@ def _oracle_full_update(oracle, sc):
             cp[k] = cp[k] + dx[sid:sid + 3]
     kept = np.zeros(sc.F, dtype=bool)
     kept[rest[pt["accepted"]]] = True
-    return dict(P=pt["P"], clone_q=cq, clone_p=cpos, calib_q=quat_boxplus(pl["calib_q"], dx[16:19]),
-                calib_p=pl["calib_p"] + dx[19:22], intr=pl["intr"] + dx[22:30], cp=cp, used=pl["used"], kept=kept)
+    out = dict(P=pt["P"], clone_q=cq, clone_p=cpos, calib_q=quat_boxplus(pl["calib_q"], dx[16:19]),
+               calib_p=pl["calib_p"] + dx[19:22], intr=pl["intr"] + dx[22:30], cp=cp, used=pl["used"], kept=kept)
+    if slam is not None and len(slam["id"]):
+        out["slam_p"] = pl["slam_p"] + np.array([dx[i:i + 3] for i in slam["id"]])
+    return out
+
+
+@pytest.mark.parametrize("kw,k_rows", [
+    (dict(C=8, F=90, seed=73, n_planes=3, feats_per_plane=15, n_slam=3, chi2_mult=99999.0, ragged=True), 3),
+    (dict(C=11, F=160, seed=5, n_planes=4, feats_per_plane=25, n_slam=5, chi2_mult=99999.0), 5),
+    (dict(C=9, F=100, seed=12, n_planes=4, feats_per_plane=20, n_slam=4, chi2_mult=99999.0, do_fej=False), 4),
+])
+def test_plane_loop_with_slam_landmarks_matches_oracle(hiplib, oracle, kw, k_rows):
+    """SLAM landmarks lying on planes that are not in the state take part in that plane's update with one constraint row whose
+    feature Jacobian stays in the landmark's columns (update/UpdaterMSCKF.cpp:232-252, :545-552); the landmarks move with
+    every accepted plane."""
+    from ov_plane_amd.synth import slam_rows_on_planes
+
+    sc = make_scene(**kw)
+    slam = slam_rows_on_planes(sc, k_rows)
+    ref = oracle.msckf_plane_update(sc, slam=slam)
+    base = oracle.msckf_plane_update(sc)
+    assert np.abs(ref["P"] - base["P"]).max() > 1e-9  # the rows matter
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id, slam=slam)
+    assert (out["ok"] == ref["plane_ok"]).all() and ref["plane_ok"].all()
+    assert (out["used"] == ref["used"]).all()
+    assert (out["dof"] == ref["plane_rows"]).all()
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    lm = slam["p"].copy()
+    for k in range(out["dx"].shape[0]):
+        if out["ok"][k]:
+            for q, i in enumerate(slam["id"]):
+                lm[q] += out["dx"][k][i:i + 3]
+    assert np.abs(lm - ref["slam_p"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    ctx.close()
 
 
 @pytest.mark.parametrize("kw", [
@@ -1145,3 +1185,89 @@ def test_state_files_match_the_reference_layout(hiplib, with_gt):
         assert gt.value.decode() == exp_gt
     else:
         assert gt.value.decode() == ""
+
+
+def test_host_cpp_mirror_updater_msckf_with_slam_landmarks_on_planes(hiplib, oracle):
+    """UpdaterMSCKF::update on a state that holds SLAM landmarks lying on planes which are not in the state
+    (update/UpdaterMSCKF.cpp:232-252): the landmark takes part in the RANSAC fit and in the refinement as a constant, and in
+    the plane update with one constraint row on its own state columns; one landmark per plane keeps the reference's
+    unordered_map iteration order out of the picture."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import Scene, quat_2_rot, slam_rows_on_planes
+
+    fit = dict(min_feat=5, max_cond=200.0, variant=0)
+    sc = make_scene(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, n_slam=2, chi2_mult=99999.0, px_noise=0.25,
+                    err_scale=0.05)
+    slam = slam_rows_on_planes(sc, 2)
+    assert sorted(slam["plane"].tolist()) == [3, 4] and list(sc.plane_in_state) == [True, True, False, False]
+    tri = oracle.triangulate(sc)
+    ok = tri["ok"]
+    R_ItoC, p_IinC = quat_2_rot(sc.calib_q), sc.calib_p
+    Rc = np.array([R_ItoC @ quat_2_rot(sc.clone_q[i]) for i in range(sc.C)])
+    pc = np.array([sc.clone_p[i] - Rc[i].T @ p_IinC for i in range(sc.C)])
+    uvn = np.asarray(sc.uv_norm, dtype=np.float32)
+    sc2 = Scene(sc)
+    sc2["p_FinG"] = np.where(ok[:, None], tri["p_FinG"], sc.p_FinG)
+    sc2["plane_id"] = sc.plane_id.copy()
+    sc2["cp"] = sc.cp.copy()
+    slam_kept = []
+    for k in range(4):
+        feats = np.where((sc.plane_id == k + 1) & ok)[0]
+        lms = [q for q in range(2) if slam["plane"][q] == k + 1] if not sc.plane_in_state[k] else []
+
+        def problem(sel, lm_sel, cp, fixp):
+            n_obs = np.r_[sc.n_meas[sel], np.zeros(len(lm_sel))].astype(np.int32)
+            rows = [(f, j) for f in sel for j in range(sc.n_meas[f])]
+            ci = np.array([sc.clone_idx[f, j] for f, j in rows], dtype=int)
+            pts = np.vstack([sc2["p_FinG"][sel]] + [slam["p"][q][None] for q in lm_sel])
+            return dict(n_feats=len(sel) + len(lm_sel), p_FinG=pts, n_obs=n_obs,
+                        obs_start=np.r_[0, np.cumsum(n_obs)[:-1]].astype(np.int32),
+                        uv_norm=np.array([uvn[f, j] for f, j in rows], dtype=np.float64).reshape(-1, 2),
+                        R_GtoC=Rc[ci].reshape(-1, 9), p_CinG=pc[ci], cp=cp, fix_plane=fixp,
+                        sigma_px_norm=sc.opts["sigma_px"] / sc.intr[0], sigma_c=sc.opts["sigma_c"],
+                        R_GtoI=quat_2_rot(sc.clone_q[-1]), p_IinG=sc.clone_p[-1], R_ItoC=R_ItoC, p_IinC=p_IinC)
+
+        keep, refined, kept_lm = None, None, []
+        if sc.plane_in_state[k]:
+            res = oracle.optimize_plane(problem(feats, [], sc.cp[k], True))
+            if res["ok"]:
+                keep, refined = feats[res["kept"]], res["p_FinG"][res["kept"]]
+        else:
+            pts = np.vstack([sc2["p_FinG"][feats]] + [slam["p"][q][None] for q in lms])
+            fitr = oracle.plane_fitting(pts, fit["min_feat"], fit["max_cond"], fit["variant"])
+            if fitr["ok"]:
+                sel = feats[fitr["inlier"][:len(feats)]]
+                lm_sel = [q for j, q in enumerate(lms) if fitr["inlier"][len(feats) + j]]
+                res = oracle.optimize_plane(problem(sel, lm_sel, -fitr["abcd"][:3] * fitr["abcd"][3], False))
+                if res["ok"] and res["n_kept"] >= 4:
+                    km = res["kept"][:len(sel)]
+                    keep, refined = sel[km], res["p_FinG"][:len(sel)][km]
+                    kept_lm = [q for j, q in enumerate(lm_sel) if res["kept"][len(sel) + j]]
+                    sc2["cp"][k] = res["cp"]
+                    sc2["cp_fej"][k] = res["cp"]
+        drop = feats if keep is None else np.setdiff1d(feats, keep)
+        sc2["plane_id"][drop] = 0
+        if keep is not None:
+            sc2["p_FinG"][keep] = refined
+            slam_kept += kept_lm
+    assert len(slam_kept) == 2  # both landmarks survive fit and refinement
+    sc2["plane_id"][~ok] = 0
+    good = np.where(ok)[0]
+    sub = Scene(sc2)
+    for key in ("uv", "clone_idx", "n_meas", "p_FinG", "plane_id"):
+        sub[key] = sc2[key][good]
+    sub["F"] = len(good)
+    slam_sel = dict(plane=slam["plane"][slam_kept], id=slam["id"][slam_kept], p=slam["p"][slam_kept], p_fej=slam["p_fej"][slam_kept])
+    ref = _oracle_full_update(oracle, sub, slam=slam_sel)
+    out = hostlib.run_updater(sc, "msckf_fit", fit_planes=fit, slam=slam)
+    exp_kept = np.zeros(sc.F, dtype=bool)
+    exp_kept[good[ref["kept"]]] = True
+    assert (out["kept"] == exp_kept).all()
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(out["cp"] - ref["cp"][sc.plane_in_state]).max() < TOL_DX
+    assert np.abs(out["slam_p"][slam_kept] - ref["slam_p"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+    assert list(out["slam_to_plane"][:2]) == [int(slam["plane"][0]), int(slam["plane"][1])]  # :636-639

@@ -371,3 +371,56 @@ def test_triangulation_c_restatement_equals_independent_numpy_and_finds_the_poin
         return e
 
     assert cost(r["p_FinG"]) <= cost(lin["p_FinG"]) * (1 + 1e-9)
+
+
+def _slam_rows_on_planes(sc, k_rows, rng):
+    from ov_plane_amd.synth import slam_rows_on_planes
+
+    return slam_rows_on_planes(sc, k_rows, seed=1)
+
+
+def test_plane_update_slam_rows_are_absorbed_by_an_uninformed_landmark(oracle):
+    """A SLAM landmark on an out-of-state plane contributes one constraint row whose feature Jacobian stays in the landmark's
+    columns (update/UpdaterMSCKF.cpp:545-552).  If that landmark is uncorrelated with the rest and practically unknown, the
+    row can only inform the landmark: every other state and covariance entry must come out as without the row."""
+    from ov_plane_amd.synth import Scene
+
+    sc = make_scene(C=8, F=90, seed=73, n_planes=3, feats_per_plane=15, n_slam=3, chi2_mult=99999.0, ragged=True)
+    rng = np.random.default_rng(1)
+    slam = _slam_rows_on_planes(sc, 2, rng)
+    sc2 = Scene(sc)
+    P = sc.P.copy()
+    for i in slam["id"]:
+        P[i:i + 3, :] = 0.0
+        P[:, i:i + 3] = 0.0
+        P[i:i + 3, i:i + 3] = 1e6 * np.eye(3)
+    sc2["P"] = P
+    base = oracle.msckf_plane_update(sc2)
+    with_rows = oracle.msckf_plane_update(sc2, slam=slam)
+    assert with_rows["plane_ok"].all() and base["plane_ok"].all()
+    keep = np.ones(sc.N, dtype=bool)
+    for i in slam["id"]:
+        keep[i:i + 3] = False
+    d = np.sqrt(np.diag(base["P"])[keep])
+    assert (np.abs(with_rows["P"][np.ix_(keep, keep)] - base["P"][np.ix_(keep, keep)]) / np.outer(d, d)).max() < 1e-6
+    assert np.abs(with_rows["clone_p"] - base["clone_p"]).max() < 1e-6
+    assert (with_rows["plane_rows"] >= base["plane_rows"]).all()
+    # and the landmark moved towards the plane: its variance along the normal collapsed to the constraint's sigma
+    for q, i in enumerate(slam["id"]):
+        cp = sc.cp[slam["plane"][q] - 1]
+        nrm = cp / np.linalg.norm(cp)
+        assert nrm @ with_rows["P"][i:i + 3, i:i + 3] @ nrm < 1.0  # from 1e6
+        assert abs(nrm @ with_rows["slam_p"][q] - np.linalg.norm(cp)) < 0.2
+
+
+def test_plane_update_slam_rows_correlate_the_landmark_with_the_window(oracle):
+    """With the scene's own (correlated, informative) landmark prior the row does change the rest of the state."""
+    sc = make_scene(C=8, F=90, seed=73, n_planes=3, feats_per_plane=15, n_slam=3, chi2_mult=99999.0, ragged=True)
+    slam = _slam_rows_on_planes(sc, 3, np.random.default_rng(1))
+    base = oracle.msckf_plane_update(sc)
+    with_rows = oracle.msckf_plane_update(sc, slam=slam)
+    assert with_rows["plane_ok"].all()
+    assert np.abs(with_rows["P"] - base["P"]).max() > 1e-9
+    assert np.abs(with_rows["slam_p"] - slam["p"]).max() > 1e-6
+    ev = np.linalg.eigvalsh(with_rows["P"])
+    assert ev.min() > -1e-12 * ev.max()
