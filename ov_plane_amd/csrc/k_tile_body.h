@@ -38,13 +38,20 @@ static constexpr int TC_TILE_WAVES = 7;
 // multiply-accumulate of two LDS tiles in "row, k" form:  acc += sign * X[row][:] . Y[col][:]
 __device__ __forceinline__ double4_t mfma_xyT(const double* X, const double* Y, double4_t acc, double sign, int lc,
                                               int lr) {
+  // all eight operands first, then two accumulation chains: a dependent f64 MFMA costs ~200 cycles, an independent one
+  // ~110, and every tile update sits in its own scalar-branch block, so nothing else could fill the gaps
+  double a[4], b[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const double a = sign * X[lc * TS + lr + 4 * s];
-    const double b = Y[lc * TS + lr + 4 * s];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    a[s] = sign * X[lc * TS + lr + 4 * s];
+    b[s] = Y[lc * TS + lr + 4 * s];
   }
-  return acc;
+  double4_t acc1 = {0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+  return acc + acc1;
 }
 
 // 16x16 diagonal block, one wave.
@@ -245,6 +252,62 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
       if (ti[s] == 0 && tj[s] == 0) publish_diag(tile[s], 0);
     });
 
+    // Store of a finished tile: the tile-packed copy (column-major inside the tile = coalesced MFMA A-operand reads in
+    // k_fwdsub) and / or the dense L (lower; the mirrored tile of the strict upper triangle is zeroed).  What stores cost here
+    // is their NUMBER - ~30 cycles of the CU's one vector-memory pipe each, 16 us of an 86 us factorization at N = 210 when
+    // every tile took twelve 8-byte stores, wherever in the kernel they were issued - so the tile is turned around in the
+    // wave's LDS scratch (free between the trailing update and the next panel solve) and leaves as 16-byte stores, and a
+    // caller that only needs the packed copy passes L = nullptr.  (ld, lc, lr: opaque per-step copies, otherwise the address
+    // arithmetic of all 15 slots is hoisted out of the step loop and spills.)
+    typedef double dbl2s __attribute__((ext_vector_type(2)));
+    auto store_tile = [&](auto sc, int ld, int lc, int lr) {
+      constexpr int s = decltype(sc)::value;
+      if (ti[s] >= 0 && !(dbg_skip & 16)) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sw[(lr + 4 * v) * TS + lc] = tile[s][v];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int l2 = 2 * (16 * lr + lc);  // two consecutive elements per lane and store
+        if (Lpack) {
+          double* pk = Lpack + (size_t)(s * TC_TILE_WAVES + tw) * (ld - ld + 256);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = l2 + 128 * h;  // packed offset = column * 16 + row
+            const int col = e >> 4, row = e & 15;
+            *reinterpret_cast<dbl2s*>(pk + e) = dbl2s{sw[row * TS + col], sw[(row + 1) * TS + col]};
+          }
+        }
+        if (!L) {
+        } else if (ti[s] < nfull) {  // interior tile (j <= i < nfull): no range checks
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = l2 + 128 * h;  // row-major inside the tile
+            const int row = e >> 4, col = e & 15;
+            *reinterpret_cast<dbl2s*>(L + (size_t)(16 * ti[s] + row) * ld + 16 * tj[s] + col) =
+                dbl2s{sw[row * TS + col], sw[row * TS + col + 1]};
+            if (ti[s] != tj[s]) *reinterpret_cast<dbl2s*>(L + (size_t)(16 * tj[s] + row) * ld + 16 * ti[s] + col) = dbl2s{0.0, 0.0};
+          }
+        } else {
+          const int c = 16 * tj[s] + lc;
+          const int c2 = 16 * ti[s] + lc;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = 16 * ti[s] + lr + 4 * v;
+            if (r < n && c < n) L[(size_t)r * ld + c] = tile[s][v];
+          }
+          if (ti[s] != tj[s]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int r2 = 16 * tj[s] + lr + 4 * v;
+              if (r2 < n && c2 < n) L[(size_t)r2 * ld + c2] = 0.0;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // sw is reused by the next tile
+      }
+    };
+
     for (int k = 0; k < nt; ++k) {
       __syncthreads();  // B2: L_kk in Dbuf, W = L_kk^-T in Wbuf
       // (c) diagonal owner reloads L_kk; panel tiles <- tile * W, published to PB
@@ -260,13 +323,18 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            double4_t acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            double pa[4], pw[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const double a = sw[lc * TS + lr + 4 * q];
-              const double b = Wbuf[(lr + 4 * q) * TS + lc];
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+              pa[q] = sw[lc * TS + lr + 4 * q];
+              pw[q] = Wbuf[(lr + 4 * q) * TS + lc];
             }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pw[0], acc, 0, 0, 0);  // two chains, see mfma_xyT
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[1], pw[1], acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[2], pw[2], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[3], pw[3], acc1, 0, 0, 0);
+            acc = acc + acc1;
             tile[s] = acc;
             double* pb = PB + ti[s] * TSZ;
 #pragma unroll
@@ -289,42 +357,17 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
         if (tj[s] > k && !(ti[s] == k + 1 && tj[s] == k + 1) && !(dbg_skip & 4))
           tile[s] = mfma_xyT(PB + ti[s] * TSZ, PB + tj[s] * TSZ, tile[s], -1.0, lc, lr);
       });
+      // column k is final: its tiles go out while the following steps run
+      int ld_k = ld, lc_k = lc, lr_k = lr;
+      asm volatile("" : "+s"(ld_k));
+      asm volatile("" : "+v"(lc_k), "+v"(lr_k));
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (tj[s] == k) store_tile(sc, ld_k, lc_k, lr_k);
+      });
       // PB is rewritten only after B2 of the next step, which every wave reaches after its trailing update
     }
-    // ---- store L (lower); the mirrored tile of the strict upper triangle is zero ----
-    sfor<MAXSLOT>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      if (ti[s] >= 0 && !(dbg_skip & 16)) {
-        const int c = 16 * tj[s] + lc;
-        const int c2 = 16 * ti[s] + lc;
-        if (Lpack) {  // tile-packed copy, column-major inside the tile = coalesced MFMA A-operand reads in k_fwdsub
-          double* pk = Lpack + (size_t)(s * TC_TILE_WAVES + tw) * 256;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) pk[lc * 16 + lr + 4 * v] = tile[s][v];
-        }
-        if (ti[s] < nfull) {  // interior tile (j <= i < nfull): no range checks
-#pragma unroll
-          for (int v = 0; v < 4; ++v) L[(size_t)(16 * ti[s] + lr + 4 * v) * ld + c] = tile[s][v];
-          if (ti[s] != tj[s]) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) L[(size_t)(16 * tj[s] + lr + 4 * v) * ld + c2] = 0.0;
-          }
-        } else {
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int r = 16 * ti[s] + lr + 4 * v;
-            if (r < n && c < n) L[(size_t)r * ld + c] = tile[s][v];
-          }
-          if (ti[s] != tj[s]) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int r2 = 16 * tj[s] + lr + 4 * v;
-              if (r2 < n && c2 < n) L[(size_t)r2 * ld + c2] = 0.0;
-            }
-          }
-        }
-      }
-    });
+    // (tiles were stored as their columns became final, see store_tile)
   }
 }
 

@@ -621,7 +621,7 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     // W1 = A L ;  T = I + L^T W1 ;  Lt = chol(T) (+ inverses of its diagonal blocks)
     HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
-    HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, c->Ltp, n, ld, c->flags, 0, c->stream));
+    HIPCHK(ovp_launch_tilechol(c->T, nullptr /* dense Lt is not needed */, c->Dinv, c->Ltp, n, ld, c->flags, 0, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->stream));
@@ -917,7 +917,7 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   // EKF update in information form with the chained factor
   HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
-  HIPCHK(ovp_launch_tilechol(c->T, c->Lt, c->Dinv, c->Ltp, n, ld, c->flags, 0, s));
+  HIPCHK(ovp_launch_tilechol(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 0, s));
   HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
   HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
   HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
