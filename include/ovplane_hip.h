@@ -60,8 +60,10 @@ typedef struct {
   double calib_q[4];         /* R_ItoC (State::_calib_IMUtoCAM.at(0))        */
   double calib_p[3];         /* p_IinC                                       */
   int calib_id;              /* ignored unless do_calib_camera_pose          */
-  double intrinsics[8];      /* fx fy cx cy k1 k2 p1 p2 (State::_cam_intrinsics.at(0)) */
+  double intrinsics[8];      /* fx fy cx cy k1 k2 p1 p2 (State::_cam_intrinsics.at(0)); k1..k4 for the fisheye model */
   int intr_id;               /* ignored unless do_calib_camera_intrinsics    */
+  int cam_fisheye;           /* 0 = ext CamRadtan, 1 = ext CamEqui (State::_cam_intrinsics_cameras.at(0), call sites
+                                update/UpdaterHelper.cpp:365,389) */
 } ovp_state_tables;
 
 /* SoA form of a vector of UpdaterHelper::UpdaterHelperFeature (update/UpdaterHelper.h:62-105),

@@ -53,6 +53,37 @@ def radtan_distort_jacobian(uv_norm, v):
     return dz_dzn, dz_dzeta
 
 
+def equi_distort_d(uv_norm, v):
+    """ext ov_core CamEqui::distort_d (fisheye): theta_d = theta + k1 theta^3 + k2 theta^5 + k3 theta^7 + k4 theta^9."""
+    fx, fy, cx, cy, k1, k2, k3, k4 = v
+    x, y = uv_norm
+    r = np.sqrt(x * x + y * y)
+    th = np.arctan(r)
+    th_d = th + k1 * th**3 + k2 * th**5 + k3 * th**7 + k4 * th**9
+    cdist = th_d / r if r > 1e-8 else 1.0
+    return np.array([fx * x * cdist + cx, fy * y * cdist + cy])
+
+
+def equi_distort_jacobian(uv_norm, v):
+    """ext CamEqui::compute_distort_jacobian, written as the derivative of cdist(r) * xy instead of the chain the C code uses."""
+    fx, fy, cx, cy, k1, k2, k3, k4 = v
+    x, y = uv_norm
+    r = np.sqrt(x * x + y * y)
+    th = np.arctan(r)
+    th_d = th + k1 * th**3 + k2 * th**5 + k3 * th**7 + k4 * th**9
+    dthd_dr = (1 + 3 * k1 * th**2 + 5 * k2 * th**4 + 7 * k3 * th**6 + 9 * k4 * th**8) / (1 + r * r)
+    cdist = th_d / r
+    dc_dr = (dthd_dr * r - th_d) / (r * r)
+    xy = np.array([x, y])
+    d = cdist * np.eye(2) + np.outer(xy, xy) * dc_dr / r
+    dz_dzn = np.diag([fx, fy]) @ d
+    dz_dzeta = np.zeros((2, 8))
+    pw = np.array([th**3, th**5, th**7, th**9])
+    dz_dzeta[0] = np.r_[x * cdist, 0, 1, 0, fx * x / r * pw]
+    dz_dzeta[1] = np.r_[0, y * cdist, 0, 1, fy * y / r * pw]
+    return dz_dzn, dz_dzeta
+
+
 # ------------------------------------------------------------------------------------------------
 # Givens pieces (Eigen JacobiRotation::makeGivens / applyOnTheLeft(0,1,G.adjoint()); SURVEY Appendix A)
 # ------------------------------------------------------------------------------------------------
@@ -190,7 +221,7 @@ def feature_jacobian_full(sc, f, sigma_c=None, p_FinG=None, cp=None, cp_fej=None
         p_FinIi = R_GtoIi @ (p_f - p_IiinG)
         p_FinCi = R_ItoC @ p_FinIi + p_IinC
         uv_norm = np.array([p_FinCi[0] / p_FinCi[2], p_FinCi[1] / p_FinCi[2]])
-        uv_dist = radtan_distort_d(uv_norm, intr)
+        uv_dist = (equi_distort_d if sc.get("fisheye", False) else radtan_distort_d)(uv_norm, intr)
         uv_m = sc.uv[f, k].astype(np.float64)
         res[c : c + 2] = white * (uv_m - uv_dist)
         if o["do_fej"]:
@@ -198,7 +229,7 @@ def feature_jacobian_full(sc, f, sigma_c=None, p_FinG=None, cp=None, cp_fej=None
             p_IiinG = st["clone_p_fej"][ci]
             p_FinIi = R_GtoIi @ (p_f_fej - p_IiinG)
             p_FinCi = R_ItoC @ p_FinIi + p_IinC
-        dz_dzn, dz_dzeta = radtan_distort_jacobian(uv_norm, intr)  # NOTE: non-FEJ uv_norm (:383,389)
+        dz_dzn, dz_dzeta = (equi_distort_jacobian if sc.get("fisheye", False) else radtan_distort_jacobian)(uv_norm, intr)  # non-FEJ uv_norm (:383,389)
         z = p_FinCi[2]
         dzn_dpfc = np.array([[1 / z, 0, -p_FinCi[0] / (z * z)], [0, 1 / z, -p_FinCi[1] / (z * z)]])
         dpfc_dpfg = R_ItoC @ R_GtoIi

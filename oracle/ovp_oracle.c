@@ -233,6 +233,53 @@ static void llt_solve_vec(const double *L, int n, int ld, double *b) {
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * ext ov_core CamEqui::distort_d / compute_distort_jacobian (fisheye; same call sites), value = fx fy cx cy k1 k2 k3 k4:
+ *   theta = atan(r), theta_d = theta + k1 theta^3 + k2 theta^5 + k3 theta^7 + k4 theta^9, uv = f * xy * theta_d / r + c
+ * ------------------------------------------------------------------------------------------- */
+void ovo_equi_distort(const double v[8], const double uvn[2], double uvd[2]) {
+  const double r = sqrt(uvn[0] * uvn[0] + uvn[1] * uvn[1]);
+  const double th = atan(r);
+  const double th_d = th + v[4] * pow(th, 3) + v[5] * pow(th, 5) + v[6] * pow(th, 7) + v[7] * pow(th, 9);
+  const double inv_r = (r > 1e-8) ? 1.0 / r : 1.0;
+  const double cdist = (r > 1e-8) ? th_d * inv_r : 1.0;
+  uvd[0] = v[0] * (uvn[0] * cdist) + v[2];
+  uvd[1] = v[1] * (uvn[1] * cdist) + v[3];
+}
+
+void ovo_equi_jacobian(const double v[8], const double uvn[2], double dz_dzn[4], double dz_dzeta[16]) {
+  const double x = uvn[0], y = uvn[1];
+  const double r = sqrt(x * x + y * y);
+  const double th = atan(r);
+  const double th_d = th + v[4] * pow(th, 3) + v[5] * pow(th, 5) + v[6] * pow(th, 7) + v[7] * pow(th, 9);
+  const double inv_r = (r > 1e-8) ? 1.0 / r : 1.0;
+  const double cdist = (r > 1e-8) ? th_d * inv_r : 1.0;
+  /* duv_dxy (dxy_dxyn + (dxy_dr + dxy_dthd dthd_dth dth_dr) dr_dxyn) */
+  const double dthd_dth = 1 + 3 * v[4] * pow(th, 2) + 5 * v[5] * pow(th, 4) + 7 * v[6] * pow(th, 6) + 9 * v[7] * pow(th, 8);
+  const double dth_dr = 1 / (r * r + 1);
+  const double dxy_dr[2] = {-x * th_d * inv_r * inv_r, -y * th_d * inv_r * inv_r};
+  const double dxy_dthd[2] = {x * inv_r, y * inv_r};
+  const double dr_dxyn[2] = {x * inv_r, y * inv_r};
+  double M[4];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      M[2 * i + j] = ((i == j) ? th_d * inv_r : 0.0) + (dxy_dr[i] + dxy_dthd[i] * dthd_dth * dth_dr) * dr_dxyn[j];
+  dz_dzn[0] = v[0] * M[0];
+  dz_dzn[1] = v[0] * M[1];
+  dz_dzn[2] = v[1] * M[2];
+  dz_dzn[3] = v[1] * M[3];
+  memset(dz_dzeta, 0, 16 * sizeof(double));
+  dz_dzeta[0] = x * cdist;
+  dz_dzeta[2] = 1;
+  dz_dzeta[8 + 1] = y * cdist;
+  dz_dzeta[8 + 3] = 1;
+  for (int k = 0; k < 4; ++k) {
+    const double pw = pow(th, 3 + 2 * k);
+    dz_dzeta[4 + k] = v[0] * x * inv_r * pw;
+    dz_dzeta[8 + 4 + k] = v[1] * y * inv_r * pw;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
  * small 3x3 helpers (row-major)
  * ------------------------------------------------------------------------------------------- */
 static void mat3_mul(const double *A, const double *B, double *C) {
@@ -332,7 +379,8 @@ int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_
     p_FinCi[2] += p_IinC[2];
     double uv_norm[2] = {p_FinCi[0] / p_FinCi[2], p_FinCi[1] / p_FinCi[2]};
     double uv_dist[2];
-    ovo_radtan_distort(st->intrinsics, uv_norm, uv_dist);
+    if (st->cam_fisheye) ovo_equi_distort(st->intrinsics, uv_norm, uv_dist);
+    else ovo_radtan_distort(st->intrinsics, uv_norm, uv_dist);
     const double uv_m[2] = {(double)uv[2 * k], (double)uv[2 * k + 1]};
     res[c] = white_px * (uv_m[0] - uv_dist[0]);
     res[c + 1] = white_px * (uv_m[1] - uv_dist[1]);
@@ -351,7 +399,8 @@ int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_
     }
     /* :388-401 */
     double dz_dzn[4], dz_dzeta[16];
-    ovo_radtan_jacobian(st->intrinsics, uv_norm, dz_dzn, dz_dzeta);
+    if (st->cam_fisheye) ovo_equi_jacobian(st->intrinsics, uv_norm, dz_dzn, dz_dzeta);
+    else ovo_radtan_jacobian(st->intrinsics, uv_norm, dz_dzn, dz_dzeta);
     const double z = p_FinCi[2];
     const double dzn_dpfc[6] = {1 / z, 0, -p_FinCi[0] / (z * z), 0, 1 / z, -p_FinCi[1] / (z * z)};
     double dpfc_dpfg[9];

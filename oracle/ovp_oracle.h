@@ -47,8 +47,9 @@ typedef struct {
   double calib_q[4];         /* R_ItoC  (State::_calib_IMUtoCAM) */
   double calib_p[3];         /* p_IinC */
   int calib_id;              /* -1 when not calibrating */
-  double intrinsics[8];      /* fx fy cx cy k1 k2 p1 p2 (State::_cam_intrinsics), radtan */
+  double intrinsics[8];      /* fx fy cx cy k1 k2 p1 p2 (State::_cam_intrinsics): radtan, or k1..k4 of the equidistant model */
   int intr_id;
+  int cam_fisheye;           /* 0 = ext CamRadtan, 1 = ext CamEqui (State::_cam_intrinsics_cameras) */
 } ovo_state;
 
 /* SoA form of UpdaterHelper::UpdaterHelperFeature (update/UpdaterHelper.h:62-105), GLOBAL_3D. */
@@ -74,6 +75,8 @@ int ovo_llt(double *A, int n, int ld);                        /* in-place lower 
 /* update/UpdaterHelper.cpp:195-513.  Column-major outputs, caller-allocated:
  *   H_f [rows x 3 (or 6)], H_x [rows x cols], res [rows]; order_id/order_size [<= n_meas+3].
  * planeid==0: point feature.  planeid!=0: cp/cp_fej used; plane_state_id>=0 means plane in state. */
+void ovo_equi_distort(const double v[8], const double uvn[2], double uvd[2]);
+void ovo_equi_jacobian(const double v[8], const double uvn[2], double dz_dzn[4], double dz_dzeta[16]);
 int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, double sigma_c,
                               int planeid, const double *cp, const double *cp_fej, int plane_state_id, double *H_f,
                               double *H_x, double *res, int *rows, int *cols, int *hf_cols, int *order_id,

@@ -39,6 +39,7 @@ class OvoState(C.Structure):
         ("calib_id", C.c_int),
         ("intrinsics", C.c_double * 8),
         ("intr_id", C.c_int),
+        ("cam_fisheye", C.c_int),
     ]
 
 
@@ -108,6 +109,7 @@ class Packed:
         st.calib_id = int(sc.ids["calib"]) if o["do_calib_pose"] else -1
         st.intrinsics[:] = list(sc.intr)
         st.intr_id = int(sc.ids["intr"]) if o["do_calib_intr"] else -1
+        st.cam_fisheye = 1 if sc.get("fisheye", False) else 0
         self.state = st
         sel = slice(None) if feats is None else np.asarray(feats)
         self.uv = np.ascontiguousarray(sc.uv[sel], dtype=np.float32)

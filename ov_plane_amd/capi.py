@@ -50,6 +50,7 @@ class StateTables(C.Structure):
         ("calib_id", C.c_int),
         ("intrinsics", C.c_double * 8),
         ("intr_id", C.c_int),
+        ("cam_fisheye", C.c_int),
     ]
 
 
@@ -293,6 +294,7 @@ class Context:
         st.calib_id = int(sc.ids["calib"])
         st.intrinsics[:] = list(s["intr"])
         st.intr_id = int(sc.ids["intr"])
+        st.cam_fisheye = 1 if sc.get("fisheye", False) else 0
         _chk(lib().ovp_state_upload(self._h, C.byref(st)), "ovp_state_upload")
 
     def batch_upload(self, uv, clone_idx, n_meas, p_FinG):

@@ -15,6 +15,9 @@ extern "C" void ovph_set_uv_norm(const float *uv_norm /* [F][M][2] or NULL */) {
 // next ovph_run_msckf_update: no plane estimates are handed over, UpdaterMSCKF::update runs plane_fitting / optimize_plane itself
 static int g_fit_planes = 0, g_fit_min_feat = 20, g_fit_variant = 0;
 static double g_fit_max_cond = 100.0;
+// lens model of camera 0 for the next harness call (0 = radtan, 1 = equidistant)
+static int g_fisheye = 0;
+extern "C" void ovph_set_fisheye(int fisheye) { g_fisheye = fisheye; }
 // mode 3 of ovph_run_updater: plane of every SLAM landmark (0 = none)
 static const int *g_slam_plane = nullptr;
 extern "C" void ovph_set_slam_planes(const int *plane_of_landmark) { g_slam_plane = plane_of_landmark; }
@@ -50,6 +53,8 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   so.max_state_size = N + 8;
   so.max_features = F + 8;
   auto state = std::make_shared<State>(so);
+  state->_cam_fisheye[0] = g_fisheye != 0;
+  g_fisheye = 0;
   // calibration values
   {
     VectorXd v(7, 1);
@@ -261,6 +266,8 @@ int build_harness_state(HarnessState &hs, StateOptions &so, int C, const double 
                         const double *cp, const double *cp_fej, int N, const double *P) {
   hs.state = std::make_shared<State>(so);
   auto &state = hs.state;
+  state->_cam_fisheye[0] = g_fisheye != 0;
+  g_fisheye = 0;
   VectorXd v(7, 1);
   for (int k = 0; k < 4; ++k) v(k) = calib_q[k];
   for (int k = 0; k < 3; ++k) v(4 + k) = calib_p[k];

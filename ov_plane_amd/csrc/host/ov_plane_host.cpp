@@ -655,6 +655,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     st.calib_id = calib->id();
     memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
     st.intr_id = intr->id();
+    st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
     gpu_check(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
   };
   auto upload_batch = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv) {

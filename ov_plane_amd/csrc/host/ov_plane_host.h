@@ -116,6 +116,9 @@ public:
   std::map<double, std::shared_ptr<ov_type::PoseJPL>> _clones_IMU;
   std::shared_ptr<ov_type::Vec> _calib_dt_CAMtoIMU;
   std::unordered_map<size_t, std::shared_ptr<ov_type::PoseJPL>> _calib_IMUtoCAM;
+  // lens model of every camera: false = ext CamRadtan, true = ext CamEqui (the reference keeps CamBase objects in
+  // _cam_intrinsics_cameras, state/State.h; missing entry = radtan)
+  std::unordered_map<size_t, bool> _cam_fisheye;
   std::unordered_map<size_t, std::shared_ptr<ov_type::Vec>> _cam_intrinsics;
   std::unordered_map<size_t, std::shared_ptr<ov_type::Landmark>> _features_SLAM;
   std::unordered_map<size_t, std::shared_ptr<ov_type::Vec>> _features_PLANE;

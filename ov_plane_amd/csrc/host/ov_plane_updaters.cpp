@@ -103,10 +103,23 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
     m3v(R_ItoC, p_FinIi, p_FinCi);
     for (int k = 0; k < 3; ++k) p_FinCi[k] += p_IinC[k];
     const double x = p_FinCi[0] / p_FinCi[2], y = p_FinCi[1] / p_FinCi[2];
-    // ext CamRadtan::distort_d (:365)
+    // ext CamRadtan::distort_d / CamEqui::distort_d (:365)
+    const bool fisheye = state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0);
     const double r2 = x * x + y * y, r4 = r2 * r2, g = 1 + v[4] * r2 + v[5] * r4;
-    const double x1 = x * g + 2 * v[6] * x * y + v[7] * (r2 + 2 * x * x);
-    const double y1 = y * g + v[6] * (r2 + 2 * y * y) + 2 * v[7] * x * y;
+    double x1, y1;
+    double rr = 0, th = 0, th_d = 0, inv_r = 1, cdist = 1;
+    if (fisheye) {
+      rr = std::sqrt(r2);
+      th = std::atan(rr);
+      th_d = th + v[4] * std::pow(th, 3) + v[5] * std::pow(th, 5) + v[6] * std::pow(th, 7) + v[7] * std::pow(th, 9);
+      inv_r = (rr > 1e-8) ? 1.0 / rr : 1.0;
+      cdist = (rr > 1e-8) ? th_d * inv_r : 1.0;
+      x1 = x * cdist;
+      y1 = y * cdist;
+    } else {
+      x1 = x * g + 2 * v[6] * x * y + v[7] * (r2 + 2 * x * x);
+      y1 = y * g + v[6] * (r2 + 2 * y * y) + 2 * v[7] * x * y;
+    }
     res(c) = white_px * ((double)feature.uvs[2 * m] - (v[0] * x1 + v[2]));
     res(c + 1) = white_px * ((double)feature.uvs[2 * m + 1] - (v[1] * y1 + v[3]));
     if (state->_options.do_fej) {  // :376-385
@@ -137,6 +150,26 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
     dz_dzeta[13] = fy * y * r4;
     dz_dzeta[14] = fy * (r2 + 2 * y * y);
     dz_dzeta[15] = 2 * fy * x * y;
+    if (fisheye) {  // ext CamEqui::compute_distort_jacobian
+      const double dthd_dth = 1 + 3 * v[4] * std::pow(th, 2) + 5 * v[5] * std::pow(th, 4) + 7 * v[6] * std::pow(th, 6) + 9 * v[7] * std::pow(th, 8);
+      const double dth_dr = 1 / (rr * rr + 1);
+      const double a0 = -x * th_d * inv_r * inv_r + x * inv_r * dthd_dth * dth_dr;
+      const double a1 = -y * th_d * inv_r * inv_r + y * inv_r * dthd_dth * dth_dr;
+      dz_dzn[0] = fx * (th_d * inv_r + a0 * x * inv_r);
+      dz_dzn[1] = fx * (a0 * y * inv_r);
+      dz_dzn[2] = fy * (a1 * x * inv_r);
+      dz_dzn[3] = fy * (th_d * inv_r + a1 * y * inv_r);
+      memset(dz_dzeta, 0, sizeof(dz_dzeta));
+      dz_dzeta[0] = x1;
+      dz_dzeta[2] = 1;
+      dz_dzeta[9] = y1;
+      dz_dzeta[11] = 1;
+      for (int k = 0; k < 4; ++k) {
+        const double pw = std::pow(th, 3 + 2 * k);
+        dz_dzeta[4 + k] = fx * x * inv_r * pw;
+        dz_dzeta[12 + k] = fy * y * inv_r * pw;
+      }
+    }
     const double z = p_FinCi[2];
     const double dzn_dpfc[6] = {1 / z, 0, -p_FinCi[0] / (z * z), 0, 1 / z, -p_FinCi[1] / (z * z)};
     double dpfc_dpfg[9], sk[9], Rsk[9];
@@ -584,6 +617,7 @@ void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std:
   st.calib_id = calib->id();
   memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
   st.intr_id = intr->id();
+  st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
   gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
   auto upload = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv, int &M_out) {
     const int Fn = (int)fv.size();

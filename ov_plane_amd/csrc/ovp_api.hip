@@ -477,6 +477,7 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
   fp.cal = c->cal;
   c->calib_id = st->calib_id;
   c->intr_id = st->intr_id;
+  c->fp.fisheye = st->cam_fisheye ? 1 : 0;
   // column map for the assembly kernel (calibration columns are enabled per update via the opts)
   std::vector<ovp::ColMap> cm(c->n_max);
   for (auto& m : cm) m.kind = m.idx = m.off = m.pad = 0;

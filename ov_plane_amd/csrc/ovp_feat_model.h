@@ -1,5 +1,5 @@
 // Measurement model of one bearing row (shared by the point and the plane feature kernels).
-// update/UpdaterHelper.cpp:345-444 (GLOBAL_3D, radtan, mono): residual, H_f row, clone block, calibration block.
+// update/UpdaterHelper.cpp:345-444 (GLOBAL_3D, radtan or equidistant lens, mono): residual, H_f row, clone block, calibration block.
 #pragma once
 #include "ovp_dev.h"
 #include "ovp_kernels.h"
@@ -23,13 +23,37 @@ __device__ __forceinline__ void build_bearing_row(const FeatParams& p, int f, in
     double pC1 = Rc[3] * pI0 + Rc[4] * pI1 + Rc[5] * pI2 + pIC1;
     double pC2 = Rc[6] * pI0 + Rc[7] * pI1 + Rc[8] * pI2 + pIC2;
     const double x = pC0 / pC2, y = pC1 / pC2;
-    // ext CamRadtan::distort_d (call site UpdaterHelper.cpp:365)
+    // ext CamRadtan::distort_d / CamEqui::distort_d (call site UpdaterHelper.cpp:365); the model is wave-uniform
     const double fx = cal[12 + 0], fy = cal[12 + 1], cx = cal[12 + 2], cy = cal[12 + 3];
     const double k1 = cal[12 + 4], k2 = cal[12 + 5], p1 = cal[12 + 6], p2 = cal[12 + 7];
     const double r2 = x * x + y * y, r4 = r2 * r2;
-    const double g = 1.0 + k1 * r2 + k2 * r4;
-    const double x1 = x * g + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
-    const double y1 = y * g + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+    double g = 0.0, x1, y1;
+    // equidistant model: theta powers, 1/r and the 2x2 d(xy1)/d(xy) (ext CamEqui::compute_distort_jacobian)
+    double th3 = 0.0, th5 = 0.0, th7 = 0.0, th9 = 0.0, inv_r = 1.0, e00 = 0.0, e01 = 0.0, e11 = 0.0;
+    if (p.fisheye) {
+      const double rr = sqrt(r2);
+      const double th = atan(rr), t2 = th * th;
+      th3 = th * t2;
+      th5 = th3 * t2;
+      th7 = th5 * t2;
+      th9 = th7 * t2;
+      const double th_d = th + k1 * th3 + k2 * th5 + p1 * th7 + p2 * th9;
+      inv_r = (rr > 1e-8) ? 1.0 / rr : 1.0;
+      const double cdist = (rr > 1e-8) ? th_d * inv_r : 1.0;
+      x1 = x * cdist;
+      y1 = y * cdist;
+      const double dthd_dth = 1.0 + 3.0 * k1 * t2 + 5.0 * k2 * t2 * t2 + 7.0 * p1 * t2 * t2 * t2 + 9.0 * p2 * t2 * t2 * t2 * t2;
+      const double dth_dr = 1.0 / (r2 + 1.0);
+      const double a0 = -x * th_d * inv_r * inv_r + x * inv_r * dthd_dth * dth_dr;
+      const double a1 = -y * th_d * inv_r * inv_r + y * inv_r * dthd_dth * dth_dr;
+      e00 = th_d * inv_r + a0 * (x * inv_r);
+      e01 = a0 * (y * inv_r);  // = a1 * (x * inv_r)
+      e11 = th_d * inv_r + a1 * (y * inv_r);
+    } else {
+      g = 1.0 + k1 * r2 + k2 * r4;
+      x1 = x * g + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+      y1 = y * g + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+    }
     const double ud = fx * x1 + cx, vd = fy * y1 + cy;
     const float* uvp = p.uv + ((size_t)f * p.max_meas + (valid ? a : 0)) * 2;
     const double um = (double)uvp[0], vm = (double)uvp[1];
@@ -48,9 +72,35 @@ __device__ __forceinline__ void build_bearing_row(const FeatParams& p, int f, in
       pC1 = Rc[3] * pI0 + Rc[4] * pI1 + Rc[5] * pI2 + pIC1;
       pC2 = Rc[6] * pI0 + Rc[7] * pI1 + Rc[8] * pI2 + pIC2;
     }
-    // ext CamRadtan::compute_distort_jacobian at the non-FEJ uv_norm (:383,389), row r only
+    // ext Cam*::compute_distort_jacobian at the non-FEJ uv_norm (:383,389), row r only
     double dzn0, dzn1;  // dz_dzn[r][0..1]
-    if (r == 0) {
+    if (p.fisheye) {
+      if (r == 0) {
+        dzn0 = fx * e00;
+        dzn1 = fx * e01;
+        crow[6] = x1;
+        crow[7] = 0.0;
+        crow[8] = 1.0;
+        crow[9] = 0.0;
+        const double q = fx * x * inv_r;
+        crow[10] = q * th3;
+        crow[11] = q * th5;
+        crow[12] = q * th7;
+        crow[13] = q * th9;
+      } else {
+        dzn0 = fy * e01;
+        dzn1 = fy * e11;
+        crow[6] = 0.0;
+        crow[7] = y1;
+        crow[8] = 0.0;
+        crow[9] = 1.0;
+        const double q = fy * y * inv_r;
+        crow[10] = q * th3;
+        crow[11] = q * th5;
+        crow[12] = q * th7;
+        crow[13] = q * th9;
+      }
+    } else if (r == 0) {
       dzn0 = fx * (g + 2.0 * k1 * x * x + 4.0 * k2 * x * x * r2 + 2.0 * p1 * y + 6.0 * p2 * x);
       dzn1 = fx * (2.0 * k1 * x * y + 4.0 * k2 * x * y * r2 + 2.0 * p1 * x + 2.0 * p2 * y);
       crow[6] = x1;

@@ -40,7 +40,8 @@ struct FeatParams {
   const int* clone_id;        // [C]
   int n_clones;
   int do_fej;
-  const double* cal;  // device: [0..8] R_ItoC row-major, [9..11] p_IinC, [12..19] fx fy cx cy k1 k2 p1 p2
+  int fisheye;        // 0 = radtan, 1 = equidistant (ext CamEqui) camera model
+  const double* cal;  // device: [0..8] R_ItoC row-major, [9..11] p_IinC, [12..19] fx fy cx cy k1 k2 p1 p2 (k1..k4 when fisheye)
   int calcol[14];  // state column of calibration column k: k<6 extrinsics, k>=6 intrinsics
   unsigned calmask;  // bit k set = calibration column k is estimated
   double white_px, chi2_mult;

@@ -28,6 +28,7 @@ def run_msckf_update(sc, triangulate=False, fit_planes=None):
     fit_planes=dict(min_feat, max_cond, variant): no plane estimates are handed over - the updater fits the planes that are
     not in the state (PlaneFitting::plane_fitting) and refines planes and on-plane features (optimize_plane) itself."""
     L = lib()
+    L.ovph_set_fisheye(1 if sc.get("fisheye", False) else 0)
     if fit_planes is not None:
         L.ovph_set_plane_fit.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
         L.ovph_set_plane_fit(1, int(fit_planes["min_feat"]), float(fit_planes["max_cond"]), int(fit_planes.get("variant", 0)))
@@ -106,6 +107,7 @@ def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=
     mode "plane_init": UpdaterPlane::init_vio_plane on a scene whose planes are all out of the state.
     """
     L = lib()
+    L.ovph_set_fisheye(1 if sc.get("fisheye", False) else 0)
     # "msckf_fit": UpdaterMSCKF::update on a state with SLAM landmarks (slam = dict(p [k,3], p_fej [k,3], plane [k]); the
     # scene must have n_slam = k landmark columns) and the scene's in-state planes; needs fit_planes
     m = {"slam_update": 0, "slam_delayed_init": 1, "plane_init": 2, "msckf_fit": 3}[mode]

@@ -119,7 +119,36 @@ def radtan_distort(xn, yn, intr):
     return fx * x1 + cx, fy * y1 + cy
 
 
-def project_all(p_f, R_GtoI, p_IinG, R_ItoC, p_IinC, intr):
+FISHEYE_INTRINSICS = np.array([380.0, 379.2, 367.215, 248.375, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673])
+
+
+def equi_distort(xn, yn, intr):
+    """ext ov_core CamEqui (fisheye): theta_d = theta + k1 theta^3 + k2 theta^5 + k3 theta^7 + k4 theta^9."""
+    fx, fy, cx, cy, k1, k2, k3, k4 = intr
+    r = np.sqrt(xn * xn + yn * yn)
+    th = np.arctan(r)
+    th_d = th + k1 * th**3 + k2 * th**5 + k3 * th**7 + k4 * th**9
+    cdist = np.where(r > 1e-8, th_d / np.maximum(r, 1e-300), 1.0)
+    return fx * xn * cdist + cx, fy * yn * cdist + cy
+
+
+def equi_undistort(u, v, intr, iters=30):
+    """Inverse of the equidistant model (Newton on theta, as cv::fisheye::undistortPoints)."""
+    fx, fy, cx, cy, k1, k2, k3, k4 = [float(a) for a in intr]
+    x0 = (np.asarray(u, dtype=np.float64) - cx) / fx
+    y0 = (np.asarray(v, dtype=np.float64) - cy) / fy
+    th_d = np.sqrt(x0 * x0 + y0 * y0)
+    th = th_d.copy()
+    for _ in range(iters):
+        t2 = th * th
+        f = th * (1 + k1 * t2 + k2 * t2**2 + k3 * t2**3 + k4 * t2**4) - th_d
+        df = 1 + 3 * k1 * t2 + 5 * k2 * t2**2 + 7 * k3 * t2**3 + 9 * k4 * t2**4
+        th = th - f / df
+    scale = np.where(th_d > 1e-12, np.tan(th) / np.maximum(th_d, 1e-300), 1.0)
+    return x0 * scale, y0 * scale
+
+
+def project_all(p_f, R_GtoI, p_IinG, R_ItoC, p_IinC, intr, fisheye=False):
     """p_f [F,3]; R_GtoI [C,3,3]; p_IinG [C,3]  ->  uv [F,C,2], z [F,C]."""
     d = p_f[:, None, :] - p_IinG[None, :, :]  # F,C,3
     p_I = np.einsum("cij,fcj->fci", R_GtoI, d)
@@ -127,7 +156,7 @@ def project_all(p_f, R_GtoI, p_IinG, R_ItoC, p_IinC, intr):
     z = p_C[..., 2]
     xn = p_C[..., 0] / z
     yn = p_C[..., 1] / z
-    u, v = radtan_distort(xn, yn, intr)
+    u, v = (equi_distort if fisheye else radtan_distort)(xn, yn, intr)
     return np.stack([u, v], axis=-1), z
 
 
@@ -234,19 +263,19 @@ def _cov(C, ids, rng, n_extra=0):
     return P
 
 
-def _triangulate_gn(p0, uv, mask, R_GtoI, p_IinG, R_ItoC, p_IinC, intr, iters=6):
+def _triangulate_gn(p0, uv, mask, R_GtoI, p_IinG, R_ItoC, p_IinC, intr, iters=6, fisheye=False):
     """Vectorised Gauss-Newton on reprojection error with the *estimated* poses (stand-in for the
     reference's upstream FeatureInitializer; SURVEY.md §8f rank 1 - input generation only here)."""
     p = p0.copy()
     eps = 1e-6
     for _ in range(iters):
-        uv0, _ = project_all(p, R_GtoI, p_IinG, R_ItoC, p_IinC, intr)
+        uv0, _ = project_all(p, R_GtoI, p_IinG, R_ItoC, p_IinC, intr, fisheye)
         r = (uv - uv0) * mask[..., None]  # F,C,2
         J = np.zeros(uv0.shape + (3,))
         for a in range(3):
             dp = np.zeros(3)
             dp[a] = eps
-            uva, _ = project_all(p + dp, R_GtoI, p_IinG, R_ItoC, p_IinC, intr)
+            uva, _ = project_all(p + dp, R_GtoI, p_IinG, R_ItoC, p_IinC, intr, fisheye)
             J[..., a] = (uva - uv0) / eps
         J = J * mask[..., None, None]
         F = p.shape[0]
@@ -276,6 +305,7 @@ def make_scene(
     feat_seed=None,
     px_noise=None,
     err_scale=0.85,
+    fisheye=False,
 ):
     """Build one synthetic update-step input.
 
@@ -303,7 +333,7 @@ def make_scene(
     p_CinI = T_IMU_CAM[:3, 3]
     R_ItoC_true = R_CtoI.T
     p_IinC_true = -R_ItoC_true @ p_CinI
-    intr_true = INTRINSICS.copy()
+    intr_true = (FISHEYE_INTRINSICS if fisheye else INTRINSICS).copy()
 
     # ---- planes: faces of a box in front of the trajectory (cf. Simulator::generate_planes) ------------
     planes_n, planes_d = [], []
@@ -334,7 +364,7 @@ def make_scene(
 
     # ---- features: rejection-sample points visible in every clone they are assigned to -----------------
     def visible(pf, lo, hi):
-        uvp, z = project_all(pf, R_true[lo:hi], p_true[lo:hi], R_ItoC_true, p_IinC_true, intr_true)
+        uvp, z = project_all(pf, R_true[lo:hi], p_true[lo:hi], R_ItoC_true, p_IinC_true, intr_true, fisheye)
         ok = (z > 0.5) & (uvp[..., 0] > 15) & (uvp[..., 0] < IMG_W - 15) & (uvp[..., 1] > 15) & (uvp[..., 1] < IMG_H - 15)
         return ok.all(axis=1)
 
@@ -409,7 +439,7 @@ def make_scene(
         clone_p_fej[i] = clone_p[i] + 1e-3 * rng.standard_normal(3)
 
     # ---- measurements (truth + N(0, sigma_px)), stored as f32 ------------------------------------------
-    uv_true, _ = project_all(p_f, R_true, p_true, R_ItoC_true, p_IinC_true, intr_true)
+    uv_true, _ = project_all(p_f, R_true, p_true, R_ItoC_true, p_IinC_true, intr_true, fisheye)
     # px_noise: the tracker's actual noise when it differs from the sigma the filter assumes
     uv_noisy = uv_true + (sigma_px if px_noise is None else px_noise) * frng.standard_normal(uv_true.shape)
     uv = np.zeros((F, C, 2), dtype=np.float32)
@@ -419,7 +449,7 @@ def make_scene(
 
     # normalised measurements as the tracker stores them (undistorted with the current intrinsics estimate, f32)
     uv_norm = np.zeros((F, C, 2), dtype=np.float32)
-    xn, yn = radtan_undistort(uv[..., 0].astype(np.float64), uv[..., 1].astype(np.float64), intr)
+    xn, yn = (equi_undistort if fisheye else radtan_undistort)(uv[..., 0].astype(np.float64), uv[..., 1].astype(np.float64), intr)
     uv_norm[..., 0] = xn.astype(np.float32)
     uv_norm[..., 1] = yn.astype(np.float32)
     for f in range(F):
@@ -432,7 +462,7 @@ def make_scene(
         m = int(n_meas[f])
         uv_dense[f, start[f] : start[f] + m] = uv[f, :m].astype(np.float64)
     p0 = p_f + 0.02 * np.linalg.norm(p_f - mid, axis=1, keepdims=True) * frng.standard_normal((F, 3))
-    p_FinG = _triangulate_gn(p0, uv_dense, mask, R_est, clone_p, quat_2_rot(calib_q), calib_p, intr)
+    p_FinG = _triangulate_gn(p0, uv_dense, mask, R_est, clone_p, quat_2_rot(calib_q), calib_p, intr, fisheye=fisheye)
 
     # ---- plane estimates ------------------------------------------------------------------------------
     cp = cp_true + 0.01 * rng.standard_normal(cp_true.shape) if n_planes else np.zeros((0, 3))
@@ -481,6 +511,7 @@ def make_scene(
         plane_in_state=in_state,
         plane_state_id=plane_state_id,
         slam_p=slam_p,
+        fisheye=bool(fisheye),
         opts=dict(
             sigma_px=float(sigma_px),
             sigma_c=float(sigma_c),

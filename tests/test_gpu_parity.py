@@ -61,6 +61,8 @@ def test_matches_committed_golden_vectors(hiplib, name):
     dict(C=10, F=70, seed=25, chi2_mult=1.0, calib=False, do_fej=False),
     dict(C=7, F=2300, seed=26, ragged=True, min_meas=3, chi2_mult=1.0),     # more features than one round of the fused K1 launch (2040)
     dict(C=9, F=700, seed=27, chi2_mult=1.0),                                # several waves per workgroup, not all eight
+    dict(C=9, F=120, seed=28, chi2_mult=1.0, fisheye=True),                  # equidistant lens (ext CamEqui)
+    dict(C=31, F=40, seed=29, chi2_mult=1.0, fisheye=True),                  # ... on the all-VALU K1 variant
 ])
 def test_matches_oracle_on_fresh_scenes(hiplib, oracle, kw):
     sc = make_scene(**kw)
@@ -240,6 +242,7 @@ def _apply_plane_dx(sc, dxs, oks):
     dict(C=11, F=160, seed=5, n_planes=4, feats_per_plane=25, chi2_mult=99999.0),
     dict(C=9, F=120, seed=8, n_planes=6, feats_per_plane=12, chi2_mult=99999.0, ragged=True),
     dict(C=30, F=200, seed=9, n_planes=4, feats_per_plane=30, chi2_mult=99999.0),
+    dict(C=8, F=100, seed=10, n_planes=4, feats_per_plane=20, chi2_mult=99999.0, fisheye=True),
 ])
 def test_plane_loop_matches_oracle(hiplib, oracle, kw):
     """UpdaterMSCKF.cpp:411-649 (planes in and out of the state) followed by the point update on the leftover features."""
@@ -347,6 +350,7 @@ def test_plane_loop_with_slam_landmarks_matches_oracle(hiplib, oracle, kw, k_row
     dict(C=11, F=120, seed=71, chi2_mult=1.0),                                           # points only
     dict(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0),         # planes + points
     dict(C=8, F=90, seed=73, n_planes=3, feats_per_plane=15, chi2_mult=99999.0, ragged=True),
+    dict(C=9, F=80, seed=74, chi2_mult=1.0, fisheye=True),
 ])
 def test_host_cpp_mirror_updater_msckf(hiplib, oracle, kw):
     """ov_plane::UpdaterMSCKF::update / StateHelper (C++ host classes, ov_plane_amd/csrc/host) over the C-ABI vs the oracle,
@@ -516,6 +520,7 @@ def _apply_dx_to_scene(sc, dx):
     dict(C=11, n_slam=12, seed=3, outliers=2),
     dict(C=11, n_slam=14, seed=4, n_planes=3, outliers=2, wrong_plane=3),   # plane rows + no-plane fallback
     dict(C=6, n_slam=5, seed=5, do_fej=False),
+    dict(C=8, n_slam=8, seed=6, fisheye=True),                               # dense host Jacobian with the equidistant lens
 ])
 def test_host_cpp_mirror_updater_slam_update(hiplib, oracle, kw):
     """ov_plane::UpdaterSLAM::update (update/UpdaterSLAM.cpp:376-682): per-landmark chi2 over the marginal covariance from the

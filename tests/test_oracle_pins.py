@@ -34,7 +34,8 @@ def test_givens_zeroes_lower_entry(oracle):
         assert (cn, sn) == (c.value, s.value)
 
 
-@pytest.mark.parametrize("kw", [dict(C=6, F=6, seed=1), dict(C=7, F=5, seed=2, ragged=True), dict(C=5, F=4, seed=3, calib=False)])
+@pytest.mark.parametrize("kw", [dict(C=6, F=6, seed=1), dict(C=7, F=5, seed=2, ragged=True), dict(C=5, F=4, seed=3, calib=False),
+                                dict(C=6, F=6, seed=4, fisheye=True)])
 def test_c_jacobian_equals_numpy_restatement(oracle, kw):
     sc = make_scene(**kw)
     for f in range(sc.F):
@@ -51,9 +52,12 @@ def _residual(sc, f, state):
     return res
 
 
-def test_jacobian_finite_differences(oracle):
-    """H_x = -d res / d x under the JPL left-multiplicative error state (do_fej off so H is evaluated at x)."""
-    sc = make_scene(C=5, F=3, seed=7, do_fej=False)
+@pytest.mark.parametrize("fisheye", [False, True])
+def test_jacobian_finite_differences(oracle, fisheye):
+    """H_x = -d res / d x under the JPL left-multiplicative error state (do_fej off so H is evaluated at x); radtan and
+    equidistant (ext CamEqui) lens models - the latter's chain-rule Jacobian is restated in C and, as the derivative of
+    cdist(r) xy, independently in numpy."""
+    sc = make_scene(C=5, F=3, seed=7, do_fej=False, fisheye=fisheye)
     sc.clone_q_fej = sc.clone_q.copy()
     sc.clone_p_fej = sc.clone_p.copy()
     f = 1
