@@ -26,6 +26,10 @@ __device__ __forceinline__ int coff(int k) {  // offset of column k; element (i,
   return 130 * pr - 2 * pr * pr + (k & 1) * (64 - 2 * pr);
 }
 
+// per-feature scratch for B in device memory: the two columns of an observation interleaved, element (i, 2 p + rr), i >= 2 p, at
+// boff(p) + 2 (i - 2 p) + rr - same footprint as the LDS layout above, but a lane's two columns are 16 contiguous bytes
+__device__ __forceinline__ int boff(int p) { return 130 * p - 2 * p * p; }
+
 // compile-time loop: guarantees that register arrays are only ever indexed by constants
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
@@ -224,6 +228,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
         }
         // rows 2b, 2b+1 of [J | C | E] (wave-uniform addresses: LDS broadcasts), fetched as 16-byte vectors, one row at a
         // time: with two waves per SIMD the other wave covers the LDS latency and the registers stay under 256
+        double2_t bpair;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const int col = 2 * b + rr;
@@ -246,8 +251,14 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
           for (int k = 0; k < 14; ++k) s1 = fma(u[k], vc[k >> 1][k & 1], s1);
 #pragma unroll
           for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[k >> 1][k & 1], s0);
-          if (lane >= 2 * b && (!BORDERED || lane < n)) Bg[coff(col) + lane - 2 * b] = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+          double bv = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+          asm volatile("" : "+v"(bv));  // finish this column before the next one's 17 broadcast reads are issued (registers)
+          __builtin_amdgcn_sched_barrier(0);
+          bpair[rr] = bv;
         }
+        // both columns of the observation leave in ONE 16-byte store (scratch layout: column pairs interleaved, boff):
+        // a vector-memory instruction costs the CU's one memory pipe ~30 cycles whatever its width
+        if (lane >= 2 * b && (!BORDERED || lane < n)) *reinterpret_cast<double2_t*>(Bg + boff(b) + 2 * (lane - 2 * b)) = bpair;
       };
       double bufA[18], bufB[18];
       fetch(bufA, 0);
@@ -258,11 +269,11 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
       if constexpr (BORDERED) {
         // border rows n..n+3 of column `lane`: r, H_f(:,0..2) of measurement row `lane`
         if (valid) {
-          double* cj = Bg + coff(lane) - (lane & ~1) + n;
+          double* cj = Bg + boff(lane >> 1) + 2 * (n - (lane & ~1)) + (lane & 1);  // element (n + q, lane) at cj[2 q]
           cj[0] = res;
-          cj[1] = hf[0];
-          cj[2] = hf[1];
-          cj[3] = hf[2];
+          cj[2] = hf[0];
+          cj[4] = hf[1];
+          cj[6] = hf[2];
         }
       }
     }
@@ -287,12 +298,13 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
       for (int jb = 0; jb < nblk; ++jb) {
         const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);
         double ab[16];
-        static_for<16>([&](auto tc) {
-          constexpr int t = decltype(tc)::value;
-          const int col = j0 + t;
-          double v = 0.0;  // upper triangle, the 4x4 corner and the padding start at zero
-          if (brow && col < n && lane >= (col & ~1)) v = Bg[coff(col) + lane - (col & ~1)];
-          ab[t] = v;
+        static_for<8>([&](auto tc) {
+          constexpr int t = 2 * decltype(tc)::value;
+          const int col = j0 + t;  // even: the column pair (col, col + 1) is one 16-byte load
+          double2_t v = {0.0, 0.0};  // upper triangle, the 4x4 corner and the padding start at zero
+          if (brow && col < n && lane >= col) v = *reinterpret_cast<const double2_t*>(Bg + boff(col >> 1) + 2 * (lane - col));
+          ab[t] = v[0];
+          ab[t + 1] = v[1];
         });
         if (jb > 0) {
           // left-looking update of rows >= j0, columns j0..j0+15 with the finished columns 0..j0-1:
@@ -406,7 +418,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
           constexpr int t = decltype(tc)::value;
           const int col = j0 + t;
           double v = (col == lane) ? 1.0 : 0.0;                       // identity padding for rows/columns >= n
-          if (valid && col < n && lane >= (col & ~1)) v = Bg[coff(col) + lane - (col & ~1)];
+          if (valid && col < n && lane >= (col & ~1)) v = Bg[boff(col >> 1) + 2 * (lane - (col & ~1)) + (col & 1)];
           ab[t] = v;
         });
         OVP_STAMP_ONLY(long long tq0 = __builtin_readcyclecounter();)
@@ -696,11 +708,19 @@ extern "C" int ovp_feat_chol_supported(const ovp::FeatParams* p, int n) {
   return !off && p->n_feats > 0 && p->max_meas <= 30 && nt <= OVP_TC_MAX_TILES;
 }
 
-extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c, hipStream_t stream) {
+extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c_in, hipStream_t stream) {
+  static const bool dbg_nochol = getenv("OVP_DBG_FUSED_NOCHOL") != nullptr;  // timing experiment only (results are wrong)
+  ovp::CholJob cj = *c_in;
+  if (dbg_nochol) cj.n = 0;
+  const ovp::CholJob* c = &cj;
+  static const bool dbg_nofeat = getenv("OVP_DBG_FUSED_NOFEAT") != nullptr;  // timing experiment only (results are wrong)
+  ovp::FeatParams pf = *p;
+  if (dbg_nofeat) pf.n_feats = 1;
+  p = &pf;
   const int F = p->n_feats;
   const int cus = 255;  // feature workgroups of one round (256 CUs, one of them factorizes)
   const int nwg = F <= cus ? F : (F <= 8 * cus ? cus : (F + 7) / 8);
-  const int nt = (c->n + 15) >> 4;
+  const int nt = (c_in->n + 15) >> 4;
   const int slots = (nt * (nt + 1) / 2 + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
   if (slots <= 15)
     hipLaunchKernelGGL(ovp::k_feat_chol<15>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);

@@ -358,7 +358,7 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
           tile[s] = mfma_xyT(PB + ti[s] * TSZ, PB + tj[s] * TSZ, tile[s], -1.0, lc, lr);
       });
       // column k is final: its tiles go out while the following steps run
-      int ld_k = ld, lc_k = lc, lr_k = lr;
+      int ld_k = __builtin_amdgcn_readfirstlane(ld), lc_k = lc, lr_k = lr;
       asm volatile("" : "+s"(ld_k));
       asm volatile("" : "+v"(lc_k), "+v"(lr_k));
       sfor<MAXSLOT>([&](auto sc) {

@@ -699,7 +699,8 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // Beside a one-wave-per-block K1 it must NOT run: K1 keeps every SIMD busy with two feature waves, and the CU that also
   // hosts the eight Cholesky waves finishes its feature blocks ~40 % later, which is the kernel's duration (K1 112 -> 157 us).
   // OVP_OVERLAP_MODE: 0 = no overlap, 1 = side stream beside K1, 2 = main stream after K1 with K2 beside it on the side
-  // stream (the fallback when the fused kernel cannot take the batch), 3 (default) = fused.
+  // stream (the fallback when the fused kernel cannot take the batch), 3 (default) = fused.  (Also tried: chol(P) as its own
+  // 160 KB-LDS launch on the side stream beside an 8-wave-workgroup K1 - the two launches did not overlap, K1 145 us.)
   static const int overlap_env = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 3;
   int overlap_mode = overlap_env;
   if (overlap_mode == 3 && !(c->n <= OVP_TILECHOL_NMAX && ovp_feat_chol_supported(&fp, c->n))) overlap_mode = 2;
