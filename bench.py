@@ -142,7 +142,7 @@ def main():
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this
         # process); only quoted when the workload is the one the passes were taken on
         traffic, traffic_note = None, None
-        tp = os.path.join(_ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")
+        tp = os.path.join(_ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")
         if os.path.exists(tp) and (C, F, world) == (30, 2000, 1):
             with open(tp) as fh:
                 kern = json.load(fh)["kernels"]
@@ -151,7 +151,7 @@ def main():
                 # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies wide coalesced reads at half their bytes -> x2 as the
                 # upper bound; WRITE_SIZE taken as reported
                 traffic = (2.0 * k1[0]["FETCH_SIZE_KB_avg_per_launch"] + k1[0]["WRITE_SIZE_KB_avg_per_launch"]) * 1024.0
-                traffic_note = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_g_hbm_traffic_pmc.json "
+                traffic_note = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_h_hbm_traffic_pmc.json "
                                 "(separate --pmc passes); mostly the materialised B scratch (34 MB), sparse rows (23 MB) "
                                 "and projector rows (10 MB) written for K2 - 1 TB/s, not the bound")
         roofline = {
