@@ -141,6 +141,41 @@ def test_full_size_properties(hiplib):
     ctx.close()
 
 
+def test_config3_plane_loop_at_full_size_matches_oracle(hiplib, oracle):
+    """BASELINE config[2]: 30 clones, 2000 features of which 1000 lie on 20 planes (10 of them in the state, N = 240).  The plane
+    loop is cheap enough for the oracle at full size (about a second); the point update on the 1000 free points is checked
+    through its information identity."""
+    sc = make_scene(C=30, F=2000, seed=0, n_planes=20, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=99999.0)
+    assert sc.N == 240
+    ref = oracle.msckf_plane_update(sc)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    o = hiplib.opts_from_scene(sc)
+    out = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert (out["ok"] == ref["plane_ok"]).all() and out["ok"].all()
+    assert (out["used"] == ref["used"]).all() and out["used"].sum() == 1000
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    P_pl = ctx.cov_download()
+    assert relP(P_pl, ref["P"]) < TOL_P
+    # point update on the free points, at the state the plane loop left on the device
+    rest = np.where(~out["used"])[0]
+    ctx.batch_upload_scene(sc, rest)
+    o.chi2_multiplier = 1.0
+    upd = ctx.msckf_update(o)
+    P1 = ctx.cov_download()
+    assert upd["accepted"].mean() > 0.9
+    ld = ((sc.N + 15) // 16) * 16
+    Ab = ctx.debug_read("Ab", (sc.N + 1, ld))
+    A, b = Ab[: sc.N, : sc.N], Ab[sc.N, : sc.N]
+    assert np.abs(P1 @ (np.linalg.inv(P_pl) + A) - np.eye(sc.N)).max() < 1e-6
+    assert np.abs(upd["dx"] - P1 @ b).max() < 1e-9
+    ctx.close()
+
+
 def test_dense_ekf_update_matches_reference_form(hiplib):
     """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H."""
     from oracle import np_ref
