@@ -159,7 +159,7 @@ def main():
             "kernel": "k_feat_chol (per-feature build + nullspace projection + chi2 gate on 255 CUs; chol(P) rides on the 256th), f64 vector ALU",
             "achieved": alg / k_s / 1e12,
             "peak": F64_PEAK_TFLOPS,
-            "peak_measured": 59.5,  # v_fma_f64 microbenchmark on this part (scratch/fma64.hip); f64 MFMA: 35-47
+            "peak_measured": 59.5,  # v_fma_f64 microbenchmark on this part (tools/fma64_bench.hip); f64 MFMA: 35-47
             "unit": "TFLOP/s",
             "frac": alg / k_s / 1e12 / F64_PEAK_TFLOPS,
             "traffic": traffic,
