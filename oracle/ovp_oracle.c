@@ -492,6 +492,162 @@ int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterHelper.cpp:35-193  get_feature_jacobian_representation for the anchored / inverse-depth landmark
+ * parameterisations, and their use in get_feature_jacobian_full (:296-302, :323-327, :411-421).
+ *   rep: 0 GLOBAL_3D, 1 GLOBAL_FULL_INVERSE_DEPTH, 2 ANCHORED_3D, 3 ANCHORED_FULL_INVERSE_DEPTH,
+ *        4 ANCHORED_MSCKF_INVERSE_DEPTH, 5 ANCHORED_INVERSE_DEPTH_SINGLE (ext ov_type::LandmarkRepresentation)
+ * Inputs: p_FinG (value; MSCKF features have fej == value), the anchor clone slot.  Outputs (row-major): dlam [3 x nl]
+ * (nl = 3, or 1 for rep 5), H_anc [3x6], H_cal [3x6] (the latter two zero for the global representations).
+ * ------------------------------------------------------------------------------------------- */
+static void inv_depth_jac(const double p[3], double J[9]) { /* d p / d (theta, phi, rho), :50-72 */
+  const double rho = 1 / sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const double phi = acos(rho * p[2]);
+  const double th = atan2(p[1], p[0]);
+  const double st = sin(th), ct = cos(th), sp = sin(phi), cph = cos(phi);
+  J[0] = -(1.0 / rho) * st * sp;
+  J[1] = (1.0 / rho) * ct * cph;
+  J[2] = -(1.0 / (rho * rho)) * ct * sp;
+  J[3] = (1.0 / rho) * ct * sp;
+  J[4] = (1.0 / rho) * st * cph;
+  J[5] = -(1.0 / (rho * rho)) * st * sp;
+  J[6] = 0.0;
+  J[7] = -(1.0 / rho) * sp;
+  J[8] = -(1.0 / (rho * rho)) * cph;
+}
+
+int ovo_feature_jacobian_representation(const ovo_opts *o, const ovo_state *st, int rep, const double p_FinG[3], int anchor_ci,
+                                        double *dlam, int *nl_out, double H_anc[18], double H_cal[18]) {
+  memset(H_anc, 0, 18 * sizeof(double));
+  memset(H_cal, 0, 18 * sizeof(double));
+  *nl_out = 3;
+  if (rep == 0) { /* :39-43 */
+    for (int i = 0; i < 9; ++i) dlam[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return 0;
+  }
+  if (rep == 1) { /* :46-76 (fej == value for the features of this path) */
+    inv_depth_jac(p_FinG, dlam);
+    return 0;
+  }
+  /* :83-101 anchor pose and calibration; with FEJ the anchor pose is the first estimate and p_FinA is re-expressed in it */
+  double R_ItoC[9], R_GtoI[9], tmp[3], d[3], p_FinA[3];
+  ovo_quat_2_rot(st->calib_q, R_ItoC);
+  const double *p_IinC = st->calib_p;
+  const double *aq = o->do_fej ? st->clone_q_fej : st->clone_q;
+  const double *ap = o->do_fej ? st->clone_p_fej : st->clone_p;
+  ovo_quat_2_rot(aq + 4 * anchor_ci, R_GtoI);
+  const double *p_IinG = ap + 3 * anchor_ci;
+  /* p_FinG_best == p_FinG (:93); into the (first-estimate) anchor frame (:95-97) */
+  for (int k = 0; k < 3; ++k) d[k] = p_FinG[k] - p_IinG[k];
+  mat3_vec(R_GtoI, d, tmp);
+  mat3_vec(R_ItoC, tmp, p_FinA);
+  for (int k = 0; k < 3; ++k) p_FinA[k] += p_IinC[k];
+  double R_CtoG[9]; /* R_GtoI^T R_ItoC^T */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += R_GtoI[3 * k + i] * R_ItoC[3 * j + k];
+      R_CtoG[3 * i + j] = a;
+    }
+  /* :102-106 H_anc = [ -R_GtoI^T skew(R_ItoC^T (p_FinA - p_IinC)) , I ] */
+  double q[3] = {p_FinA[0] - p_IinC[0], p_FinA[1] - p_IinC[1], p_FinA[2] - p_IinC[2]}, v[3], S[9];
+  for (int i = 0; i < 3; ++i) v[i] = R_ItoC[i] * q[0] + R_ItoC[3 + i] * q[1] + R_ItoC[6 + i] * q[2];
+  skew3(v, S);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += R_GtoI[3 * k + i] * S[3 * k + j];
+      H_anc[6 * i + j] = -a;
+      H_anc[6 * i + 3 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  if (o->do_calib_camera_pose) { /* :113-119 H_calib = [ -R_CtoG skew(p_FinA - p_IinC) , -R_CtoG ] */
+    skew3(q, S);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double a = 0;
+        for (int k = 0; k < 3; ++k) a += R_CtoG[3 * i + k] * S[3 * k + j];
+        H_cal[6 * i + j] = -a;
+        H_cal[6 * i + 3 + j] = -R_CtoG[3 * i + j];
+      }
+  }
+  double J[9];
+  if (rep == 2) { /* :122-125 */
+    memcpy(dlam, R_CtoG, sizeof(J));
+    return 0;
+  }
+  if (rep == 3) {
+    inv_depth_jac(p_FinA, J); /* :128-152 */
+  } else if (rep == 4) {      /* :155-173 */
+    const double rho = 1 / p_FinA[2], al = p_FinA[0] / p_FinA[2], be = p_FinA[1] / p_FinA[2];
+    const double Jm[9] = {1.0 / rho, 0.0, -(1.0 / (rho * rho)) * al, 0.0, 1.0 / rho, -(1.0 / (rho * rho)) * be,
+                          0.0, 0.0, -(1.0 / (rho * rho))};
+    memcpy(J, Jm, sizeof(J));
+  } else if (rep == 5) { /* :176-187 */
+    const double rho = 1.0 / p_FinA[2];
+    double dr[3];
+    for (int k = 0; k < 3; ++k) dr[k] = -(1.0 / (rho * rho)) * (rho * p_FinA[k]);
+    for (int i = 0; i < 3; ++i) dlam[i] = R_CtoG[3 * i] * dr[0] + R_CtoG[3 * i + 1] * dr[1] + R_CtoG[3 * i + 2] * dr[2];
+    *nl_out = 1;
+    return 0;
+  } else {
+    return -1;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) dlam[3 * i + j] = R_CtoG[3 * i] * J[j] + R_CtoG[3 * i + 1] * J[3 + j] + R_CtoG[3 * i + 2] * J[6 + j];
+  return 0;
+}
+
+/* get_feature_jacobian_full for a feature held in representation `rep` with anchor clone slot anchor_ci: the GLOBAL_3D
+ * rows (H_f = w dz_dpfg) chained with the representation Jacobians, :411-421.  Column-major outputs like
+ * ovo_feature_jacobian_full; H_f gets nl columns. */
+int ovo_feature_jacobian_full_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, int rep, int anchor_ci,
+                                  double *H_f, double *H_x, double *res, int *rows_out, int *cols_out, int *hf_cols_out,
+                                  int *order_id, int *order_size, int *n_order_out) {
+  int rows, cols, hfc, no;
+  double *Hg = (double *)malloc(sizeof(double) * (size_t)(2 * fb->max_meas + 1) * 6);
+  int rc = ovo_feature_jacobian_full(o, st, fb, f, o->sigma_constraint, 0, NULL, NULL, -1, Hg, H_x, res, &rows, &cols, &hfc,
+                                     order_id, order_size, &no);
+  if (rc) {
+    free(Hg);
+    return rc;
+  }
+  double dlam[9], H_anc[18], H_cal[18];
+  int nl;
+  rc = ovo_feature_jacobian_representation(o, st, rep, fb->p_FinG + 3 * (size_t)f, anchor_ci, dlam, &nl, H_anc, H_cal);
+  if (rc) {
+    free(Hg);
+    return rc;
+  }
+  for (int j = 0; j < nl; ++j)
+    for (int i = 0; i < rows; ++i) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += CM(Hg, rows, i, k) * dlam[nl * k + j];
+      CM(H_f, rows, i, j) = a;
+    }
+  if (rep >= 2) {
+    int ct = 0;
+    for (int v = 0; v < no; ++v) {
+      const double *J = NULL;
+      if (order_id[v] == st->clone_id[anchor_ci]) J = H_anc;
+      else if (o->do_calib_camera_pose && order_id[v] == st->calib_id) J = H_cal;
+      if (J)
+        for (int j = 0; j < 6; ++j)
+          for (int i = 0; i < rows; ++i) {
+            double a = 0;
+            for (int k = 0; k < 3; ++k) a += CM(Hg, rows, i, k) * J[6 * k + j];
+            CM(H_x, rows, i, ct + j) += a;
+          }
+      ct += order_size[v];
+    }
+  }
+  *rows_out = rows;
+  *cols_out = cols;
+  *hf_cols_out = nl;
+  *n_order_out = no;
+  free(Hg);
+  return 0;
+}
+
 /* update/UpdaterHelper.cpp:515-546 ; update/UpdaterPlane.cpp:483-517 */
 void ovo_nullspace_project(double *H_f, int rows, int hf_cols, double *H_x, int cols, double *H_cp, int cp_cols,
                            double *res) {

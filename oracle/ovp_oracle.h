@@ -75,6 +75,13 @@ int ovo_llt(double *A, int n, int ld);                        /* in-place lower 
 /* update/UpdaterHelper.cpp:195-513.  Column-major outputs, caller-allocated:
  *   H_f [rows x 3 (or 6)], H_x [rows x cols], res [rows]; order_id/order_size [<= n_meas+3].
  * planeid==0: point feature.  planeid!=0: cp/cp_fej used; plane_state_id>=0 means plane in state. */
+/* update/UpdaterHelper.cpp:35-193 and its use at :411-421; rep = ext LandmarkRepresentation (0 GLOBAL_3D ... 5
+ * ANCHORED_INVERSE_DEPTH_SINGLE), see ovp_oracle.c */
+int ovo_feature_jacobian_representation(const ovo_opts *o, const ovo_state *st, int rep, const double p_FinG[3], int anchor_ci,
+                                        double *dlam, int *nl_out, double H_anc[18], double H_cal[18]);
+int ovo_feature_jacobian_full_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, int rep, int anchor_ci,
+                                  double *H_f, double *H_x, double *res, int *rows_out, int *cols_out, int *hf_cols_out,
+                                  int *order_id, int *order_size, int *n_order_out);
 void ovo_equi_distort(const double v[8], const double uvn[2], double uvd[2]);
 void ovo_equi_jacobian(const double v[8], const double uvn[2], double dz_dzn[4], double dz_dzeta[16]);
 int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, double sigma_c,

@@ -153,6 +153,27 @@ def feature_jacobian_full(sc, f, planeid=0, cp=None, cp_fej=None, plane_state_id
     return Hf, Hx, res[:r].copy(), order
 
 
+def feature_jacobian_full_rep(sc, f, rep, anchor_ci):
+    """ovo_feature_jacobian_full_rep: the feature held in ext LandmarkRepresentation `rep` (0..5) anchored in clone slot
+    anchor_ci.  Returns (H_f [rows, 3 or 1], H_x, res, order)."""
+    pk = Packed(sc)
+    m = int(sc.n_meas[f])
+    maxr, maxc = 3 * m + 1, 6 * m + 17
+    H_f = np.zeros(maxr * 6)
+    H_x = np.zeros(maxr * maxc)
+    res = np.zeros(maxr)
+    rows, cols, hfc, no = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    oid = np.zeros(m + 4, dtype=np.int32)
+    osz = np.zeros(m + 4, dtype=np.int32)
+    rc = lib().ovo_feature_jacobian_full_rep(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), C.c_int(f), C.c_int(rep),
+                                             C.c_int(anchor_ci), _dp(H_f), _dp(H_x), _dp(res), C.byref(rows), C.byref(cols),
+                                             C.byref(hfc), _ip(oid), _ip(osz), C.byref(no))
+    assert rc == 0
+    r, c, h, n = rows.value, cols.value, hfc.value, no.value
+    return (H_f[: r * h].reshape(h, r).T.copy(), H_x[: r * c].reshape(c, r).T.copy(), res[:r].copy(),
+            [(int(oid[i]), int(osz[i])) for i in range(n)])
+
+
 def msckf_point_update(sc, feats=None):
     """Runs ovo_msckf_point_update. Returns dict(dx, P, accepted, chi2, rows_compressed, timings)."""
     pk = Packed(sc, feats)

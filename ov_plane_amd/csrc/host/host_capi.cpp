@@ -897,3 +897,62 @@ extern "C" int ovph_format_state_files(int C, const double *clone_q, const doubl
   memcpy(gt, c.c_str(), c.size() + 1);
   return 0;
 }
+
+// UpdaterHelper::get_feature_jacobian_full for ONE feature held in landmark representation `rep` anchored in clone slot
+// anchor_ci (ext LandmarkRepresentation 0..5).  Outputs column-major: H_f [rows x hf_cols], H_x [rows x cols], res [rows],
+// order ids / sizes of the H_x columns.  Needs the device only because a State owns a context.
+extern "C" int ovph_feature_jacobian_rep(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
+                                         const double *clone_p_fej, const double *calib_q, const double *calib_p, const double *intr,
+                                         int N, const double *P, int m, const float *uv, const int *clone_idx, const double *p_FinG,
+                                         int rep, int anchor_ci, double sigma_px, int do_fej, double *H_f, double *H_x, double *res,
+                                         int *rows_out, int *cols_out, int *hf_cols_out, int *order_id, int *order_size, int *n_order) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.max_state_size = N + 8;
+  so.max_features = 16;
+  HarnessState hs;
+  int rc = build_harness_state(hs, so, C, clone_q, clone_p, clone_q_fej, clone_p_fej, calib_q, calib_p, intr, 0, nullptr, nullptr, 0,
+                               nullptr, nullptr, N, P);
+  if (rc) return rc;
+  auto &state = hs.state;
+  UpdaterHelper::UpdaterHelperFeature feat;
+  feat.featid = 5000;
+  for (int k = 0; k < m; ++k) {
+    feat.timestamps.push_back(hs.times[clone_idx[k]]);
+    feat.uvs.push_back(uv[2 * k]);
+    feat.uvs.push_back(uv[2 * k + 1]);
+  }
+  memcpy(feat.p_FinG, p_FinG, 3 * sizeof(double));
+  memcpy(feat.p_FinG_fej, p_FinG, 3 * sizeof(double));
+  feat.feat_representation = (LandmarkRepresentation::Representation)rep;
+  if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
+    feat.anchor_cam_id = 0;
+    feat.anchor_clone_timestamp = hs.times[anchor_ci];
+    auto anchor = state->_clones_IMU.at(feat.anchor_clone_timestamp);
+    auto calib = state->_calib_IMUtoCAM.at(0);
+    const double *Ra = anchor->Rot(), *pa = anchor->pos(), *Rc = calib->Rot(), *pc = calib->pos();
+    const double d[3] = {p_FinG[0] - pa[0], p_FinG[1] - pa[1], p_FinG[2] - pa[2]};
+    double t[3];
+    for (int i = 0; i < 3; ++i) t[i] = Ra[3 * i] * d[0] + Ra[3 * i + 1] * d[1] + Ra[3 * i + 2] * d[2];
+    for (int i = 0; i < 3; ++i) feat.p_FinA[i] = Rc[3 * i] * t[0] + Rc[3 * i + 1] * t[1] + Rc[3 * i + 2] * t[2] + pc[i];
+    memcpy(feat.p_FinA_fej, feat.p_FinA, 3 * sizeof(double));
+  }
+  MatrixXd Hf, Hx;
+  VectorXd r;
+  std::vector<std::shared_ptr<Type>> order;
+  UpdaterHelper::get_feature_jacobian_full(state, feat, sigma_px, 1.0, Hf, Hx, r, order);
+  *rows_out = Hf.rows();
+  *cols_out = Hx.cols();
+  *hf_cols_out = Hf.cols();
+  memcpy(H_f, Hf.data(), sizeof(double) * (size_t)Hf.rows() * Hf.cols());
+  memcpy(H_x, Hx.data(), sizeof(double) * (size_t)Hx.rows() * Hx.cols());
+  memcpy(res, r.data(), sizeof(double) * (size_t)r.rows());
+  *n_order = (int)order.size();
+  for (size_t k = 0; k < order.size(); ++k) {
+    order_id[k] = order[k]->id();
+    order_size[k] = order[k]->size();
+  }
+  return 0;
+}

@@ -38,6 +38,12 @@ struct StateOptions {
   double sigma_plane_merge = 0.001;
   double plane_merge_chi2 = 1.00;
   double plane_merge_deg_max = 1.00;
+  // StateOptions.h:90-96.  MSCKF features: the projected system is the same for every three-parameter representation (the
+  // anchor terms of H_x are H_f_global * dpfg_dx and die with the left nullspace of H_f; tests/test_oracle_pins.py pins this),
+  // and ANCHORED_INVERSE_DEPTH_SINGLE is mapped to the MSCKF inverse depth for such features (update/UpdaterMSCKF.cpp:478-481):
+  // the device path serves all of them with its GLOBAL_3D arithmetic.  SLAM landmarks are kept in GLOBAL_3D by this build.
+  ov_type::LandmarkRepresentation::Representation feat_rep_msckf = ov_type::LandmarkRepresentation::GLOBAL_3D;
+  ov_type::LandmarkRepresentation::Representation feat_rep_slam = ov_type::LandmarkRepresentation::GLOBAL_3D;
   int max_msckf_plane = 20;            // StateOptions.h:123
   bool use_refine_plane_feat = true;   // StateOptions.h: refine on-plane features and the plane with optimize_plane
   bool use_groundtruths = false;
@@ -174,14 +180,22 @@ private:
 // update/UpdaterHelper.h:55-157: host (dense) versions for the small SLAM / initialisation systems
 class UpdaterHelper {
 public:
-  struct UpdaterHelperFeature {  // update/UpdaterHelper.h:62-105, mono, GLOBAL_3D
+  struct UpdaterHelperFeature {  // update/UpdaterHelper.h:62-105, mono
     size_t featid = 0;
     std::vector<float> uvs;          // [2k]
     std::vector<double> timestamps;  // [k]
+    ov_type::LandmarkRepresentation::Representation feat_representation = ov_type::LandmarkRepresentation::GLOBAL_3D;
+    int anchor_cam_id = -1;
+    double anchor_clone_timestamp = -1;
+    double p_FinA[3] = {0, 0, 0}, p_FinA_fej[3] = {0, 0, 0};
     double p_FinG[3] = {0, 0, 0}, p_FinG_fej[3] = {0, 0, 0};
     size_t planeid = 0;
     double cp_FinG[3] = {0, 0, 0}, cp_FinG_fej[3] = {0, 0, 0};
   };
+  // update/UpdaterHelper.cpp:35-193: d p_FinG / d (representation parameters) and, for the anchored representations, the
+  // blocks w.r.t. the anchor clone (and the extrinsics when they are estimated)
+  static void get_feature_jacobian_representation(std::shared_ptr<State> state, UpdaterHelperFeature &feature, MatrixXd &H_f,
+                                                  std::vector<MatrixXd> &H_x, std::vector<std::shared_ptr<ov_type::Type>> &x_order);
   // update/UpdaterHelper.cpp:195-513
   static void get_feature_jacobian_full(std::shared_ptr<State> state, UpdaterHelperFeature &feature, double sigma_px, double sigma_c,
                                         MatrixXd &H_f, MatrixXd &H_x, VectorXd &res, std::vector<std::shared_ptr<ov_type::Type>> &x_order);

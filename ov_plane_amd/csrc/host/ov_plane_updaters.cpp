@@ -38,7 +38,125 @@ static inline void skew3(const double *w, double *S) {
   S[8] = 0;
 }
 
-// ---- update/UpdaterHelper.cpp:195-513 (GLOBAL_3D, radtan, mono) ----------------------------------
+// ---- update/UpdaterHelper.cpp:35-193 -------------------------------------------------------------
+static void inv_depth_jac(const double p[3], MatrixXd &J) {  // d p / d (theta, phi, rho), :50-72
+  const double rho = 1 / std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const double phi = std::acos(rho * p[2]), th = std::atan2(p[1], p[0]);
+  const double st = std::sin(th), ct = std::cos(th), sp = std::sin(phi), cp = std::cos(phi);
+  J = MatrixXd::Zero(3, 3);
+  J(0, 0) = -(1.0 / rho) * st * sp;
+  J(0, 1) = (1.0 / rho) * ct * cp;
+  J(0, 2) = -(1.0 / (rho * rho)) * ct * sp;
+  J(1, 0) = (1.0 / rho) * ct * sp;
+  J(1, 1) = (1.0 / rho) * st * cp;
+  J(1, 2) = -(1.0 / (rho * rho)) * st * sp;
+  J(2, 1) = -(1.0 / rho) * sp;
+  J(2, 2) = -(1.0 / (rho * rho)) * cp;
+}
+
+void UpdaterHelper::get_feature_jacobian_representation(std::shared_ptr<State> state, UpdaterHelperFeature &feature, MatrixXd &H_f,
+                                                        std::vector<MatrixXd> &H_x, std::vector<std::shared_ptr<Type>> &x_order) {
+  typedef LandmarkRepresentation LR;
+  if (feature.feat_representation == LR::GLOBAL_3D) {  // :39-43
+    H_f = MatrixXd::Zero(3, 3);
+    for (int k = 0; k < 3; ++k) H_f(k, k) = 1.0;
+    return;
+  }
+  if (feature.feat_representation == LR::GLOBAL_FULL_INVERSE_DEPTH) {  // :46-76
+    inv_depth_jac(state->_options.do_fej ? feature.p_FinG_fej : feature.p_FinG, H_f);
+    return;
+  }
+  assert(feature.anchor_cam_id != -1);  // :83
+  auto calib = state->_calib_IMUtoCAM.at(feature.anchor_cam_id);
+  auto anchor = state->_clones_IMU.at(feature.anchor_clone_timestamp);
+  const double *R_ItoC = calib->Rot(), *p_IinC = calib->pos();
+  const double *R_GtoI = anchor->Rot(), *p_IinG = anchor->pos();
+  double p_FinA[3] = {feature.p_FinA[0], feature.p_FinA[1], feature.p_FinA[2]};
+  if (state->_options.do_fej) {  // :91-98
+    double q[3] = {p_FinA[0] - p_IinC[0], p_FinA[1] - p_IinC[1], p_FinA[2] - p_IinC[2]}, t[3], best[3];
+    for (int i = 0; i < 3; ++i) t[i] = R_ItoC[i] * q[0] + R_ItoC[3 + i] * q[1] + R_ItoC[6 + i] * q[2];
+    for (int i = 0; i < 3; ++i) best[i] = R_GtoI[i] * t[0] + R_GtoI[3 + i] * t[1] + R_GtoI[6 + i] * t[2] + p_IinG[i];
+    R_GtoI = anchor->Rot_fej();
+    p_IinG = anchor->pos_fej();
+    const double d[3] = {best[0] - p_IinG[0], best[1] - p_IinG[1], best[2] - p_IinG[2]};
+    m3v(R_GtoI, d, t);
+    m3v(R_ItoC, t, p_FinA);
+    for (int k = 0; k < 3; ++k) p_FinA[k] += p_IinC[k];
+  }
+  MatrixXd R_CtoG(3, 3);  // R_GtoI^T R_ItoC^T
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += R_GtoI[3 * k + i] * R_ItoC[3 * j + k];
+      R_CtoG(i, j) = a;
+    }
+  const double q[3] = {p_FinA[0] - p_IinC[0], p_FinA[1] - p_IinC[1], p_FinA[2] - p_IinC[2]};
+  {  // :102-109
+    double v[3], S[9];
+    for (int i = 0; i < 3; ++i) v[i] = R_ItoC[i] * q[0] + R_ItoC[3 + i] * q[1] + R_ItoC[6 + i] * q[2];
+    skew3(v, S);
+    MatrixXd H_anc = MatrixXd::Zero(3, 6);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double a = 0;
+        for (int k = 0; k < 3; ++k) a += R_GtoI[3 * k + i] * S[3 * k + j];
+        H_anc(i, j) = -a;
+        H_anc(i, 3 + j) = (i == j) ? 1.0 : 0.0;
+      }
+    x_order.push_back(anchor);
+    H_x.push_back(H_anc);
+  }
+  if (state->_options.do_calib_camera_pose) {  // :112-119
+    double S[9];
+    skew3(q, S);
+    MatrixXd H_calib = MatrixXd::Zero(3, 6);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double a = 0;
+        for (int k = 0; k < 3; ++k) a += R_CtoG(i, k) * S[3 * k + j];
+        H_calib(i, j) = -a;
+        H_calib(i, 3 + j) = -R_CtoG(i, j);
+      }
+    x_order.push_back(calib);
+    H_x.push_back(H_calib);
+  }
+  MatrixXd J;
+  if (feature.feat_representation == LR::ANCHORED_3D) {  // :122-125
+    H_f = R_CtoG;
+    return;
+  }
+  if (feature.feat_representation == LR::ANCHORED_FULL_INVERSE_DEPTH) {  // :128-152
+    inv_depth_jac(p_FinA, J);
+  } else if (feature.feat_representation == LR::ANCHORED_MSCKF_INVERSE_DEPTH) {  // :155-173
+    const double rho = 1 / p_FinA[2], al = p_FinA[0] / p_FinA[2], be = p_FinA[1] / p_FinA[2];
+    J = MatrixXd::Zero(3, 3);
+    J(0, 0) = 1.0 / rho;
+    J(0, 2) = -(1.0 / (rho * rho)) * al;
+    J(1, 1) = 1.0 / rho;
+    J(1, 2) = -(1.0 / (rho * rho)) * be;
+    J(2, 2) = -(1.0 / (rho * rho));
+  } else if (feature.feat_representation == LR::ANCHORED_INVERSE_DEPTH_SINGLE) {  // :176-187
+    const double rho = 1.0 / p_FinA[2];
+    H_f = MatrixXd::Zero(3, 1);
+    for (int i = 0; i < 3; ++i) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += R_CtoG(i, k) * (-(1.0 / (rho * rho)) * (rho * p_FinA[k]));
+      H_f(i, 0) = a;
+    }
+    return;
+  } else {
+    assert(false);  // :190
+  }
+  H_f = MatrixXd::Zero(3, 3);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += R_CtoG(i, k) * J(k, j);
+      H_f(i, j) = a;
+    }
+}
+
+// ---- update/UpdaterHelper.cpp:195-513 (every landmark representation, radtan / equidistant, mono) ---
 void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, UpdaterHelperFeature &feature, double sigma_px,
                                               double sigma_c, MatrixXd &H_f, MatrixXd &H_x, VectorXd &res,
                                               std::vector<std::shared_ptr<Type>> &x_order) {
@@ -71,6 +189,15 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
       total_hx += clone_Ci->size();
     }
   }
+  const bool relative = LandmarkRepresentation::is_relative_representation(feature.feat_representation);
+  if (relative) {  // :241-263 the anchor clone (and its extrinsics) are part of the system
+    std::shared_ptr<PoseJPL> clone_anchor = state->_clones_IMU.at(feature.anchor_clone_timestamp);
+    if (find_col(clone_anchor) < 0) {
+      map_hx.push_back({clone_anchor, total_hx});
+      x_order.push_back(clone_anchor);
+      total_hx += clone_anchor->size();
+    }
+  }
   const bool plane_in_state = (state->_features_PLANE.find(feature.planeid) != state->_features_PLANE.end());  // :269
   if (feature.planeid != 0 && plane_in_state) {
     std::shared_ptr<Vec> planecp = state->_features_PLANE.at(feature.planeid);
@@ -80,10 +207,27 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
       total_hx += planecp->size();
     }
   }
-  const double *p_FinG = feature.p_FinG;
-  const double *p_FinG_fej = feature.p_FinG_fej;
+  // :283-302 position in the global frame; for the anchored representations the "best" estimate serves as FEJ value too
+  double p_FinG_buf[3];
+  if (relative) {
+    auto calib_a = state->_calib_IMUtoCAM.at(feature.anchor_cam_id);
+    auto anchor = state->_clones_IMU.at(feature.anchor_clone_timestamp);
+    const double *Rc = calib_a->Rot(), *pc = calib_a->pos(), *Ra = anchor->Rot(), *pa = anchor->pos();
+    const double q[3] = {feature.p_FinA[0] - pc[0], feature.p_FinA[1] - pc[1], feature.p_FinA[2] - pc[2]};
+    double t[3];
+    for (int i = 0; i < 3; ++i) t[i] = Rc[i] * q[0] + Rc[3 + i] * q[1] + Rc[6 + i] * q[2];
+    for (int i = 0; i < 3; ++i) p_FinG_buf[i] = Ra[i] * t[0] + Ra[3 + i] * t[1] + Ra[6 + i] * t[2] + pa[i];
+  }
+  const double *p_FinG = relative ? p_FinG_buf : feature.p_FinG;
+  const double *p_FinG_fej = relative ? p_FinG_buf : feature.p_FinG_fej;
   int c = 0;
-  int jacobsize = 3 + ((feature.planeid != 0 && !plane_in_state) ? 3 : 0);  // :310-311
+  const int nlam = (feature.feat_representation != LandmarkRepresentation::ANCHORED_INVERSE_DEPTH_SINGLE) ? 3 : 1;
+  int jacobsize = nlam + ((feature.planeid != 0 && !plane_in_state) ? 3 : 0);  // :310-311
+  // :323-327 representation Jacobians, once per feature
+  MatrixXd dpfg_dlambda;
+  std::vector<MatrixXd> dpfg_dx;
+  std::vector<std::shared_ptr<Type>> dpfg_dx_order;
+  get_feature_jacobian_representation(state, feature, dpfg_dlambda, dpfg_dx, dpfg_dx_order);
   int meassize = (feature.planeid != 0) ? (3 * total_meas) : (2 * total_meas);
   if (total_meas == 0 && feature.planeid != 0) meassize = 1;
   res = VectorXd::Zero(meassize, 1);
@@ -183,13 +327,20 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
       for (int j = 0; j < 3; ++j)
         dz_dpfg[3 * i + j] = dz_dpfc[3 * i] * dpfc_dpfg[j] + dz_dpfc[3 * i + 1] * dpfc_dpfg[3 + j] + dz_dpfc[3 * i + 2] * dpfc_dpfg[6 + j];
     for (int i = 0; i < 2; ++i)
-      for (int j = 0; j < 3; ++j) H_f(c + i, j) = white_px * dz_dpfg[3 * i + j];  // :411
+      for (int j = 0; j < nlam; ++j)  // :411
+        H_f(c + i, j) = white_px * (dz_dpfg[3 * i] * dpfg_dlambda(0, j) + dz_dpfg[3 * i + 1] * dpfg_dlambda(1, j) + dz_dpfg[3 * i + 2] * dpfg_dlambda(2, j));
     const int cc = find_col(clone_Ii);
     for (int i = 0; i < 2; ++i)
       for (int j = 0; j < 3; ++j) {  // :414
         H_x(c + i, cc + j) = white_px * (dz_dpfc[3 * i] * Rsk[j] + dz_dpfc[3 * i + 1] * Rsk[3 + j] + dz_dpfc[3 * i + 2] * Rsk[6 + j]);
         H_x(c + i, cc + 3 + j) = -white_px * dz_dpfg[3 * i + j];
       }
+    for (size_t e = 0; e < dpfg_dx_order.size(); ++e) {  // :419-421 (+= : this may be the anchoring pose itself)
+      const int ce = find_col(dpfg_dx_order[e]);
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < dpfg_dx_order[e]->size(); ++j)
+          H_x(c + i, ce + j) += white_px * (dz_dpfg[3 * i] * dpfg_dx[e](0, j) + dz_dpfg[3 * i + 1] * dpfg_dx[e](1, j) + dz_dpfg[3 * i + 2] * dpfg_dx[e](2, j));
+    }
     if (state->_options.do_calib_camera_pose) {  // :426-435
       const double w[3] = {p_FinCi[0] - p_IinC[0], p_FinCi[1] - p_IinC[1], p_FinCi[2] - p_IinC[2]};
       double skc[9];

@@ -339,6 +339,22 @@ protected:
   std::shared_ptr<Vec> _v, _bg, _ba;
 };
 
+// ext ov_type::LandmarkRepresentation (types/LandmarkRepresentation.h)
+struct LandmarkRepresentation {
+  enum Representation {
+    GLOBAL_3D = 0,
+    GLOBAL_FULL_INVERSE_DEPTH = 1,
+    ANCHORED_3D = 2,
+    ANCHORED_FULL_INVERSE_DEPTH = 3,
+    ANCHORED_MSCKF_INVERSE_DEPTH = 4,
+    ANCHORED_INVERSE_DEPTH_SINGLE = 5,
+    UNKNOWN = 6
+  };
+  static bool is_relative_representation(Representation r) {
+    return r == ANCHORED_3D || r == ANCHORED_FULL_INVERSE_DEPTH || r == ANCHORED_MSCKF_INVERSE_DEPTH || r == ANCHORED_INVERSE_DEPTH_SINGLE;
+  }
+};
+
 // ext ov_type::Landmark (GLOBAL_3D only here: value == xyz); fields used by UpdaterSLAM
 class Landmark : public Vec {
 public:

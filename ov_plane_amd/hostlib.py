@@ -308,3 +308,33 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0)
     out["P"] = np.ascontiguousarray(out["P"].T)
     out["dt"] = float(out["dt"][0])
     return out
+
+
+def feature_jacobian_rep(sc, f, rep, anchor_ci):
+    """ov_plane::UpdaterHelper::get_feature_jacobian_full (C++ host mirror) for feature f of a synth scene held in landmark
+    representation rep (0..5) anchored in clone slot anchor_ci.  Returns (H_f, H_x, res, order)."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    m = int(sc.n_meas[f])
+    N = int(sc.N)
+    P = np.asfortranarray(sc.P)
+    uv = np.ascontiguousarray(sc.uv[f, :m], dtype=np.float32)
+    cidx = np.ascontiguousarray(sc.clone_idx[f, :m], dtype=np.int32)
+    pf = f64(sc.p_FinG[f])
+    cq, cp_, cqf, cpf_ = f64(sc.clone_q), f64(sc.clone_p), f64(sc.clone_q_fej), f64(sc.clone_p_fej)
+    calq, calp, intr = f64(sc.calib_q), f64(sc.calib_p), f64(sc.intr)
+    maxr, maxc = 2 * m, 6 * m + 20
+    H_f, H_x, res = np.zeros(maxr * 3), np.zeros(maxr * maxc), np.zeros(maxr)
+    rows, cols, hfc, no = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    oid, osz = np.zeros(m + 4, dtype=np.int32), np.zeros(m + 4, dtype=np.int32)
+    L.ovph_feature_jacobian_rep.restype = C.c_int
+    rc = L.ovph_feature_jacobian_rep(C.c_int(sc.C), p(cq), p(cp_), p(cqf), p(cpf_), p(calq), p(calp), p(intr), C.c_int(N), p(P),
+                                     C.c_int(m), p(uv), p(cidx), p(pf), C.c_int(rep), C.c_int(anchor_ci),
+                                     C.c_double(sc.opts["sigma_px"]), C.c_int(int(sc.opts["do_fej"])), p(H_f), p(H_x), p(res),
+                                     C.byref(rows), C.byref(cols), C.byref(hfc), p(oid), p(osz), C.byref(no))
+    if rc != 0:
+        raise RuntimeError("ovph_feature_jacobian_rep failed with %d" % rc)
+    r, c, h, n = rows.value, cols.value, hfc.value, no.value
+    return (H_f[: r * h].reshape(h, r).T.copy(), H_x[: r * c].reshape(c, r).T.copy(), res[:r].copy(),
+            [(int(oid[i]), int(osz[i])) for i in range(n)])

@@ -1311,3 +1311,24 @@ def test_host_cpp_mirror_updater_msckf_with_slam_landmarks_on_planes(hiplib, ora
     assert np.abs(out["slam_p"][slam_kept] - ref["slam_p"]).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
     assert list(out["slam_to_plane"][:2]) == [int(slam["plane"][0]), int(slam["plane"][1])]  # :636-639
+
+
+@pytest.mark.parametrize("do_fej", [False, True])
+def test_host_cpp_mirror_landmark_representations(hiplib, oracle, do_fej):
+    """UpdaterHelper::get_feature_jacobian_representation / get_feature_jacobian_full (C++ host mirror) for every ext
+    LandmarkRepresentation against the C restatement (itself pinned by finite differences): the dense path UpdaterSLAM uses."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_scene(C=7, F=4, seed=5, do_fej=do_fej, ragged=True)
+    for f in range(sc.F):
+        anchor = int(sc.clone_idx[f, min(1, sc.n_meas[f] - 1)])
+        for rep in range(6):
+            H_f, H_x, r, order = hostlib.feature_jacobian_rep(sc, f, rep, anchor)
+            R_f, R_x, rr, rorder = oracle.feature_jacobian_full_rep(sc, f, rep, anchor)
+            assert order == rorder and H_f.shape == R_f.shape, (f, rep)
+            assert np.abs(r - rr).max() < 1e-9
+            assert np.abs(H_f - R_f).max() < 1e-9 * max(1.0, np.abs(R_f).max()), (f, rep)
+            assert np.abs(H_x - R_x).max() < 1e-9 * max(1.0, np.abs(R_x).max()), (f, rep)

@@ -428,3 +428,111 @@ def test_plane_update_slam_rows_correlate_the_landmark_with_the_window(oracle):
     assert np.abs(with_rows["slam_p"] - slam["p"]).max() > 1e-6
     ev = np.linalg.eigvalsh(with_rows["P"])
     assert ev.min() > -1e-12 * ev.max()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# landmark representations (update/UpdaterHelper.cpp:35-193): ext ov_type::LandmarkRepresentation 0..5
+# ------------------------------------------------------------------------------------------------------------------
+def _rep_lambda(rep, p_G, R_GtoA, p_AinG, R_ItoC, p_IinC):
+    """parameters of the landmark in representation rep (ext ov_type::Landmark::set_from_xyz)"""
+    p_A = R_ItoC @ R_GtoA @ (p_G - p_AinG) + p_IinC
+    p = p_G if rep == 1 else p_A
+    if rep in (1, 3):
+        rho = 1 / np.linalg.norm(p)
+        return np.array([np.arctan2(p[1], p[0]), np.arccos(rho * p[2]), rho]), None
+    if rep == 2:
+        return p_A.copy(), None
+    if rep == 4:
+        return np.array([p_A[0] / p_A[2], p_A[1] / p_A[2], 1 / p_A[2]]), None
+    return np.array([1 / p_A[2]]), p_A / p_A[2]  # rep 5: inverse depth along a fixed bearing
+
+
+def _rep_xyz(rep, lam, bearing, R_GtoA, p_AinG, R_ItoC, p_IinC):
+    """global position of the landmark (ext Landmark::get_xyz followed by the anchor transform, UpdaterHelper.cpp:283-295)"""
+    if rep in (1, 3):
+        th, phi, rho = lam
+        p = np.array([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)]) / rho
+    elif rep == 2:
+        p = lam
+    elif rep == 4:
+        p = np.array([lam[0], lam[1], 1.0]) / lam[2]
+    else:
+        p = bearing / lam[0]
+    if rep == 1:
+        return p
+    return R_GtoA.T @ R_ItoC.T @ (p - p_IinC) + p_AinG
+
+
+@pytest.mark.parametrize("rep", [1, 2, 3, 4, 5])
+def test_representation_jacobians_by_finite_differences(oracle, rep):
+    """H_f = -d res / d lambda and the anchor / calibration blocks of H_x = -d res / d x when the landmark is held in an
+    anchored or inverse-depth representation: the residual is composed in numpy (representation -> global point -> np_ref
+    residual), the Jacobians come from the C restatement of get_feature_jacobian_representation."""
+    from ov_plane_amd.synth import quat_2_rot
+
+    sc = make_scene(C=5, F=3, seed=7, do_fej=False)
+    sc.clone_q_fej, sc.clone_p_fej = sc.clone_q.copy(), sc.clone_p.copy()
+    f, anchor = 1, 2
+    H_f, H_x, res0, order = oracle.feature_jacobian_full_rep(sc, f, rep, anchor)
+    assert H_f.shape[1] == (1 if rep == 5 else 3)
+    base = dict(clone_q=sc.clone_q, clone_p=sc.clone_p, calib_q=sc.calib_q, calib_p=sc.calib_p, intr=sc.intr)
+
+    def pose(st):
+        return quat_2_rot(st["clone_q"][anchor]), st["clone_p"][anchor], quat_2_rot(st["calib_q"]), st["calib_p"]
+
+    lam0, bearing = _rep_lambda(rep, sc.p_FinG[f], *pose(base))
+
+    def residual(st, lam):
+        stf = {k: np.array(v, dtype=np.float64, copy=True) for k, v in st.items()}
+        stf["clone_q_fej"], stf["clone_p_fej"] = stf["clone_q"], stf["clone_p"]
+        p = _rep_xyz(rep, lam, bearing, *pose(stf))
+        return np_ref.feature_jacobian_full(sc, f, p_FinG=p, state=stf)[2]
+
+    assert np.abs(residual(base, lam0) - res0).max() < 1e-9
+    eps = 1e-6
+    for k in range(len(lam0)):
+        lam = lam0.copy()
+        lam[k] += eps
+        num = -(residual(base, lam) - res0) / eps
+        assert np.abs(num - H_f[:, k]).max() / max(1.0, np.abs(H_f[:, k]).max()) < 5e-5, k
+    col = 0
+    for sid, sz in order:
+        for k in range(sz):
+            st = {key: np.array(val, dtype=np.float64, copy=True) for key, val in base.items()}
+            d = np.zeros(sz)
+            d[k] = eps
+            if sid == sc.ids["calib"]:
+                st["calib_q"] = quat_boxplus(sc.calib_q, d[:3])
+                st["calib_p"] = sc.calib_p + d[3:]
+            elif sid == sc.ids["intr"]:
+                st["intr"] = sc.intr + d
+            else:
+                ci = int(np.where(sc.ids["clones"] == sid)[0][0])
+                st["clone_q"][ci] = quat_boxplus(sc.clone_q[ci], d[:3])
+                st["clone_p"][ci] = sc.clone_p[ci] + d[3:]
+            num = -(residual(st, lam0) - res0) / eps
+            assert np.abs(num - H_x[:, col]).max() / max(1.0, np.abs(H_x[:, col]).max()) < 5e-5, (sid, k)
+            col += 1
+
+
+@pytest.mark.parametrize("do_fej", [False, True])
+def test_msckf_features_are_representation_invariant_after_the_nullspace_projection(oracle, do_fej):
+    """For the three-parameter representations the extra anchor / calibration terms of H_x are H_f_global * dpfg_dx
+    (update/UpdaterHelper.cpp:419-421) and H_f = H_f_global * dpfg_dlambda with an invertible 3x3 factor, so the left
+    nullspace of H_f annihilates them: the projected system - all an MSCKF feature contributes to the update - is the
+    GLOBAL_3D one.  This is why the device path (GLOBAL_3D arithmetic) serves every feat_rep_msckf; ANCHORED_INVERSE_DEPTH_SINGLE
+    is mapped to the MSCKF inverse depth for such features by the reference itself (update/UpdaterMSCKF.cpp:478-481)."""
+    sc = make_scene(C=7, F=4, seed=5, do_fej=do_fej, ragged=True)
+    for f in range(sc.F):
+        anchor = int(sc.clone_idx[f, 0])
+        H_f0, H_x0, r0, order0 = oracle.feature_jacobian_full(sc, f)
+        Hp0, rp0 = np_ref.nullspace_project_inplace(H_f0.copy(), H_x0.copy(), r0.copy())
+        for rep in (1, 2, 3, 4):
+            H_f, H_x, r, order = oracle.feature_jacobian_full_rep(sc, f, rep, anchor)
+            assert order == order0 and np.abs(r - r0).max() == 0.0
+            if rep >= 2:
+                assert np.abs(H_x - H_x0).max() > 1e-3  # the anchor terms are there before the projection
+            Hp, rp = np_ref.nullspace_project_inplace(H_f.copy(), H_x.copy(), r.copy())
+            scale = np.abs(Hp0.T @ Hp0).max()
+            assert np.abs(Hp.T @ Hp - Hp0.T @ Hp0).max() < 1e-9 * scale, (f, rep)
+            assert np.abs(Hp.T @ rp - Hp0.T @ rp0).max() < 1e-9 * max(1.0, np.abs(Hp0.T @ rp0).max()), (f, rep)
