@@ -518,6 +518,14 @@ static void inv_depth_jac(const double p[3], double J[9]) { /* d p / d (theta, p
 
 int ovo_feature_jacobian_representation(const ovo_opts *o, const ovo_state *st, int rep, const double p_FinG[3], int anchor_ci,
                                         double *dlam, int *nl_out, double H_anc[18], double H_cal[18]) {
+  return ovo_feature_jacobian_representation_fej(o, st, rep, p_FinG, NULL, anchor_ci, dlam, nl_out, H_anc, H_cal);
+}
+
+/* p_FinG_fej: first estimate of a GLOBAL_FULL_INVERSE_DEPTH landmark (NULL: equal to the value, as for MSCKF features); the
+ * anchored representations re-express the CURRENT global point in the first-estimate anchor frame instead (:91-98) */
+int ovo_feature_jacobian_representation_fej(const ovo_opts *o, const ovo_state *st, int rep, const double p_FinG[3],
+                                            const double *p_FinG_fej, int anchor_ci, double *dlam, int *nl_out, double H_anc[18],
+                                            double H_cal[18]) {
   memset(H_anc, 0, 18 * sizeof(double));
   memset(H_cal, 0, 18 * sizeof(double));
   *nl_out = 3;
@@ -525,8 +533,8 @@ int ovo_feature_jacobian_representation(const ovo_opts *o, const ovo_state *st, 
     for (int i = 0; i < 9; ++i) dlam[i] = (i % 4 == 0) ? 1.0 : 0.0;
     return 0;
   }
-  if (rep == 1) { /* :46-76 (fej == value for the features of this path) */
-    inv_depth_jac(p_FinG, dlam);
+  if (rep == 1) { /* :46-76 */
+    inv_depth_jac((o->do_fej && p_FinG_fej) ? p_FinG_fej : p_FinG, dlam);
     return 0;
   }
   /* :83-101 anchor pose and calibration; with FEJ the anchor pose is the first estimate and p_FinA is re-expressed in it */
@@ -605,7 +613,9 @@ int ovo_feature_jacobian_full_rep(const ovo_opts *o, const ovo_state *st, const 
                                   int *order_id, int *order_size, int *n_order_out) {
   int rows, cols, hfc, no;
   double *Hg = (double *)malloc(sizeof(double) * (size_t)(2 * fb->max_meas + 1) * 6);
-  int rc = ovo_feature_jacobian_full(o, st, fb, f, o->sigma_constraint, 0, NULL, NULL, -1, Hg, H_x, res, &rows, &cols, &hfc,
+  ovo_feats fbl = *fb;
+  if (rep >= 2) fbl.p_FinG_fej = NULL; /* :299-302: the "best" global point also serves as first estimate */
+  int rc = ovo_feature_jacobian_full(o, st, &fbl, f, o->sigma_constraint, 0, NULL, NULL, -1, Hg, H_x, res, &rows, &cols, &hfc,
                                      order_id, order_size, &no);
   if (rc) {
     free(Hg);
@@ -613,7 +623,8 @@ int ovo_feature_jacobian_full_rep(const ovo_opts *o, const ovo_state *st, const 
   }
   double dlam[9], H_anc[18], H_cal[18];
   int nl;
-  rc = ovo_feature_jacobian_representation(o, st, rep, fb->p_FinG + 3 * (size_t)f, anchor_ci, dlam, &nl, H_anc, H_cal);
+  rc = ovo_feature_jacobian_representation_fej(o, st, rep, fb->p_FinG + 3 * (size_t)f,
+                                               fb->p_FinG_fej ? fb->p_FinG_fej + 3 * (size_t)f : NULL, anchor_ci, dlam, &nl, H_anc, H_cal);
   if (rc) {
     free(Hg);
     return rc;
@@ -1590,6 +1601,16 @@ static double chi2_of(const double *P, int n, const double *H, int rows, int col
 int ovo_slam_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *lm_id, const int *plane_of_feat,
                     int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P, double *dx,
                     uint8_t *accepted, double *chi2_out, uint8_t *fellback) {
+  return ovo_slam_update_rep(o, st, fb, lm_id, plane_of_feat, n_planes, cp, cp_fej, plane_state_id, P, dx, accepted, chi2_out,
+                             fellback, NULL, NULL);
+}
+
+/* the same with landmarks held in any ext LandmarkRepresentation: lm_rep[f] (0..5), lm_anchor[f] the anchor clone slot.
+ * fb->p_FinG / p_FinG_fej stay the landmark's GLOBAL position (value / first estimate); dx on the landmark's columns is the
+ * correction of its representation parameters.  Plane rows need GLOBAL_3D (update/UpdaterHelper.cpp:455-456). */
+int ovo_slam_update_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *lm_id, const int *plane_of_feat,
+                        int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P, double *dx,
+                        uint8_t *accepted, double *chi2_out, uint8_t *fellback, const int *lm_rep, const int *lm_anchor) {
   const int n = st->n_state, F = fb->n_feats, mm = fb->max_meas;
   size_t max_meas = 0;
   for (int f = 0; f < F; ++f) max_meas += 3 * (size_t)fb->n_meas[f];
@@ -1625,16 +1646,24 @@ int ovo_slam_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb,
     }
     int rows = 0, cols = 0, hfc = 0, no = 0;
     double chi2 = 0.0;
+    const int rep = lm_rep ? lm_rep[f] : 0;
+    if (rep != 0 && planeid != 0) return -30;
     for (int attempt = 0; attempt < 2; ++attempt) {
-      ovo_feature_jacobian_full(o, st, fb, f, o->sigma_constraint, planeid, cpv, cpf, psid, H_f, H_x, res, &rows, &cols, &hfc, oid,
-                                osz, &no);
+      int nlm = 3;
+      if (rep != 0) {
+        ovo_feature_jacobian_full_rep(o, st, fb, f, rep, lm_anchor[f], H_f, H_x, res, &rows, &cols, &hfc, oid, osz, &no);
+        nlm = hfc;
+      } else {
+        ovo_feature_jacobian_full(o, st, fb, f, o->sigma_constraint, planeid, cpv, cpf, psid, H_f, H_x, res, &rows, &cols, &hfc,
+                                  oid, osz, &no);
+      }
       /* :517-522 append the landmark columns */
       memcpy(H_xf, H_x, sizeof(double) * (size_t)rows * cols);
-      memcpy(H_xf + (size_t)rows * cols, H_f, sizeof(double) * (size_t)rows * 3);
+      memcpy(H_xf + (size_t)rows * cols, H_f, sizeof(double) * (size_t)rows * nlm);
       oid[no] = lm_id[f];
-      osz[no] = 3;
+      osz[no] = nlm;
       ++no;
-      cols += 3;
+      cols += nlm;
       chi2 = chi2_of(P, n, H_xf, rows, cols, oid, osz, no, res); /* :529-532 */
       const double thr = o->chi2_multiplier * ovo_chi2_quantile_095(rows);
       if (planeid != 0 && chi2 > thr) { /* :547-553 fallback without the plane */
@@ -1738,6 +1767,132 @@ int ovo_slam_delayed_init(const ovo_opts *o, const ovo_state *st_in, const ovo_f
   free(osz);
   free(dx);
   return 0;
+}
+
+/* ext Landmark::set_from_xyz (types/Landmark.cpp of ov_core, restated): representation parameters of a point given in the
+ * frame the representation lives in (global for rep 0/1, anchor camera for rep 2..5). */
+static void lm_params_from_xyz(int rep, const double p[3], double out[3]) {
+  if (rep == 0 || rep == 2) {
+    memcpy(out, p, 3 * sizeof(double));
+  } else if (rep == 1 || rep == 3) {
+    const double rho = 1.0 / sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    out[0] = atan2(p[1], p[0]);
+    out[1] = acos(rho * p[2]);
+    out[2] = rho;
+  } else if (rep == 4) {
+    out[0] = p[0] / p[2];
+    out[1] = p[1] / p[2];
+    out[2] = 1.0 / p[2];
+  } else { /* 5: only the inverse depth is a state; the bearing is kept aside (Landmark::_uv_norm_zero) */
+    out[0] = 1.0 / p[2];
+    out[1] = out[2] = 0.0;
+  }
+}
+
+/* update/UpdaterSLAM.cpp:204-364 with StateOptions::feat_rep_slam = rep (:230-296).  A relative landmark is anchored in the
+ * camera of its LAST measurement (ext FeatureInitializer::single_triangulation: anchor_clone_timestamp = timestamps.back()),
+ * and triangulation hands over p_FinA: it is derived here from fb->p_FinG with the poses on entry, and stays fixed while the
+ * poses are corrected by the earlier initialisations of the same call.  rep 5 (ANCHORED_INVERSE_DEPTH_SINGLE): Jacobians
+ * of rep 4, depth column moved to the state side, bearing columns projected out, a 1-d variable is initialised (:262-283).
+ * p_out [3*F]: representation parameters (rep 5: p_out[3f] only). */
+int ovo_slam_delayed_init_rep(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, int rep, double *P, int n_cap,
+                              int *n_io, ovo_state_values *val, uint8_t *ok, double *chi2_out, int *new_id, double *p_out) {
+  const int F = fb->n_feats, mm = fb->max_meas;
+  const int maxrows = 3 * mm + 1, maxcols = 6 * mm + 14 + 3 + 1;
+  const int relative = rep >= 2, k_new = (rep == 5) ? 1 : 3, jrep = (rep == 5) ? 4 : rep;
+  double *H_f = (double *)malloc(sizeof(double) * (size_t)maxrows * 6);
+  double *H_x = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *H_x2 = (double *)malloc(sizeof(double) * (size_t)maxrows * (size_t)maxcols);
+  double *res = (double *)malloc(sizeof(double) * (size_t)maxrows);
+  int *oid = (int *)malloc(sizeof(int) * (size_t)(mm + 6));
+  int *osz = (int *)malloc(sizeof(int) * (size_t)(mm + 6));
+  double *dx = (double *)malloc(sizeof(double) * (size_t)n_cap);
+  double *pA = (double *)malloc(sizeof(double) * 3 * (size_t)F);
+  double *pG = (double *)malloc(sizeof(double) * 3 * (size_t)F);
+  int *anc = (int *)malloc(sizeof(int) * (size_t)F);
+  memcpy(pG, fb->p_FinG, sizeof(double) * 3 * (size_t)F);
+  for (int f = 0; f < F; ++f) { /* what triangulation leaves on the Feature */
+    anc[f] = fb->n_meas[f] > 0 ? fb->clone_idx[(size_t)f * mm + fb->n_meas[f] - 1] : 0;
+    double R_ItoC[9], R_GtoI[9], d[3], t[3];
+    ovo_quat_2_rot(val->calib_q, R_ItoC);
+    ovo_quat_2_rot(val->clone_q + 4 * anc[f], R_GtoI);
+    for (int q = 0; q < 3; ++q) d[q] = fb->p_FinG[3 * f + q] - val->clone_p[3 * anc[f] + q];
+    mat3_vec(R_GtoI, d, t);
+    mat3_vec(R_ItoC, t, pA + 3 * f);
+    for (int q = 0; q < 3; ++q) pA[3 * f + q] += val->calib_p[q];
+  }
+  int rc_all = 0;
+  for (int f = 0; f < F; ++f) {
+    ok[f] = 0;
+    chi2_out[f] = 0.0;
+    new_id[f] = -1;
+    lm_params_from_xyz(rep, relative ? pA + 3 * f : fb->p_FinG + 3 * f, p_out + 3 * f);
+    if (fb->n_meas[f] < 2) continue; /* :112-118 */
+    ovo_state st = *st_in;
+    st.n_state = *n_io;
+    st.clone_q = val->clone_q;
+    st.clone_p = val->clone_p;
+    memcpy(st.calib_q, val->calib_q, sizeof(st.calib_q));
+    memcpy(st.calib_p, val->calib_p, sizeof(st.calib_p));
+    memcpy(st.intrinsics, val->intrinsics, sizeof(st.intrinsics));
+    if (relative) { /* UpdaterHelper.cpp:284-296: global position through the CURRENT anchor pose and calibration */
+      double R_ItoC[9], R_GtoI[9], d[3], t[3];
+      ovo_quat_2_rot(st.calib_q, R_ItoC);
+      ovo_quat_2_rot(st.clone_q + 4 * anc[f], R_GtoI);
+      for (int q = 0; q < 3; ++q) d[q] = pA[3 * f + q] - st.calib_p[q];
+      for (int i = 0; i < 3; ++i) t[i] = R_ItoC[i] * d[0] + R_ItoC[3 + i] * d[1] + R_ItoC[6 + i] * d[2];
+      for (int i = 0; i < 3; ++i)
+        pG[3 * f + i] = R_GtoI[i] * t[0] + R_GtoI[3 + i] * t[1] + R_GtoI[6 + i] * t[2] + st.clone_p[3 * anc[f] + i];
+    }
+    ovo_feats fbl = *fb;
+    fbl.p_FinG = pG;
+    fbl.p_FinG_fej = NULL; /* :240-246 first estimate = value */
+    int rows, cols, hfc, no;
+    int rc = ovo_feature_jacobian_full_rep(o, &st, &fbl, f, jrep, anc[f], H_f, H_x, res, &rows, &cols, &hfc, oid, osz, &no);
+    if (rc) {
+      rc_all = rc;
+      break;
+    }
+    double *HR = H_x, *HL = H_f;
+    if (rep == 5) { /* :262-283 */
+      for (int i = 0; i < rows; ++i) CM(H_x, rows, i, cols) = CM(H_f, rows, i, 2);
+      ovo_nullspace_project(H_f, rows, 2, H_x, cols + 1, NULL, 0, res);
+      const int r2 = rows - 2;
+      for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < r2; ++i) CM(H_x2, r2, i, j) = CM(H_x, rows, i + 2, j);
+      for (int i = 0; i < r2; ++i) H_f[i] = CM(H_x, rows, i + 2, cols);
+      for (int i = 0; i < r2; ++i) res[i] = res[i + 2];
+      rows = r2;
+      HR = H_x2;
+      HL = H_f;
+    }
+    double delta[3] = {0, 0, 0}, chi2 = 0.0;
+    int dof = 0, nn = *n_io;
+    const int r = ovo_initialize(P, n_cap, &nn, oid, osz, no, HR, HL, rows, k_new, 1.0, res, o->chi2_multiplier, 1, delta, dx, &chi2,
+                                 &dof); /* :304 */
+    chi2_out[f] = chi2;
+    if (r == 1) {
+      ok[f] = 1;
+      new_id[f] = *n_io;
+      *n_io = nn;
+      for (int q = 0; q < k_new; ++q) p_out[3 * f + q] += delta[q];
+      for (int g = 0; g < f; ++g)
+        if (new_id[g] >= 0)
+          for (int q = 0; q < k_new; ++q) p_out[3 * g + q] += dx[new_id[g] + q];
+      ovo_apply_dx(st_in, 0, NULL, dx, val);
+    }
+  }
+  free(H_f);
+  free(H_x);
+  free(H_x2);
+  free(res);
+  free(oid);
+  free(osz);
+  free(dx);
+  free(pA);
+  free(pG);
+  free(anc);
+  return rc_all;
 }
 
 /* ================================================================================================================
@@ -2347,4 +2502,96 @@ int ovo_triangulate(const ovo_triang_opts *o, const ovo_state *st, const ovo_fea
   free(Rc);
   free(pc);
   return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterSLAM.cpp:708-850  perform_anchor_change for one landmark held in an anchored representation `rep`
+ * (2..5): position re-expressed in the new anchor camera frame (current and first estimates), anchor-change Jacobian
+ *   Phi = H_f,new^-1 [ H_x,old | H_x,new terms (subtracted) | H_f,old ]      over  [old anchor, extrinsics, new anchor, landmark]
+ * and StateHelper::EKFPropagation of the landmark's block with Q = 0.  P is n x n column-major, lm_id the landmark's id.
+ * ------------------------------------------------------------------------------------------- */
+int ovo_anchor_change(const ovo_opts *o, const ovo_state *st, int rep, int old_ci, int new_ci, int lm_id,
+                      const double p_FinA_old[3], const double p_FinA_old_fej[3], double *P, double p_FinA_new[3],
+                      double p_FinA_new_fej[3]) {
+  if (rep < 2 || rep > 5) return -1;
+  const int n = st->n_state;
+  double R_ItoC[9];
+  ovo_quat_2_rot(st->calib_q, R_ItoC);
+  const double *p_IinC = st->calib_p;
+  double p_FinG[3] = {0, 0, 0};
+  for (int pass = 0; pass < 2; ++pass) { /* :739-775, pass 0 = current estimates, 1 = first estimates */
+    const double *cq = pass ? st->clone_q_fej : st->clone_q, *cp = pass ? st->clone_p_fej : st->clone_p;
+    const double *pin = pass ? p_FinA_old_fej : p_FinA_old;
+    double *pout = pass ? p_FinA_new_fej : p_FinA_new;
+    double Ro[9], Rn[9], R_GtoOLD[9], R_GtoNEW[9], p_OLD[3], p_NEW[3], g[3];
+    ovo_quat_2_rot(cq + 4 * old_ci, Ro);
+    ovo_quat_2_rot(cq + 4 * new_ci, Rn);
+    mat3_mul(R_ItoC, Ro, R_GtoOLD);
+    mat3_mul(R_ItoC, Rn, R_GtoNEW);
+    for (int i = 0; i < 3; ++i) {
+      p_OLD[i] = cp[3 * old_ci + i] - (R_GtoOLD[i] * p_IinC[0] + R_GtoOLD[3 + i] * p_IinC[1] + R_GtoOLD[6 + i] * p_IinC[2]);
+      p_NEW[i] = cp[3 * new_ci + i] - (R_GtoNEW[i] * p_IinC[0] + R_GtoNEW[3 + i] * p_IinC[1] + R_GtoNEW[6 + i] * p_IinC[2]);
+    }
+    for (int i = 0; i < 3; ++i) g[i] = R_GtoOLD[i] * pin[0] + R_GtoOLD[3 + i] * pin[1] + R_GtoOLD[6 + i] * pin[2] + p_OLD[i];
+    if (!pass) memcpy(p_FinG, g, sizeof(g));
+    for (int i = 0; i < 3; ++i) g[i] -= p_NEW[i];
+    mat3_vec(R_GtoNEW, g, pout);
+  }
+  double Hf_old[9], Hf_new[9], Ha_old[18], Hc_old[18], Ha_new[18], Hc_new[18];
+  int nl, nl2;
+  if (ovo_feature_jacobian_representation(o, st, rep, p_FinG, old_ci, Hf_old, &nl, Ha_old, Hc_old)) return -2;
+  if (ovo_feature_jacobian_representation(o, st, rep, p_FinG, new_ci, Hf_new, &nl2, Ha_new, Hc_new)) return -2;
+  /* H_f,new^-1 (3 x 3), or the pseudo-inverse of the 3 x 1 column (:815-819) */
+  double Hinv[9];
+  if (nl == 1) {
+    const double nn = Hf_new[0] * Hf_new[0] + Hf_new[1] * Hf_new[1] + Hf_new[2] * Hf_new[2];
+    for (int k = 0; k < 3; ++k) Hinv[k] = Hf_new[k] / nn;
+  } else {
+    double A[9], Ai[9]; /* small_inverse works column-major */
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A[3 * j + i] = Hf_new[3 * i + j];
+    if (small_inverse(A, 3, Ai)) return -3;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Hinv[3 * i + j] = Ai[3 * j + i];
+  }
+  /* order_OLD: old anchor, extrinsics (if estimated), new anchor, landmark (:787-808) */
+  int old_id[4], old_size[4], n_old = 0, col_cal = -1, col_new, col_lm;
+  int cols = 0;
+  old_id[n_old] = st->clone_id[old_ci];
+  old_size[n_old++] = 6;
+  cols += 6;
+  if (o->do_calib_camera_pose) {
+    col_cal = cols;
+    old_id[n_old] = st->calib_id;
+    old_size[n_old++] = 6;
+    cols += 6;
+  }
+  col_new = cols;
+  old_id[n_old] = st->clone_id[new_ci];
+  old_size[n_old++] = 6;
+  cols += 6;
+  col_lm = cols;
+  old_id[n_old] = lm_id;
+  old_size[n_old++] = nl;
+  cols += nl;
+  double *Phi = (double *)calloc((size_t)nl * cols, sizeof(double));
+  double *Q = (double *)calloc((size_t)nl * nl, sizeof(double));
+#define OVO_ADD(col0, B, bc, sgn)                                          \
+  for (int i = 0; i < nl; ++i)                                             \
+    for (int j = 0; j < (bc); ++j) {                                       \
+      double a = 0;                                                        \
+      for (int k = 0; k < 3; ++k) a += Hinv[3 * i + k] * (B)[(bc)*k + j];  \
+      CM(Phi, nl, i, (col0) + j) += (sgn)*a;                               \
+    }
+  OVO_ADD(0, Ha_old, 6, 1.0);
+  if (col_cal >= 0) OVO_ADD(col_cal, Hc_old, 6, 1.0);
+  OVO_ADD(col_lm, Hf_old, nl, 1.0);
+  OVO_ADD(col_new, Ha_new, 6, -1.0);
+  if (col_cal >= 0) OVO_ADD(col_cal, Hc_new, 6, -1.0);
+#undef OVO_ADD
+  int neg = 0;
+  int rc = ovo_ekf_propagation(P, n, lm_id, nl, old_id, old_size, n_old, Phi, Q, &neg);
+  free(Phi);
+  free(Q);
+  return rc ? rc : (neg ? -4 : 0);
 }

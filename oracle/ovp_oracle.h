@@ -79,9 +79,19 @@ int ovo_llt(double *A, int n, int ld);                        /* in-place lower 
  * ANCHORED_INVERSE_DEPTH_SINGLE), see ovp_oracle.c */
 int ovo_feature_jacobian_representation(const ovo_opts *o, const ovo_state *st, int rep, const double p_FinG[3], int anchor_ci,
                                         double *dlam, int *nl_out, double H_anc[18], double H_cal[18]);
+int ovo_feature_jacobian_representation_fej(const ovo_opts *o, const ovo_state *st, int rep, const double p_FinG[3],
+                                            const double *p_FinG_fej, int anchor_ci, double *dlam, int *nl_out, double H_anc[18],
+                                            double H_cal[18]);
+int ovo_slam_update_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *lm_id, const int *plane_of_feat,
+                        int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P, double *dx,
+                        uint8_t *accepted, double *chi2, uint8_t *fellback, const int *lm_rep, const int *lm_anchor);
 int ovo_feature_jacobian_full_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, int rep, int anchor_ci,
                                   double *H_f, double *H_x, double *res, int *rows_out, int *cols_out, int *hf_cols_out,
                                   int *order_id, int *order_size, int *n_order_out);
+/* update/UpdaterSLAM.cpp:708-850 perform_anchor_change, see ovp_oracle.c */
+int ovo_anchor_change(const ovo_opts *o, const ovo_state *st, int rep, int old_ci, int new_ci, int lm_id,
+                      const double p_FinA_old[3], const double p_FinA_old_fej[3], double *P, double p_FinA_new[3],
+                      double p_FinA_new_fej[3]);
 void ovo_equi_distort(const double v[8], const double uvn[2], double uvd[2]);
 void ovo_equi_jacobian(const double v[8], const double uvn[2], double dz_dzn[4], double dz_dzeta[16]);
 int ovo_feature_jacobian_full(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int f, double sigma_c,
@@ -185,6 +195,10 @@ int ovo_plane_init(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, 
 int ovo_initialize(double *P, int n_cap, int *n, const int *order_id, const int *order_size, int n_order, double *H_R,
                    double *H_L, int rows, int k, double r_iso, double *res, double chi2_mult, int do_update,
                    double *new_var_delta, double *dx, double *chi2_out, int *dof_out);
+
+/* UpdaterSLAM.cpp:204-364 with StateOptions::feat_rep_slam = rep (0..5), see ovp_oracle.c */
+int ovo_slam_delayed_init_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, int rep, double *P, int n_cap, int *n,
+                              ovo_state_values *val, uint8_t *ok, double *chi2_out, int *new_id, double *p_out);
 
 /* ---- state/Propagator.cpp (a11) ------------------------------------------------------------------------------- */
 typedef struct {

@@ -174,6 +174,31 @@ def feature_jacobian_full_rep(sc, f, rep, anchor_ci):
             [(int(oid[i]), int(osz[i])) for i in range(n)])
 
 
+def feature_jacobian_representation(sc, rep, p_FinG, anchor_ci):
+    """ovo_feature_jacobian_representation: (dpfg_dlambda [3, 3 or 1], H_anc [3,6], H_calib [3,6])."""
+    pk = Packed(sc)
+    dl, Ha, Hc = np.zeros(9), np.zeros(18), np.zeros(18)
+    nl = C.c_int()
+    pg = np.ascontiguousarray(p_FinG, dtype=np.float64)
+    rc = lib().ovo_feature_jacobian_representation(C.byref(pk.opts), C.byref(pk.state), C.c_int(rep), _dp(pg), C.c_int(anchor_ci),
+                                                   _dp(dl), C.byref(nl), _dp(Ha), _dp(Hc))
+    assert rc == 0
+    return dl[: 3 * nl.value].reshape(3, nl.value).copy(), Ha.reshape(3, 6).copy(), Hc.reshape(3, 6).copy()
+
+
+def anchor_change(sc, rep, old_ci, new_ci, lm_id, p_FinA, p_FinA_fej):
+    """ovo_anchor_change on the scene's state (sc.P must cover the landmark columns).  Returns dict(P, p_FinA, p_FinA_fej)."""
+    pk = Packed(sc)
+    P = np.asfortranarray(sc.P.copy())
+    pa = np.ascontiguousarray(p_FinA, dtype=np.float64)
+    pf = np.ascontiguousarray(p_FinA_fej, dtype=np.float64)
+    pn, pnf = np.zeros(3), np.zeros(3)
+    rc = lib().ovo_anchor_change(C.byref(pk.opts), C.byref(pk.state), C.c_int(rep), C.c_int(old_ci), C.c_int(new_ci),
+                                 C.c_int(lm_id), _dp(pa), _dp(pf), _dp(P), _dp(pn), _dp(pnf))
+    assert rc == 0, rc
+    return dict(P=np.ascontiguousarray(P), p_FinA=pn, p_FinA_fej=pnf)
+
+
 def msckf_point_update(sc, feats=None):
     """Runs ovo_msckf_point_update. Returns dict(dx, P, accepted, chi2, rows_compressed, timings)."""
     pk = Packed(sc, feats)
@@ -308,8 +333,9 @@ def plane_init(sc, const_init_multi=5.0, const_init_chi2=1.0, n_extra=None):
                 new_id=nid[:n_planes], cp=cp_out[:n_planes])
 
 
-def slam_update(sc, lm_id, use_planes=False):
-    """ovo_slam_update: features of the scene are observations of landmarks already in the state (ids lm_id[f])."""
+def slam_update(sc, lm_id, use_planes=False, rep=None, anchor=None):
+    """ovo_slam_update: features of the scene are observations of landmarks already in the state (ids lm_id[f]).
+    rep / anchor [F]: ext LandmarkRepresentation and anchor clone slot of every landmark (None = GLOBAL_3D)."""
     L = lib()
     pk = Packed(sc)
     P = np.asfortranarray(sc.P.copy())
@@ -324,13 +350,21 @@ def slam_update(sc, lm_id, use_planes=False):
     cp = np.ascontiguousarray(sc.cp if npl else np.zeros((1, 3)), dtype=np.float64)
     cpf = np.ascontiguousarray(sc.cp_fej if npl else np.zeros((1, 3)), dtype=np.float64)
     sid = np.ascontiguousarray(sc.plane_state_id if npl else -np.ones(1), dtype=np.int32)
-    rc = L.ovo_slam_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(lm), _ip(pof), C.c_int(npl), _dp(cp),
-                           _dp(cpf), _ip(sid), _dp(P), _dp(dx), acc.ctypes.data_as(u8), _dp(chi2), fb.ctypes.data_as(u8))
+    if rep is None:
+        rc = L.ovo_slam_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(lm), _ip(pof), C.c_int(npl), _dp(cp),
+                               _dp(cpf), _ip(sid), _dp(P), _dp(dx), acc.ctypes.data_as(u8), _dp(chi2), fb.ctypes.data_as(u8))
+    else:
+        rp = np.ascontiguousarray(rep, dtype=np.int32)
+        an = np.ascontiguousarray(anchor, dtype=np.int32)
+        rc = L.ovo_slam_update_rep(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _ip(lm), _ip(pof), C.c_int(npl), _dp(cp),
+                                   _dp(cpf), _ip(sid), _dp(P), _dp(dx), acc.ctypes.data_as(u8), _dp(chi2),
+                                   fb.ctypes.data_as(u8), _ip(rp), _ip(an))
     return dict(rc=rc, P=np.ascontiguousarray(P), dx=dx, accepted=acc.astype(bool), chi2=chi2, fellback=fb.astype(bool))
 
 
-def slam_delayed_init(sc):
-    """ovo_slam_delayed_init on every feature of the scene (no planes)."""
+def slam_delayed_init(sc, rep=None):
+    """ovo_slam_delayed_init on every feature of the scene (no planes); rep = StateOptions::feat_rep_slam (None = GLOBAL_3D
+    through the original entry; out["p"] are the representation parameters)."""
     L = lib()
     pk = Packed(sc)
     cap = sc.N + 3 * sc.F
@@ -351,8 +385,14 @@ def slam_delayed_init(sc):
     nid = np.zeros(sc.F, dtype=np.int32)
     pout = np.zeros((sc.F, 3))
     nn = C.c_int(sc.N)
-    L.ovo_slam_delayed_init(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), C.c_int(cap), C.byref(nn),
-                            C.byref(val), ok.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _ip(nid), _dp(pout))
+    if rep is None:
+        L.ovo_slam_delayed_init(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), C.c_int(cap), C.byref(nn),
+                                C.byref(val), ok.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _ip(nid), _dp(pout))
+    else:
+        rc = L.ovo_slam_delayed_init_rep(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), C.c_int(int(rep)), _dp(P),
+                                         C.c_int(cap), C.byref(nn), C.byref(val), ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                         _dp(chi2), _ip(nid), _dp(pout))
+        assert rc == 0, rc
     n2 = nn.value
     return dict(P=np.ascontiguousarray(P[:n2, :n2]), n=n2, clone_q=cq, clone_p=cpv, calib_q=np.array(val.calib_q[:]),
                 calib_p=np.array(val.calib_p[:]), intr=np.array(val.intrinsics[:]), ok=ok.astype(bool), chi2=chi2, new_id=nid,

@@ -18,6 +18,15 @@ static double g_fit_max_cond = 100.0;
 // lens model of camera 0 for the next harness call (0 = radtan, 1 = equidistant)
 static int g_fisheye = 0;
 extern "C" void ovph_set_fisheye(int fisheye) { g_fisheye = fisheye; }
+// mode 0 of ovph_run_updater: hold every landmark in this ext LandmarkRepresentation (1..4), anchored in this clone slot
+static int g_slam_rep = 0, g_slam_anchor = 0;
+extern "C" void ovph_set_slam_rep(int rep, int anchor_ci) {
+  g_slam_rep = rep;
+  g_slam_anchor = anchor_ci;
+}
+// mode 1 of ovph_run_updater: StateOptions::feat_rep_slam of the landmarks delayed_init creates
+static int g_feat_rep_slam = 0;
+extern "C" void ovph_set_feat_rep_slam(int rep) { g_feat_rep_slam = rep; }
 // mode 3 of ovph_run_updater: plane of every SLAM landmark (0 = none)
 static const int *g_slam_plane = nullptr;
 extern "C" void ovph_set_slam_planes(const int *plane_of_landmark) { g_slam_plane = plane_of_landmark; }
@@ -452,18 +461,50 @@ extern "C" int ovph_run_updater(int mode, int C, const double *clone_q, const do
     }
     return 0;
   }
+  if (mode == 0 && g_slam_rep != 0) {
+    // re-express the landmarks (built as GLOBAL_3D from their global value / first estimate) in the requested representation
+    auto calib = state->_calib_IMUtoCAM.at(0);
+    auto anchor = state->_clones_IMU.at(hs.times[g_slam_anchor]);
+    for (auto &lm : hs.landmarks) {
+      double pg[3], pgf[3], pa[3], paf[3], t[3];
+      lm->get_xyz(false, pg);
+      lm->get_xyz(true, pgf);
+      lm->_feat_representation = (LandmarkRepresentation::Representation)g_slam_rep;
+      if (LandmarkRepresentation::is_relative_representation(lm->_feat_representation)) {
+        lm->_anchor_cam_id = 0;
+        lm->_anchor_clone_timestamp = hs.times[g_slam_anchor];
+        for (int pass = 0; pass < 2; ++pass) {
+          const double *R = pass ? anchor->Rot_fej() : anchor->Rot(), *pp = pass ? anchor->pos_fej() : anchor->pos();
+          const double *src = pass ? pgf : pg;
+          double *dst = pass ? paf : pa;
+          const double d[3] = {src[0] - pp[0], src[1] - pp[1], src[2] - pp[2]};
+          for (int i = 0; i < 3; ++i) t[i] = R[3 * i] * d[0] + R[3 * i + 1] * d[1] + R[3 * i + 2] * d[2];
+          for (int i = 0; i < 3; ++i)
+            dst[i] = calib->Rot()[3 * i] * t[0] + calib->Rot()[3 * i + 1] * t[1] + calib->Rot()[3 * i + 2] * t[2] + calib->pos()[i];
+        }
+        lm->set_from_xyz(pa, false);
+        lm->set_from_xyz(paf, true);
+      } else {
+        lm->set_from_xyz(pg, false);
+        lm->set_from_xyz(pgf, true);
+      }
+    }
+    g_slam_rep = 0;
+  }
   if (mode == 0) {
     UpdaterSLAM up(uo, ua, fio);
     up.update(state, fv, feat2plane);
   } else if (mode == 1) {
     UpdaterSLAM up(uo, ua, fio);
+    state->_options.feat_rep_slam = (LandmarkRepresentation::Representation)g_feat_rep_slam;
+    g_feat_rep_slam = 0;
     up.delayed_init(state, fv, feat2plane);
     for (int f = 0; f < F; ++f) {
       out_new_id[f] = -1;
       auto it = state->_features_SLAM.find(id0 + f);
       if (it == state->_features_SLAM.end()) continue;
       out_new_id[f] = it->second->id();
-      memcpy(out_new_p + 3 * f, it->second->value().data(), 3 * sizeof(double));
+      memcpy(out_new_p + 3 * f, it->second->value().data(), (size_t)it->second->size() * sizeof(double));
     }
   } else {
     if (!g_fit_planes)  // otherwise init_vio_plane triangulates, fits and refines itself (UpdaterPlane.cpp:76-290)
@@ -955,4 +996,46 @@ extern "C" int ovph_feature_jacobian_rep(int C, const double *clone_q, const dou
     order_size[k] = order[k]->size();
   }
   return 0;
+}
+
+// UpdaterSLAM::change_anchors on a state whose first landmark is held in the anchored representation `rep` (2..4) and anchored
+// in the oldest clone, with one clone more than max_clone_size in the window: the landmark moves to the newest clone.
+// lm_p_FinA / lm_p_FinA_fej: its position in the old anchor camera frame.  Outputs: landmark value / fej (representation
+// parameters), its new anchor clone slot, the covariance.
+extern "C" int ovph_run_change_anchors(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
+                                       const double *clone_p_fej, const double *calib_q, const double *calib_p, const double *intr,
+                                       int n_slam, const double *slam_p, int N, const double *P, int rep, const double *lm_p_FinA,
+                                       const double *lm_p_FinA_fej, int do_fej, double *out_value, double *out_fej, int *out_anchor_ci,
+                                       double *out_P) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C - 1;
+  so.max_state_size = N + 8;
+  so.max_features = 16;
+  HarnessState hs;
+  int rc = build_harness_state(hs, so, C, clone_q, clone_p, clone_q_fej, clone_p_fej, calib_q, calib_p, intr, n_slam, slam_p, slam_p, 0,
+                               nullptr, nullptr, N, P);
+  if (rc) return rc;
+  auto &state = hs.state;
+  auto lm = hs.landmarks.at(0);
+  lm->_feat_representation = (LandmarkRepresentation::Representation)rep;
+  lm->_anchor_cam_id = 0;
+  lm->_anchor_clone_timestamp = hs.times[0];
+  lm->set_from_xyz(lm_p_FinA, false);
+  lm->set_from_xyz(lm_p_FinA_fej, true);
+  UpdaterOptions uo, ua;
+  ov_core::FeatureInitializerOptions fio;
+  UpdaterSLAM up(uo, ua, fio);
+  up.change_anchors(state);
+  for (int k = 0; k < 3; ++k) {
+    out_value[k] = lm->value()(k);
+    out_fej[k] = lm->fej()(k);
+  }
+  *out_anchor_ci = -1;
+  for (int i = 0; i < C; ++i)
+    if (hs.times[i] == lm->_anchor_clone_timestamp) *out_anchor_ci = i;
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)N * N);
+  return lm->has_had_anchor_change ? 0 : -20;
 }

@@ -215,9 +215,16 @@ public:
   // update/UpdaterSLAM.cpp:66-374, downstream of triangulation (features carry p_FinG)
   void delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                     const std::map<size_t, size_t> &feat2plane);
+  // update/UpdaterSLAM.cpp:684-706: landmarks anchored in the clone that is about to be marginalised move to the newest one
+  void change_anchors(std::shared_ptr<State> state);
 
 protected:
+  // update/UpdaterSLAM.cpp:708-850: new anchor-frame value of the landmark and covariance propagation with the
+  // anchor-change Jacobian  Phi = H_f,new^-1 [H_x,old | H_f,old | -H_x,new]
+  void perform_anchor_change(std::shared_ptr<State> state, std::shared_ptr<ov_type::Landmark> landmark, double new_anchor_timestamp,
+                             size_t new_cam_id);
   UpdaterOptions _options_slam, _options_aruco;
+  friend struct UpdaterSLAMTestAccess;
 };
 
 // update/UpdaterPlane.h:55-123

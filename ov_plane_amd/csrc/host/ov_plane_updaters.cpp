@@ -552,8 +552,17 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
         }
       }
     }
-    landmark->get_xyz(false, feat.p_FinG);
-    landmark->get_xyz(true, feat.p_FinG_fej);
+    // :478-493 the landmark in its own representation
+    feat.feat_representation = landmark->_feat_representation;
+    if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
+      feat.anchor_cam_id = landmark->_anchor_cam_id;
+      feat.anchor_clone_timestamp = landmark->_anchor_clone_timestamp;
+      landmark->get_xyz(false, feat.p_FinA);
+      landmark->get_xyz(true, feat.p_FinA_fej);
+    } else {
+      landmark->get_xyz(false, feat.p_FinG);
+      landmark->get_xyz(true, feat.p_FinG_fej);
+    }
     MatrixXd H_f, H_x, H_xf;
     VectorXd res;
     std::vector<std::shared_ptr<Type>> Hx_order, Hxf_order;
@@ -637,6 +646,21 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     }
   }
   // (triangulation and the joint point/plane refinement :120-202 are upstream: features carry p_FinG)
+  // a p_FinG that came without its anchor gets what ext single_triangulation would have left behind, with the poses as they
+  // are now (the initialisations below move them)
+  for (auto &fp : feature_vec) {
+    ov_core::Feature &ft = *fp;
+    if (ft.anchor_cam_id != -1) continue;
+    ft.anchor_cam_id = 0;
+    ft.anchor_clone_timestamp = ft.timestamps.back();
+    auto an = state->_clones_IMU.at(ft.anchor_clone_timestamp);
+    auto cal = state->_calib_IMUtoCAM.at(0);
+    const double d[3] = {ft.p_FinG[0] - an->pos()[0], ft.p_FinG[1] - an->pos()[1], ft.p_FinG[2] - an->pos()[2]};
+    double t[3];
+    m3v(an->Rot(), d, t);
+    m3v(cal->Rot(), t, ft.p_FinA);
+    for (int k = 0; k < 3; ++k) ft.p_FinA[k] += cal->pos()[k];
+  }
   auto it2 = feature_vec.begin();
   while (it2 != feature_vec.end()) {
     UpdaterHelper::UpdaterHelperFeature feat;
@@ -656,17 +680,51 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
         }
       }
     }
-    memcpy(feat.p_FinG, (*it2)->p_FinG, sizeof(feat.p_FinG));
-    memcpy(feat.p_FinG_fej, (*it2)->p_FinG, sizeof(feat.p_FinG));
+    // :230-246 representation of the new landmark; the single inverse depth is linearised as the MSCKF inverse depth
+    const auto feat_rep = state->_options.feat_rep_slam;
+    const bool single = feat_rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE;
+    feat.feat_representation = single ? LandmarkRepresentation::Representation::ANCHORED_MSCKF_INVERSE_DEPTH : feat_rep;
+    if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
+      ov_core::Feature &ft = **it2;
+      feat.anchor_cam_id = ft.anchor_cam_id;
+      feat.anchor_clone_timestamp = ft.anchor_clone_timestamp;
+      memcpy(feat.p_FinA, ft.p_FinA, sizeof(feat.p_FinA));
+      memcpy(feat.p_FinA_fej, ft.p_FinA, sizeof(feat.p_FinA));
+    } else {
+      memcpy(feat.p_FinG, (*it2)->p_FinG, sizeof(feat.p_FinG));
+      memcpy(feat.p_FinG_fej, (*it2)->p_FinG, sizeof(feat.p_FinG));
+    }
     MatrixXd H_f, H_x;
     VectorXd res;
     std::vector<std::shared_ptr<Type>> Hx_order;
     const double sigma_c = state->_options.sigma_constraint;
-    UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
-    auto landmark = std::make_shared<Landmark>(3);  // :289-296
+    // :262-283 single inverse depth: the depth column joins the state side, the bearing columns are projected out
+    auto jacobian = [&]() {
+      UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
+      if (!single) return;
+      MatrixXd H_xf(H_x.rows(), H_x.cols() + 1);
+      for (int j = 0; j < H_x.cols(); ++j)
+        for (int i = 0; i < H_x.rows(); ++i) H_xf(i, j) = H_x(i, j);
+      for (int i = 0; i < H_x.rows(); ++i) H_xf(i, H_x.cols()) = H_f(i, H_f.cols() - 1);
+      MatrixXd H_b = H_f.block(0, 0, H_f.rows(), H_f.cols() - 1);
+      UpdaterHelper::nullspace_project_inplace(H_b, H_xf, res);
+      H_x = H_xf.block(0, 0, H_xf.rows(), H_xf.cols() - 1);
+      H_f = H_xf.block(0, H_xf.cols() - 1, H_xf.rows(), 1);
+    };
+    jacobian();
+    auto landmark = std::make_shared<Landmark>(single ? 1 : 3);  // :285-296
     landmark->_featid = feat.featid;
-    landmark->set_from_xyz(feat.p_FinG, false);
-    landmark->set_from_xyz(feat.p_FinG_fej, true);
+    landmark->_feat_representation = feat_rep;
+    landmark->_unique_camera_id = (*it2)->anchor_cam_id;
+    if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
+      landmark->_anchor_cam_id = feat.anchor_cam_id;
+      landmark->_anchor_clone_timestamp = feat.anchor_clone_timestamp;
+      landmark->set_from_xyz(feat.p_FinA, false);
+      landmark->set_from_xyz(feat.p_FinA_fej, true);
+    } else {
+      landmark->set_from_xyz(feat.p_FinG, false);
+      landmark->set_from_xyz(feat.p_FinG_fej, true);
+    }
     MatrixXd R = MatrixXd::Identity(res.rows(), res.rows());
     const double chi2_multipler = _options_slam.chi2_multipler;
     if (StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler)) {  // :304
@@ -677,7 +735,7 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     } else if (feat.planeid != 0) {  // :310-359 fallback without the plane
       feat.planeid = 0;
       state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;
-      UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
+      jacobian();
       R = MatrixXd::Identity(res.rows(), res.rows());
       if (StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler)) {
         state->_features_SLAM.insert({(*it2)->featid, landmark});
@@ -695,6 +753,132 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
 }
 
 // ---- update/UpdaterPlane.cpp ---------------------------------------------------------------------
+// ---- update/UpdaterSLAM.cpp:684-850 ---------------------------------------------------------------
+void UpdaterSLAM::change_anchors(std::shared_ptr<State> state) {
+  if ((int)state->_clones_IMU.size() <= state->_options.max_clone_size) return;  // :687-689
+  const double marg_timestep = state->margtimestep();
+  for (auto &f : state->_features_SLAM) {
+    if (!LandmarkRepresentation::is_relative_representation(f.second->_feat_representation)) continue;  // :697-699
+    assert(marg_timestep <= f.second->_anchor_clone_timestamp);
+    if (f.second->_anchor_clone_timestamp == marg_timestep)
+      perform_anchor_change(state, f.second, state->_timestamp, (size_t)f.second->_anchor_cam_id);
+  }
+}
+
+void UpdaterSLAM::perform_anchor_change(std::shared_ptr<State> state, std::shared_ptr<Landmark> landmark, double new_anchor_timestamp,
+                                        size_t new_cam_id) {
+  assert(LandmarkRepresentation::is_relative_representation(landmark->_feat_representation));
+  assert(landmark->_anchor_cam_id != -1);
+  // :716-727 Jacobians of p_FinG w.r.t. the old representation
+  UpdaterHelper::UpdaterHelperFeature old_feat;
+  old_feat.featid = landmark->_featid;
+  old_feat.feat_representation = landmark->_feat_representation;
+  old_feat.anchor_cam_id = landmark->_anchor_cam_id;
+  old_feat.anchor_clone_timestamp = landmark->_anchor_clone_timestamp;
+  landmark->get_xyz(false, old_feat.p_FinA);
+  landmark->get_xyz(true, old_feat.p_FinA_fej);
+  MatrixXd H_f_old;
+  std::vector<MatrixXd> H_x_old;
+  std::vector<std::shared_ptr<Type>> x_order_old;
+  UpdaterHelper::get_feature_jacobian_representation(state, old_feat, H_f_old, H_x_old, x_order_old);
+  // :730-734
+  UpdaterHelper::UpdaterHelperFeature new_feat;
+  new_feat.featid = landmark->_featid;
+  new_feat.feat_representation = landmark->_feat_representation;
+  new_feat.anchor_cam_id = (int)new_cam_id;
+  new_feat.anchor_clone_timestamp = new_anchor_timestamp;
+  // :739-775 the landmark in the new anchor camera frame, at the current and at the first estimates
+  auto transfer = [&](bool fej, const double p_old[3], double p_new[3]) {
+    auto co = state->_clones_IMU.at(old_feat.anchor_clone_timestamp), cn = state->_clones_IMU.at(new_feat.anchor_clone_timestamp);
+    auto ko = state->_calib_IMUtoCAM.at(old_feat.anchor_cam_id), kn = state->_calib_IMUtoCAM.at(new_feat.anchor_cam_id);
+    double R_GtoOLD[9], R_GtoNEW[9], p_OLDinG[3], p_NEWinG[3];
+    m3m(ko->Rot(), fej ? co->Rot_fej() : co->Rot(), R_GtoOLD);
+    m3m(kn->Rot(), fej ? cn->Rot_fej() : cn->Rot(), R_GtoNEW);
+    const double *po = fej ? co->pos_fej() : co->pos(), *pn = fej ? cn->pos_fej() : cn->pos();
+    for (int i = 0; i < 3; ++i) {
+      p_OLDinG[i] = po[i] - (R_GtoOLD[i] * ko->pos()[0] + R_GtoOLD[3 + i] * ko->pos()[1] + R_GtoOLD[6 + i] * ko->pos()[2]);
+      p_NEWinG[i] = pn[i] - (R_GtoNEW[i] * kn->pos()[0] + R_GtoNEW[3 + i] * kn->pos()[1] + R_GtoNEW[6 + i] * kn->pos()[2]);
+    }
+    // p_new = R_GtoNEW (R_GtoOLD^T p_old + p_OLDinG - p_NEWinG)
+    double g[3];
+    for (int i = 0; i < 3; ++i)
+      g[i] = R_GtoOLD[i] * p_old[0] + R_GtoOLD[3 + i] * p_old[1] + R_GtoOLD[6 + i] * p_old[2] + p_OLDinG[i] - p_NEWinG[i];
+    m3v(R_GtoNEW, g, p_new);
+  };
+  transfer(false, old_feat.p_FinA, new_feat.p_FinA);
+  transfer(true, old_feat.p_FinA_fej, new_feat.p_FinA_fej);
+  // :778-781
+  MatrixXd H_f_new;
+  std::vector<MatrixXd> H_x_new;
+  std::vector<std::shared_ptr<Type>> x_order_new;
+  UpdaterHelper::get_feature_jacobian_representation(state, new_feat, H_f_new, H_x_new, x_order_new);
+  // :787-808 order of the old states the new landmark error depends on
+  std::vector<std::shared_ptr<Type>> phi_order_NEW{landmark}, phi_order_OLD;
+  std::vector<std::pair<std::shared_ptr<Type>, int>> Phi_id_map;
+  auto find_phi = [&](const std::shared_ptr<Type> &v) {
+    for (auto &p : Phi_id_map)
+      if (p.first == v) return p.second;
+    return -1;
+  };
+  int current_it = 0;
+  for (const auto &var : x_order_old)
+    if (find_phi(var) < 0) {
+      Phi_id_map.push_back({var, current_it});
+      phi_order_OLD.push_back(var);
+      current_it += var->size();
+    }
+  for (const auto &var : x_order_new)
+    if (find_phi(var) < 0) {
+      Phi_id_map.push_back({var, current_it});
+      phi_order_OLD.push_back(var);
+      current_it += var->size();
+    }
+  Phi_id_map.push_back({landmark, current_it});
+  phi_order_OLD.push_back(landmark);
+  current_it += landmark->size();
+  // :811-836  pf_new_error = Hfnew^-1 (Hfold pf_olderror + Hxold x_olderror - Hxnew x_newerror)
+  const int phisize = (new_feat.feat_representation != LandmarkRepresentation::ANCHORED_INVERSE_DEPTH_SINGLE) ? 3 : 1;
+  MatrixXd Phi = MatrixXd::Zero(phisize, current_it), Q = MatrixXd::Zero(phisize, phisize);
+  MatrixXd H_f_new_inv(phisize, 3);
+  if (phisize == 1) {
+    double nn = 0;
+    for (int k = 0; k < 3; ++k) nn += H_f_new(k, 0) * H_f_new(k, 0);
+    for (int k = 0; k < 3; ++k) H_f_new_inv(0, k) = H_f_new(k, 0) / nn;
+  } else {
+    // 3x3 inverse (the reference solves with a column-pivoted QR)
+    const MatrixXd &A = H_f_new;
+    const double c00 = A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1), c01 = A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2), c02 = A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1);
+    const double det = A(0, 0) * c00 + A(1, 0) * c01 + A(2, 0) * c02;
+    H_f_new_inv(0, 0) = c00 / det;
+    H_f_new_inv(0, 1) = c01 / det;
+    H_f_new_inv(0, 2) = c02 / det;
+    H_f_new_inv(1, 0) = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) / det;
+    H_f_new_inv(1, 1) = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) / det;
+    H_f_new_inv(1, 2) = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) / det;
+    H_f_new_inv(2, 0) = (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0)) / det;
+    H_f_new_inv(2, 1) = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) / det;
+    H_f_new_inv(2, 2) = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) / det;
+  }
+  auto add_block = [&](int col0, const MatrixXd &B, double sign) {
+    for (int i = 0; i < phisize; ++i)
+      for (int j = 0; j < B.cols(); ++j) {
+        double a = 0;
+        for (int k = 0; k < 3; ++k) a += H_f_new_inv(i, k) * B(k, j);
+        Phi(i, col0 + j) += sign * a;
+      }
+  };
+  for (size_t i = 0; i < H_x_old.size(); i++) add_block(find_phi(x_order_old[i]), H_x_old[i], 1.0);
+  add_block(find_phi(landmark), H_f_old, 1.0);
+  for (size_t i = 0; i < H_x_new.size(); i++) add_block(find_phi(x_order_new[i]), H_x_new[i], -1.0);
+  StateHelper::EKFPropagation(state, phi_order_NEW, phi_order_OLD, Phi, Q);  // :839
+  // :842-848
+  landmark->_anchor_cam_id = new_feat.anchor_cam_id;
+  landmark->_anchor_clone_timestamp = new_feat.anchor_clone_timestamp;
+  landmark->set_from_xyz(new_feat.p_FinA, false);
+  landmark->set_from_xyz(new_feat.p_FinA_fej, true);
+  landmark->has_had_anchor_change = true;
+}
+
 UpdaterPlane::UpdaterPlane(UpdaterOptions &options, ov_core::FeatureInitializerOptions &feat_init_options)
     : _options(options), _featinit(feat_init_options) {
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);

@@ -355,19 +355,81 @@ struct LandmarkRepresentation {
   }
 };
 
-// ext ov_type::Landmark (GLOBAL_3D only here: value == xyz); fields used by UpdaterSLAM
+// ext ov_type::Landmark (types/Landmark.h/.cpp): a 3-dof (1-dof for ANCHORED_INVERSE_DEPTH_SINGLE) Vec holding the
+// landmark in one of the six representations; get_xyz / set_from_xyz convert to / from the position in the global
+// (GLOBAL_*) or anchor camera (ANCHORED_*) frame
 class Landmark : public Vec {
 public:
   explicit Landmark(int dim) : Vec(dim) {}
   size_t _featid = 0;
+  int _unique_camera_id = -1;
+  int _anchor_cam_id = -1;
+  double _anchor_clone_timestamp = -1;
+  bool has_had_anchor_change = false;
   bool should_marg = false;
+  double uv_norm_zero[3] = {0, 0, 1}, uv_norm_zero_fej[3] = {0, 0, 1};  // bearing of the single-depth representation
+  LandmarkRepresentation::Representation _feat_representation = LandmarkRepresentation::GLOBAL_3D;
+
   void get_xyz(bool getfej, double out[3]) const {
     const VectorXd &v = getfej ? fej() : value();
-    for (int k = 0; k < 3; ++k) out[k] = v(k);
+    typedef LandmarkRepresentation LR;
+    switch (_feat_representation) {
+    case LR::GLOBAL_3D:
+    case LR::ANCHORED_3D:
+      for (int k = 0; k < 3; ++k) out[k] = v(k);
+      return;
+    case LR::GLOBAL_FULL_INVERSE_DEPTH:
+    case LR::ANCHORED_FULL_INVERSE_DEPTH: {
+      const double th = v(0), phi = v(1), rho = v(2);
+      out[0] = (1 / rho) * std::cos(th) * std::sin(phi);
+      out[1] = (1 / rho) * std::sin(th) * std::sin(phi);
+      out[2] = (1 / rho) * std::cos(phi);
+      return;
+    }
+    case LR::ANCHORED_MSCKF_INVERSE_DEPTH:
+      out[0] = (1 / v(2)) * v(0);
+      out[1] = (1 / v(2)) * v(1);
+      out[2] = (1 / v(2));
+      return;
+    case LR::ANCHORED_INVERSE_DEPTH_SINGLE: {
+      const double *b = getfej ? uv_norm_zero_fej : uv_norm_zero;
+      for (int k = 0; k < 3; ++k) out[k] = (1.0 / v(0)) * b[k];
+      return;
+    }
+    default:
+      assert(false);
+    }
   }
   void set_from_xyz(const double p[3], bool isfej) {
-    VectorXd v(3, 1);
-    for (int k = 0; k < 3; ++k) v(k) = p[k];
+    typedef LandmarkRepresentation LR;
+    VectorXd v(size(), 1);
+    switch (_feat_representation) {
+    case LR::GLOBAL_3D:
+    case LR::ANCHORED_3D:
+      for (int k = 0; k < 3; ++k) v(k) = p[k];
+      break;
+    case LR::GLOBAL_FULL_INVERSE_DEPTH:
+    case LR::ANCHORED_FULL_INVERSE_DEPTH: {
+      const double rho = 1 / std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+      v(0) = std::atan2(p[1], p[0]);
+      v(1) = std::acos(rho * p[2]);
+      v(2) = rho;
+      break;
+    }
+    case LR::ANCHORED_MSCKF_INVERSE_DEPTH:
+      v(0) = p[0] / p[2];
+      v(1) = p[1] / p[2];
+      v(2) = 1 / p[2];
+      break;
+    case LR::ANCHORED_INVERSE_DEPTH_SINGLE: {
+      v(0) = 1.0 / p[2];
+      double *b = isfej ? uv_norm_zero_fej : uv_norm_zero;
+      for (int k = 0; k < 3; ++k) b[k] = (1.0 / p[2]) * p[k];
+      break;
+    }
+    default:
+      assert(false);
+    }
     if (isfej) set_fej(v);
     else set_value(v);
   }
@@ -384,6 +446,11 @@ struct Feature {
   std::vector<float> uvs_norm;     // [2*k] undistorted normalised coordinates (filled by the tracker); empty = p_FinG is given
   std::vector<double> timestamps;  // [k] clone timestamps of camera 0
   double p_FinG[3] = {0, 0, 0};
+  // anchor of the triangulated position (ext FeatureInitializer::single_triangulation: the last pose of the camera that saw
+  // the feature most); -1 = triangulation has not filled it, p_FinA is then derived from p_FinG where it is needed
+  int anchor_cam_id = -1;
+  double anchor_clone_timestamp = -1;
+  double p_FinA[3] = {0, 0, 0};
 };
 // ext ov_core::FeatureInitializerOptions (feat/FeatureInitializerOptions.h), defaults of open_vins
 struct FeatureInitializerOptions {

@@ -97,7 +97,8 @@ def run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, new_value0):
     return out
 
 
-def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=None, slam=None):
+def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=None, slam=None, slam_rep=None,
+                feat_rep_slam=None):
     """Drives the C++ host mirrors on a synth scene.
     fit_planes=dict(min_feat, max_cond, variant) (mode "plane_init" only): the features carry normalised measurements and
     no position, no plane estimates are handed over - init_vio_plane triangulates, fits and refines itself.
@@ -108,6 +109,10 @@ def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=
     """
     L = lib()
     L.ovph_set_fisheye(1 if sc.get("fisheye", False) else 0)
+    if slam_rep is not None:  # mode "slam_update": (representation, anchor clone slot) of every landmark; out["slam_p"] are its parameters
+        L.ovph_set_slam_rep(int(slam_rep[0]), int(slam_rep[1]))
+    if feat_rep_slam is not None:  # mode "slam_delayed_init": StateOptions::feat_rep_slam; out["new_p"] are landmark parameters
+        L.ovph_set_feat_rep_slam(int(feat_rep_slam))
     # "msckf_fit": UpdaterMSCKF::update on a state with SLAM landmarks (slam = dict(p [k,3], p_fej [k,3], plane [k]); the
     # scene must have n_slam = k landmark columns) and the scene's in-state planes; needs fit_planes
     m = {"slam_update": 0, "slam_delayed_init": 1, "plane_init": 2, "msckf_fit": 3}[mode]
@@ -338,3 +343,27 @@ def feature_jacobian_rep(sc, f, rep, anchor_ci):
     r, c, h, n = rows.value, cols.value, hfc.value, no.value
     return (H_f[: r * h].reshape(h, r).T.copy(), H_x[: r * c].reshape(c, r).T.copy(), res[:r].copy(),
             [(int(oid[i]), int(osz[i])) for i in range(n)])
+
+
+def run_change_anchors(sc, rep, p_FinA, p_FinA_fej):
+    """Drives ov_plane::UpdaterSLAM::change_anchors (C++ host mirror) on a make_scene(n_slam >= 1) state whose first landmark
+    is held in the anchored representation rep and anchored in the oldest clone.  Returns dict(value, fej, anchor_ci, P)."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N = int(sc.N)
+    P = np.asfortranarray(sc.P)
+    cq, cp_, cqf, cpf_ = f64(sc.clone_q), f64(sc.clone_p), f64(sc.clone_q_fej), f64(sc.clone_p_fej)
+    calq, calp, intr, slam = f64(sc.calib_q), f64(sc.calib_p), f64(sc.intr), f64(sc.slam_p)
+    pa, pf = f64(p_FinA), f64(p_FinA_fej)
+    out = dict(value=np.zeros(3), fej=np.zeros(3), P=np.zeros((N, N)))
+    anchor = C.c_int(-1)
+    L.ovph_run_change_anchors.restype = C.c_int
+    rc = L.ovph_run_change_anchors(C.c_int(sc.C), p(cq), p(cp_), p(cqf), p(cpf_), p(calq), p(calp), p(intr), C.c_int(len(slam)),
+                                   p(slam), C.c_int(N), p(P), C.c_int(rep), p(pa), p(pf), C.c_int(int(sc.opts["do_fej"])),
+                                   p(out["value"]), p(out["fej"]), C.byref(anchor), p(out["P"]))
+    if rc != 0:
+        raise RuntimeError("ovph_run_change_anchors failed with %d" % rc)
+    out["anchor_ci"] = anchor.value
+    out["P"] = np.ascontiguousarray(out["P"].T)
+    return out

@@ -1332,3 +1332,100 @@ def test_host_cpp_mirror_landmark_representations(hiplib, oracle, do_fej):
             assert np.abs(r - rr).max() < 1e-9
             assert np.abs(H_f - R_f).max() < 1e-9 * max(1.0, np.abs(R_f).max()), (f, rep)
             assert np.abs(H_x - R_x).max() < 1e-9 * max(1.0, np.abs(R_x).max()), (f, rep)
+
+
+@pytest.mark.parametrize("rep,do_fej", [(2, True), (3, True), (4, True), (4, False)])
+def test_host_cpp_mirror_change_anchors(hiplib, oracle, rep, do_fej):
+    """UpdaterSLAM::change_anchors / perform_anchor_change (update/UpdaterSLAM.cpp:684-850) on the device-resident covariance
+    against the restatement (which is pinned by the invariance of the landmark's global error covariance)."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import quat_2_rot
+
+    sc = make_scene(C=6, F=4, seed=5, n_slam=2, do_fej=do_fej)
+    lm_id = int(sc.ids["slam"][0])
+    R_ItoC, p_IinC = quat_2_rot(sc.calib_q), sc.calib_p
+    p_G = sc.p_FinG[0]
+    p_A = R_ItoC @ quat_2_rot(sc.clone_q[0]) @ (p_G - sc.clone_p[0]) + p_IinC
+    p_A_fej = p_A + np.array([2e-3, -1e-3, 3e-3]) * do_fej
+    ref = oracle.anchor_change(sc, rep, 0, sc.C - 1, lm_id, p_A, p_A_fej)
+    out = hostlib.run_change_anchors(sc, rep, p_A, p_A_fej)
+    assert out["anchor_ci"] == sc.C - 1
+
+    def params(p):  # representation parameters of an anchor-frame position (ext Landmark::set_from_xyz)
+        if rep == 2:
+            return p
+        if rep == 3:
+            rho = 1 / np.linalg.norm(p)
+            return np.array([np.arctan2(p[1], p[0]), np.arccos(rho * p[2]), rho])
+        return np.array([p[0] / p[2], p[1] / p[2], 1 / p[2]])
+
+    assert np.abs(out["value"] - params(ref["p_FinA"])).max() < 1e-10
+    assert np.abs(out["fej"] - params(ref["p_FinA_fej"])).max() < 1e-10
+    assert relP(out["P"], ref["P"]) < TOL_P
+    assert np.abs(out["P"] - ref["P"]).max() < 1e-9 * np.abs(ref["P"]).max()
+
+
+@pytest.mark.parametrize("rep", [1, 2, 3, 4])
+def test_host_cpp_mirror_updater_slam_update_with_landmark_representations(hiplib, oracle, rep):
+    """UpdaterSLAM::update with the landmarks held in an inverse-depth / anchored representation: dense Jacobians with the
+    representation and anchor terms on the host (update/UpdaterHelper.cpp:35-193, :411-421), EKF update on the device; the
+    correction of a landmark is one of its representation parameters."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import make_slam_scene, quat_2_rot
+
+    sc = make_slam_scene(C=8, n_slam=8, seed=6, outliers=1)
+    anchor = 2
+    ref = oracle.slam_update(sc, sc.lm_id, rep=np.full(sc.F, rep), anchor=np.full(sc.F, anchor))
+    assert ref["rc"] == 0 and ref["accepted"].sum() >= 6 and not ref["accepted"].all()
+    out = hostlib.run_updater(sc, "slam_update", slam_rep=(rep, anchor))
+    assert (out["kept"] == ref["accepted"]).all()
+    dx = ref["dx"]
+    R_ItoC, p_IinC = quat_2_rot(sc.calib_q), sc.calib_p
+
+    def params(p_G):
+        p = p_G if rep == 1 else R_ItoC @ quat_2_rot(sc.clone_q[anchor]) @ (p_G - sc.clone_p[anchor]) + p_IinC
+        if rep in (1, 3):
+            rho = 1 / np.linalg.norm(p)
+            return np.array([np.arctan2(p[1], p[0]), np.arccos(rho * p[2]), rho])
+        if rep == 2:
+            return p
+        return np.array([p[0] / p[2], p[1] / p[2], 1 / p[2]])
+
+    for k in range(sc.F):
+        i = int(sc.lm_id[k])
+        assert np.abs(out["slam_p"][k] - (params(sc.slam_p[k]) + dx[i:i + 3])).max() < TOL_DX, k
+    cq, cp, intr = _apply_dx_to_scene(sc, dx)
+    assert np.abs(out["clone_p"] - cp).max() < TOL_DX and np.abs(out["clone_q"] - cq).max() < TOL_DX
+    assert np.abs(out["intr"] - intr).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+
+
+@pytest.mark.parametrize("rep", [1, 2, 3, 4, 5])
+def test_host_cpp_mirror_updater_slam_delayed_init_with_feat_rep_slam(hiplib, oracle, rep):
+    """UpdaterSLAM::delayed_init with StateOptions::feat_rep_slam != GLOBAL_3D (update/UpdaterSLAM.cpp:230-296): the landmark
+    joins the state in its representation, anchored in the camera of its last measurement; the single inverse depth drops
+    its bearing columns by a nullspace projection and adds ONE column to the state."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_scene(C=8, F=6, seed=6, ragged=True, chi2_mult=0.6)
+    ref = oracle.slam_delayed_init(sc, rep=rep)
+    out = hostlib.run_updater(sc, "slam_delayed_init", feat_rep_slam=rep)
+    k = 1 if rep == 5 else 3
+    ok = ref["ok"]
+    assert ok.any() and not ok.all()
+    assert out["n"] == ref["n"] == sc.N + k * ok.sum()
+    assert (out["new_id"][:sc.F] == ref["new_id"]).all()
+    assert np.abs(out["new_p"][:sc.F][ok][:, :k] - ref["p"][ok][:, :k]).max() < TOL_DX
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and np.abs(out["clone_q"] - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(out["intr"] - ref["intr"]).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+    assert (out["kept"] == ok).all() and out["deleted"].all()
