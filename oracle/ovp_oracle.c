@@ -710,6 +710,12 @@ void ovo_marginal_cov(const double *P, int n, const int *order_id, const int *or
 /* state/StateHelper.cpp:121-202 (R = I) */
 int ovo_ekf_update(double *P, int n, const int *order_id, const int *order_size, int n_order, const double *H,
                    int rows, int ld, const double *res, double *dx, int *neg_diag) {
+  return ovo_ekf_update_rdiag(P, n, order_id, order_size, n_order, H, rows, ld, res, NULL, dx, neg_diag);
+}
+
+/* the same with R = diag(r_diag) instead of I (UpdaterZeroVelocity.cpp:265 hands a non-isotropic diagonal R) */
+int ovo_ekf_update_rdiag(double *P, int n, const int *order_id, const int *order_size, int n_order, const double *H,
+                         int rows, int ld, const double *res, const double *r_diag, double *dx, int *neg_diag) {
   int cols = 0;
   for (int i = 0; i < n_order; ++i) cols += order_size[i];
   int *gcol = (int *)malloc(sizeof(int) * (size_t)cols);
@@ -735,7 +741,7 @@ int ovo_ekf_update(double *P, int n, const int *order_id, const int *order_size,
       const double mkj = CM(M, n, gcol[k], j);
       for (int i = 0; i <= j; ++i) CM(S, rows, i, j) += CM(H, ld, i, k) * mkj;
     }
-  for (int i = 0; i < rows; ++i) CM(S, rows, i, i) += 1.0;
+  for (int i = 0; i < rows; ++i) CM(S, rows, i, i) += r_diag ? r_diag[i] : 1.0;
   for (int j = 0; j < rows; ++j)
     for (int i = j + 1; i < rows; ++i) CM(S, rows, i, j) = CM(S, rows, j, i);
   /* Sinv via LLT :165-166 */
@@ -1767,6 +1773,107 @@ int ovo_slam_delayed_init(const ovo_opts *o, const ovo_state *st_in, const ovo_f
   free(osz);
   free(dx);
   return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * update/UpdaterZeroVelocity.cpp:68-318 with the constants the reference hard-codes (:113-116): the raw IMU readings of
+ * [time0, time1] as measurements of "angular velocity = 0, specific force = R g" (:141-176), discrete noise sigma^2/dt
+ * times zupt_noise_multiplier (:168-180), bias random walk dt * sigma (sic, :184-186) added to the 9 x 9 marginal for the chi2
+ * (:191-194) and, when accepted, to P through EKFPropagation with Phi = I (:256-262), then EKFUpdate (:265).
+ * imu_id = Type::id() of the IMU (error order th p v bg ba).  disparity_passed: outcome of :207-227 (the feature tracks are
+ * not this function's input).  Returns 1 accepted / 0 rejected / <0 error; dx [n] = correction of the whole state.
+ * ------------------------------------------------------------------------------------------- */
+int ovo_zupt_update(const ovo_imu_state *x, const ovo_prop_opts *po, int imu_id, const double *imu, int n_imu, double time0,
+                    double time1, double noise_multiplier, double chi2_multiplier, double max_velocity, int disparity_passed,
+                    double *P, int n, double *dx, double *chi2_out, int *rows_out) {
+  const int cap = n_imu + 4;
+  double *sel = (double *)malloc(sizeof(double) * 7 * (size_t)cap);
+  const int ns = ovo_select_imu_readings(imu, n_imu, time0, time1, sel, cap);
+  *chi2_out = 0.0;
+  *rows_out = 0;
+  if (ns < 2) { /* :107-111 */
+    free(sel);
+    return 0;
+  }
+  const int ni = ns - 1, m = 6 * ni;
+  double *H = (double *)calloc((size_t)m * 9, sizeof(double));
+  double *res = (double *)calloc((size_t)m, sizeof(double));
+  double *Rd = (double *)calloc((size_t)m, sizeof(double));
+  double Rv[9], Rj[9], Rg[3], Rjg[3], S3[9];
+  const double g[3] = {0.0, 0.0, po->gravity_mag};
+  ovo_quat_2_rot(x->q, Rv);
+  ovo_quat_2_rot(po->do_fej ? x->q_fej : x->q, Rj);
+  mat3_vec(Rv, g, Rg);
+  mat3_vec(Rj, g, Rjg);
+  skew3(Rjg, S3);
+  double dt_sum = 0.0;
+  for (int i = 0; i < ni; ++i) {
+    const double *r0 = sel + 7 * i, *r1 = sel + 7 * (i + 1);
+    const double dt = r1[0] - r0[0];
+    for (int k = 0; k < 3; ++k) {
+      res[6 * i + k] = -(r0[1 + k] - x->bg[k]);
+      res[6 * i + 3 + k] = -((r0[4 + k] - x->ba[k]) - Rg[k]);
+      CM(H, m, 6 * i + k, 3 + k) = -1.0;
+      for (int j = 0; j < 3; ++j) CM(H, m, 6 * i + 3 + k, j) = -S3[3 * k + j];
+      CM(H, m, 6 * i + 3 + k, 6 + k) = -1.0;
+      Rd[6 * i + k] = noise_multiplier * (po->sigma_w * po->sigma_w / dt);
+      Rd[6 * i + 3 + k] = noise_multiplier * (po->sigma_a * po->sigma_a / dt);
+    }
+    dt_sum += dt;
+  }
+  double Qb[36];
+  memset(Qb, 0, sizeof(Qb));
+  for (int k = 0; k < 3; ++k) {
+    Qb[7 * k] = dt_sum * po->sigma_wb;
+    Qb[7 * (3 + k)] = dt_sum * po->sigma_ab;
+  }
+  const int oid[3] = {imu_id, imu_id + 9, imu_id + 12}, osz[3] = {3, 3, 3};
+  double Pm[81];
+  ovo_marginal_cov(P, n, oid, osz, 3, Pm);
+  for (int a = 0; a < 6; ++a) CM(Pm, 9, 3 + a, 3 + a) += Qb[7 * a];
+  /* S = H Pm H^T + R, chi2 = res^T S^-1 res */
+  double *HP = (double *)calloc((size_t)m * 9, sizeof(double));
+  double *S = (double *)calloc((size_t)m * (size_t)m, sizeof(double));
+  for (int b = 0; b < 9; ++b)
+    for (int a = 0; a < 9; ++a)
+      for (int i = 0; i < m; ++i) CM(HP, m, i, b) += CM(H, m, i, a) * CM(Pm, 9, a, b);
+  for (int j = 0; j < m; ++j)
+    for (int a = 0; a < 9; ++a)
+      for (int i = 0; i < m; ++i) CM(S, m, i, j) += CM(HP, m, i, a) * CM(H, m, j, a);
+  for (int i = 0; i < m; ++i) CM(S, m, i, i) += Rd[i];
+  int rc = 0;
+  if (ovo_llt(S, m, m)) {
+    rc = -1;
+  } else {
+    double *y = (double *)malloc(sizeof(double) * (size_t)m);
+    memcpy(y, res, sizeof(double) * (size_t)m);
+    llt_solve_vec(S, m, m, y);
+    double c2 = 0.0;
+    for (int i = 0; i < m; ++i) c2 += res[i] * y[i];
+    free(y);
+    *chi2_out = c2;
+    *rows_out = m;
+    const double vn = sqrt(x->v[0] * x->v[0] + x->v[1] * x->v[1] + x->v[2] * x->v[2]);
+    if (!disparity_passed && (c2 > chi2_multiplier * ovo_chi2_quantile_095(m) || vn > max_velocity)) { /* :231-236 */
+      rc = 0;
+    } else {
+      double Phi[36];
+      memset(Phi, 0, sizeof(Phi));
+      for (int k = 0; k < 6; ++k) Phi[7 * k] = 1.0;
+      const int bid[2] = {imu_id + 9, imu_id + 12}, bsz[2] = {3, 3};
+      int neg = 0;
+      if (ovo_ekf_propagation(P, n, imu_id + 9, 6, bid, bsz, 2, Phi, Qb, &neg) || neg) rc = -2;
+      else if (ovo_ekf_update_rdiag(P, n, oid, osz, 3, H, m, m, res, Rd, dx, &neg) || neg) rc = -3;
+      else rc = 1;
+    }
+  }
+  free(sel);
+  free(H);
+  free(res);
+  free(Rd);
+  free(HP);
+  free(S);
+  return rc;
 }
 
 /* ext Landmark::set_from_xyz (types/Landmark.cpp of ov_core, restated): representation parameters of a point given in the

@@ -117,6 +117,9 @@ void ovo_marginal_cov(const double *P, int n, const int *order_id, const int *or
 int ovo_ekf_update(double *P, int n, const int *order_id, const int *order_size, int n_order, const double *H,
                    int rows, int ld, const double *res, double *dx, int *neg_diag);
 
+int ovo_ekf_update_rdiag(double *P, int n, const int *order_id, const int *order_size, int n_order, const double *H,
+                         int rows, int ld, const double *res, const double *r_diag /* NULL = I */, double *dx, int *neg_diag);
+
 /* state/StateHelper.cpp:41-119 */
 int ovo_ekf_propagation(double *P, int n, int new_start, int phi_size, const int *old_id, const int *old_size,
                         int n_old, const double *Phi, const double *Q, int *neg_diag);
@@ -222,6 +225,11 @@ void ovo_predict_and_compute(ovo_imu_state *x, const ovo_prop_opts *po, const do
 /* Propagator.cpp:37-118: Phi_summed / Qd_summed over the selected readings, propagated mean, last_w (:110-114). */
 int ovo_propagate_summed(ovo_imu_state *x, const ovo_prop_opts *po, const double *imu, int n_imu, double time0, double time1,
                          double *Phi, double *Qs, double *last_w, int *n_sel);
+
+/* update/UpdaterZeroVelocity.cpp:68-318, see ovp_oracle.c */
+int ovo_zupt_update(const ovo_imu_state *x, const ovo_prop_opts *po, int imu_id, const double *imu, int n_imu, double time0,
+                    double time1, double noise_multiplier, double chi2_multiplier, double max_velocity, int disparity_passed,
+                    double *P, int n, double *dx, double *chi2_out, int *rows_out);
 
 /* ---- ext ov_core::FeatureInitializer (source not in the reference tree - restated from memory) ------- */
 typedef struct {

@@ -453,6 +453,26 @@ def propagate_summed(x, po, imu, time0, time1):
     return dict(rc=rc, x=xo, Phi=np.ascontiguousarray(Phi), Q=np.ascontiguousarray(Q), last_w=lw, n_sel=n.value)
 
 
+def zupt_update(x, po, P, imu, time0, time1, imu_id=0, noise_mult=10.0, chi2_mult=1.0, max_velocity=0.5,
+                disparity_passed=False):
+    """ovo_zupt_update (update/UpdaterZeroVelocity.cpp:68-318): returns accepted, chi2, rows, dx [n] and the updated P."""
+    L = lib()
+    s = _imu_struct(x)
+    o = _prop_opts(po)
+    imu = np.ascontiguousarray(imu, dtype=np.float64)
+    n = P.shape[0]
+    Pc = np.array(P, order="F", dtype=np.float64)
+    dx = np.zeros(n)
+    chi2 = C.c_double(0)
+    rows = C.c_int(0)
+    L.ovo_zupt_update.restype = C.c_int
+    rc = L.ovo_zupt_update(C.byref(s), C.byref(o), C.c_int(imu_id), _dp(imu), C.c_int(imu.shape[0]), C.c_double(time0),
+                           C.c_double(time1), C.c_double(noise_mult), C.c_double(chi2_mult), C.c_double(max_velocity),
+                           C.c_int(int(disparity_passed)), _dp(Pc), C.c_int(n), _dp(dx), C.byref(chi2), C.byref(rows))
+    assert rc >= 0, rc
+    return dict(accepted=rc == 1, chi2=chi2.value, rows=rows.value, dx=dx, P=np.ascontiguousarray(Pc))
+
+
 # ---- ext FeatureInitializer (SURVEY 8f rank 1) ---------------------------------------------------------------------------
 class OvoTriangOpts(C.Structure):
     _fields_ = [("refine_features", C.c_int), ("max_runs", C.c_int), ("init_lamda", C.c_double), ("max_lamda", C.c_double),

@@ -614,6 +614,92 @@ extern "C" int ovph_run_propagate(int C, const double *clone_q, const double *cl
   return 0;
 }
 
+// UpdaterZeroVelocity::try_update harness: the state of ovph_run_propagate, n_calls (1 or 2) consecutive camera times
+// timestamps[k]; the feature database holds n_tracks tracks seen at t_state (uv0), timestamps[0] (uv1) and, with two calls,
+// timestamps[1] (uv1 again).  Outputs per call: accepted, chi2; final IMU value, calib_dt, covariance, state timestamp, and
+// how many measurements the database still holds at timestamps[0] (cleanup_measurements_exact on the second acceptance).
+extern "C" int ovph_run_zupt(int C, const double *clone_q, const double *clone_p, const double *imu_x16, const double *imu_x16_fej,
+                             double calib_dt, int N, const double *P, int n_imu, const double *imu, double t_state, int n_calls,
+                             const double *timestamps, const double *sigmas4, double gravity_mag, int do_fej, double noise_mult,
+                             double chi2_mult, double max_velocity, double max_disparity, int n_tracks, const float *uv0,
+                             const float *uv1,
+                             /* outputs */ int *out_accepted, double *out_chi2, double *out_x16, double *out_calib_dt, double *out_P,
+                             double *out_timestamp, int *out_meas_at_t1) {
+  StateOptions so;
+  so.do_fej = do_fej != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C + 1;
+  so.max_state_size = N + 16;
+  so.max_features = 16;
+  auto state = std::make_shared<State>(so);
+  const double w0[3] = {0, 0, 0};
+  for (int i = 0; i < C; ++i) {
+    VectorXd v(7, 1);
+    for (int q = 0; q < 4; ++q) v(q) = clone_q[4 * i + q];
+    for (int q = 0; q < 3; ++q) v(4 + q) = clone_p[3 * i + q];
+    state->_imu->pose()->set_value(v);
+    state->_imu->pose()->set_fej(v);
+    state->_timestamp = t_state - 0.1 * (C - i);
+    StateHelper::augment_clone(state, w0);
+  }
+  if (state->max_covariance_size() != N) return -11;
+  VectorXd x(16, 1), xf(16, 1), dtv(1, 1);
+  for (int k = 0; k < 16; ++k) {
+    x(k) = imu_x16[k];
+    xf(k) = imu_x16_fej[k];
+  }
+  state->_imu->set_value(x);
+  state->_imu->set_fej(xf);
+  dtv(0) = calib_dt;
+  state->_calib_dt_CAMtoIMU->set_value(dtv);
+  state->_calib_dt_CAMtoIMU->set_fej(dtv);
+  state->_timestamp = t_state;
+  std::vector<std::shared_ptr<Type>> all;
+  all.push_back(state->_imu);
+  all.push_back(state->_calib_dt_CAMtoIMU);
+  all.push_back(state->_calib_IMUtoCAM.at(0));
+  all.push_back(state->_cam_intrinsics.at(0));
+  for (auto &c : state->_clones_IMU) all.push_back(c.second);
+  MatrixXd Pm(N, N);
+  memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+  StateHelper::set_initial_covariance(state, Pm, all);
+  NoiseManager nm;
+  nm.sigma_w = sigmas4[0];
+  nm.sigma_a = sigmas4[1];
+  nm.sigma_wb = sigmas4[2];
+  nm.sigma_ab = sigmas4[3];
+  auto prop = std::make_shared<Propagator>(nm, gravity_mag);
+  auto db = std::make_shared<ov_core::FeatureDatabase>();
+  for (int f = 0; f < n_tracks; ++f) {
+    db->update_feature(100 + f, t_state, 0, uv0[2 * f], uv0[2 * f + 1], 0.f, 0.f);
+    for (int k = 0; k < n_calls; ++k) db->update_feature(100 + f, timestamps[k], 0, uv1[2 * f], uv1[2 * f + 1], 0.f, 0.f);
+  }
+  UpdaterOptions uo;
+  uo.chi2_multipler = chi2_mult;
+  UpdaterZeroVelocity zupt(uo, nm, db, prop, gravity_mag, max_velocity, noise_mult, max_disparity);
+  for (int i = 0; i < n_imu; ++i) {
+    ov_core::ImuData d;
+    d.timestamp = imu[7 * i];
+    for (int k = 0; k < 3; ++k) {
+      d.wm[k] = imu[7 * i + 1 + k];
+      d.am[k] = imu[7 * i + 4 + k];
+    }
+    zupt.feed_imu(d);
+  }
+  for (int k = 0; k < n_calls; ++k) {
+    out_accepted[k] = zupt.try_update(state, timestamps[k]) ? 1 : 0;
+    out_chi2[k] = zupt.last_chi2();
+  }
+  memcpy(out_x16, state->_imu->value().data(), 16 * sizeof(double));
+  *out_calib_dt = state->_calib_dt_CAMtoIMU->value()(0);
+  if (state->max_covariance_size() != N) return -12;
+  MatrixXd Pn = StateHelper::get_full_covariance(state);
+  memcpy(out_P, Pn.data(), sizeof(double) * (size_t)N * N);
+  *out_timestamp = state->_timestamp;
+  *out_meas_at_t1 = (int)db->features_containing(timestamps[0]).size();
+  return 0;
+}
+
 // StateHelper::marginalize_slam + merge_planes_and_marginalize harness.  State: clones, n_slam landmarks (should_marg flags),
 // n_planes in-state planes (ids 1..n).  merge_pairs [n_pairs x 2] = (old id, new id); active_planes = ids observed by features.
 // Outputs: final P / n, for every plane id 1..n+8 its Type::id() (or -1) and value, landmark ids (or -1).

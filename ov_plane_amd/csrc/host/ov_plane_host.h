@@ -303,4 +303,30 @@ protected:
   double _Phi[225], _Qs[225], _last_w[3];
 };
 
+// update/UpdaterZeroVelocity.h:59-147.  Detection (chi2 of the raw IMU readings against "standing still", disparity override)
+// on the host from the 9x9 marginal of the device covariance; the bias random walk goes through StateHelper::EKFPropagation
+// and the 6(n-1)-row update through StateHelper::EKFUpdate, both on the device.
+class UpdaterZeroVelocity {
+public:
+  UpdaterZeroVelocity(UpdaterOptions &options, NoiseManager &noises, std::shared_ptr<ov_core::FeatureDatabase> db,
+                      std::shared_ptr<Propagator> prop, double gravity_mag, double zupt_max_velocity, double zupt_noise_multiplier,
+                      double zupt_max_disparity);
+  void feed_imu(const ov_core::ImuData &message, double oldest_time = -1);  // UpdaterZeroVelocity.h:83-103
+  bool try_update(std::shared_ptr<State> state, double timestamp);         // UpdaterZeroVelocity.cpp:68-318
+  double last_chi2() const { return _last_chi2; }                          // diagnostics and tests
+
+protected:
+  UpdaterOptions _options;
+  NoiseManager _noises;
+  std::shared_ptr<ov_core::FeatureDatabase> _db;
+  std::shared_ptr<Propagator> _prop;
+  double _gravity[3];
+  double _zupt_max_velocity = 1.0, _zupt_noise_multiplier = 1.0, _zupt_max_disparity = 1.0;
+  std::vector<ov_core::ImuData> imu_data;
+  double last_prop_time_offset = 0.0;
+  bool have_last_prop_time_offset = false;
+  double last_zupt_state_timestamp = 0.0;
+  double _last_chi2 = 0.0;
+};
+
 }  // namespace ov_plane

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstddef>
 #include <memory>
+#include <unordered_map>
 #include <vector>
 
 namespace ov_plane {
@@ -451,6 +452,111 @@ struct Feature {
   int anchor_cam_id = -1;
   double anchor_clone_timestamp = -1;
   double p_FinA[3] = {0, 0, 0};
+};
+// ext ov_core::FeatureDatabase (feat/FeatureDatabase.h), the part the update classes use: id -> track, single camera
+class FeatureDatabase {
+public:
+  std::shared_ptr<Feature> get_feature(size_t id, bool remove = false) {
+    auto it = features_idlookup.find(id);
+    if (it == features_idlookup.end()) return nullptr;
+    auto f = it->second;
+    if (remove) features_idlookup.erase(it);
+    return f;
+  }
+  void update_feature(size_t id, double timestamp, size_t /*cam_id*/, float u, float v, float u_n, float v_n) {
+    auto &f = features_idlookup[id];
+    if (!f) {
+      f = std::make_shared<Feature>();
+      f->featid = id;
+    }
+    f->uvs.push_back(u);
+    f->uvs.push_back(v);
+    f->uvs_norm.push_back(u_n);
+    f->uvs_norm.push_back(v_n);
+    f->timestamps.push_back(timestamp);
+  }
+  // every track with a measurement at exactly this time
+  std::vector<std::shared_ptr<Feature>> features_containing(double timestamp, bool remove = false, bool skip_deleted = false) {
+    std::vector<std::shared_ptr<Feature>> out;
+    for (auto it = features_idlookup.begin(); it != features_idlookup.end();) {
+      auto &f = it->second;
+      if (skip_deleted && f->to_delete) {
+        ++it;
+        continue;
+      }
+      bool has = false;
+      for (double t : f->timestamps)
+        if (t == timestamp) {
+          has = true;
+          break;
+        }
+      if (has) {
+        out.push_back(f);
+        if (remove) {
+          it = features_idlookup.erase(it);
+          continue;
+        }
+      }
+      ++it;
+    }
+    return out;
+  }
+  // drops the measurements taken at exactly this time; tracks left empty are flagged
+  void cleanup_measurements_exact(double timestamp) {
+    for (auto it = features_idlookup.begin(); it != features_idlookup.end();) {
+      auto &f = it->second;
+      for (size_t k = 0; k < f->timestamps.size();) {
+        if (f->timestamps[k] == timestamp) {
+          f->timestamps.erase(f->timestamps.begin() + k);
+          f->uvs.erase(f->uvs.begin() + 2 * k, f->uvs.begin() + 2 * k + 2);
+          if (f->uvs_norm.size() >= 2 * (k + 1)) f->uvs_norm.erase(f->uvs_norm.begin() + 2 * k, f->uvs_norm.begin() + 2 * k + 2);
+        } else {
+          ++k;
+        }
+      }
+      if (f->timestamps.empty()) {
+        f->to_delete = true;
+        it = features_idlookup.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  std::unordered_map<size_t, std::shared_ptr<Feature>> &get_internal_data() { return features_idlookup; }
+  size_t size() const { return features_idlookup.size(); }
+
+protected:
+  std::unordered_map<size_t, std::shared_ptr<Feature>> features_idlookup;
+};
+// ext ov_core::FeatureHelper::compute_disparity (feat/FeatureHelper.h): pixel displacement of the tracks seen at both times
+struct FeatureHelper {
+  static void compute_disparity(std::shared_ptr<FeatureDatabase> db, double time0, double time1, double &disp_mean, double &disp_var,
+                                int &total_feats) {
+    std::vector<double> disparities;
+    for (auto &feat : db->features_containing(time0, false, true)) {
+      int i0 = -1, i1 = -1;
+      for (size_t k = 0; k < feat->timestamps.size(); ++k) {
+        if (i0 < 0 && feat->timestamps[k] == time0) i0 = (int)k;
+        if (i1 < 0 && feat->timestamps[k] == time1) i1 = (int)k;
+      }
+      if (i0 < 0 || i1 < 0) continue;
+      const float du = feat->uvs[2 * i1] - feat->uvs[2 * i0], dv = feat->uvs[2 * i1 + 1] - feat->uvs[2 * i0 + 1];
+      disparities.push_back((double)std::sqrt(du * du + dv * dv));  // Vector2f::norm()
+    }
+    if (disparities.size() < 2) {
+      disp_mean = -1;
+      disp_var = -1;
+      total_feats = 0;
+      return;
+    }
+    disp_mean = 0;
+    for (double d : disparities) disp_mean += d;
+    disp_mean /= (double)disparities.size();
+    disp_var = 0;
+    for (double d : disparities) disp_var += (d - disp_mean) * (d - disp_mean);
+    disp_var = std::sqrt(disp_var / (double)(disparities.size() - 1));
+    total_feats = (int)disparities.size();
+  }
 };
 // ext ov_core::FeatureInitializerOptions (feat/FeatureInitializerOptions.h), defaults of open_vins
 struct FeatureInitializerOptions {

@@ -211,6 +211,41 @@ def run_propagate(sc, x, imu, t_state, timestamp, calib_dt, po):
     return out
 
 
+def run_zupt(sc, x, imu, t_state, timestamps, calib_dt, po, noise_mult=10.0, chi2_mult=1.0, max_velocity=0.5, max_disparity=1.0,
+             uv0=None, uv1=None):
+    """Drives ov_plane::UpdaterZeroVelocity::try_update (C++ host mirror; covariance on the device) at the camera times
+    `timestamps` (1 or 2) on the clone window / covariance of a synth scene with IMU state x and readings imu [n,7]; uv0 / uv1
+    [n,2]: pixel positions of the tracks the feature database holds at t_state and at the new camera times."""
+    L = lib()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N = int(sc.N)
+    x16 = f64(np.concatenate([x["q"], x["p"], x["v"], x["bg"], x["ba"]]))
+    x16f = f64(np.concatenate([x["q_fej"], x["p_fej"], x["v_fej"], x["bg_fej"], x["ba_fej"]]))
+    P = np.asfortranarray(sc.P)
+    imu = f64(imu)
+    ts = f64(timestamps)
+    sig = f64([po["sigma_w"], po["sigma_a"], po["sigma_wb"], po["sigma_ab"]])
+    cq, cp_ = f64(sc.clone_q), f64(sc.clone_p)
+    uv0 = np.zeros((0, 2), np.float32) if uv0 is None else np.ascontiguousarray(uv0, dtype=np.float32)
+    uv1 = np.zeros((0, 2), np.float32) if uv1 is None else np.ascontiguousarray(uv1, dtype=np.float32)
+    acc = np.zeros(len(ts), dtype=np.int32)
+    chi2 = np.zeros(len(ts))
+    out = dict(x16=np.zeros(16), P=np.zeros((N, N)))
+    dt_out, t_out, n_meas = C.c_double(0), C.c_double(0), C.c_int(0)
+    L.ovph_run_zupt.restype = C.c_int
+    rc = L.ovph_run_zupt(C.c_int(sc.C), p(cq), p(cp_), p(x16), p(x16f), C.c_double(calib_dt), C.c_int(N), p(P),
+                         C.c_int(imu.shape[0]), p(imu), C.c_double(t_state), C.c_int(len(ts)), p(ts), p(sig),
+                         C.c_double(po["gravity_mag"]), C.c_int(int(po["do_fej"])), C.c_double(noise_mult), C.c_double(chi2_mult),
+                         C.c_double(max_velocity), C.c_double(max_disparity), C.c_int(uv0.shape[0]), p(uv0), p(uv1), p(acc),
+                         p(chi2), p(out["x16"]), C.byref(dt_out), p(out["P"]), C.byref(t_out), C.byref(n_meas))
+    if rc != 0:
+        raise RuntimeError("ovph_run_zupt failed with %d" % rc)
+    out["P"] = np.ascontiguousarray(out["P"].T)
+    out.update(accepted=acc.astype(bool), chi2=chi2, calib_dt=dt_out.value, timestamp=t_out.value, meas_at_t1=n_meas.value)
+    return out
+
+
 def run_state_maintenance(sc, should_marg, merge_pairs, active_planes, sigma_plane_merge=0.001, plane_merge_chi2=1.0,
                           plane_merge_deg_max=1.0):
     """StateHelper::marginalize_slam followed by merge_planes_and_marginalize on a make_slam_scene-like state

@@ -566,18 +566,22 @@ def _roty(a):
     return np.array([[c, 0, s], [0, 1.0, 0], [-s, 0, c]])
 
 
-def make_imu_scenario(seed=0, rate=400.0, t_state=100.0, dt_cam=0.1, t_off=0.004, fej_perturb=1e-3, low_rate=False):
+def make_imu_scenario(seed=0, rate=400.0, t_state=100.0, dt_cam=0.1, t_off=0.004, fej_perturb=1e-3, low_rate=False,
+                      stationary=False, n_cam=1):
     """IMU state + a stream of inertial readings around one camera interval (imitating Simulator's 400 Hz IMU / 10 Hz
     camera, config/sim/estimator_config.yaml:177-178).  Returns (x, imu, time0, time1):
       x    dict q p v bg ba (+ *_fej first estimates)
       imu  [n,7] rows (t, wm xyz, am xyz); readings neither start nor end on time0/time1, so both ends are interpolated
       time0 = t_state + t_off, time1 = t_state + dt_cam + t_off  (Propagator.cpp:67-68)
     `low_rate` produces a stream slower than the camera (exercises the CASE 3.1 branch of select_imu_readings).
+    `stationary`: the platform stands still (angular velocity = 0, specific force = R g, velocity estimate ~ 0): the input of
+    UpdaterZeroVelocity; `n_cam` camera intervals are covered by the stream.
     """
     rng = np.random.default_rng(4242 + seed)
     q = rot_2_quat(_rotz(0.3 * rng.standard_normal()) @ _roty(0.1 * rng.standard_normal()))
-    x = dict(q=q, p=rng.uniform(-2, 2, 3), v=np.array([0.8, 0.2, -0.05]) + 0.1 * rng.standard_normal(3),
-             bg=1e-3 * rng.standard_normal(3), ba=1e-2 * rng.standard_normal(3))
+    p = rng.uniform(-2, 2, 3)
+    v = 2e-3 * rng.standard_normal(3) if stationary else np.array([0.8, 0.2, -0.05]) + 0.1 * rng.standard_normal(3)
+    x = dict(q=q, p=p, v=v, bg=1e-3 * rng.standard_normal(3), ba=1e-2 * rng.standard_normal(3))
     x["q_fej"] = quat_boxplus(x["q"], fej_perturb * rng.standard_normal(3))
     x["p_fej"] = x["p"] + fej_perturb * rng.standard_normal(3)
     x["v_fej"] = x["v"] + fej_perturb * rng.standard_normal(3)
@@ -587,14 +591,15 @@ def make_imu_scenario(seed=0, rate=400.0, t_state=100.0, dt_cam=0.1, t_off=0.004
     if low_rate:
         ts = time0 - 0.013 + np.arange(0, 6) * 0.07
     else:
-        ts = time0 - 0.0113 + np.arange(0, int((dt_cam + 0.03) * rate)) / rate
+        ts = time0 - 0.0113 + np.arange(0, int((n_cam * dt_cam + 0.03) * rate)) / rate
     R = quat_2_rot(x["q"])
     ph = rng.uniform(0, 2 * np.pi, 6)
     imu = np.zeros((len(ts), 7))
     imu[:, 0] = ts
     for k in range(3):
-        imu[:, 1 + k] = 0.35 * np.sin(2 * np.pi * 0.7 * (ts - ts[0]) + ph[k]) + x["bg"][k]
-        imu[:, 4 + k] = 0.6 * np.sin(2 * np.pi * 1.1 * (ts - ts[0]) + ph[3 + k]) + x["ba"][k]
+        amp = 0.0 if stationary else 1.0
+        imu[:, 1 + k] = amp * 0.35 * np.sin(2 * np.pi * 0.7 * (ts - ts[0]) + ph[k]) + x["bg"][k]
+        imu[:, 4 + k] = amp * 0.6 * np.sin(2 * np.pi * 1.1 * (ts - ts[0]) + ph[3 + k]) + x["ba"][k]
     imu[:, 4:7] += R @ np.array([0, 0, 9.81])
     imu[:, 1:4] += 1.7e-4 * np.sqrt(rate) * rng.standard_normal((len(ts), 3))
     imu[:, 4:7] += 2.0e-3 * np.sqrt(rate) * rng.standard_normal((len(ts), 3))

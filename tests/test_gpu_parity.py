@@ -1429,3 +1429,60 @@ def test_host_cpp_mirror_updater_slam_delayed_init_with_feat_rep_slam(hiplib, or
     assert np.abs(out["intr"] - ref["intr"]).max() < TOL_DX
     assert relP(out["P"], ref["P"]) < TOL_P
     assert (out["kept"] == ok).all() and out["deleted"].all()
+
+
+@pytest.mark.parametrize("case", ["standing", "moving", "moving_low_disparity", "two_frames"])
+def test_host_cpp_mirror_updater_zero_velocity(hiplib, oracle, case):
+    """ov_plane::UpdaterZeroVelocity::try_update (update/UpdaterZeroVelocity.cpp:68-318): detection on the host from the
+    9 x 9 marginal of the device covariance, bias walk (StateHelper::EKFPropagation) and the stacked IMU rows
+    (StateHelper::EKFUpdate, non-isotropic diagonal R) on the device; state time moves on without a clone; on the second
+    consecutive acceptance the tracks lose the measurements of the previous zero-velocity time (:245-247)."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+    from ov_plane_amd.synth import PROP_OPTS, make_imu_scenario
+
+    sc = make_scene(C=6, F=4, seed=91)
+    po = dict(PROP_OPTS)
+    t_off, t_state = 0.004, 100.0
+    standing = case in ("standing", "two_frames")
+    n_cam = 2 if case == "two_frames" else 1
+    x, imu, t0, t1 = make_imu_scenario(5, t_state=t_state, t_off=t_off, stationary=standing, n_cam=n_cam)
+    stamps = [t_state + 0.1 * (k + 1) for k in range(n_cam)]
+    rng = np.random.default_rng(3)
+    uv0 = rng.uniform(50, 700, (30, 2)).astype(np.float32)
+    shift = 0.2 if case == "moving_low_disparity" else 6.0   # pixels between the two images
+    uv1 = (uv0 + shift * np.array([0.6, 0.8])).astype(np.float32)
+    out = hostlib.run_zupt(sc, x, imu, t_state, stamps, t_off, po, uv0=uv0, uv1=uv1)
+    disparity_passed = case == "moving_low_disparity"
+    ref = oracle.zupt_update(x, po, sc.P, imu, t0, t1, disparity_passed=disparity_passed)
+    assert out["accepted"][0] == ref["accepted"] == (case != "moving")
+    assert abs(out["chi2"][0] - ref["chi2"]) < 1e-8 * max(1.0, ref["chi2"])
+    if not ref["accepted"]:
+        assert out["timestamp"] == t_state and np.abs(out["P"] - sc.P).max() < 1e-15 and out["meas_at_t1"] == 30
+        return
+    dx, P, xr, dt_new = ref["dx"], ref["P"], x, t_off
+    from ov_plane_amd.synth import quat_boxplus
+
+    def _apply_imu_dx(xa, d):
+        return dict(xa, q=quat_boxplus(xa["q"], d[0:3]), p=xa["p"] + d[3:6], v=xa["v"] + d[6:9], bg=xa["bg"] + d[9:12],
+                    ba=xa["ba"] + d[12:15])
+
+    xr = _apply_imu_dx(x, dx)
+    dt_new = t_off + dx[15]
+    if n_cam == 2:
+        # second frame: time0 = previous camera time + the PREVIOUS offset, time1 = new camera time + the corrected offset
+        ref2 = oracle.zupt_update(xr, po, P, imu, stamps[0] + t_off, stamps[1] + dt_new)
+        assert ref2["accepted"] and out["accepted"][1]
+        assert abs(out["chi2"][1] - ref2["chi2"]) < 1e-7 * max(1.0, ref2["chi2"])
+        xr = _apply_imu_dx(xr, ref2["dx"])
+        dt_new += ref2["dx"][15]
+        P = ref2["P"]
+        assert out["meas_at_t1"] == 0          # cleanup_measurements_exact(last_zupt_state_timestamp)
+    else:
+        assert out["meas_at_t1"] == 30
+    assert out["timestamp"] == stamps[-1]
+    x16 = np.concatenate([xr["q"], xr["p"], xr["v"], xr["bg"], xr["ba"]])
+    assert np.abs(out["x16"] - x16).max() < TOL_DX and abs(out["calib_dt"] - dt_new) < TOL_DX
+    assert relP(out["P"], P) < TOL_P

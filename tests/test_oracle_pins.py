@@ -645,3 +645,70 @@ def test_delayed_init_representation_keeps_the_global_landmark_and_the_old_state
     for f in np.nonzero(r["ok"])[0]:
         anchor = int(sc.clone_idx[f, sc.n_meas[f] - 1])
         assert np.abs(_lm_global(rep, r["p"][f], val, anchor) - r0["p"][f]).max() < 1e-2, f  # second order in the correction (inverse depth)
+
+
+def _apply_imu_dx(x, dx, imu_id=0):
+    x2 = dict(x)
+    x2["q"] = quat_boxplus(x["q"], dx[imu_id:imu_id + 3])
+    x2["p"] = x["p"] + dx[imu_id + 3:imu_id + 6]
+    x2["v"] = x["v"] + dx[imu_id + 6:imu_id + 9]
+    x2["bg"] = x["bg"] + dx[imu_id + 9:imu_id + 12]
+    x2["ba"] = x["ba"] + dx[imu_id + 12:imu_id + 15]
+    return x2
+
+
+@pytest.mark.parametrize("do_fej", [True, False])
+def test_zero_velocity_update_is_the_information_form_update_of_its_stacked_imu_rows(oracle, do_fej):
+    """update/UpdaterZeroVelocity.cpp:68-318 against an independent numpy statement: rows -(w_m - b_g) and -(a_m - b_a - R g)
+    per IMU interval with H = [0 -I 0 ; -skew(R g) 0 -I], R = mult * sigma^2 / dt, bias walk dt * sigma added to P first;
+    P+ = (P1^-1 + H^T R^-1 H)^-1, dx = P+ H^T R^-1 r.  A standing platform passes the chi2 gate, a moving one fails it
+    unless the image disparity says "standing" (:231)."""
+    from ov_plane_amd.synth import PROP_OPTS, make_imu_scenario, quat_2_rot, skew
+
+    sc = make_scene(C=6, F=4, seed=91)
+    po = dict(PROP_OPTS, do_fej=do_fej)
+    x, imu, t0, t1 = make_imu_scenario(3, stationary=True)
+    out = oracle.zupt_update(x, po, sc.P, imu, t0, t1)
+    assert out["accepted"] and out["rows"] % 6 == 0 and out["rows"] >= 6 * 39
+    # independent statement
+    sel = oracle.select_imu_readings(imu, t0, t1) if hasattr(oracle, "select_imu_readings") else None
+    if sel is None:
+        inside = imu[(imu[:, 0] > t0) & (imu[:, 0] < t1)]
+        lerp = lambda t: np.concatenate([[t], [np.interp(t, imu[:, 0], imu[:, k]) for k in range(1, 7)]])  # noqa: E731
+        sel = np.vstack([lerp(t0), inside, lerp(t1)])
+    n = sel.shape[0] - 1
+    assert out["rows"] == 6 * n
+    N = sc.N
+    Hf = np.zeros((6 * n, N))
+    r = np.zeros(6 * n)
+    Rd = np.zeros(6 * n)
+    g = np.array([0, 0, po["gravity_mag"]])
+    Rv, Rj = quat_2_rot(x["q"]), quat_2_rot(x["q_fej"] if do_fej else x["q"])
+    for i in range(n):
+        dt = sel[i + 1, 0] - sel[i, 0]
+        r[6 * i:6 * i + 3] = -(sel[i, 1:4] - x["bg"])
+        r[6 * i + 3:6 * i + 6] = -(sel[i, 4:7] - x["ba"] - Rv @ g)
+        Hf[6 * i:6 * i + 3, 9:12] = -np.eye(3)
+        Hf[6 * i + 3:6 * i + 6, 0:3] = -skew(Rj @ g)
+        Hf[6 * i + 3:6 * i + 6, 12:15] = -np.eye(3)
+        Rd[6 * i:6 * i + 3] = 10.0 * po["sigma_w"] ** 2 / dt
+        Rd[6 * i + 3:6 * i + 6] = 10.0 * po["sigma_a"] ** 2 / dt
+    dts = sel[-1, 0] - sel[0, 0]
+    P1 = sc.P.copy()
+    P1[9:12, 9:12] += dts * po["sigma_wb"] * np.eye(3)
+    P1[12:15, 12:15] += dts * po["sigma_ab"] * np.eye(3)
+    S = Hf @ P1 @ Hf.T + np.diag(Rd)
+    assert abs(out["chi2"] - r @ np.linalg.solve(S, r)) < 1e-8 * max(1.0, out["chi2"])
+    Pp = np.linalg.inv(np.linalg.inv(P1) + Hf.T @ (Hf / Rd[:, None]))
+    d = np.sqrt(np.diag(P1))
+    assert (np.abs(out["P"] - Pp) / np.outer(d, d)).max() < 1e-7
+    dxr = Pp @ Hf.T @ (r / Rd)
+    assert np.abs(out["dx"] - dxr).max() < 1e-8 * max(1.0, np.abs(dxr).max())
+    # a moving platform
+    xm, imum, t0m, t1m = make_imu_scenario(3, stationary=False)
+    rej = oracle.zupt_update(xm, po, sc.P, imum, t0m, t1m)
+    assert not rej["accepted"] and rej["chi2"] > 100 * rej["rows"] and np.abs(rej["P"] - sc.P).max() == 0.0
+    assert oracle.zupt_update(xm, po, sc.P, imum, t0m, t1m, disparity_passed=True)["accepted"]
+    # standing, but the velocity estimate says otherwise (:231 second clause)
+    xv = dict(x, v=np.array([0.7, 0.0, 0.0]))
+    assert not oracle.zupt_update(xv, po, sc.P, imu, t0, t1)["accepted"]
