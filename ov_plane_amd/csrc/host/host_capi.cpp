@@ -780,6 +780,16 @@ extern "C" int ovph_run_plane_givens(int op /* 0 nullspace, 1 compress */, int r
   return ro;
 }
 
+// ovph_run_sequence extras: per-frame IMU value [K][16] and IMU pose covariance [K][36] (column-major) after each frame; with
+// uv_norm [F][M][2] the features arrive untriangulated (uvs_norm set, no position) and UpdaterMSCKF::update triangulates them
+static double *g_seq_traj = nullptr, *g_seq_posecov = nullptr;
+static const float *g_seq_uv_norm = nullptr;
+extern "C" void ovph_set_sequence_trace(double *traj, double *posecov, const float *uv_norm) {
+  g_seq_traj = traj;
+  g_seq_posecov = posecov;
+  g_seq_uv_norm = uv_norm;
+}
+
 // Closed loop over several camera frames with the reference's own call order (core/VioManager.cpp:348 propagate_and_clone,
 // :670 UpdaterMSCKF::update, :864-866 marginalize_old_clone): state with C clones, IMU state, covariance P (N = 30 + 6 C).
 // Frame k: propagate + clone to frame_time[k], update with that frame's features (slots index the C+1 clones of the window,
@@ -885,13 +895,26 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
         ft->uvs.push_back(uv[((size_t)f * M + q) * 2]);
         ft->uvs.push_back(uv[((size_t)f * M + q) * 2 + 1]);
       }
-      memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+      if (g_seq_uv_norm) {
+        for (int q = 0; q < 2 * n_meas[f]; ++q) ft->uvs_norm.push_back(g_seq_uv_norm[(size_t)f * M * 2 + q]);
+      } else {
+        memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
+      }
       fv.push_back(ft);
     }
     updater.update(state, fv, fextra, fused, feat2plane);  // VioManager.cpp:670
     n_kept_per_frame[k] = (int)fv.size();
     StateHelper::marginalize_old_clone(state);  // VioManager.cpp:864-866
+    if (g_seq_traj) memcpy(g_seq_traj + 16 * (size_t)k, state->_imu->value().data(), 16 * sizeof(double));
+    if (g_seq_posecov) {
+      std::vector<std::shared_ptr<Type>> po;
+      po.push_back(state->_imu->pose());
+      MatrixXd Pp = StateHelper::get_marginal_covariance(state, po);
+      memcpy(g_seq_posecov + 36 * (size_t)k, Pp.data(), 36 * sizeof(double));
+    }
   }
+  g_seq_traj = g_seq_posecov = nullptr;
+  g_seq_uv_norm = nullptr;
   int i = 0;
   for (auto &c : state->_clones_IMU) {
     memcpy(out_clone_q + 4 * i, c.second->quat(), 4 * sizeof(double));

@@ -296,12 +296,14 @@ def run_plane_givens(op, H_f, H_x, H_cp, res):
     return Hx[:ro].copy(), (Hc[:ro].copy() if H_cp is not None else None), r[:ro].copy()
 
 
-def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0):
+def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0, trace=False):
     """Closed loop over several frames through the C++ host mirror (Propagator::propagate_and_clone ->
     UpdaterMSCKF::update -> StateHelper::marginalize_old_clone per frame).
 
     init: dict(C, N, clone_q, clone_p, clone_q_fej, clone_p_fej, calib_q, calib_p, intr, x (IMU dict), dt, P, t_state)
     frames: list of dict(uv [F,M,2] f32, slot [F,M] int32 (index into the C+1 clones of the window), n_meas [F], p_FinG [F,3])
+    A frame may carry `uv_norm` [F,M,2] instead of p_FinG (all frames or none): the updater then triangulates its features.
+    trace: also return the IMU value ("traj" [K,16]) and its pose covariance ("posecov" [K,6,6]) after every frame.
     """
     L = lib()
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
@@ -312,7 +314,8 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0)
     x16f = f64(np.concatenate([x["q_fej"], x["p_fej"], x["v_fej"], x["bg_fej"], x["ba_fej"]]))
     M = max(int(fr["uv"].shape[1]) for fr in frames)
     offs = np.zeros(len(frames) + 1, dtype=np.int32)
-    uv_l, slot_l, nm_l, pf_l = [], [], [], []
+    uv_l, slot_l, nm_l, pf_l, uvn_l = [], [], [], [], []
+    with_norm = all("uv_norm" in fr for fr in frames)
     for k, fr in enumerate(frames):
         F = int(fr["uv"].shape[0])
         offs[k + 1] = offs[k] + F
@@ -323,7 +326,11 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0)
         uv_l.append(uvp)
         slot_l.append(sl)
         nm_l.append(np.asarray(fr["n_meas"], dtype=np.int32))
-        pf_l.append(np.asarray(fr["p_FinG"], dtype=np.float64))
+        pf_l.append(np.asarray(fr["p_FinG"], dtype=np.float64) if "p_FinG" in fr else np.zeros((F, 3)))
+        if with_norm:
+            un = np.zeros((F, M, 2), dtype=np.float32)
+            un[:, : fr["uv_norm"].shape[1]] = fr["uv_norm"]
+            uvn_l.append(un)
     uv = np.ascontiguousarray(np.concatenate(uv_l), dtype=np.float32)
     slot = np.ascontiguousarray(np.concatenate(slot_l), dtype=np.int32)
     nm = np.ascontiguousarray(np.concatenate(nm_l), dtype=np.int32)
@@ -336,6 +343,11 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0)
     calq, calp, intr = f64(init["calib_q"]), f64(init["calib_p"]), f64(init["intr"])
     out = dict(clone_q=np.zeros((Cn, 4)), clone_p=np.zeros((Cn, 3)), x16=np.zeros(16), calib_q=np.zeros(4), calib_p=np.zeros(3),
                intr=np.zeros(8), dt=np.zeros(1), P=np.zeros((N, N)), kept=np.zeros(len(frames), dtype=np.int32))
+    K = len(frames)
+    traj, posecov = np.zeros((K, 16)), np.zeros((K, 36))
+    uvn = np.ascontiguousarray(np.concatenate(uvn_l), dtype=np.float32) if with_norm else None
+    if trace or with_norm:
+        L.ovph_set_sequence_trace(p(traj) if trace else None, p(posecov) if trace else None, p(uvn) if with_norm else None)
     L.ovph_run_sequence.restype = C.c_int
     rc = L.ovph_run_sequence(
         C.c_int(Cn), p(cq), p(cp_), p(cqf), p(cpf), p(calq), p(calp), p(intr), p(x16), p(x16f), C.c_double(init["dt"]),
@@ -347,6 +359,9 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0)
         raise RuntimeError("ovph_run_sequence failed with %d" % rc)
     out["P"] = np.ascontiguousarray(out["P"].T)
     out["dt"] = float(out["dt"][0])
+    if trace:
+        out["traj"] = traj
+        out["posecov"] = posecov.reshape(K, 6, 6)   # symmetric: the column-major layout does not matter
     return out
 
 

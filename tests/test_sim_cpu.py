@@ -1,0 +1,89 @@
+"""ov_plane_amd/sim.py (Simulator + ext BsplineSE3 restated): self-consistency of the spline, the geometry of
+the simulated world and the statistics of the measurements.  No reference vectors exist for any of it (parity unpinned)."""
+import numpy as np
+import pytest
+
+from ov_plane_amd.sim import BsplineSE3, SimPlane, Simulator, log_so3, synthetic_trajectory
+from ov_plane_amd.synth import quat_2_rot, radtan_distort
+
+
+@pytest.fixture(scope="module")
+def traj():
+    return synthetic_trajectory(duration=24.0)
+
+
+def test_spline_interpolates_the_trajectory_and_its_derivatives_are_consistent(traj):
+    sp = BsplineSE3()
+    sp.feed_trajectory(traj)
+    assert sp.dt == 0.05 and sp.get_start_time() == traj[0, 0] + 0.1
+    assert sp.get_pose(traj[0, 0]) is None and sp.get_pose(traj[-1, 0] + 1.0) is None
+    for row in traj[200:2000:173]:
+        R, p = sp.get_pose(row[0])
+        assert np.linalg.norm(p - row[1:4]) < 1e-3                       # a B-spline smooths, it does not interpolate exactly
+        assert np.linalg.norm(log_so3(R @ quat_2_rot(row[4:8]).T)) < 1e-3
+    h = 1e-5
+    for t in (12.3457, 17.01, 25.5):
+        R, p, w, v = sp.get_velocity(t)
+        (Rp, pp), (Rm, pm) = sp.get_pose(t + h), sp.get_pose(t - h)
+        assert np.abs((pp - pm) / (2 * h) - v).max() < 1e-8
+        assert np.abs(-log_so3(Rp @ Rm.T) / (2 * h) - w).max() < 1e-8   # JPL: R_GtoI(t+h) = exp(-w h) R_GtoI(t)
+        _, _, w2, v2, alpha, a = sp.get_acceleration(t)
+        vp, vm = sp.get_velocity(t + h), sp.get_velocity(t - h)
+        assert np.abs(w2 - w).max() == 0 and np.abs(v2 - v).max() == 0
+        assert np.abs((vp[3] - vm[3]) / (2 * h) - a).max() < 1e-6
+        assert np.abs((vp[2] - vm[2]) / (2 * h) - alpha).max() < 1e-6
+
+
+def test_sim_plane_intersection_and_closest_point():
+    tl, tr, bl, br = np.array([0., 0, 2]), np.array([4., 0, 2]), np.array([0., 3, 2]), np.array([4., 3, 2])
+    pl = SimPlane(7, tl, tr, bl, br)
+    assert np.allclose(np.abs(pl.cp()), [0, 0, 2])
+    assert abs(pl.calculate_intersection(np.array([1., 1, 0]), np.array([0., 0, 1])) - 2.0) < 1e-12
+    assert pl.calculate_intersection(np.array([1., 1, 0]), np.array([0., 0, -1])) is None      # behind the ray
+    assert pl.calculate_intersection(np.array([9., 1, 0]), np.array([0., 0, 1])) is None       # outside the rectangle
+
+
+def test_simulator_world_and_measurements(traj):
+    sim = Simulator(traj, num_pts=60, num_pts_plane=60)
+    # six faces of a box around the trajectory, the trajectory strictly inside
+    assert len(sim.planes) == 6 and sorted(p.plane_id for p in sim.planes) == [1, 2, 3, 4, 5, 6]
+    cps = np.array([p.cp() for p in sim.planes])
+    assert (np.count_nonzero(np.abs(cps) > 1e-9, axis=1) == 1).all()
+    # planar map features lie on their plane, free ones are 2..5 m deep when generated
+    for fid, f in sim.featmap.items():
+        if int(f[3]) != -1:
+            cp = sim.planes[int(f[3]) - 1].cp()
+            n, d = cp / np.linalg.norm(cp), np.linalg.norm(cp)
+            assert abs(n @ f[:3] - d) < 1e-9
+    assert sim.timestamp > sim.spline.get_start_time()      # skipped ahead until the platform moved 1.2 m
+    # IMU / camera interleaving: 400 Hz / 10 Hz
+    imu, frames = [], []
+    while len(frames) < 6:
+        r = sim.get_next_imu()
+        if r is not None:
+            imu.append(r)
+        c = sim.get_next_cam()
+        if c is not None:
+            frames.append(c)
+    assert 200 <= len(imu) <= 241
+    assert np.allclose(np.diff([r[0] for r in imu]), 1 / 400.0)
+    assert np.allclose(np.diff([c[0] for c in frames]), 0.1)
+    # a camera frame: every feature at most once, one per 10-pixel cell, pixel noise of one sigma around the projection
+    t_cam, uvs = frames[-2]   # (the bias history has to bound the query time, Simulator.cpp:291-298)
+    assert len(uvs) == 120 and len({fid for fid, _ in uvs}) == 120
+    st = sim.get_state(t_cam)
+    R, p = quat_2_rot(st["q"]), st["p"]
+    err = []
+    for fid, d in uvs:
+        pc = sim.R_ItoC @ (R @ (sim.featmap[fid][:3] - p)) + sim.p_IinC
+        u, v = radtan_distort(pc[0] / pc[2], pc[1] / pc[2], sim.intr)
+        err.append([d[0] - u, d[1] - v])
+        assert int(d[2]) == int(sim.featmap[fid][3])
+    err = np.array(err)
+    assert 0.7 < err.std() < 1.3 and np.abs(err.mean(axis=0)).max() < 0.4
+    # the IMU measures the spline's angular velocity and specific force up to noise and (still tiny) biases
+    t, wm, am = imu[-1]
+    acc = sim.spline.get_acceleration(t)
+    assert np.abs(wm - acc[2]).max() < 6 * 1.6968e-4 * 20 + 1e-3
+    assert np.abs(am - acc[0] @ (acc[5] + np.array([0, 0, 9.81]))).max() < 6 * 2e-3 * 20 + 1e-2
+    assert np.linalg.norm(sim.true_bias_gyro) > 0 and len(sim.hist_true_bias_time) == len(imu) + 2
