@@ -13,8 +13,9 @@ from .synth import radtan_undistort, state_layout
 
 
 def collect(sim, n_frames):
-    """Runs the simulator until n_frames camera frames exist.  Returns (imu [n,7], frames [(time_cam, {fid: uv})])."""
-    imu, frames = [], []
+    """Runs the simulator until n_frames camera frames exist.  Returns (imu [n,7], frames [(time_cam, {fid: uv})],
+    plane_of {fid: plane id or -1})."""
+    imu, frames, plane_of = [], [], {}
     while sim.is_running and len(frames) < n_frames:
         r = sim.get_next_imu()
         if r is not None:
@@ -22,12 +23,13 @@ def collect(sim, n_frames):
         c = sim.get_next_cam()
         if c is not None:
             frames.append((c[0], {fid: d[:2].copy() for fid, d in c[1]}))
+            plane_of.update({fid: int(d[2]) for fid, d in c[1]})
     # readings past the last frame so the final propagation has its bounding measurement
     for _ in range(4):
         r = sim.get_next_imu()
         if r is not None:
             imu.append(np.concatenate([[r[0]], r[1], r[2]]))
-    return np.array(imu), frames
+    return np.array(imu), frames, plane_of
 
 
 def initial_state(sim, frames, C, rng=None, sigmas=None):
@@ -85,25 +87,28 @@ def schedule(frames, C, min_meas=3, max_feats=None):
             marg = tr[0][0] == lo
             if lost or marg:
                 if len(tr) >= min_meas:
-                    use.append(tr)
+                    use.append((fid, tr))
                 del tracks[fid]
         if max_feats is not None:
-            use = sorted(use, key=len, reverse=True)[:max_feats]
+            use = sorted(use, key=lambda e: len(e[1]), reverse=True)[:max_feats]
         F, M = len(use), C + 1
         uv = np.zeros((F, M, 2), dtype=np.float32)
         slot = -np.ones((F, M), dtype=np.int32)
         nm = np.zeros(F, dtype=np.int32)
-        for f, tr in enumerate(use):
+        for f, (_, tr) in enumerate(use):
             nm[f] = len(tr)
             for q, (j, m) in enumerate(tr):
                 uv[f, q] = m
                 slot[f, q] = j - lo
-        out.append(dict(uv=uv, slot=slot, n_meas=nm))
+        out.append(dict(uv=uv, slot=slot, n_meas=nm, fid=np.array([fid for fid, _ in use], dtype=np.int64)))
     return out
 
 
-def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=None):
-    """Simulate, estimate, score.  Returns dict with per-frame truth / estimate / errors and the summary numbers."""
+def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=None, planes=0, plane_min_feat=6, sigma_c=0.01):
+    """Simulate, estimate, score.  Returns dict with per-frame truth / estimate / errors and the summary numbers.
+    planes: 0 = points only; 1 = the simulator's point-to-plane associations become feat2plane and UpdaterMSCKF uses the
+    planar regularities (planes estimated per update, StateOptions::use_plane_constraint_msckf); 2 = UpdaterPlane::init_vio_plane
+    also puts the planes into the state (use_plane_slam_feats)."""
     from . import hostlib
     from .sim import log_so3
     from .synth import PROP_OPTS, quat_2_rot
@@ -111,7 +116,7 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
     po = dict(PROP_OPTS if po is None else po)
     po.update(sigma_w=sim.params["sigma_w"], sigma_a=sim.params["sigma_a"], sigma_wb=sim.params["sigma_wb"],
               sigma_ab=sim.params["sigma_ab"], gravity_mag=sim.params["gravity_mag"])
-    imu, frames = collect(sim, C + 1 + n_frames)
+    imu, frames, plane_of = collect(sim, C + 1 + n_frames)
     init = initial_state(sim, frames, C)
     frames = frames[:C] + frames[C + 1:]      # the image taken at the initial state time has no clone
     live = schedule(frames, C, max_feats=max_feats)
@@ -119,7 +124,11 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
         xn, yn = radtan_undistort(fr["uv"][..., 0], fr["uv"][..., 1], init["intr"])
         fr["uv_norm"] = np.stack([xn, yn], axis=-1).astype(np.float32)
     times = np.array([t for t, _ in frames[C:]])
-    out = hostlib.run_sequence(init, imu, times, live, po, sigma_px=sigma_px, chi2_mult=chi2_mult, trace=True)
+    if planes:
+        for fr in live:
+            fr["plane"] = np.array([max(plane_of[int(f)], 0) for f in fr["fid"]], dtype=np.int32)
+    out = hostlib.run_sequence(init, imu, times, live, po, sigma_px=sigma_px, chi2_mult=chi2_mult, trace=True, plane_mode=planes,
+                               plane_min_feat=plane_min_feat, sigma_c=sigma_c)
     K = len(live)
     e_pos, e_ori, nees_p, nees_o = np.zeros(K), np.zeros(K), np.zeros(K), np.zeros(K)
     for k in range(K):
@@ -133,5 +142,7 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
         nees_o[k] = dth @ np.linalg.solve(Pk[0:3, 0:3], dth)
     return dict(times=times, traj=out["traj"], posecov=out["posecov"], e_pos=e_pos, e_ori=e_ori, nees_pos=nees_p, nees_ori=nees_o,
                 feats_per_frame=np.array([len(fr["n_meas"]) for fr in live]), kept_per_frame=out["kept"],
+                planar_per_frame=np.array([int((fr["plane"] > 0).sum()) if planes else 0 for fr in live]),
+                planes_in_state=out.get("planes_in_state", 0),
                 rmse_pos=float(np.sqrt(np.mean(e_pos**2))), rmse_ori_deg=float(np.degrees(np.sqrt(np.mean(e_ori**2)))),
                 final=out)

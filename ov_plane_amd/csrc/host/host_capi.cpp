@@ -789,6 +789,21 @@ extern "C" void ovph_set_sequence_trace(double *traj, double *posecov, const flo
   g_seq_posecov = posecov;
   g_seq_uv_norm = uv_norm;
 }
+// ... planar regularities in the loop: plane id (0 = none) of every feature of the concatenated list -> feat2plane.
+// mode 1: point-on-plane constraints with planes estimated per update (UpdaterMSCKF, planes stay out of the state);
+// mode 2: additionally UpdaterPlane::init_vio_plane before the update (core/VioManager.cpp:583-588), planes join the state
+// (the final covariance is then larger than N and not returned; out_planes_in_state [1] receives how many planes it holds)
+static const int *g_seq_plane = nullptr;
+static int g_seq_plane_mode = 0, g_seq_plane_min_feat = 20;
+static int *g_seq_planes_in_state = nullptr;
+static double g_seq_sigma_c = 0.01;
+extern "C" void ovph_set_sequence_planes(const int *plane_of_feat, int mode, int min_feat, double sigma_c, int *out_planes_in_state) {
+  g_seq_plane = plane_of_feat;
+  g_seq_plane_mode = mode;
+  g_seq_plane_min_feat = min_feat;
+  g_seq_sigma_c = sigma_c;
+  g_seq_planes_in_state = out_planes_in_state;
+}
 
 // Closed loop over several camera frames with the reference's own call order (core/VioManager.cpp:348 propagate_and_clone,
 // :670 UpdaterMSCKF::update, :864-866 marginalize_old_clone): state with C clones, IMU state, covariance P (N = 30 + 6 C).
@@ -808,8 +823,16 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
   so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
   so.max_clone_size = C;
   so.use_rk4_integration = use_rk4 != 0;
-  so.max_state_size = N + 16;
+  so.max_state_size = N + 16 + 3 * 16;
   so.max_features = 4096;
+  const int plane_mode = g_seq_plane ? g_seq_plane_mode : 0;
+  if (plane_mode) {
+    so.use_plane_constraint = so.use_plane_constraint_msckf = true;
+    so.use_plane_constraint_slamu = so.use_plane_constraint_slamd = true;
+    so.use_plane_slam_feats = plane_mode == 2;
+    so.sigma_constraint = g_seq_sigma_c;
+    so.plane_init_min_feat = so.plane_msckf_min_feat = g_seq_plane_min_feat;
+  }
   auto state = std::make_shared<State>(so);
   {
     VectorXd v(7, 1);
@@ -881,8 +904,10 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
   uo.chi2_multipler = chi2_mult;
   ov_core::FeatureInitializerOptions fio;
   UpdaterMSCKF updater(uo, fio);
+  UpdaterPlane updater_plane(uo, fio);
   std::map<size_t, size_t> feat2plane;
   for (int k = 0; k < K; ++k) {
+    feat2plane.clear();
     prop.propagate_and_clone(state, frame_time[k]);  // VioManager.cpp:348
     std::vector<double> times;
     for (auto &c : state->_clones_IMU) times.push_back(c.first);
@@ -901,6 +926,19 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
         memcpy(ft->p_FinG, p_FinG + 3 * f, 3 * sizeof(double));
       }
       fv.push_back(ft);
+      if (plane_mode && g_seq_plane[f] > 0) feat2plane[ft->featid] = (size_t)g_seq_plane[f];
+    }
+    if (plane_mode == 2) {  // VioManager.cpp:543-600: planar candidates first try to initialise their planes
+      std::vector<std::shared_ptr<ov_core::Feature>> fplane, finit_used;
+      for (auto &ft : fv)
+        if (feat2plane.count(ft->featid)) fplane.push_back(ft);
+      updater_plane.init_vio_plane(state, fplane, finit_used, feat2plane);
+      std::set<size_t> used;
+      for (auto &ft : finit_used) used.insert(ft->featid);
+      std::vector<std::shared_ptr<ov_core::Feature>> rest;
+      for (auto &ft : fv)
+        if (!used.count(ft->featid)) rest.push_back(ft);
+      fv.swap(rest);
     }
     updater.update(state, fv, fextra, fused, feat2plane);  // VioManager.cpp:670
     n_kept_per_frame[k] = (int)fv.size();
@@ -915,6 +953,9 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
   }
   g_seq_traj = g_seq_posecov = nullptr;
   g_seq_uv_norm = nullptr;
+  if (g_seq_planes_in_state) *g_seq_planes_in_state = (int)state->_features_PLANE.size();
+  g_seq_plane = nullptr;
+  g_seq_planes_in_state = nullptr;
   int i = 0;
   for (auto &c : state->_clones_IMU) {
     memcpy(out_clone_q + 4 * i, c.second->quat(), 4 * sizeof(double));
@@ -927,6 +968,7 @@ extern "C" int ovph_run_sequence(int C, const double *clone_q, const double *clo
   memcpy(out_calib_p, state->_calib_IMUtoCAM.at(0)->pos(), 3 * sizeof(double));
   memcpy(out_intr, state->_cam_intrinsics.at(0)->value().data(), 8 * sizeof(double));
   *out_dt = state->_calib_dt_CAMtoIMU->value()(0);
+  if (plane_mode == 2) return 0;  // planes joined the state: the covariance is larger than the caller's buffer
   if (state->max_covariance_size() != N) return -12;
   MatrixXd Pn = StateHelper::get_full_covariance(state);
   memcpy(out_P, Pn.data(), sizeof(double) * (size_t)N * N);

@@ -30,6 +30,7 @@ struct StateOptions {
   bool use_plane_constraint_msckf = false;
   bool use_plane_constraint_slamu = false;
   bool use_plane_constraint_slamd = false;
+  bool use_plane_slam_feats = false;   // StateOptions.h:105, read by the caller of UpdaterPlane::init_vio_plane (VioManager.cpp:585)
   double sigma_constraint = 0.01;
   double const_init_multi = 1.0;
   double const_init_chi2 = 1.0;
@@ -41,7 +42,8 @@ struct StateOptions {
   // StateOptions.h:90-96.  MSCKF features: the projected system is the same for every three-parameter representation (the
   // anchor terms of H_x are H_f_global * dpfg_dx and die with the left nullspace of H_f; tests/test_oracle_pins.py pins this),
   // and ANCHORED_INVERSE_DEPTH_SINGLE is mapped to the MSCKF inverse depth for such features (update/UpdaterMSCKF.cpp:478-481):
-  // the device path serves all of them with its GLOBAL_3D arithmetic.  SLAM landmarks are kept in GLOBAL_3D by this build.
+  // the device path serves all of them with its GLOBAL_3D arithmetic.  SLAM landmarks live in feat_rep_slam (host-built dense
+  // Jacobians, UpdaterSLAM::update / delayed_init / change_anchors).
   ov_type::LandmarkRepresentation::Representation feat_rep_msckf = ov_type::LandmarkRepresentation::GLOBAL_3D;
   ov_type::LandmarkRepresentation::Representation feat_rep_slam = ov_type::LandmarkRepresentation::GLOBAL_3D;
   int max_msckf_plane = 20;            // StateOptions.h:123

@@ -296,7 +296,8 @@ def run_plane_givens(op, H_f, H_x, H_cp, res):
     return Hx[:ro].copy(), (Hc[:ro].copy() if H_cp is not None else None), r[:ro].copy()
 
 
-def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0, trace=False):
+def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0, trace=False, plane_mode=0, plane_min_feat=20,
+                 sigma_c=0.01):
     """Closed loop over several frames through the C++ host mirror (Propagator::propagate_and_clone ->
     UpdaterMSCKF::update -> StateHelper::marginalize_old_clone per frame).
 
@@ -304,6 +305,8 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0,
     frames: list of dict(uv [F,M,2] f32, slot [F,M] int32 (index into the C+1 clones of the window), n_meas [F], p_FinG [F,3])
     A frame may carry `uv_norm` [F,M,2] instead of p_FinG (all frames or none): the updater then triangulates its features.
     trace: also return the IMU value ("traj" [K,16]) and its pose covariance ("posecov" [K,6,6]) after every frame.
+    plane_mode 1 / 2 with per-frame `plane` [F] (0 = free point): planar regularities in UpdaterMSCKF / additionally
+    UpdaterPlane::init_vio_plane (the planes join the state; the final P is then not returned, "planes_in_state" is).
     """
     L = lib()
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
@@ -348,6 +351,11 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0,
     uvn = np.ascontiguousarray(np.concatenate(uvn_l), dtype=np.float32) if with_norm else None
     if trace or with_norm:
         L.ovph_set_sequence_trace(p(traj) if trace else None, p(posecov) if trace else None, p(uvn) if with_norm else None)
+    n_in_state = C.c_int(0)
+    if plane_mode:
+        pl = np.ascontiguousarray(np.concatenate([np.asarray(fr["plane"], dtype=np.int32) for fr in frames]), dtype=np.int32)
+        L.ovph_set_sequence_planes(p(pl), C.c_int(int(plane_mode)), C.c_int(int(plane_min_feat)), C.c_double(sigma_c),
+                                   C.byref(n_in_state))
     L.ovph_run_sequence.restype = C.c_int
     rc = L.ovph_run_sequence(
         C.c_int(Cn), p(cq), p(cp_), p(cqf), p(cpf), p(calq), p(calp), p(intr), p(x16), p(x16f), C.c_double(init["dt"]),
@@ -359,6 +367,7 @@ def run_sequence(init, imu, frame_time, frames, po, sigma_px=1.0, chi2_mult=1.0,
         raise RuntimeError("ovph_run_sequence failed with %d" % rc)
     out["P"] = np.ascontiguousarray(out["P"].T)
     out["dt"] = float(out["dt"][0])
+    out["planes_in_state"] = n_in_state.value
     if trace:
         out["traj"] = traj
         out["posecov"] = posecov.reshape(K, 6, 6)   # symmetric: the column-major layout does not matter

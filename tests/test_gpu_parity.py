@@ -1503,11 +1503,14 @@ def test_host_cpp_mirror_updater_zero_velocity(hiplib, oracle, case):
     assert relP(out["P"], P) < TOL_P
 
 
-def test_closed_loop_vio_on_simulated_data_is_accurate_and_consistent(hiplib):
+@pytest.mark.parametrize("planes", [0, 1, 2])
+def test_closed_loop_vio_on_simulated_data_is_accurate_and_consistent(hiplib, planes):
     """the restated Simulator (ov_plane_amd/sim.py) drives propagate -> triangulate -> MSCKF update ->
     marginalise through the C++ host mirror with the covariance on the device for 12 s of motion.  No oracle here: the filter is
     scored against the simulator's ground truth - drift stays at the centimetre level and the NEES of position and orientation
-    stays around its expectation of 3 (the estimator neither diverges nor becomes overconfident)."""
+    stays around its expectation of 3 (the estimator neither diverges nor becomes overconfident).  planes = 1: the simulator's
+    point-to-plane associations arrive as feat2plane and UpdaterMSCKF uses the planar regularities; planes = 2: additionally
+    UpdaterPlane::init_vio_plane puts planes into the state (core/VioManager.cpp:583-588)."""
     from ov_plane_amd.build import build_host
 
     build_host()
@@ -1515,12 +1518,15 @@ def test_closed_loop_vio_on_simulated_data_is_accurate_and_consistent(hiplib):
     from ov_plane_amd.sim import Simulator, synthetic_trajectory
 
     sim = Simulator(synthetic_trajectory(duration=30.0), num_pts=100, num_pts_plane=100)
-    r = closed_loop.run(sim, n_frames=120, C=11)
+    r = closed_loop.run(sim, n_frames=120, C=11, planes=planes)
+    assert (r["planes_in_state"] >= 1) == (planes == 2) and (r["planar_per_frame"].sum() > 0) == (planes > 0)
     assert r["feats_per_frame"].sum() > 5 * 120, r["feats_per_frame"]
     assert r["kept_per_frame"].sum() >= 0.7 * r["feats_per_frame"].sum(), (r["kept_per_frame"], r["feats_per_frame"])
     assert r["rmse_pos"] < 0.15 and r["e_pos"].max() < 0.3, (r["rmse_pos"], r["e_pos"].max())
     assert r["rmse_ori_deg"] < 0.3, r["rmse_ori_deg"]
     assert 0.2 < r["nees_pos"].mean() < 9.0 and 0.2 < r["nees_ori"].mean() < 9.0, (r["nees_pos"].mean(), r["nees_ori"].mean())
+    if planes == 2:
+        return    # the covariance grew by the planes and is not returned
     P = r["final"]["P"]
     # the newest clone is a copy of the IMU pose: P is positive SEMI-definite by construction
     w = np.linalg.eigvalsh(P)
