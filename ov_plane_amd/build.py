@@ -32,7 +32,7 @@ def build_lib(force=False, verbose=False):
 
 
 HOST_DIR = os.path.join(CSRC, "host")
-HOST_SOURCES = ["ov_plane_host.cpp", "ov_plane_updaters.cpp", "ov_plane_propagator.cpp", "ov_plane_zupt.cpp", "ov_plane_planefit.cpp", "ov_plane_io.cpp", "host_capi.cpp"]
+HOST_SOURCES = ["ov_plane_host.cpp", "ov_plane_updaters.cpp", "ov_plane_propagator.cpp", "ov_plane_zupt.cpp", "ov_plane_planefit.cpp", "ov_plane_io.cpp", "ov_plane_session.cpp", "host_capi.cpp"]
 HOST_HEADERS = ["ov_plane_host.h", "ov_types.h"]
 HOST_OUT = os.path.join(_HERE, "libovplane_host.so")
 

@@ -12,6 +12,11 @@ import numpy as np
 from .synth import radtan_undistort, state_layout
 
 
+# ids up to 4 * max_aruco_features (1024 by default) belong to ArUco corners, which are never marginalised
+# (state/StateHelper.cpp:638-652); ext TrackSIM shifts the simulator's map ids past them the same way
+FID_OFFSET = 4 * 1024 + 1
+
+
 def collect(sim, n_frames):
     """Runs the simulator until n_frames camera frames exist.  Returns (imu [n,7], frames [(time_cam, {fid: uv})],
     plane_of {fid: plane id or -1})."""
@@ -146,3 +151,95 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
                 planes_in_state=out.get("planes_in_state", 0),
                 rmse_pos=float(np.sqrt(np.mean(e_pos**2))), rmse_ori_deg=float(np.degrees(np.sqrt(np.mean(e_ori**2)))),
                 final=out)
+
+
+def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, planes=0, plane_min_feat=6, sigma_c=0.01,
+                max_slam=0, feat_rep_slam=0, min_meas=3):
+    """Closed loop through hostlib.Session, frame by frame, with the tracker-side bookkeeping of core/VioManager.cpp:360-506:
+    a track is an MSCKF feature once it is lost or reaches back to the clone about to be marginalised; a track that spans the
+    whole window (more than max_clone_size measurements) becomes a SLAM landmark while there is room (max_slam), and from then
+    on every new measurement of it is a SLAM update until it is no longer seen (the session then marginalises it).
+    feat_rep_slam: ext LandmarkRepresentation of the landmarks (0 GLOBAL_3D ... 5 ANCHORED_INVERSE_DEPTH_SINGLE)."""
+    from . import hostlib
+    from .sim import log_so3
+    from .synth import PROP_OPTS, quat_2_rot
+
+    po = dict(PROP_OPTS if po is None else po)
+    po.update(sigma_w=sim.params["sigma_w"], sigma_a=sim.params["sigma_a"], sigma_wb=sim.params["sigma_wb"],
+              sigma_ab=sim.params["sigma_ab"], gravity_mag=sim.params["gravity_mag"])
+    imu, frames, plane_of = collect(sim, C + 1 + n_frames)
+    init = initial_state(sim, frames, C)
+    frames = frames[:C] + frames[C + 1:]
+    ses = hostlib.Session(init, po, sigma_px=sigma_px, chi2_mult=chi2_mult, plane_mode=planes, plane_min_feat=plane_min_feat,
+                          sigma_c=sigma_c, max_slam=max_slam, feat_rep_slam=feat_rep_slam, cam_dt=1.0 / sim.params["sim_freq_cam"])
+    ses.feed_imu(imu)
+    tracks = {}
+    for k in range(C):
+        for fid, uv in frames[k][1].items():
+            tracks.setdefault(fid, []).append((k, uv))
+    slam_ids = set()
+    K = len(frames) - C
+    traj, posecov, counts = np.zeros((K, 16)), np.zeros((K, 6, 6)), np.zeros((K, 6), dtype=np.int32)
+    n_feats = np.zeros((K, 3), dtype=np.int32)
+    for k in range(C, len(frames)):
+        t_k, seen = frames[k]
+        lo = k - C
+        items = []                                           # (fid, kind, [(frame, uv), ...])
+        for fid in sorted(slam_ids):                         # landmarks seen in this frame: one new measurement each
+            if fid in seen:
+                items.append((fid, 1, [(k, seen[fid])]))
+        n_slam_kept = len(items)
+        for fid, uv in seen.items():
+            if fid not in slam_ids:
+                tracks.setdefault(fid, []).append((k, uv))
+        maxtracks, msckf = [], []
+        for fid in sorted(tracks):
+            tr = [(j, uv) for j, uv in tracks[fid] if j >= lo]
+            tracks[fid] = tr
+            if not tr:
+                del tracks[fid]
+                continue
+            lost, marg = fid not in seen, tr[0][0] == lo
+            if lost or marg:
+                if not lost and len(tr) > C:                 # :418-436 reached the maximum track length
+                    maxtracks.append((fid, tr))
+                elif len(tr) >= min_meas:
+                    msckf.append((fid, tr))
+                del tracks[fid]
+        room = max(max_slam - n_slam_kept, 0)                # :449-460 the last ones of the list become landmarks
+        new_slam = maxtracks[len(maxtracks) - min(room, len(maxtracks)):] if room else []
+        rest = maxtracks[:len(maxtracks) - len(new_slam)]
+        items += [(fid, 2, tr) for fid, tr in new_slam] + [(fid, 0, tr) for fid, tr in msckf + rest]
+        F, M = len(items), C + 1
+        uv = np.zeros((F, M, 2), dtype=np.float32)
+        slot = -np.ones((F, M), dtype=np.int32)
+        nm = np.zeros(F, dtype=np.int32)
+        for f, (_, _, tr) in enumerate(items):
+            nm[f] = len(tr)
+            for q, (j, m) in enumerate(tr):
+                uv[f, q], slot[f, q] = m, j - lo
+        xn, yn = radtan_undistort(uv[..., 0], uv[..., 1], init["intr"])
+        uvn = np.stack([xn, yn], axis=-1).astype(np.float32)
+        fid = np.array([it[0] for it in items], dtype=np.int64)
+        kind = np.array([it[1] for it in items], dtype=np.int32)
+        pl = np.array([max(plane_of[int(f)], 0) for f in fid], dtype=np.int32) if planes else None
+        out = ses.step(t_k, uv, uvn, slot, nm, fid + FID_OFFSET, kind, pl)
+        slam_ids = {i - FID_OFFSET for i in out["slam_ids"]}
+        for f in slam_ids:
+            tracks.pop(f, None)
+        i = k - C
+        traj[i], posecov[i], counts[i] = out["x16"], out["posecov"], out["counts"]
+        n_feats[i] = [(kind == 0).sum(), (kind == 1).sum(), (kind == 2).sum()]
+    ses.close()
+    times = np.array([t for t, _ in frames[C:]])
+    e_pos, e_ori, nees_p, nees_o = np.zeros(K), np.zeros(K), np.zeros(K), np.zeros(K)
+    for i in range(K):
+        gt = sim.get_state(times[i] + sim.params["calib_camimu_dt"])
+        dp = traj[i, 4:7] - gt["p"]
+        dth = log_so3(quat_2_rot(traj[i, 0:4]) @ quat_2_rot(gt["q"]).T)
+        e_pos[i], e_ori[i] = np.linalg.norm(dp), np.linalg.norm(dth)
+        nees_p[i] = dp @ np.linalg.solve(posecov[i][3:6, 3:6], dp)
+        nees_o[i] = dth @ np.linalg.solve(posecov[i][0:3, 0:3], dth)
+    return dict(times=times, traj=traj, posecov=posecov, counts=counts, n_feats=n_feats, e_pos=e_pos, e_ori=e_ori,
+                nees_pos=nees_p, nees_ori=nees_o, rmse_pos=float(np.sqrt(np.mean(e_pos**2))),
+                rmse_ori_deg=float(np.degrees(np.sqrt(np.mean(e_ori**2)))))

@@ -138,6 +138,7 @@ private:
   friend class StateHelper;
   friend class UpdaterMSCKF;
   friend class UpdaterPlane;
+  friend class UpdaterSLAM;
   friend struct StateTestAccess;  // host_capi.cpp harness: swaps a cloned Vec for a Landmark at the same id
   ovp_ctx *_gpu = nullptr;  // replaces Eigen::MatrixXd _Cov (state/State.h:130)
   std::vector<std::shared_ptr<ov_type::Type>> _variables;
@@ -214,7 +215,7 @@ public:
   // update/UpdaterSLAM.cpp:376-682 (landmarks already in the state)
   void update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
               const std::map<size_t, size_t> &feat2plane);
-  // update/UpdaterSLAM.cpp:66-374, downstream of triangulation (features carry p_FinG)
+  // update/UpdaterSLAM.cpp:66-374; features with uvs_norm are triangulated on the device first, others carry p_FinG
   void delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                     const std::map<size_t, size_t> &feat2plane);
   // update/UpdaterSLAM.cpp:684-706: landmarks anchored in the clone that is about to be marginalised move to the newest one
@@ -225,7 +226,11 @@ protected:
   // anchor-change Jacobian  Phi = H_f,new^-1 [H_x,old | H_f,old | -H_x,new]
   void perform_anchor_change(std::shared_ptr<State> state, std::shared_ptr<ov_type::Landmark> landmark, double new_anchor_timestamp,
                              size_t new_cam_id);
+  // update/UpdaterSLAM.cpp:120-166: triangulation (+ refinement) of the features that carry normalised measurements
+  static void triangulate_on_device(std::shared_ptr<State> state, const ov_core::FeatureInitializerOptions &fio,
+                                    std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec);
   UpdaterOptions _options_slam, _options_aruco;
+  ov_core::FeatureInitializerOptions _featinit;  // ext FeatureInitializer options (the reference keeps an initializer_feat)
   friend struct UpdaterSLAMTestAccess;
 };
 

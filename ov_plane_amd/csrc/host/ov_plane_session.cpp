@@ -1,0 +1,230 @@
+// A filter session over the host mirror: the slice of ov_plane::VioManager::do_feature_propagate_update (core/VioManager.cpp:
+// 330-930) that sequences the updaters around a camera frame - propagate and clone (:348), marginalise the SLAM landmarks that
+// lost their track (:463-485), plane initialisation (:583-588), MSCKF(+plane) update (:670), SLAM update (:676-688), SLAM
+// delayed initialisation (:692), anchor change (:861), marginalisation of the oldest clone (:864-872).  Which track is used
+// when (lost / about to be marginalised / long enough to become a landmark, :360-506) is the caller's tracker-side bookkeeping
+// (ov_plane_amd/closed_loop.py); the covariance lives on the device for the whole session.
+//
+// C interface (ctypes): ovph_session_open / _feed_imu / _step / _close.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <vector>
+
+#include "ov_plane_host.h"
+
+using namespace ov_plane;
+using namespace ov_type;
+
+namespace {
+struct Session {
+  std::shared_ptr<State> state;
+  std::shared_ptr<Propagator> prop;
+  std::unique_ptr<UpdaterMSCKF> msckf;
+  std::unique_ptr<UpdaterSLAM> slam;
+  std::unique_ptr<UpdaterPlane> plane;
+  int C = 0, plane_mode = 0;
+};
+}  // namespace
+
+// Window of C clones (oldest first, 1 / cam_rate apart, the last one cam_dt before t_state), IMU value x16 at t_state, prior P
+// (N = 30 + 6 C, State.cpp order: IMU | dt | extrinsics | intrinsics | clones).  opts_i: use_rk4, do_fej, plane_mode (0 none,
+// 1 MSCKF plane constraints, 2 + planes into the state), plane_min_feat, max_slam_features, feat_rep_slam.
+// opts_d: sigma_w, sigma_a, sigma_wb, sigma_ab, gravity, sigma_px, chi2_mult (MSCKF), chi2_mult (SLAM), sigma_c, cam_dt.
+extern "C" void *ovph_session_open(int C, const double *clone_q, const double *clone_p, const double *calib_q, const double *calib_p,
+                                   const double *intr, const double *imu_x16, double calib_dt, int N, const double *P, double t_state,
+                                   const int *opts_i, const double *opts_d) {
+  auto s = std::make_unique<Session>();
+  s->C = C;
+  s->plane_mode = opts_i[2];
+  StateOptions so;
+  so.use_rk4_integration = opts_i[0] != 0;
+  so.do_fej = opts_i[1] != 0;
+  so.do_calib_camera_pose = so.do_calib_camera_intrinsics = so.do_calib_camera_timeoffset = true;
+  so.max_clone_size = C;
+  so.max_slam_features = opts_i[4];
+  so.feat_rep_slam = (LandmarkRepresentation::Representation)opts_i[5];
+  so.max_state_size = N + 16 + 3 * 16 + 3 * std::max(opts_i[4], 0);
+  so.max_features = 4096;
+  if (s->plane_mode) {
+    so.use_plane_constraint = so.use_plane_constraint_msckf = true;
+    so.use_plane_constraint_slamu = so.use_plane_constraint_slamd = true;
+    so.use_plane_slam_feats = s->plane_mode == 2;
+    so.sigma_constraint = opts_d[8];
+    so.plane_init_min_feat = so.plane_msckf_min_feat = opts_i[3];
+  }
+  auto state = std::make_shared<State>(so);
+  s->state = state;
+  {
+    VectorXd v(7, 1), iv(8, 1);
+    for (int k = 0; k < 4; ++k) v(k) = calib_q[k];
+    for (int k = 0; k < 3; ++k) v(4 + k) = calib_p[k];
+    state->_calib_IMUtoCAM.at(0)->set_value(v);
+    state->_calib_IMUtoCAM.at(0)->set_fej(v);
+    for (int k = 0; k < 8; ++k) iv(k) = intr[k];
+    state->_cam_intrinsics.at(0)->set_value(iv);
+    state->_cam_intrinsics.at(0)->set_fej(iv);
+  }
+  const double w0[3] = {0, 0, 0}, cam_dt = opts_d[9];
+  for (int i = 0; i < C; ++i) {
+    VectorXd a(7, 1);
+    for (int k = 0; k < 4; ++k) a(k) = clone_q[4 * i + k];
+    for (int k = 0; k < 3; ++k) a(4 + k) = clone_p[3 * i + k];
+    state->_imu->pose()->set_value(a);
+    state->_imu->pose()->set_fej(a);
+    state->_timestamp = t_state - cam_dt * (C - i);
+    StateHelper::augment_clone(state, w0);
+  }
+  if (state->max_covariance_size() != N) return nullptr;
+  VectorXd x(16, 1), dtv(1, 1);
+  for (int k = 0; k < 16; ++k) x(k) = imu_x16[k];
+  state->_imu->set_value(x);
+  state->_imu->set_fej(x);
+  dtv(0) = calib_dt;
+  state->_calib_dt_CAMtoIMU->set_value(dtv);
+  state->_calib_dt_CAMtoIMU->set_fej(dtv);
+  state->_timestamp = t_state;
+  {
+    std::vector<std::shared_ptr<Type>> all;
+    all.push_back(state->_imu);
+    all.push_back(state->_calib_dt_CAMtoIMU);
+    all.push_back(state->_calib_IMUtoCAM.at(0));
+    all.push_back(state->_cam_intrinsics.at(0));
+    for (auto &c : state->_clones_IMU) all.push_back(c.second);
+    MatrixXd Pm(N, N);
+    memcpy(Pm.data(), P, sizeof(double) * (size_t)N * N);
+    StateHelper::set_initial_covariance(state, Pm, all);
+  }
+  NoiseManager nm;
+  nm.sigma_w = opts_d[0];
+  nm.sigma_a = opts_d[1];
+  nm.sigma_wb = opts_d[2];
+  nm.sigma_ab = opts_d[3];
+  s->prop = std::make_shared<Propagator>(nm, opts_d[4]);
+  UpdaterOptions um, us;
+  um.sigma_pix = us.sigma_pix = opts_d[5];
+  um.chi2_multipler = opts_d[6];
+  us.chi2_multipler = opts_d[7];
+  ov_core::FeatureInitializerOptions fio;
+  s->msckf = std::make_unique<UpdaterMSCKF>(um, fio);
+  s->slam = std::make_unique<UpdaterSLAM>(us, us, fio);
+  s->plane = std::make_unique<UpdaterPlane>(um, fio);
+  return s.release();
+}
+
+extern "C" void ovph_session_close(void *h) { delete static_cast<Session *>(h); }
+
+extern "C" int ovph_session_feed_imu(void *h, int n, const double *imu7) {
+  auto *s = static_cast<Session *>(h);
+  for (int i = 0; i < n; ++i) {
+    ov_core::ImuData d;
+    d.timestamp = imu7[7 * i];
+    for (int k = 0; k < 3; ++k) {
+      d.wm[k] = imu7[7 * i + 1 + k];
+      d.am[k] = imu7[7 * i + 4 + k];
+    }
+    s->prop->feed_imu(d, s->state->_timestamp);
+  }
+  return 0;
+}
+
+// One camera frame.  Features f = 0..F-1: id gfid[f], kind[f] (0 MSCKF track, 1 new measurement(s) of a SLAM landmark in the
+// state, 2 long track that should become a SLAM landmark), n_meas[f] measurements uv / uv_norm [F][M][2] taken in the window
+// slots clone_slot [F][M] (0 = oldest of the C + 1 clones after cloning, C = this frame), plane[f] (0 = free point).
+// Outputs: counts[0..5] = MSCKF features left after the update (passed the gates), SLAM landmarks updated, initialised,
+// marginalised because their track ended, landmarks in the state, planes in the state; IMU value [16] and pose covariance [36]
+// after the frame; ids of the landmarks in the state (slam_ids, at most slam_cap).
+extern "C" int ovph_session_step(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
+                                 const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
+                                 double *x16, double *posecov36, int slam_cap, long long *slam_ids) {
+  auto *s = static_cast<Session *>(h);
+  auto &state = s->state;
+  s->prop->propagate_and_clone(state, frame_time);  // VioManager.cpp:348
+  std::vector<double> times;
+  for (auto &c : state->_clones_IMU) times.push_back(c.first);
+  std::vector<std::shared_ptr<ov_core::Feature>> f_msckf, f_slam_up, f_slam_new, fextra, fused;
+  std::map<size_t, size_t> feat2plane;
+  std::set<size_t> seen_landmarks;
+  for (int f = 0; f < F; ++f) {
+    auto ft = std::make_shared<ov_core::Feature>();
+    ft->featid = (size_t)gfid[f];
+    for (int q = 0; q < n_meas[f]; ++q) {
+      const int sl = clone_slot[(size_t)f * M + q];
+      if (sl < 0 || sl >= (int)times.size()) return -21;
+      ft->timestamps.push_back(times[sl]);
+      for (int c = 0; c < 2; ++c) {
+        ft->uvs.push_back(uv[((size_t)f * M + q) * 2 + c]);
+        ft->uvs_norm.push_back(uv_norm[((size_t)f * M + q) * 2 + c]);
+      }
+    }
+    if (s->plane_mode && plane && plane[f] > 0) feat2plane[ft->featid] = (size_t)plane[f];
+    if (kind[f] == 1) {
+      if (!state->_features_SLAM.count(ft->featid)) return -22;  // the caller's bookkeeping is out of step with the state
+      seen_landmarks.insert(ft->featid);
+      ft->uvs_norm.clear();  // a landmark needs no triangulation
+      f_slam_up.push_back(ft);
+    } else if (kind[f] == 2) {
+      f_slam_new.push_back(ft);
+    } else {
+      f_msckf.push_back(ft);
+    }
+  }
+  // VioManager.cpp:463-485 landmarks that were not tracked into this frame leave the state
+  int n_marg = 0;
+  for (auto &lm : state->_features_SLAM)
+    if (!seen_landmarks.count(lm.first)) {
+      lm.second->should_marg = true;
+      ++n_marg;
+    }
+  StateHelper::marginalize_slam(state);
+  {  // :487-500 a landmark that was flagged by a failed update is gone now although it is still tracked: its single new
+     // measurement would be a delayed initialisation with one observation, which :112-118 of UpdaterSLAM.cpp drops
+    std::vector<std::shared_ptr<ov_core::Feature>> still;
+    for (auto &ft : f_slam_up)
+      if (state->_features_SLAM.count(ft->featid)) still.push_back(ft);
+    f_slam_up.swap(still);
+  }
+  // :543-600 planar candidates first try to initialise their planes
+  if (s->plane_mode == 2) {
+    std::vector<std::shared_ptr<ov_core::Feature>> fplane, finit_used, rest;
+    for (auto &ft : f_msckf)
+      if (feat2plane.count(ft->featid)) fplane.push_back(ft);
+    s->plane->init_vio_plane(state, fplane, finit_used, feat2plane);
+    std::set<size_t> used;
+    for (auto &ft : finit_used) used.insert(ft->featid);
+    for (auto &ft : f_msckf)
+      if (!used.count(ft->featid)) rest.push_back(ft);
+    f_msckf.swap(rest);
+  }
+  if (getenv("OVP_SESSION_DEBUG"))
+    fprintf(stderr, "[session] t=%.3f n=%d msckf=%zu slam_up=%zu slam_new=%zu landmarks=%zu cap=%d\n", frame_time,
+            state->max_covariance_size(), f_msckf.size(), f_slam_up.size(), f_slam_new.size(), state->_features_SLAM.size(),
+            state->_options.max_state_size);
+  s->msckf->update(state, f_msckf, fextra, fused, feat2plane);  // :670
+  const int n_up = (int)f_slam_up.size();
+  s->slam->update(state, f_slam_up, feat2plane);                // :676-688
+  const size_t before = state->_features_SLAM.size();
+  s->slam->delayed_init(state, f_slam_new, feat2plane);         // :692
+  counts[0] = (int)f_msckf.size();
+  counts[1] = n_up;
+  counts[2] = (int)(state->_features_SLAM.size() - before);
+  counts[3] = n_marg;
+  s->slam->change_anchors(state);             // :861
+  StateHelper::marginalize_old_clone(state);  // :864-872
+  counts[4] = (int)state->_features_SLAM.size();
+  counts[5] = (int)state->_features_PLANE.size();
+  memcpy(x16, state->_imu->value().data(), 16 * sizeof(double));
+  {
+    std::vector<std::shared_ptr<Type>> po;
+    po.push_back(state->_imu->pose());
+    MatrixXd Pp = StateHelper::get_marginal_covariance(state, po);
+    memcpy(posecov36, Pp.data(), 36 * sizeof(double));
+  }
+  int k = 0;
+  for (auto &lm : state->_features_SLAM)
+    if (k < slam_cap) slam_ids[k++] = (long long)lm.first;
+  return 0;
+}

@@ -444,8 +444,8 @@ void UpdaterHelper::measurement_compress_inplace(MatrixXd &H_x, VectorXd &res) {
 }
 
 // ---- update/UpdaterSLAM.cpp ----------------------------------------------------------------------
-UpdaterSLAM::UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_aruco, ov_core::FeatureInitializerOptions &)
-    : _options_slam(options_slam), _options_aruco(options_aruco) {
+UpdaterSLAM::UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_aruco, ov_core::FeatureInitializerOptions &fio)
+    : _options_slam(options_slam), _options_aruco(options_aruco), _featinit(fio) {
   _options_slam.sigma_pix_sq = std::pow(_options_slam.sigma_pix, 2);
   _options_aruco.sigma_pix_sq = std::pow(_options_aruco.sigma_pix, 2);
 }
@@ -631,6 +631,93 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   StateHelper::EKFUpdate(state, Hx_order_big, Hx_big, res_big, R_big);  // :673
 }
 
+// update/UpdaterSLAM.cpp:120-166 (the same block opens UpdaterMSCKF::update and UpdaterPlane::init_vio_plane): features that
+// arrive with normalised measurements are triangulated (+ refined) on the device against the clone window; failures are flagged
+// and leave the vector.  Features whose position was handed over (no uvs_norm) pass through.
+void UpdaterSLAM::triangulate_on_device(std::shared_ptr<State> state, const ov_core::FeatureInitializerOptions &fio,
+                                        std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec) {
+  bool any_norm = false;
+  for (auto &f : feature_vec) any_norm = any_norm || (!f->uvs_norm.empty() && f->uvs_norm.size() == f->uvs.size());
+  if (!any_norm) return;
+  std::map<double, int> clone_slot;
+  std::vector<std::shared_ptr<PoseJPL>> clones;
+  for (const auto &c : state->_clones_IMU) {
+    clone_slot[c.first] = (int)clones.size();
+    clones.push_back(c.second);
+  }
+  const int C = (int)clones.size(), F = (int)feature_vec.size();
+  std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
+  std::vector<int> cid(C);
+  for (int i = 0; i < C; ++i) {
+    memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
+    memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
+    memcpy(&cqf[4 * i], clones[i]->quat_fej(), 4 * sizeof(double));
+    memcpy(&cpf[3 * i], clones[i]->pos_fej(), 3 * sizeof(double));
+    cid[i] = clones[i]->id();
+  }
+  ovp_state_tables st;
+  st.n_state = ovp_cov_size(state->_gpu);
+  st.n_clones = C;
+  st.clone_q = cq.data();
+  st.clone_p = cp.data();
+  st.clone_q_fej = cqf.data();
+  st.clone_p_fej = cpf.data();
+  st.clone_id = cid.data();
+  auto calib = state->_calib_IMUtoCAM.at(0);
+  auto intr = state->_cam_intrinsics.at(0);
+  memcpy(st.calib_q, calib->quat(), 4 * sizeof(double));
+  memcpy(st.calib_p, calib->pos(), 3 * sizeof(double));
+  st.calib_id = calib->id();
+  memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
+  st.intr_id = intr->id();
+  st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
+  gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
+  int M = 1;
+  for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
+  std::vector<float> uv((size_t)F * M * 2, 0.f), uvn((size_t)F * M * 2, 0.f);
+  std::vector<int> cidx((size_t)F * M, -1), nm(F);
+  std::vector<double> pf((size_t)F * 3);
+  for (int f = 0; f < F; ++f) {
+    nm[f] = (int)feature_vec[f]->timestamps.size();
+    for (int k = 0; k < nm[f]; ++k) {
+      cidx[(size_t)f * M + k] = clone_slot.at(feature_vec[f]->timestamps[k]);
+      uv[((size_t)f * M + k) * 2] = feature_vec[f]->uvs[2 * k];
+      uv[((size_t)f * M + k) * 2 + 1] = feature_vec[f]->uvs[2 * k + 1];
+    }
+    for (size_t k = 0; k < feature_vec[f]->uvs_norm.size(); ++k) uvn[(size_t)f * M * 2 + k] = feature_vec[f]->uvs_norm[k];
+    memcpy(&pf[3 * f], feature_vec[f]->p_FinG, 3 * sizeof(double));
+  }
+  ovp_feature_batch fb{F, M, uv.data(), cidx.data(), nm.data(), pf.data()};
+  gpu_check2(ovp_batch_upload(state->_gpu, &fb), "ovp_batch_upload");
+  ovp_triang_opts to;
+  to.refine_features = fio.refine_features ? 1 : 0;
+  to.max_runs = fio.max_runs;
+  to.init_lamda = fio.init_lamda;
+  to.max_lamda = fio.max_lamda;
+  to.min_dx = fio.min_dx;
+  to.min_dcost = fio.min_dcost;
+  to.lam_mult = fio.lam_mult;
+  to.min_dist = fio.min_dist;
+  to.max_dist = fio.max_dist;
+  to.max_baseline = fio.max_baseline;
+  to.max_cond_number = fio.max_cond_number;
+  std::vector<uint8_t> okv(F, 0);
+  gpu_check2(ovp_triangulate(state->_gpu, &to, uvn.data(), pf.data(), okv.data()), "ovp_triangulate");
+  size_t f = 0;
+  auto it1 = feature_vec.begin();
+  while (it1 != feature_vec.end()) {
+    const bool had_norm = !(*it1)->uvs_norm.empty();
+    if (had_norm && !okv[f]) {
+      (*it1)->to_delete = true;  // :161-165
+      it1 = feature_vec.erase(it1);
+    } else {
+      if (had_norm) memcpy((*it1)->p_FinG, &pf[3 * f], 3 * sizeof(double));
+      it1++;
+    }
+    ++f;
+  }
+}
+
 void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                                const std::map<size_t, size_t> &feat2plane) {
   if (feature_vec.empty()) return;
@@ -645,7 +732,10 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
       it0++;
     }
   }
-  // (triangulation and the joint point/plane refinement :120-202 are upstream: features carry p_FinG)
+  // :120-166 triangulation of the features that come with normalised measurements (the joint point / plane refinement
+  // :168-202 is not repeated here: positions handed over, or triangulated, are used as they are)
+  triangulate_on_device(state, _featinit, feature_vec);
+  if (feature_vec.empty()) return;
   // a p_FinG that came without its anchor gets what ext single_triangulation would have left behind, with the poses as they
   // are now (the initialisations below move them)
   for (auto &fp : feature_vec) {

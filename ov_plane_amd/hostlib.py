@@ -426,3 +426,62 @@ def run_change_anchors(sc, rep, p_FinA, p_FinA_fej):
     out["anchor_ci"] = anchor.value
     out["P"] = np.ascontiguousarray(out["P"].T)
     return out
+
+
+class Session:
+    """A filter session of the C++ host mirror (csrc/host/ov_plane_session.cpp: propagate -> marginalise lost landmarks ->
+    plane init -> MSCKF update -> SLAM update -> SLAM delayed init -> anchor change -> marginalise the oldest clone), the
+    covariance resident on the device between frames.  init: the dict of closed_loop.initial_state."""
+
+    def __init__(self, init, po, sigma_px=1.0, chi2_mult=1.0, chi2_mult_slam=1.0, plane_mode=0, plane_min_feat=20, sigma_c=0.01,
+                 max_slam=0, feat_rep_slam=0, cam_dt=0.1):
+        L = lib()
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        x = init["x"]
+        x16 = f64(np.concatenate([x["q"], x["p"], x["v"], x["bg"], x["ba"]]))
+        oi = np.array([int(po["use_rk4"]), int(po["do_fej"]), plane_mode, plane_min_feat, max_slam, feat_rep_slam], dtype=np.int32)
+        od = f64([po["sigma_w"], po["sigma_a"], po["sigma_wb"], po["sigma_ab"], po["gravity_mag"], sigma_px, chi2_mult,
+                  chi2_mult_slam, sigma_c, cam_dt])
+        P = np.asfortranarray(init["P"])
+        L.ovph_session_open.restype = C.c_void_p
+        self._L = L
+        self.C = int(init["C"])
+        self.max_slam = max_slam
+        self._h = L.ovph_session_open(C.c_int(self.C), p(f64(init["clone_q"])), p(f64(init["clone_p"])), p(f64(init["calib_q"])),
+                                      p(f64(init["calib_p"])), p(f64(init["intr"])), p(x16), C.c_double(init["dt"]),
+                                      C.c_int(int(init["N"])), p(P), C.c_double(init["t_state"]), p(oi), p(od))
+        if not self._h:
+            raise RuntimeError("ovph_session_open failed")
+
+    def feed_imu(self, imu):
+        imu = np.ascontiguousarray(imu, dtype=np.float64).reshape(-1, 7)
+        self._L.ovph_session_feed_imu(C.c_void_p(self._h), C.c_int(imu.shape[0]), imu.ctypes.data_as(C.c_void_p))
+
+    def step(self, frame_time, uv, uv_norm, slot, n_meas, fid, kind, plane=None):
+        """One camera frame (arrays as in ovph_session_step).  Returns dict(counts, x16, posecov [6,6], slam_ids)."""
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        F = int(len(n_meas))
+        M = int(uv.shape[1]) if F else 1
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(F, M, 2)
+        uvn = np.ascontiguousarray(uv_norm, dtype=np.float32).reshape(F, M, 2)
+        slot = np.ascontiguousarray(slot, dtype=np.int32).reshape(F, M)
+        nm = np.ascontiguousarray(n_meas, dtype=np.int32)
+        gf = np.ascontiguousarray(fid, dtype=np.int64)
+        kd = np.ascontiguousarray(kind, dtype=np.int32)
+        pl = np.ascontiguousarray(plane if plane is not None else np.zeros(F), dtype=np.int32)
+        counts = np.zeros(6, dtype=np.int32)
+        x16, pc = np.zeros(16), np.zeros(36)
+        cap = max(self.max_slam, 1) + 8
+        ids = -np.ones(cap, dtype=np.int64)
+        self._L.ovph_session_step.restype = C.c_int
+        rc = self._L.ovph_session_step(C.c_void_p(self._h), C.c_double(frame_time), C.c_int(F), C.c_int(M), p(uv), p(uvn), p(slot),
+                                       p(nm), p(gf), p(kd), p(pl), p(counts), p(x16), p(pc), C.c_int(cap), p(ids))
+        if rc != 0:
+            raise RuntimeError("ovph_session_step failed with %d" % rc)
+        return dict(counts=counts, x16=x16, posecov=pc.reshape(6, 6), slam_ids=[int(i) for i in ids[:counts[4]]])
+
+    def close(self):
+        if self._h:
+            self._L.ovph_session_close(C.c_void_p(self._h))
+            self._h = None
