@@ -154,12 +154,14 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
 
 
 def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, planes=0, plane_min_feat=6, sigma_c=0.01,
-                max_slam=0, feat_rep_slam=0, min_meas=3):
+                max_slam=0, feat_rep_slam=0, min_meas=3, out_dir=None):
     """Closed loop through hostlib.Session, frame by frame, with the tracker-side bookkeeping of core/VioManager.cpp:360-506:
     a track is an MSCKF feature once it is lost or reaches back to the clone about to be marginalised; a track that spans the
     whole window (more than max_clone_size measurements) becomes a SLAM landmark while there is room (max_slam), and from then
     on every new measurement of it is a SLAM update until it is no longer seen (the session then marginalises it).
-    feat_rep_slam: ext LandmarkRepresentation of the landmarks (0 GLOBAL_3D ... 5 ANCHORED_INVERSE_DEPTH_SINGLE)."""
+    feat_rep_slam: ext LandmarkRepresentation of the landmarks (0 GLOBAL_3D ... 5 ANCHORED_INVERSE_DEPTH_SINGLE).
+    out_dir: write state_estimate.txt / state_deviation.txt / state_groundtruth.txt / timing.txt there, in the formats a run of
+    the reference's simulation leaves behind (what its results/ scripts and ov_eval read)."""
     from . import hostlib
     from .sim import log_so3
     from .synth import PROP_OPTS, quat_2_rot
@@ -173,6 +175,16 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
     ses = hostlib.Session(init, po, sigma_px=sigma_px, chi2_mult=chi2_mult, plane_mode=planes, plane_min_feat=plane_min_feat,
                           sigma_c=sigma_c, max_slam=max_slam, feat_rep_slam=feat_rep_slam, cam_dt=1.0 / sim.params["sim_freq_cam"])
     ses.feed_imu(imu)
+    if out_dir is not None:
+        import os
+
+        os.makedirs(out_dir, exist_ok=True)
+        ses.open_files(*(os.path.join(out_dir, n) for n in ("state_estimate.txt", "state_deviation.txt", "state_groundtruth.txt",
+                                                            "timing.txt")))
+    from .sim import P_IINC, R_ITOC
+    from .synth import rot_2_quat
+
+    truth_tail = np.concatenate([[sim.params["calib_camimu_dt"]], sim.intr, rot_2_quat(R_ITOC), P_IINC])
     tracks = {}
     for k in range(C):
         for fid, uv in frames[k][1].items():
@@ -223,7 +235,9 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
         fid = np.array([it[0] for it in items], dtype=np.int64)
         kind = np.array([it[1] for it in items], dtype=np.int32)
         pl = np.array([max(plane_of[int(f)], 0) for f in fid], dtype=np.int32) if planes else None
-        out = ses.step(t_k, uv, uvn, slot, nm, fid + FID_OFFSET, kind, pl)
+        gt = sim.get_state(t_k + sim.params["calib_camimu_dt"])
+        truth = np.concatenate([[gt["t"]], gt["q"], gt["p"], gt["v"], gt["bg"], gt["ba"], truth_tail])
+        out = ses.step(t_k, uv, uvn, slot, nm, fid + FID_OFFSET, kind, pl, truth)
         slam_ids = {i - FID_OFFSET for i in out["slam_ids"]}
         for f in slam_ids:
             tracks.pop(f, None)

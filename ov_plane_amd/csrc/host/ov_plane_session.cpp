@@ -14,7 +14,11 @@
 #include <set>
 #include <vector>
 
+#include <chrono>
+#include <fstream>
+
 #include "ov_plane_host.h"
+#include "ov_plane_io.h"
 
 using namespace ov_plane;
 using namespace ov_type;
@@ -27,7 +31,13 @@ struct Session {
   std::unique_ptr<UpdaterSLAM> slam;
   std::unique_ptr<UpdaterPlane> plane;
   int C = 0, plane_mode = 0;
+  // what a run of the reference leaves behind (ros/ROSVisualizerHelper.cpp:152-302, core/VioManager.cpp:110-118, 911-927)
+  std::ofstream of_est, of_std, of_gt, of_timing;
+  bool files = false;
 };
+double seconds_since(const std::chrono::steady_clock::time_point &t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 }  // namespace
 
 // Window of C clones (oldest first, 1 / cam_rate apart, the last one cam_dt before t_state), IMU value x16 at t_state, prior P
@@ -117,6 +127,25 @@ extern "C" void *ovph_session_open(int C, const double *clone_q, const double *c
 
 extern "C" void ovph_session_close(void *h) { delete static_cast<Session *>(h); }
 
+// Output files of a run, in the reference's formats: state estimate / standard deviation / groundtruth (one line per frame,
+// written by ovph_session_step when it is handed the true state) and the timing CSV.  Empty or null path = not written.
+extern "C" int ovph_session_open_files(void *h, const char *est, const char *stdev, const char *gt, const char *timing) {
+  auto *s = static_cast<Session *>(h);
+  auto open = [](std::ofstream &f, const char *p) {
+    if (p && *p) f.open(p, std::ofstream::out | std::ofstream::trunc);
+    return !(p && *p) || f.is_open();
+  };
+  if (!open(s->of_est, est) || !open(s->of_std, stdev) || !open(s->of_gt, gt) || !open(s->of_timing, timing)) return -1;
+  // header line as the visualizer writes it when it opens the files (ros/ROS1Visualizer.cpp:158-167)
+  const char *hdr = "# timestamp(s) q p v bg ba cam_imu_dt num_cam cam0_k cam0_d cam0_rot cam0_trans .... etc";
+  if (s->of_est.is_open()) s->of_est << hdr << std::endl;
+  if (s->of_std.is_open()) s->of_std << hdr << std::endl;
+  if (s->of_gt.is_open()) s->of_gt << hdr << std::endl;
+  if (s->of_timing.is_open()) write_timing_header(s->of_timing, s->state->_options);
+  s->files = true;
+  return 0;
+}
+
 extern "C" int ovph_session_feed_imu(void *h, int n, const double *imu7) {
   auto *s = static_cast<Session *>(h);
   for (int i = 0; i < n; ++i) {
@@ -137,12 +166,22 @@ extern "C" int ovph_session_feed_imu(void *h, int n, const double *imu7) {
 // Outputs: counts[0..5] = MSCKF features left after the update (passed the gates), SLAM landmarks updated, initialised,
 // marginalised because their track ended, landmarks in the state, planes in the state; IMU value [16] and pose covariance [36]
 // after the frame; ids of the landmarks in the state (slam_ids, at most slam_cap).
+// truth (or NULL) feeds the groundtruth file: [0..16] t, q, p, v, bg, ba of the simulator at this frame, [17] true camera time
+// offset, [18..25] true intrinsics, [26..32] true extrinsics (q_ItoC, p_IinC).
 extern "C" int ovph_session_step(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
                                  const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
-                                 double *x16, double *posecov36, int slam_cap, long long *slam_ids) {
+                                 double *x16, double *posecov36, int slam_cap, long long *slam_ids, const double *truth17) {
   auto *s = static_cast<Session *>(h);
   auto &state = s->state;
+  TimingRecord tr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto t_prev = t_start;
+  auto lap = [&](double &field) {
+    field = seconds_since(t_prev);
+    t_prev = std::chrono::steady_clock::now();
+  };
   s->prop->propagate_and_clone(state, frame_time);  // VioManager.cpp:348
+  lap(tr.prop);
   std::vector<double> times;
   for (auto &c : state->_clones_IMU) times.push_back(c.first);
   std::vector<std::shared_ptr<ov_core::Feature>> f_msckf, f_slam_up, f_slam_new, fextra, fused;
@@ -199,21 +238,40 @@ extern "C" int ovph_session_step(void *h, double frame_time, int F, int M, const
       if (!used.count(ft->featid)) rest.push_back(ft);
     f_msckf.swap(rest);
   }
+  lap(tr.planeinit);
   if (getenv("OVP_SESSION_DEBUG"))
     fprintf(stderr, "[session] t=%.3f n=%d msckf=%zu slam_up=%zu slam_new=%zu landmarks=%zu cap=%d\n", frame_time,
             state->max_covariance_size(), f_msckf.size(), f_slam_up.size(), f_slam_new.size(), state->_features_SLAM.size(),
             state->_options.max_state_size);
   s->msckf->update(state, f_msckf, fextra, fused, feat2plane);  // :670
+  lap(tr.msckf);
   const int n_up = (int)f_slam_up.size();
   s->slam->update(state, f_slam_up, feat2plane);                // :676-688
+  lap(tr.slam_update);
   const size_t before = state->_features_SLAM.size();
   s->slam->delayed_init(state, f_slam_new, feat2plane);         // :692
+  lap(tr.slam_delay);
   counts[0] = (int)f_msckf.size();
   counts[1] = n_up;
   counts[2] = (int)(state->_features_SLAM.size() - before);
   counts[3] = n_marg;
   s->slam->change_anchors(state);             // :861
   StateHelper::marginalize_old_clone(state);  // :864-872
+  lap(tr.marg);
+  tr.total = seconds_since(t_start);
+  tr.timestamp_inI = state->_timestamp + state->_calib_dt_CAMtoIMU->value()(0);  // :911-914
+  if (s->of_timing.is_open()) write_timing_row(s->of_timing, state->_options, tr);
+  if (s->files && truth17 && (s->of_est.is_open() || s->of_std.is_open() || s->of_gt.is_open())) {
+    SimTruth st;
+    memcpy(st.state_gt, truth17, sizeof(st.state_gt));
+    st.calib_camimu_dt = truth17[17];
+    memcpy(st.intrinsics, truth17 + 18, sizeof(st.intrinsics));
+    memcpy(st.extrinsics, truth17 + 26, sizeof(st.extrinsics));
+    std::ofstream null_stream;
+    ROSVisualizerHelper::sim_save_total_state_to_file(state, &st, s->of_est.is_open() ? s->of_est : null_stream,
+                                                      s->of_std.is_open() ? s->of_std : null_stream,
+                                                      s->of_gt.is_open() ? s->of_gt : null_stream);
+  }
   counts[4] = (int)state->_features_SLAM.size();
   counts[5] = (int)state->_features_PLANE.size();
   memcpy(x16, state->_imu->value().data(), 16 * sizeof(double));

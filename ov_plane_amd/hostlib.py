@@ -458,8 +458,15 @@ class Session:
         imu = np.ascontiguousarray(imu, dtype=np.float64).reshape(-1, 7)
         self._L.ovph_session_feed_imu(C.c_void_p(self._h), C.c_int(imu.shape[0]), imu.ctypes.data_as(C.c_void_p))
 
-    def step(self, frame_time, uv, uv_norm, slot, n_meas, fid, kind, plane=None):
-        """One camera frame (arrays as in ovph_session_step).  Returns dict(counts, x16, posecov [6,6], slam_ids)."""
+    def open_files(self, est=None, std=None, gt=None, timing=None):
+        """Output files in the reference's formats (state estimate / standard deviations / groundtruth, timing CSV)."""
+        enc = lambda s: (s or "").encode()  # noqa: E731
+        if self._L.ovph_session_open_files(C.c_void_p(self._h), enc(est), enc(std), enc(gt), enc(timing)) != 0:
+            raise RuntimeError("ovph_session_open_files failed")
+
+    def step(self, frame_time, uv, uv_norm, slot, n_meas, fid, kind, plane=None, truth=None):
+        """One camera frame (arrays as in ovph_session_step).  Returns dict(counts, x16, posecov [6,6], slam_ids).
+        truth [33]: simulator state, time offset, intrinsics and extrinsics for the groundtruth file (open_files)."""
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         F = int(len(n_meas))
         M = int(uv.shape[1]) if F else 1
@@ -476,7 +483,8 @@ class Session:
         ids = -np.ones(cap, dtype=np.int64)
         self._L.ovph_session_step.restype = C.c_int
         rc = self._L.ovph_session_step(C.c_void_p(self._h), C.c_double(frame_time), C.c_int(F), C.c_int(M), p(uv), p(uvn), p(slot),
-                                       p(nm), p(gf), p(kd), p(pl), p(counts), p(x16), p(pc), C.c_int(cap), p(ids))
+                                       p(nm), p(gf), p(kd), p(pl), p(counts), p(x16), p(pc), C.c_int(cap), p(ids),
+                                       p(np.ascontiguousarray(truth, dtype=np.float64)) if truth is not None else None)
         if rc != 0:
             raise RuntimeError("ovph_session_step failed with %d" % rc)
         return dict(counts=counts, x16=x16, posecov=pc.reshape(6, 6), slam_ids=[int(i) for i in ids[:counts[4]]])

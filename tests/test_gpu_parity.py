@@ -1534,7 +1534,7 @@ def test_closed_loop_vio_on_simulated_data_is_accurate_and_consistent(hiplib, pl
 
 
 @pytest.mark.parametrize("planes,max_slam,rep", [(0, 0, 0), (2, 0, 0), (0, 25, 0), (2, 25, 0), (0, 25, 2), (0, 25, 4), (0, 25, 5)])
-def test_filter_session_with_slam_landmarks_planes_and_anchor_changes(hiplib, planes, max_slam, rep):
+def test_filter_session_with_slam_landmarks_planes_and_anchor_changes(hiplib, tmp_path, planes, max_slam, rep):
     """csrc/host/ov_plane_session.cpp: the VioManager slice (propagate -> marginalise lost landmarks -> plane init -> MSCKF update
     -> SLAM update -> delayed init -> anchor change -> marginalise the oldest clone) frame by frame with the covariance resident
     on the device, driven by the simulator.  Long tracks become SLAM landmarks (GLOBAL_3D, ANCHORED_3D, ANCHORED_MSCKF_INVERSE_DEPTH
@@ -1547,8 +1547,23 @@ def test_filter_session_with_slam_landmarks_planes_and_anchor_changes(hiplib, pl
     from ov_plane_amd.sim import Simulator, synthetic_trajectory
 
     sim = Simulator(synthetic_trajectory(duration=30.0), num_pts=100, num_pts_plane=100)
-    r = closed_loop.run_session(sim, n_frames=120, C=11, planes=planes, max_slam=max_slam, feat_rep_slam=rep)
+    out_dir = str(tmp_path) if (planes, max_slam, rep) == (2, 25, 0) else None
+    r = closed_loop.run_session(sim, n_frames=120, C=11, planes=planes, max_slam=max_slam, feat_rep_slam=rep, out_dir=out_dir)
     c = r["counts"]
+    if out_dir:
+        # the files a run of the reference's simulation leaves behind: one line per frame, groundtruth and estimate aligned
+        est = np.loadtxt(os.path.join(out_dir, "state_estimate.txt"))
+        std = np.loadtxt(os.path.join(out_dir, "state_deviation.txt"))
+        gt = np.loadtxt(os.path.join(out_dir, "state_groundtruth.txt"))
+        assert est.shape[0] == std.shape[0] == gt.shape[0] == 120 and est.shape[1] == gt.shape[1]
+        assert np.abs(est[:, 0] - r["times"]).max() < 5e-3 and np.abs(est[:, 1:8] - r["traj"][:, 0:7]).max() < 1e-5
+        assert np.abs(np.linalg.norm(est[:, 5:8] - gt[:, 5:8], axis=1) - r["e_pos"]).max() < 1e-5
+        assert (std[:, 1:] >= 0).all() and np.abs(std[:, 4:7] - np.sqrt(np.stack([np.diag(P)[3:6] for P in r["posecov"]]))).max() < 1e-5
+        with open(os.path.join(out_dir, "timing.txt")) as fh:
+            lines = fh.read().strip().split("\n")
+        assert lines[0].startswith("#") and "slam update" in lines[0] and len(lines) == 121
+        tm = np.array([[float(v) for v in ln.split(",")] for ln in lines[1:]])
+        assert (tm[:, 1:] >= 0).all() and np.abs(tm[:, 1:-1].sum(axis=1) - tm[:, -1]).max() < 2e-3
     assert r["rmse_pos"] < 0.15 and r["e_pos"].max() < 0.3, (r["rmse_pos"], r["e_pos"].max())
     assert r["rmse_ori_deg"] < 0.3, r["rmse_ori_deg"]
     assert 0.2 < r["nees_pos"].mean() < 9.0 and 0.2 < r["nees_ori"].mean() < 9.0, (r["nees_pos"].mean(), r["nees_ori"].mean())
