@@ -428,6 +428,18 @@ def run_change_anchors(sc, rep, p_FinA, p_FinA_fej):
     return out
 
 
+def load_trajectory(path, cap=200000):
+    """Trajectory file (`t tx ty tz qx qy qz qw`, '#' comments) through the C++ reader of csrc/host/ov_plane_io.cpp
+    (sim/Simulator.cpp load_data; data/udel_arl_short.txt is such a file).  Returns [n, 8]."""
+    out = np.zeros((cap, 8))
+    L = lib()
+    L.ovph_load_trajectory.restype = C.c_int
+    n = L.ovph_load_trajectory(str(path).encode(), out.ctypes.data_as(C.c_void_p), C.c_int(cap))
+    if n < 0:
+        raise FileNotFoundError(path)
+    return out[:min(n, cap)].copy()
+
+
 class Session:
     """A filter session of the C++ host mirror (csrc/host/ov_plane_session.cpp: propagate -> marginalise lost landmarks ->
     plane init -> MSCKF update -> SLAM update -> SLAM delayed init -> anchor change -> marginalise the oldest clone), the

@@ -1576,3 +1576,21 @@ def test_filter_session_with_slam_landmarks_planes_and_anchor_changes(hiplib, tm
         assert c[-1, 5] >= 1
     if planes == 0:
         assert c[:, 5].sum() == 0
+
+
+def test_filter_session_on_the_reference_dataset_excerpt(hiplib):
+    """The reference's default simulation dataset (first 60 s of data/udel_arl_short.txt, committed under tests/golden/) through
+    the C++ trajectory loader, the restated simulator and the filter session with SLAM landmarks and planes: 30 s of estimation
+    at the dataset's 1.2 m/s."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import closed_loop, hostlib
+    from ov_plane_amd.sim import Simulator
+
+    traj = hostlib.load_trajectory(os.path.join(GOLD, "udel_arl_short_60s.txt"))
+    sim = Simulator(traj, num_pts=100, num_pts_plane=100)
+    r = closed_loop.run_session(sim, n_frames=300, C=11, planes=2, max_slam=25)
+    assert r["rmse_pos"] < 0.3 and r["rmse_ori_deg"] < 0.5, (r["rmse_pos"], r["rmse_ori_deg"])
+    assert 0.2 < r["nees_pos"].mean() < 9.0 and 0.2 < r["nees_ori"].mean() < 9.0, (r["nees_pos"].mean(), r["nees_ori"].mean())
+    assert r["counts"][:, 1].sum() > 10 * 300

@@ -87,3 +87,31 @@ def test_simulator_world_and_measurements(traj):
     assert np.abs(wm - acc[2]).max() < 6 * 1.6968e-4 * 20 + 1e-3
     assert np.abs(am - acc[0] @ (acc[5] + np.array([0, 0, 9.81]))).max() < 6 * 2e-3 * 20 + 1e-2
     assert np.linalg.norm(sim.true_bias_gyro) > 0 and len(sim.hist_true_bias_time) == len(imu) + 2
+
+
+def test_simulator_on_the_reference_dataset_excerpt():
+    """tests/golden/udel_arl_short_60s.txt = the first 60 s of the reference's default simulation dataset
+    (data/udel_arl_short.txt, launch/simulation.launch:39), read by the C++ loader: 20 Hz poses -> 0.05 s control points, the
+    simulation starts where the platform has moved sim_distance_threshold (it stands still at first), the box of planes
+    encloses the path."""
+    import os
+
+    from ov_plane_amd import hostlib
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "udel_arl_short_60s.txt")
+    traj = hostlib.load_trajectory(path)
+    assert traj.shape == (1200, 8) and abs(traj[0, 0] - 1550864017.67095) < 1e-4
+    assert np.abs(np.linalg.norm(traj[:, 4:8], axis=1) - 1).max() < 1e-5
+    assert np.abs(traj - np.loadtxt(path)).max() < 1e-9
+    sim = Simulator(traj, num_pts=40, num_pts_plane=40)
+    assert abs(sim.spline.dt - 0.05) < 1e-3
+    assert 5.0 < sim.timestamp - sim.spline.get_start_time() < 8.0      # it stands still for the first seconds
+    lo = np.min([np.min([p.tl, p.tr, p.bl, p.br], axis=0) for p in sim.planes], axis=0)
+    hi = np.max([np.max([p.tl, p.tr, p.bl, p.br], axis=0) for p in sim.planes], axis=0)
+    pos = sim.traj_data[:, 1:4]
+    assert (pos.min(axis=0) > lo).all() and (pos.max(axis=0) < hi).all()
+    c = None
+    while c is None:
+        sim.get_next_imu()
+        c = sim.get_next_cam()
+    assert len(c[1]) == 80
