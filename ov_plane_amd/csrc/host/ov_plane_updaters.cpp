@@ -469,8 +469,15 @@ static void clean_old_measurements(ov_core::Feature &ft, const std::map<double, 
   ft.uvs_norm = uvn2;
 }
 
-static double chi2_host(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &order, const MatrixXd &H, const VectorXd &res) {
-  MatrixXd P_marg = StateHelper::get_marginal_covariance(state, order);
+// P_full: the covariance downloaded once by the caller (it does not change inside UpdaterSLAM::update's gate loop, so the
+// per-feature StateHelper::get_marginal_covariance of :526 becomes a host-side gather instead of a device round trip each)
+static double chi2_host(const MatrixXd &P_full, const std::vector<std::shared_ptr<Type>> &order, const MatrixXd &H, const VectorXd &res) {
+  std::vector<int> gid;
+  for (const auto &v : order)
+    for (int k = 0; k < v->size(); ++k) gid.push_back(v->id() + k);
+  MatrixXd P_marg((int)gid.size(), (int)gid.size());
+  for (size_t b = 0; b < gid.size(); ++b)
+    for (size_t a = 0; a < gid.size(); ++a) P_marg((int)a, (int)b) = P_full(gid[a], gid[b]);
   const int rows = H.rows(), cols = H.cols();
   MatrixXd HP(rows, cols);
   for (int k = 0; k < cols; ++k)
@@ -531,6 +538,8 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
     std::vector<std::shared_ptr<Type>> order;
   };
   std::vector<Blk> blocks;
+  if (feature_vec.empty()) return;
+  const MatrixXd P_full = StateHelper::get_full_covariance(state);  // one download serves every gate below
   auto it2 = feature_vec.begin();
   while (it2 != feature_vec.end()) {
     std::shared_ptr<Landmark> landmark = state->_features_SLAM.at((*it2)->featid);
@@ -580,13 +589,13 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
       Hxf_order.push_back(landmark);
     };
     build();
-    double chi2 = chi2_host(state, Hxf_order, H_xf, res);  // :529-532
+    double chi2 = chi2_host(P_full, Hxf_order, H_xf, res);  // :529-532
     double chi2_check = ovp_chi2_quantile_095(res.rows());
     if (feat.planeid != 0 && chi2 > chi2_multipler * chi2_check) {  // :547-609 fallback without the plane
       feat.planeid = 0;
       state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;
       build();
-      chi2 = chi2_host(state, Hxf_order, H_xf, res);
+      chi2 = chi2_host(P_full, Hxf_order, H_xf, res);
       chi2_check = ovp_chi2_quantile_095(res.rows());
     }
     if (chi2 > chi2_multipler * chi2_check) {  // :596-619
