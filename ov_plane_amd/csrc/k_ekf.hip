@@ -178,6 +178,33 @@ __global__ void k_gather_marginal(const double* __restrict__ P, int ldp, const i
   if (k < m) out[(size_t)i * m + k] = P[(size_t)cols[i] * ldp + cols[k]];
 }
 
+// Sub-state update (N above the tile factorization's limit): out[i*ldo + k] = P[ids[i]][ids[k]] ; G[r*ldg + k] = P[r][ids[k]] ;
+// C = A - B ; P -= D.
+__global__ void k_gather_block(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int m,
+                               double* __restrict__ out, int ldo) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k < m) out[(size_t)i * ldo + k] = P[(size_t)ids[i] * ldp + ids[k]];
+}
+__global__ void k_gather_cols(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int n, int m,
+                              double* __restrict__ G, int ldg) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (k < m && r < n) G[(size_t)r * ldg + k] = P[(size_t)r * ldp + ids[k]];
+}
+__global__ void k_mat_sub(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int rows, int cols,
+                          int ld) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k < cols && i < rows) C[(size_t)i * ld + k] = A[(size_t)i * ld + k] - B[(size_t)i * ld + k];
+}
+// P -= D on the lower triangle, mirrored (the reference mirrors its upper triangle the same way, StateHelper.cpp:171-172)
+__global__ void k_sub_sym(double* __restrict__ P, const double* __restrict__ D, int n, int ld) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k <= i && i < n) {
+    const double v = P[(size_t)i * ld + k] - D[(size_t)i * ld + k];
+    P[(size_t)i * ld + k] = v;
+    P[(size_t)k * ld + i] = v;
+  }
+}
+
 // StateHelper::clone: P[new..new+sz) rows/cols = copies of [src..src+sz)
 __global__ void k_cov_clone(double* __restrict__ P, int ldp, int n_old, int src, int sz) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -364,6 +391,23 @@ hipError_t ovp_launch_cov_finish(const double* Y, int n, int ld, const double* b
 hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out,
                                       hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_gather_marginal, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, cols, m, out);
+  return hipGetLastError();
+}
+
+hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_gather_block, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_gather_cols, dim3((m + 127) / 128, n), dim3(128), 0, stream, P, ldp, ids, n, m, G, ldg);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_sub_sym, dim3((n + 127) / 128, n), dim3(128), 0, stream, P, D, n, ld);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_mat_sub, dim3((cols + 127) / 128, rows), dim3(128), 0, stream, A, B, C, rows, cols, ld);
   return hipGetLastError();
 }
 

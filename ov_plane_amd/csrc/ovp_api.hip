@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -18,6 +19,10 @@ extern "C" {
 hipError_t ovp_launch_scatter_gram(const double* Acc, const double* bcc, int cols, const int* col_ids, double* Ab,
                                    int lda, int n, hipStream_t stream);
 hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out, hipStream_t stream);
+hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream);
+hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream);
+hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream);
+hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream);
 hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, hipStream_t stream);
 hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, int n_old, int id, int sz,
                                       hipStream_t stream);
@@ -185,6 +190,11 @@ struct ovp_ctx {
   int* idbuf = nullptr;      // scratch ints (ids)
   double* smallbuf = nullptr;  // scratch doubles (Phi, Q, CPT, PCP, marginal)
   size_t small_cap = 0;
+  // sub-state update (n above the tile factorization's limit): involved state columns and six ns x ns scratch matrices
+  int* sub_ids = nullptr;
+  int sub_ns = 0;
+  std::vector<int> h_clone_id;  // host copy of the clone columns (ovp_state_upload)
+  double* sub_buf = nullptr;
   // pinned host staging
   double *h_dx = nullptr, *h_chi2 = nullptr;
   unsigned char* h_accept = nullptr;
@@ -343,7 +353,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
                  c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
-                 c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d};
+                 c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -477,6 +487,7 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
   fp.cal = c->cal;
   c->calib_id = st->calib_id;
   c->intr_id = st->intr_id;
+  c->h_clone_id.assign(st->clone_id, st->clone_id + C);
   c->fp.fisheye = st->cam_fisheye ? 1 : 0;
   // column map for the assembly kernel (calibration columns are enabled per update via the opts)
   std::vector<ovp::ColMap> cm(c->n_max);
@@ -602,10 +613,54 @@ extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
 }
 
 // ---- the update step ---------------------------------------------------------------------------
+// States above the tile factorization's limit (N > 288: e.g. 30 clones plus 50 landmarks).  A measurement batch never
+// touches all of such a state: A = H^T H is non-zero on ns <= 288 involved columns s only.  With G = P[:, s]:
+//     P+ = P - G (A - A Pss+ A) G^T ,   Pss+ = (Pss^-1 + A)^-1   (from (I + P A)^-1 = I - P+ A restricted to s),
+// so the factorizations run on the ns x ns problem through the same tile kernels and the rest is three MFMA products.
+static bool substate_ok(const ovp_ctx* c) { return c->n > OVP_TILECHOL_NMAX && c->sub_ns > 0 && c->sub_ns <= OVP_TILECHOL_NMAX; }
+
+static int set_substate(ovp_ctx* c, const std::vector<int>& ids) {
+  c->sub_ns = 0;
+  if (c->n <= OVP_TILECHOL_NMAX || ids.empty() || (int)ids.size() > OVP_TILECHOL_NMAX) return 0;
+  if (!c->sub_ids) HIPCHK(hipMalloc((void**)&c->sub_ids, sizeof(int) * (OVP_TILECHOL_NMAX + 16)));
+  if (!c->sub_buf) HIPCHK(dalloc(&c->sub_buf, (size_t)6 * OVP_TILECHOL_NMAX * OVP_TILECHOL_NMAX));
+  HIPCHK(hipMemcpyAsync(c->sub_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // ids is the caller's temporary
+  c->sub_ns = (int)ids.size();
+  return 0;
+}
+
 static int chol_of_P(ovp_ctx* c, hipStream_t s) {
   const int n = c->n, ld = c->ld;
   if (n <= OVP_TILECHOL_NMAX) return (int)ovp_launch_tilechol(c->P, c->L, nullptr, nullptr, n, ld, c->flags, 0, s);
+  if (substate_ok(c)) return 0;  // the sub-state update factors Pss, not P
   return (int)ovp_launch_chol(c->P, c->L, n, ld, c->flags, 0, s);
+}
+
+static int ekf_substate(ovp_ctx* c) {
+  const int n = c->n, ld = c->ld, ns = c->sub_ns, lds = OVP_TILECHOL_NMAX;
+  const size_t sz = (size_t)OVP_TILECHOL_NMAX * OVP_TILECHOL_NMAX;
+  double *S_P = c->sub_buf, *S_A = S_P + sz, *S_L = S_A + sz, *S_W = S_L + sz, *S_T = S_W + sz, *S_Y = S_T + sz;
+  hipStream_t s = c->stream;
+  HIPCHK(ovp_launch_gather_block(c->P, ld, c->sub_ids, ns, S_P, lds, s));
+  HIPCHK(ovp_launch_gather_block(c->Ab, ld, c->sub_ids, ns, S_A, lds, s));
+  // Pss+ = Ls (I + Ls^T A Ls)^-1 Ls^T exactly as the full-state path does it
+  HIPCHK(ovp_launch_tilechol(S_P, S_L, nullptr, nullptr, ns, lds, c->flags, 0, s));
+  HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, S_A, lds, S_L, lds, S_W, lds, 0, 0, s));
+  HIPCHK(ovp_launch_gemm4(1, 0, ns, ns, ns, S_L, lds, S_W, lds, S_T, lds, 1, 1, s));
+  HIPCHK(ovp_launch_tilechol(S_T, nullptr, c->Dinv, c->Ltp, ns, lds, c->flags, 0, s));
+  HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, S_L, S_Y, ns, lds, 0, s));
+  HIPCHK(ovp_launch_gemm4(1, 0, ns, ns, ns, S_Y, lds, S_Y, lds, S_P, lds, 0, 1, s));
+  // Lambda = A - A Pss+ A
+  HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, S_A, lds, S_P, lds, S_W, lds, 0, 0, s));
+  HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, S_W, lds, S_A, lds, S_T, lds, 0, 1, s));
+  HIPCHK(ovp_launch_mat_sub(S_A, S_T, S_T, ns, ns, lds, s));
+  // P -= G Lambda G^T   (G in Y, G Lambda in W1, the product in T)
+  HIPCHK(ovp_launch_gather_cols(c->P, ld, c->sub_ids, n, ns, c->Y, ld, s));
+  HIPCHK(ovp_launch_gemm4(0, 0, n, ns, ns, c->Y, ld, S_T, lds, c->W1, ld, 0, 0, s));
+  HIPCHK(ovp_launch_gemm4(0, 1, n, n, ns, c->W1, ld, c->Y, ld, c->T, ld, 0, 1, s));
+  HIPCHK(ovp_launch_sub_sym(c->P, c->T, n, ld, s));
+  return 0;
 }
 
 static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish = false) {
@@ -638,7 +693,21 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     }
     return 0;
   }
-  // large-state fallback: global-memory factorization
+  if (substate_ok(c)) {
+    int rc = ekf_substate(c);
+    if (rc) return rc;
+    if (publish) {
+      const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
+      c->pub_seq = ++c->seq;
+      HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->ticket, c->res_block, c->h_res_block_dev, words,
+                                (char*)c->h_res_block_dev + ((char*)c->h_seq - (char*)c->h_res_block), c->pub_seq, c->stream));
+      c->pub_pending = true;
+    } else {
+      HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, c->stream));
+    }
+    return 0;
+  }
+  // large-state fallback when the measurements touch more than 288 columns: global-memory factorization
   HIPCHK(ovp_launch_gemm(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, c->stream));
   HIPCHK(ovp_launch_gemm(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, c->stream));
   HIPCHK(ovp_launch_chol(c->T, c->Lt, n, ld, c->flags, 0, c->stream));
@@ -694,6 +763,19 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
 
 static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   ovp::FeatParams& fp = c->fp;
+  if (n > OVP_TILECHOL_NMAX) {  // the columns a point-feature batch can touch: clones, and calibration when it is estimated
+    std::vector<int> ids;
+    for (int cid : c->h_clone_id)
+      for (int k = 0; k < 6; ++k) ids.push_back(cid + k);
+    if (fp.calmask & 0x3Fu)
+      for (int k = 0; k < 6; ++k) ids.push_back(c->calib_id + k);
+    if (fp.calmask & (0xFFu << 6))
+      for (int k = 0; k < 8; ++k) ids.push_back(c->intr_id + k);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    int rs = set_substate(c, ids);
+    if (rs) return rs;
+  }
   // chol(P) does not depend on the measurements.  Default (mode 3): it rides in workgroup 0 of the fused feature kernel, on a
   // CU of its own, and is hidden behind the features; K2 follows on the main stream and nothing forks or joins.
   // Beside a one-wave-per-block K1 it must NOT run: K1 keeps every SIMD busy with two feature waves, and the CU that also
@@ -1213,6 +1295,13 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
   HIPCHK(ovp_launch_gemm(0, 0, cols, 1, rows, c->Hd, ld, c->resd, 1, c->bcc, 1, 0, c->stream));
   HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, c->stream));
   HIPCHK(ovp_launch_scatter_gram(c->Acc, c->bcc, cols, c->idbuf, c->Ab, c->ld, n, c->stream));
+  {
+    std::vector<int> ids(col_ids, col_ids + cols);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    int rs = set_substate(c, ids);
+    if (rs) return rs;
+  }
   int rc = ekf_from_gram(c, false);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));

@@ -211,6 +211,41 @@ def test_dense_ekf_update_matches_reference_form(hiplib):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["landmark_update", "delayed_init_rows", "everything"])
+def test_dense_ekf_update_above_the_tile_limit(hiplib, case):
+    """N = 366 (30 clones + 52 landmarks) is past the register-resident factorization (N <= 288).  Measurements that touch at
+    most 288 columns take the sub-state update (factor P[s,s], then P -= G (A - A Pss+ A) G^T); one that touches every column
+    falls back to the global-memory kernels.  Both against the reference form."""
+    from oracle import np_ref
+    from ov_plane_amd.synth import make_slam_scene
+
+    rng = np.random.default_rng(11)
+    sc = make_slam_scene(C=30, n_slam=52, seed=3)
+    assert sc.N == 366
+    if case == "landmark_update":      # newest clone, calibration, one landmark
+        order = [(int(sc.ids["clones"][-1]), 6), (int(sc.ids["calib"]), 6), (int(sc.ids["intr"]), 8), (int(sc.ids["slam"][7]), 3)]
+        rows = 2
+    elif case == "delayed_init_rows":   # a full track: every clone + calibration
+        order = [(int(sc.ids["calib"]), 6), (int(sc.ids["intr"]), 8)] + [(int(c), 6) for c in sc.ids["clones"]]
+        rows = 59
+    else:
+        order = [(0, sc.N)]
+        rows = 40
+    cols = np_ref.order_cols(order)
+    H = rng.standard_normal((rows, len(cols))) * 20.0
+    res = rng.standard_normal(rows)
+    Pn, dx = np_ref.ekf_update(sc.P, order, H, res)
+    ctx = hiplib.Context(sc.N + 8, sc.C + 2, 4)
+    ctx.cov_upload(sc.P)
+    dxg, info = ctx.ekf_update(H, cols, res)
+    Pg = ctx.cov_download()
+    # the sub-state form subtracts (A - A Pss+ A, P - G Lambda G^T): a few digits less than the factor form, far inside 1e-4
+    assert np.abs(dxg - dx).max() < 1e-7 * max(1.0, np.abs(dx).max())
+    assert relP(Pg, Pn) < 1e-6
+    assert np.abs(Pg - Pg.T).max() < 1e-12 * np.abs(Pg).max()
+    ctx.close()
+
+
 def test_covariance_bookkeeping(hiplib):
     """propagate / clone / marginalise / marginal-gather against the restatement (StateHelper.cpp:41-119,231-396)."""
     from oracle import np_ref
