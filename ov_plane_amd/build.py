@@ -46,7 +46,7 @@ def build_host(force=False, verbose=False):
         stale = any(os.path.getmtime(os.path.join(HOST_DIR, f)) > t for f in HOST_SOURCES + HOST_HEADERS) or os.path.getmtime(OUT) > t
     if not stale:
         return HOST_OUT
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + HOST_DIR, "-I" + os.path.join(_HERE, "..", "include")] + \
+    cmd = ["g++", "-std=c++17", "-O3", "-fPIC", "-shared", "-I" + HOST_DIR, "-I" + os.path.join(_HERE, "..", "include")] + \
           [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] + ["-o", HOST_OUT, "-L" + _HERE, "-lovplane_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
