@@ -142,6 +142,8 @@ typedef struct {
   int max_runs;
   double init_lamda, max_lamda, min_dx, min_dcost, lam_mult;
   double min_dist, max_dist, max_baseline, max_cond_number;
+  int triangulate_1d; /* single_triangulation_1d instead of single_triangulation: depth along the anchor bearing (UpdaterMSCKF.cpp:148-152) */
+  int reserved;
 } ovp_triang_opts;
 void ovp_triang_defaults(ovp_triang_opts *o);
 

@@ -2474,6 +2474,8 @@ void ovo_triang_defaults(ovo_triang_opts *o) {
   o->max_dist = 60.0;
   o->max_baseline = 40.0;
   o->max_cond_number = 10000.0;
+  o->triangulate_1d = 0;
+  o->reserved = 0;
 }
 
 int ovo_triangulate(const ovo_triang_opts *o, const ovo_state *st, const ovo_feats *fb, const float *uv_norm,
@@ -2527,12 +2529,38 @@ int ovo_triangulate(const ovo_triang_opts *o, const ovo_state *st, const ovo_fea
       for (int i = 0; i < 3; ++i) b[i] += Ai[3 * i] * r->p_CinA[0] + Ai[3 * i + 1] * r->p_CinA[1] + Ai[3 * i + 2] * r->p_CinA[2];
     }
     double pA[3], ev[3];
-    if (tri_solve3(A, b, pA)) continue;
-    tri_sym3_eig(A, ev);
-    double emax = fmax(ev[0], fmax(ev[1], ev[2])), emin = fmin(ev[0], fmin(ev[1], ev[2]));
-    const double condA = emax / emin;
-    const double nrm0 = sqrt(pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2]);
-    if (fabs(condA) > o->max_cond_number || pA[2] < o->min_dist || pA[2] > o->max_dist || isnan(nrm0)) continue;
+    if (o->triangulate_1d) {
+      /* ext FeatureInitializer::single_triangulation_1d: the bearing of the anchor observation is taken as exact, the depth
+       * along it solves  sum_i |S_i a|^2 d = sum_i (S_i a).(S_i p_CiinA)  over the other observations, S_i = skew(b_i) */
+      double a[3] = {(double)uvn[2 * (m - 1)], (double)uvn[2 * (m - 1) + 1], 1.0};
+      const double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      for (int q = 0; q < 3; ++q) a[q] /= na;
+      double A1 = 0.0, b1 = 0.0;
+      for (int k = 0; k < m - 1; ++k) {
+        const tri_rel *r = rel + k;
+        const double bc[3] = {(double)uvn[2 * k], (double)uvn[2 * k + 1], 1.0};
+        double bi[3], S[9], Sa[3], Sp[3];
+        for (int q = 0; q < 3; ++q) bi[q] = r->R_AtoC[q] * bc[0] + r->R_AtoC[3 + q] * bc[1] + r->R_AtoC[6 + q] * bc[2];
+        const double nb = sqrt(bi[0] * bi[0] + bi[1] * bi[1] + bi[2] * bi[2]);
+        for (int q = 0; q < 3; ++q) bi[q] /= nb;
+        skew3(bi, S);
+        mat3_vec(S, a, Sa);
+        mat3_vec(S, r->p_CinA, Sp);
+        A1 += Sa[0] * Sa[0] + Sa[1] * Sa[1] + Sa[2] * Sa[2];
+        b1 += Sa[0] * Sp[0] + Sa[1] * Sp[1] + Sa[2] * Sp[2];
+      }
+      const double depth = b1 / A1;
+      for (int q = 0; q < 3; ++q) pA[q] = depth * a[q];
+      const double nrm1 = sqrt(pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2]);
+      if (pA[2] < o->min_dist || pA[2] > o->max_dist || isnan(nrm1)) continue;
+    } else {
+      if (tri_solve3(A, b, pA)) continue;
+      tri_sym3_eig(A, ev);
+      double emax = fmax(ev[0], fmax(ev[1], ev[2])), emin = fmin(ev[0], fmin(ev[1], ev[2]));
+      const double condA = emax / emin;
+      const double nrm0 = sqrt(pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2]);
+      if (fabs(condA) > o->max_cond_number || pA[2] < o->min_dist || pA[2] > o->max_dist || isnan(nrm0)) continue;
+    }
     if (o->refine_features) {
       double rho = 1.0 / pA[2], alpha = pA[0] / pA[2], beta = pA[1] / pA[2];
       double lam = o->init_lamda, eps = 10000.0;

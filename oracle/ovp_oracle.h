@@ -235,6 +235,7 @@ int ovo_zupt_update(const ovo_imu_state *x, const ovo_prop_opts *po, int imu_id,
 typedef struct {
   int refine_features, max_runs;
   double init_lamda, max_lamda, min_dx, min_dcost, lam_mult, min_dist, max_dist, max_baseline, max_cond_number;
+  int triangulate_1d, reserved; /* single_triangulation_1d (update/UpdaterMSCKF.cpp:148-152) */
 } ovo_triang_opts;
 void ovo_triang_defaults(ovo_triang_opts *o); /* ext FeatureInitializerOptions defaults */
 /* single_triangulation (+ single_gaussnewton when refine_features) of every feature of the batch against the camera poses of

@@ -477,7 +477,8 @@ def zupt_update(x, po, P, imu, time0, time1, imu_id=0, noise_mult=10.0, chi2_mul
 class OvoTriangOpts(C.Structure):
     _fields_ = [("refine_features", C.c_int), ("max_runs", C.c_int), ("init_lamda", C.c_double), ("max_lamda", C.c_double),
                 ("min_dx", C.c_double), ("min_dcost", C.c_double), ("lam_mult", C.c_double), ("min_dist", C.c_double),
-                ("max_dist", C.c_double), ("max_baseline", C.c_double), ("max_cond_number", C.c_double)]
+                ("max_dist", C.c_double), ("max_baseline", C.c_double), ("max_cond_number", C.c_double), ("triangulate_1d", C.c_int),
+                ("reserved", C.c_int)]
 
 
 def triang_defaults(**over):

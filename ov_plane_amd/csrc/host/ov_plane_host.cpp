@@ -723,6 +723,8 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
         for (size_t k = 0; k < feature_vec[f]->uvs_norm.size(); ++k) uvn[(size_t)f * M * 2 + k] = feature_vec[f]->uvs_norm[k];
       ovp_triang_opts to;
       to.refine_features = _featinit.refine_features ? 1 : 0;
+      to.triangulate_1d = _featinit.triangulate_1d ? 1 : 0;
+      to.reserved = 0;
       to.max_runs = _featinit.max_runs;
       to.init_lamda = _featinit.init_lamda;
       to.max_lamda = _featinit.max_lamda;

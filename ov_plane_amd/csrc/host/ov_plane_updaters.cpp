@@ -700,6 +700,8 @@ void UpdaterSLAM::triangulate_on_device(std::shared_ptr<State> state, const ov_c
   gpu_check2(ovp_batch_upload(state->_gpu, &fb), "ovp_batch_upload");
   ovp_triang_opts to;
   to.refine_features = fio.refine_features ? 1 : 0;
+  to.triangulate_1d = fio.triangulate_1d ? 1 : 0;
+  to.reserved = 0;
   to.max_runs = fio.max_runs;
   to.init_lamda = fio.init_lamda;
   to.max_lamda = fio.max_lamda;
@@ -1115,6 +1117,8 @@ void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std:
         for (size_t k = 0; k < valid[f]->uvs_norm.size(); ++k) uvn[(size_t)f * Mv * 2 + k] = valid[f]->uvs_norm[k];
       ovp_triang_opts to;
       to.refine_features = _featinit.refine_features ? 1 : 0;
+      to.triangulate_1d = _featinit.triangulate_1d ? 1 : 0;
+      to.reserved = 0;
       to.max_runs = _featinit.max_runs;
       to.init_lamda = _featinit.init_lamda;
       to.max_lamda = _featinit.max_lamda;

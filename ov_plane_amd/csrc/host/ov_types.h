@@ -560,7 +560,7 @@ struct FeatureHelper {
 };
 // ext ov_core::FeatureInitializerOptions (feat/FeatureInitializerOptions.h), defaults of open_vins
 struct FeatureInitializerOptions {
-  bool triangulate_1d = false;  // only the 3-d triangulation is built (every shipped config uses it)
+  bool triangulate_1d = false;  // depth along the anchor bearing only (single_triangulation_1d)
   bool refine_features = true;
   int max_runs = 5;
   double init_lamda = 1e-3, max_lamda = 1e10, min_dx = 1e-6, min_dcost = 1e-6, lam_mult = 10;

@@ -194,8 +194,48 @@ __global__ __launch_bounds__(TRI_WAVES * 64) void k_triangulate(const TriParams 
   const double A[9] = {s9[0], s9[1], s9[2], s9[1], s9[3], s9[4], s9[2], s9[4], s9[5]};
   const double b[3] = {s9[6], s9[7], s9[8]};
   double pA[3] = {0.0, 0.0, 0.0}, ev[3];
-  bool good = tri_solve3(A, b, pA);
-  if (good) {
+  bool good;
+  if (p.triangulate_1d) {
+    // ext single_triangulation_1d: depth d along the anchor bearing a from  sum_i |S_i a|^2 d = sum_i (S_i a).(S_i p_CiinA),
+    // S_i = skew(b_i); the anchor's own observation is skipped, no condition-number test
+    const float ua = p.uvn[((size_t)f * p.max_meas + (m - 1)) * 2], va = p.uvn[((size_t)f * p.max_meas + (m - 1)) * 2 + 1];
+    double a[3] = {(double)ua, (double)va, 1.0};
+    const double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] /= na;
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+      const double bc[3] = {(double)un, (double)vn, 1.0};
+      double bi[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bi[k] = R[k] * bc[0] + R[3 + k] * bc[1] + R[6 + k] * bc[2];
+      const double nb = sqrt(bi[0] * bi[0] + bi[1] * bi[1] + bi[2] * bi[2]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bi[k] /= nb;
+      const double Sa[3] = {bi[1] * a[2] - bi[2] * a[1], bi[2] * a[0] - bi[0] * a[2], bi[0] * a[1] - bi[1] * a[0]};
+      const double Sp[3] = {bi[1] * pCinA[2] - bi[2] * pCinA[1], bi[2] * pCinA[0] - bi[0] * pCinA[2],
+                            bi[0] * pCinA[1] - bi[1] * pCinA[0]};
+      const bool anchor = lane == m - 1;
+      buf[lane * TRI_PITCH + 0] = anchor ? 0.0 : (Sa[0] * Sa[0] + Sa[1] * Sa[1] + Sa[2] * Sa[2]);
+      buf[lane * TRI_PITCH + 1] = anchor ? 0.0 : (Sa[0] * Sp[0] + Sa[1] * Sp[1] + Sa[2] * Sp[2]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double A1 = 0.0, b1 = 0.0;
+    for (int k = 0; k < m - 1; ++k) {
+      A1 += buf[k * TRI_PITCH + 0];
+      b1 += buf[k * TRI_PITCH + 1];
+    }
+    const double depth = b1 / A1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pA[k] = depth * a[k];
+    const double nrm0 = sqrt(pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2]);
+    good = !(pA[2] < p.min_dist || pA[2] > p.max_dist || isnan(nrm0));
+  } else {
+    good = tri_solve3(A, b, pA);
+  }
+  if (good && !p.triangulate_1d) {
     tri_sym3_eig(A, ev);
     const double emax = fmax(ev[0], fmax(ev[1], ev[2])), emin = fmin(ev[0], fmin(ev[1], ev[2]));
     const double condA = emax / emin;

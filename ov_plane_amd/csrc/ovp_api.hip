@@ -531,6 +531,8 @@ extern "C" void ovp_triang_defaults(ovp_triang_opts* o) {
   o->max_dist = 60.0;
   o->max_baseline = 40.0;
   o->max_cond_number = 10000.0;
+  o->triangulate_1d = 0;
+  o->reserved = 0;
 }
 
 extern "C" int ovp_triangulate(ovp_ctx* c, const ovp_triang_opts* o, const float* uv_norm, double* p_FinG_out, uint8_t* ok) {
@@ -551,6 +553,7 @@ extern "C" int ovp_triangulate(ovp_ctx* c, const ovp_triang_opts* o, const float
   tp.clone_p = c->clone_p;
   tp.cal = c->cal;
   tp.refine_features = o->refine_features;
+  tp.triangulate_1d = o->triangulate_1d;
   tp.max_runs = o->max_runs;
   tp.init_lamda = o->init_lamda;
   tp.max_lamda = o->max_lamda;

@@ -69,6 +69,7 @@ struct TriParams {
   const double* cal;      // [0..8] R_ItoC, [9..11] p_IinC
   int refine_features, max_runs;
   double init_lamda, max_lamda, min_dx, min_dcost, lam_mult, min_dist, max_dist, max_baseline, max_cond_number;
+  int triangulate_1d;
   double* p_FinG;         // [n_feats][3] out
   unsigned char* ok;      // [n_feats] out
 };

@@ -784,24 +784,27 @@ def test_host_cpp_mirror_state_maintenance(hiplib, oracle):
     assert out["slam_id"][[0, 2, 4]].tolist() == exp_ids
 
 
-@pytest.mark.parametrize("kw,refine", [
-    (dict(C=11, F=200, seed=3, ragged=True, min_meas=2), 1),
-    (dict(C=30, F=300, seed=4), 1),
-    (dict(C=8, F=120, seed=5, ragged=True, min_meas=2), 0),
+@pytest.mark.parametrize("kw,refine,one_d", [
+    (dict(C=11, F=200, seed=3, ragged=True, min_meas=2), 1, 0),
+    (dict(C=30, F=300, seed=4), 1, 0),
+    (dict(C=8, F=120, seed=5, ragged=True, min_meas=2), 0, 0),
+    (dict(C=11, F=150, seed=6, ragged=True, min_meas=2), 0, 1),     # single_triangulation_1d, no refinement
+    (dict(C=30, F=100, seed=7), 1, 1),                               # ... followed by single_gaussnewton
 ])
-def test_triangulation_matches_oracle(hiplib, oracle, kw, refine):
+def test_triangulation_matches_oracle(hiplib, oracle, kw, refine, one_d):
     """ext FeatureInitializer::single_triangulation + single_gaussnewton on the device (SURVEY 8f rank 1) against the
     restatement: same features kept / dropped, positions identical up to rounding (sums in the reference's order, no FMA
     contraction, single-precision residuals), and the triangulated batch feeds the update like the scene's own points."""
     sc = make_scene(**kw)
-    ref = oracle.triangulate(sc, oracle.triang_defaults(refine_features=refine))
+    ref = oracle.triangulate(sc, oracle.triang_defaults(refine_features=refine, triangulate_1d=one_d))
     ctx = hiplib.Context(sc.N, sc.C, sc.F)
     ctx.cov_upload(sc.P)
     ctx.state_upload(sc)
     ctx.batch_upload_scene(sc)
-    out = ctx.triangulate(sc.uv_norm, hiplib.triang_defaults(refine_features=refine))
+    out = ctx.triangulate(sc.uv_norm, hiplib.triang_defaults(refine_features=refine, triangulate_1d=one_d))
     assert (out["ok"] == ref["ok"]).all()
-    assert ref["ok"].sum() > 0.8 * sc.F and ((~ref["ok"]).any() or not kw.get("ragged", False))
+    # (the 1-d version has no condition-number test: short tracks are not rejected there)
+    assert ref["ok"].sum() > 0.8 * sc.F and ((~ref["ok"]).any() or not kw.get("ragged", False) or one_d)
     ok = ref["ok"]
     assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < 1e-11
     # the linearisation points now on the device are the triangulated ones: update with them == oracle update with them

@@ -712,3 +712,50 @@ def test_zero_velocity_update_is_the_information_form_update_of_its_stacked_imu_
     # standing, but the velocity estimate says otherwise (:231 second clause)
     xv = dict(x, v=np.array([0.7, 0.0, 0.0]))
     assert not oracle.zupt_update(xv, po, sc.P, imu, t0, t1)["accepted"]
+
+
+def test_triangulation_1d_is_the_least_squares_depth_along_the_anchor_bearing():
+    """ext FeatureInitializer::single_triangulation_1d: with the anchor observation's bearing a taken as exact, the point is
+    d a where d minimises sum_i |skew(b_i) (d a - p_CiinA)|^2 over the other observations.  Independent numpy statement of that
+    least-squares problem, geometric sanity against the scene's truth, and the refinement still runs after it."""
+    from ov_plane_amd.synth import make_scene, quat_2_rot
+    from oracle import pyoracle
+
+    sc = make_scene(C=11, F=40, seed=7, ragged=True, min_meas=3)
+    r = pyoracle.triangulate(sc, pyoracle.triang_defaults(refine_features=0, triangulate_1d=1))
+    R_ItoC = quat_2_rot(sc.calib_q)
+    n_ok = 0
+    for f in range(sc.F):
+        m = int(sc.n_meas[f])
+        cams = []
+        for k in range(m):
+            ci = int(sc.clone_idx[f, k])
+            R = R_ItoC @ quat_2_rot(sc.clone_q[ci])
+            cams.append((R, sc.clone_p[ci] - R.T @ sc.calib_p))
+        RA, pA = cams[-1]
+        a = np.array([sc.uv_norm[f, m - 1, 0], sc.uv_norm[f, m - 1, 1], 1.0], dtype=np.float64)
+        a /= np.linalg.norm(a)
+        rows, rhs = [], []
+        for k in range(m - 1):
+            R, pc = cams[k]
+            b = (R @ RA.T).T @ np.array([sc.uv_norm[f, k, 0], sc.uv_norm[f, k, 1], 1.0], dtype=np.float64)
+            b /= np.linalg.norm(b)
+            S = np.array([[0, -b[2], b[1]], [b[2], 0, -b[0]], [-b[1], b[0], 0]])
+            rows.append(S @ a)
+            rhs.append(S @ (RA @ (pc - pA)))
+        d = np.linalg.lstsq(np.concatenate(rows)[:, None], np.concatenate(rhs), rcond=None)[0][0]
+        p = RA.T @ (d * a) + pA
+        ok = 0.1 <= d * a[2] <= 60.0
+        assert ok == bool(r["ok"][f]), f
+        if ok:
+            n_ok += 1
+            assert np.abs(p - r["p_FinG"][f]).max() < 1e-9 * max(1.0, np.abs(p).max()), f
+    assert n_ok > 0.9 * sc.F
+    err1 = np.linalg.norm(r["p_FinG"] - sc.truth["p_f"], axis=1)[r["ok"]]
+    assert np.median(err1) < 0.3
+    rr = pyoracle.triangulate(sc, pyoracle.triang_defaults(refine_features=1, triangulate_1d=1))
+    r3 = pyoracle.triangulate(sc, pyoracle.triang_defaults(refine_features=1))
+    both = rr["ok"] & r3["ok"]
+    assert both.sum() > 0.8 * sc.F
+    # the refinement converges to the same minimum from either start for most features
+    assert np.median(np.linalg.norm(rr["p_FinG"][both] - r3["p_FinG"][both], axis=1)) < 1e-3
