@@ -88,7 +88,10 @@ typedef struct {
 } ovp_update_info;
 
 /* ---- context --------------------------------------------------------------------------------- */
-/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create its own. */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create its own.
+ * Sizes: n_state_max <= 700 (the feature kernels stage projector rows in LDS); states up to 288 columns take the register-
+ * resident factorizations, larger ones the sub-state update (a batch may then touch at most 288 columns to stay fast);
+ * ovp_msckf_plane_update / ovp_plane_init are offered up to 288 columns (OVP_E_CAPACITY beyond). */
 int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int n_feats_max, void *stream, ovp_ctx **out);
 int ovp_ctx_destroy(ovp_ctx *ctx);
 int ovp_sync(ovp_ctx *ctx);
