@@ -195,6 +195,24 @@ def main():
                          "gram_then_ekf": float(stage_ms[2]), "gpu_total": float(stage_ms[3])},
             "roofline": roofline,
         }
+        if world == 1:
+            # second figure of SURVEY 8(d): StateHelper::EKFPropagation of the IMU block (k = 15) on the resident covariance,
+            # host call to completion (Phi / Q upload, strips, negative-diagonal check), outside the timed region above
+            try:
+                rng = np.random.default_rng(1)
+                Phi = np.eye(15) + 1e-3 * rng.standard_normal((15, 15))
+                Qd = 1e-8 * np.eye(15)
+                ctx.cov_upload(sc.P)
+                for _ in range(5):
+                    ctx.cov_propagate(0, [0], [15], Phi, Qd)
+                t0 = time.perf_counter()
+                n_prop = 50
+                for _ in range(n_prop):
+                    ctx.cov_propagate(0, [0], [15], Phi, Qd)
+                line["propagation_cov_step_us"] = 1e6 * (time.perf_counter() - t0) / n_prop
+            except Exception as e:  # the headline number must not depend on this extra
+                line["propagation_cov_step_us"] = None
+                print("propagation timing skipped: %r" % (e,), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle
 
