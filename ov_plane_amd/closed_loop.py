@@ -154,14 +154,16 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
 
 
 def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, planes=0, plane_min_feat=6, sigma_c=0.01,
-                max_slam=0, feat_rep_slam=0, min_meas=3, out_dir=None):
+                max_slam=0, feat_rep_slam=0, min_meas=3, out_dir=None, zupt=None):
     """Closed loop through hostlib.Session, frame by frame, with the tracker-side bookkeeping of core/VioManager.cpp:360-506:
     a track is an MSCKF feature once it is lost or reaches back to the clone about to be marginalised; a track that spans the
     whole window (more than max_clone_size measurements) becomes a SLAM landmark while there is room (max_slam), and from then
     on every new measurement of it is a SLAM update until it is no longer seen (the session then marginalises it).
     feat_rep_slam: ext LandmarkRepresentation of the landmarks (0 GLOBAL_3D ... 5 ANCHORED_INVERSE_DEPTH_SINGLE).
     out_dir: write state_estimate.txt / state_deviation.txt / state_groundtruth.txt / timing.txt there, in the formats a run of
-    the reference's simulation leaves behind (what its results/ scripts and ov_eval read)."""
+    the reference's simulation leaves behind (what its results/ scripts and ov_eval read).
+    zupt: dict of Session.enable_zupt keywords (or {}) = VioManagerOptions::try_zupt: a frame at which the platform is found
+    standing still gets a zero-velocity update instead of a clone (core/VioManager.cpp:311-331) and its measurements are dropped."""
     from . import hostlib
     from .sim import log_so3
     from .synth import PROP_OPTS, quat_2_rot
@@ -174,6 +176,8 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
     frames = frames[:C] + frames[C + 1:]
     ses = hostlib.Session(init, po, sigma_px=sigma_px, chi2_mult=chi2_mult, plane_mode=planes, plane_min_feat=plane_min_feat,
                           sigma_c=sigma_c, max_slam=max_slam, feat_rep_slam=feat_rep_slam, cam_dt=1.0 / sim.params["sim_freq_cam"])
+    if zupt is not None:
+        ses.enable_zupt(po, **zupt)
     ses.feed_imu(imu)
     if out_dir is not None:
         import os
@@ -189,13 +193,28 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
     for k in range(C):
         for fid, uv in frames[k][1].items():
             tracks.setdefault(fid, []).append((k, uv))
+    window = list(range(C))                                   # frames that have a clone in the state, oldest first
+    if zupt is not None:
+        fk = frames[C - 1]
+        ses.feed_tracks(fk[0], np.array(list(fk[1]), dtype=np.int64) + FID_OFFSET, np.array(list(fk[1].values())).reshape(-1, 2))
     slam_ids = set()
     K = len(frames) - C
     traj, posecov, counts = np.zeros((K, 16)), np.zeros((K, 6, 6)), np.zeros((K, 6), dtype=np.int32)
     n_feats = np.zeros((K, 3), dtype=np.int32)
+    zupt_frames = np.zeros(K, dtype=bool)
     for k in range(C, len(frames)):
         t_k, seen = frames[k]
-        lo = k - C
+        i = k - C
+        if zupt is not None:
+            ses.feed_tracks(t_k, np.array(list(seen), dtype=np.int64) + FID_OFFSET, np.array(list(seen.values())).reshape(-1, 2))
+            z = ses.try_zupt(t_k)
+            if z is not None:                                 # standing still: no clone, this image's measurements are dropped
+                traj[i], posecov[i], zupt_frames[i] = z["x16"], z["posecov"], True
+                counts[i, 4], counts[i, 5] = len(slam_ids), counts[i - 1, 5] if i else 0
+                continue
+        win = window + [k]
+        in_win = {fr: j for j, fr in enumerate(win)}
+        lo = win[0]
         items = []                                           # (fid, kind, [(frame, uv), ...])
         for fid in sorted(slam_ids):                         # landmarks seen in this frame: one new measurement each
             if fid in seen:
@@ -206,7 +225,7 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
                 tracks.setdefault(fid, []).append((k, uv))
         maxtracks, msckf = [], []
         for fid in sorted(tracks):
-            tr = [(j, uv) for j, uv in tracks[fid] if j >= lo]
+            tr = [(j, uv) for j, uv in tracks[fid] if j in in_win]
             tracks[fid] = tr
             if not tr:
                 del tracks[fid]
@@ -229,7 +248,7 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
         for f, (_, _, tr) in enumerate(items):
             nm[f] = len(tr)
             for q, (j, m) in enumerate(tr):
-                uv[f, q], slot[f, q] = m, j - lo
+                uv[f, q], slot[f, q] = m, in_win[j]
         xn, yn = radtan_undistort(uv[..., 0], uv[..., 1], init["intr"])
         uvn = np.stack([xn, yn], axis=-1).astype(np.float32)
         fid = np.array([it[0] for it in items], dtype=np.int64)
@@ -238,10 +257,10 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
         gt = sim.get_state(t_k + sim.params["calib_camimu_dt"])
         truth = np.concatenate([[gt["t"]], gt["q"], gt["p"], gt["v"], gt["bg"], gt["ba"], truth_tail])
         out = ses.step(t_k, uv, uvn, slot, nm, fid + FID_OFFSET, kind, pl, truth)
-        slam_ids = {i - FID_OFFSET for i in out["slam_ids"]}
+        window = win[1:]
+        slam_ids = {i_ - FID_OFFSET for i_ in out["slam_ids"]}
         for f in slam_ids:
             tracks.pop(f, None)
-        i = k - C
         traj[i], posecov[i], counts[i] = out["x16"], out["posecov"], out["counts"]
         n_feats[i] = [(kind == 0).sum(), (kind == 1).sum(), (kind == 2).sum()]
     ses.close()
@@ -254,6 +273,6 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
         e_pos[i], e_ori[i] = np.linalg.norm(dp), np.linalg.norm(dth)
         nees_p[i] = dp @ np.linalg.solve(posecov[i][3:6, 3:6], dp)
         nees_o[i] = dth @ np.linalg.solve(posecov[i][0:3, 0:3], dth)
-    return dict(times=times, traj=traj, posecov=posecov, counts=counts, n_feats=n_feats, e_pos=e_pos, e_ori=e_ori,
-                nees_pos=nees_p, nees_ori=nees_o, rmse_pos=float(np.sqrt(np.mean(e_pos**2))),
+    return dict(times=times, traj=traj, posecov=posecov, counts=counts, n_feats=n_feats, zupt_frames=zupt_frames, e_pos=e_pos,
+                e_ori=e_ori, nees_pos=nees_p, nees_ori=nees_o, rmse_pos=float(np.sqrt(np.mean(e_pos**2))),
                 rmse_ori_deg=float(np.degrees(np.sqrt(np.mean(e_ori**2)))))

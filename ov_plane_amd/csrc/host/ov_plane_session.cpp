@@ -30,6 +30,8 @@ struct Session {
   std::unique_ptr<UpdaterMSCKF> msckf;
   std::unique_ptr<UpdaterSLAM> slam;
   std::unique_ptr<UpdaterPlane> plane;
+  std::unique_ptr<UpdaterZeroVelocity> zupt;              // only with try_zupt (VioManagerOptions::try_zupt)
+  std::shared_ptr<ov_core::FeatureDatabase> db;           // raw tracks of the last frames: the disparity test of the detector
   int C = 0, plane_mode = 0;
   // what a run of the reference leaves behind (ros/ROSVisualizerHelper.cpp:152-302, core/VioManager.cpp:110-118, 911-927)
   std::ofstream of_est, of_std, of_gt, of_timing;
@@ -127,6 +129,58 @@ extern "C" void *ovph_session_open(int C, const double *clone_q, const double *c
 
 extern "C" void ovph_session_close(void *h) { delete static_cast<Session *>(h); }
 
+// Zero-velocity updates (core/VioManager.cpp:311-331): zupt4 = max velocity, noise multiplier, max disparity, chi2 multiplier.
+// The IMU readings fed afterwards also reach the detector; ovph_session_feed_tracks hands it the raw pixel tracks of a frame.
+extern "C" int ovph_session_enable_zupt(void *h, const double *zupt4, const double *sigmas4, double gravity_mag) {
+  auto *s = static_cast<Session *>(h);
+  NoiseManager nm;
+  nm.sigma_w = sigmas4[0];
+  nm.sigma_a = sigmas4[1];
+  nm.sigma_wb = sigmas4[2];
+  nm.sigma_ab = sigmas4[3];
+  UpdaterOptions uo;
+  uo.chi2_multipler = zupt4[3];
+  s->db = std::make_shared<ov_core::FeatureDatabase>();
+  s->zupt = std::make_unique<UpdaterZeroVelocity>(uo, nm, s->db, s->prop, gravity_mag, zupt4[0], zupt4[1], zupt4[2]);
+  return 0;
+}
+
+extern "C" int ovph_session_feed_tracks(void *h, double frame_time, int n, const long long *fid, const float *uv) {
+  auto *s = static_cast<Session *>(h);
+  if (!s->db) return 0;
+  for (int i = 0; i < n; ++i) s->db->update_feature((size_t)fid[i], frame_time, 0, uv[2 * i], uv[2 * i + 1], 0.f, 0.f);
+  // the detector looks one frame back: forget what is older than a few frames
+  auto &all = s->db->get_internal_data();
+  for (auto it = all.begin(); it != all.end();) {
+    auto &f = *it->second;
+    while (!f.timestamps.empty() && f.timestamps.front() < frame_time - 1.0) {
+      f.timestamps.erase(f.timestamps.begin());
+      f.uvs.erase(f.uvs.begin(), f.uvs.begin() + 2);
+      if (f.uvs_norm.size() >= 2) f.uvs_norm.erase(f.uvs_norm.begin(), f.uvs_norm.begin() + 2);
+    }
+    if (f.timestamps.empty()) it = all.erase(it);
+    else ++it;
+  }
+  return 0;
+}
+
+// VioManager.cpp:311-331: returns 1 when the platform was found standing still and the zero-velocity update was applied - the
+// frame is then NOT cloned and ovph_session_step must not be called for it; 0 otherwise.  x16 / posecov36 as in the step.
+extern "C" int ovph_session_try_zupt(void *h, double frame_time, double *x16, double *posecov36, double *chi2) {
+  auto *s = static_cast<Session *>(h);
+  if (!s->zupt) return 0;
+  const bool did = s->zupt->try_update(s->state, frame_time);
+  if (chi2) *chi2 = s->zupt->last_chi2();
+  if (did) {
+    memcpy(x16, s->state->_imu->value().data(), 16 * sizeof(double));
+    std::vector<std::shared_ptr<Type>> po;
+    po.push_back(s->state->_imu->pose());
+    MatrixXd Pp = StateHelper::get_marginal_covariance(s->state, po);
+    memcpy(posecov36, Pp.data(), 36 * sizeof(double));
+  }
+  return did ? 1 : 0;
+}
+
 // Output files of a run, in the reference's formats: state estimate / standard deviation / groundtruth (one line per frame,
 // written by ovph_session_step when it is handed the true state) and the timing CSV.  Empty or null path = not written.
 extern "C" int ovph_session_open_files(void *h, const char *est, const char *stdev, const char *gt, const char *timing) {
@@ -156,6 +210,7 @@ extern "C" int ovph_session_feed_imu(void *h, int n, const double *imu7) {
       d.am[k] = imu7[7 * i + 4 + k];
     }
     s->prop->feed_imu(d, s->state->_timestamp);
+    if (s->zupt) s->zupt->feed_imu(d, s->state->_timestamp);
   }
   return 0;
 }

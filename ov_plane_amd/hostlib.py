@@ -470,6 +470,31 @@ class Session:
         imu = np.ascontiguousarray(imu, dtype=np.float64).reshape(-1, 7)
         self._L.ovph_session_feed_imu(C.c_void_p(self._h), C.c_int(imu.shape[0]), imu.ctypes.data_as(C.c_void_p))
 
+    def enable_zupt(self, po, max_velocity=0.1, noise_multiplier=10.0, max_disparity=0.5, chi2_mult=1.0):
+        """UpdaterZeroVelocity in front of every frame (VioManagerOptions::try_zupt and its zupt_* values); call before
+        feed_imu so the detector sees the readings too."""
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        z = f64([max_velocity, noise_multiplier, max_disparity, chi2_mult])
+        sg = f64([po["sigma_w"], po["sigma_a"], po["sigma_wb"], po["sigma_ab"]])
+        self._L.ovph_session_enable_zupt(C.c_void_p(self._h), z.ctypes.data_as(C.c_void_p), sg.ctypes.data_as(C.c_void_p),
+                                         C.c_double(po["gravity_mag"]))
+
+    def feed_tracks(self, frame_time, fid, uv):
+        """raw pixel tracks of a frame for the detector's disparity test (ext FeatureDatabase)"""
+        fid = np.ascontiguousarray(fid, dtype=np.int64)
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        self._L.ovph_session_feed_tracks(C.c_void_p(self._h), C.c_double(frame_time), C.c_int(len(fid)),
+                                         fid.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p))
+
+    def try_zupt(self, frame_time):
+        """None when the frame has to be processed normally, else dict(x16, posecov, chi2): the zero-velocity update was
+        applied and the frame is not cloned."""
+        x16, pc, chi2 = np.zeros(16), np.zeros(36), C.c_double(0)
+        self._L.ovph_session_try_zupt.restype = C.c_int
+        did = self._L.ovph_session_try_zupt(C.c_void_p(self._h), C.c_double(frame_time), x16.ctypes.data_as(C.c_void_p),
+                                            pc.ctypes.data_as(C.c_void_p), C.byref(chi2))
+        return dict(x16=x16, posecov=pc.reshape(6, 6), chi2=chi2.value) if did else None
+
     def open_files(self, est=None, std=None, gt=None, timing=None):
         """Output files in the reference's formats (state estimate / standard deviations / groundtruth, timing CSV)."""
         enc = lambda s: (s or "").encode()  # noqa: E731

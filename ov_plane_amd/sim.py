@@ -417,16 +417,19 @@ class Simulator:
         self.planes = [SimPlane(k + 1, *c) for k, c in enumerate(corners)]
 
 
-def synthetic_trajectory(duration=30.0, rate=100.0, seed=0):
+def synthetic_trajectory(duration=30.0, rate=100.0, seed=0, pause=0.0):
     """A smooth room-sized loop in the trajectory file format (`t tx ty tz qx qy qz qw`, JPL q_GtoI), standing in for
-    ov_data/sim/*.txt (not in the reference tree): ~1 m/s, yaw following the path with roll / pitch wobble."""
+    ov_data/sim/*.txt (not in the reference tree): ~1 m/s, yaw following the path with roll / pitch wobble.  With `pause`
+    the platform stands still for that many seconds first and then eases into the loop (zero-velocity update scenario)."""
     rng = np.random.default_rng(seed)
     ph = rng.uniform(0, 2 * np.pi, 3)
-    t = np.arange(0.0, duration, 1.0 / rate)
+    t_file = np.arange(0.0, duration, 1.0 / rate)
+    u = np.maximum(t_file - pause, 0.0)
+    t = u * u / (u + 1.5) if pause > 0 else t_file           # path parameter: at rest until `pause`, then accelerating smoothly
     w = 2 * np.pi / 20.0
     p = np.stack([3.0 * np.cos(w * t), 2.0 * np.sin(w * t), 0.4 * np.sin(2 * w * t + ph[0])], axis=1)
     out = np.zeros((len(t), 8))
-    out[:, 0] = t + 10.0
+    out[:, 0] = t_file + 10.0
     out[:, 1:4] = p
     # sensor frame like a forward-looking rig: z_I along the heading, x_I to the right, y_I down (the camera of
     # kalibr_imucam_chain.yaml looks along the IMU's z axis)

@@ -1632,3 +1632,26 @@ def test_filter_session_on_the_reference_dataset_excerpt(hiplib):
     assert r["rmse_pos"] < 0.3 and r["rmse_ori_deg"] < 0.5, (r["rmse_pos"], r["rmse_ori_deg"])
     assert 0.2 < r["nees_pos"].mean() < 9.0 and 0.2 < r["nees_ori"].mean() < 9.0, (r["nees_pos"].mean(), r["nees_ori"].mean())
     assert r["counts"][:, 1].sum() > 10 * 300
+
+
+def test_filter_session_zero_velocity_updates_while_standing(hiplib):
+    """VioManagerOptions::try_zupt in the session (core/VioManager.cpp:311-331): the platform stands still for the first seconds;
+    every such frame is recognised by UpdaterZeroVelocity (chi2 of the raw IMU readings / disparity of the tracks), gets a
+    zero-velocity update on the device instead of a clone, and the estimate does not move; once it accelerates the detector
+    lets go and the normal pipeline (MSCKF + SLAM) takes over.  (No NEES claim for the start from rest: the first updates
+    triangulate over clones without parallax, with or without the zero-velocity updates.)"""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import closed_loop
+    from ov_plane_amd.sim import Simulator, synthetic_trajectory
+
+    sim = Simulator(synthetic_trajectory(duration=30.0, pause=5.0), num_pts=100, num_pts_plane=100, sim_distance_threshold=-1.0)
+    r = closed_loop.run_session(sim, n_frames=120, C=11, max_slam=25, zupt={})
+    z = r["zupt_frames"]
+    n_still = int(z.sum())
+    assert 30 <= n_still <= 45 and z[:n_still].all() and not z[n_still:].any(), np.nonzero(z)[0]
+    assert r["e_pos"][:n_still].max() < 5e-3 and np.degrees(r["e_ori"][:n_still]).max() < 0.05
+    assert (r["counts"][:n_still, :4] == 0).all()                      # no update, no clone while standing
+    assert r["counts"][n_still + 15:, 1].min() >= 10                   # landmarks are tracked once it moves
+    assert r["rmse_pos"] < 0.3 and r["e_pos"].max() < 0.5, (r["rmse_pos"], r["e_pos"].max())
