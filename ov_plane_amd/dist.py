@@ -41,3 +41,23 @@ def sharded_update(ctx, opts, group=None):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     ctx.ekf_update_from_gram_async()
     return ctx.fetch_results()
+
+
+def sharded_plane_then_point_update(ctx, opts, upload_feats, n_feats, plane_args, rank=0, world=1, group=None, point_opts=None):
+    """BASELINE config 4 on several GPUs: the plane loop is sequential across planes and cheap (a few
+    hundred microseconds per plane), so EVERY rank runs it on the whole batch - deterministic kernels, identical replicas of
+    P and of the pose tables afterwards, no collective - and only the point features that no accepted plane consumed are
+    sharded for the point update (one all-reduce, `sharded_update`).
+
+    upload_feats(indices or None): uploads those features of the frame (None = all) as the context's batch.
+    plane_args: (plane_of_feat [n_feats], cp, cp_fej, plane_state_id) as for Context.plane_update.
+    Returns (plane results, point results, indices of this rank's point shard)."""
+    import numpy as np
+
+    upload_feats(None)
+    out_pl = ctx.plane_update(opts, *plane_args)
+    rest = np.nonzero(~out_pl["used"][:n_feats])[0]
+    lo, hi = shard_bounds(len(rest), rank, world)
+    mine = rest[lo:hi]
+    upload_feats(mine)
+    return out_pl, sharded_update(ctx, point_opts if point_opts is not None else opts, group), mine

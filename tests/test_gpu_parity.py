@@ -517,6 +517,43 @@ def test_rccl_allreduce_path_single_rank(hiplib, oracle):
         dist.destroy_process_group()
 
 
+def test_plane_loop_replicated_then_points_sharded(hiplib, oracle):
+    """dist.sharded_plane_then_point_update (BASELINE config 4's shape at a size the oracle finishes): plane loop on the whole
+    batch, point update on this rank's shard of the free points; with one rank it must equal the plain sequence and the oracle's
+    plane loop followed by its point update."""
+    import torch
+
+    from ov_plane_amd.dist import sharded_plane_then_point_update
+
+    sc = make_scene(C=12, F=300, seed=19, n_planes=6, feats_per_plane=25, planes_in_state_frac=0.5, chi2_mult=99999.0)
+    ref = oracle.msckf_plane_update(sc)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = hiplib.Context(sc.N, sc.C, sc.F, stream=stream.cuda_stream)
+        ctx.cov_upload(sc.P)
+        ctx.state_upload(sc)
+        o = hiplib.opts_from_scene(sc)
+        o2 = hiplib.opts_from_scene(sc)
+        o2.chi2_multiplier = 1.0
+        pl, pt, mine = sharded_plane_then_point_update(ctx, o, lambda idx: ctx.batch_upload_scene(sc, idx), sc.F,
+                                                       (sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id), point_opts=o2)
+        P1 = ctx.cov_download()
+    assert (pl["ok"] == ref["plane_ok"]).all() and (pl["used"] == ref["used"]).all()
+    assert (mine == np.nonzero(~ref["used"])[0]).all()
+    # the same through the plain calls
+    ctx2 = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx2.cov_upload(sc.P)
+    ctx2.state_upload(sc)
+    ctx2.batch_upload_scene(sc)
+    pl2 = ctx2.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    ctx2.batch_upload_scene(sc, np.nonzero(~pl2["used"])[0])
+    pt2 = ctx2.msckf_update(o2)
+    assert np.abs(pl["dx"] - pl2["dx"]).max() == 0.0 and np.abs(pt["dx"] - pt2["dx"]).max() == 0.0
+    assert np.abs(P1 - ctx2.cov_download()).max() == 0.0 and (pt["accepted"] == pt2["accepted"]).all()
+    ctx.close()
+    ctx2.close()
+
+
 @pytest.mark.parametrize("r_iso,chi2_mult,expect", [(1.0, 1e9, 1), (0.25, 1e9, 1), (1.0, 1e-9, 0)])
 def test_host_cpp_initialize_matches_oracle(hiplib, oracle, r_iso, chi2_mult, expect):
     """StateHelper::initialize / initialize_invertible (state/StateHelper.cpp:398-586): Givens split, chi2 against the prior,
