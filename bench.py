@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--clones", type=int, default=30)
     ap.add_argument("--feats", type=int, default=2000, help="features per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plane-config", action="store_true", help="skip the extra 2000 point + 20 plane figure")
     ap.add_argument("--cpu-sample-feats", type=int, default=2000)
     args = ap.parse_args()
 
@@ -213,6 +214,46 @@ def main():
             except Exception as e:  # the headline number must not depend on this extra
                 line["propagation_cov_step_us"] = None
                 print("propagation timing skipped: %r" % (e,), file=sys.stderr)
+        if world == 1 and not args.no_plane_config:
+            try:
+                ctx.close()   # the headline context is done; its polling / mapped buffers must not sit beside the next one
+            except Exception:
+                pass
+            # BASELINE config 2 of the metric ("30 clones, 2000 point + 20 plane feats"): reported next to the headline, never as
+            # `value`.  Plane loop (sequential over the 20 planes) + point update on the features no plane consumed.
+            try:
+                sc3 = make_scene(C=C, F=F, seed=0, n_planes=20, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=1.0)
+                ctx3 = capi.Context(sc3.N, sc3.C, sc3.F, device=local_rank)
+                o3 = capi.opts_from_scene(sc3)
+
+                def step3():
+                    ctx3.cov_upload(sc3.P)
+                    ctx3.state_upload(sc3)
+                    ctx3.batch_upload_scene(sc3)
+                    t0 = time.perf_counter()
+                    pl = ctx3.plane_update(o3, sc3.plane_id, sc3.cp, sc3.cp_fej, sc3.plane_state_id)
+                    t1 = time.perf_counter()
+                    ctx3.batch_upload_scene(sc3, np.where(~pl["used"])[0])
+                    t2 = time.perf_counter()
+                    pt = ctx3.msckf_update(o3)
+                    t3 = time.perf_counter()
+                    return pl, pt, (t1 - t0, t3 - t2)
+
+                for _ in range(3):
+                    step3()
+                reps = [step3() for _ in range(10)]
+                tt = np.array([r[2] for r in reps]).mean(axis=0)
+                pl, pt, _ = reps[-1]
+                line["plane_config"] = {
+                    "workload": "%d clones, %d feats of which %d on 20 planes (10 in the state), N=%d" % (C, F, int(pl["used"].sum()),
+                                                                                                         sc3.N),
+                    "plane_loop_ms": 1e3 * float(tt[0]), "point_update_ms": 1e3 * float(tt[1]),
+                    "total_ms": 1e3 * float(tt.sum()), "features_per_s": F / float(tt.sum()),
+                    "planes_accepted": int(pl["ok"].sum()), "points_accepted": int(pt["accepted"].sum())}
+                ctx3.close()
+            except Exception as e:
+                line["plane_config"] = None
+                print("plane config skipped: %r" % (e,), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle
 
