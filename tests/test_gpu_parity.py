@@ -1692,3 +1692,29 @@ def test_filter_session_zero_velocity_updates_while_standing(hiplib):
     assert (r["counts"][:n_still, :4] == 0).all()                      # no update, no clone while standing
     assert r["counts"][n_still + 15:, 1].min() >= 10                   # landmarks are tracked once it moves
     assert r["rmse_pos"] < 0.3 and r["e_pos"].max() < 0.5, (r["rmse_pos"], r["e_pos"].max())
+
+
+def test_filter_session_rejects_inconsistent_bookkeeping(hiplib):
+    """The session does not guess: a SLAM measurement for a landmark that is not in the state, or a window slot outside the
+    C + 1 clones, is an error of the caller's tracker-side bookkeeping (no silent drop, no crash)."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import closed_loop, hostlib
+    from ov_plane_amd.sim import Simulator, synthetic_trajectory
+    from ov_plane_amd.synth import PROP_OPTS
+
+    C = 6
+    sim = Simulator(synthetic_trajectory(duration=12.0), num_pts=30, num_pts_plane=30)
+    imu, frames, _ = closed_loop.collect(sim, C + 3)
+    init = closed_loop.initial_state(sim, frames, C)
+    uv = np.full((1, C + 1, 2), 100.0, dtype=np.float32)
+    nm = np.array([1], dtype=np.int32)
+    for kind, slot0, msg in ((1, C, "-22"), (0, C + 1, "-21")):
+        ses = hostlib.Session(init, dict(PROP_OPTS), max_slam=5)
+        ses.feed_imu(imu)
+        slot = -np.ones((1, C + 1), dtype=np.int32)
+        slot[0, 0] = slot0
+        with pytest.raises(RuntimeError, match=msg):
+            ses.step(frames[C + 1][0], uv, uv * 0, slot, nm, np.array([99999]), np.array([kind], dtype=np.int32))
+        ses.close()
