@@ -175,6 +175,11 @@ typedef struct {
   const int *slam_state_id;   /* [n_slam] Type::id() of the landmark */
   const double *slam_p;       /* [n_slam*3] Landmark::get_xyz(false) */
   const double *slam_p_fej;   /* [n_slam*3] Landmark::get_xyz(true) */
+  /* Diagnostics (ovp_msckf_plane_update only; NULL in production): force_decision[k] = 1 accepts / 0 rejects plane k whatever
+   * its chi2 says (the statistic is still computed and returned), any other value lets the gate decide.  The reference has the
+   * same switch in spirit (chi2_multipler = 99999 in the simulation configs); with it the parity tests compare states and
+   * covariances under the oracle's own accept / reject sequence, separately from the decision statistics. */
+  const uint8_t *force_decision; /* [n_planes] */
 } ovp_plane_batch;
 
 /* UpdaterMSCKF::update, per-plane loop with MSCKF features (update/UpdaterMSCKF.cpp:411-649): for every plane in
@@ -278,6 +283,11 @@ int ovp_plane_optimize(ovp_ctx *ctx, const ovp_planeopt_batch *batch, double *cp
 /* copies an internal device buffer to host for tests: name in {"A","b","L","T","Lt","Y","G","rec","chi2",
  * "gramS","syrk"}; returns the byte count copied (or <0). */
 long ovp_debug_read(ovp_ctx *ctx, const char *name, void *host, long max_bytes);
+/* tile Cholesky (the factorization every EKF update and every plane of the plane loop runs) on a host matrix: dense factor of the
+ * matrix bordered with brow ((n+1) x (n+1), row-major; brow may be NULL), z = L^-1 brow, y = L^-T z, pivots; avg_ms = average
+ * duration over `reps` launches.  n <= 271. */
+int ovp_debug_chol2(ovp_ctx *ctx, const double *A_host, int n, int lda, const double *brow_host, int add_identity, double *L_host,
+                    double *z_host, double *y_host, double *piv_host, int reps, float *avg_ms);
 /* per-stage GPU time of the last update in milliseconds: [0]=build/gate, [1]=gram, [2]=ekf, [3]=total */
 int ovp_last_timings(ovp_ctx *ctx, float *ms4);
 /* enables hipEvent timing of the dominant kernel; returns avg ms per launch since last reset */

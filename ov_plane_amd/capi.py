@@ -77,6 +77,7 @@ class PlaneBatch(C.Structure):
         ("slam_state_id", C.c_void_p),
         ("slam_p", C.c_void_p),
         ("slam_p_fej", C.c_void_p),
+        ("force_decision", C.c_void_p),
     ]
 
 
@@ -115,7 +116,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
+    "ovp_ctx_stream", "ovp_debug_chol2", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
 ]
 
 
@@ -353,7 +354,8 @@ class Context:
             raise OvpError(rc, "ovp_msckf_fetch_results")
         return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
 
-    def plane_update(self, opts: UpdateOpts, plane_of_feat, cp, cp_fej, plane_state_id, raise_on_error=True, slam=None):
+    def plane_update(self, opts: UpdateOpts, plane_of_feat, cp, cp_fej, plane_state_id, raise_on_error=True, slam=None,
+                     force_decision=None):
         """UpdaterMSCKF::update per-plane loop. Returns dict(dx [n_planes, n], ok, chi2, dof, used).
         slam = dict(plane [k] 1-based, id [k], p [k,3], p_fej [k,3]): SLAM landmarks lying on out-of-state planes."""
         plane_of_feat = np.ascontiguousarray(plane_of_feat, dtype=np.int32)
@@ -376,6 +378,10 @@ class Context:
             pb.n_slam = len(s_id)
             pb.slam_plane, pb.slam_state_id = s_pl.ctypes.data, s_id.ctypes.data
             pb.slam_p, pb.slam_p_fej = s_p.ctypes.data, s_pf.ctypes.data
+        if force_decision is not None:
+            fd = np.ascontiguousarray(force_decision, dtype=np.uint8)
+            assert fd.shape[0] == npl
+            pb.force_decision = fd.ctypes.data
         rc = lib().ovp_msckf_plane_update(self._h, C.byref(opts), C.byref(pb), dx.ctypes.data, ok.ctypes.data,
                                           chi2.ctypes.data, dof.ctypes.data, used.ctypes.data)
         if rc != 0 and raise_on_error:
@@ -485,6 +491,22 @@ class Context:
                                       ok.ctypes.data, its.ctypes.data), "ovp_plane_optimize")
         return [dict(ok=bool(ok[k]), cp=cp_out[k].copy(), p_FinG=p_out[fs[k]:fs[k + 1]].copy(),
                      kept=kept[fs[k]:fs[k + 1]].astype(bool), iterations=int(its[k])) for k in range(P)]
+
+    def debug_chol2(self, A, brow=None, add_identity=False, reps=0):
+        """k_chol2 on a host matrix: dict(L [(n+1),(n+1)], z, y, piv, ms, rc)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        n = A.shape[0]
+        nb = n + (1 if brow is not None else 0)
+        L = np.zeros((nb, nb))
+        z, y, piv = np.zeros(n), np.zeros(n), np.zeros(n)
+        ms = C.c_float(0)
+        b = None if brow is None else np.ascontiguousarray(brow, dtype=np.float64)
+        f = lib().ovp_debug_chol2
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        rc = f(self._h, A.ctypes.data, n, n, None if b is None else b.ctypes.data, int(add_identity), L.ctypes.data,
+               z.ctypes.data, y.ctypes.data, piv.ctypes.data, int(reps), C.byref(ms))
+        return dict(L=L, z=z, y=y, piv=piv, ms=ms.value, rc=rc)
 
     def sync(self):
         _chk(lib().ovp_sync(self._h), "ovp_sync")

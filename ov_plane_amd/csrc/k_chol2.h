@@ -1,0 +1,68 @@
+// Parameter blocks of k_chol2 (k_chol2.hip): second-generation tile Cholesky with a bordered right-hand side, and the
+// plane-loop epilogues that run inside it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ovp {
+
+struct Chol2Job {
+  const double* A;      // n x n, lower triangle read (row-major, leading dimension ld)
+  int n, ld;
+  int add_identity;     // factorize A + I
+  int mode;             // 0 = factor only, 1 = plane update (gate / back substitution / commit), 2 = plane range part
+  const int* sel;       // optional: A += ((*sel) ^ sel_xor) * sel_stride  (double-buffered input chosen on the device)
+  int sel_xor;
+  size_t sel_stride;
+  const double* brow;   // optional border row [n]: z = L^-1 brow^T is produced along the way
+  int* flag;            // set to 1 on a non-positive pivot
+  double piv_floor;     // > 0: pivots are clamped from below (regularised, rank-deficient systems: mode 2) and never flagged
+  // mode 0 outputs (any may be null)
+  double* Lpack;        // tile-packed factor of the n x n part (the layout k_fwdsub reads)
+  double* Ldense;       // dense factor of the bordered matrix, (n + 1) x ldo
+  int ldo;
+  double* z_out;        // [n]
+  double* y_out;        // [n] L^-T z
+  double* piv_out;      // [n] pivots before the square root
+  long long* stamps;    // optional [nt + 1][8] cycle stamps of wave 0 (diagnostics)
+  int dbg;              // timing experiments only: 1 = skip the fused elimination, 2 = skip the trailing MFMAs, 4 = skip LDS staging
+};
+
+// per-plane arguments of the plane loop's solve (modes 1 and 2)
+struct PlaneSolve {
+  // gate (update/UpdaterMSCKF.cpp:606-631)
+  double* scal;             // [0] = rr (all projected residual rows), [1] = pr, [2] = rank deficiency  (device)
+  unsigned* range_done;     // sequence word: the range workgroup stores `seq` when scal[1..2] are valid
+  unsigned seq;
+  double thr;
+  int rows_total, rows_u, n_involved;
+  int force;                // ovp_plane_batch::force_decision (0 / 1), anything else = the gate decides
+  double tol_strict, tol_loose;
+  double* res_out;          // [4]: chi2, accept, rank deficiency, pr
+  // solution and commit
+  const double* L0;         // factor of the covariance at the start of the loop, dense lower triangular
+  int ld0;
+  double* dx_out;           // [n] correction of this plane (for the host)
+  double* dx_last;          // [n] scratch copy on the device
+  int* cur;                 // index of the current accumulated-T buffer, toggled on accept
+  const int* feat_list;     // features of this plane ...
+  int n_feat_local;
+  unsigned char* feat_used; // ... marked as consumed on accept
+  double *clone_R, *clone_p;
+  const int* clone_id;
+  int n_clones;
+  double* cal;
+  int calib_id, intr_id;
+  double* cp;
+  const int* plane_sid;
+  int n_planes;
+  int n_slam;
+  const int* slam_id;
+  double* slam_p;
+};
+
+}  // namespace ovp
+
+extern "C" {
+int ovp_chol2_max_n(void);
+hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream);
+}

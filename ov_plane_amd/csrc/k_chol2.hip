@@ -1,0 +1,755 @@
+// Register-resident tile Cholesky, second generation: no factor wave, no inverse, no panel product.
+//
+// k_tilechol (k_tile.hip) spends its step in a serial chain: 16x16 Cholesky of the diagonal block by one wave, then its inverse,
+// a workgroup barrier, the panel product with the inverse, another barrier, the trailing update (3.5 of 5.4 us per 16 columns
+// at N = 240).  Here every wave that owns panel tiles of the current tile column runs the 16-column elimination ITSELF, on a
+// private copy of the diagonal block AND on up to four of its panel tiles at once:
+//   lane = 16 g + r : DPP row g works on panel tile g of this wave, r = row inside the tile; registers d[16] = row r of the
+//   diagonal block (identical in the four DPP rows and in every wave), p[16] = row r of the panel tile;
+//   column c:  l = d[c] / sqrt(pivot)  (pivot = lane c's d[c], one v_mov_b64_dpp row_newbcast),  q = p[c] / sqrt(pivot),
+//              d[j] -= l * L_jc,  p[j] -= q * L_jc   with L_jc = lane j's l taken INSIDE the FMA (v_fmac_f64_dpp row_newbcast:j).
+// The panel solve X L_kk^T = A_ik thus finishes with the last column of the diagonal block: no inverse, no second barrier, no
+// cross-lane traffic besides the DPP operand.  Redundant factorizations of the diagonal block cost nothing (the waves would
+// wait for it anyway) and are bit-identical.  The trailing update stays on v_mfma_f64_16x16x4_f64 with operands from LDS.
+//
+// Bordered right-hand side: an extra row `brow` below the matrix is factorized along (its tiles are ordinary panel tiles), so
+// z = L^-1 brow^T and |z|^2 come for free; a right-looking... (see chol2_backsolve) gives L^-T z without leaving the registers.
+// Modes (Chol2Job::mode): 0 = factor only (packed factor / dense factor / z written out), 1 = plane loop, update part
+// (gate, back substitution, dx = L0 y, commit of the state tables), 2 = plane loop, range part (|Lr^-1 bn|^2, rank).
+#include "k_tile_body.h"
+#include "k_chol2.h"
+#include <cstring>
+
+namespace ovp {
+
+static constexpr int C2_TS = 18;             // LDS row pitch of a 16x16 tile (doubles): rows 16-byte aligned
+static constexpr int C2_TSZ = 16 * C2_TS;    // doubles per LDS tile
+static constexpr int C2_WAVES = 12;          // 4 elimination waves + 8 tile waves
+
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+
+// d[j] += bcast_j(nl) * l   (lane j of the own 16-lane row supplies nl); `first` inserts the two wait states a DPP read of a
+// VGPR written by the previous VALU instruction needs (inline asm is invisible to the hazard recognizer)
+#define C2_FMAC_DPP(acc, src_dpp, mul, J)                                                                      \
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src_dpp), "v"(mul))
+
+#define C2_FMAC_DPP_NOP(acc, src_dpp, mul, J)                                                                       \
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src_dpp), "v"(mul))
+
+// same, preceded by the two wait states (use it for the first consumer of a freshly computed DPP source)
+template <int J>
+__device__ __forceinline__ void fmac_bcast_nop(double& acc, const double& src_dpp, const double& mul) {
+  if constexpr (J == 0) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 0);
+  else if constexpr (J == 1) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 1);
+  else if constexpr (J == 2) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 2);
+  else if constexpr (J == 3) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 3);
+  else if constexpr (J == 4) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 4);
+  else if constexpr (J == 5) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 5);
+  else if constexpr (J == 6) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 6);
+  else if constexpr (J == 7) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 7);
+  else if constexpr (J == 8) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 8);
+  else if constexpr (J == 9) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 9);
+  else if constexpr (J == 10) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 10);
+  else if constexpr (J == 11) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 11);
+  else if constexpr (J == 12) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 12);
+  else if constexpr (J == 13) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 13);
+  else if constexpr (J == 14) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 14);
+  else C2_FMAC_DPP_NOP(acc, src_dpp, mul, 15);
+}
+
+template <int J>
+__device__ __forceinline__ void fmac_bcast(double& acc, const double& src_dpp, const double& mul) {
+  if constexpr (J == 0) C2_FMAC_DPP(acc, src_dpp, mul, 0);
+  else if constexpr (J == 1) C2_FMAC_DPP(acc, src_dpp, mul, 1);
+  else if constexpr (J == 2) C2_FMAC_DPP(acc, src_dpp, mul, 2);
+  else if constexpr (J == 3) C2_FMAC_DPP(acc, src_dpp, mul, 3);
+  else if constexpr (J == 4) C2_FMAC_DPP(acc, src_dpp, mul, 4);
+  else if constexpr (J == 5) C2_FMAC_DPP(acc, src_dpp, mul, 5);
+  else if constexpr (J == 6) C2_FMAC_DPP(acc, src_dpp, mul, 6);
+  else if constexpr (J == 7) C2_FMAC_DPP(acc, src_dpp, mul, 7);
+  else if constexpr (J == 8) C2_FMAC_DPP(acc, src_dpp, mul, 8);
+  else if constexpr (J == 9) C2_FMAC_DPP(acc, src_dpp, mul, 9);
+  else if constexpr (J == 10) C2_FMAC_DPP(acc, src_dpp, mul, 10);
+  else if constexpr (J == 11) C2_FMAC_DPP(acc, src_dpp, mul, 11);
+  else if constexpr (J == 12) C2_FMAC_DPP(acc, src_dpp, mul, 12);
+  else if constexpr (J == 13) C2_FMAC_DPP(acc, src_dpp, mul, 13);
+  else if constexpr (J == 14) C2_FMAC_DPP(acc, src_dpp, mul, 14);
+  else C2_FMAC_DPP(acc, src_dpp, mul, 15);
+}
+
+#define C2_MOV_DPP(dst, src, J) \
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src))
+
+template <int J>
+__device__ __forceinline__ double bcast_row(const double& src) {
+  double dst;
+  if constexpr (J == 0) C2_MOV_DPP(dst, src, 0);
+  else if constexpr (J == 1) C2_MOV_DPP(dst, src, 1);
+  else if constexpr (J == 2) C2_MOV_DPP(dst, src, 2);
+  else if constexpr (J == 3) C2_MOV_DPP(dst, src, 3);
+  else if constexpr (J == 4) C2_MOV_DPP(dst, src, 4);
+  else if constexpr (J == 5) C2_MOV_DPP(dst, src, 5);
+  else if constexpr (J == 6) C2_MOV_DPP(dst, src, 6);
+  else if constexpr (J == 7) C2_MOV_DPP(dst, src, 7);
+  else if constexpr (J == 8) C2_MOV_DPP(dst, src, 8);
+  else if constexpr (J == 9) C2_MOV_DPP(dst, src, 9);
+  else if constexpr (J == 10) C2_MOV_DPP(dst, src, 10);
+  else if constexpr (J == 11) C2_MOV_DPP(dst, src, 11);
+  else if constexpr (J == 12) C2_MOV_DPP(dst, src, 12);
+  else if constexpr (J == 13) C2_MOV_DPP(dst, src, 13);
+  else if constexpr (J == 14) C2_MOV_DPP(dst, src, 14);
+  else C2_MOV_DPP(dst, src, 15);
+  return dst;
+}
+
+// Fused elimination of a 16x16 diagonal block (d: row r = lane & 15, a copy in each DPP row) and of one panel tile per DPP row
+// (p).  On return d = row r of L_kk (entries above the diagonal are garbage), p = row r of A_ik L_kk^-T.  piv_out[c] = pivot of
+// column c before the square root (lane-uniform).  Returns true if a pivot was not positive.
+__device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], double* __restrict__ piv_out, const bool write_piv,
+                                             const double floor) {
+  bool bad = false;
+  double piv = bcast_row<0>(d[0]);
+  sfor<16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (write_piv) piv_out[c] = piv;
+    bad = bad || !(piv > 0.0);
+    const double inv = rsqrt_nr2(floor > 0.0 ? fmax(piv, floor) : piv);
+    const double l = d[c] * inv;
+    const double q = p[c] * inv;
+    double nl = -l;
+    d[c] = l;
+    p[c] = q;
+    if constexpr (c + 1 < 16) {
+      // next pivot first: its broadcast / rsq / Newton chain then overlaps the remaining updates of this column
+      fmac_bcast_nop<c + 1>(d[c + 1], nl, l);
+      piv = bcast_row<c + 1>(d[c + 1]);
+      fmac_bcast<c + 1>(p[c + 1], nl, q);
+      sfor<14 - c>([&](auto jc) {
+        constexpr int j = c + 2 + decltype(jc)::value;
+        fmac_bcast<j>(d[j], nl, l);
+        fmac_bcast<j>(p[j], nl, q);
+      });
+    }
+  });
+  return bad;
+}
+
+// acc -= X Y^T for two row-major LDS tiles (pitch C2_TS): MFMA operand element [row lc][k = lr + 4 s]
+__device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* Y, double4_t acc, int lc, int lr) {
+  const double* xp = X + lc * C2_TS + lr;
+  const double* yp = Y + lc * C2_TS + lr;
+  double a0 = -xp[0], b0 = yp[0], a1 = -xp[4], b1 = yp[4];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+  a0 = -xp[8];
+  b0 = yp[8];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+  a1 = -xp[12];
+  b1 = yp[12];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+  return acc;
+}
+
+#define C2_WSYNC()                                           \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+  } while (0)
+
+// Roles.  Waves 0..3 eliminate (VALU, DPP chains), waves 4..11 hold the tiles and run the trailing update (MFMA): the
+// elimination of panel k + 1 overlaps the trailing update of step k on the other execution pipe of the same SIMDs.
+// Hand-over through LDS counters (a wave's LDS traffic is in order, so data written before the increment is visible to whoever
+// sees the increment):
+//   cnt_col   += 1 per tile wave once its tiles of the NEXT column are in LDS          (tile waves -> elimination waves)
+//   cnt_panel += 1 per elimination wave once its part of the panel is in LDS           (elimination waves -> tile waves)
+//   cnt_trail += 1 per tile wave at the end of a step: the panel buffer of that step may be overwritten two steps later
+static constexpr int C2_EW = 4;
+static constexpr int C2_TW = C2_WAVES - C2_EW;
+
+__device__ __forceinline__ void c2_wait_ge(int* ctr, int target) {
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void c2_signal(int* ctr, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// f(slot) for the slots lo..hi (wave-uniform bounds) of the statically indexed tile registers: one jump into the unrolled
+// sequence instead of a test per slot (a skipped slot costs ~40 cycles of branch and instruction fetch)
+template <int MAXSLOT, class F>
+__device__ __forceinline__ void slot_range(int lo, int hi, F&& f) {
+  if (lo > hi) return;
+#define C2_CASE(S)                                                        \
+  case S:                                                                 \
+    if constexpr (S < MAXSLOT) f(std::integral_constant<int, S>{});       \
+    if (hi <= S) break;                                                   \
+    [[fallthrough]];
+  switch (lo) {
+    C2_CASE(0) C2_CASE(1) C2_CASE(2) C2_CASE(3) C2_CASE(4) C2_CASE(5) C2_CASE(6) C2_CASE(7) C2_CASE(8) C2_CASE(9) C2_CASE(10)
+    C2_CASE(11) C2_CASE(12) C2_CASE(13) C2_CASE(14) C2_CASE(15) C2_CASE(16) C2_CASE(17) C2_CASE(18) C2_CASE(19) C2_CASE(20)
+    C2_CASE(21) C2_CASE(22) C2_CASE(23)
+    default: break;
+  }
+#undef C2_CASE
+}
+
+// LDS carve-up (doubles)
+struct Chol2Lds {
+  double* Dbuf;   // current diagonal block, row-major
+  double* PB;     // 2 x nt panel tiles
+  double* Dsave;  // nt finished diagonal blocks L_kk (row-major, zero above the diagonal)
+  double* zbuf;   // border row of the factor: z = L^-1 brow^T   [nt * 16]
+  double* ybuf;   // back substitution result                     [nt * 16]
+  double* pivs;   // pivots before the square root               [nt * 16]
+  double* slots;  // [C2_TW][16] partial sums of the back substitution
+  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail
+};
+__host__ __device__ constexpr int chol2_lds_doubles(int nt) { return C2_TSZ * (1 + 3 * nt) + 3 * 16 * nt + C2_TW * 16 + 8; }
+__device__ __forceinline__ Chol2Lds chol2_carve(double* lds, int nt) {
+  Chol2Lds s;
+  s.Dbuf = lds;
+  s.PB = s.Dbuf + C2_TSZ;
+  s.Dsave = s.PB + 2 * nt * C2_TSZ;
+  s.zbuf = s.Dsave + nt * C2_TSZ;
+  s.ybuf = s.zbuf + 16 * nt;
+  s.pivs = s.ybuf + 16 * nt;
+  s.slots = s.pivs + 16 * nt;
+  s.cnt = reinterpret_cast<int*>(s.slots + C2_TW * 16);
+  return s;
+}
+
+// Element (r, c) of the matrix that is factorized: the n x n input (+ I), the border row n, identity padding behind it.
+__device__ __forceinline__ double c2_elem(const Chol2Job& J, const double* __restrict__ A, int r, int c, int nb) {
+  const int n = J.n;
+  double x;
+  if (r < n && c < n) {
+    x = A[(size_t)r * J.ld + c];
+    if (r == c && J.add_identity) x += 1.0;
+  } else if (r == n && nb > n) {
+    x = (c < n) ? J.brow[c] : (c == n ? 1e300 : 0.0);
+  } else if (c == n && nb > n) {
+    x = (r < n) ? J.brow[r] : 0.0;  // (upper part, never used)
+  } else {
+    x = (r == c) ? 1.0 : 0.0;
+  }
+  return x;
+}
+
+// tile slots of tile wave tw in tile column k (contiguous: the tiles are dealt out cyclically over the column-major list)
+__device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int& hi) {
+  const int cs = k * nt - (k * (k - 1)) / 2;  // list index of tile (k, k)
+  const int ce = cs + (nt - k) - 1;           // ... of tile (nt - 1, k)
+  lo = (cs - tw + C2_TW - 1) / C2_TW;         // smallest s with s * C2_TW + tw >= cs   (cs >= 0, tw < C2_TW)
+  hi = (ce - tw >= 0) ? (ce - tw) / C2_TW : -1;
+  if (cs - tw < 0) lo = 0;
+}
+
+#define C2_STAMP(kk, i)                                                                              \
+  do {                                                                                               \
+    if (J.stamps && lane == 0) J.stamps[(kk) * 16 + (i)] = (long long)__builtin_readcyclecounter();  \
+  } while (0)
+
+// The factorization proper.  On return (tile waves): tile[] = final factor tiles (MFMA accumulator layout); S.Dsave = diagonal
+// blocks, S.zbuf = border row (if any), S.pivs = pivots.  Every wave of the workgroup (C2_WAVES x 64 threads) must call it.
+template <int MAXSLOT>
+__device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& S, double4_t (&tile)[MAXSLOT], int (&ti)[MAXSLOT],
+                                             int (&tj)[MAXSLOT], int& bad_out) {
+  const int n = J.n;
+  const int nb = J.brow ? n + 1 : n;  // bordered dimension
+  const int nt = (nb + 15) >> 4;
+  const int ntiles = nt * (nt + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int tb = n >> 4, rb = n & 15;  // tile row / row inside the tile of the border row
+  int* cnt_col = S.cnt;
+  int* cnt_panel = S.cnt + 1;
+  int* cnt_trail = S.cnt + 2;
+  if (tid < 4) S.cnt[tid] = 0;
+  for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) S.zbuf[i] = 0.0;
+  sfor<MAXSLOT>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    ti[s] = -1;
+    tj[s] = -1;
+    tile[s] = double4_t{0.0, 0.0, 0.0, 0.0};
+  });
+  __syncthreads();
+  bool bad = false;
+
+  if (wave < C2_EW) {
+    // =============================== elimination waves ===============================
+    const int ew = wave, g = lr, r = lc;
+    __builtin_amdgcn_s_setprio(3);  // the serial chain: its instructions go first, the tile waves fill the gaps
+    for (int k = 0; k < nt; ++k) {
+      double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
+      if (ew == 0) C2_STAMP(k, 0);
+      c2_wait_ge(cnt_col, C2_TW * (k + 1));  // column k is in LDS
+      if (ew == 0) C2_STAMP(k, 1);
+      const int my_i = k + 1 + ew + C2_EW * g;
+      const bool has_p = my_i < nt;
+      if (ew == 0 || k + 1 + ew < nt) {
+        double d[16], p[16];
+        {
+          const dbl2_t* dr = reinterpret_cast<const dbl2_t*>(S.Dbuf + r * C2_TS);
+          const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(pbk + (has_p ? my_i : 0) * C2_TSZ + r * C2_TS);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const dbl2_t dv = dr[q];
+            d[2 * q] = dv[0];
+            d[2 * q + 1] = dv[1];
+            const dbl2_t pq = pr[q];
+            p[2 * q] = has_p ? pq[0] : 0.0;
+            p[2 * q + 1] = has_p ? pq[1] : 0.0;
+          }
+        }
+        if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, ew == 0 && lane == 0, J.piv_floor) || bad;
+        if (ew == 0) C2_STAMP(k, 2);
+        if (has_p) {
+          dbl2_t* pw = reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) pw[q] = dbl2_t{p[2 * q], p[2 * q + 1]};
+          if (my_i == tb && r == rb && nb > n) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
+          }
+        }
+        if (ew == 0 && g == 0) {
+          dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dw[q] = dbl2_t{(2 * q <= r) ? d[2 * q] : 0.0, (2 * q + 1 <= r) ? d[2 * q + 1] : 0.0};
+          if (k == tb && r == rb && nb > n) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+              if (c < rb) S.zbuf[16 * k + c] = d[c];
+          }
+        }
+      }
+      c2_signal(cnt_panel, lane);
+      if (ew == 0) C2_STAMP(k, 3);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    // ================================== tile waves ===================================
+    const int tw = wave - C2_EW;
+    // ---- load: tile index idx = slot * C2_TW + tw, column-major over the lower tile triangle ----
+    {
+      const double* Abase = J.A + (J.sel ? (size_t)((*J.sel) ^ J.sel_xor) * J.sel_stride : (size_t)0);
+      int jj = 0, cstart = 0;
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const int idx = s * C2_TW + tw;
+        int i = -1, j = -1;
+        if (idx < ntiles) {
+          while (cstart + (nt - jj) <= idx) {
+            cstart += nt - jj;
+            ++jj;
+          }
+          j = jj;
+          i = jj + (idx - cstart);
+        }
+        i = __builtin_amdgcn_readfirstlane(i);
+        j = __builtin_amdgcn_readfirstlane(j);
+        ti[s] = i;
+        tj[s] = j;
+        // raw loads from clamped addresses (all of a wave's tiles in flight together); only the diagonal tiles and the tile
+        // rows that hold the border / padding pay for selects behind their loads
+        double4_t t = {0.0, 0.0, 0.0, 0.0};
+        if (i >= 0) {
+          const int c = 16 * j + lc;
+          const int cc = c < n ? c : n - 1;
+          const bool special = (i >= (n >> 4)) || (i == j);
+          double brow_c = 0.0;
+          if (nb > n && i == tb) brow_c = J.brow[cc];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = 16 * i + lr + 4 * v;
+            const int rc = r < n ? r : n - 1;
+            double x = Abase[(size_t)rc * J.ld + cc];
+            if (special) {
+              double pad = (r == c) ? 1.0 : 0.0;
+              if (nb > n && r == n) pad = (c < n) ? brow_c : (c == n ? 1e300 : 0.0);
+              x = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
+            }
+            t[v] = x;
+          }
+        }
+        tile[s] = t;
+      });
+    }
+    const int s_last = (ntiles - 1 - tw >= 0) ? (ntiles - 1 - tw) / C2_TW : -1;
+    auto put_rowmajor = [&](double* buf, const double4_t& t) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) buf[(lr + 4 * v) * C2_TS + lc] = t[v];
+    };
+    auto get_acc = [&](const double* buf) {
+      double4_t t;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[v] = buf[(lr + 4 * v) * C2_TS + lc];
+      return t;
+    };
+    // column 0: diagonal block and panel tiles go to LDS
+    {
+      int lo, hi;
+      c2_col_slots(0, nt, tw, lo, hi);
+      slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (ti[s] == 0) put_rowmajor(S.Dbuf, tile[s]);
+        else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
+      });
+      c2_signal(cnt_col, lane);
+    }
+    for (int k = 0; k < nt; ++k) {
+      double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
+      double* pbn = S.PB + ((k + 1) & 1) * nt * C2_TSZ;
+      int lo, hi, lo1 = 0, hi1 = -1;
+      // per-step opaque copies: otherwise the LDS address arithmetic of every slot is hoisted out of the step loop and spills
+      int lc_k = lc, lr_k = lr;
+      asm volatile("" : "+v"(lc_k), "+v"(lr_k));
+      c2_col_slots(k, nt, tw, lo, hi);
+      auto put_rowmajor_k = [&](double* buf, const double4_t& t) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) buf[(lr_k + 4 * v) * C2_TS + lc_k] = t[v];
+      };
+      auto get_acc_k = [&](const double* buf) {
+        double4_t t;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[v] = buf[(lr_k + 4 * v) * C2_TS + lc_k];
+        return t;
+      };
+      if (k + 1 < nt) c2_col_slots(k + 1, nt, tw, lo1, hi1);
+      if (tw == 0) C2_STAMP(k, 8);
+      c2_wait_ge(cnt_panel, C2_EW * (k + 1));  // panel k (and L_kk) are in LDS
+      if (tw == 0) C2_STAMP(k, 9);
+      if (k + 1 < nt) {
+        // ---- trailing update, column k + 1 first: it is handed to the elimination waves while the rest is updated ----
+        slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
+        });
+        if (tw == 0) C2_STAMP(k, 10);
+        c2_wait_ge(cnt_trail, C2_TW * k);  // every tile wave is done with panel k - 1, whose buffer receives column k + 1
+        slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (ti[s] == k + 1) put_rowmajor_k(S.Dbuf, tile[s]);
+          else put_rowmajor_k(pbn + ti[s] * C2_TSZ, tile[s]);
+        });
+        c2_signal(cnt_col, lane);
+        if (tw == 0) C2_STAMP(k, 11);
+      }
+      // own tiles of column k take their final values (off the critical path: the panel buffer lives two more steps)
+      slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
+      });
+      if (k + 1 < nt) {
+        slot_range<MAXSLOT>(hi1 + 1 > lo1 ? hi1 + 1 : lo1, s_last, [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
+        });
+      }
+      c2_signal(cnt_trail, lane);
+      if (tw == 0) C2_STAMP(k, 12);
+    }
+  }
+  bad_out = (bad && !(J.piv_floor > 0.0)) ? 1 : 0;
+}
+
+// y = L^-T z on the n x n part of the factor held in tile[] (left-looking over tile columns, descending): every tile wave adds
+// up L_ik^T y_i over its tiles of column k, wave 0 sums the partial vectors in a fixed order and back-substitutes the 16x16
+// block with the same DPP broadcast-in-FMA chain as the factorization.  Entries at or behind the border row are zero.
+template <int MAXSLOT>
+__device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt, const double4_t (&tile)[MAXSLOT],
+                                                const int (&ti)[MAXSLOT], const int (&tj)[MAXSLOT]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  for (int k = nt - 1; k >= 0; --k) {
+    if (wave >= C2_EW) {
+      const int tw = wave - C2_EW;
+      int lo, hi;
+      c2_col_slots(k, nt, tw, lo, hi);
+      double part = 0.0;
+      slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (ti[s] > k) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) part = fma(tile[s][v], S.ybuf[16 * ti[s] + lr + 4 * v], part);
+        }
+      });
+      part += shfl_xor_f64(part, 16);
+      part += shfl_xor_f64(part, 32);
+      if (lane < 16) S.slots[tw * 16 + lane] = part;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int r = lc;
+      double rhs = S.zbuf[16 * k + r];
+#pragma unroll
+      for (int w = 0; w < C2_TW; ++w) rhs -= S.slots[w * 16 + r];
+      if (16 * k + r >= n) rhs = 0.0;
+      // column r of L_kk: col[c] = L_kk[c][r], c >= r
+      double col[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) col[c] = S.Dsave[k * C2_TSZ + c * C2_TS + r];
+      const double ninv = -1.0 / col[r];
+      double y = 0.0;
+      sfor<16>([&](auto cc) {
+        constexpr int c = 15 - decltype(cc)::value;
+        double nt_ = rhs * ninv;  // -y_c in lane c
+        if (r == c) y = -nt_;
+        fmac_bcast_nop<c>(rhs, nt_, col[c]);  // rhs_r -= L_cr y_c   (lanes r < c use it; the others are done)
+      });
+      if (lane < 16) S.ybuf[16 * k + r] = (16 * k + r < n) ? y : 0.0;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int MAXSLOT>
+__global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, const Chol2Job J1, const PlaneSolve ps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const Chol2Job& J = blockIdx.x == 0 ? J0 : J1;
+  const int n = J.n;
+  const int nb = J.brow ? n + 1 : n;
+  const int nt = (nb + 15) >> 4;
+  const Chol2Lds S = chol2_carve(lds, nt);
+  double4_t tile[MAXSLOT];
+  int ti[MAXSLOT], tj[MAXSLOT];
+  int bad = 0;
+  __shared__ int sh_bad;
+  if (threadIdx.x == 0) sh_bad = 0;
+  chol2_factor<MAXSLOT>(J, S, tile, ti, tj, bad);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  if (bad && lane == 0) atomicOr(&sh_bad, 1);  // a wave only sees the pivots of the steps it took part in
+  __syncthreads();
+  bad = sh_bad;
+  if (bad && tid == 0 && J.flag) *J.flag = 1;
+
+  if (J.mode == 0) {
+    // ---- outputs of a plain factorization ----
+    if (J.z_out)
+      for (int i = tid; i < n; i += C2_WAVES * 64) J.z_out[i] = S.zbuf[i];
+    if (J.y_out) {  // diagnostics: y = L^-T z
+      chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj);
+      for (int i = tid; i < n; i += C2_WAVES * 64) J.y_out[i] = S.ybuf[i];
+    }
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (ti[s] >= 0) {
+        if (J.Ldense) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rr = 16 * ti[s] + lr + 4 * v, cc = 16 * tj[s] + lc;
+            if (rr < nb && cc < nb) {
+              J.Ldense[(size_t)rr * J.ldo + cc] = (cc <= rr) ? tile[s][v] : 0.0;
+              if (ti[s] != tj[s]) J.Ldense[(size_t)cc * J.ldo + rr] = 0.0;
+            }
+          }
+        }
+        if (J.Lpack && 16 * ti[s] < n && 16 * tj[s] < n) {
+          // tile-packed copy for k_fwdsub: tile index over the n x n part (nt_n tile rows), column-major inside the tile;
+          // rows / columns at or behind the border row are replaced by the identity
+          const int ntn = (n + 15) >> 4;
+          const int tidx = tj[s] * ntn - (tj[s] * (tj[s] - 1)) / 2 + (ti[s] - tj[s]);
+          double* pk = J.Lpack + (size_t)tidx * 256;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = lr + 4 * v, col = lc;
+            const int gr = 16 * ti[s] + row, gc = 16 * tj[s] + col;
+            double x = tile[s][v];
+            if (gr >= n || gc >= n) x = (gr == gc) ? 1.0 : 0.0;
+            if (ti[s] == tj[s] && col > row) x = 0.0;
+            pk[col * 16 + row] = x;
+          }
+        }
+      }
+    });
+    if (J.piv_out)
+      for (int i = tid; i < n; i += C2_WAVES * 64) J.piv_out[i] = S.pivs[i];
+    return;
+  }
+
+  if (J.mode == 2) {
+    // ---- range part of the plane's residual:  pr = |Lr^-1 bn|^2, rank deficiency of the normalised Gram ----
+    // The columns arrive permuted (involved non-clone columns, clone columns, then the columns the plane does not touch, which
+    // are unit pivots).  Pivots below tol_strict are deficient; behind the first of them the Schur complements carry the
+    // amplified rounding error of the near-singular leading block (1e-16 / 1e-10), so there a pivot counts as deficient below
+    // tol_loose (measured: deficient 1e-10..1e-5, regular >= 1e-3).
+    if (wave == 0) {
+      double pr = 0.0;
+      for (int i = lane; i < n; i += 64) pr = fma(S.zbuf[i], S.zbuf[i], pr);
+      pr = wave_sum(pr);
+      if (lane == 0) {
+        int ndeg = 0;
+        bool seen = false;
+        for (int i = 0; i < ps.n_involved; ++i) {
+          const double pv = S.pivs[i];
+          if (pv < ps.tol_strict) {
+            ++ndeg;
+            seen = true;
+          } else if (seen && pv < ps.tol_loose) {
+            ++ndeg;
+          }
+        }
+        ps.scal[1] = pr;
+        ps.scal[2] = (double)ndeg;
+        __threadfence();
+        __hip_atomic_store(ps.range_done, ps.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+
+  // ---- mode 1: plane update.  zz = |Lt^-1 c|^2 = b . dx ----
+  __shared__ double sh_zz;
+  __shared__ int sh_ok;
+  if (wave == 0) {
+    double zz = 0.0;
+    for (int i = lane; i < n; i += 64) zz = fma(S.zbuf[i], S.zbuf[i], zz);
+    zz = wave_sum(zz);
+    if (lane == 0) {
+      // the other workgroup publishes pr and the rank; both take the same time, this wait is short
+      while (__hip_atomic_load(ps.range_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) __builtin_amdgcn_s_sleep(2);
+      const double rr = ps.scal[0], pr = ps.scal[1], ndeg = ps.scal[2];
+      const double rank = (double)ps.n_involved - ndeg;
+      const double noise_rows = fmax((double)ps.rows_u - rank, 0.0);
+      const double denom = (double)ps.rows_total - rank;
+      const double s2 = denom > 0.5 ? fmax(rr - pr, 0.0) / denom : 0.0;
+      const double chi2 = (pr - zz) + noise_rows * s2;
+      const bool fact_ok = (bad == 0);
+      const bool ok = fact_ok && (ps.force == 0 ? false : (ps.force == 1 ? true : (chi2 <= ps.thr)));
+      ps.res_out[0] = chi2;
+      ps.res_out[1] = ok ? 1.0 : 0.0;
+      ps.res_out[2] = ndeg;
+      ps.res_out[3] = pr;
+      sh_zz = zz;
+      sh_ok = ok ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
+
+  chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj);
+  // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
+  // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
+  double* dxs = S.zbuf;  // z is no longer needed
+  __syncthreads();
+  {
+    const int half = tid & 1;
+    for (int row = tid >> 1; row < ((n + C2_WAVES * 32 - 1) / (C2_WAVES * 32)) * (C2_WAVES * 32); row += C2_WAVES * 32) {
+    double s = 0.0;
+    if (row < n) {
+      const int npair = (row + 2) >> 1;            // 16-byte pairs covering columns 0..row (ld is even, rows are 16-byte aligned)
+      const int p0 = half ? (npair >> 1) : 0, p1 = half ? npair : (npair >> 1);
+      const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(ps.L0 + (size_t)row * ps.ld0);
+      double s1 = 0.0;
+#pragma unroll 8
+      for (int q = p0; q < p1; ++q) {
+        const dbl2_t v = lrow[q];
+        const int c0 = 2 * q;
+        s = fma(v[0], S.ybuf[c0], s);
+        s1 = fma(c0 + 1 <= row ? v[1] : 0.0, S.ybuf[c0 + 1], s1);
+      }
+      s += s1;
+    }
+    s += swap_pair_f64(s);
+    if (row < n && half == 0) dxs[row] = s;
+    }
+  }
+  __syncthreads();
+  // ---- commit (ext Type::update on the device tables, update/UpdaterMSCKF.cpp:646-648) ----
+  for (int i = tid; i < n; i += C2_WAVES * 64) {
+    ps.dx_out[i] = dxs[i];
+    ps.dx_last[i] = dxs[i];
+  }
+  if (tid == 0) *ps.cur ^= 1;  // the accumulated T of this plane becomes the current one
+  for (int i = tid; i < ps.n_feat_local; i += C2_WAVES * 64) ps.feat_used[ps.feat_list[i]] = 1;
+  auto rot_update = [&](double* R, const double* dth) {
+    double qx = 0.5 * dth[0], qy = 0.5 * dth[1], qz = 0.5 * dth[2], qw = 1.0;
+    const double nn = 1.0 / sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    qx *= nn;
+    qy *= nn;
+    qz *= nn;
+    qw *= nn;
+    const double a = 2.0 * qw * qw - 1.0;
+    double D[9];
+    D[0] = a + 2.0 * qx * qx;
+    D[1] = 2.0 * qw * qz + 2.0 * qx * qy;
+    D[2] = -2.0 * qw * qy + 2.0 * qx * qz;
+    D[3] = -2.0 * qw * qz + 2.0 * qy * qx;
+    D[4] = a + 2.0 * qy * qy;
+    D[5] = 2.0 * qw * qx + 2.0 * qy * qz;
+    D[6] = 2.0 * qw * qy + 2.0 * qz * qx;
+    D[7] = -2.0 * qw * qx + 2.0 * qz * qy;
+    D[8] = a + 2.0 * qz * qz;
+    double O[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) O[3 * i + j] = D[3 * i] * R[j] + D[3 * i + 1] * R[3 + j] + D[3 * i + 2] * R[6 + j];
+    for (int i = 0; i < 9; ++i) R[i] = O[i];
+  };
+  if (tid < ps.n_clones) {
+    const int id = ps.clone_id[tid];
+    rot_update(ps.clone_R + 9 * tid, dxs + id);
+    for (int k = 0; k < 3; ++k) ps.clone_p[3 * tid + k] += dxs[id + 3 + k];
+  } else if (tid == ps.n_clones) {
+    if (ps.calib_id >= 0) {
+      rot_update(ps.cal, dxs + ps.calib_id);
+      for (int k = 0; k < 3; ++k) ps.cal[9 + k] += dxs[ps.calib_id + 3 + k];
+    }
+    if (ps.intr_id >= 0)
+      for (int k = 0; k < 8; ++k) ps.cal[12 + k] += dxs[ps.intr_id + k];
+  } else if (tid > ps.n_clones && tid <= ps.n_clones + ps.n_planes) {
+    const int pl = tid - ps.n_clones - 1;
+    if (ps.plane_sid[pl] >= 0)
+      for (int k = 0; k < 3; ++k) ps.cp[3 * pl + k] += dxs[ps.plane_sid[pl] + k];
+  }
+  for (int q = tid; q < ps.n_slam; q += C2_WAVES * 64)
+    for (int k = 0; k < 3; ++k) ps.slam_p[3 * q + k] += dxs[ps.slam_id[q] + k];
+}
+
+}  // namespace ovp
+
+extern "C" {
+
+int ovp_chol2_max_n(void) { return 16 * 17 - 1; }  // bordered dimension n + 1 <= 272 (17 tile rows, 20 tile slots per wave)
+
+// one workgroup (j1 == nullptr) or two (plane loop: update part and range part side by side)
+hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream) {
+  using namespace ovp;
+  auto ntof = [](const Chol2Job* j) { return ((j->brow ? j->n + 1 : j->n) + 15) / 16; };
+  int nt = ntof(j0);
+  if (j1 && ntof(j1) > nt) nt = ntof(j1);
+  const int slots = (nt * (nt + 1) / 2 + C2_TW - 1) / C2_TW;
+  const size_t shmem = (size_t)chol2_lds_doubles(nt) * sizeof(double);
+  Chol2Job dummy = *j0;
+  PlaneSolve psd = PlaneSolve();
+  const Chol2Job& b = j1 ? *j1 : dummy;
+  const PlaneSolve& p = ps ? *ps : psd;
+  const dim3 grid(j1 ? 2 : 1), block(C2_WAVES * 64);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_chol2<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr = true;
+  }
+  if (slots <= 10)
+    hipLaunchKernelGGL((k_chol2<10>), grid, block, shmem, stream, *j0, b, p);
+  else if (slots <= 15)
+    hipLaunchKernelGGL((k_chol2<15>), grid, block, shmem, stream, *j0, b, p);
+  else if (slots <= 17)
+    hipLaunchKernelGGL((k_chol2<17>), grid, block, shmem, stream, *j0, b, p);
+  else if (slots <= 20)
+    hipLaunchKernelGGL((k_chol2<20>), grid, block, shmem, stream, *j0, b, p);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+}

@@ -107,7 +107,8 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   OVP_STAMP_DECL;
   OVP_STAMP(0);
   const bool valid = lane < n;
-  const bool feat_ok = (m >= 2) && (m <= OVP_MAX_MEAS_DEV);  // UpdaterMSCKF.cpp:94-96
+  // UpdaterMSCKF.cpp:94-96; features used by an accepted plane left feature_vec before the point loop (:657-666)
+  const bool feat_ok = (m >= 2) && (m <= OVP_MAX_MEAS_DEV) && !(p.skip && p.skip[f]);
   const int* cidx = p.clone_idx + (size_t)f * p.max_meas;
   const int ci = cidx[valid ? a : 0];
   const int ida = p.clone_id[ci];

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_dx_from_factor(const double* __restric
 // On accept: M <- V^T, pose tables / calibration / in-state planes updated with dx, dx stored for the host.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_plane_gate(const double* __restrict__ scal, const int* __restrict__ flags,
-                                                     double thr, int rows_total, int rows_u, int n_involved,
+                                                     double thr, int rows_total, int rows_u, int n_involved, int force,
                                                      double* __restrict__ res_out /* [4]: chi2, accept, n_deg, pr */) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double rr = scal[0], pr = scal[1], ndeg = scal[2], bdx = scal[3];
@@ -516,7 +516,8 @@ __global__ __launch_bounds__(256) void k_plane_gate(const double* __restrict__ s
   const double denom = (double)rows_total - rank;
   const double s2 = denom > 0.5 ? fmax(rr - pr, 0.0) / denom : 0.0;
   const double chi2 = (pr - bdx) + noise_rows * s2;
-  const bool ok = (flags[0] == 0) && (chi2 <= thr);
+  // force: 0 / 1 = decision handed over by the caller (ovp_plane_batch::force_decision), anything else = the gate decides
+  const bool ok = (flags[0] == 0) && (force == 0 ? false : (force == 1 ? true : (chi2 <= thr)));
   res_out[0] = chi2;
   res_out[1] = ok ? 1.0 : 0.0;
   res_out[2] = ndeg;
@@ -733,9 +734,9 @@ hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const doubl
   return hipGetLastError();
 }
 hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
-                                 int n_involved, double* res_out, hipStream_t stream) {
+                                 int n_involved, int force, double* res_out, hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_plane_gate, dim3(1), dim3(64), 0, stream, scal, flags, thr, rows_total, rows_u, n_involved,
-                     res_out);
+                     force, res_out);
   return hipGetLastError();
 }
 hipError_t ovp_launch_plane_slam_rows(double* E, int lde, int n, int plane1, int n_slam, const int* slam_plane, const int* slam_id,

@@ -1,0 +1,324 @@
+// Plane loop, second generation (update/UpdaterMSCKF.cpp:411-649): the kernels between the per-feature rows (k_plane_feat,
+// k_plane.hip) and the factorization (k_chol2.hip).
+//
+// Every plane is a sequential EKF update, but nothing in it needs the covariance itself: with P0 = L0 L0^T the covariance at the
+// start of the loop and A_j, b_j the information pairs of the planes accepted so far,
+//     P_k = L0 T_k^-1 L0^T,   T_k = I + L0^T (sum_j A_j) L0 = T_(k-1) + L0^T A_k L0,
+//     dx_k = L0 T_k^-1 (L0^T b_k),   b_k . dx_k = |Lt^-1 L0^T b_k|^2   (Lt Lt^T = T_k),
+// so a plane costs: rows -> pair (k_gram_pair + k_plane_assemble2), two products (W = A L0, T_try = T + L0^T W, c = L0^T b),
+// ONE launch of k_chol2 whose two workgroups factorize T_try (bordered with c) and the normalised Gram (bordered with its
+// right-hand side, for the range part of the residual and the rank), take the gate decision, back-substitute, form dx and
+// commit the state tables.  The covariance is materialised once, after the last plane.
+#include "ovp_dev.h"
+#include "ovp_kernels.h"
+#include "k_plane2.h"
+
+namespace ovp {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int gram_index3(int p, int q) { return p * OVP_REC - (p * (p - 1)) / 2 + (q - p); }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Extended pair over [state columns | residual | plane columns] -> Ab (pair on the state columns; an out-of-state plane is
+// eliminated by its 3x3 Schur complement == UpdaterHelper::nullspace_project_inplace(Hcp_big, ...), UpdaterMSCKF.cpp:603),
+// the normalised, regularised Gram of the involved columns in the order `perm` (for the range part / rank), and the total
+// projected residual energy.  One workgroup per row of Ab (row n = b).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
+  const int r = blockIdx.x;  // 0..n
+  const int t = threadIdx.x;
+  const int n = a.n;
+  __shared__ double cst[10];
+  __shared__ double red[256];
+  __shared__ double sh_h[PA_MAXQ][7];
+  __shared__ int sh_col[PA_MAXQ][7];
+  __shared__ int sh_nq;
+  __shared__ double Ai[9], bc[3], xr[3], dr_sh, slam_rr;
+  __shared__ ColMap cm_sh[OVP_TC_MAX_TILES * 16];  // the column classification of the whole state (the entries below chase it)
+  for (int i = t; i < n; i += 256) cm_sh[i] = a.colmap[i];
+
+  // ---- constraint-row moments summed over the plane's features (fixed order) ----
+  {
+    const int e = t % 10, part = t / 10;
+    double s = 0.0;
+    if (t < 250)
+      for (int f = part; f < a.nf; f += 25) s += a.cst[(size_t)f * 10 + e];
+    red[t] = (t < 250) ? s : 0.0;
+    __syncthreads();
+    if (t < 10) {
+      double acc = 0.0;
+      for (int l = 0; l < 25; ++l) acc += red[l * 10 + t];
+      cst[t] = acc;
+    }
+  }
+  // ---- SLAM landmarks lying on this (out-of-state) plane: one point-on-plane row each (UpdaterMSCKF.cpp:545-552) ----
+  if (t == 0) {
+    int nq = 0;
+    double rr = 0.0;
+    if (!a.in_state)
+      for (int q = 0; q < a.n_slam && nq < PA_MAXQ; ++q) {
+        if (a.slam_plane[q] != a.plane1) continue;
+        const double* pv = a.slam_p + 3 * q;
+        const double* pj = a.do_fej ? a.slam_p_fej + 3 * q : pv;
+        const double* cp = a.cp;
+        const double* cj = a.do_fej ? a.cp_fej : a.cp;
+        double d = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+        double nv[3] = {cp[0] / d, cp[1] / d, cp[2] / d};
+        const double res = a.white_c * (0.0 - ((nv[0] * pv[0] + nv[1] * pv[1] + nv[2] * pv[2]) - d));
+        d = sqrt(cj[0] * cj[0] + cj[1] * cj[1] + cj[2] * cj[2]);
+        nv[0] = cj[0] / d;
+        nv[1] = cj[1] / d;
+        nv[2] = cj[2] / d;
+        const double np = nv[0] * pj[0] + nv[1] * pj[1] + nv[2] * pj[2];
+        for (int k = 0; k < 3; ++k) {
+          sh_h[nq][k] = a.white_c * nv[k];
+          sh_h[nq][3 + k] = a.white_c * 1.0 / d * (pj[k] - np * nv[k] - d * nv[k]);
+          sh_col[nq][k] = a.slam_id[q] + k;
+          sh_col[nq][3 + k] = n + 1 + k;
+        }
+        sh_h[nq][6] = res;
+        sh_col[nq][6] = n;
+        rr += res * res;
+        ++nq;
+      }
+    sh_nq = nq;
+    slam_rr = rr;
+  }
+  __syncthreads();
+
+  auto classify = [&](int col) {
+    ColMap m;
+    m.kind = 0;
+    m.idx = m.off = m.pad = 0;
+    if (col < n) {
+      m = cm_sh[col];
+      if (a.plane_sid >= 0 && col >= a.plane_sid && col < a.plane_sid + 3) {
+        m.kind = 4;
+        m.idx = col - a.plane_sid;
+      }
+    } else if (col == n) {
+      m.kind = 3;
+    } else if (a.plane_sid < 0) {
+      m.kind = 4;
+      m.idx = col - n - 1;
+    }
+    return m;
+  };
+  // entry (row, col) of the extended pair
+  auto entry = [&](int row, int col) {
+    const ColMap mr = classify(row), mc = classify(col);
+    double s = 0.0;
+    if (mr.kind == 4 || mc.kind == 4) {
+      if (mr.kind == 4 && mc.kind == 4) {
+        const int i = min(mr.idx, mc.idx), j = max(mr.idx, mc.idx);
+        s = cst[i == 0 ? j : (i == 1 ? 2 + j : 5)];
+      } else if (mr.kind == 3 || mc.kind == 3) {
+        s = cst[6 + (mr.kind == 4 ? mr.idx : mc.idx)];
+      }
+    } else if (mr.kind != 0 && mc.kind != 0) {
+      auto gcol = [](const ColMap& m) { return m.kind == 1 ? m.off : (m.kind == 2 ? 6 + m.idx : 20); };
+      const int gr = gcol(mr), gc = gcol(mc);
+      const int gi = gram_index3(min(gr, gc), max(gr, gc));
+      auto slot_sum = [&](int slot) {
+        double v = 0.0;
+        for (int ch = 0; ch < a.n_chunks; ++ch) v += a.gramS[((size_t)slot * a.n_chunks + ch) * OVP_GRAM_ELEMS + gi];
+        return v;
+      };
+      if (mr.kind == 1 && mc.kind == 1) {
+        if (mr.idx == mc.idx) s = slot_sum(mr.idx);
+      } else if (mr.kind == 1) {
+        s = slot_sum(mr.idx);
+      } else if (mc.kind == 1) {
+        s = slot_sum(mc.idx);
+      } else {
+        for (int sl = 0; sl < a.n_clones; ++sl) s += slot_sum(sl);
+      }
+    }
+    {
+      const int I = max(row, col), J = min(row, col);
+      const int ti = I >> 4, tj = J >> 4;
+      const int tile = ti * (ti + 1) / 2 + tj;
+      const int e = (I & 15) * 16 + (J & 15);
+      double d = 0.0;
+      for (int sp = 0; sp < a.n_split; ++sp) d += a.part[((size_t)sp * a.ntile + tile) * 256 + e];
+      s -= d;
+    }
+    for (int q = 0; q < sh_nq; ++q) {
+      double hr = 0.0, hc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (sh_col[q][k] == row) hr = sh_h[q][k];
+        if (sh_col[q][k] == col) hc = sh_h[q][k];
+      }
+      if (!(row == n && col == n)) s += hr * hc;
+    }
+    return s;
+  };
+
+  // ---- block-shared quantities: E_cc (out-of-state plane), b_c, this row's plane entries, the row's diagonal entry.  Every
+  // entry is a chain of dependent loads, so they are spread over twelve threads instead of being walked by one ----
+  __shared__ double ecc[6], err_sh;
+  if (!a.in_state) {
+    if (t < 6) {
+      const int i = t < 3 ? 0 : (t < 5 ? 1 : 2), j = t < 3 ? t : (t < 5 ? t - 2 : 2);
+      ecc[t] = entry(n + 1 + i, n + 1 + j);
+    } else if (t >= 64 && t < 67) {
+      bc[t - 64] = entry(n, n + 1 + (t - 64));
+    } else if (t >= 128 && t < 131) {
+      xr[t - 128] = entry(r, n + 1 + (t - 128));
+    }
+  } else if (t < 3) {
+    bc[t] = xr[t] = 0.0;
+  }
+  if (t == 192) err_sh = r < n ? entry(r, r) : 0.0;
+  __syncthreads();
+  if (t == 0) {
+    if (!a.in_state) {
+      const double a00 = ecc[0], a01 = ecc[1], a02 = ecc[2], a11 = ecc[3], a12 = ecc[4], a22 = ecc[5];
+      const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+      const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+      Ai[0] = c00 * id;
+      Ai[1] = c01 * id;
+      Ai[2] = c02 * id;
+      Ai[3] = Ai[1];
+      Ai[4] = (a00 * a22 - a02 * a02) * id;
+      Ai[5] = (a01 * a02 - a00 * a12) * id;
+      Ai[6] = Ai[2];
+      Ai[7] = Ai[5];
+      Ai[8] = (a00 * a11 - a01 * a01) * id;
+    } else {
+      for (int k = 0; k < 9; ++k) Ai[k] = 0.0;
+    }
+  }
+  __syncthreads();
+  auto schur = [&](const double (&u)[3], const double (&v)[3]) {
+    const double t0 = Ai[0] * v[0] + Ai[1] * v[1] + Ai[2] * v[2];
+    const double t1 = Ai[3] * v[0] + Ai[4] * v[1] + Ai[5] * v[2];
+    const double t2 = Ai[6] * v[0] + Ai[7] * v[1] + Ai[8] * v[2];
+    return u[0] * t0 + u[1] * t1 + u[2] * t2;
+  };
+  const double xrr[3] = {xr[0], xr[1], xr[2]};
+  if (t == 192) dr_sh = r < n ? err_sh - (a.in_state ? 0.0 : schur(xrr, xrr)) : 0.0;
+  if (r == n && t == 193) {
+    const double bcc[3] = {bc[0], bc[1], bc[2]};
+    a.scal[0] = cst[9] + slam_rr - (a.in_state ? 0.0 : schur(bcc, bcc));
+  }
+  __syncthreads();
+  const double dr = dr_sh;
+  const int pr = r < n ? a.perm[r] : -1;
+  for (int c = t; c < n; c += 256) {
+    double xc[3] = {0.0, 0.0, 0.0};
+    if (!a.in_state) {
+      xc[0] = entry(n + 1, c);
+      xc[1] = entry(n + 2, c);
+      xc[2] = entry(n + 3, c);
+    }
+    const double v = entry(r, c) - (a.in_state ? 0.0 : schur(xrr, xc));
+    a.Ab[(size_t)r * a.lda + c] = v;
+    const int pc = a.perm[c];
+    if (pc >= 0 && (pr >= 0 || r == n)) {
+      const double dc = (r == c) ? dr : entry(c, c) - (a.in_state ? 0.0 : schur(xc, xc));
+      if (r == n) {
+        a.bn[pc] = dc > 0.0 ? v / sqrt(dc) : 0.0;
+      } else {
+        double w;
+        if (dr > 0.0 && dc > 0.0) w = (r == c) ? 1.0 + a.eps : v / sqrt(dr * dc);
+        else w = (r == c) ? 1.0 : 0.0;
+        a.An[(size_t)pr * a.ldn + pc] = w;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// T_try = T_cur + L0^T W on the lower tile triangle (W = A L0 from k_gemm4), c = L0^T b.  T_cur / T_try are the two halves of
+// Tbuf selected by the device word *cur (toggled by k_chol2 when a plane is accepted).  L0 is lower triangular: the products
+// start at k = 16 bi.  grid = (nt, nt + 1): block row nt computes c.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plane_dT(int n, const double* __restrict__ L0, int ld, const double* __restrict__ W,
+                                                   const double* __restrict__ b, double* __restrict__ Tbuf, size_t tstride,
+                                                   const int* __restrict__ cur, double* __restrict__ crow) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int nt = gridDim.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane >> 4, lc = lane & 15;
+  __shared__ double red[4][256];
+  if (bi == nt) {
+    // c[j] = sum_K L0[K][j] b[K], j in tile bj: 16 columns x 16 partial sums
+    const int j = 16 * bj + (tid & 15), p = tid >> 4;
+    double s = 0.0;
+    if (j < n)
+      for (int K = 16 * bj + p; K < n; K += 16) s = fma(L0[(size_t)K * ld + j], b[K], s);
+    red[0][tid] = s;
+    __syncthreads();
+    if (tid < 16) {
+      double acc = 0.0;
+      for (int q = 0; q < 16; ++q) acc += red[0][q * 16 + tid];
+      if (16 * bj + tid < n) crow[16 * bj + tid] = acc;
+    }
+    return;
+  }
+  if (bj > bi) return;
+  const int sel = *cur;
+  const double* Tc = Tbuf + (size_t)sel * tstride;
+  double* Tt = Tbuf + (size_t)(sel ^ 1) * tstride;
+  const int i0 = bi * 16, j0 = bj * 16;
+  const int ai = i0 + lc, bjj = j0 + lc;
+  const int ks0 = (16 * bi) >> 2;  // first k-step (4 consecutive k) with a non-zero L0[k][i0..]
+  const int nsteps = (n + 3) >> 2;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int st = ks0 + wave; st < nsteps; st += 16) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 4 * (st + 4 * u) + lr;
+      av[u] = 0.0;
+      bv[u] = 0.0;
+      if (k < n && (st + 4 * u) < nsteps) {
+        if (ai < n) av[u] = L0[(size_t)k * ld + ai];
+        if (bjj < n) bv[u] = W[(size_t)k * ld + bjj];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) red[wave][(lr + 4 * v) * 16 + lc] = acc[v];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  const int gr = i0 + row, gc = j0 + col;
+  if (gr < n && gc < n) Tt[(size_t)gr * ld + gc] = Tc[(size_t)gr * ld + gc] + sum;
+}
+
+// dst <- the half of buf selected by *cur (lower triangle mirrored to a full symmetric matrix when `sym`)
+__global__ __launch_bounds__(256) void k_select_copy(double* __restrict__ dst, const double* __restrict__ buf, size_t stride,
+                                                      const int* __restrict__ cur, int n, int ld, int sym) {
+  const double* src = buf + (size_t)(*cur) * stride;
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < n; c += 256) {
+    const double v = (sym && c > r) ? src[(size_t)c * ld + r] : src[(size_t)r * ld + c];
+    dst[(size_t)r * ld + c] = v;
+  }
+}
+
+}  // namespace ovp
+
+extern "C" {
+hipError_t ovp_launch_plane_assemble2(const ovp::PlaneAsm* a, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_plane_assemble2, dim3(a->n + 1), dim3(256), 0, stream, *a);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_plane_dT(int n, const double* L0, int ld, const double* W, const double* b, double* Tbuf, size_t tstride,
+                               const int* cur, double* crow, hipStream_t stream) {
+  const int nt = (n + 15) / 16;
+  hipLaunchKernelGGL(ovp::k_plane_dT, dim3(nt, nt + 1), dim3(256), 0, stream, n, L0, ld, W, b, Tbuf, tstride, cur, crow);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_select_copy(double* dst, const double* buf, size_t stride, const int* cur, int n, int ld, int sym,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_select_copy, dim3(n), dim3(256), 0, stream, dst, buf, stride, cur, n, ld, sym);
+  return hipGetLastError();
+}
+}

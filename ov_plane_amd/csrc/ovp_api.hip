@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "ovp_kernels.h"
+#include "k_chol2.h"
+#include "k_plane2.h"
 
 extern "C" int ovp_dbg_tilechol_skip;
 extern "C" {
@@ -57,7 +59,7 @@ hipError_t ovp_launch_range_energy(const double* Lr, const double* Dinv, const d
 hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const double* b, double* dx, double* scal,
                                      hipStream_t stream);
 hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
-                                 int n_involved, double* res_out, hipStream_t stream);
+                                 int n_involved, int force, double* res_out, hipStream_t stream);
 hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
                                          hipStream_t stream);
 hipError_t ovp_launch_plane_slam_rows(double* E, int lde, int n, int plane1, int n_slam, const int* slam_plane, const int* slam_id,
@@ -187,6 +189,18 @@ struct ovp_ctx {
   int *pl_slam_i = nullptr;
   double *pl_slam_d = nullptr;
   int pl_slam_cap = 0, pl_n_slam = 0;
+  // second-generation plane loop (k_plane2.hip / k_chol2.hip)
+  double *pl_Tbuf = nullptr, *pl_crow = nullptr, *pl_dxlast = nullptr;
+  int *pl_cur = nullptr, *pl_perm = nullptr;
+  unsigned* pl_range_done = nullptr;
+  unsigned pl_seq = 0;
+  unsigned char* pl_used = nullptr;   // [f_max] features consumed by accepted planes (device)
+  bool pl_used_valid = false;         // pl_used refers to the uploaded batch
+  int pl2_cap = 0;
+  void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
+  size_t pl_stage_cap = 0;
+  void* pl_hres = nullptr;            // pinned host copy of the plane results
+  size_t pl_hres_cap = 0;
   int* idbuf = nullptr;      // scratch ints (ids)
   double* smallbuf = nullptr;  // scratch doubles (Phi, Q, CPT, PCP, marginal)
   size_t small_cap = 0;
@@ -353,10 +367,13 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->clone_R, c->clone_p,
                  c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
                  c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
-                 c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf};
+                 c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
+                 c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
+  if (c->pl_hstage) hipHostFree(c->pl_hstage);
+  if (c->pl_hres) hipHostFree(c->pl_hres);
   hipEventDestroy(c->ev_fork);
   hipEventDestroy(c->ev_join);
   for (int i = 0; i < 6; ++i) hipEventDestroy(c->ev_t[i]);
@@ -961,7 +978,7 @@ extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx
 // Leaves: V in c->Y, dx in c->dx, [chi2, ok, n_deg, pr] in c->pl_res + 4*pl, the extended Gram in c->pl_E.
 static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::FeatParams& fp, int pl, int start, int nf,
                             int in_state, int sid, double white_c, const double* Mf, int factor_dense, double thr,
-                            int rows_total, int rows_u, int n_involved) {
+                            int rows_total, int rows_u, int n_involved, int force = -1) {
   const int n = c->n, ld = c->ld, ldg = c->ldg;
   hipStream_t s = c->stream;
   ovp::PlaneParams pp;
@@ -1008,7 +1025,7 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
   HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
   HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-  HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_total, rows_u, n_involved, c->pl_res + 4 * pl, s));
+  HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_total, rows_u, n_involved, force, c->pl_res + 4 * pl, s));
   return 0;
 }
 
@@ -1042,8 +1059,10 @@ static int plane_buffers(ovp_ctx* c, int NP) {
 }
 
 // ---- UpdaterMSCKF::update, per-plane loop ------------------------------------------------------
-extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
-                                      uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
+// First-generation plane loop (chained factor M <- M Lt^-T, one full EKF update per plane): kept for states above the
+// register budget of k_chol2 (ovp_chol2_max_n() < n <= 288) and as a cross-check (OVP_PLANE_V1).
+static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
+                           uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
   if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
@@ -1141,7 +1160,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   double* Mf = c->L;
   for (const PlaneJob& j : jobs) {
     rc = plane_job_device(c, o, fp, j.pl, j.start, j.nf, j.in_state, j.sid, 1.0 / o->sigma_constraint, Mf, 1, j.thr, j.rows_total,
-                          j.rows_u, j.n_involved);
+                          j.rows_u, j.n_involved, pb->force_decision ? (int)pb->force_decision[j.pl] : -1);
     if (rc) return rc;
     HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * j.pl, c->Y, Mf, n, ld, c->dx, c->pl_dx + (size_t)j.pl * n, c->clone_R,
                                    c->clone_p, c->clone_id, fp.n_clones, c->cal, o->do_calib_camera_pose ? c->calib_id : -1,
@@ -1173,6 +1192,357 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       for (int k = 0; k < j.nf; ++k) feat_used[featlist[j.start + k]] = 1;
   }
   if (c->h_flags[0]) return OVP_E_NOTSPD;
+  return 0;
+}
+
+
+// ---- UpdaterMSCKF::update, per-plane loop (second generation) ------------------------------------------------------------
+// See k_plane2.hip for the algebra.  Everything of a call is enqueued without a host synchronisation: the per-call tables go
+// through one pinned staging block, the results come back through one pinned block read after a single stream sync.
+struct PlaneJobH { int pl, start, nf, rows_total, rows_u, n_involved, in_state, sid, n_inv_cols, ns_pl; double thr; };
+
+static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_bytes) {
+  const int ld = c->ld;
+  if (!c->pl_Tbuf) {
+    const size_t nn = (size_t)(c->n_max + 1) * ld;
+    HIPCHK(dalloc(&c->pl_Tbuf, 2 * nn));
+    HIPCHK(dalloc(&c->pl_crow, (size_t)c->n_max + 16));
+    HIPCHK(dalloc(&c->pl_dxlast, (size_t)c->n_max + 16));
+    HIPCHK(hipMalloc((void**)&c->pl_cur, 16));
+    HIPCHK(hipMalloc((void**)&c->pl_range_done, 16));
+    HIPCHK(hipMemset(c->pl_range_done, 0, 16));
+    HIPCHK(hipMalloc((void**)&c->pl_used, (size_t)c->f_max + 16));
+  }
+  if (NP > c->pl2_cap) {
+    if (c->pl_perm) hipFree(c->pl_perm);
+    c->pl2_cap = NP + 8;
+    HIPCHK(hipMalloc((void**)&c->pl_perm, sizeof(int) * (size_t)c->pl2_cap * c->n_max));
+  }
+  if (stage_bytes > c->pl_stage_cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pl_hstage) hipHostFree(c->pl_hstage);
+    if (c->pl_dstage) hipFree(c->pl_dstage);
+    c->pl_stage_cap = stage_bytes + 4096;
+    HIPCHK(hipHostMalloc(&c->pl_hstage, c->pl_stage_cap, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&c->pl_dstage, c->pl_stage_cap));
+  }
+  if (res_bytes > c->pl_hres_cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pl_hres) hipHostFree(c->pl_hres);
+    c->pl_hres_cap = res_bytes + 4096;
+    HIPCHK(hipHostMalloc(&c->pl_hres, c->pl_hres_cap, hipHostMallocDefault));
+  }
+  return 0;
+}
+
+extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
+                                      uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
+  if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
+  if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
+  if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
+  const int n = c->n, ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
+  static const bool force_v1 = getenv("OVP_PLANE_V1") != nullptr;
+  if (n > ovp_chol2_max_n() || force_v1) return plane_update_v1(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
+  c->pl_used_valid = false;
+  if (feat_used) memset(feat_used, 0, (size_t)F);
+  for (int pl = 0; pl < NP; ++pl) {
+    if (plane_ok) plane_ok[pl] = 0;
+    if (plane_chi2) plane_chi2[pl] = 0.0;
+    if (plane_dof) plane_dof[pl] = 0;
+  }
+  if (dx_planes && NP > 0) memset(dx_planes, 0, sizeof(double) * (size_t)n * NP);
+  if (NP == 0) return 0;
+  for (int k = 0; k < NP; ++k)
+    if (pb->plane_state_id[k] >= 0 && pb->plane_state_id[k] + 3 > n) return OVP_E_ARG;
+  const int n_slam = pb->n_slam > 0 ? pb->n_slam : 0;
+  if (n_slam > 0 && (!pb->slam_plane || !pb->slam_state_id || !pb->slam_p || !pb->slam_p_fej)) return OVP_E_ARG;
+  for (int q = 0; q < n_slam; ++q)
+    if (pb->slam_state_id[q] < 0 || pb->slam_state_id[q] + 3 > n || pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP) return OVP_E_ARG;
+  int rc = fill_feat_params(c, o);
+  if (rc) return rc;
+  ovp::FeatParams fp = c->fp;
+  fp.skip = nullptr;
+  // ---- host-side grouping (update/UpdaterMSCKF.cpp:204-229) ----
+  std::vector<PlaneJobH> jobs;
+  std::vector<int> featlist;
+  std::vector<int> perms;  // per job: n entries
+  const int ncal = (o->do_calib_camera_pose ? 6 : 0) + (o->do_calib_camera_intrinsics ? 8 : 0);
+  for (int pl = 0; pl < NP; ++pl) {
+    PlaneJobH j;
+    j.pl = pl;
+    j.start = (int)featlist.size();
+    j.nf = 0;
+    j.rows_total = 0;
+    j.sid = pb->plane_state_id[pl];
+    j.in_state = j.sid >= 0;
+    unsigned long long seen = 0ull;
+    for (int f = 0; f < F; ++f) {
+      if (pb->plane_of_feat[f] != pl + 1) continue;
+      const int m = c->h_n_meas[f];
+      if (m < 2) continue;
+      if (m > 31) return OVP_E_CAPACITY;  // 2m+1 rows must fit one wavefront
+      featlist.push_back(f);
+      j.nf++;
+      j.rows_total += 3 * m - 3;
+      for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
+    }
+    int ns_pl = 0;  // SLAM landmarks on this (out-of-state) plane: one row and three involved columns each
+    if (!j.in_state)
+      for (int q = 0; q < n_slam; ++q)
+        if (pb->slam_plane[q] == pl + 1) ++ns_pl;
+    if (ns_pl > PA_MAXQ) return OVP_E_CAPACITY;
+    j.ns_pl = ns_pl;
+    if (j.nf == 0 || (!j.in_state && j.nf + ns_pl < 4)) {  // update/UpdaterMSCKF.cpp:316-317,384-396
+      featlist.resize(j.start);
+      continue;
+    }
+    j.rows_total += ns_pl;
+    const int c_ref = 6 * __builtin_popcountll(seen) + ncal + 3 * ns_pl;
+    const int rows_c = j.rows_total > c_ref ? c_ref : j.rows_total;  // UpdaterPlane::measurement_compress_inplace
+    j.rows_u = j.in_state ? rows_c : rows_c - 3;
+    j.n_involved = c_ref + (j.in_state ? 3 : 0);
+    if (!j.in_state) j.rows_total -= 3;
+    if (j.rows_u < 1) {
+      featlist.resize(j.start);
+      continue;
+    }
+    j.thr = o->chi2_multiplier * ovp_chi2_quantile_095(j.rows_u);
+    // order of the involved columns in the normalised Gram: everything that is not a clone first, the clones last (a rank
+    // deficiency - gauge freedom, planar scene - then shows up in the trailing pivots, k_chol2 mode 2)
+    {
+      std::vector<int> perm(n, -1);
+      int pos = 0;
+      std::vector<char> inv(n, 0);
+      if (o->do_calib_camera_pose)
+        for (int k = 0; k < 6; ++k) inv[c->calib_id + k] = 1;
+      if (o->do_calib_camera_intrinsics)
+        for (int k = 0; k < 8; ++k) inv[c->intr_id + k] = 1;
+      if (j.in_state)
+        for (int k = 0; k < 3; ++k) inv[j.sid + k] = 1;
+      if (!j.in_state)
+        for (int q = 0; q < n_slam; ++q)
+          if (pb->slam_plane[q] == pl + 1)
+            for (int k = 0; k < 3; ++k) inv[pb->slam_state_id[q] + k] = 1;
+      for (int col = 0; col < n; ++col)
+        if (inv[col]) perm[col] = pos++;
+      for (int ci = 0; ci < (int)c->h_clone_id.size(); ++ci)
+        if ((seen >> ci) & 1ull)
+          for (int k = 0; k < 6; ++k) {
+            const int col = c->h_clone_id[ci] + k;
+            if (col >= 0 && col < n && perm[col] < 0) perm[col] = pos++;
+          }
+      j.n_inv_cols = pos;
+      perms.insert(perms.end(), perm.begin(), perm.end());
+    }
+    jobs.push_back(j);
+  }
+  const int NJ = (int)jobs.size();
+  // ---- staging layout: ints [featlist | sid NP | perms NJ*n | slam_plane | slam_id], doubles [cp | cp_fej | slam_p | slam_p_fej] ----
+  const size_t n_int = featlist.size() + (size_t)NP + perms.size() + 2 * (size_t)n_slam;
+  const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
+  const size_t n_dbl = 6 * (size_t)NP + 6 * (size_t)n_slam;
+  const size_t stage_bytes = int_bytes + n_dbl * sizeof(double);
+  const size_t res_bytes = sizeof(double) * (4 * (size_t)NP + (size_t)n * NP) + (size_t)F + 64;
+  rc = plane_buffers(c, NP);  // shared with the first generation: pl_res, pl_dx, pl_cst, pl_An, ...
+  if (rc) return rc;
+  rc = plane2_buffers(c, NP, stage_bytes, res_bytes);
+  if (rc) return rc;
+  int* hi = (int*)c->pl_hstage;
+  double* hd = (double*)((char*)c->pl_hstage + int_bytes);
+  int* di = (int*)c->pl_dstage;
+  double* dd = (double*)((char*)c->pl_dstage + int_bytes);
+  size_t io = 0;
+  const size_t o_feat = io;
+  memcpy(hi + io, featlist.data(), sizeof(int) * featlist.size());
+  io += featlist.size();
+  const size_t o_sid = io;
+  memcpy(hi + io, pb->plane_state_id, sizeof(int) * NP);
+  io += NP;
+  const size_t o_perm = io;
+  if (!perms.empty()) memcpy(hi + io, perms.data(), sizeof(int) * perms.size());
+  io += perms.size();
+  const size_t o_spl = io;
+  if (n_slam) memcpy(hi + io, pb->slam_plane, sizeof(int) * n_slam);
+  io += n_slam;
+  const size_t o_sidx = io;
+  if (n_slam) memcpy(hi + io, pb->slam_state_id, sizeof(int) * n_slam);
+  io += n_slam;
+  memcpy(hd, pb->cp, sizeof(double) * 3 * NP);
+  memcpy(hd + 3 * NP, pb->cp_fej, sizeof(double) * 3 * NP);
+  if (n_slam) {
+    memcpy(hd + 6 * NP, pb->slam_p, sizeof(double) * 3 * n_slam);
+    memcpy(hd + 6 * NP + 3 * n_slam, pb->slam_p_fej, sizeof(double) * 3 * n_slam);
+  }
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(c->pl_dstage, c->pl_hstage, stage_bytes, hipMemcpyHostToDevice, s));
+  const int* d_feat = di + o_feat;
+  const int* d_sid = di + o_sid;
+  const int* d_perm = di + o_perm;
+  const int* d_spl = di + o_spl;
+  const int* d_sidx = di + o_sidx;
+  double* d_cp = dd;
+  double* d_cpfej = dd + 3 * NP;
+  double* d_slam_p = dd + 6 * NP;
+  double* d_slam_pfej = dd + 6 * NP + 3 * n_slam;
+  HIPCHK(hipMemsetAsync(c->pl_res, 0, sizeof(double) * 4 * NP, s));
+  HIPCHK(hipMemsetAsync(c->pl_dx, 0, sizeof(double) * (size_t)n * NP, s));
+  HIPCHK(hipMemsetAsync(c->pl_used, 0, (size_t)F, s));
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  const size_t tstride = (size_t)(c->n_max + 1) * ld;
+  if (NJ > 0) {
+    HIPCHK(hipMemsetAsync(c->pl_cur, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(c->pl_Tbuf, 0, sizeof(double) * (size_t)n * ld, s));  // half 0: sum of the accepted L0^T A L0
+    rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
+    if (rc) return rc;
+  }
+  const double white_c = 1.0 / o->sigma_constraint;
+  for (int jn = 0; jn < NJ; ++jn) {
+    const PlaneJobH& j = jobs[jn];
+    // (1) per-feature rows
+    ovp::PlaneParams pp;
+    pp.feat_list = d_feat + j.start;
+    pp.n_local = j.nf;
+    pp.plane = j.pl;
+    pp.in_state = j.in_state;
+    pp.plane_sid = j.sid;
+    pp.white_c = white_c;
+    pp.cp = d_cp;
+    pp.cp_fej = d_cpfej;
+    pp.cst = c->pl_cst;
+    ovp::FeatParams fpl = fp;
+    fpl.n = n;
+    fpl.P = c->P;
+    HIPCHK(ovp_launch_plane_feat(&fpl, &pp, j.nf, s));
+    // (2) Gram products
+    const int chunks = (2 * j.nf + c->rows_per_chunk - 1) / c->rows_per_chunk;
+    int nsplit = 1;
+    HIPCHK(ovp_launch_gram_pair(c->rec, fp.n_clones, j.nf, c->rows_per_chunk, chunks, c->gramS, c->G, 3 * j.nf, c->ldg, n + 4,
+                                c->n_split, c->part, &nsplit, s));
+    // (3) pair on the state columns, normalised Gram, residual energy
+    ovp::PlaneAsm pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.gramS = c->gramS;
+    pa.n_clones = fp.n_clones;
+    pa.n_chunks = chunks;
+    pa.part = c->part;
+    pa.n_split = nsplit;
+    {
+      const int nt16 = (n + 4 + 15) / 16;
+      pa.ntile = nt16 * (nt16 + 1) / 2;
+    }
+    pa.colmap = c->colmap;
+    pa.n = n;
+    pa.plane_sid = j.sid;
+    pa.in_state = j.in_state;
+    pa.cst = c->pl_cst;
+    pa.nf = j.nf;
+    pa.n_slam = j.in_state ? 0 : n_slam;
+    pa.plane1 = j.pl + 1;
+    pa.slam_plane = d_spl;
+    pa.slam_id = d_sidx;
+    pa.slam_p = d_slam_p;
+    pa.slam_p_fej = d_slam_pfej;
+    pa.cp = d_cp + 3 * j.pl;
+    pa.cp_fej = d_cpfej + 3 * j.pl;
+    pa.white_c = white_c;
+    pa.do_fej = fp.do_fej;
+    pa.Ab = c->Ab;
+    pa.lda = ld;
+    pa.perm = d_perm + (size_t)jn * n;
+    pa.An = c->pl_An;
+    pa.ldn = ld;
+    pa.bn = c->pl_bn;
+    pa.eps = 1e-10;
+    pa.scal = c->pl_scal;
+    HIPCHK(ovp_launch_plane_assemble2(&pa, s));
+    // (4) W = A L0 ;  T_try = T_cur + L0^T W ;  c = L0^T b
+    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, s));
+    HIPCHK(ovp_launch_plane_dT(n, c->L, ld, c->W1, c->Ab + (size_t)n * ld, c->pl_Tbuf, tstride, c->pl_cur, c->pl_crow, s));
+    // (5) both factorizations, gate, solve, commit
+    ovp::Chol2Job j0, j1;
+    memset(&j0, 0, sizeof(j0));
+    memset(&j1, 0, sizeof(j1));
+    j0.A = c->pl_Tbuf;
+    j0.sel = c->pl_cur;
+    j0.sel_xor = 1;
+    j0.sel_stride = tstride;
+    j0.n = n;
+    j0.ld = ld;
+    j0.add_identity = 1;
+    j0.mode = 1;
+    j0.brow = c->pl_crow;
+    j0.flag = c->flags;
+    j1.A = c->pl_An;
+    j1.n = j.n_inv_cols;
+    j1.ld = ld;
+    j1.add_identity = 0;
+    j1.mode = 2;
+    j1.brow = c->pl_bn;
+    j1.flag = c->flags + 2;
+    j1.piv_floor = 1e-13;
+    ovp::PlaneSolve ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.scal = c->pl_scal;
+    ps.range_done = c->pl_range_done;
+    ps.seq = ++c->pl_seq;
+    ps.thr = j.thr;
+    ps.rows_total = j.rows_total;
+    ps.rows_u = j.rows_u;
+    ps.n_involved = j.n_inv_cols;
+    ps.force = pb->force_decision ? (int)pb->force_decision[j.pl] : -1;
+    ps.tol_strict = 1e-8;
+    ps.tol_loose = 1e-4;
+    ps.res_out = c->pl_res + 4 * j.pl;
+    ps.L0 = c->L;
+    ps.ld0 = ld;
+    ps.dx_out = c->pl_dx + (size_t)j.pl * n;
+    ps.dx_last = c->pl_dxlast;
+    ps.cur = c->pl_cur;
+    ps.feat_list = d_feat + j.start;
+    ps.n_feat_local = j.nf;
+    ps.feat_used = c->pl_used;
+    ps.clone_R = c->clone_R;
+    ps.clone_p = c->clone_p;
+    ps.clone_id = c->clone_id;
+    ps.n_clones = fp.n_clones;
+    ps.cal = c->cal;
+    ps.calib_id = o->do_calib_camera_pose ? c->calib_id : -1;
+    ps.intr_id = o->do_calib_camera_intrinsics ? c->intr_id : -1;
+    ps.cp = d_cp;
+    ps.plane_sid = d_sid;
+    ps.n_planes = NP;
+    ps.n_slam = n_slam;
+    ps.slam_id = d_sidx;
+    ps.slam_p = d_slam_p;
+    HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
+  }
+  // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
+  if (NJ > 0) {
+    HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
+    HIPCHK(ovp_launch_tilechol(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 1, s));
+    HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
+    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, s));
+  }
+  // ---- results: one pinned block, one synchronisation ----
+  double* hres = (double*)c->pl_hres;
+  double* hdx = hres + 4 * (size_t)NP;
+  unsigned char* hused = (unsigned char*)(hdx + (size_t)n * NP);
+  HIPCHK(hipMemcpyAsync(hres, c->pl_res, sizeof(double) * 4 * NP, hipMemcpyDeviceToHost, s));
+  if (dx_planes) HIPCHK(hipMemcpyAsync(hdx, c->pl_dx, sizeof(double) * (size_t)n * NP, hipMemcpyDeviceToHost, s));
+  if (F) HIPCHK(hipMemcpyAsync(hused, c->pl_used, (size_t)F, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  c->pl_used_valid = true;
+  if (dx_planes) memcpy(dx_planes, hdx, sizeof(double) * (size_t)n * NP);
+  if (feat_used && F) memcpy(feat_used, hused, (size_t)F);
+  for (const PlaneJobH& j : jobs) {
+    if (plane_ok) plane_ok[j.pl] = hres[4 * j.pl + 1] > 0.5 ? 1 : 0;
+    if (plane_chi2) plane_chi2[j.pl] = hres[4 * j.pl];
+    if (plane_dof) plane_dof[j.pl] = j.rows_u;
+  }
+  const int bad = c->h_flags[0] | c->h_flags[2];
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  if (bad) return OVP_E_NOTSPD;
   return 0;
 }
 
@@ -1469,6 +1839,85 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
   if (hipStreamSynchronize(c->stream) != hipSuccess) return OVP_E_STATE;
   if (hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return OVP_E_STATE;
   return (long)bytes;
+}
+
+// Diagnostics / micro-benchmark of the second-generation tile Cholesky (k_chol2.hip): factorizes the n x n host matrix A (+ I)
+// bordered with the row brow, returns the dense factor of the bordered matrix ((n+1) x (n+1) row-major, or n x n without a border),
+// z = L^-1 brow, y = L^-T z and the pivots; avg_ms = average duration of `reps` launches (HIP events).
+extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda, const double* brow_host, int add_identity,
+                               double* L_host, double* z_host, double* y_host, double* piv_host, int reps, float* avg_ms) {
+  if (!c || !A_host || n < 1 || lda < n) return OVP_E_ARG;
+  const int nb = brow_host ? n + 1 : n;
+  if (nb > ovp_chol2_max_n() + 1) return OVP_E_CAPACITY;
+  double *dA = nullptr, *dL = nullptr, *dv = nullptr;
+  HIPCHK(dalloc(&dA, (size_t)n * n));
+  HIPCHK(dalloc(&dL, (size_t)nb * nb));
+  HIPCHK(dalloc(&dv, (size_t)4 * n + 16));
+  HIPCHK(hipMemcpy2D(dA, sizeof(double) * n, A_host, sizeof(double) * lda, sizeof(double) * n, n, hipMemcpyHostToDevice));
+  if (brow_host) HIPCHK(hipMemcpy(dv, brow_host, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dL, 0, sizeof(double) * (size_t)nb * nb));
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  ovp::Chol2Job j;
+  memset(&j, 0, sizeof(j));
+  j.A = dA;
+  j.n = n;
+  j.ld = n;
+  j.add_identity = add_identity;
+  j.mode = 0;
+  j.brow = brow_host ? dv : nullptr;
+  j.flag = c->flags;
+  j.Ldense = dL;
+  j.ldo = nb;
+  j.z_out = brow_host ? dv + n : nullptr;
+  j.y_out = brow_host ? dv + 2 * n : nullptr;
+  j.piv_out = dv + 3 * n;
+  HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (getenv("OVP_C2_STAMPS")) {
+    long long* st = nullptr;
+    HIPCHK(hipMalloc((void**)&st, sizeof(long long) * 16 * 32));
+    HIPCHK(hipMemset(st, 0, sizeof(long long) * 16 * 32));
+    ovp::Chol2Job jt = j;
+    jt.Ldense = nullptr;
+    jt.y_out = nullptr;
+    jt.stamps = st;
+    HIPCHK(ovp_launch_chol2(&jt, nullptr, nullptr, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    long long h[16 * 32];
+    HIPCHK(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(st);
+    const int nt = (nb + 15) / 16;
+    fprintf(stderr, "chol2 stamps (cycles): elimination wave 0 [wait column | read+eliminate | write] ; tile wave 0 [wait panel | reload + next column | wait buffer + publish | rest]\n");
+    for (int k = 0; k < nt; ++k) {
+      const long long* e = h + k * 16;
+      fprintf(stderr, " k=%2d E: %6lld %6lld %6lld | T: %6lld %6lld %6lld %6lld | E step %6lld T step %6lld\n", k, e[1] - e[0], e[2] - e[1],
+              e[3] - e[2], e[9] - e[8], e[10] - e[9], e[11] - e[10], e[12] - e[11], e[3] - e[0], e[12] - e[8]);
+    }
+  }
+  if (reps > 0) {
+    ovp::Chol2Job jt = j;  // timing: the factorization alone (no dense output)
+    jt.Ldense = nullptr;
+    jt.y_out = nullptr;
+    jt.dbg = getenv("OVP_C2_DBG") ? atoi(getenv("OVP_C2_DBG")) : 0;
+    HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(ovp_launch_chol2(&jt, nullptr, nullptr, c->stream));
+    HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev_t[0], c->ev_t[1]);
+    if (avg_ms) *avg_ms = ms / reps;
+  }
+  if (L_host) HIPCHK(hipMemcpy(L_host, dL, sizeof(double) * (size_t)nb * nb, hipMemcpyDeviceToHost));
+  if (z_host && brow_host) HIPCHK(hipMemcpy(z_host, dv + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (y_host && brow_host) HIPCHK(hipMemcpy(y_host, dv + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (piv_host) HIPCHK(hipMemcpy(piv_host, dv + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  int fl[4];
+  HIPCHK(hipMemcpy(fl, c->flags, sizeof(fl), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+  hipFree(dA);
+  hipFree(dL);
+  hipFree(dv);
+  return fl[0] ? OVP_E_NOTSPD : 0;
 }
 
 extern "C" int ovp_last_timings(ovp_ctx* c, float* ms4) {

@@ -55,6 +55,7 @@ struct FeatParams {
   double* rec;  // [n_clones][n_feats][2][OVP_REC]
   double* chi2;
   unsigned char* accept;
+  const unsigned char* skip;  // optional [n_feats]: 1 = feature was consumed by an accepted plane (not part of this update)
   long long* dbg_cycles;  // optional [n_feats][8] phase stamps (diagnostics)
 };
 

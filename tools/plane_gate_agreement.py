@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Plane-level chi2 gate (update/UpdaterMSCKF.cpp:607-631) at chi2_multipler = 1: device statistic against the oracle's.
+
+For every seed: the oracle runs the plane loop of a config-3 sized scene (30 clones, 20 planes x 50 features, half the planes in
+the state) with the real gate; the device runs the same loop with the oracle's accept / reject sequence forced
+(ovp_plane_batch::force_decision), so both see the same state and covariance at every plane and the two statistics are compared
+plane by plane: value difference, the decision the device's own gate would have taken, distance of the disagreements from the
+threshold.  Prints one JSON object (committed under profiles/)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+
+
+def run(seeds, C=30, F=2000, n_planes=20, feats_per_plane=50, chi2_mult=1.0, verbose=False):
+    from oracle import pyoracle
+    from ov_plane_amd import capi
+    from ov_plane_amd.synth import make_scene
+
+    rows = []
+    ctx = None
+    for seed in seeds:
+        try:
+            sc = make_scene(C=C, F=F, seed=seed, n_planes=n_planes, feats_per_plane=feats_per_plane, planes_in_state_frac=0.5,
+                            chi2_mult=chi2_mult)
+        except RuntimeError:  # the generator could not place every feature in view for this seed
+            continue
+        ref = pyoracle.msckf_plane_update(sc)
+        if ctx is None:
+            ctx = capi.Context(sc.N, sc.C, sc.F)
+        ctx.cov_upload(sc.P)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)
+        o = capi.opts_from_scene(sc)
+        out = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id, force_decision=ref["plane_ok"].astype(np.uint8))
+        P = ctx.cov_download()
+        d = np.sqrt(np.abs(np.diag(ref["P"])))
+        relP = float((np.abs(P - ref["P"]) / np.outer(d, d)).max())
+        for k in range(n_planes):
+            if ref["plane_rows"][k] <= 0:
+                continue
+            thr = chi2_mult * capi.lib().ovp_chi2_quantile_095(int(out["dof"][k]))
+            rows.append(dict(seed=int(seed), plane=k, dof=int(out["dof"][k]), dof_ref=int(ref["plane_rows"][k]), thr=float(thr),
+                             chi2_dev=float(out["chi2"][k]), chi2_ref=float(ref["plane_chi2"][k]),
+                             ok_ref=bool(ref["plane_ok"][k]), ok_dev=bool(out["chi2"][k] <= thr), relP=relP))
+        if verbose:
+            print("seed %d: oracle accepted %d/%d, relP %.2e" % (seed, int(ref["plane_ok"].sum()), n_planes, relP), file=sys.stderr)
+    if ctx is not None:
+        ctx.close()
+    return rows
+
+
+def summarise(rows):
+    d = np.array([r["chi2_dev"] - r["chi2_ref"] for r in rows])
+    dis = [r for r in rows if r["ok_ref"] != r["ok_dev"]]
+    margin = [abs(r["chi2_ref"] - r["thr"]) for r in dis]
+    return dict(planes=len(rows), seeds=len({r["seed"] for r in rows}), oracle_accept_rate=float(np.mean([r["ok_ref"] for r in rows])),
+                disagreements=len(dis), disagreement_rate=len(dis) / max(len(rows), 1),
+                diff_mean=float(d.mean()), diff_std=float(d.std()), diff_abs_max=float(np.abs(d).max()),
+                disagreement_margin_max=float(max(margin)) if margin else 0.0,
+                dof_mismatch=int(sum(r["dof"] != r["dof_ref"] for r in rows)),
+                relP_max=float(max(r["relP"] for r in rows)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=50)
+    ap.add_argument("--first-seed", type=int, default=100)
+    ap.add_argument("--rows", action="store_true", help="include the per-plane table")
+    args = ap.parse_args()
+    rows = run(range(args.first_seed, args.first_seed + args.seeds), verbose=True)  # a few seeds are skipped (see run)
+    out = summarise(rows)
+    if args.rows:
+        out["rows"] = rows
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
