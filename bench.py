@@ -1,15 +1,21 @@
 #!/usr/bin/env python
-"""bench.py - MSCKF update-step throughput on MI355X (BASELINE.json metric).
+"""bench.py - MSCKF(+plane) update-step time and features/s on MI355X (BASELINE.json metric).
 
-A "step" is one full MSCKF point-feature update (UpdaterMSCKF::update, update/UpdaterMSCKF.cpp:671-814) over one
-synthetic batch: per-feature Jacobians -> nullspace projection -> chi2 gate -> compression -> EKF covariance/state
-update, inputs (feature batch, pose tables, covariance) resident in HBM, dx / accept mask fetched to the host at
-the end of every step.  N=1 workload = BASELINE.json configs[1]: 30 clones, 2000 MSCKF point features, 0 planes.
-N>1: features are sharded (every rank owns --feats features of the same filter, weak scaling), the information
-pair (A, b) is summed with one RCCL all-reduce and every rank applies the identical update to its replica of P.
+A "step" is one full UpdaterMSCKF::update downstream of triangulation (update/UpdaterMSCKF.cpp:411-814) over one synthetic
+frame: host -> device copy of the feature batch, the sequential per-plane loop (point-on-plane Jacobians, projection, plane-level
+chi2 gate, EKF update per plane), then the point-feature update on the features no accepted plane consumed (Jacobians,
+nullspace projection, per-feature chi2 gate, compression, EKF update), results (dx, accept masks, chi2) back on the host.  The
+covariance and the pose tables are resident in HBM; every step starts from the same prior (restored device-to-device).
 
-Prints ONE JSON line on rank 0.
-"""
+  --gpus 1  (default): BASELINE.json configs[2] - 30 clones, 2000 features of which 1000 lie on 20 planes (10 of them state
+             variables, N = 240).  This is the configuration the metric's target is quoted on; configs[1] (2000 point features,
+             0 planes) is reported beside it as `point_config`, configs[3] on one GPU as `config4_1gpu`.
+  --gpus N>1: BASELINE.json configs[3] - 30 clones, 8000 features of which 2500 lie on 50 planes (N = 285), STRONG scaling: the
+             plane loop is sequential across planes, so every rank runs it on the whole frame (identical replicas, no
+             collective); the free points are sharded over the ranks, ONE RCCL all-reduce sums the information pairs, every
+             rank applies the identical update.  `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run).
+
+Prints ONE JSON line on rank 0."""
 from __future__ import annotations
 
 import argparse
@@ -24,59 +30,186 @@ sys.path.insert(0, _ROOT)
 import numpy as np  # noqa: E402
 
 F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §5
+WORKLOADS = {
+    "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
+    "config3": dict(C=30, F=2000, n_planes=20, feats_per_plane=50),
+    "config4": dict(C=30, F=8000, n_planes=50, feats_per_plane=50),
+}
 
 
 def algorithmic_flops_per_feature(m: int, calib: bool = True) -> float:
     """reference-algorithm FLOPs of build + projection + gate for one feature with m observations."""
     c = 6 * m + (14 if calib else 0)
     q = 2 * m - 3
-    build = 400.0 * m
-    proj = 12.0 * (2 * m) * (c + 1)
-    gate = 2.0 * q * c * c + 2.0 * q * q * c + q**3 / 3.0 + 2.0 * q * q
-    return build + proj + gate
+    return 400.0 * m + 12.0 * (2 * m) * (c + 1) + 2.0 * q * c * c + 2.0 * q * q * c + q**3 / 3.0 + 2.0 * q * q
 
 
 def executed_flops_per_feature(m: int) -> float:
-    """FLOPs the structured kernel k_feat_gate actually issues per feature."""
+    """FLOPs the structured feature kernel issues per feature."""
     n = 2 * m
-    phase_a = 450.0 * n
-    phase_a2 = n * (14 * 6 + 14 * 14) * 2.0
-    phase_b = n * m * 2 * (36 + 2 * 34)
-    chol = 64 * 64 * 64 / 3.0 * 2.0 * (n / 64.0) + 4 * n * 64.0
-    proj = 64.0 * (45 + 18 + 30) * 2
-    return phase_a + phase_a2 + phase_b + chol + proj
+    return 450.0 * n + n * (14 * 6 + 14 * 14) * 2.0 + n * m * 2 * (36 + 2 * 34) + (64**3 / 3.0 * 2.0 * (n / 64.0) + 4 * n * 64.0) + 64.0 * 93 * 2
 
 
-class _DevArray:
-    """Zero-copy __cuda_array_interface__ view of a device buffer owned by the C library."""
+def chol2_flops(n: int, n_inv: int) -> float:
+    """FLOPs of one k_chol2 launch of the plane loop: Cholesky of the (n+1)-dimensional bordered T and of the (n_inv+1)-dimensional
+    bordered normalised Gram (k^3 / 3 each), back substitution and dx = L0 y (n^2 each, only on accepted planes - not counted)."""
+    return (n + 1) ** 3 / 3.0 + (n_inv + 1) ** 3 / 3.0
 
-    def __init__(self, ptr, shape, typestr="<f8"):
-        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2,
-                                             strides=None)
+
+def make_workload(name, seed=0, feat_seed=None, chi2_mult=1.0):
+    from ov_plane_amd.synth import make_scene
+
+    w = WORKLOADS[name]
+    kw = dict(C=w["C"], F=w["F"], seed=seed, chi2_mult=chi2_mult)
+    if feat_seed is not None:
+        kw["feat_seed"] = feat_seed
+    if w["n_planes"]:
+        kw.update(n_planes=w["n_planes"], feats_per_plane=w["feats_per_plane"], planes_in_state_frac=0.5)
+    return make_scene(**kw)
+
+
+def describe(name, sc):
+    w = WORKLOADS[name]
+    if w["n_planes"]:
+        return "%d clones, %d feats of which %d on %d planes (%d of them in the state), calib on (N=%d)" % (
+            w["C"], w["F"], w["n_planes"] * w["feats_per_plane"], w["n_planes"], int((np.asarray(sc.plane_state_id) >= 0).sum()), sc.N)
+    return "%d clones, %d MSCKF point feats, 0 planes, calib on (N=%d)" % (w["C"], w["F"], sc.N)
+
+
+class StepRunner:
+    """One filter on one GPU: the step of the docstring, for scenes with or without planes."""
+
+    def __init__(self, capi, torch, sc, device, feats_max=None):
+        self.capi, self.torch, self.sc = capi, torch, sc
+        self.ctx = capi.Context(sc.N, sc.C, feats_max or sc.F, device=device)
+        self.stream = torch.cuda.ExternalStream(self.ctx.stream_handle(), device=torch.device("cuda", device))
+        self.P0 = torch.from_numpy(np.ascontiguousarray(sc.P)).to("cuda:%d" % device)
+        self.opts = capi.opts_from_scene(sc)
+        self.opts_pts = capi.opts_from_scene(sc)
+        self.has_planes = sc.cp.shape[0] > 0
+        self.opts_pts.skip_plane_used = 1 if self.has_planes else 0
+
+    def step(self):
+        """Single GPU: H2D batch, plane loop, point update on the rest (device-side mask), results on the host."""
+        sc, ctx = self.sc, self.ctx
+        ctx.cov_set_device(self.P0.data_ptr(), sc.N, sc.N)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)
+        pl = None
+        if self.has_planes:
+            pl = ctx.plane_update(self.opts, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+        pt = ctx.msckf_update(self.opts_pts)
+        return pl, pt
+
+    def step_sharded(self, dist, rank, world, gram_t):
+        """Feature-sharded step: replicated plane loop, sharded point update with one all-reduce."""
+        from ov_plane_amd.dist import shard_bounds
+
+        sc, ctx = self.sc, self.ctx
+        ctx.cov_set_device(self.P0.data_ptr(), sc.N, sc.N)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)
+        pl = None
+        rest = np.arange(sc.F)
+        if self.has_planes:
+            pl = ctx.plane_update(self.opts, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+            rest = np.nonzero(~pl["used"])[0]
+        lo, hi = shard_bounds(len(rest), rank, world)
+        ctx.batch_upload_scene(sc, rest[lo:hi])
+        ctx.build_gate_gram_async(self.opts)
+        dist.all_reduce(gram_t, op=dist.ReduceOp.SUM)
+        ctx.ekf_update_from_gram_async()
+        return pl, ctx.fetch_results()
+
+    def close(self):
+        self.ctx.close()
+
+
+def time_steps(torch, fn, steps, warmup, barrier=None):
+    for _ in range(warmup):
+        out = fn()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, out
+
+
+def cpu_baseline(sc, name, budget_feats=None):
+    """The oracle (oracle/ovp_oracle.c: the reference's algorithm in its own loop order, one thread) on the same frame: plane loop
+    on every plane, point update on the features the planes did not consume (a bounded prefix of them when budget_feats is set)."""
+    from oracle import pyoracle
+    from ov_plane_amd.synth import Scene
+
+    pyoracle.build()
+    t0 = time.perf_counter()
+    if sc.cp.shape[0] > 0:
+        pl = pyoracle.msckf_plane_update(sc)
+        sc2 = Scene(sc)
+        for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
+            sc2[k] = pl[k]
+        rest = np.where(~pl["used"])[0]
+        n_used = int(pl["used"].sum())
+    else:
+        sc2, rest, n_used = sc, np.arange(sc.F), 0
+    t1 = time.perf_counter()
+    sample = rest if budget_feats is None else rest[:budget_feats]
+    pt = pyoracle.msckf_point_update(sc2, feats=sample)
+    t2 = time.perf_counter()
+    t_plane, t_pts = t1 - t0, t2 - t1
+    # point part scaled to the whole rest when only a prefix was run (it is linear in the feature count up to the final update)
+    t_full = t_plane + t_pts * (len(rest) / max(len(sample), 1))
+    return dict(
+        value=sc.F / t_full, unit="features/s", cores=1, kind="port",
+        sample="oracle/ovp_oracle.c (reference loop order, 1 thread) on the %s frame: plane loop over all planes %.2f s (%d features "
+               "consumed), point update on %d of the %d remaining features %.2f s (feat system %.2f s, compression %.2f s, update "
+               "%.3f s)%s" % (name, t_plane, n_used, len(sample), len(rest), t_pts, pt["timings"][0], pt["timings"][1],
+                             pt["timings"][2], "" if len(sample) == len(rest) else "; scaled linearly to the whole frame"),
+        ms_per_step=1e3 * t_full)
+
+
+def reexec_under_torchrun(n):
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvp(cmd[0], cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--clones", type=int, default=30)
-    ap.add_argument("--feats", type=int, default=2000, help="features per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["auto", "config2", "config3", "config4"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-plane-config", action="store_true", help="skip the extra 2000 point + 20 plane figure")
-    ap.add_argument("--cpu-sample-feats", type=int, default=2000)
+    ap.add_argument("--no-extras", action="store_true", help="skip the side figures (point_config, config4_1gpu, propagation)")
+    ap.add_argument("--cpu-sample-feats", type=int, default=1000)
     args = ap.parse_args()
 
+    world_env = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and world_env == 0:
+        reexec_under_torchrun(args.gpus)  # does not return
     import torch
 
     from ov_plane_amd import capi
-    from ov_plane_amd.synth import make_scene
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = max(world_env, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -84,100 +217,42 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+        assert dist.get_world_size() == args.gpus
+    name = args.workload if args.workload != "auto" else ("config3" if world == 1 else "config4")
+    sc = make_workload(name)
+    run = StepRunner(capi, torch, sc, local_rank)
+    barrier = (lambda: dist.barrier()) if world > 1 else None
 
-    C, F = args.clones, args.feats
-    sc = make_scene(C=C, F=F, seed=0, feat_seed=100 + rank, chi2_mult=1.0)
-    # the library creates its own stream pair (CU-partitioned, see ovp_ctx_create); torch work of this process (the RCCL
-    # all_reduce for N > 1, the device copy of P) is ordered on the same stream through an ExternalStream view
-    ctx = capi.Context(sc.N, sc.C, sc.F, device=local_rank)
-    stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", local_rank))
-    with torch.cuda.stream(stream):
-        ctx.state_upload(sc)
-        ctx.batch_upload_scene(sc)  # inputs resident in HBM before the timed region
-        P0 = torch.from_numpy(np.ascontiguousarray(sc.P)).to("cuda")
-        opts = capi.opts_from_scene(sc)
-        gram_t = None
+    with torch.cuda.stream(run.stream):
         if world > 1:
-            ptr, rows, ld = ctx.gram_buffer()
-            gram_t = torch.as_tensor(_DevArray(ptr, (rows * ld,)), device="cuda")
+            from ov_plane_amd.dist import DeviceBufferView
 
-        def step():
-            ctx.cov_set_device(P0.data_ptr(), sc.N, sc.N)
-            ctx.build_gate_gram_async(opts)
-            if world > 1:
-                dist.all_reduce(gram_t, op=dist.ReduceOp.SUM)
-            ctx.ekf_update_from_gram_async()
-            return ctx.fetch_results()
+            ptr, rows, ld = run.ctx.gram_buffer()
+            gram_t = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
+            fn = lambda: run.step_sharded(dist, rank, world, gram_t)  # noqa: E731
+        else:
+            fn = run.step
+        elapsed, (pl, pt) = time_steps(torch, fn, args.steps, args.warmup, barrier)
+        # dominant-kernel launch times with HIP events, in a pass of their own (events between dependent launches cost
+        # microseconds each, they must not sit in the timed region above)
+        run.ctx.kernel_timer(enable=True, reset=True)
+        run.ctx.plane_kernel_timer(enable=True, reset=True)
+        time_steps(torch, fn, max(5, min(args.steps, 20)), 0, barrier)
+        k1_ms, k1_n = run.ctx.kernel_timer(enable=False, reset=False)
+        c2_ms, c2_n = run.ctx.plane_kernel_timer(enable=False, reset=False)
 
-        for _ in range(args.warmup):
-            out = step()
-        ctx.kernel_timer(enable=True, reset=True)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        k_ms, k_n = ctx.kernel_timer(enable=False, reset=False)
-        stage_ms = ctx.timings_ms()
-
-    elapsed = t1 - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    total_feats = F * world
-    value = total_feats * args.steps / elapsed
+    value = sc.F * args.steps / elapsed
 
     if rank == 0:
-        m = C
-        alg = algorithmic_flops_per_feature(m) * F
-        exe = executed_flops_per_feature(m) * F
-        k_s = max(k_ms, 1e-9) * 1e-3
-        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this
-        # process); only quoted when the workload is the one the passes were taken on
-        traffic, traffic_note = None, None
-        tp = os.path.join(_ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")
-        if os.path.exists(tp) and (C, F, world) == (30, 2000, 1):
-            with open(tp) as fh:
-                kern = json.load(fh)["kernels"]
-            k1 = [v for k, v in kern.items() if "k_feat_chol" in k or "k_feat_gate" in k]
-            if k1:
-                # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies wide coalesced reads at half their bytes -> x2 as the
-                # upper bound; WRITE_SIZE taken as reported
-                traffic = (2.0 * k1[0]["FETCH_SIZE_KB_avg_per_launch"] + k1[0]["WRITE_SIZE_KB_avg_per_launch"]) * 1024.0
-                traffic_note = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_h_hbm_traffic_pmc.json "
-                                "(separate --pmc passes); mostly the materialised B scratch (34 MB), sparse rows (23 MB) "
-                                "and projector rows (10 MB) written for K2 - 1 TB/s, not the bound")
-        roofline = {
-            "bound": "mfma",
-            "kernel": "k_feat_chol (per-feature build + nullspace projection + chi2 gate on 255 CUs; chol(P) rides on the 256th), f64 vector ALU",
-            "achieved": alg / k_s / 1e12,
-            "peak": F64_PEAK_TFLOPS,
-            "peak_measured": 59.5,  # v_fma_f64 microbenchmark on this part (tools/fma64_bench.hip); f64 MFMA: 35-47
-            "unit": "TFLOP/s",
-            "frac": alg / k_s / 1e12 / F64_PEAK_TFLOPS,
-            "traffic": traffic,
-            "traffic_note": traffic_note,
-            "avg_launch_ms": k_ms,
-            "launches_timed": k_n,
-            "algorithmic_flops_per_launch": alg,
-            "executed_flops_per_launch": exe,
-            "achieved_executed": exe / k_s / 1e12,
-            "frac_executed": exe / k_s / 1e12 / F64_PEAK_TFLOPS,
-            "note": "achieved/frac use the SURVEY 8(d) reference-algorithm FLOPs (5.77 MFLOP per feature) as the contract "
-                    "asks; the Gram-form kernel issues 9x fewer FLOPs, so that rate can exceed the hardware peak - the "
-                    "hardware utilisation is frac_executed (the kernel is VALU-issue bound: DPP exchanges, LDS "
-                    "broadcasts and readlanes around the f64 FMAs, DESIGN.md section 5)",
-        }
+        C = sc.C
+        n_pts_done = int(run.ctx.n_feats) if world > 1 else int((~pl["used"]).sum()) if pl is not None else sc.F
         line = {
-            "metric": "MSCKF update-step features/sec at %d clones" % C,
+            "metric": "MSCKF+plane update-step features/sec at %d clones" % C,
             "value": value,
             "unit": "features/s",
             "n_gpus": world,
@@ -185,97 +260,108 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d clones, %d MSCKF point feats per GPU, 0 planes, calib on (N=%d)" % (C, F, sc.N),
-                       "clones": C, "feats_per_gpu": F, "state_dim": int(sc.N),
-                       "accepted": int(out["accepted"].sum()), "parallelism": "feature-shard x%d" % world},
-            "stage_ms": {"k1_build_project_gate": float(stage_ms[0]),
-                         "gram_then_ekf": float(stage_ms[2]), "gpu_total": float(stage_ms[3])},
-            "roofline": roofline,
+            "config": {"workload": describe(name, sc), "baseline_config": name, "clones": C, "feats": int(sc.F),
+                       "state_dim": int(sc.N), "planes": int(sc.cp.shape[0]),
+                       "planes_accepted": int(pl["ok"].sum()) if pl is not None else 0,
+                       "points_accepted": int(pt["accepted"].sum()),
+                       "parallelism": "1 GPU" if world == 1 else "plane loop replicated, free points sharded x%d (RCCL ranks: %d)"
+                                      % (world, dist.get_world_size()),
+                       "timed_region": "H2D feature batch + plane loop + point update + D2H results; covariance and pose tables "
+                                       "resident (restored on the device at the start of every step)"},
         }
-        if world == 1:
-            # second figure of SURVEY 8(d): StateHelper::EKFPropagation of the IMU block (k = 15) on the resident covariance,
-            # host call to completion (Phi / Q upload, strips, negative-diagonal check), outside the timed region above
-            try:
-                rng = np.random.default_rng(1)
-                Phi = np.eye(15) + 1e-3 * rng.standard_normal((15, 15))
-                Qd = 1e-8 * np.eye(15)
-                ctx.cov_upload(sc.P)
-                for _ in range(5):
-                    ctx.cov_propagate(0, [0], [15], Phi, Qd)
-                t0 = time.perf_counter()
-                n_prop = 50
-                for _ in range(n_prop):
-                    ctx.cov_propagate(0, [0], [15], Phi, Qd)
-                line["propagation_cov_step_us"] = 1e6 * (time.perf_counter() - t0) / n_prop
-            except Exception as e:  # the headline number must not depend on this extra
-                line["propagation_cov_step_us"] = None
-                print("propagation timing skipped: %r" % (e,), file=sys.stderr)
-        if world == 1 and not args.no_plane_config:
-            try:
-                ctx.close()   # the headline context is done; its polling / mapped buffers must not sit beside the next one
-            except Exception:
-                pass
-            # BASELINE config 2 of the metric ("30 clones, 2000 point + 20 plane feats"): reported next to the headline, never as
-            # `value`.  Plane loop (sequential over the 20 planes) + point update on the features no plane consumed.
-            try:
-                sc3 = make_scene(C=C, F=F, seed=0, n_planes=20, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=1.0)
-                ctx3 = capi.Context(sc3.N, sc3.C, sc3.F, device=local_rank)
-                o3 = capi.opts_from_scene(sc3)
-
-                def step3():
-                    ctx3.cov_upload(sc3.P)
-                    ctx3.state_upload(sc3)
-                    ctx3.batch_upload_scene(sc3)
-                    t0 = time.perf_counter()
-                    pl = ctx3.plane_update(o3, sc3.plane_id, sc3.cp, sc3.cp_fej, sc3.plane_state_id)
-                    t1 = time.perf_counter()
-                    ctx3.batch_upload_scene(sc3, np.where(~pl["used"])[0])
-                    t2 = time.perf_counter()
-                    pt = ctx3.msckf_update(o3)
-                    t3 = time.perf_counter()
-                    return pl, pt, (t1 - t0, t3 - t2)
-
-                for _ in range(3):
-                    step3()
-                reps = [step3() for _ in range(10)]
-                tt = np.array([r[2] for r in reps]).mean(axis=0)
-                pl, pt, _ = reps[-1]
-                line["plane_config"] = {
-                    "workload": "%d clones, %d feats of which %d on 20 planes (10 in the state), N=%d" % (C, F, int(pl["used"].sum()),
-                                                                                                         sc3.N),
-                    "plane_loop_ms": 1e3 * float(tt[0]), "point_update_ms": 1e3 * float(tt[1]),
-                    "total_ms": 1e3 * float(tt.sum()), "features_per_s": F / float(tt.sum()),
-                    "planes_accepted": int(pl["ok"].sum()), "points_accepted": int(pt["accepted"].sum())}
-                ctx3.close()
-            except Exception as e:
-                line["plane_config"] = None
-                print("plane config skipped: %r" % (e,), file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import pyoracle
-
-            pyoracle.build()
-            nf = min(args.cpu_sample_feats, F)
-            tb = time.perf_counter()
-            ref = pyoracle.msckf_point_update(sc, feats=np.arange(nf))
-            tcpu = time.perf_counter() - tb
-            line["cpu_baseline"] = {
-                "value": nf / tcpu,
-                "unit": "features/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": "oracle/ovp_oracle.c (reference loop order, 1 thread) on the first %d of %d features, one "
-                          "update step, %.2f s (feat system %.2f s, compression %.2f s, update %.3f s)"
-                          % (nf, F, tcpu, ref["timings"][0], ref["timings"][1], ref["timings"][2]),
-                "ms_per_step_sample": 1e3 * tcpu,
+        # ---- roofline of the dominant kernel ----
+        if run.has_planes and c2_n:
+            n_inv_avg = 6 * C + 14 + 1.5  # involved columns of a plane: clones + calibration (+3 when the plane is in the state)
+            fl = chol2_flops(sc.N, int(n_inv_avg))
+            ks = c2_ms * 1e-3
+            line["roofline"] = {
+                "bound": "mfma",
+                "kernel": "k_chol2 (one launch per plane: bordered tile Cholesky of T = I + L0^T A L0 and of the normalised Gram "
+                          "side by side on two CUs, gate, back substitution, dx, commit) - a latency-bound serial chain, the "
+                          "plane loop is %d of these in sequence" % int(sc.cp.shape[0]),
+                "achieved": fl / ks / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / ks / 1e12 / F64_PEAK_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": c2_ms, "launches_timed": c2_n, "algorithmic_flops_per_launch": fl,
+                "share_of_step": c2_ms * int(sc.cp.shape[0]) / ms_per_step,
+                "note": "f64 MFMA + DPP-broadcast FMA chains on 2 of 256 CUs: the fraction of the chip's peak is by construction "
+                        "tiny; what bounds the kernel is the dependent pivot chain (n sequential pivots) and the f64 pipe of one "
+                        "CU (DESIGN.md section 4)",
             }
+        if k1_n:
+            m = C
+            per_launch = n_pts_done if world > 1 else sc.F  # features the launch walks (skipped ones exit early)
+            alg = algorithmic_flops_per_feature(m) * n_pts_done
+            exe = executed_flops_per_feature(m) * n_pts_done
+            ks = max(k1_ms, 1e-9) * 1e-3
+            line["roofline_point_kernel"] = {
+                "bound": "mfma",
+                "kernel": "k_feat_chol (per-feature build + nullspace projection + chi2 gate of the point update; chol(P) rides "
+                          "on one CU of the same launch)",
+                "achieved": exe / ks / 1e12, "peak": F64_PEAK_TFLOPS, "peak_measured": 59.5, "unit": "TFLOP/s",
+                "frac": exe / ks / 1e12 / F64_PEAK_TFLOPS, "avg_launch_ms": k1_ms, "launches_timed": k1_n,
+                "features_gated_per_launch": n_pts_done, "features_walked_per_launch": per_launch,
+                "executed_flops_per_launch": exe, "reference_algorithm_flops_per_launch": alg,
+                "reference_algorithm_rate": alg / ks / 1e12,
+                "note": "frac = executed FLOPs of the Gram-form kernel / launch time / f64 peak; the SURVEY 8(d) reference-"
+                        "algorithm figure (5.77 MFLOP per feature, 9x more than executed) is carried separately",
+            }
+            if "roofline" not in line:
+                line["roofline"] = line["roofline_point_kernel"]
+        if world == 1 and not args.no_extras:
+            extras(line, capi, torch, args, local_rank, name)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(sc, name, args.cpu_sample_feats)
+                line["speedup_vs_cpu_baseline"] = line["cpu_baseline"]["ms_per_step"] / ms_per_step
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = None
+                print("cpu baseline skipped: %r" % (e,), file=sys.stderr)
         print(json.dumps(line))
+    run.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(line, capi, torch, args, device, headline):
+    """Side figures, measured after the timed region, never `value`."""
+    for key, wname in (("point_config", "config2"), ("config4_1gpu", "config4")):
+        if wname == headline:
+            continue
+        try:
+            sc = make_workload(wname)
+            r = StepRunner(capi, torch, sc, device)
+            with torch.cuda.stream(r.stream):
+                el, (pl, pt) = time_steps(torch, r.step, 20, 3)
+            line[key] = {"workload": describe(wname, sc), "ms_per_step": 1e3 * el / 20, "features_per_s": sc.F * 20 / el,
+                         "planes_accepted": int(pl["ok"].sum()) if pl is not None else 0,
+                         "points_accepted": int(pt["accepted"].sum())}
+            r.close()
+        except Exception as e:  # noqa: BLE001  (the headline must not depend on an extra)
+            line[key] = None
+            print("%s skipped: %r" % (key, e), file=sys.stderr)
+    # second figure of SURVEY 8(d): StateHelper::EKFPropagation of the IMU block (k = 15) on the resident covariance
+    try:
+        sc = make_workload("config2")
+        ctx = capi.Context(sc.N, sc.C, 16, device=device)
+        rng = np.random.default_rng(1)
+        Phi = np.eye(15) + 1e-3 * rng.standard_normal((15, 15))
+        Qd = 1e-8 * np.eye(15)
+        ctx.cov_upload(sc.P)
+        for _ in range(5):
+            ctx.cov_propagate(0, [0], [15], Phi, Qd)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ctx.cov_propagate(0, [0], [15], Phi, Qd)
+        line["propagation_cov_step_us"] = 1e6 * (time.perf_counter() - t0) / 50
+        ctx.close()
+    except Exception as e:  # noqa: BLE001
+        line["propagation_cov_step_us"] = None
+        print("propagation timing skipped: %r" % (e,), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -44,7 +44,9 @@ typedef struct {
   int do_fej;                     /* StateOptions::do_fej                      */
   int do_calib_camera_pose;       /* StateOptions::do_calib_camera_pose        */
   int do_calib_camera_intrinsics; /* StateOptions::do_calib_camera_intrinsics  */
-  int reserved;
+  int skip_plane_used;            /* point update only: 1 = leave out the features the accepted planes of the preceding
+                                     ovp_msckf_plane_update on this batch consumed (the reference erases them from feature_vec
+                                     before the point loop, update/UpdaterMSCKF.cpp:657-666); the mask stays on the device */
 } ovp_update_opts;
 
 /* Values of the ov_type variables the Jacobians read (state/State.h:86-121): clone poses (value and
@@ -283,6 +285,9 @@ int ovp_plane_optimize(ovp_ctx *ctx, const ovp_planeopt_batch *batch, double *cp
 /* copies an internal device buffer to host for tests: name in {"A","b","L","T","Lt","Y","G","rec","chi2",
  * "gramS","syrk"}; returns the byte count copied (or <0). */
 long ovp_debug_read(ovp_ctx *ctx, const char *name, void *host, long max_bytes);
+/* like ovp_kernel_timer, for the dominant kernel of the plane loop (k_chol2: both factorizations, gate, solve and commit of one
+ * plane): HIP events around every launch of ovp_msckf_plane_update while enabled */
+int ovp_plane_kernel_timer(ovp_ctx *ctx, int enable, int reset, float *avg_ms, int *n_launches);
 /* tile Cholesky (the factorization every EKF update and every plane of the plane loop runs) on a host matrix: dense factor of the
  * matrix bordered with brow ((n+1) x (n+1), row-major; brow may be NULL), z = L^-1 brow, y = L^-T z, pivots; avg_ms = average
  * duration over `reps` launches.  n <= 271. */

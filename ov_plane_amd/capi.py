@@ -32,7 +32,7 @@ class UpdateOpts(C.Structure):
         ("do_fej", C.c_int),
         ("do_calib_camera_pose", C.c_int),
         ("do_calib_camera_intrinsics", C.c_int),
-        ("reserved", C.c_int),
+        ("skip_plane_used", C.c_int),
     ]
 
 
@@ -116,7 +116,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream", "ovp_debug_chol2", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
+    "ovp_ctx_stream", "ovp_debug_chol2", "ovp_plane_kernel_timer", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
 ]
 
 
@@ -166,6 +166,7 @@ def lib():
         L.ovp_last_timings.argtypes = [C.c_void_p, C.c_void_p]
         L.ovp_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.ovp_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.ovp_plane_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.ovp_triang_defaults.argtypes = [C.POINTER(TriangOpts)]
         L.ovp_triang_defaults.restype = None
         L.ovp_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangOpts), C.c_void_p, C.c_void_p, C.c_void_p]
@@ -525,6 +526,11 @@ class Context:
     def kernel_timer(self, enable=True, reset=False):
         ms, nl = C.c_float(0), C.c_int(0)
         lib().ovp_kernel_timer(self._h, int(enable), int(reset), C.byref(ms), C.byref(nl))
+        return ms.value, nl.value
+
+    def plane_kernel_timer(self, enable=True, reset=False):
+        ms, nl = C.c_float(0), C.c_int(0)
+        lib().ovp_plane_kernel_timer(self._h, int(enable), int(reset), C.byref(ms), C.byref(nl))
         return ms.value, nl.value
 
     def debug_read(self, name, shape, dtype=np.float64):

@@ -287,42 +287,47 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (ew == 0) C2_STAMP(k, 0);
       c2_wait_ge(cnt_col, C2_TW * (k + 1));  // column k is in LDS
       if (ew == 0) C2_STAMP(k, 1);
-      const int my_i = k + 1 + ew + C2_EW * g;
-      const bool has_p = my_i < nt;
-      if (ew == 0 || k + 1 + ew < nt) {
-        double d[16], p[16];
-        {
-          const dbl2_t* dr = reinterpret_cast<const dbl2_t*>(S.Dbuf + r * C2_TS);
-          const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(pbk + (has_p ? my_i : 0) * C2_TSZ + r * C2_TS);
+      // panel tiles k+1 .. nt-1 are dealt out over (elimination wave, DPP row): 16 per pass, a second pass only when the
+      // column has 17 of them (bordered dimension 273..288, first column)
+      for (int base = 0; base == 0 || k + 1 + base < nt; base += 4 * C2_EW) {
+        const int my_i = k + 1 + base + ew + C2_EW * g;
+        const bool has_p = my_i < nt;
+        const bool first = (base == 0);
+        if ((first && ew == 0) || k + 1 + base + ew < nt) {
+          double d[16], p[16];
+          {
+            const dbl2_t* dr = reinterpret_cast<const dbl2_t*>(S.Dbuf + r * C2_TS);
+            const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(pbk + (has_p ? my_i : 0) * C2_TSZ + r * C2_TS);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const dbl2_t dv = dr[q];
-            d[2 * q] = dv[0];
-            d[2 * q + 1] = dv[1];
-            const dbl2_t pq = pr[q];
-            p[2 * q] = has_p ? pq[0] : 0.0;
-            p[2 * q + 1] = has_p ? pq[1] : 0.0;
+            for (int q = 0; q < 8; ++q) {
+              const dbl2_t dv = dr[q];
+              d[2 * q] = dv[0];
+              d[2 * q + 1] = dv[1];
+              const dbl2_t pq = pr[q];
+              p[2 * q] = has_p ? pq[0] : 0.0;
+              p[2 * q + 1] = has_p ? pq[1] : 0.0;
+            }
           }
-        }
-        if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, ew == 0 && lane == 0, J.piv_floor) || bad;
-        if (ew == 0) C2_STAMP(k, 2);
-        if (has_p) {
-          dbl2_t* pw = reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS);
+          if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, J.piv_floor) || bad;
+          if (ew == 0) C2_STAMP(k, 2);
+          if (has_p) {
+            dbl2_t* pw = reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) pw[q] = dbl2_t{p[2 * q], p[2 * q + 1]};
-          if (my_i == tb && r == rb && nb > n) {
+            for (int q = 0; q < 8; ++q) pw[q] = dbl2_t{p[2 * q], p[2 * q + 1]};
+            if (my_i == tb && r == rb && nb > n) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
+              for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
+            }
           }
-        }
-        if (ew == 0 && g == 0) {
-          dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
+          if (first && ew == 0 && g == 0) {
+            dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) dw[q] = dbl2_t{(2 * q <= r) ? d[2 * q] : 0.0, (2 * q + 1 <= r) ? d[2 * q + 1] : 0.0};
-          if (k == tb && r == rb && nb > n) {
+            for (int q = 0; q < 8; ++q) dw[q] = dbl2_t{(2 * q <= r) ? d[2 * q] : 0.0, (2 * q + 1 <= r) ? d[2 * q + 1] : 0.0};
+            if (k == tb && r == rb && nb > n) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-              if (c < rb) S.zbuf[16 * k + c] = d[c];
+              for (int c = 0; c < 16; ++c)
+                if (c < rb) S.zbuf[16 * k + c] = d[c];
+            }
           }
         }
       }
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
 
 extern "C" {
 
-int ovp_chol2_max_n(void) { return 16 * 17 - 1; }  // bordered dimension n + 1 <= 272 (17 tile rows, 20 tile slots per wave)
+int ovp_chol2_max_n(void) { return 16 * 18 - 1; }  // bordered dimension n + 1 <= 272 (17 tile rows, 20 tile slots per wave)
 
 // one workgroup (j1 == nullptr) or two (plane loop: update part and range part side by side)
 hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream) {
@@ -737,6 +742,7 @@ hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, co
     (void)hipFuncSetAttribute((const void*)k_chol2<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<22>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr = true;
   }
@@ -748,6 +754,8 @@ hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, co
     hipLaunchKernelGGL((k_chol2<17>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 20)
     hipLaunchKernelGGL((k_chol2<20>), grid, block, shmem, stream, *j0, b, p);
+  else if (slots <= 22)  // n + 1 up to 288: the tile registers no longer fit 168 VGPRs, part of them lives in scratch
+    hipLaunchKernelGGL((k_chol2<22>), grid, block, shmem, stream, *j0, b, p);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -36,7 +36,14 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
   __shared__ int sh_nq;
   __shared__ double Ai[9], bc[3], xr[3], dr_sh, slam_rr;
   __shared__ ColMap cm_sh[OVP_TC_MAX_TILES * 16];  // the column classification of the whole state (the entries below chase it)
+  __shared__ double gsum[OVP_GRAM_ELEMS];           // Gram of the sparse rows summed over the clones
   for (int i = t; i < n; i += 256) cm_sh[i] = a.colmap[i];
+  if (t < OVP_GRAM_ELEMS) {
+    double g = 0.0;
+    for (int sl = 0; sl < a.n_clones; ++sl)
+      for (int ch = 0; ch < a.n_chunks; ++ch) g += a.gramS[((size_t)sl * a.n_chunks + ch) * OVP_GRAM_ELEMS + t];
+    gsum[t] = g;
+  }
 
   // ---- constraint-row moments summed over the plane's features (fixed order) ----
   {
@@ -105,45 +112,43 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
     }
     return m;
   };
-  // entry (row, col) of the extended pair
+  // entry (row, col) of the extended pair.  Branch-free on purpose: every call issues the same loads (from a dummy address when
+  // a term does not apply) and selects afterwards, so the loads of the several entries a thread needs are all in flight
+  // together instead of one memory round trip per entry.
   auto entry = [&](int row, int col) {
     const ColMap mr = classify(row), mc = classify(col);
-    double s = 0.0;
-    if (mr.kind == 4 || mc.kind == 4) {
-      if (mr.kind == 4 && mc.kind == 4) {
-        const int i = min(mr.idx, mc.idx), j = max(mr.idx, mc.idx);
-        s = cst[i == 0 ? j : (i == 1 ? 2 + j : 5)];
-      } else if (mr.kind == 3 || mc.kind == 3) {
-        s = cst[6 + (mr.kind == 4 ? mr.idx : mc.idx)];
-      }
-    } else if (mr.kind != 0 && mc.kind != 0) {
-      auto gcol = [](const ColMap& m) { return m.kind == 1 ? m.off : (m.kind == 2 ? 6 + m.idx : 20); };
-      const int gr = gcol(mr), gc = gcol(mc);
-      const int gi = gram_index3(min(gr, gc), max(gr, gc));
-      auto slot_sum = [&](int slot) {
-        double v = 0.0;
-        for (int ch = 0; ch < a.n_chunks; ++ch) v += a.gramS[((size_t)slot * a.n_chunks + ch) * OVP_GRAM_ELEMS + gi];
-        return v;
-      };
-      if (mr.kind == 1 && mc.kind == 1) {
-        if (mr.idx == mc.idx) s = slot_sum(mr.idx);
-      } else if (mr.kind == 1) {
-        s = slot_sum(mr.idx);
-      } else if (mc.kind == 1) {
-        s = slot_sum(mc.idx);
-      } else {
-        for (int sl = 0; sl < a.n_clones; ++sl) s += slot_sum(sl);
-      }
+    const bool pl = (mr.kind == 4 || mc.kind == 4);
+    // plane columns: structured part from the constraint-row moments
+    double s_pl = 0.0;
+    {
+      const int i = min(mr.idx, mc.idx), j = max(mr.idx, mc.idx);
+      const double hh = cst[(mr.kind == 4 && mc.kind == 4) ? (i == 0 ? j : (i == 1 ? 2 + j : 5)) : 0];
+      const double hr = cst[6 + ((mr.kind == 4 ? mr.idx : mc.idx) % 3)];
+      if (mr.kind == 4 && mc.kind == 4) s_pl = hh;
+      else if (mr.kind == 3 || mc.kind == 3) s_pl = hr;
     }
+    // sparse rows: one clone's Gram, or the sum over the clones (calibration x calibration / residual)
+    const int gr = mr.kind == 1 ? mr.off : (mr.kind == 2 ? 6 + mr.idx : 20);
+    const int gc = mc.kind == 1 ? mc.off : (mc.kind == 2 ? 6 + mc.idx : 20);
+    const int gi = gram_index3(min(gr, gc), max(gr, gc));
+    const bool any1 = (mr.kind == 1 || mc.kind == 1);
+    const bool both1_diff = (mr.kind == 1 && mc.kind == 1 && mr.idx != mc.idx);
+    const int slot = mr.kind == 1 ? mr.idx : (mc.kind == 1 ? mc.idx : 0);
+    double g1 = 0.0;
+    for (int ch = 0; ch < a.n_chunks; ++ch) g1 += a.gramS[((size_t)slot * a.n_chunks + ch) * OVP_GRAM_ELEMS + gi];
+    const double gall = gsum[gi];
+    double s_g = 0.0;
+    if (!pl && mr.kind != 0 && mc.kind != 0) s_g = any1 ? (both1_diff ? 0.0 : g1) : gall;
+    // dense downdate G^T G
+    double d = 0.0;
     {
       const int I = max(row, col), J = min(row, col);
       const int ti = I >> 4, tj = J >> 4;
       const int tile = ti * (ti + 1) / 2 + tj;
       const int e = (I & 15) * 16 + (J & 15);
-      double d = 0.0;
       for (int sp = 0; sp < a.n_split; ++sp) d += a.part[((size_t)sp * a.ntile + tile) * 256 + e];
-      s -= d;
     }
+    double s = (pl ? s_pl : s_g) - d;
     for (int q = 0; q < sh_nq; ++q) {
       double hr = 0.0, hc = 0.0;
 #pragma unroll

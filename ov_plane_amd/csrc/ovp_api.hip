@@ -201,6 +201,10 @@ struct ovp_ctx {
   size_t pl_stage_cap = 0;
   void* pl_hres = nullptr;            // pinned host copy of the plane results
   size_t pl_hres_cap = 0;
+  bool pl_ktimer = false;
+  std::vector<hipEvent_t> pl_ev;
+  double pl_ktime_ms = 0.0;
+  int pl_klaunches = 0;
   int* idbuf = nullptr;      // scratch ints (ids)
   double* smallbuf = nullptr;  // scratch doubles (Phi, Q, CPT, PCP, marginal)
   size_t small_cap = 0;
@@ -614,6 +618,7 @@ extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
   c->n_feats = b->n_feats;
   c->max_meas = b->max_meas;
   c->have_batch = true;
+  c->pl_used_valid = false;
   return 0;
 }
 extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
@@ -629,6 +634,7 @@ extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
   c->n_feats = b->n_feats;
   c->max_meas = b->max_meas;
   c->have_batch = true;
+  c->pl_used_valid = false;
   return 0;
 }
 
@@ -778,6 +784,11 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   fp.chi2 = (double*)((char*)c->h_res_block_dev + ((char*)c->chi2 - (char*)c->res_block));
   fp.accept = (unsigned char*)c->h_res_block_dev + ((char*)c->accept - (char*)c->res_block);
   fp.dbg_cycles = c->dbg_cycles;
+  fp.skip = nullptr;
+  if (o->skip_plane_used) {
+    if (!c->pl_used_valid || !c->pl_used) return OVP_E_STATE;  // no plane update ran on this batch
+    fp.skip = c->pl_used;
+  }
   return 0;
 }
 
@@ -1514,7 +1525,16 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.n_slam = n_slam;
     ps.slam_id = d_sidx;
     ps.slam_p = d_slam_p;
+    if (c->pl_ktimer) {
+      while ((int)c->pl_ev.size() < 2 * (jn + 1)) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->pl_ev.push_back(e);
+      }
+      HIPCHK(hipEventRecord(c->pl_ev[2 * jn], s));
+    }
     HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
+    if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev[2 * jn + 1], s));
   }
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
   if (NJ > 0) {
@@ -1532,6 +1552,14 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (F) HIPCHK(hipMemcpyAsync(hused, c->pl_used, (size_t)F, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  if (c->pl_ktimer)
+    for (int jn = 0; jn < NJ; ++jn) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->pl_ev[2 * jn], c->pl_ev[2 * jn + 1]) == hipSuccess) {
+        c->pl_ktime_ms += ms;
+        c->pl_klaunches += 1;
+      }
+    }
   c->pl_used_valid = true;
   if (dx_planes) memcpy(dx_planes, hdx, sizeof(double) * (size_t)n * NP);
   if (feat_used && F) memcpy(feat_used, hused, (size_t)F);
@@ -1923,6 +1951,18 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
 extern "C" int ovp_last_timings(ovp_ctx* c, float* ms4) {
   if (!c || !ms4) return OVP_E_ARG;
   memcpy(ms4, c->last_ms, sizeof(float) * 4);
+  return 0;
+}
+
+extern "C" int ovp_plane_kernel_timer(ovp_ctx* c, int enable, int reset, float* avg_ms, int* n_launches) {
+  if (!c) return OVP_E_ARG;
+  if (avg_ms) *avg_ms = c->pl_klaunches ? (float)(c->pl_ktime_ms / c->pl_klaunches) : 0.f;
+  if (n_launches) *n_launches = c->pl_klaunches;
+  if (reset) {
+    c->pl_ktime_ms = 0.0;
+    c->pl_klaunches = 0;
+  }
+  c->pl_ktimer = enable != 0;
   return 0;
 }
 

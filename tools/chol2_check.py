@@ -12,7 +12,7 @@ from ov_plane_amd import capi  # noqa: E402
 def main():
     ctx = capi.Context(288, 30, 64)
     rng = np.random.default_rng(0)
-    for n in [5, 16, 31, 48, 96, 100, 197, 210, 240, 255, 256, 271]:
+    for n in [5, 16, 31, 48, 96, 100, 197, 210, 240, 255, 256, 271, 272, 285, 287]:
         for border in [False, True]:
             M = rng.standard_normal((n, n + 5))
             A = M @ M.T / n + 0.1 * np.eye(n)
