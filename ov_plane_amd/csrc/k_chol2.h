@@ -15,7 +15,7 @@ struct Chol2Job {
   size_t sel_stride;
   const double* brow;   // optional border row [n]: z = L^-1 brow^T is produced along the way
   int* flag;            // set to 1 on a non-positive pivot
-  double piv_floor;     // > 0: pivots are clamped from below (regularised, rank-deficient systems: mode 2) and never flagged
+  double piv_floor;     // > 0: columns whose pivot falls below it are dropped (rank-deficient semi-definite systems: mode 2), never flagged
   // mode 0 outputs (any may be null)
   double* Lpack;        // tile-packed factor of the n x n part (the layout k_fwdsub reads)
   double* Ldense;       // dense factor of the bordered matrix, (n + 1) x ldo

@@ -113,7 +113,9 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
     constexpr int c = decltype(cc)::value;
     if (write_piv) piv_out[c] = piv;
     bad = bad || !(piv > 0.0);
-    const double inv = rsqrt_nr2(floor > 0.0 ? fmax(piv, floor) : piv);
+    // floor > 0: a pivot below it marks a direction the (positive semi-definite) matrix does not determine - the column is
+    // dropped (no elimination with it, zero entry in the solution) instead of being divided by
+    const double inv = (floor > 0.0 && !(piv >= floor)) ? 0.0 : rsqrt_nr2(piv);
     const double l = d[c] * inv;
     const double q = p[c] * inv;
     double nl = -l;
@@ -581,10 +583,11 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
 
   if (J.mode == 2) {
     // ---- range part of the plane's residual:  pr = |Lr^-1 bn|^2, rank deficiency of the normalised Gram ----
-    // The columns arrive permuted (involved non-clone columns, clone columns, then the columns the plane does not touch, which
-    // are unit pivots).  Pivots below tol_strict are deficient; behind the first of them the Schur complements carry the
-    // amplified rounding error of the near-singular leading block (1e-16 / 1e-10), so there a pivot counts as deficient below
-    // tol_loose (measured: deficient 1e-10..1e-5, regular >= 1e-3).
+    // Rank: with the regularisation eps on the unit diagonal a deficient direction shows up as a pivot of eps x (1 .. 1e5) - the
+    // factor is |v|^2 / v_c^2 for the null vector v completed at column c - while the pivots of the well-determined directions
+    // stay above 1e-3 (measured on config-3 sized planes, tools/plane_gate_agreement.py): eps = 1e-12 and a threshold of 1e-5
+    // leave two decades on either side.  (The columns arrive with the clones last, so the deficiency of the gauge freedom
+    // completes in the trailing pivots.)
     if (wave == 0) {
       double pr = 0.0;
       for (int i = lane; i < n; i += 64) pr = fma(S.zbuf[i], S.zbuf[i], pr);

@@ -1463,7 +1463,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     pa.An = c->pl_An;
     pa.ldn = ld;
     pa.bn = c->pl_bn;
-    pa.eps = 1e-10;
+    pa.eps = 1e-12;
     pa.scal = c->pl_scal;
     HIPCHK(ovp_launch_plane_assemble2(&pa, s));
     // (4) W = A L0 ;  T_try = T_cur + L0^T W ;  c = L0^T b
@@ -1490,7 +1490,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     j1.mode = 2;
     j1.brow = c->pl_bn;
     j1.flag = c->flags + 2;
-    j1.piv_floor = 1e-13;
+    j1.piv_floor = 1e-5;
     ovp::PlaneSolve ps;
     memset(&ps, 0, sizeof(ps));
     ps.scal = c->pl_scal;
@@ -1501,8 +1501,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.rows_u = j.rows_u;
     ps.n_involved = j.n_inv_cols;
     ps.force = pb->force_decision ? (int)pb->force_decision[j.pl] : -1;
-    ps.tol_strict = 1e-8;
-    ps.tol_loose = 1e-4;
+    ps.tol_strict = 1e-5;
+    ps.tol_loose = 1e-5;
     ps.res_out = c->pl_res + 4 * j.pl;
     ps.L0 = c->L;
     ps.ld0 = ld;
@@ -1831,6 +1831,9 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
   else if (!strcmp(name, "P")) { src = c->P; bytes = nn; }
   else if (!strcmp(name, "G")) { src = c->G; bytes = (size_t)3 * c->n_feats * c->ldg * sizeof(double); }
   else if (!strcmp(name, "rec")) { src = c->rec; bytes = (size_t)c->fp.n_clones * c->n_feats * 2 * 21 * sizeof(double); }
+  else if (!strcmp(name, "plres")) { src = c->pl_res; bytes = (size_t)4 * c->pl_cap * sizeof(double); if (!src) return OVP_E_STATE; }
+  else if (!strcmp(name, "An")) { src = c->pl_An; bytes = nn; if (!src) return OVP_E_STATE; }
+  else if (!strcmp(name, "bn")) { src = c->pl_bn; bytes = (size_t)c->n_max * sizeof(double); if (!src) return OVP_E_STATE; }
   else if (!strcmp(name, "chi2")) {
     hipStreamSynchronize(c->stream);
     bytes = (size_t)c->n_feats * sizeof(double);

@@ -1718,3 +1718,30 @@ def test_filter_session_rejects_inconsistent_bookkeeping(hiplib):
         with pytest.raises(RuntimeError, match=msg):
             ses.step(frames[C + 1][0], uv, uv * 0, slot, nm, np.array([99999]), np.array([kind], dtype=np.int32))
         ses.close()
+
+
+def test_plane_gate_at_multiplier_one_over_fifty_scenes(hiplib, oracle):
+    """Plane-level chi2 gate (update/UpdaterMSCKF.cpp:607-631) at chi2_multipler = 1 - the value of the real-data configs
+    (config/euroc_mav/estimator_config.yaml:155) - on >= 50 config-3 sized scenes (30 clones, 20 planes x 50 features, N = 240).
+
+    The reference's statistic carries (kept rows - rank) rows of a rank-deficient Givens sweep whose content is decided by rounding
+    (tests/test_oracle_pins.py::test_plane_chi2_*); the device computes its deterministic part plus the expectation of those rows.
+    So the device loop runs with the oracle's accept / reject sequence forced (ovp_plane_batch::force_decision): state and
+    covariance must then agree to the path's tolerances on every scene, and the two statistics are compared plane by plane -
+    bounded mean and spread of the difference, decisions equal except in a band around the threshold that is as wide as the
+    spread of the rounding-dependent part (committed numbers: profiles/r02_plane_gate_agreement.json)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "plane_gate_agreement", os.path.join(os.path.dirname(GOLD), "..", "tools", "plane_gate_agreement.py"))
+    pga = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pga)
+    rows = pga.run(range(100, 156))
+    s = pga.summarise(rows)
+    assert s["seeds"] >= 50 and s["planes"] >= 1000
+    assert s["dof_mismatch"] == 0                      # same row count in the test as the reference (res_big.rows())
+    assert s["relP_max"] < TOL_P                       # covariance after the whole loop, every scene (observed 2e-11)
+    assert 0.7 < s["oracle_accept_rate"] < 0.95        # the gate is really deciding at this multiplier
+    assert abs(s["diff_mean"]) < 4.0 and s["diff_std"] < 5.0, s      # observed -2.9 +- 4.1 against a threshold of ~225
+    assert s["disagreement_rate"] < 0.05, s            # observed 2.8 %
+    assert s["disagreement_margin_max"] < 16.0, s      # every disagreement sits within 4 sigma of the threshold (observed 10.8)
