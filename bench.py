@@ -101,25 +101,22 @@ class StepRunner:
         pt = ctx.msckf_update(self.opts_pts)
         return pl, pt
 
-    def step_sharded(self, dist, rank, world, gram_t):
-        """Feature-sharded step: replicated plane loop, sharded point update with one all-reduce."""
-        from ov_plane_amd.dist import shard_bounds
+    def step_sharded(self, rank, world):
+        """Feature-sharded step through the functions of ov_plane_amd.dist that the gloo tests drive: replicated
+        plane loop, the free points split over the ranks, one RCCL all-reduce of the information pair on the context's stream."""
+        from ov_plane_amd.dist import shard_bounds, sharded_plane_then_point_update, sharded_update
 
         sc, ctx = self.sc, self.ctx
         ctx.cov_set_device(self.P0.data_ptr(), sc.N, sc.N)
         ctx.state_upload(sc)
-        ctx.batch_upload_scene(sc)
-        pl = None
-        rest = np.arange(sc.F)
         if self.has_planes:
-            pl = ctx.plane_update(self.opts, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
-            rest = np.nonzero(~pl["used"])[0]
-        lo, hi = shard_bounds(len(rest), rank, world)
-        ctx.batch_upload_scene(sc, rest[lo:hi])
-        ctx.build_gate_gram_async(self.opts)
-        dist.all_reduce(gram_t, op=dist.ReduceOp.SUM)
-        ctx.ekf_update_from_gram_async()
-        return pl, ctx.fetch_results()
+            pl, pt, _ = sharded_plane_then_point_update(
+                ctx, self.opts, lambda idx: ctx.batch_upload_scene(sc, idx), sc.F,
+                (sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id), rank=rank, world=world)
+            return pl, pt
+        lo, hi = shard_bounds(sc.F, rank, world)
+        ctx.batch_upload_scene(sc, np.arange(lo, hi))
+        return None, sharded_update(ctx, self.opts)
 
     def close(self):
         self.ctx.close()
@@ -225,11 +222,7 @@ def main():
 
     with torch.cuda.stream(run.stream):
         if world > 1:
-            from ov_plane_amd.dist import DeviceBufferView
-
-            ptr, rows, ld = run.ctx.gram_buffer()
-            gram_t = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
-            fn = lambda: run.step_sharded(dist, rank, world, gram_t)  # noqa: E731
+            fn = lambda: run.step_sharded(rank, world)  # noqa: E731
         else:
             fn = run.step
         elapsed, (pl, pt) = time_steps(torch, fn, args.steps, args.warmup, barrier)

@@ -1015,6 +1015,9 @@ extern "C" int ovph_load_trajectory(const char *path, double *out, int cap) {
   return (int)poses.size();
 }
 
+// per-frame trace of every following UpdaterMSCKF::update (point update) into `path`; NULL / "" stops tracing
+extern "C" int ovph_update_trace(const char *path) { return ov_plane::open_update_trace(path ? path : "") ? 0 : -1; }
+
 // no device needed: reads every frame of `in` with the C++ reader and writes it back to `out` with the C++ writer
 extern "C" int ovph_trace_copy(const char *in, const char *out) {
   std::ifstream is(in, std::ios::binary);

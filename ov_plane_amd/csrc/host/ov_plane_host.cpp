@@ -1,4 +1,6 @@
 #include "ov_plane_host.h"
+#include "ov_plane_io.h"
+#include <fstream>
 
 #include <algorithm>
 #include <cstdio>
@@ -603,6 +605,23 @@ UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, ov_core::FeatureInitializerO
   // the chi-square table (:59-62) lives inside libovplane_hip.so (ovp_chi2_quantile_095)
 }
 
+// ---- per-frame trace of the point update: every UpdaterMSCKF::update appends one record while a file is open
+static std::ofstream g_update_trace;
+static bool g_update_trace_header = false;
+bool open_update_trace(const std::string &path) {
+  if (g_update_trace.is_open()) g_update_trace.close();
+  if (path.empty()) return true;
+  g_update_trace.open(path, std::ios::binary);
+  g_update_trace_header = true;
+  return g_update_trace.is_open();
+}
+static std::ostream *update_trace_stream() { return g_update_trace.is_open() ? &g_update_trace : nullptr; }
+static bool update_trace_take_header() {
+  const bool h = g_update_trace_header;
+  g_update_trace_header = false;
+  return h;
+}
+
 void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                           std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_extra,
                           std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane) {
@@ -971,12 +990,71 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   std::vector<double> dx(n, 0.0);
   std::vector<uint8_t> ok(feature_vec.size(), 0);
   ovp_update_info info;
-  int rc = ovp_msckf_update(state->_gpu, &o, dx.data(), ok.data(), nullptr, &info);
+  // optional per-frame trace (ov_plane_io.h FrameTrace): everything this update reads, and below what it returned
+  FrameTrace tr;
+  std::ostream *tos = update_trace_stream();
+  if (tos) {
+    const int F = (int)feature_vec.size();
+    int M = 1;
+    for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
+    tr.timestamp = state->_timestamp;
+    tr.C = C;
+    tr.F = F;
+    tr.M = M;
+    tr.N = n;
+    for (int i = 0; i < C; ++i) {
+      memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
+      memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
+    }
+    tr.clone_q = cq;
+    tr.clone_p = cp;
+    tr.clone_q_fej = cqf;
+    tr.clone_p_fej = cpf;
+    tr.clone_id.assign(cid.begin(), cid.end());
+    auto calib = state->_calib_IMUtoCAM.at(0);
+    auto intr = state->_cam_intrinsics.at(0);
+    memcpy(tr.calib_q, calib->quat(), 4 * sizeof(double));
+    memcpy(tr.calib_p, calib->pos(), 3 * sizeof(double));
+    memcpy(tr.intrinsics, intr->value().data(), 8 * sizeof(double));
+    tr.calib_id = state->_options.do_calib_camera_pose ? calib->id() : -1;
+    tr.intr_id = state->_options.do_calib_camera_intrinsics ? intr->id() : -1;
+    tr.P.assign((size_t)n * n, 0.0);
+    gpu_check(ovp_cov_download(state->_gpu, tr.P.data(), n, n), "ovp_cov_download");
+    tr.uv.assign((size_t)F * M * 2, 0.f);
+    tr.clone_idx.assign((size_t)F * M, -1);
+    tr.n_meas.assign(F, 0);
+    tr.p_FinG.assign((size_t)F * 3, 0.0);
+    for (int f = 0; f < F; ++f) {
+      tr.n_meas[f] = (int)feature_vec[f]->timestamps.size();
+      for (int k = 0; k < tr.n_meas[f]; ++k) {
+        tr.clone_idx[(size_t)f * M + k] = clone_slot.at(feature_vec[f]->timestamps[k]);
+        tr.uv[((size_t)f * M + k) * 2] = feature_vec[f]->uvs[2 * k];
+        tr.uv[((size_t)f * M + k) * 2 + 1] = feature_vec[f]->uvs[2 * k + 1];
+      }
+      memcpy(&tr.p_FinG[3 * f], feature_vec[f]->p_FinG, 3 * sizeof(double));
+    }
+    tr.sigma_px = o.sigma_px;
+    tr.chi2_mult = o.chi2_multiplier;
+    tr.sigma_c = o.sigma_constraint;
+    tr.do_fej = o.do_fej;
+    tr.do_calib_pose = o.do_calib_camera_pose;
+    tr.do_calib_intr = o.do_calib_camera_intrinsics;
+  }
+  std::vector<double> chi2v(tos ? feature_vec.size() : 0, 0.0);
+  int rc = ovp_msckf_update(state->_gpu, &o, dx.data(), ok.data(), tos ? chi2v.data() : nullptr, &info);
   if (rc == OVP_E_NEGDIAG) {
     PRINT_ERROR("StateHelper::EKFUpdate() - negative covariance diagonal\n");
     std::exit(EXIT_FAILURE);
   }
   gpu_check(rc, "ovp_msckf_update");
+  if (tos) {
+    tr.dx = dx;
+    tr.accepted = ok;
+    tr.chi2 = chi2v;
+    tr.P_after.assign((size_t)n * n, 0.0);
+    gpu_check(ovp_cov_download(state->_gpu, tr.P_after.data(), n, n), "ovp_cov_download");
+    write_frame_trace(*tos, tr, update_trace_take_header());
+  }
   // :755-757 rejected features are flagged and erased, :791-793 the rest is flagged as used
   std::vector<std::shared_ptr<ov_core::Feature>> kept;
   for (size_t f = 0; f < feature_vec.size(); ++f) {

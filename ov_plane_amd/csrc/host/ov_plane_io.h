@@ -63,5 +63,7 @@ struct FrameTrace {
 };
 bool write_frame_trace(std::ostream &os, const FrameTrace &f, bool with_header);
 bool read_frame_trace(std::istream &is, FrameTrace &f, bool expect_header);
+// while a file is open every UpdaterMSCKF::update appends the inputs and outputs of its point update ("" closes it)
+bool open_update_trace(const std::string &path);
 
 }  // namespace ov_plane

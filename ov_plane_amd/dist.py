@@ -24,21 +24,40 @@ class DeviceBufferView:
                                              strides=None)
 
 
+def _gram_tensor(ctx):
+    """torch view of the context's reduce buffer [A | b]: the device buffer of libovplane_hip.so, or whatever tensor a stand-in
+    context (the CPU one of tests/test_dist_cpu.py) hands out through gram_tensor()."""
+    import torch
+
+    if hasattr(ctx, "gram_tensor"):
+        return ctx.gram_tensor()
+    ptr, rows, ld = ctx.gram_buffer()
+    return torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
+
+
+def _collective_stream(ctx):
+    """Context manager that makes the stream the context orders its work on the current torch stream (no-op for a CPU stand-in)."""
+    import contextlib
+
+    import torch
+
+    if hasattr(ctx, "stream_handle") and torch.cuda.is_available():
+        return torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_handle()))
+    return contextlib.nullcontext()
+
+
 def sharded_update(ctx, opts, group=None):
     """One update step on a rank that already holds its shard (ctx.batch_*), the shared pose tables and P.
 
     The all-reduce is enqueued on the stream the context orders its work on (ovp_ctx_stream), wrapped as a
     torch.cuda.ExternalStream, so that it runs between the two halves of the staged update without a host sync.
     Returns ctx.fetch_results()."""
-    import torch
     import torch.distributed as dist
 
     ctx.build_gate_gram_async(opts)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        ptr, rows, ld = ctx.gram_buffer()
-        with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_handle())):
-            t = torch.as_tensor(DeviceBufferView(ptr, rows * ld), device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        with _collective_stream(ctx):
+            dist.all_reduce(_gram_tensor(ctx), op=dist.ReduceOp.SUM, group=group)
     ctx.ekf_update_from_gram_async()
     return ctx.fetch_results()
 

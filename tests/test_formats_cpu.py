@@ -77,3 +77,22 @@ def test_committed_trace_fixture_holds_the_oracle_outputs(oracle):
     assert np.array_equal(f["uv"], sc.uv) and np.allclose(f["P"], sc.P, atol=0)
     assert (f["accepted"].astype(bool) == ref["accepted"]).all()
     assert np.abs(f["dx"] - ref["dx"]).max() < 1e-12 and np.abs(f["P_after"] - ref["P"]).max() < 1e-12
+
+
+def test_euroc_sized_trace_matches_the_oracle_frame_by_frame(oracle):
+    """tests/golden/trace_euroc_like.ovptrc: every fifth point update of a 40-frame closed-loop run at the sizes of the reference's
+    real-data configuration (11 clones + the new one, at most 20 MSCKF features, chi2_multipler 1;
+    config/euroc_mav/estimator_config.yaml:16-19,155), recorded on the MI355X by tools/record_euroc_like_trace.py with the DEVICE's
+    outputs - the stand-in for BASELINE config 5, whose ROS replay cannot run here.  The oracle, given each frame's recorded
+    inputs, must take the same gate decisions and arrive at the recorded state correction and covariance."""
+    frames = trace.read_frames(os.path.join(GOLD, "trace_euroc_like.ovptrc"))
+    assert len(frames) >= 8
+    for f in frames:
+        assert f["C"] == 12 and 2 <= f["F"] <= 20 and f["chi2_mult"] == 1.0 and "dx" in f
+        sc = trace.scene_from_frame(f)
+        ref = oracle.msckf_point_update(sc)
+        assert (ref["accepted"] == f["accepted"].astype(bool)).all()
+        assert np.abs(ref["chi2"] - f["chi2"]).max() <= 1e-8 * max(1.0, np.abs(ref["chi2"]).max())
+        assert np.abs(ref["dx"] - f["dx"]).max() < 1e-6
+        d = np.sqrt(np.abs(np.diag(ref["P"])))
+        assert (np.abs(ref["P"] - f["P_after"]) / np.outer(d, d)).max() < 1e-4

@@ -191,6 +191,51 @@ def test_config3_plane_loop_at_full_size_matches_oracle(hiplib, oracle):
     ctx.close()
 
 
+def test_config4_on_one_gpu_plane_loop_and_point_update(hiplib, oracle):
+    """BASELINE config[3] on a single GPU, where it fits: 30 clones, 8000 features of which 2500 lie on 50 planes (25 of them in the
+    state, N = 285 - the largest state of the BASELINE configurations, above 16 tile rows).  Plane loop against the oracle (about
+    ten seconds for it), then the point update on the 5500 free points straight from the device-side used mask
+    (ovp_update_opts::skip_plane_used), checked through its information identity."""
+    sc = make_scene(C=30, F=8000, seed=0, n_planes=50, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=99999.0)
+    assert sc.N == 285 and int((sc.plane_id > 0).sum()) == 2500
+    ref = oracle.msckf_plane_update(sc)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    o = hiplib.opts_from_scene(sc)
+    out = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert (out["ok"] == ref["plane_ok"]).all() and out["ok"].all()
+    assert (out["used"] == ref["used"]).all() and out["used"].sum() == 2500
+    assert (out["dof"] == ref["plane_rows"]).all()
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    P_pl = ctx.cov_download()
+    assert relP(P_pl, ref["P"]) < TOL_P
+    # point update on the free points: same batch, the features of the accepted planes are skipped on the device
+    o.chi2_multiplier = 1.0
+    o.skip_plane_used = 1
+    upd = ctx.msckf_update(o)
+    P1 = ctx.cov_download()
+    assert not upd["accepted"][out["used"]].any()
+    assert upd["accepted"][~out["used"]].mean() > 0.9
+    ld = ((sc.N + 15) // 16) * 16
+    Ab = ctx.debug_read("Ab", (sc.N + 1, ld))
+    A, b = Ab[: sc.N, : sc.N], Ab[sc.N, : sc.N]
+    assert np.abs(P1 @ (np.linalg.inv(P_pl) + A) - np.eye(sc.N)).max() < 1e-6
+    assert np.abs(upd["dx"] - P1 @ b).max() < 1e-9
+    # the same point update with the leftovers uploaded as a batch of their own: identical information pair
+    rest = np.where(~out["used"])[0]
+    ctx.cov_upload(P_pl)
+    ctx.batch_upload_scene(sc, rest)
+    o.skip_plane_used = 0
+    upd2 = ctx.msckf_update(o)
+    assert (upd2["accepted"] == upd["accepted"][rest]).all()
+    assert np.abs(upd2["dx"] - upd["dx"]).max() < 1e-9
+    ctx.close()
+
+
 def test_dense_ekf_update_matches_reference_form(hiplib):
     """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H."""
     from oracle import np_ref
@@ -1273,6 +1318,26 @@ def test_committed_trace_frame_replays_on_the_device(hiplib):
     assert np.abs(out["chi2"] - f["chi2"]).max() <= 1e-8 * max(1.0, np.abs(f["chi2"]).max())
     assert np.abs(out["dx"] - f["dx"]).max() < TOL_DX
     assert relP(out["P"], f["P_after"]) < TOL_P
+    out["ctx"].close()
+
+
+def test_euroc_sized_trace_replays_on_the_device(hiplib, oracle):
+    """tests/golden/trace_euroc_like.ovptrc (see tests/test_formats_cpu.py): replaying the recorded frames through the C-ABI
+    reproduces the recorded device outputs and agrees with the oracle on every frame (11 + 1 clones, <= 20 features, gate at
+    chi2_multipler = 1: the small-batch regime of config/euroc_mav/estimator_config.yaml)."""
+    from ov_plane_amd import trace
+
+    path = os.path.join(GOLD, "trace_euroc_like.ovptrc")
+    rows = trace.replay(path)
+    assert len(rows) >= 8
+    for r in rows:
+        assert r["accept_mismatch"] == 0 and r["max_abs_ddx"] < 1e-9 and r["max_rel_dP"] < 1e-8, r
+    f = trace.read_frames(path)[-1]
+    sc = trace.scene_from_frame(f)
+    out = run_gpu(hiplib, sc)
+    ref = oracle.msckf_point_update(sc)
+    assert (out["accepted"] == ref["accepted"]).all()
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX and relP(out["P"], ref["P"]) < TOL_P
     out["ctx"].close()
 
 
