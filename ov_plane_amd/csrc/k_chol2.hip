@@ -340,6 +340,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   } else {
     // ================================== tile waves ===================================
     const int tw = wave - C2_EW;
+    if (tw == 0) C2_STAMP(1, 13);
     // ---- load: tile index idx = slot * C2_TW + tw, column-major over the lower tile triangle ----
     {
       const double* Abase = J.A + (J.sel ? (size_t)((*J.sel) ^ J.sel_xor) * J.sel_stride : (size_t)0);
@@ -360,31 +361,40 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         j = __builtin_amdgcn_readfirstlane(j);
         ti[s] = i;
         tj[s] = j;
-        // raw loads from clamped addresses (all of a wave's tiles in flight together); only the diagonal tiles and the tile
-        // rows that hold the border / padding pay for selects behind their loads
+        // pass 1: raw loads from clamped addresses, nothing uses them yet - all of the wave's tiles are in flight together
         double4_t t = {0.0, 0.0, 0.0, 0.0};
         if (i >= 0) {
           const int c = 16 * j + lc;
           const int cc = c < n ? c : n - 1;
-          const bool special = (i >= (n >> 4)) || (i == j);
-          double brow_c = 0.0;
-          if (nb > n && i == tb) brow_c = J.brow[cc];
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int r = 16 * i + lr + 4 * v;
             const int rc = r < n ? r : n - 1;
-            double x = Abase[(size_t)rc * J.ld + cc];
-            if (special) {
-              double pad = (r == c) ? 1.0 : 0.0;
-              if (nb > n && r == n) pad = (c < n) ? brow_c : (c == n ? 1e300 : 0.0);
-              x = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
-            }
-            t[v] = x;
+            t[v] = Abase[(size_t)rc * J.ld + cc];
           }
         }
         tile[s] = t;
       });
+      if (tw == 0) C2_STAMP(0, 13);
+      // pass 2: the diagonal tiles (+ I) and the tile rows that hold the border row / the identity padding
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const int i = ti[s], j = tj[s];
+        if (i >= 0 && (i >= (n >> 4) || i == j)) {
+          const int c = 16 * j + lc;
+          const double brow_c = (nb > n && i == tb) ? J.brow[c < n ? c : n - 1] : 0.0;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = 16 * i + lr + 4 * v;
+            double pad = (r == c) ? 1.0 : 0.0;
+            if (nb > n && r == n) pad = (c < n) ? brow_c : (c == n ? 1e300 : 0.0);
+            const double x = tile[s][v];
+            tile[s][v] = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
+          }
+        }
+      });
     }
+    if (tw == 0) C2_STAMP(0, 14);
     const int s_last = (ntiles - 1 - tw >= 0) ? (ntiles - 1 - tw) / C2_TW : -1;
     auto put_rowmajor = [&](double* buf, const double4_t& t) {
 #pragma unroll
@@ -406,6 +416,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
       });
       c2_signal(cnt_col, lane);
+      if (tw == 0) C2_STAMP(0, 15);
     }
     for (int k = 0; k < nt; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;

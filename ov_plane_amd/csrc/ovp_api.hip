@@ -1919,6 +1919,8 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
     hipFree(st);
     const int nt = (nb + 15) / 16;
     fprintf(stderr, "chol2 stamps (cycles): elimination wave 0 [wait column | read+eliminate | write] ; tile wave 0 [wait panel | reload + next column | wait buffer + publish | rest]\n");
+    fprintf(stderr, " tile wave 0 prologue: issue loads %lld, patch special tiles %lld, publish column 0 %lld (elimination wave 0 starts waiting at %lld after the tile wave)\n",
+            h[13] - h[16 + 13], h[14] - h[13], h[15] - h[14], h[0] - h[16 + 13]);
     for (int k = 0; k < nt; ++k) {
       const long long* e = h + k * 16;
       fprintf(stderr, " k=%2d E: %6lld %6lld %6lld | T: %6lld %6lld %6lld %6lld | E step %6lld T step %6lld\n", k, e[1] - e[0], e[2] - e[1],
