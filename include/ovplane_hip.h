@@ -50,7 +50,10 @@ typedef struct {
 } ovp_update_opts;
 
 /* Values of the ov_type variables the Jacobians read (state/State.h:86-121): clone poses (value and
- * first-estimate), camera extrinsics/intrinsics (monocular: cam 0, radtan). Host pointers. */
+ * first-estimate), camera extrinsics/intrinsics.  MONOCULAR ONLY: one camera (cam 0, radtan or equidistant) - every shipped
+ * configuration of the reference sets max_cameras: 1; the per-camera measurement loop of update/UpdaterHelper.cpp:335-344 is
+ * taken for a single camera id, a stereo pair would need a second calibration block and camera index per measurement.
+ * Host pointers. */
 typedef struct {
   int n_state;               /* N = State::_Cov.rows()                       */
   int n_clones;

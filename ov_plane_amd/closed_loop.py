@@ -154,7 +154,7 @@ def run(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, max_feats=
 
 
 def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, planes=0, plane_min_feat=6, sigma_c=0.01,
-                max_slam=0, feat_rep_slam=0, min_meas=3, out_dir=None, zupt=None):
+                max_slam=0, feat_rep_slam=0, min_meas=3, out_dir=None, zupt=None, track_planes=True, forget_planes_at=None):
     """Closed loop through hostlib.Session, frame by frame, with the tracker-side bookkeeping of core/VioManager.cpp:360-506:
     a track is an MSCKF feature once it is lost or reaches back to the clone about to be marginalised; a track that spans the
     whole window (more than max_clone_size measurements) becomes a SLAM landmark while there is room (max_slam), and from then
@@ -162,6 +162,9 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
     feat_rep_slam: ext LandmarkRepresentation of the landmarks (0 GLOBAL_3D ... 5 ANCHORED_INVERSE_DEPTH_SINGLE).
     out_dir: write state_estimate.txt / state_deviation.txt / state_groundtruth.txt / timing.txt there, in the formats a run of
     the reference's simulation leaves behind (what its results/ scripts and ov_eval read).
+    track_planes: hand the planes of all live tracks to the session every frame (the tracker's feature -> plane map,
+    core/VioManager.cpp:513-534), so that a plane nobody observes any more leaves the state; forget_planes_at = frame index from
+    which the tracker reports no plane at all (test hook: every plane of the state must then be marginalised).
     zupt: dict of Session.enable_zupt keywords (or {}) = VioManagerOptions::try_zupt: a frame at which the platform is found
     standing still gets a zero-velocity update instead of a clone (core/VioManager.cpp:311-331) and its measurements are dropped."""
     from . import hostlib
@@ -256,7 +259,13 @@ def run_session(sim, n_frames=60, C=11, po=None, sigma_px=1.0, chi2_mult=1.0, pl
         pl = np.array([max(plane_of[int(f)], 0) for f in fid], dtype=np.int32) if planes else None
         gt = sim.get_state(t_k + sim.params["calib_camimu_dt"])
         truth = np.concatenate([[gt["t"]], gt["q"], gt["p"], gt["v"], gt["bg"], gt["ba"], truth_tail])
-        out = ses.step(t_k, uv, uvn, slot, nm, fid + FID_OFFSET, kind, pl, truth)
+        active = None
+        if planes == 2 and track_planes:
+            live = set(seen) | set(tracks) | {it[0] for it in items}
+            active = {plane_of[int(f)] for f in live if plane_of[int(f)] > 0}
+            if forget_planes_at is not None and i >= forget_planes_at:
+                active, pl = set(), np.zeros(len(fid), dtype=np.int32)
+        out = ses.step(t_k, uv, uvn, slot, nm, fid + FID_OFFSET, kind, pl, truth, active_planes=active)
         window = win[1:]
         slam_ids = {i_ - FID_OFFSET for i_ in out["slam_ids"]}
         for f in slam_ids:

@@ -866,6 +866,12 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
           if (state->_options.use_refine_plane_feat &&
               !PlaneFitting::optimize_plane(feats, cp, clones_cam, sigma_px_norm, sigma_c, true, stateI, calib0))
             continue;
+          // :284-302 ground truth for the features (the plane itself is a state variable and keeps its estimate)
+          if (state->_options.use_groundtruths && !state->_true_planes.empty() && !state->_true_features.empty())
+            for (auto &ft : feats) {
+              auto itt = state->_true_features.find(ft->featid);
+              if (itt != state->_true_features.end()) memcpy(ft->p_FinG, itt->second.data(), 3 * sizeof(double));
+            }
         } else {
           if (feats.size() < 4) continue;  // :320-321
           double abcd[4];
@@ -875,6 +881,15 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
           if (state->_options.use_refine_plane_feat &&
               !PlaneFitting::optimize_plane(feats, cp, clones_cam, sigma_px_norm, sigma_c, false, stateI, calib0))
             continue;  // :355-357
+          // :363-380 ground truth for the plane and its features
+          if (state->_options.use_groundtruths && !state->_true_planes.empty() && !state->_true_features.empty()) {
+            auto itp = state->_true_planes.find(pid);
+            if (itp != state->_true_planes.end()) memcpy(cp, itp->second.data(), 3 * sizeof(double));
+            for (auto &ft : feats) {
+              auto itt = state->_true_features.find(ft->featid);
+              if (itt != state->_true_features.end()) memcpy(ft->p_FinG, itt->second.data(), 3 * sizeof(double));
+            }
+          }
           bool has_msckf_feat = false;  // :384-392
           for (auto &ft : feats) has_msckf_feat = has_msckf_feat || !state->_features_SLAM.count(ft->featid);
           if (!has_msckf_feat || feats.size() < 4) continue;  // :395-396

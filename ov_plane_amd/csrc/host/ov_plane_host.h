@@ -4,6 +4,7 @@
 // feature vector side effects) stays here.  Citations relative to /root/reference/ov_plane/src/.
 #pragma once
 #include <cmath>
+#include <array>
 #include <map>
 #include <mutex>
 #include <set>
@@ -48,7 +49,7 @@ struct StateOptions {
   ov_type::LandmarkRepresentation::Representation feat_rep_slam = ov_type::LandmarkRepresentation::GLOBAL_3D;
   int max_msckf_plane = 20;            // StateOptions.h:123
   bool use_refine_plane_feat = true;   // StateOptions.h: refine on-plane features and the plane with optimize_plane
-  bool use_groundtruths = false;
+  bool use_groundtruths = false;       // debugging aid of the simulation: overwrite fitted planes / their features with the truth (update/UpdaterMSCKF.cpp:284-302,363-380)
   int plane_msckf_min_feat = 20;       // plane_fitting: minimum inliers (MSCKF planes), StateOptions.h:147
   double plane_msckf_max_cond = 100.0; //                 condition number limit of the 5-point solve, :150
   int plane_init_min_feat = 20;        // :141
@@ -133,6 +134,9 @@ public:
   std::unordered_map<size_t, size_t> _features_SLAM_to_PLANE;
   // out-of-state plane estimates the caller obtained upstream (PlaneFitting, out of scope here; UpdaterMSCKF.cpp:319-400)
   std::map<size_t, std::vector<double>> _plane_estimates_cp_inG;
+  // simulation ground truth (state/State.h:120-121), read by UpdaterMSCKF::update when StateOptions::use_groundtruths is set
+  std::unordered_map<size_t, std::array<double, 3>> _true_planes;
+  std::unordered_map<size_t, std::array<double, 3>> _true_features;
 
 private:
   friend class StateHelper;

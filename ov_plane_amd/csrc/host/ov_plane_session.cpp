@@ -223,11 +223,43 @@ extern "C" int ovph_session_feed_imu(void *h, int n, const double *imu7) {
 // after the frame; ids of the landmarks in the state (slam_ids, at most slam_cap).
 // truth (or NULL) feeds the groundtruth file: [0..16] t, q, p, v, bg, ba of the simulator at this frame, [17] true camera time
 // offset, [18..25] true intrinsics, [26..32] true extrinsics (q_ItoC, p_IinC).
+// Tracker-side plane bookkeeping (core/VioManager.cpp:513-534): active_planes[n_active] = ids of the planes the tracker currently
+// sees (the distinct values of its feature -> plane map over ALL live tracks, not only the ones used in this frame),
+// merge_pairs[2 * n_merge] = (surviving id, old id) pairs of planes the front end merged.  With active_planes != NULL the step runs
+// StateHelper::merge_planes_and_marginalize like the reference does every frame: merged planes are fused (3-row update) and
+// planes nobody observes any more leave the state.  NULL keeps every plane (the caller guarantees they stay observed).
+extern "C" int ovph_session_step2(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
+                                  const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
+                                  double *x16, double *posecov36, int slam_cap, long long *slam_ids, const double *truth17,
+                                  int n_active, const long long *active_planes, int n_merge, const long long *merge_pairs);
+
 extern "C" int ovph_session_step(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
                                  const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
                                  double *x16, double *posecov36, int slam_cap, long long *slam_ids, const double *truth17) {
+  return ovph_session_step2(h, frame_time, F, M, uv, uv_norm, clone_slot, n_meas, gfid, kind, plane, counts, x16, posecov36, slam_cap,
+                            slam_ids, truth17, 0, nullptr, 0, nullptr);
+}
+
+extern "C" int ovph_session_step2(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
+                                  const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
+                                  double *x16, double *posecov36, int slam_cap, long long *slam_ids, const double *truth17,
+                                  int n_active, const long long *active_planes, int n_merge, const long long *merge_pairs) {
   auto *s = static_cast<Session *>(h);
   auto &state = s->state;
+  // the inputs are checked BEFORE the state is touched: a rejected call must leave the filter where it was (a propagated state
+  // with an extra clone could not be stepped again: "Propagation called again at same timestep" is fatal)
+  {
+    const int n_window = (int)state->_clones_IMU.size() + 1;  // clones after this frame's cloning
+    for (int f = 0; f < F; ++f) {
+      if (n_meas[f] < 0 || n_meas[f] > M) return -21;
+      for (int q = 0; q < n_meas[f]; ++q) {
+        const int sl = clone_slot[(size_t)f * M + q];
+        if (sl < 0 || sl >= n_window) return -21;
+      }
+      if (kind[f] < 0 || kind[f] > 2) return -23;
+      if (kind[f] == 1 && !state->_features_SLAM.count((size_t)gfid[f])) return -22;  // the caller's bookkeeping is out of step
+    }
+  }
   TimingRecord tr;
   const auto t_start = std::chrono::steady_clock::now();
   auto t_prev = t_start;
@@ -274,6 +306,15 @@ extern "C" int ovph_session_step(void *h, double frame_time, int F, int M, const
       ++n_marg;
     }
   StateHelper::marginalize_slam(state);
+  // :513-534 planes the front end merged are fused, planes that are no longer observed leave the state
+  if (active_planes && s->plane_mode == 2) {
+    std::map<size_t, size_t> f2p_active = feat2plane;
+    size_t fake = (size_t)-1;  // ids that cannot collide with tracker ids: only the VALUES of the map are read
+    for (int k = 0; k < n_active; ++k) f2p_active[fake--] = (size_t)active_planes[k];
+    std::map<size_t, std::set<size_t>> plane2oldplane;
+    for (int k = 0; k < n_merge; ++k) plane2oldplane[(size_t)merge_pairs[2 * k]].insert((size_t)merge_pairs[2 * k + 1]);
+    StateHelper::merge_planes_and_marginalize(state, f2p_active, plane2oldplane);
+  }
   {  // :487-500 a landmark that was flagged by a failed update is gone now although it is still tracked: its single new
      // measurement would be a delayed initialisation with one observation, which :112-118 of UpdaterSLAM.cpp drops
     std::vector<std::shared_ptr<ov_core::Feature>> still;

@@ -501,9 +501,12 @@ class Session:
         if self._L.ovph_session_open_files(C.c_void_p(self._h), enc(est), enc(std), enc(gt), enc(timing)) != 0:
             raise RuntimeError("ovph_session_open_files failed")
 
-    def step(self, frame_time, uv, uv_norm, slot, n_meas, fid, kind, plane=None, truth=None):
-        """One camera frame (arrays as in ovph_session_step).  Returns dict(counts, x16, posecov [6,6], slam_ids).
-        truth [33]: simulator state, time offset, intrinsics and extrinsics for the groundtruth file (open_files)."""
+    def step(self, frame_time, uv, uv_norm, slot, n_meas, fid, kind, plane=None, truth=None, active_planes=None, merged_planes=None):
+        """One camera frame (arrays as in ovph_session_step2).  Returns dict(counts, x16, posecov [6,6], slam_ids).
+        truth [33]: simulator state, time offset, intrinsics and extrinsics for the groundtruth file (open_files).
+        active_planes: ids of the planes the tracker currently sees (over all live tracks); planes in the state that are not among
+        them are marginalised, merged_planes [(surviving id, old id), ...] are fused first (core/VioManager.cpp:513-534 ->
+        StateHelper::merge_planes_and_marginalize).  None = no plane leaves the state."""
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         F = int(len(n_meas))
         M = int(uv.shape[1]) if F else 1
@@ -518,10 +521,14 @@ class Session:
         x16, pc = np.zeros(16), np.zeros(36)
         cap = max(self.max_slam, 1) + 8
         ids = -np.ones(cap, dtype=np.int64)
-        self._L.ovph_session_step.restype = C.c_int
-        rc = self._L.ovph_session_step(C.c_void_p(self._h), C.c_double(frame_time), C.c_int(F), C.c_int(M), p(uv), p(uvn), p(slot),
-                                       p(nm), p(gf), p(kd), p(pl), p(counts), p(x16), p(pc), C.c_int(cap), p(ids),
-                                       p(np.ascontiguousarray(truth, dtype=np.float64)) if truth is not None else None)
+        act = None if active_planes is None else np.ascontiguousarray(sorted(set(int(a) for a in active_planes)), dtype=np.int64)
+        mrg = np.ascontiguousarray(merged_planes if merged_planes is not None else np.zeros((0, 2)), dtype=np.int64).reshape(-1, 2)
+        self._L.ovph_session_step2.restype = C.c_int
+        rc = self._L.ovph_session_step2(C.c_void_p(self._h), C.c_double(frame_time), C.c_int(F), C.c_int(M), p(uv), p(uvn), p(slot),
+                                        p(nm), p(gf), p(kd), p(pl), p(counts), p(x16), p(pc), C.c_int(cap), p(ids),
+                                        p(np.ascontiguousarray(truth, dtype=np.float64)) if truth is not None else None,
+                                        C.c_int(0 if act is None else len(act)), p(act) if act is not None else None,
+                                        C.c_int(len(mrg)), p(mrg) if len(mrg) else None)
         if rc != 0:
             raise RuntimeError("ovph_session_step failed with %d" % rc)
         return dict(counts=counts, x16=x16, posecov=pc.reshape(6, 6), slam_ids=[int(i) for i in ids[:counts[4]]])

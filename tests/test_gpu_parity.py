@@ -1782,7 +1782,29 @@ def test_filter_session_rejects_inconsistent_bookkeeping(hiplib):
         slot[0, 0] = slot0
         with pytest.raises(RuntimeError, match=msg):
             ses.step(frames[C + 1][0], uv, uv * 0, slot, nm, np.array([99999]), np.array([kind], dtype=np.int32))
+        # the rejected call left the filter untouched: the same frame can be stepped again (inputs are validated before the
+        # propagation; a second propagation to the same time would be fatal)
+        out = ses.step(frames[C + 1][0], uv[:0], uv[:0], slot[:0], nm[:0], np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int32))
+        assert np.isfinite(out["x16"]).all()
         ses.close()
+
+
+def test_filter_session_marginalises_planes_nobody_observes(hiplib):
+    """core/VioManager.cpp:513-534 -> StateHelper::merge_planes_and_marginalize every frame: with the tracker's plane list handed
+    over, planes stay in the state while their features are tracked and leave it (three covariance columns each) as soon as
+    the tracker reports them no longer - here from frame 25 on, by the test hook of closed_loop.run_session."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import closed_loop
+    from ov_plane_amd.sim import Simulator, synthetic_trajectory
+
+    sim = Simulator(synthetic_trajectory(duration=20.0), num_pts=60, num_pts_plane=120)
+    r = closed_loop.run_session(sim, n_frames=40, C=8, planes=2, forget_planes_at=25)
+    n_planes = r["counts"][:, 5]
+    assert n_planes[:25].max() >= 1, n_planes
+    assert (n_planes[25:] == 0).all(), n_planes
+    assert np.isfinite(r["traj"]).all() and r["rmse_pos"] < 0.3
 
 
 def test_plane_gate_at_multiplier_one_over_fifty_scenes(hiplib, oracle):
