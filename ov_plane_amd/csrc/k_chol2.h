@@ -15,6 +15,7 @@ struct Chol2Job {
   size_t sel_stride;
   const double* brow;   // optional border row [n]: z = L^-1 brow^T is produced along the way
   int* flag;            // set to 1 on a non-positive pivot
+  const double* floor_scale;  // optional device scalar: the effective floor is piv_floor * (*floor_scale)
   double piv_floor;     // > 0: columns whose pivot falls below it are dropped (rank-deficient semi-definite systems: mode 2), never flagged
   // mode 0 outputs (any may be null)
   double* Lpack;        // tile-packed factor of the n x n part (the layout k_fwdsub reads)
@@ -64,5 +65,6 @@ struct PlaneSolve {
 
 extern "C" {
 int ovp_chol2_max_n(void);
+hipError_t ovp_launch_max_diag(const double* A, int n, int ld, double* out, hipStream_t stream);
 hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream);
 }

@@ -283,6 +283,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   if (wave < C2_EW) {
     // =============================== elimination waves ===============================
     const int ew = wave, g = lr, r = lc;
+    const double floor_eff = J.floor_scale ? J.piv_floor * (*J.floor_scale) : J.piv_floor;
     __builtin_amdgcn_s_setprio(3);  // the serial chain: its instructions go first, the tile waves fill the gaps
     for (int k = 0; k < nt; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
               p[2 * q + 1] = has_p ? pq[1] : 0.0;
             }
           }
-          if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, J.piv_floor) || bad;
+          if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, floor_eff) || bad;
           if (ew == 0) C2_STAMP(k, 2);
           if (has_p) {
             dbl2_t* pw = reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS);
@@ -731,9 +732,28 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
     for (int k = 0; k < 3; ++k) ps.slam_p[3 * q + k] += dxs[ps.slam_id[q] + k];
 }
 
+// out[0] = max_i A_ii (one workgroup): the scale the drop threshold of a semi-definite factorization refers to
+__global__ __launch_bounds__(256) void k_max_diag(const double* __restrict__ A, int n, int ld, double* __restrict__ out) {
+  __shared__ double red[256];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, A[(size_t)i * ld + i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
 }  // namespace ovp
 
 extern "C" {
+
+hipError_t ovp_launch_max_diag(const double* A, int n, int ld, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_max_diag, dim3(1), dim3(256), 0, stream, A, n, ld, out);
+  return hipGetLastError();
+}
 
 int ovp_chol2_max_n(void) { return 16 * 18 - 1; }  // bordered dimension n + 1 <= 272 (17 tile rows, 20 tile slots per wave)
 

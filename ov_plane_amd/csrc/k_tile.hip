@@ -131,9 +131,10 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm4(int M, int N, int K, const double* __restrict__ A, int lda,
                                                const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
-                                               int add_identity, int symmetric) {
+                                               int add_identity, int symmetric, const int* __restrict__ cancel) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (symmetric && bj > bi) return;
+  if (cancel && *cancel) return;  // a factorization upstream failed: the destination (the resident covariance) stays as it was
   const int i0 = bi * 16, j0 = bj * 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
@@ -249,21 +250,28 @@ hipError_t ovp_launch_fwdsub(const double* Ltp, const double* Dinv, const double
   return hipGetLastError();
 }
 
+hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                             double* C, int ldc, int add_identity, int symmetric, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
                             int ldb, double* C, int ldc, int add_identity, int symmetric, hipStream_t stream) {
+  return ovp_launch_gemm4c(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, add_identity, symmetric, nullptr, stream);
+}
+// cancel: device flag; a non-zero value turns the product into a no-op (used for the write of the updated covariance)
+hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                             double* C, int ldc, int add_identity, int symmetric, const int* cancel, hipStream_t stream) {
   dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);
   if (!transA && !transB)
     hipLaunchKernelGGL((ovp::k_gemm4<false, false>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
-                       add_identity, symmetric);
+                       add_identity, symmetric, cancel);
   else if (transA && !transB)
     hipLaunchKernelGGL((ovp::k_gemm4<true, false>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
-                       add_identity, symmetric);
+                       add_identity, symmetric, cancel);
   else if (!transA && transB)
     hipLaunchKernelGGL((ovp::k_gemm4<false, true>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
-                       add_identity, symmetric);
+                       add_identity, symmetric, cancel);
   else
     hipLaunchKernelGGL((ovp::k_gemm4<true, true>), grid, block, 0, stream, M, N, K, A, lda, B, ldb, C, ldc,
-                       add_identity, symmetric);
+                       add_identity, symmetric, cancel);
   return hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ hipError_t ovp_launch_range_energy(const double* Lr, const double* Dinv, const d
                                    double* scal, hipStream_t stream);
 hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const double* b, double* dx, double* scal,
                                      hipStream_t stream);
+hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                             double* C, int ldc, int add_identity, int symmetric, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
                                  int n_involved, int force, double* res_out, hipStream_t stream);
 hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
@@ -706,7 +708,8 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     HIPCHK(ovp_launch_tilechol(c->T, nullptr /* dense Lt is not needed */, c->Dinv, c->Ltp, n, ld, c->flags, 0, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
-    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->stream));
+    // (skipped on the device when a factorization failed: the resident covariance then stays what it was, OVP_E_NOTSPD)
+    HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, c->stream));
     if (publish) {
       // the last block of the dx kernel also publishes [flags | dx] to the pinned host block (no separate launch)
       const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
@@ -739,6 +742,44 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
   HIPCHK(ovp_launch_chol(c->T, c->Lt, n, ld, c->flags, 0, c->stream));
   HIPCHK(ovp_launch_trsm_right_lt(c->L, c->Lt, c->Y, n, ld, c->stream));
   HIPCHK(ovp_launch_cov_finish(c->Y, n, ld, b, c->P, ld, c->dx, c->flags + 1, c->stream));
+  return 0;
+}
+
+// Update of a covariance that is positive SEMI-definite (an exact stochastic clone before the next propagation, a zero-variance
+// prior): P has no Cholesky factor, but the reference's own form needs none (state/StateHelper.cpp:159-187):
+//   P+ = P - P H^T (H P H^T + I)^-1 H P,   with H := La^T, La La^T = A the (pivot-dropping) Cholesky factor of the information
+// matrix of the batch - H^T H = A and H^T r = b is all the update depends on.  S = I + La^T P La is positive definite whatever P is.
+// Runs after a failed chol(P) (flags[0]): the pair [A | b] is still in c->Ab, P was not touched (ovp_launch_gemm4c cancel flag).
+static int ekf_sform(ovp_ctx* c) {
+  const int n = c->n, ld = c->ld;
+  if (n > OVP_TILECHOL_NMAX || n > ovp_chol2_max_n()) return OVP_E_NOTSPD;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  HIPCHK(hipMemsetAsync(c->W1, 0, sizeof(double) * (size_t)n * ld, s));
+  HIPCHK(ovp_launch_max_diag(c->Ab, n, ld, c->smallbuf, s));
+  ovp::Chol2Job j;
+  memset(&j, 0, sizeof(j));
+  j.A = c->Ab;
+  j.n = n;
+  j.ld = ld;
+  j.mode = 0;
+  j.flag = c->flags + 3;
+  j.piv_floor = 1e-13;  // directions that carry less than 1e-13 of the largest diagonal entry count as unobserved
+  j.floor_scale = c->smallbuf;
+  j.Ldense = c->W1;     // La (lower triangular, zero columns where a pivot was dropped)
+  j.ldo = ld;
+  HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, s));
+  HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->P, ld, c->W1, ld, c->Y, ld, 0, 0, s));   // Wm = P La
+  HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->W1, ld, c->Y, ld, c->T, ld, 1, 1, s));   // S = I + La^T Wm
+  HIPCHK(ovp_launch_tilechol(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 0, s));
+  HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->Y, c->L, n, ld, 1, s));               // V = Ls^-1 Wm^T
+  HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->L, ld, c->T, ld, 0, 1, s));    // V^T V
+  HIPCHK(ovp_launch_sub_sym(c->P, c->T, n, ld, s));
+  HIPCHK(ovp_launch_dx_rows(c->P, n, ld, c->Ab + (size_t)n * ld, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, s));
+  HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
   return 0;
 }
 
@@ -931,6 +972,11 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
       }
       __builtin_ia32_pause();
     }
+  }
+  if (c->h_flags[0]) {
+    // chol(P) failed: the prior is only positive semi-definite.  Same update in the reference's S-form (no factor of P needed).
+    int rs = ekf_sform(c);
+    if (rs) return rs;
   }
   if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
   if (accepted_host && F) memcpy(accepted_host, c->h_accept, (size_t)F);
@@ -1541,7 +1587,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
     HIPCHK(ovp_launch_tilechol(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 1, s));
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
-    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, s));
+    HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
   }
   // ---- results: one pinned block, one synchronisation ----
   double* hres = (double*)c->pl_hres;
@@ -1708,6 +1754,10 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
   HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->h_flags[0]) {  // positive semi-definite prior: S-form instead of the factor of P
+    int rs = ekf_sform(c);
+    if (rs) return rs;
+  }
   if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
   if (info) {
     memset(info, 0, sizeof(*info));

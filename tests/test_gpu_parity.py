@@ -236,6 +236,38 @@ def test_config4_on_one_gpu_plane_loop_and_point_update(hiplib, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["exact_clone", "zero_variance"])
+def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case):
+    """state/StateHelper.cpp:159-187 never factors P, so the reference updates a covariance that is only positive SEMI-definite:
+    right after StateHelper::clone the new pose is an exact copy of the IMU pose (:346-396), and a variable may carry a
+    zero-variance prior.  The device's fast path factors P; when that fails it falls back to the S-form on the Cholesky factor of the
+    batch's information matrix (ekf_sform) instead of returning OVP_E_NOTSPD.  Both priors below are exactly singular."""
+    sc = make_scene(C=9, F=80, seed=41, chi2_mult=1.0)
+    P = sc.P.copy()
+    if case == "exact_clone":
+        a, b = sc.ids["clones"][-2], sc.ids["clones"][-1]  # the newest clone becomes an exact copy of the one before it
+        idx = np.arange(sc.N)
+        idx[b:b + 6] = np.arange(a, a + 6)
+        P = P[np.ix_(idx, idx)]
+        sc["clone_q"][-1], sc["clone_p"][-1] = sc["clone_q"][-2], sc["clone_p"][-2]
+        sc["clone_q_fej"][-1], sc["clone_p_fej"][-1] = sc["clone_q_fej"][-2], sc["clone_p_fej"][-2]
+    else:
+        k = sc.ids["intr"] + 4  # first distortion coefficient known exactly
+        P[k, :] = 0.0
+        P[:, k] = 0.0
+    assert np.linalg.eigvalsh(P).min() < 1e-12 * np.linalg.eigvalsh(P).max()
+    sc["P"] = P
+    ref = oracle.msckf_point_update(sc)
+    out = run_gpu(hiplib, sc)
+    assert out["rc"] == 0
+    assert (out["accepted"] == ref["accepted"]).all()
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+    d = np.sqrt(np.abs(np.diag(ref["P"])))
+    d[d == 0] = 1.0
+    assert (np.abs(out["P"] - ref["P"]) / np.outer(d, d)).max() < TOL_P
+    out["ctx"].close()
+
+
 def test_dense_ekf_update_matches_reference_form(hiplib):
     """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H."""
     from oracle import np_ref
