@@ -56,6 +56,22 @@ def chol2_flops(n: int, n_inv: int) -> float:
     return (n + 1) ** 3 / 3.0 + (n_inv + 1) ** 3 / 3.0
 
 
+def pmc_traffic(kernel_substr, name, world):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this process;
+    quoted only for the workload the passes were taken on): 2 x FETCH_SIZE + WRITE_SIZE - the guide's gfx950 correction (wide
+    coalesced reads are tallied at half their bytes) applied as the upper bound, WRITE_SIZE as reported."""
+    tp = os.path.join(_ROOT, "profiles", "r02_f_hbm_traffic_pmc.json")
+    if not os.path.exists(tp) or name != "config3" or world != 1:
+        return None, None
+    with open(tp) as fh:
+        kern = json.load(fh)["kernels"]
+    hit = [v for k, v in kern.items() if kernel_substr in k]
+    if not hit or "FETCH_SIZE_KB_avg_per_launch" not in hit[0]:
+        return None, None
+    b = (2.0 * hit[0]["FETCH_SIZE_KB_avg_per_launch"] + hit[0].get("WRITE_SIZE_KB_avg_per_launch", 0.0)) * 1024.0
+    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r02_f_hbm_traffic_pmc.json (separate rocprofv3 --pmc passes over the same step)"
+
+
 def make_workload(name, seed=0, feat_seed=None, chi2_mult=1.0):
     from ov_plane_amd.synth import make_scene
 
@@ -277,7 +293,8 @@ def main():
                           "side by side on two CUs, gate, back substitution, dx, commit) - a latency-bound serial chain, the "
                           "plane loop is %d of these in sequence" % int(sc.cp.shape[0]),
                 "achieved": fl / ks / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / ks / 1e12 / F64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_chol2", name, world)[0], "traffic_note": pmc_traffic("k_chol2", name, world)[1],
+                "algorithmic_bytes_per_launch": 8.0 * ((sc.N + 1) ** 2 / 2 + (n_inv_avg + 1) ** 2 / 2 + sc.N ** 2 / 2),
                 "avg_launch_ms": c2_ms, "launches_timed": c2_n, "algorithmic_flops_per_launch": fl,
                 "share_of_step": c2_ms * int(sc.cp.shape[0]) / ms_per_step,
                 "note": "f64 MFMA + DPP-broadcast FMA chains on 2 of 256 CUs: the fraction of the chip's peak is by construction "
@@ -295,7 +312,8 @@ def main():
                 "kernel": "k_feat_chol (per-feature build + nullspace projection + chi2 gate of the point update; chol(P) rides "
                           "on one CU of the same launch)",
                 "achieved": exe / ks / 1e12, "peak": F64_PEAK_TFLOPS, "peak_measured": 59.5, "unit": "TFLOP/s",
-                "frac": exe / ks / 1e12 / F64_PEAK_TFLOPS, "avg_launch_ms": k1_ms, "launches_timed": k1_n,
+                "frac": exe / ks / 1e12 / F64_PEAK_TFLOPS, "traffic": pmc_traffic("k_feat_chol", name, world)[0],
+                "avg_launch_ms": k1_ms, "launches_timed": k1_n,
                 "features_gated_per_launch": n_pts_done, "features_walked_per_launch": per_launch,
                 "executed_flops_per_launch": exe, "reference_algorithm_flops_per_launch": alg,
                 "reference_algorithm_rate": alg / ks / 1e12,
