@@ -25,42 +25,73 @@ __device__ __forceinline__ int gram_index3(int p, int q) { return p * OVP_REC - 
 // the normalised, regularised Gram of the involved columns in the order `perm` (for the range part / rank), and the total
 // projected residual energy.  One workgroup per row of Ab (row n = b).
 // ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
+static constexpr int PA_THREADS = 320;  // one thread per state column (n <= 288) - no column loop, every load of a thread is issued once
+
+__global__ __launch_bounds__(PA_THREADS) void k_plane_assemble2(const PlaneAsm a) {
   const int r = blockIdx.x;  // 0..n
   const int t = threadIdx.x;
   const int n = a.n;
+  const int c = t;           // this thread's column
   __shared__ double cst[10];
   __shared__ double red[256];
   __shared__ double sh_h[PA_MAXQ][7];
   __shared__ int sh_col[PA_MAXQ][7];
   __shared__ int sh_nq;
-  __shared__ double Ai[9], bc[3], xr[3], dr_sh, slam_rr;
-  __shared__ ColMap cm_sh[OVP_TC_MAX_TILES * 16];  // the column classification of the whole state (the entries below chase it)
-  __shared__ double gsum[OVP_GRAM_ELEMS];           // Gram of the sparse rows summed over the clones
-  for (int i = t; i < n; i += 256) cm_sh[i] = a.colmap[i];
+  __shared__ double Ai[9], bc[3], xr[3], dr_sh, slam_rr, ecc[6], err_sh;
+  __shared__ ColMap cm_sh[OVP_TC_MAX_TILES * 16];
+  __shared__ double gsum[OVP_GRAM_ELEMS];  // Gram of the sparse rows summed over the clones
+
+  // The kernel is a chain of memory round trips, not of arithmetic, so it is laid out by what depends on what:
+  //   round 1 (addresses known up front): G^T G partials of every entry this thread needs, column classification, moments
+  //   round 2 (needs the classification): the per-clone Gram entries
+  //   then LDS-only steps: 3x3 inverse of the plane block, this row's diagonal, the Schur complement, normalisation.
+  // Entries of the extended pair a thread needs: E(r,c), E(p0..2,c), E(c,c) and one of the 13 block-shared ones.
+  auto part_term = [&](int row, int col) {
+    const int I = max(row, col), J = min(row, col);
+    const int ti = I >> 4, tj = J >> 4;
+    const int tile = ti * (ti + 1) / 2 + tj;
+    const int e = (I & 15) * 16 + (J & 15);
+    double d = 0.0;
+    for (int sp = 0; sp < a.n_split; ++sp) d += a.part[((size_t)sp * a.ntile + tile) * 256 + e];
+    return d;
+  };
+  // the block-shared entry of this thread (if any): (row, col) in the extended index space
+  int sh_row = -1, sh_col_ = -1, sh_kind = -1;
+  if (!a.in_state) {
+    if (t < 6) {
+      const int i = t < 3 ? 0 : (t < 5 ? 1 : 2), j = t < 3 ? t : (t < 5 ? t - 2 : 2);
+      sh_row = n + 1 + i, sh_col_ = n + 1 + j, sh_kind = 0;
+    } else if (t >= 64 && t < 67) {
+      sh_row = n, sh_col_ = n + 1 + (t - 64), sh_kind = 1;
+    } else if (t >= 128 && t < 131) {
+      sh_row = r, sh_col_ = n + 1 + (t - 128), sh_kind = 2;
+    }
+  }
+  if (t == 192 && r < n) sh_row = r, sh_col_ = r, sh_kind = 3;
+  const bool colv = c < n;
+  const int cq = colv ? c : 0;
+  // ---- round 1 ----
+  const double d_rc = part_term(r, cq), d_cc = part_term(cq, cq);
+  double d_pc[3] = {0.0, 0.0, 0.0};
+  if (!a.in_state)
+    for (int k = 0; k < 3; ++k) d_pc[k] = part_term(n + 1 + k, cq);
+  const double d_sh = sh_kind >= 0 ? part_term(sh_row, sh_col_) : 0.0;
+  for (int i = t; i < n; i += PA_THREADS) cm_sh[i] = a.colmap[i];
   if (t < OVP_GRAM_ELEMS) {
     double g = 0.0;
     for (int sl = 0; sl < a.n_clones; ++sl)
       for (int ch = 0; ch < a.n_chunks; ++ch) g += a.gramS[((size_t)sl * a.n_chunks + ch) * OVP_GRAM_ELEMS + t];
     gsum[t] = g;
   }
-
-  // ---- constraint-row moments summed over the plane's features (fixed order) ----
   {
     const int e = t % 10, part = t / 10;
-    double s = 0.0;
+    double sacc = 0.0;
     if (t < 250)
-      for (int f = part; f < a.nf; f += 25) s += a.cst[(size_t)f * 10 + e];
-    red[t] = (t < 250) ? s : 0.0;
-    __syncthreads();
-    if (t < 10) {
-      double acc = 0.0;
-      for (int l = 0; l < 25; ++l) acc += red[l * 10 + t];
-      cst[t] = acc;
-    }
+      for (int f = part; f < a.nf; f += 25) sacc += a.cst[(size_t)f * 10 + e];
+    if (t < 256) red[t] = (t < 250) ? sacc : 0.0;
   }
-  // ---- SLAM landmarks lying on this (out-of-state) plane: one point-on-plane row each (UpdaterMSCKF.cpp:545-552) ----
-  if (t == 0) {
+  // SLAM landmarks lying on this (out-of-state) plane: one point-on-plane row each (UpdaterMSCKF.cpp:545-552)
+  if (t == 255) {
     int nq = 0;
     double rr = 0.0;
     if (!a.in_state)
@@ -93,7 +124,11 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
     slam_rr = rr;
   }
   __syncthreads();
-
+  if (t < 10) {
+    double acc = 0.0;
+    for (int l = 0; l < 25; ++l) acc += red[l * 10 + t];
+    cst[t] = acc;
+  }
   auto classify = [&](int col) {
     ColMap m;
     m.kind = 0;
@@ -112,13 +147,27 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
     }
     return m;
   };
-  // entry (row, col) of the extended pair.  Branch-free on purpose: every call issues the same loads (from a dummy address when
-  // a term does not apply) and selects afterwards, so the loads of the several entries a thread needs are all in flight
-  // together instead of one memory round trip per entry.
-  auto entry = [&](int row, int col) {
+  // ---- round 2: the per-clone Gram entry of every needed (row, col); plane / clone-sum cases load a dummy element ----
+  auto gram_load = [&](int row, int col) {
+    const ColMap mr = classify(row), mc = classify(col);
+    const int gr = mr.kind == 1 ? mr.off : (mr.kind == 2 ? 6 + mr.idx : 20);
+    const int gc = mc.kind == 1 ? mc.off : (mc.kind == 2 ? 6 + mc.idx : 20);
+    const int gi = gram_index3(min(gr, gc), max(gr, gc));
+    const int slot = mr.kind == 1 ? mr.idx : (mc.kind == 1 ? mc.idx : 0);
+    double g1 = 0.0;
+    for (int ch = 0; ch < a.n_chunks; ++ch) g1 += a.gramS[((size_t)slot * a.n_chunks + ch) * OVP_GRAM_ELEMS + gi];
+    return g1;
+  };
+  const double g_rc = gram_load(r, cq), g_cc = gram_load(cq, cq);
+  double g_pc[3] = {0.0, 0.0, 0.0};
+  if (!a.in_state)
+    for (int k = 0; k < 3; ++k) g_pc[k] = gram_load(n + 1 + k, cq);
+  const double g_sh = sh_kind >= 0 ? gram_load(sh_row, sh_col_) : 0.0;
+  __syncthreads();  // cst, gsum, SLAM rows
+  // ---- LDS-only from here: combine the terms of an entry ----
+  auto finish = [&](int row, int col, double g1, double d) {
     const ColMap mr = classify(row), mc = classify(col);
     const bool pl = (mr.kind == 4 || mc.kind == 4);
-    // plane columns: structured part from the constraint-row moments
     double s_pl = 0.0;
     {
       const int i = min(mr.idx, mc.idx), j = max(mr.idx, mc.idx);
@@ -127,27 +176,13 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
       if (mr.kind == 4 && mc.kind == 4) s_pl = hh;
       else if (mr.kind == 3 || mc.kind == 3) s_pl = hr;
     }
-    // sparse rows: one clone's Gram, or the sum over the clones (calibration x calibration / residual)
     const int gr = mr.kind == 1 ? mr.off : (mr.kind == 2 ? 6 + mr.idx : 20);
     const int gc = mc.kind == 1 ? mc.off : (mc.kind == 2 ? 6 + mc.idx : 20);
     const int gi = gram_index3(min(gr, gc), max(gr, gc));
     const bool any1 = (mr.kind == 1 || mc.kind == 1);
     const bool both1_diff = (mr.kind == 1 && mc.kind == 1 && mr.idx != mc.idx);
-    const int slot = mr.kind == 1 ? mr.idx : (mc.kind == 1 ? mc.idx : 0);
-    double g1 = 0.0;
-    for (int ch = 0; ch < a.n_chunks; ++ch) g1 += a.gramS[((size_t)slot * a.n_chunks + ch) * OVP_GRAM_ELEMS + gi];
-    const double gall = gsum[gi];
     double s_g = 0.0;
-    if (!pl && mr.kind != 0 && mc.kind != 0) s_g = any1 ? (both1_diff ? 0.0 : g1) : gall;
-    // dense downdate G^T G
-    double d = 0.0;
-    {
-      const int I = max(row, col), J = min(row, col);
-      const int ti = I >> 4, tj = J >> 4;
-      const int tile = ti * (ti + 1) / 2 + tj;
-      const int e = (I & 15) * 16 + (J & 15);
-      for (int sp = 0; sp < a.n_split; ++sp) d += a.part[((size_t)sp * a.ntile + tile) * 256 + e];
-    }
+    if (!pl && mr.kind != 0 && mc.kind != 0) s_g = any1 ? (both1_diff ? 0.0 : g1) : gsum[gi];
     double s = (pl ? s_pl : s_g) - d;
     for (int q = 0; q < sh_nq; ++q) {
       double hr = 0.0, hc = 0.0;
@@ -160,23 +195,16 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
     }
     return s;
   };
-
-  // ---- block-shared quantities: E_cc (out-of-state plane), b_c, this row's plane entries, the row's diagonal entry.  Every
-  // entry is a chain of dependent loads, so they are spread over twelve threads instead of being walked by one ----
-  __shared__ double ecc[6], err_sh;
-  if (!a.in_state) {
-    if (t < 6) {
-      const int i = t < 3 ? 0 : (t < 5 ? 1 : 2), j = t < 3 ? t : (t < 5 ? t - 2 : 2);
-      ecc[t] = entry(n + 1 + i, n + 1 + j);
-    } else if (t >= 64 && t < 67) {
-      bc[t - 64] = entry(n, n + 1 + (t - 64));
-    } else if (t >= 128 && t < 131) {
-      xr[t - 128] = entry(r, n + 1 + (t - 128));
-    }
-  } else if (t < 3) {
+  if (sh_kind >= 0) {
+    const double v = finish(sh_row, sh_col_, g_sh, d_sh);
+    if (sh_kind == 0) ecc[t] = v;
+    else if (sh_kind == 1) bc[t - 64] = v;
+    else if (sh_kind == 2) xr[t - 128] = v;
+    else err_sh = v;
+  } else if (a.in_state && t < 3) {
     bc[t] = xr[t] = 0.0;
   }
-  if (t == 192) err_sh = r < n ? entry(r, r) : 0.0;
+  if (t == 192 && r >= n) err_sh = 0.0;
   __syncthreads();
   if (t == 0) {
     if (!a.in_state) {
@@ -210,28 +238,24 @@ __global__ __launch_bounds__(256) void k_plane_assemble2(const PlaneAsm a) {
     a.scal[0] = cst[9] + slam_rr - (a.in_state ? 0.0 : schur(bcc, bcc));
   }
   __syncthreads();
+  if (!colv) return;
   const double dr = dr_sh;
   const int pr = r < n ? a.perm[r] : -1;
-  for (int c = t; c < n; c += 256) {
-    double xc[3] = {0.0, 0.0, 0.0};
-    if (!a.in_state) {
-      xc[0] = entry(n + 1, c);
-      xc[1] = entry(n + 2, c);
-      xc[2] = entry(n + 3, c);
-    }
-    const double v = entry(r, c) - (a.in_state ? 0.0 : schur(xrr, xc));
-    a.Ab[(size_t)r * a.lda + c] = v;
-    const int pc = a.perm[c];
-    if (pc >= 0 && (pr >= 0 || r == n)) {
-      const double dc = (r == c) ? dr : entry(c, c) - (a.in_state ? 0.0 : schur(xc, xc));
-      if (r == n) {
-        a.bn[pc] = dc > 0.0 ? v / sqrt(dc) : 0.0;
-      } else {
-        double w;
-        if (dr > 0.0 && dc > 0.0) w = (r == c) ? 1.0 + a.eps : v / sqrt(dr * dc);
-        else w = (r == c) ? 1.0 : 0.0;
-        a.An[(size_t)pr * a.ldn + pc] = w;
-      }
+  double xc[3] = {0.0, 0.0, 0.0};
+  if (!a.in_state)
+    for (int k = 0; k < 3; ++k) xc[k] = finish(n + 1 + k, c, g_pc[k], d_pc[k]);
+  const double v = finish(r, c, g_rc, d_rc) - (a.in_state ? 0.0 : schur(xrr, xc));
+  a.Ab[(size_t)r * a.lda + c] = v;
+  const int pc = a.perm[c];
+  if (pc >= 0 && (pr >= 0 || r == n)) {
+    const double dc = (r == c) ? dr : finish(c, c, g_cc, d_cc) - (a.in_state ? 0.0 : schur(xc, xc));
+    if (r == n) {
+      a.bn[pc] = dc > 0.0 ? v / sqrt(dc) : 0.0;
+    } else {
+      double w;
+      if (dr > 0.0 && dc > 0.0) w = (r == c) ? 1.0 + a.eps : v / sqrt(dr * dc);
+      else w = (r == c) ? 1.0 : 0.0;
+      a.An[(size_t)pr * a.ldn + pc] = w;
     }
   }
 }
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(256) void k_select_copy(double* __restrict__ dst, c
 
 extern "C" {
 hipError_t ovp_launch_plane_assemble2(const ovp::PlaneAsm* a, hipStream_t stream) {
-  hipLaunchKernelGGL(ovp::k_plane_assemble2, dim3(a->n + 1), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL(ovp::k_plane_assemble2, dim3(a->n + 1), dim3(ovp::PA_THREADS), 0, stream, *a);
   return hipGetLastError();
 }
 hipError_t ovp_launch_plane_dT(int n, const double* L0, int ld, const double* W, const double* b, double* Tbuf, size_t tstride,
