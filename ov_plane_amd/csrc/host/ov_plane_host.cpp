@@ -940,6 +940,9 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
         auto it = feat2plane.find(feature_vec[f]->featid);
         if (it == feat2plane.end()) continue;
         if (fitted_planes.count(it->second) && !plane_feat_kept.count(feature_vec[f]->featid)) continue;  // not an inlier of the fit
+        // the plane kernels take a feature's 2 m + 1 rows in one wavefront: a track with more than 31 observations keeps its
+        // bearing measurements but not the plane constraint (it goes through the point loop below)
+        if (feature_vec[f]->timestamps.size() > 31) continue;
         auto pos = std::find(used_planes.begin(), used_planes.end(), it->second);
         if (pos != used_planes.end()) pof[f] = 1 + (int)(pos - used_planes.begin());
       }
@@ -973,8 +976,18 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       pb.slam_p = s_p.data();
       pb.slam_p_fej = s_pf.data();
       std::vector<int> pdof(NP, 0);
-      gpu_check(ovp_msckf_plane_update(state->_gpu, &o, &pb, dxp.data(), pok.data(), nullptr, pdof.data(), fused.data()),
-                "ovp_msckf_plane_update");
+      {
+        const int rcp = ovp_msckf_plane_update(state->_gpu, &o, &pb, dxp.data(), pok.data(), nullptr, pdof.data(), fused.data());
+        if (rcp == OVP_E_CAPACITY) {
+          // state above the plane loop's limit (288 columns): the regularities are not used in this update, every feature takes
+          // the point loop - the filter degrades to plain MSCKF instead of stopping
+          PRINT_ERROR("UpdaterMSCKF::update() - state too large for the plane constraints (%d columns), skipped\n", n);
+          std::fill(pok.begin(), pok.end(), 0);
+          std::fill(fused.begin(), fused.end(), 0);
+        } else {
+          gpu_check(rcp, "ovp_msckf_plane_update");
+        }
+      }
       for (int k = 0; k < NP; ++k)
         if (pok[k]) StateHelper::apply_correction(state, &dxp[(size_t)k * n]);  // :648 per accepted plane, in order
       for (size_t q = 0; q < s_id.size(); ++q) {  // :626-639
