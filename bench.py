@@ -355,6 +355,47 @@ def extras(line, capi, torch, args, device, headline):
         except Exception as e:  # noqa: BLE001  (the headline must not depend on an extra)
             line[key] = None
             print("%s skipped: %r" % (key, e), file=sys.stderr)
+    # small-batch latency at the sizes of the real-data configuration (11 + 1 clones, <= 20 features, gate at multiplier 1): the
+    # frames of tests/golden/trace_euroc_like.ovptrc (recorded closed loop, stand-in for BASELINE config 5) through the C-ABI -
+    # upload of state / covariance / batch, update, results - next to the oracle on the same frames
+    try:
+        from ov_plane_amd import trace
+
+        frames = trace.read_frames(os.path.join(_ROOT, "tests", "golden", "trace_euroc_like.ovptrc"))
+        scs = [trace.scene_from_frame(f) for f in frames]
+        ctx = capi.Context(max(s_.N for s_ in scs), max(s_.C for s_ in scs), 32, device=device)
+
+        def one(s_):
+            ctx.cov_upload(s_.P)
+            ctx.state_upload(s_)
+            ctx.batch_upload_scene(s_)
+            return ctx.msckf_update(capi.opts_from_scene(s_))
+
+        for s_ in scs:
+            one(s_)
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            for s_ in scs:
+                one(s_)
+        dev_us = 1e6 * (time.perf_counter() - t0) / (reps * len(scs))
+        ctx.close()
+        from oracle import pyoracle
+
+        pyoracle.build()
+        t0 = time.perf_counter()
+        for s_ in scs:
+            pyoracle.msckf_point_update(s_)
+        cpu_us = 1e6 * (time.perf_counter() - t0) / len(scs)
+        line["euroc_like_frame"] = {
+            "workload": "%d recorded point updates, 12 clones, %d-%d MSCKF features, chi2_multipler 1 (tests/golden/trace_euroc_like.ovptrc)"
+                        % (len(scs), min(s_.F for s_ in scs), max(s_.F for s_ in scs)),
+            "device_us_per_update": dev_us, "oracle_us_per_update_1_core": cpu_us,
+            "note": "host call to completion including the uploads of covariance (N = 102), pose tables and batch; at this size "
+                    "the step is launch and transfer latency, not arithmetic"}
+    except Exception as e:  # noqa: BLE001
+        line["euroc_like_frame"] = None
+        print("euroc-like frame timing skipped: %r" % (e,), file=sys.stderr)
     # second figure of SURVEY 8(d): StateHelper::EKFPropagation of the IMU block (k = 15) on the resident covariance
     try:
         sc = make_workload("config2")
