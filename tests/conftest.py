@@ -22,6 +22,15 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def hiplib():
+    # torch ships its own HIP runtime: when it initialises AFTER libovplane_hip.so has brought up the system one, it no longer
+    # finds a device (seen with `-k` selections that reach the RCCL tests first through this fixture).  Bring torch up first.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from ov_plane_amd.build import build_lib
 
     build_lib()
