@@ -239,7 +239,7 @@ struct ovp_ctx {
   bool kpending = false;
 };
 
-extern "C" const char* ovp_version(void) { return "ovplane_hip 0.1 (gfx950)"; }
+extern "C" const char* ovp_version(void) { return "ovplane_hip 0.2 (gfx950)"; }
 
 extern "C" const char* ovp_error_string(int code) {
   switch (code) {
