@@ -1864,3 +1864,33 @@ def test_plane_gate_at_multiplier_one_over_fifty_scenes(hiplib, oracle):
     assert abs(s["diff_mean"]) < 4.0 and s["diff_std"] < 5.0, s      # observed -2.9 +- 4.1 against a threshold of ~225
     assert s["disagreement_rate"] < 0.05, s            # observed 2.8 %
     assert s["disagreement_margin_max"] < 16.0, s      # every disagreement sits within 4 sigma of the threshold (observed 10.8)
+
+
+@pytest.mark.parametrize("n", [5, 16, 31, 100, 197, 240, 256, 285, 287])
+def test_tile_cholesky_with_border_row_matches_numpy(hiplib, n):
+    """k_chol2 (the factorization every plane of the plane loop runs) on its own, through ovp_debug_chol2: factor of A + I, the
+    border row z = L^-1 b that rides along as one more matrix row, the back substitution y = L^-T z on the register-resident
+    factor, and the pivots - against numpy on a random SPD matrix.  Sizes cover one tile, partial last tiles, a border row that
+    opens a tile row of its own (n a multiple of 16), the 17-panel-tile second elimination pass (n + 1 > 272) and the scratch-
+    backed register configuration (n = 285, the state of BASELINE config 4)."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 5))
+    A = M @ M.T / n + 0.1 * np.eye(n)
+    b = rng.standard_normal(n)
+    ctx = hiplib.Context(288, 30, 8)
+    out = ctx.debug_chol2(A, b, add_identity=True)
+    assert out["rc"] == 0
+    L = np.linalg.cholesky(A + np.eye(n))
+    z = np.linalg.solve(L, b)
+    y = np.linalg.solve(L.T, z)
+    assert np.abs(out["L"][:n, :n] - L).max() < 1e-13
+    assert np.abs(out["L"][n, :n] - z).max() < 1e-12 and np.abs(out["z"] - z).max() < 1e-12
+    assert np.abs(out["y"] - y).max() < 1e-12
+    assert np.abs(out["piv"] - np.diag(L) ** 2).max() < 1e-12
+    # without a border, and a matrix that is not positive definite is reported, not factorized into garbage silently
+    out2 = ctx.debug_chol2(A, None, add_identity=False)
+    assert out2["rc"] == 0 and np.abs(out2["L"] - np.linalg.cholesky(A)).max() < 1e-13
+    Abad = A.copy()
+    Abad[n // 2, n // 2] = -1.0
+    assert ctx.debug_chol2(Abad, None)["rc"] == -3  # OVP_E_NOTSPD
+    ctx.close()
