@@ -635,7 +635,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   // ------------------------------------------------------------------------------------------
   unsigned long long seen = 0ull;
   if (accept) {
-    for (int b = 0; b < m; ++b) seen |= 1ull << cidx[b];
+    seen = wave_or_u64(valid ? (1ull << ci) : 0ull);  // (a rolled loop over cidx[] was m dependent loads)
     if (valid) {
       double* ro = p.rec + (((size_t)ci * p.n_feats + f) * 2 + r) * OVP_REC;
 #pragma unroll

@@ -78,9 +78,19 @@ __global__ __launch_bounds__(PA_THREADS) void k_plane_assemble2(const PlaneAsm a
   const double d_sh = sh_kind >= 0 ? part_term(sh_row, sh_col_) : 0.0;
   for (int i = t; i < n; i += PA_THREADS) cm_sh[i] = a.colmap[i];
   if (t < OVP_GRAM_ELEMS) {
+    // sum over clones x chunks in a fixed order, eight loads in flight at a time (a rolled loop of dependent adds made every
+    // load a round trip of its own: 30 x 0.5 us)
+    const int total = a.n_clones * a.n_chunks;
     double g = 0.0;
-    for (int sl = 0; sl < a.n_clones; ++sl)
-      for (int ch = 0; ch < a.n_chunks; ++ch) g += a.gramS[((size_t)sl * a.n_chunks + ch) * OVP_GRAM_ELEMS + t];
+    int k = 0;
+    for (; k + 8 <= total; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = a.gramS[(size_t)(k + u) * OVP_GRAM_ELEMS + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g += v[u];
+    }
+    for (; k < total; ++k) g += a.gramS[(size_t)k * OVP_GRAM_ELEMS + t];
     gsum[t] = g;
   }
   {

@@ -84,6 +84,18 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// bitwise OR of a 64-bit mask over the wave (every lane gets the result)
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const int src = ((int)(threadIdx.x & 63) ^ s) << 2;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(v & 0xffffffffull));
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(v >> 32));
+    v |= ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
 // index into a packed lower-triangular matrix (row i >= col j)
 __device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1)) / 2 + j; }
 
