@@ -203,6 +203,11 @@ struct ovp_ctx {
   size_t pl_stage_cap = 0;
   void* pl_hres = nullptr;            // pinned host copy of the plane results
   size_t pl_hres_cap = 0;
+  // one device block + one pinned staging block each for the pose tables and for the feature batch (a single copy per upload)
+  void *state_block = nullptr, *h_state_stage = nullptr, *batch_block = nullptr, *h_batch_stage = nullptr;
+  size_t state_bytes = 0, batch_cap = 0;
+  size_t so_R = 0, so_Rf = 0, so_p = 0, so_pf = 0, so_cal = 0, so_id = 0, so_cm = 0;
+  hipEvent_t ev_state = nullptr, ev_batch = nullptr;
   bool pl_ktimer = false;
   std::vector<hipEvent_t> pl_ev;
   double pl_ktime_ms = 0.0;
@@ -309,18 +314,48 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   c->dx = (double*)((char*)c->res_block + 16);
   c->chi2 = c->dx + c->n_max;
   c->accept = (unsigned char*)(c->chi2 + n_feats_max);
-  HIPCHK(dalloc(&c->clone_R, (size_t)9 * n_clones_max));
-  HIPCHK(dalloc(&c->clone_p, (size_t)3 * n_clones_max));
-  HIPCHK(dalloc(&c->clone_R_fej, (size_t)9 * n_clones_max));
-  HIPCHK(dalloc(&c->clone_p_fej, (size_t)3 * n_clones_max));
-  HIPCHK(dalloc(&c->clone_id, (size_t)n_clones_max));
-  HIPCHK(dalloc(&c->cal, (size_t)32));
-  HIPCHK(dalloc(&c->colmap, (size_t)c->n_max));
+  {
+    // pose tables: [R | R_fej | p | p_fej | cal(32) | clone_id | colmap], fixed offsets (capacities), uploaded as one block
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    size_t o = 0;
+    c->so_R = o;
+    o = al(o + sizeof(double) * 9 * n_clones_max);
+    c->so_Rf = o;
+    o = al(o + sizeof(double) * 9 * n_clones_max);
+    c->so_p = o;
+    o = al(o + sizeof(double) * 3 * n_clones_max);
+    c->so_pf = o;
+    o = al(o + sizeof(double) * 3 * n_clones_max);
+    c->so_cal = o;
+    o = al(o + sizeof(double) * 32);
+    c->so_id = o;
+    o = al(o + sizeof(int) * n_clones_max);
+    c->so_cm = o;
+    o = al(o + sizeof(ovp::ColMap) * c->n_max);
+    c->state_bytes = o;
+    HIPCHK(hipMalloc(&c->state_block, o));
+    HIPCHK(hipMemset(c->state_block, 0, o));
+    HIPCHK(hipHostMalloc(&c->h_state_stage, o, hipHostMallocDefault));
+    char* b = (char*)c->state_block;
+    c->clone_R = (double*)(b + c->so_R);
+    c->clone_R_fej = (double*)(b + c->so_Rf);
+    c->clone_p = (double*)(b + c->so_p);
+    c->clone_p_fej = (double*)(b + c->so_pf);
+    c->cal = (double*)(b + c->so_cal);
+    c->clone_id = (int*)(b + c->so_id);
+    c->colmap = (ovp::ColMap*)(b + c->so_cm);
+    HIPCHK(hipEventCreateWithFlags(&c->ev_state, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_batch, hipEventDisableTiming));
+  }
   HIPCHK(dalloc(&c->chi2_table, (size_t)OVP_CHI2_TABLE + 1));
-  HIPCHK(dalloc(&c->uv, (size_t)n_feats_max * OVP_MAX_MEAS * 2));
-  HIPCHK(dalloc(&c->clone_idx, (size_t)n_feats_max * OVP_MAX_MEAS));
-  HIPCHK(dalloc(&c->n_meas, (size_t)n_feats_max));
-  HIPCHK(dalloc(&c->p_FinG, (size_t)n_feats_max * 3));
+  {
+    // feature batch: [p_FinG | n_meas | clone_idx | uv], compact per upload (p_FinG always first: ovp_triangulate writes it)
+    const size_t F = (size_t)n_feats_max, M = OVP_MAX_MEAS;
+    c->batch_cap = sizeof(double) * 3 * F + sizeof(int) * F + sizeof(int) * F * M + sizeof(float) * 2 * F * M + 256;
+    HIPCHK(hipMalloc(&c->batch_block, c->batch_cap));
+    HIPCHK(hipHostMalloc(&c->h_batch_stage, c->batch_cap, hipHostMallocDefault));
+    c->p_FinG = (double*)c->batch_block;
+  }
   HIPCHK(dalloc(&c->G, (size_t)3 * n_feats_max * c->ldg));
   HIPCHK(dalloc(&c->Bscr, (size_t)n_feats_max * OVP_BSCR));
   HIPCHK(dalloc(&c->rec, (size_t)n_clones_max * n_feats_max * 2 * 21));
@@ -370,14 +405,17 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->stream2);
-  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->clone_R, c->clone_p,
-                 c->clone_R_fej, c->clone_p_fej, c->clone_id, c->cal, c->colmap, c->chi2_table, c->uv, c->clone_idx, c->n_meas,
-                 c->p_FinG, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
+  void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->state_block, c->batch_block,
+                 c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
                  c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
+  if (c->h_state_stage) hipHostFree(c->h_state_stage);
+  if (c->h_batch_stage) hipHostFree(c->h_batch_stage);
+  if (c->ev_state) hipEventDestroy(c->ev_state);
+  if (c->ev_batch) hipEventDestroy(c->ev_batch);
   if (c->pl_hstage) hipHostFree(c->pl_hstage);
   if (c->pl_hres) hipHostFree(c->pl_hres);
   hipEventDestroy(c->ev_fork);
@@ -482,39 +520,30 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
   if (!c || !st || !st->clone_q || !st->clone_p || !st->clone_q_fej || !st->clone_p_fej || !st->clone_id) return OVP_E_ARG;
   if (st->n_clones < 1 || st->n_clones > c->c_max || st->n_state > c->n_max) return OVP_E_CAPACITY;
   const int C = st->n_clones;
-  std::vector<double> R(9 * C), Rf(9 * C);
-  for (int i = 0; i < C; ++i) {
-    quat_2_rot(st->clone_q + 4 * i, &R[9 * i]);
-    quat_2_rot(st->clone_q_fej + 4 * i, &Rf[9 * i]);
+  for (int i = 0; i < C; ++i)
     if (st->clone_id[i] < 0 || st->clone_id[i] + 6 > st->n_state) return OVP_E_ARG;
+  // everything goes through ONE pinned block and ONE copy, no synchronisation (seven pageable copies + a sync cost ~50 us,
+  // more than the GPU time of a small update)
+  HIPCHK(hipEventSynchronize(c->ev_state));  // the previous upload has left the staging block (normally long ago)
+  char* h = (char*)c->h_state_stage;
+  double* R = (double*)(h + c->so_R);
+  double* Rf = (double*)(h + c->so_Rf);
+  for (int i = 0; i < C; ++i) {
+    quat_2_rot(st->clone_q + 4 * i, R + 9 * i);
+    quat_2_rot(st->clone_q_fej + 4 * i, Rf + 9 * i);
   }
-  HIPCHK(hipMemcpyAsync(c->clone_R, R.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->clone_R_fej, Rf.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->clone_p, st->clone_p, sizeof(double) * 3 * C, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->clone_p_fej, st->clone_p_fej, sizeof(double) * 3 * C, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->clone_id, st->clone_id, sizeof(int) * C, hipMemcpyHostToDevice, c->stream));
-  ovp::FeatParams& fp = c->fp;
-  fp.clone_R = c->clone_R;
-  fp.clone_p = c->clone_p;
-  fp.clone_R_fej = c->clone_R_fej;
-  fp.clone_p_fej = c->clone_p_fej;
-  fp.clone_id = c->clone_id;
-  fp.n_clones = C;
+  memcpy(h + c->so_p, st->clone_p, sizeof(double) * 3 * C);
+  memcpy(h + c->so_pf, st->clone_p_fej, sizeof(double) * 3 * C);
+  memcpy(h + c->so_id, st->clone_id, sizeof(int) * C);
   {
-    double cal[20];
+    double* cal = (double*)(h + c->so_cal);
     quat_2_rot(st->calib_q, cal);
     memcpy(cal + 9, st->calib_p, sizeof(double) * 3);
     memcpy(cal + 12, st->intrinsics, sizeof(double) * 8);
-    HIPCHK(hipMemcpyAsync(c->cal, cal, sizeof(cal), hipMemcpyHostToDevice, c->stream));
   }
-  fp.cal = c->cal;
-  c->calib_id = st->calib_id;
-  c->intr_id = st->intr_id;
-  c->h_clone_id.assign(st->clone_id, st->clone_id + C);
-  c->fp.fisheye = st->cam_fisheye ? 1 : 0;
   // column map for the assembly kernel (calibration columns are enabled per update via the opts)
-  std::vector<ovp::ColMap> cm(c->n_max);
-  for (auto& m : cm) m.kind = m.idx = m.off = m.pad = 0;
+  ovp::ColMap* cm = (ovp::ColMap*)(h + c->so_cm);
+  memset(cm, 0, sizeof(ovp::ColMap) * c->n_max);
   for (int i = 0; i < C; ++i)
     for (int k = 0; k < 6; ++k) {
       ovp::ColMap& m = cm[st->clone_id[i] + k];
@@ -534,8 +563,20 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
       m.kind = 2;
       m.idx = 6 + k;
     }
-  HIPCHK(hipMemcpyAsync(c->colmap, cm.data(), sizeof(ovp::ColMap) * c->n_max, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(c->state_block, c->h_state_stage, c->state_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->ev_state, c->stream));
+  ovp::FeatParams& fp = c->fp;
+  fp.clone_R = c->clone_R;
+  fp.clone_p = c->clone_p;
+  fp.clone_R_fej = c->clone_R_fej;
+  fp.clone_p_fej = c->clone_p_fej;
+  fp.clone_id = c->clone_id;
+  fp.n_clones = C;
+  fp.cal = c->cal;
+  c->calib_id = st->calib_id;
+  c->intr_id = st->intr_id;
+  c->h_clone_id.assign(st->clone_id, st->clone_id + C);
+  c->fp.fisheye = st->cam_fisheye ? 1 : 0;
   c->have_state = true;
   return 0;
 }
@@ -602,12 +643,26 @@ extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
   if (!c || !b || b->n_feats < 0 || b->max_meas < 1 || b->max_meas > OVP_MAX_MEAS) return OVP_E_ARG;
   if (b->n_feats > c->f_max) return OVP_E_CAPACITY;
   const size_t F = (size_t)b->n_feats, M = (size_t)b->max_meas;
+  // compact layout [p_FinG | n_meas | clone_idx | uv] in one pinned block, one copy, no synchronisation: the caller's arrays
+  // are free again on return because they were copied into the staging block
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t o_p = 0, o_nm = al(o_p + sizeof(double) * 3 * F), o_ci = al(o_nm + sizeof(int) * F),
+               o_uv = al(o_ci + sizeof(int) * F * M), total = al(o_uv + sizeof(float) * 2 * F * M);
+  if (total > c->batch_cap) return OVP_E_CAPACITY;
+  char* d = (char*)c->batch_block;
+  c->p_FinG = (double*)(d + o_p);
+  c->n_meas = (int*)(d + o_nm);
+  c->clone_idx = (int*)(d + o_ci);
+  c->uv = (float*)(d + o_uv);
   if (F) {
-    HIPCHK(hipMemcpyAsync(c->uv, b->uv, sizeof(float) * F * M * 2, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->clone_idx, b->clone_idx, sizeof(int) * F * M, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->n_meas, b->n_meas, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->p_FinG, b->p_FinG, sizeof(double) * F * 3, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_batch));
+    char* h = (char*)c->h_batch_stage;
+    memcpy(h + o_p, b->p_FinG, sizeof(double) * 3 * F);
+    memcpy(h + o_nm, b->n_meas, sizeof(int) * F);
+    memcpy(h + o_ci, b->clone_idx, sizeof(int) * F * M);
+    memcpy(h + o_uv, b->uv, sizeof(float) * 2 * F * M);
+    HIPCHK(hipMemcpyAsync(c->batch_block, c->h_batch_stage, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev_batch, c->stream));
   }
   c->h_n_meas.assign(b->n_meas, b->n_meas + F);
   c->h_nmeas.assign(b->n_meas, b->n_meas + F);
