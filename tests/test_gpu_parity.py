@@ -1894,3 +1894,33 @@ def test_tile_cholesky_with_border_row_matches_numpy(hiplib, n):
     Abad[n // 2, n // 2] = -1.0
     assert ctx.debug_chol2(Abad, None)["rc"] == -3  # OVP_E_NOTSPD
     ctx.close()
+
+
+def test_plane_loop_with_every_plane_rejected_or_absent(hiplib):
+    """Edge cases of the plane loop: (i) every plane fails its chi2 test (multiplier 1e-9) - the state tables, the used mask and
+    the covariance stay what they were (the covariance is re-materialised from its factor: equal to rounding); (ii) the same through
+    force_decision = 0; (iii) a plane batch in which no feature lies on a plane - nothing is enqueued at all."""
+    sc = make_scene(C=9, F=90, seed=17, n_planes=3, feats_per_plane=15, chi2_mult=1e-9)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    o = hiplib.opts_from_scene(sc)
+    d = np.sqrt(np.diag(sc.P))
+    for force in (None, np.zeros(3, dtype=np.uint8)):
+        ctx.cov_upload(sc.P)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)
+        if force is not None:
+            o.chi2_multiplier = 99999.0
+        out = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id, force_decision=force)
+        assert not out["ok"].any() and not out["used"].any() and (out["dof"] > 0).all() and (out["chi2"] > 0).all()
+        assert np.abs(out["dx"]).max() == 0.0
+        assert (np.abs(ctx.cov_download() - sc.P) / np.outer(d, d)).max() < 1e-12
+        # the point update that follows sees every feature (nothing was consumed)
+        o2 = hiplib.opts_from_scene(sc)
+        o2.chi2_multiplier = 1.0
+        o2.skip_plane_used = 1
+        assert ctx.msckf_update(o2)["accepted"].sum() > 0.8 * sc.F
+    ctx.cov_upload(sc.P)
+    ctx.batch_upload_scene(sc)
+    none = ctx.plane_update(o, np.zeros(sc.F, dtype=np.int32), sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert not none["ok"].any() and (none["dof"] == 0).all() and np.array_equal(ctx.cov_download(), sc.P)
+    ctx.close()
