@@ -235,6 +235,18 @@ int ovp_cov_augment_dt(ovp_ctx *ctx, int pose_id, int dt_id, const double dnc_dt
  * new block = H_Linv (H_R P H_R^T + R) H_Linv^T.  The caller applies H_Linv * res to the new variable's value. */
 int ovp_cov_initialize_invertible(ovp_ctx *ctx, const double *H_R_host, int k, int cols, int ld, const int *col_ids,
                                   const double *H_Linv_host, const double *R_host);
+/* StateHelper::initialize downstream of its Givens split (state/StateHelper.cpp:448-487) as ONE device sequence with one
+ * synchronisation: Mahalanobis test of the update rows against the prior (:464-475), StateHelper::initialize_invertible with the
+ * init rows (:489-586) and StateHelper::EKFUpdate with the update rows (:483-485).  The three separate calls (ovp_cov_marginal,
+ * ovp_cov_initialize_invertible, ovp_ekf_update) cost a host round trip each - 0.4 ms per landmark of UpdaterSLAM::delayed_init.
+ *   Hx_init [k x cols], H_up [rup x cols] column-major (leading dimensions k and rup), col_ids[cols]; H_Linv, R_init [k x k];
+ *   res_up [rup]; noise of the update rows = r_iso * I (every caller whitens to an isotropic R); chi2_threshold =
+ *   multiplier * quantile(rows of the FULL residual), as the reference compares.
+ * accepted = 0: the test failed, nothing changed.  accepted = 1: the state has k more columns, dx_host[n + k] is the correction of
+ * the EKF update (zeros when rup == 0 or do_update == 0); the caller applies H_Linv * res_init to the new variable's value. */
+int ovp_cov_initialize(ovp_ctx *ctx, const double *Hx_init, const double *H_up, int k, int rup, int cols, const int *col_ids,
+                       const double *H_Linv, const double *R_init, const double *res_up, double r_iso, double chi2_threshold,
+                       int do_update, int *accepted, double *chi2, double *dx_host);
 /* current covariance dimension */
 int ovp_cov_size(ovp_ctx *ctx);
 

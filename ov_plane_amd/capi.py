@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libovplane_hip.so")
 OVP_MAX_MEAS = 32
+OVP_E_ARG, OVP_E_CAPACITY, OVP_E_NOTSPD, OVP_E_NEGDIAG, OVP_E_NODEVICE, OVP_E_STATE = -1, -2, -3, -4, -5, -6
 
 
 class OvpError(RuntimeError):
@@ -116,7 +117,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream", "ovp_debug_chol2", "ovp_plane_kernel_timer", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
+    "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_plane_kernel_timer", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
 ]
 
 
@@ -163,6 +164,9 @@ def lib():
         L.ovp_cov_clone.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ovp_cov_marginalize.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ovp_cov_size.argtypes = [C.c_void_p]
+        L.ovp_cov_initialize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_double), C.c_void_p]
         L.ovp_last_timings.argtypes = [C.c_void_p, C.c_void_p]
         L.ovp_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.ovp_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -422,6 +426,26 @@ class Context:
         _chk(lib().ovp_ekf_update(self._h, H.ctypes.data, H.shape[0], H.shape[1], H.shape[0], col_ids.ctypes.data,
                                   res.ctypes.data, dx.ctypes.data, C.byref(info)), "ovp_ekf_update")
         return dx, info
+
+    def cov_initialize(self, Hx_init, H_up, col_ids, H_Linv, R_init, res_up, r_iso, chi2_threshold, do_update=True):
+        """StateHelper::initialize downstream of its Givens split as one device sequence (state/StateHelper.cpp:448-487):
+        returns (accepted, chi2, dx); the covariance grows by k = Hx_init.shape[0] columns when accepted."""
+        Hx = np.asfortranarray(Hx_init, dtype=np.float64)
+        k, cols = Hx.shape
+        Hu = np.asfortranarray(H_up, dtype=np.float64).reshape(-1, cols, order="F") if H_up is not None else np.zeros((0, cols))
+        rup = Hu.shape[0]
+        Hi = np.asfortranarray(H_Linv, dtype=np.float64)
+        Ri = np.asfortranarray(R_init, dtype=np.float64)
+        ru = np.ascontiguousarray(res_up if res_up is not None else np.zeros(0), dtype=np.float64)
+        ids = np.ascontiguousarray(col_ids, dtype=np.int32)
+        dx = np.zeros(self.cov_size() + k)
+        acc = C.c_int(0)
+        chi2 = C.c_double(0.0)
+        _chk(lib().ovp_cov_initialize(self._h, Hx.ctypes.data, Hu.ctypes.data if rup else None, k, rup, cols, ids.ctypes.data,
+                                      Hi.ctypes.data, Ri.ctypes.data, ru.ctypes.data if rup else None, float(r_iso),
+                                      float(chi2_threshold), 1 if do_update else 0, C.byref(acc), C.byref(chi2), dx.ctypes.data),
+             "ovp_cov_initialize")
+        return bool(acc.value), chi2.value, dx
 
     def triangulate(self, uv_norm, opts=None):
         """ovp_triangulate on the uploaded batch; returns dict(p_FinG [F,3], ok [F])."""

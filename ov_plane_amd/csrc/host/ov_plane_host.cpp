@@ -481,6 +481,12 @@ static bool small_inverse(const MatrixXd &A, MatrixXd &Ainv) {  // replaces colP
   return true;
 }
 
+// OVP_HOST_INIT_SPLIT=1 keeps the three separate device calls (gate / augmentation / update) for A/B timing and tests
+static bool fused_initialize_enabled() {
+  const char *e = getenv("OVP_HOST_INIT_SPLIT");  // read per call: the tests flip it inside one process
+  return !(e && e[0] == '1');
+}
+
 // ---- state/StateHelper.cpp:398-487 -------------------------------------------------------------
 bool StateHelper::initialize(std::shared_ptr<State> state, std::shared_ptr<Type> new_variable,
                              const std::vector<std::shared_ptr<Type>> &H_order, MatrixXd &H_R, MatrixXd &H_L, MatrixXd &R,
@@ -509,6 +515,45 @@ bool StateHelper::initialize(std::shared_ptr<State> state, std::shared_ptr<Type>
   MatrixXd Hup = H_R.block(new_var_size, 0, rup, cols);
   VectorXd resup = res.block(new_var_size, 0, rup, 1);
   MatrixXd Rup = R.block(new_var_size, new_var_size, rup, rup);
+  // Device path: gate (:464-475), initialize_invertible (:477-480) and the update with the remaining rows (:483-485) as one
+  // enqueue with one synchronisation (ovp_cov_initialize); OVP_E_CAPACITY = outside that entry's limits, nothing was touched.
+  if (fused_initialize_enabled()) {
+    std::vector<int> col_ids;
+    for (const auto &v : H_order)
+      for (int k = 0; k < v->size(); ++k) col_ids.push_back(v->id() + k);
+    MatrixXd H_Linv;
+    if (!small_inverse(H_finit, H_Linv)) {
+      PRINT_ERROR("StateHelper::initialize() - H_L is singular\n");
+      std::exit(EXIT_FAILURE);
+    }
+    const int oldSize = ovp_cov_size(state->_gpu);
+    std::vector<double> dx((size_t)oldSize + new_var_size, 0.0);
+    int accepted = 0;
+    double chi2_dev = 0.0;
+    const double thr = chi_2_mult * ovp_chi2_quantile_095(res.rows());
+    int rc = ovp_cov_initialize(state->_gpu, Hxinit.data(), rup > 0 ? Hup.data() : nullptr, new_var_size, rup, cols, col_ids.data(),
+                                H_Linv.data(), Rinit.data(), rup > 0 ? resup.data() : nullptr, rup > 0 ? Rup(0, 0) : 1.0, thr,
+                                do_update ? 1 : 0, &accepted, &chi2_dev, dx.data());
+    if (rc != OVP_E_CAPACITY) {
+      if (rc == OVP_E_NEGDIAG) {
+        PRINT_ERROR("StateHelper::EKFUpdate() - negative covariance diagonal\n");
+        std::exit(EXIT_FAILURE);
+      }
+      gpu_check(rc, "ovp_cov_initialize");
+      if (!accepted) return false;
+      VectorXd d(new_var_size, 1);  // :577 new_variable->update(H_Linv * res)
+      for (int i = 0; i < new_var_size; ++i) {
+        double sacc = 0.0;
+        for (int a = 0; a < new_var_size; ++a) sacc += H_Linv(i, a) * resinit(a);
+        d(i) = sacc;
+      }
+      new_variable->update(d);
+      new_variable->set_local_id(oldSize);
+      state->_variables.push_back(new_variable);
+      if (rup > 0 && do_update) apply_correction(state, dx.data());
+      return true;
+    }
+  }
   // :464-475 Mahalanobis test of the update part against the prior, dof = res.rows()
   double chi2 = 0.0;
   if (rup > 0) {

@@ -1,6 +1,7 @@
 // Host mirrors of UpdaterHelper (dense Jacobians for the small SLAM systems), UpdaterSLAM and UpdaterPlane.
 // The covariance work goes to the device through StateHelper (EKFUpdate / initialize / get_marginal_covariance) or the
 // batched C-ABI calls; what stays here is what is host scalar code in the reference as well.
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -729,6 +730,22 @@ void UpdaterSLAM::triangulate_on_device(std::shared_ptr<State> state, const ov_c
   }
 }
 
+// OVP_HOST_PROFILE=1: wall-clock split of UpdaterSLAM::delayed_init, printed when the process exits
+namespace {
+struct DelayedInitProfile {
+  double t_tri = 0, t_jac = 0, t_init = 0;
+  long calls = 0, cands = 0, accepted = 0;
+  bool on = getenv("OVP_HOST_PROFILE") != nullptr;
+  ~DelayedInitProfile() {
+    if (on && calls)
+      fprintf(stderr, "[delayed_init] calls %ld candidates %ld accepted %ld | per call: triangulate %.1f us, jacobians %.1f us, initialize %.1f us (%.1f us per candidate)\n",
+              calls, cands, accepted, 1e6 * t_tri / calls, 1e6 * t_jac / calls, 1e6 * t_init / calls, cands ? 1e6 * t_init / cands : 0.0);
+  }
+};
+DelayedInitProfile g_diprof;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                                const std::map<size_t, size_t> &feat2plane) {
   if (feature_vec.empty()) return;
@@ -745,7 +762,10 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   }
   // :120-166 triangulation of the features that come with normalised measurements (the joint point / plane refinement
   // :168-202 is not repeated here: positions handed over, or triangulated, are used as they are)
+  const double t_a = now_s();
   triangulate_on_device(state, _featinit, feature_vec);
+  g_diprof.t_tri += now_s() - t_a;
+  g_diprof.calls++;
   if (feature_vec.empty()) return;
   // a p_FinG that came without its anchor gets what ext single_triangulation would have left behind, with the poses as they
   // are now (the initialisations below move them)
@@ -812,7 +832,10 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
       H_x = H_xf.block(0, 0, H_xf.rows(), H_xf.cols() - 1);
       H_f = H_xf.block(0, H_xf.cols() - 1, H_xf.rows(), 1);
     };
+    const double t_b = now_s();
     jacobian();
+    g_diprof.t_jac += now_s() - t_b;
+    g_diprof.cands++;
     auto landmark = std::make_shared<Landmark>(single ? 1 : 3);  // :285-296
     landmark->_featid = feat.featid;
     landmark->_feat_representation = feat_rep;
@@ -828,7 +851,11 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     }
     MatrixXd R = MatrixXd::Identity(res.rows(), res.rows());
     const double chi2_multipler = _options_slam.chi2_multipler;
-    if (StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler)) {  // :304
+    const double t_c = now_s();
+    const bool init_ok = StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler);  // :304
+    g_diprof.t_init += now_s() - t_c;
+    g_diprof.accepted += init_ok;
+    if (init_ok) {
       state->_features_SLAM.insert({(*it2)->featid, landmark});
       (*it2)->to_delete = true;
       if (feat.planeid != 0) state->_features_SLAM_to_PLANE[(*it2)->featid] = feat.planeid;

@@ -58,6 +58,16 @@ hipError_t ovp_launch_range_energy(const double* Lr, const double* Dinv, const d
                                    double* scal, hipStream_t stream);
 hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const double* b, double* dx, double* scal,
                                      hipStream_t stream);
+hipError_t ovp_launch_init_m(const double* P, int ldp, int n, const int* ids, int cols, const double* Ht, int m, double* Mall,
+                             hipStream_t stream);
+hipError_t ovp_launch_init_core(double* P, int ldp, int n, const int* ids, int cols, const double* Ht, int k, int rup, double* Mall,
+                                const double* Hinv, const double* Rk, const double* resid, double r_iso, double thr, double* Linv,
+                                double* y, double* res, hipStream_t stream);
+hipError_t ovp_launch_init_update(const double* Psrc, double* Pdst, int ldp, int n2, const double* Mall, int m, int k, int rup,
+                                  const double* Linv, const double* y, double* res, double* dx, hipStream_t stream);
+size_t ovp_init_core_lds(int k, int rup, int cols);
+size_t ovp_init_max_lds();
+int ovp_init_max_rows();
 hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                              double* C, int ldc, int add_identity, int symmetric, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
@@ -1775,6 +1785,50 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
   const int n = c->n;
   for (int j = 0; j < cols; ++j)
     if (col_ids[j] < 0 || col_ids[j] >= n) return OVP_E_ARG;
+  // few rows (a frame's landmark re-observations, a zero-velocity update): the reference's own S-form on the kernels of
+  // csrc/k_init.hip - S = H P H^T + I in LDS, P+ = P - W W^T - instead of two N x N factorizations
+  const char* form_env = getenv("OVP_EKF_INFO_FORM");  // read per call: the tests run both forms in one process
+  const bool info_form_only = form_env && form_env[0] == '1';
+  if (!info_form_only && rows <= ovp_init_max_rows() && ovp_init_core_lds(0, rows, cols) <= ovp_init_max_lds() && cols <= c->n_max) {
+    hipStream_t s = c->stream;
+    const size_t oHt = 0, oRes = oHt + (size_t)cols * rows, oId = oRes + rows + 8;
+    const size_t bytes = oId * sizeof(double) + sizeof(int) * (size_t)cols + 64;
+    const size_t res_doubles = 4 + (size_t)c->n_max + 8;
+    int rc = plane2_buffers(c, 0, bytes, res_doubles * sizeof(double));
+    if (rc) return rc;
+    double* h = (double*)c->pl_hstage;
+    double* d = (double*)c->pl_dstage;
+    for (int a = 0; a < cols; ++a) memcpy(h + oHt + (size_t)a * rows, H_host + (size_t)a * ld, sizeof(double) * rows);  // = H^T row-major
+    memcpy(h + oRes, res_host, sizeof(double) * rows);
+    memcpy(h + oId, col_ids, sizeof(int) * cols);
+    const int* did = (const int*)(d + oId);
+    double* dres = c->smallbuf;
+    double* dM = dres + res_doubles;
+    double* dLi = dM + (size_t)n * rows;
+    double* dy = dLi + (size_t)rows * rows;
+    if ((size_t)(dy + rows + 8 - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
+    HIPCHK(hipMemcpyAsync(c->pl_dstage, c->pl_hstage, bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(ovp_launch_init_m(c->P, c->ld, n, did, cols, d + oHt, rows, dM, s));
+    HIPCHK(ovp_launch_init_core(c->P, c->ld, n, did, cols, d + oHt, 0, rows, dM, d + oRes /* unused: k = 0 */, d + oRes, d + oRes, 1.0,
+                                1e300, dLi, dy, dres, s));
+    HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, c->ld, n, dM, rows, 0, rows, dLi, dy, dres, dres + 4, s));
+    double* hres = (double*)c->pl_hres;
+    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * (4 + (size_t)n), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (info) {
+      memset(info, 0, sizeof(*info));
+      info->n_rows = rows;
+      info->n_cols = cols;
+      info->not_spd = hres[1] > 0.5 ? 0 : 1;
+      info->neg_diag = hres[2] != 0.0;
+    }
+    if (!(hres[1] > 0.5)) return OVP_E_NOTSPD;  // S = H P H^T + I lost definiteness: P is not a covariance; nothing was written
+    double* t = c->P;
+    c->P = c->P_tmp;
+    c->P_tmp = t;
+    if (dx_host) memcpy(dx_host, hres + 4, sizeof(double) * n);
+    return hres[2] != 0.0 ? OVP_E_NEGDIAG : 0;
+  }
   const size_t need = (size_t)ld * cols;
   if (need > c->Hd_cap) {
     if (c->Hd) hipFree(c->Hd);
@@ -1922,6 +1976,81 @@ extern "C" int ovp_cov_augment_dt(ovp_ctx* c, int pose_id, int dt_id, const doub
 }
 
 // ---- diagnostics -------------------------------------------------------------------------------
+// ---- StateHelper::initialize as one device sequence (csrc/k_init.hip) ---------------------------------------------------
+extern "C" int ovp_cov_initialize(ovp_ctx* c, const double* Hx_init, const double* H_up, int k, int rup, int cols, const int* col_ids,
+                                  const double* H_Linv, const double* R_init, const double* res_up, double r_iso,
+                                  double chi2_threshold, int do_update, int* accepted, double* chi2, double* dx_host) {
+  if (!c || !Hx_init || !col_ids || !H_Linv || !R_init || k < 1 || k > 6 || cols < 1 || rup < 0) return OVP_E_ARG;
+  if (rup > 0 && (!H_up || !res_up || !(r_iso > 0.0))) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  const int n = c->n, n2 = n + k, ld = c->ld, m = k + rup;
+  if (n2 > c->n_max || cols > c->n_max) return OVP_E_CAPACITY;
+  // S = H P H^T + R and the gathered rows of P H^T live in the LDS of one workgroup: the caller takes the three separate calls
+  // for more rows than that holds (OVP_E_CAPACITY, nothing has been touched)
+  if (rup > ovp_init_max_rows() || ovp_init_core_lds(k, rup, cols) > ovp_init_max_lds()) return OVP_E_CAPACITY;
+  for (int j = 0; j < cols; ++j)
+    if (col_ids[j] < 0 || col_ids[j] >= n) return OVP_E_ARG;
+  hipStream_t s = c->stream;
+  const bool upd = rup > 0 && do_update;
+  // one pinned staging block: [H_all^T cols x m | Hinv 36 | Rk 36 | res rup] ids
+  const size_t oHt = 0, oHi = oHt + (size_t)cols * m, oRk = oHi + 36, oRes = oRk + 36, oId = oRes + rup + 8;
+  const size_t bytes = oId * sizeof(double) + sizeof(int) * (size_t)cols + 64;
+  const size_t res_doubles = 4 + (size_t)c->n_max + 8;
+  int rc = plane2_buffers(c, 0, bytes, res_doubles * sizeof(double));  // the plane loop's pinned staging and result blocks
+  if (rc) return rc;
+  double* h = (double*)c->pl_hstage;
+  double* d = (double*)c->pl_dstage;
+  for (int a = 0; a < cols; ++a) {
+    double* row = h + oHt + (size_t)a * m;
+    for (int i = 0; i < k; ++i) row[i] = Hx_init[(size_t)a * k + i];
+    for (int i = 0; i < rup; ++i) row[k + i] = H_up[(size_t)a * rup + i];
+  }
+  for (int i = 0; i < 36; ++i) h[oHi + i] = h[oRk + i] = 0.0;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      h[oHi + (size_t)i * k + j] = H_Linv[(size_t)j * k + i];
+      h[oRk + (size_t)i * k + j] = R_init[(size_t)j * k + i];
+    }
+  for (int i = 0; i < rup; ++i) h[oRes + i] = res_up[i];
+  memcpy(h + oId, col_ids, sizeof(int) * cols);
+  const int* did = (const int*)(d + oId);
+  // device scratch: result block [chi2 | accept | negdiag | - | dx n2], M_all [n2 x m], Linv [rup x rup], y [rup]
+  double* dres = c->smallbuf;
+  double* dM = dres + res_doubles;
+  double* dLi = dM + (size_t)n2 * m;
+  double* dy = dLi + (size_t)rup * rup;
+  if ((size_t)(dy + rup + 8 - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
+  HIPCHK(hipMemcpyAsync(c->pl_dstage, c->pl_hstage, bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(ovp_launch_init_m(c->P, ld, n, did, cols, d + oHt, m, dM, s));
+  HIPCHK(ovp_launch_init_core(c->P, ld, n, did, cols, d + oHt, k, rup, dM, d + oHi, d + oRk, d + oRes, r_iso > 0.0 ? r_iso : 1.0,
+                              chi2_threshold, dLi, dy, dres, s));
+  double* hres = (double*)c->pl_hres;
+  if (upd) {
+    // P+ = P - W W^T goes to the second covariance buffer (a tile reads entries other tiles overwrite)
+    HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, ld, n2, dM, m, k, rup, dLi, dy, dres, dres + 4, s));
+    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * (4 + (size_t)n2), hipMemcpyDeviceToHost, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  const bool ok = hres[1] > 0.5;
+  if (accepted) *accepted = ok ? 1 : 0;
+  if (chi2) *chi2 = hres[0];
+  if (!ok) return 0;
+  c->n = n2;
+  if (upd) {
+    double* t = c->P;
+    c->P = c->P_tmp;
+    c->P_tmp = t;
+  }
+  if (dx_host) {
+    if (upd) memcpy(dx_host, hres + 4, sizeof(double) * n2);
+    else memset(dx_host, 0, sizeof(double) * n2);
+  }
+  if (upd && hres[2] != 0.0) return OVP_E_NEGDIAG;
+  return 0;
+}
+
 extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long max_bytes) {
   if (!c || !name || !host) return OVP_E_ARG;
   const size_t nn = (size_t)(c->n_max + 1) * c->ld * sizeof(double);

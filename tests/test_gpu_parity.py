@@ -268,9 +268,13 @@ def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case
     out["ctx"].close()
 
 
-def test_dense_ekf_update_matches_reference_form(hiplib):
-    """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H."""
+@pytest.mark.parametrize("info_form", ["0", "1"])
+def test_dense_ekf_update_matches_reference_form(hiplib, info_form, monkeypatch):
+    """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H: the S-form kernels
+    that take few-row updates (csrc/k_init.hip) and the information form behind them (OVP_EKF_INFO_FORM=1)."""
     from oracle import np_ref
+
+    monkeypatch.setenv("OVP_EKF_INFO_FORM", info_form)
 
     rng = np.random.default_rng(4)
     sc = make_scene(C=6, F=4, seed=41)
@@ -288,14 +292,17 @@ def test_dense_ekf_update_matches_reference_form(hiplib):
     ctx.close()
 
 
+@pytest.mark.parametrize("info_form", ["0", "1"])
 @pytest.mark.parametrize("case", ["landmark_update", "delayed_init_rows", "everything"])
-def test_dense_ekf_update_above_the_tile_limit(hiplib, case):
-    """N = 366 (30 clones + 52 landmarks) is past the register-resident factorization (N <= 288).  Measurements that touch at
+def test_dense_ekf_update_above_the_tile_limit(hiplib, case, info_form, monkeypatch):
+    """(info_form = 0: the few-row S-form kernels of csrc/k_init.hip, which do not depend on N; 1: the information form.)
+    N = 366 (30 clones + 52 landmarks) is past the register-resident factorization (N <= 288).  Measurements that touch at
     most 288 columns take the sub-state update (factor P[s,s], then P -= G (A - A Pss+ A) G^T); one that touches every column
     falls back to the global-memory kernels.  Both against the reference form."""
     from oracle import np_ref
     from ov_plane_amd.synth import make_slam_scene
 
+    monkeypatch.setenv("OVP_EKF_INFO_FORM", info_form)
     rng = np.random.default_rng(11)
     sc = make_slam_scene(C=30, n_slam=52, seed=3)
     assert sc.N == 366
@@ -631,10 +638,13 @@ def test_plane_loop_replicated_then_points_sharded(hiplib, oracle):
     ctx2.close()
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
 @pytest.mark.parametrize("r_iso,chi2_mult,expect", [(1.0, 1e9, 1), (0.25, 1e9, 1), (1.0, 1e-9, 0)])
-def test_host_cpp_initialize_matches_oracle(hiplib, oracle, r_iso, chi2_mult, expect):
+def test_host_cpp_initialize_matches_oracle(hiplib, oracle, r_iso, chi2_mult, expect, split, monkeypatch):
     """StateHelper::initialize / initialize_invertible (state/StateHelper.cpp:398-586): Givens split, chi2 against the prior,
-    covariance augmentation on the device, EKF update with the remaining rows."""
+    covariance augmentation on the device, EKF update with the remaining rows - as one device sequence (ovp_cov_initialize,
+    split = 0) and as the three separate calls it replaces (split = 1)."""
+    monkeypatch.setenv("OVP_HOST_INIT_SPLIT", split)
     from ov_plane_amd.build import build_host
     from ov_plane_amd.synth import quat_boxplus
 
@@ -753,9 +763,11 @@ def test_host_cpp_mirror_updater_slam_update(hiplib, oracle, kw):
     dict(C=11, F=8, seed=5, ragged=True),
     dict(C=8, F=6, seed=6, ragged=True, chi2_mult=0.6),   # two candidates fail the gate
 ])
-def test_host_cpp_mirror_updater_slam_delayed_init(hiplib, oracle, kw):
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_host_cpp_mirror_updater_slam_delayed_init(hiplib, oracle, kw, split, monkeypatch):
     """ov_plane::UpdaterSLAM::delayed_init downstream of triangulation (update/UpdaterSLAM.cpp:204-364): one
     StateHelper::initialize per feature, the state grows by 3 for every accepted landmark."""
+    monkeypatch.setenv("OVP_HOST_INIT_SPLIT", split)
     from ov_plane_amd.build import build_host
 
     build_host()
@@ -1923,4 +1935,62 @@ def test_plane_loop_with_every_plane_rejected_or_absent(hiplib):
     ctx.batch_upload_scene(sc)
     none = ctx.plane_update(o, np.zeros(sc.F, dtype=np.int32), sc.cp, sc.cp_fej, sc.plane_state_id)
     assert not none["ok"].any() and (none["dof"] == 0).all() and np.array_equal(ctx.cov_download(), sc.P)
+    ctx.close()
+
+
+def test_cov_initialize_one_call_matches_separate_calls_and_rejects_cleanly(hiplib):
+    """ovp_cov_initialize (gate + initialize_invertible + EKFUpdate, state/StateHelper.cpp:448-487) against the same three steps
+    in numpy; a rejected candidate leaves the covariance and its dimension bit-identical; problems outside the entry's limits
+    are refused with OVP_E_CAPACITY before anything is touched."""
+    rng = np.random.default_rng(3)
+    sc = make_scene(C=11, F=4, seed=12)
+    n = sc.P.shape[0]
+    cols, k, rup, r = 24, 3, 17, 0.7
+    ids = np.sort(rng.choice(n, cols, replace=False)).astype(np.int32)
+    Hx = rng.standard_normal((k, cols)) * 5.0
+    Hu = rng.standard_normal((rup, cols)) * 5.0
+    HL = rng.standard_normal((k, k)) + 3.0 * np.eye(k)
+    HLi = np.linalg.inv(HL)
+    Ri = r * np.eye(k)
+    res = rng.standard_normal(rup)
+    # numpy: gate, augmentation (StateHelper.cpp:531-566), update (:159-187)
+    Pm = sc.P[np.ix_(ids, ids)]
+    S = Hu @ Pm @ Hu.T + r * np.eye(rup)
+    chi2_ref = float(res @ np.linalg.solve(S, res))
+    M = sc.P[:, ids] @ Hx.T
+    Pll = HLi @ (Hx @ Pm @ Hx.T + Ri) @ HLi.T
+    Pxl = -M @ HLi.T
+    P2 = np.zeros((n + k, n + k))
+    P2[:n, :n] = sc.P
+    P2[:n, n:] = Pxl
+    P2[n:, :n] = Pxl.T
+    P2[n:, n:] = Pll
+    Hf = np.zeros((rup, n + k))
+    Hf[:, ids] = Hu
+    Sf = Hf @ P2 @ Hf.T + r * np.eye(rup)
+    K = P2 @ Hf.T @ np.linalg.inv(Sf)
+    dx_ref = K @ res
+    P3 = P2 - K @ Hf @ P2
+    ctx = hiplib.Context(n + 8, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    # reject: nothing changes
+    ok, chi2, _ = ctx.cov_initialize(Hx, Hu, ids, HLi, Ri, res, r, chi2_ref * 0.5)
+    assert not ok and abs(chi2 - chi2_ref) < 1e-9 * max(1.0, chi2_ref)
+    assert ctx.cov_size() == n and np.array_equal(ctx.cov_download(), sc.P)
+    # outside the limits: refused
+    with pytest.raises(hiplib.OvpError) as e:
+        ctx.cov_initialize(Hx, rng.standard_normal((81, cols)), ids, HLi, Ri, rng.standard_normal(81), r, 1e9)
+    assert e.value.code == hiplib.OVP_E_CAPACITY and ctx.cov_size() == n
+    # accept
+    ok, chi2, dx = ctx.cov_initialize(Hx, Hu, ids, HLi, Ri, res, r, chi2_ref * 2.0)
+    assert ok and ctx.cov_size() == n + k
+    assert relP(ctx.cov_download(), P3) < TOL_P
+    assert np.abs(dx - dx_ref).max() < TOL_DX
+    # accept without the update rows being applied (do_update = false), and with no update rows at all
+    ctx.cov_upload(sc.P)
+    ok, _, dx = ctx.cov_initialize(Hx, Hu, ids, HLi, Ri, res, r, 1e9, do_update=False)
+    assert ok and relP(ctx.cov_download(), P2) < TOL_P and not dx.any()
+    ctx.cov_upload(sc.P)
+    ok, chi2, dx = ctx.cov_initialize(Hx, None, ids, HLi, Ri, None, 1.0, 0.0)
+    assert ok and chi2 == 0.0 and relP(ctx.cov_download(), P2) < TOL_P
     ctx.close()
