@@ -105,8 +105,10 @@ __device__ __forceinline__ double bcast_row(const double& src) {
 // Fused elimination of a 16x16 diagonal block (d: row r = lane & 15, a copy in each DPP row) and of one panel tile per DPP row
 // (p).  On return d = row r of L_kk (entries above the diagonal are garbage), p = row r of A_ik L_kk^-T.  piv_out[c] = pivot of
 // column c before the square root (lane-uniform).  Returns true if a pivot was not positive.
+// pw (null for lanes without a panel tile): row r of the panel tile's LDS image; a pair of columns is stored as soon as it is
+// final, so the publication of the panel rides in the gaps of the chain instead of following it.
 __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], double* __restrict__ piv_out, const bool write_piv,
-                                             const double floor) {
+                                             const double floor, dbl2_t* __restrict__ pw) {
   bool bad = false;
   double piv = bcast_row<0>(d[0]);
   sfor<16>([&](auto cc) {
@@ -131,6 +133,9 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
         fmac_bcast<j>(d[j], nl, l);
         fmac_bcast<j>(p[j], nl, q);
       });
+    }
+    if constexpr ((c & 1) == 1) {
+      if (pw) pw[c >> 1] = dbl2_t{p[c - 1], p[c]};
     }
   });
   return bad;
@@ -311,12 +316,10 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
               p[2 * q + 1] = has_p ? pq[1] : 0.0;
             }
           }
-          if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, floor_eff) || bad;
+          dbl2_t* pw = has_p ? reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS) : nullptr;
+          if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, floor_eff, pw) || bad;
           if (ew == 0) C2_STAMP(k, 2);
           if (has_p) {
-            dbl2_t* pw = reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) pw[q] = dbl2_t{p[2 * q], p[2 * q + 1]};
             if (my_i == tb && r == rb && nb > n) {
 #pragma unroll
               for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
