@@ -341,6 +341,12 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (ew == 0) C2_STAMP(k, 3);
     }
     __builtin_amdgcn_s_setprio(0);
+    // the elimination waves own no tiles: redefining the (unused) tile registers here tells the register allocator that they
+    // are dead throughout the loop above, whose d / p arrays would otherwise compete with 34 live tiles for 168 registers
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      tile[s] = double4_t{0.0, 0.0, 0.0, 0.0};
+    });
   } else {
     // ================================== tile waves ===================================
     const int tw = wave - C2_EW;
@@ -478,55 +484,215 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   bad_out = (bad && !(J.piv_floor > 0.0)) ? 1 : 0;
 }
 
-// y = L^-T z on the n x n part of the factor held in tile[] (left-looking over tile columns, descending): every tile wave adds
-// up L_ik^T y_i over its tiles of column k, wave 0 sums the partial vectors in a fixed order and back-substitutes the 16x16
-// block with the same DPP broadcast-in-FMA chain as the factorization.  Entries at or behind the border row are zero.
+// y = L^-T z on the n x n part of the factor held in tile[] (entries at or behind the border row are zero).
+//
+// Sixteen dependent block steps; what matters is the length of one step, so the chain  y_k = L_kk^-T (z_k - sum_{i>k} L_ik^T y_i)
+// runs inside ONE wave with nothing but DPP-broadcast FMAs on it:
+//   * preparation (all waves, once): the tile waves drop their sub-diagonal tiles L_(k+1)k into the panel buffers (free after the
+//     factorization); the 16 DPP rows of the elimination waves invert one diagonal block each, lane c solving L x = e_c - the
+//     inverse replaces L_kk in S.Dsave.  The diagonal solve of a step becomes a product with L_kk^-T instead of a 16-column chain.
+//   * wave 0, step k:  v = z_k - S_k - L_(k+1)k^T y_(k+1),  y_k = L_kk^-T v : two 16 x 16 products as broadcast-in-FMA chains,
+//     operands prefetched from LDS a step ahead.
+//   * tile waves, one step AHEAD of the chain: S_k = sum_{i >= k+2} L_ik^T y_i from their register tiles (needs y_(k+2), which
+//     was published a whole step earlier), one partial vector per wave, summed by wave 0 in a fixed order.
+// Hand-over through two LDS counters; no workgroup barrier inside the recurrence (the first version had two per step and a
+// 16-column substitution chain in between: 29 us at 16 tile columns).
 template <int MAXSLOT>
 __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt, const double4_t (&tile)[MAXSLOT],
-                                                const int (&ti)[MAXSLOT], const int (&tj)[MAXSLOT]) {
+                                                const int (&ti)[MAXSLOT], const int (&tj)[MAXSLOT], long long* stamps = nullptr) {
+#define BS_STAMP(kk, i)                                                                       \
+  do {                                                                                        \
+    if (stamps && lane == 0) stamps[(kk) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
-  for (int k = nt - 1; k >= 0; --k) {
-    if (wave >= C2_EW) {
-      const int tw = wave - C2_EW;
-      int lo, hi;
-      c2_col_slots(k, nt, tw, lo, hi);
-      double part = 0.0;
-      slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (ti[s] > k) {
+  double* SD = S.PB;                        // [nt] sub-diagonal tiles, row-major, pitch C2_TS
+  double* SL = S.PB + (size_t)nt * C2_TSZ;  // [nt][C2_TW][16] partial sums S_k
+  int* cnt_y = S.cnt + 4;
+  int* cnt_s = reinterpret_cast<int*>(S.Dbuf);  // one counter per column (the diagonal-block buffer is free): a tile wave with an
+                                                // empty column may run ahead of the others, a single running count would not
+                                                // say WHOSE partial sums are in
+  BS_STAMP(nt, 3);
+  if (tid == 0) *cnt_y = 0;
+  if (tid < 32) cnt_s[tid] = 0;
+  // ---- preparation ----
+  if (wave >= C2_EW) {
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (ti[s] >= 0 && ti[s] == tj[s] + 1) {
+        double* buf = SD + tj[s] * C2_TSZ;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) part = fma(tile[s][v], S.ybuf[16 * ti[s] + lr + 4 * v], part);
-        }
+        for (int v = 0; v < 4; ++v) buf[(lr + 4 * v) * C2_TS + lc] = tile[s][v];
+      }
+    });
+  } else {
+    for (int k = wave * 4 + lr; k < nt; k += 4 * C2_EW) {
+      double* blk = S.Dsave + k * C2_TSZ;
+      // reciprocals of the diagonal: one division per lane (lane i: 1 / L_ii), handed round with DPP broadcasts
+      const double dmine = blk[lc * C2_TS + lc];
+      const double rmine = dmine != 0.0 ? 1.0 / dmine : 0.0;
+      double x[16];
+      sfor<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        double sacc = (i == lc) ? 1.0 : 0.0;
+        sfor<i>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          sacc = fma(-blk[i * C2_TS + j], x[j], sacc);
+        });
+        x[i] = sacc * bcast_row<i>(rmine);
       });
-      part += shfl_xor_f64(part, 16);
-      part += shfl_xor_f64(part, 32);
-      if (lane < 16) S.slots[tw * 16 + lane] = part;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const int r = lc;
-      double rhs = S.zbuf[16 * k + r];
+      C2_WSYNC();  // every lane of the row has read L_kk
 #pragma unroll
-      for (int w = 0; w < C2_TW; ++w) rhs -= S.slots[w * 16 + r];
-      if (16 * k + r >= n) rhs = 0.0;
-      // column r of L_kk: col[c] = L_kk[c][r], c >= r
-      double col[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) col[c] = S.Dsave[k * C2_TSZ + c * C2_TS + r];
-      const double ninv = -1.0 / col[r];
-      double y = 0.0;
-      sfor<16>([&](auto cc) {
-        constexpr int c = 15 - decltype(cc)::value;
-        double nt_ = rhs * ninv;  // -y_c in lane c
-        if (r == c) y = -nt_;
-        fmac_bcast_nop<c>(rhs, nt_, col[c]);  // rhs_r -= L_cr y_c   (lanes r < c use it; the others are done)
-      });
-      if (lane < 16) S.ybuf[16 * k + r] = (16 * k + r < n) ? y : 0.0;
+      for (int i = 0; i < 16; ++i) blk[i * C2_TS + lc] = x[i];
     }
-    __syncthreads();
   }
+  if (wave == 1)  // tile slot nt - 1 of SD has no sub-diagonal tile: the first step multiplies it by y = 0
+    for (int e = lane; e < C2_TSZ; e += 64) SD[(nt - 1) * C2_TSZ + e] = 0.0;
+  if (wave == 2 || wave == 3)  // partial sums of the waves that own no tile of a column stay zero
+    for (int e = (wave - 2) * 64 + lane; e < nt * C2_TW * 16; e += 128) SL[e] = 0.0;
+  BS_STAMP(nt, 4);
+  __syncthreads();
+  BS_STAMP(nt, 5);
+  if (wave == 0) {
+    // ---- the chain ----
+    const int r = lc;
+    double y = 0.0;
+    double sd[16], di[16];
+    // operands of a step are loaded into the registers the previous step has just finished with: the sub-diagonal tile right
+    // after the first product, the inverse block right after the second (a second register set for a full prefetch made the
+    // kernel spill inside the factorization)
+    // (unconditional loads from a clamped tile index: a select per element turned into a branch per element)
+    auto load_sd = [&](int k) {
+      const double* sblk = SD + (k >= 0 ? k : 0) * C2_TSZ + r;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sd[c] = sblk[c * C2_TS];
+    };
+    auto load_di = [&](int k) {
+      const double* dblk = S.Dsave + (k >= 0 ? k : 0) * C2_TSZ + r;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) di[c] = dblk[c * C2_TS];
+    };
+    load_sd(nt - 1);
+    load_di(nt - 1);
+    for (int k = nt - 1; k >= 0; --k) {
+      BS_STAMP(k, 4);
+      // right-hand side, counter and partial sums in one batch of LDS reads in front of the first product, which does not need
+      // them (a wave's LDS operations complete in order: sums read behind a counter that shows everybody are at least that new)
+      static_assert(C2_TW == 8, "eight partial vectors");
+      const int kc = k <= nt - 3 ? k : 0;
+      const double* sl = SL + ((size_t)kc * C2_TW) * 16 + r;
+      int got = __hip_atomic_load(cnt_s + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");  // compiler only: the sums are requested behind the counter
+      double p0 = sl[0], p1 = sl[16], p2 = sl[32], p3 = sl[48], p4 = sl[64], p5 = sl[80], p6 = sl[96], p7 = sl[112];
+      double v = S.zbuf[16 * k + r];
+      // t = L_(k+1)k^T y_(k+1): needs only the previous step's y
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      fmac_bcast_nop<0>(t0, y, sd[0]);
+      fmac_bcast_nop<1>(t1, y, sd[1]);
+      fmac_bcast_nop<2>(t2, y, sd[2]);
+      fmac_bcast_nop<3>(t3, y, sd[3]);
+      fmac_bcast<4>(t0, y, sd[4]);
+      fmac_bcast<5>(t1, y, sd[5]);
+      fmac_bcast<6>(t2, y, sd[6]);
+      fmac_bcast<7>(t3, y, sd[7]);
+      fmac_bcast<8>(t0, y, sd[8]);
+      fmac_bcast<9>(t1, y, sd[9]);
+      fmac_bcast<10>(t2, y, sd[10]);
+      fmac_bcast<11>(t3, y, sd[11]);
+      fmac_bcast<12>(t0, y, sd[12]);
+      fmac_bcast<13>(t1, y, sd[13]);
+      fmac_bcast<14>(t2, y, sd[14]);
+      fmac_bcast<15>(t3, y, sd[15]);
+      double tsum = (t0 + t1) + (t2 + t3);
+      asm volatile("" : "+v"(tsum));  // the products above are finished before sd is reloaded
+      load_sd(k - 1);
+      BS_STAMP(k, 5);
+      if (k <= nt - 3) {
+        // column k has nt - k - 2 tiles below the sub-diagonal, dealt out cyclically: that many waves (at most all) report
+        const int need = (nt - k - 2 < C2_TW) ? nt - k - 2 : C2_TW;
+        while (got < need) {  // (the first read was issued in front of the first product)
+          __builtin_amdgcn_s_sleep(1);
+          got = __hip_atomic_load(cnt_s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+          p0 = sl[0], p1 = sl[16], p2 = sl[32], p3 = sl[48], p4 = sl[64], p5 = sl[80], p6 = sl[96], p7 = sl[112];
+          asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7));
+        }
+        BS_STAMP(k, 6);
+        v -= ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+      }
+      v -= tsum;
+      if (16 * k + r >= n) v = 0.0;
+      double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+      fmac_bcast_nop<0>(y0, v, di[0]);
+      fmac_bcast_nop<1>(y1, v, di[1]);
+      fmac_bcast_nop<2>(y2, v, di[2]);
+      fmac_bcast_nop<3>(y3, v, di[3]);
+      fmac_bcast<4>(y0, v, di[4]);
+      fmac_bcast<5>(y1, v, di[5]);
+      fmac_bcast<6>(y2, v, di[6]);
+      fmac_bcast<7>(y3, v, di[7]);
+      fmac_bcast<8>(y0, v, di[8]);
+      fmac_bcast<9>(y1, v, di[9]);
+      fmac_bcast<10>(y2, v, di[10]);
+      fmac_bcast<11>(y3, v, di[11]);
+      fmac_bcast<12>(y0, v, di[12]);
+      fmac_bcast<13>(y1, v, di[13]);
+      fmac_bcast<14>(y2, v, di[14]);
+      fmac_bcast<15>(y3, v, di[15]);
+      y = (y0 + y1) + (y2 + y3);
+      if (16 * k + r >= n) y = 0.0;
+      if (lane < 16) S.ybuf[16 * k + r] = y;
+      c2_signal(cnt_y, lane);  // (before the next operands are requested: the release fence waits for everything in flight)
+      load_di(k - 1);
+      BS_STAMP(k, 7);
+    }
+    // (same device as at the end of the elimination loop: the tile registers are dead across the chain)
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      const_cast<double4_t&>(tile[s]) = double4_t{0.0, 0.0, 0.0, 0.0};
+    });
+  } else if (wave >= C2_EW) {
+    // ---- partial sums, ahead of the chain ----
+    // ONE static pass over the wave's tile registers in descending list order = columns from right to left, rows from the
+    // bottom up inside a column - exactly the order in which the y blocks they need are published: the last tile of column k a
+    // wave can own is (k + 2, k), so when y_(k+2) arrives one product, one reduction and the hand-over are left.  (Dispatching
+    // into the unrolled tile sequence once per column, as the factorization does, cost ~17 scalar branches per column here.)
+    const int tw = wave - C2_EW;
+    int cur = nt;       // column whose partial sum is being accumulated (nt = none yet)
+    int pub = 0;        // y blocks known to be published
+    double part = 0.0;
+    bool any = false;   // the wave owns a tile (i >= cur + 2) of column cur
+    auto flush_to = [&](int jnew) {  // closes column cur (a wave without tiles in a column says nothing: wave 0 knows how many
+                                     // waves own tiles of it, the partial sums of the others were zeroed above)
+      if (any && cur <= nt - 3) {
+        const double pv = rows_sum_f64(part);
+        if (lane < 16) SL[((size_t)cur * C2_TW + tw) * 16 + lane] = pv;
+        c2_signal(cnt_s + cur, lane);
+      }
+      cur = jnew;
+      part = 0.0;
+      any = false;
+    };
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = MAXSLOT - 1 - decltype(sc)::value;
+      const int i = ti[s], j = tj[s];
+      if (i >= 0) {
+        if (j != cur) flush_to(j);
+        if (i >= j + 2) {
+          if (pub < nt - i) {
+            c2_wait_ge(cnt_y, nt - i);
+            pub = nt - i;
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) part = fma(tile[s][v], S.ybuf[16 * i + lr + 4 * v], part);
+          any = true;
+        }
+      }
+    });
+    flush_to(-1);
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -557,7 +723,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
     if (J.z_out)
       for (int i = tid; i < n; i += C2_WAVES * 64) J.z_out[i] = S.zbuf[i];
     if (J.y_out) {  // diagnostics: y = L^-T z
-      chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj);
+      chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj, J.stamps);
       for (int i = tid; i < n; i += C2_WAVES * 64) J.y_out[i] = S.ybuf[i];
     }
     sfor<MAXSLOT>([&](auto sc) {

@@ -2144,7 +2144,7 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
     HIPCHK(hipMemset(st, 0, sizeof(long long) * 16 * 32));
     ovp::Chol2Job jt = j;
     jt.Ldense = nullptr;
-    jt.y_out = nullptr;
+    if (!getenv("OVP_C2_TIME_Y")) jt.y_out = nullptr;
     jt.stamps = st;
     HIPCHK(ovp_launch_chol2(&jt, nullptr, nullptr, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2160,11 +2160,21 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
       fprintf(stderr, " k=%2d E: %6lld %6lld %6lld | T: %6lld %6lld %6lld %6lld | E step %6lld T step %6lld\n", k, e[1] - e[0], e[2] - e[1],
               e[3] - e[2], e[9] - e[8], e[10] - e[9], e[11] - e[10], e[12] - e[11], e[3] - e[0], e[12] - e[8]);
     }
+    if (jt.y_out) {
+      fprintf(stderr, "back substitution: preparation (sub-diagonal tiles to LDS, inverses of the diagonal blocks) %lld cycles + barrier %lld, chain %lld\n",
+              h[nt * 16 + 4] - h[nt * 16 + 3], h[nt * 16 + 5] - h[nt * 16 + 4], h[7] - h[nt * 16 + 5]);
+      fprintf(stderr, "back substitution, wave 0 per step: [first product + loads | wait for the partial sums | sum, second product, publish]\n");
+      for (int k = nt - 1; k >= 0; --k) {
+        const long long* e = h + k * 16;
+        fprintf(stderr, " k=%2d  %6lld %6lld %6lld | step %6lld\n", k, e[5] - e[4], k <= nt - 3 ? e[6] - e[5] : 0LL,
+                e[7] - (k <= nt - 3 ? e[6] : e[5]), e[7] - e[4]);
+      }
+    }
   }
   if (reps > 0) {
     ovp::Chol2Job jt = j;  // timing: the factorization alone (no dense output)
     jt.Ldense = nullptr;
-    jt.y_out = nullptr;
+    if (!getenv("OVP_C2_TIME_Y")) jt.y_out = nullptr;  // OVP_C2_TIME_Y: with the back substitution
     jt.dbg = getenv("OVP_C2_DBG") ? atoi(getenv("OVP_C2_DBG")) : 0;
     HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
     for (int r = 0; r < reps; ++r) HIPCHK(ovp_launch_chol2(&jt, nullptr, nullptr, c->stream));

@@ -96,6 +96,19 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
   return v;
 }
 
+// sum over the four 16-lane rows of the wave (lanes l, l + 16, l + 32, l + 48), every lane gets the result: the gfx950 row /
+// half swaps are plain VALU operations (a ds_bpermute round trip through the LDS crossbar costs ~130 cycles each)
+__device__ __forceinline__ double rows_sum_f64(double v) {
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+  lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+}
+
 // index into a packed lower-triangular matrix (row i >= col j)
 __device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1)) / 2 + j; }
 
