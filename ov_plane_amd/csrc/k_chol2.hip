@@ -795,6 +795,8 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   }
 
   // ---- mode 1: plane update.  zz = |Lt^-1 c|^2 = b . dx ----
+#define M1_STAMP(i) C2_STAMP(nt + 1, i)
+  M1_STAMP(0);
   __shared__ double sh_zz;
   __shared__ int sh_ok;
   if (wave == 0) {
@@ -822,8 +824,10 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   }
   __syncthreads();
   if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
+  M1_STAMP(1);
 
   chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj);
+  M1_STAMP(2);
   // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
   double* dxs = S.zbuf;  // z is no longer needed
@@ -851,6 +855,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
     }
   }
   __syncthreads();
+  M1_STAMP(3);
   // ---- commit (ext Type::update on the device tables, update/UpdaterMSCKF.cpp:646-648) ----
   for (int i = tid; i < n; i += C2_WAVES * 64) {
     ps.dx_out[i] = dxs[i];
@@ -899,6 +904,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   }
   for (int q = tid; q < ps.n_slam; q += C2_WAVES * 64)
     for (int k = 0; k < 3; ++k) ps.slam_p[3 * q + k] += dxs[ps.slam_id[q] + k];
+  M1_STAMP(4);
 }
 
 // out[0] = max_i A_ii (one workgroup): the scale the drop threshold of a semi-definite factorization refers to

@@ -1644,8 +1644,23 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       }
       HIPCHK(hipEventRecord(c->pl_ev[2 * jn], s));
     }
+    static const bool pl_stamps = getenv("OVP_PL_STAMPS") != nullptr;  // diagnostics: cycle stamps of the last plane's tail
+    static long long* d_stamps = nullptr;
+    if (pl_stamps) {
+      if (!d_stamps) HIPCHK(hipMalloc((void**)&d_stamps, sizeof(long long) * 16 * 32));
+      j0.stamps = d_stamps;
+    }
     HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
     if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev[2 * jn + 1], s));
+    if (pl_stamps && jn == NJ - 1) {
+      long long h[16 * 32];
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost));
+      const int ntb = (n + 1 + 15) / 16;
+      const long long* e = h + (ntb + 1) * 16;
+      fprintf(stderr, "[plane tail, cycles] factor %lld | gate %lld | back substitution %lld | dx = L0 y %lld | commit %lld\n",
+              e[0] - h[0], e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]);
+    }
   }
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
   if (NJ > 0) {
