@@ -260,7 +260,12 @@ __device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int
 
 // The factorization proper.  On return (tile waves): tile[] = final factor tiles (MFMA accumulator layout); S.Dsave = diagonal
 // blocks, S.zbuf = border row (if any), S.pivs = pivots.  Every wave of the workgroup (C2_WAVES x 64 threads) must call it.
-template <int MAXSLOT>
+// ROLE 0 = elimination wave, 1 = tile wave: the kernel body is instantiated once per role and the role decided once, at the top of
+// the kernel.  With one body and `if (wave < C2_EW)` inside it the register allocator sees the tile registers live on the
+// elimination waves' paths too (they merge with the tile waves' behind every role-specific block) and spills them around the
+// dependent chains: 376 spill instructions and 190 KB of scratch writes per launch that carried dead values.  In the ROLE 0
+// instantiation the tile array does not exist (143 spill instructions, all on the tile waves' side; no measurable change in time).
+template <int MAXSLOT, int ROLE>
 __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& S, double4_t (&tile)[MAXSLOT], int (&ti)[MAXSLOT],
                                              int (&tj)[MAXSLOT], int& bad_out) {
   const int n = J.n;
@@ -276,16 +281,17 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   int* cnt_trail = S.cnt + 2;
   if (tid < 4) S.cnt[tid] = 0;
   for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) S.zbuf[i] = 0.0;
-  sfor<MAXSLOT>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    ti[s] = -1;
-    tj[s] = -1;
-    tile[s] = double4_t{0.0, 0.0, 0.0, 0.0};
-  });
+  if constexpr (ROLE == 1)
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      ti[s] = -1;
+      tj[s] = -1;
+      tile[s] = double4_t{0.0, 0.0, 0.0, 0.0};
+    });
   __syncthreads();
   bool bad = false;
 
-  if (wave < C2_EW) {
+  if constexpr (ROLE == 0) {
     // =============================== elimination waves ===============================
     const int ew = wave, g = lr, r = lc;
     const double floor_eff = J.floor_scale ? J.piv_floor * (*J.floor_scale) : J.piv_floor;
@@ -341,12 +347,6 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (ew == 0) C2_STAMP(k, 3);
     }
     __builtin_amdgcn_s_setprio(0);
-    // the elimination waves own no tiles: redefining the (unused) tile registers here tells the register allocator that they
-    // are dead throughout the loop above, whose d / p arrays would otherwise compete with 34 live tiles for 168 registers
-    sfor<MAXSLOT>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      tile[s] = double4_t{0.0, 0.0, 0.0, 0.0};
-    });
   } else {
     // ================================== tile waves ===================================
     const int tw = wave - C2_EW;
@@ -497,7 +497,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
 //     was published a whole step earlier), one partial vector per wave, summed by wave 0 in a fixed order.
 // Hand-over through two LDS counters; no workgroup barrier inside the recurrence (the first version had two per step and a
 // 16-column substitution chain in between: 29 us at 16 tile columns).
-template <int MAXSLOT>
+template <int MAXSLOT, int ROLE>
 __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt, const double4_t (&tile)[MAXSLOT],
                                                 const int (&ti)[MAXSLOT], const int (&tj)[MAXSLOT], long long* stamps = nullptr) {
 #define BS_STAMP(kk, i)                                                                       \
@@ -517,7 +517,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
   if (tid == 0) *cnt_y = 0;
   if (tid < 32) cnt_s[tid] = 0;
   // ---- preparation ----
-  if (wave >= C2_EW) {
+  if constexpr (ROLE == 1) {
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if (ti[s] >= 0 && ti[s] == tj[s] + 1) {
@@ -554,6 +554,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
   BS_STAMP(nt, 4);
   __syncthreads();
   BS_STAMP(nt, 5);
+  if constexpr (ROLE == 0) {
   if (wave == 0) {
     // ---- the chain ----
     const int r = lc;
@@ -647,12 +648,8 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
       load_di(k - 1);
       BS_STAMP(k, 7);
     }
-    // (same device as at the end of the elimination loop: the tile registers are dead across the chain)
-    sfor<MAXSLOT>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      const_cast<double4_t&>(tile[s]) = double4_t{0.0, 0.0, 0.0, 0.0};
-    });
-  } else if (wave >= C2_EW) {
+  }
+  } else {
     // ---- partial sums, ahead of the chain ----
     // ONE static pass over the wave's tile registers in descending list order = columns from right to left, rows from the
     // bottom up inside a column - exactly the order in which the y blocks they need are published: the last tile of column k a
@@ -696,20 +693,26 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int MAXSLOT>
-__global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, const Chol2Job J1, const PlaneSolve ps) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const Chol2Job& J = blockIdx.x == 0 ? J0 : J1;
+struct Chol2Shared {  // workgroup variables both role instantiations of the body see
+  int bad, ok;
+  double zz;
+};
+
+template <int MAXSLOT, int ROLE>
+__device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& ps, double* lds, Chol2Shared& sh) {
   const int n = J.n;
   const int nb = J.brow ? n + 1 : n;
   const int nt = (nb + 15) >> 4;
   const Chol2Lds S = chol2_carve(lds, nt);
-  double4_t tile[MAXSLOT];
-  int ti[MAXSLOT], tj[MAXSLOT];
+  constexpr int NS = ROLE == 1 ? MAXSLOT : 1;  // tile registers exist on the tile waves only
+  double4_t tile[NS];
+  int ti[NS], tj[NS];
   int bad = 0;
-  __shared__ int sh_bad;
+  int& sh_bad = sh.bad;
+  int& sh_ok = sh.ok;
+  double& sh_zz = sh.zz;
   if (threadIdx.x == 0) sh_bad = 0;
-  chol2_factor<MAXSLOT>(J, S, tile, ti, tj, bad);
+  chol2_factor<NS, ROLE>(J, S, tile, ti, tj, bad);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
@@ -723,9 +726,10 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
     if (J.z_out)
       for (int i = tid; i < n; i += C2_WAVES * 64) J.z_out[i] = S.zbuf[i];
     if (J.y_out) {  // diagnostics: y = L^-T z
-      chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj, J.stamps);
+      chol2_backsolve<NS, ROLE>(S, n, nt, tile, ti, tj, J.stamps);
       for (int i = tid; i < n; i += C2_WAVES * 64) J.y_out[i] = S.ybuf[i];
     }
+    if constexpr (ROLE == 1) {
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if (ti[s] >= 0) {
@@ -757,6 +761,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
         }
       }
     });
+    }
     if (J.piv_out)
       for (int i = tid; i < n; i += C2_WAVES * 64) J.piv_out[i] = S.pivs[i];
     return;
@@ -797,8 +802,6 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   // ---- mode 1: plane update.  zz = |Lt^-1 c|^2 = b . dx ----
 #define M1_STAMP(i) C2_STAMP(nt + 1, i)
   M1_STAMP(0);
-  __shared__ double sh_zz;
-  __shared__ int sh_ok;
   if (wave == 0) {
     double zz = 0.0;
     for (int i = lane; i < n; i += 64) zz = fma(S.zbuf[i], S.zbuf[i], zz);
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
   M1_STAMP(1);
 
-  chol2_backsolve<MAXSLOT>(S, n, nt, tile, ti, tj);
+  chol2_backsolve<NS, ROLE>(S, n, nt, tile, ti, tj);
   M1_STAMP(2);
   // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
@@ -905,6 +908,17 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   for (int q = tid; q < ps.n_slam; q += C2_WAVES * 64)
     for (int k = 0; k < 3; ++k) ps.slam_p[3 * q + k] += dxs[ps.slam_id[q] + k];
   M1_STAMP(4);
+}
+
+template <int MAXSLOT>
+__global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, const Chol2Job J1, const PlaneSolve ps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ Chol2Shared sh;
+  const Chol2Job& J = blockIdx.x == 0 ? J0 : J1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // both instantiations execute the same sequence of workgroup barriers
+  if (wave < C2_EW) chol2_body<MAXSLOT, 0>(J, ps, lds, sh);
+  else chol2_body<MAXSLOT, 1>(J, ps, lds, sh);
 }
 
 // out[0] = max_i A_ii (one workgroup): the scale the drop threshold of a semi-definite factorization refers to
