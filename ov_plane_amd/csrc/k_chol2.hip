@@ -529,18 +529,36 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
   } else {
     for (int k = wave * 4 + lr; k < nt; k += 4 * C2_EW) {
       double* blk = S.Dsave + k * C2_TSZ;
-      // reciprocals of the diagonal: one division per lane (lane i: 1 / L_ii), handed round with DPP broadcasts
-      const double dmine = blk[lc * C2_TS + lc];
+      // lane r holds row r of L_kk (one batch of 16-byte LDS reads); lane c builds column c of X = L_kk^-1 by forward
+      // substitution, x_i = (delta_ic - sum_{j<i} L_ij x_j) / L_ii, with L_ij taken from lane i INSIDE the FMA (DPP row
+      // broadcast) - no LDS traffic and one division per lane on the dependent chain
+      double l[16];
+      {
+        const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(blk + lc * C2_TS);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const dbl2_t v = lrow[q];
+          l[2 * q] = v[0];
+          l[2 * q + 1] = v[1];
+        }
+      }
+      double dmine = 0.0;
+      sfor<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (lc == i) dmine = l[i];
+      });
       const double rmine = dmine != 0.0 ? 1.0 / dmine : 0.0;
       double x[16];
       sfor<16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        double sacc = (i == lc) ? 1.0 : 0.0;
+        double s0 = (i == lc) ? 1.0 : 0.0, s1 = 0.0;
         sfor<i>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          sacc = fma(-blk[i * C2_TS + j], x[j], sacc);
+          double nx = -x[j];
+          if constexpr ((j & 1) == 0) fmac_bcast_nop<i>(s0, l[j], nx);  // s += L_ij (lane i's l[j]) * (-x_j)
+          else fmac_bcast_nop<i>(s1, l[j], nx);
         });
-        x[i] = sacc * bcast_row<i>(rmine);
+        x[i] = (s0 + s1) * bcast_row<i>(rmine);
       });
       C2_WSYNC();  // every lane of the row has read L_kk
 #pragma unroll
