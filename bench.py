@@ -297,6 +297,7 @@ def main():
                 "algorithmic_bytes_per_launch": 8.0 * ((sc.N + 1) ** 2 / 2 + (n_inv_avg + 1) ** 2 / 2 + sc.N ** 2 / 2),
                 "avg_launch_ms": c2_ms, "launches_timed": c2_n, "algorithmic_flops_per_launch": fl,
                 "share_of_step": c2_ms * int(sc.cp.shape[0]) / ms_per_step,
+                "cus_occupied": 2, "frac_of_occupied_cus": fl / ks / 1e12 / (F64_PEAK_TFLOPS * 2.0 / 256.0),
                 "note": "f64 MFMA + DPP-broadcast FMA chains on 2 of 256 CUs: the fraction of the chip's peak is by construction "
                         "tiny; what bounds the kernel is the dependent pivot chain (n sequential pivots) and the f64 pipe of one "
                         "CU (DESIGN.md section 4)",
