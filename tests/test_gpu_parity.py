@@ -1994,3 +1994,23 @@ def test_cov_initialize_one_call_matches_separate_calls_and_rejects_cleanly(hipl
     ok, chi2, dx = ctx.cov_initialize(Hx, None, ids, HLi, Ri, None, 1.0, 0.0)
     assert ok and chi2 == 0.0 and relP(ctx.cov_download(), P2) < TOL_P
     ctx.close()
+
+
+def test_plane_loop_is_bitwise_repeatable(hiplib):
+    """The wave roles of k_chol2 hand data over through LDS counters (factorization, back substitution): forty runs of the
+    config-3 plane loop on the same frame must give the same bits (dx of every plane, decisions, covariance)."""
+    sc = make_scene(C=30, F=2000, seed=0, n_planes=20, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=1.0)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    o = hiplib.opts_from_scene(sc)
+    ref = None
+    for _ in range(40):
+        ctx.cov_upload(sc.P)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)
+        pl = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+        key = (pl["dx"].tobytes(), pl["ok"].tobytes(), ctx.cov_download().tobytes())
+        if ref is None:
+            ref = key
+            assert pl["ok"].sum() >= 10
+        assert key == ref
+    ctx.close()
