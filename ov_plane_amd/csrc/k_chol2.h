@@ -59,6 +59,12 @@ struct PlaneSolve {
   int n_slam;
   const int* slam_id;
   double* slam_p;
+  // the factor of the accepted T for the covariance product behind the loop (k_fwdsub's inputs): cond[1] = seq_plane on every
+  // accept; with emit != 0 the plane also leaves Lpack / Dinv behind and sets cond[0] = seq_plane - the k_tilechol behind the loop
+  // (ovp_launch_tilechol_unless) then finds its work done if this plane stays the last accepted one
+  int emit, seq_plane;
+  double *Lpack, *Dinv;
+  int* cond;
 };
 
 }  // namespace ovp

@@ -711,6 +711,23 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// tile-packed copy of a factor tile for k_fwdsub: tile index over the n x n part (nt_n tile rows), column-major inside the tile;
+// rows / columns at or behind the border row are replaced by the identity
+__device__ __forceinline__ void c2_pack_tile(double* __restrict__ Lpack, const double4_t& t, int i, int j, int n, int lr, int lc) {
+  const int ntn = (n + 15) >> 4;
+  const int tidx = j * ntn - (j * (j - 1)) / 2 + (i - j);
+  double* pk = Lpack + (size_t)tidx * 256;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = lr + 4 * v, col = lc;
+    const int gr = 16 * i + row, gc = 16 * j + col;
+    double x = t[v];
+    if (gr >= n || gc >= n) x = (gr == gc) ? 1.0 : 0.0;
+    if (i == j && col > row) x = 0.0;
+    pk[col * 16 + row] = x;
+  }
+}
+
 struct Chol2Shared {  // workgroup variables both role instantiations of the body see
   int bad, ok;
   double zz;
@@ -761,22 +778,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
             }
           }
         }
-        if (J.Lpack && 16 * ti[s] < n && 16 * tj[s] < n) {
-          // tile-packed copy for k_fwdsub: tile index over the n x n part (nt_n tile rows), column-major inside the tile;
-          // rows / columns at or behind the border row are replaced by the identity
-          const int ntn = (n + 15) >> 4;
-          const int tidx = tj[s] * ntn - (tj[s] * (tj[s] - 1)) / 2 + (ti[s] - tj[s]);
-          double* pk = J.Lpack + (size_t)tidx * 256;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int row = lr + 4 * v, col = lc;
-            const int gr = 16 * ti[s] + row, gc = 16 * tj[s] + col;
-            double x = tile[s][v];
-            if (gr >= n || gc >= n) x = (gr == gc) ? 1.0 : 0.0;
-            if (ti[s] == tj[s] && col > row) x = 0.0;
-            pk[col * 16 + row] = x;
-          }
-        }
+        if (J.Lpack && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(J.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
       }
     });
     }
@@ -926,6 +928,27 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
   for (int q = tid; q < ps.n_slam; q += C2_WAVES * 64)
     for (int k = 0; k < 3; ++k) ps.slam_p[3 * q + k] += dxs[ps.slam_id[q] + k];
   M1_STAMP(4);
+  // ---- the factor for the covariance product behind the loop ----
+  if (ps.cond) {
+    if (tid == 0) ps.cond[1] = ps.seq_plane;
+    if (ps.emit) {
+      if constexpr (ROLE == 1) {
+        sfor<MAXSLOT>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
+        });
+      } else {
+        // inverses of the diagonal blocks (the back substitution left them in S.Dsave), identity at / behind the border row
+        const int ntn = (n + 15) >> 4;
+        for (int e = tid; e < ntn * 256; e += C2_EW * 64) {
+          const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
+          const int gr = 16 * k + i, gc = 16 * k + c;
+          ps.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
+        }
+        if (tid == 0) ps.cond[0] = ps.seq_plane;
+      }
+    }
+  }
 }
 
 template <int MAXSLOT>

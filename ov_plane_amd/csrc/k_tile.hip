@@ -21,8 +21,11 @@ template <int MAXSLOT>
 __global__ __launch_bounds__(TC_WAVES * 64) void k_tilechol(const double* __restrict__ A, double* __restrict__ L,
                                                            double* __restrict__ Dinv, double* __restrict__ Lpack, int n,
                                                            int ld, int* __restrict__ flag, int add_identity,
-                                                           int dbg_skip) {
+                                                           int dbg_skip, const int* __restrict__ cond) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // cond = {have, want} on the device: the factor this launch would produce is already there when the two agree (the last
+  // accepted plane of the plane loop left Lpack / Dinv behind itself, k_chol2) - decided on the device, no host round trip
+  if (cond && cond[0] != 0 && cond[0] == cond[1]) return;
   tilechol_body<MAXSLOT>(A, L, Dinv, Lpack, n, ld, flag, add_identity, dbg_skip, lds);
 }
 
@@ -215,8 +218,14 @@ extern "C" {
 
 // returns hipErrorInvalidValue when n is too large for the register-resident path (caller falls back)
 extern "C" { int ovp_dbg_tilechol_skip = 0; }
+hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag,
+                                      int add_identity, const int* cond, hipStream_t stream);
 hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag,
                                int add_identity, hipStream_t stream) {
+  return ovp_launch_tilechol_unless(A, L, Dinv, Lpack, n, ld, flag, add_identity, nullptr, stream);
+}
+hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag,
+                                      int add_identity, const int* cond, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   const int ntiles = nt * (nt + 1) / 2;
   const int slots = (ntiles + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
@@ -224,10 +233,10 @@ hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double*
   static const bool force25 = getenv("OVP_TC_FORCE25") != nullptr;  // diagnostics: cost of the per-slot tests
   if (slots <= 15 && !force25) {
     hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
-                       flag, add_identity, ovp_dbg_tilechol_skip);
+                       flag, add_identity, ovp_dbg_tilechol_skip, cond);
   } else if (slots <= 18 && !force25) {  // N <= 240: still without register spills
     hipLaunchKernelGGL((ovp::k_tilechol<18>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
-                       flag, add_identity, ovp_dbg_tilechol_skip);
+                       flag, add_identity, ovp_dbg_tilechol_skip, cond);
   } else if (slots <= 25) {
     static bool attr = false;
     if (!attr) {
@@ -235,7 +244,7 @@ hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double*
       attr = true;
     }
     hipLaunchKernelGGL((ovp::k_tilechol<25>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
-                       flag, add_identity, ovp_dbg_tilechol_skip);
+                       flag, add_identity, ovp_dbg_tilechol_skip, cond);
   } else {
     return hipErrorInvalidValue;
   }

@@ -34,6 +34,8 @@ hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, c
 hipError_t ovp_launch_augment_dt(double* P, int ldp, int n, int pose, int dt, const double* d, hipStream_t stream);
 hipError_t ovp_launch_init_invertible(double* P, int ldp, int n, const int* cols, int ncols, const double* HR, int k,
                                       double* Ma, const double* Hinv, const double* Rk, hipStream_t stream);
+hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag,
+                                      int add_identity, const int* cond, hipStream_t stream);
 hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag, int add_identity,
                                hipStream_t stream);
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
@@ -1512,7 +1514,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
   const size_t tstride = (size_t)(c->n_max + 1) * ld;
   if (NJ > 0) {
-    HIPCHK(hipMemsetAsync(c->pl_cur, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(c->pl_cur, 0, 3 * sizeof(int), s));  // [0] current T buffer, [1..2] factor bookkeeping (PlaneSolve::cond)
     HIPCHK(hipMemsetAsync(c->pl_Tbuf, 0, sizeof(double) * (size_t)n * ld, s));  // half 0: sum of the accepted L0^T A L0
     rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
     if (rc) return rc;
@@ -1620,6 +1622,15 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.dx_out = c->pl_dx + (size_t)j.pl * n;
     ps.dx_last = c->pl_dxlast;
     ps.cur = c->pl_cur;
+    // The covariance product behind the loop needs the factor of the last ACCEPTED T.  The last few planes leave theirs behind when
+    // they are accepted (~8 us of stores each); if one of them stays the last accepted plane, the k_tilechol behind the loop
+    // (94 us at N = 240) finds nothing to do.  Which plane that is, is decided on the device.
+    static const int emit_last = getenv("OVP_PL_EMIT_LAST") ? atoi(getenv("OVP_PL_EMIT_LAST")) : 4;
+    ps.cond = c->pl_cur + 1;
+    ps.seq_plane = jn + 1;
+    ps.emit = (jn >= NJ - emit_last) ? 1 : 0;
+    ps.Lpack = c->Ltp;
+    ps.Dinv = c->Dinv;
     ps.feat_list = d_feat + j.start;
     ps.n_feat_local = j.nf;
     ps.feat_used = c->pl_used;
@@ -1665,7 +1676,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
   if (NJ > 0) {
     HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
-    HIPCHK(ovp_launch_tilechol(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 1, s));
+    HIPCHK(ovp_launch_tilechol_unless(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 1, c->pl_cur + 1, s));
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
   }
