@@ -2014,3 +2014,67 @@ def test_plane_loop_is_bitwise_repeatable(hiplib):
             assert pl["ok"].sum() >= 10
         assert key == ref
     ctx.close()
+
+
+def test_few_row_updates_on_a_singular_covariance_and_at_the_row_limit(hiplib):
+    """The S-form kernels (csrc/k_init.hip) need no factor of P: a dense update and a landmark initialisation right after an exact
+    stochastic clone (P positive SEMI-definite, ovp_cov_clone copies rows and columns) against the reference form in numpy; the
+    row limit of the path (80 rows) and the first size behind it (information form) give the same update."""
+    rng = np.random.default_rng(21)
+    sc = make_scene(C=6, F=4, seed=5)
+    n = sc.P.shape[0]
+    ctx = hiplib.Context(n + 16, sc.C + 2, sc.F)
+    ctx.cov_upload(sc.P)
+    src = int(sc.ids["clones"][0])
+    ctx.cov_clone(src, 6)                      # exact copy: singular covariance of dimension n + 6
+    Pc = ctx.cov_download()
+    assert np.linalg.matrix_rank(Pc) == n and np.abs(Pc[n:, n:] - Pc[src:src + 6, src:src + 6]).max() < 1e-12 * np.abs(Pc).max()
+    N = n + 6
+    cols = np.concatenate([np.arange(src, src + 6), np.arange(n, n + 6), np.arange(3)]).astype(np.int32)
+    H = rng.standard_normal((12, len(cols))) * 10.0
+    res = rng.standard_normal(12)
+    Hf = np.zeros((12, N))
+    Hf[:, cols] = H
+    S = Hf @ Pc @ Hf.T + np.eye(12)
+    K = Pc @ Hf.T @ np.linalg.inv(S)
+    dx, _ = ctx.ekf_update(H, cols, res)
+    assert np.abs(dx - K @ res).max() < TOL_DX
+    P1 = Pc - K @ Hf @ Pc
+    assert relP(ctx.cov_download(), P1) < TOL_P
+    # landmark initialisation on the (still singular) result
+    k, rup = 3, 9
+    Hx = rng.standard_normal((k, len(cols))) * 5.0
+    Hu = rng.standard_normal((rup, len(cols))) * 5.0
+    HLi = np.linalg.inv(rng.standard_normal((k, k)) + 3.0 * np.eye(k))
+    r = rng.standard_normal(rup)
+    ok, chi2, dx2 = ctx.cov_initialize(Hx, Hu, cols, HLi, np.eye(k), r, 1.0, 1e9)
+    Pm = P1[np.ix_(cols, cols)]
+    M = P1[:, cols] @ Hx.T
+    P2 = np.zeros((N + k, N + k))
+    P2[:N, :N] = P1
+    P2[:N, N:] = -M @ HLi.T
+    P2[N:, :N] = P2[:N, N:].T
+    P2[N:, N:] = HLi @ (Hx @ Pm @ Hx.T + np.eye(k)) @ HLi.T
+    Hf2 = np.zeros((rup, N + k))
+    Hf2[:, cols] = Hu
+    S2 = Hf2 @ P2 @ Hf2.T + np.eye(rup)
+    K2 = P2 @ Hf2.T @ np.linalg.inv(S2)
+    assert ok and abs(chi2 - r @ np.linalg.solve(Hu @ Pm @ Hu.T + np.eye(rup), r)) < 1e-8 * max(1.0, chi2)
+    assert np.abs(dx2 - K2 @ r).max() < TOL_DX and relP(ctx.cov_download(), P2 - K2 @ Hf2 @ P2) < TOL_P
+    ctx.close()
+    # 80 rows (S-form) and 81 rows (information form) of the same random system agree with numpy
+    sc = make_scene(C=11, F=4, seed=6)
+    n = sc.P.shape[0]
+    cols = np.arange(n, dtype=np.int32)[:60]
+    for rows in (80, 81):
+        ctx = hiplib.Context(n, sc.C, sc.F)
+        ctx.cov_upload(sc.P)
+        H = rng.standard_normal((rows, len(cols))) * 3.0
+        res = rng.standard_normal(rows)
+        Hf = np.zeros((rows, n))
+        Hf[:, cols] = H
+        K = sc.P @ Hf.T @ np.linalg.inv(Hf @ sc.P @ Hf.T + np.eye(rows))
+        dx, _ = ctx.ekf_update(H, cols, res)
+        assert np.abs(dx - K @ res).max() < TOL_DX
+        assert relP(ctx.cov_download(), sc.P - K @ Hf @ sc.P) < TOL_P
+        ctx.close()
