@@ -352,10 +352,25 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
     const int tw = wave - C2_EW;
     if (tw == 0) C2_STAMP(1, 13);
     // ---- load: tile index idx = slot * C2_TW + tw, column-major over the lower tile triangle ----
+    // Column 0 first (its tiles are the first nt of the list = slots 0..2 of every wave): loaded, patched and handed to the
+    // elimination waves before the other ~120 tiles are requested - those then stream in (the CU's memory pipe at 8-byte loads,
+    // ~9 K cycles) while column 0 is being eliminated, instead of in front of it.
+    const int s_last = (ntiles - 1 - tw >= 0) ? (ntiles - 1 - tw) / C2_TW : -1;
+    auto put_rowmajor = [&](double* buf, const double4_t& t) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) buf[(lr + 4 * v) * C2_TS + lc] = t[v];
+    };
+    auto get_acc = [&](const double* buf) {
+      double4_t t;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[v] = buf[(lr + 4 * v) * C2_TS + lc];
+      return t;
+    };
     {
       const double* Abase = J.A + (J.sel ? (size_t)((*J.sel) ^ J.sel_xor) * J.sel_stride : (size_t)0);
       int jj = 0, cstart = 0;
-      sfor<MAXSLOT>([&](auto sc) {
+      constexpr int SC0 = MAXSLOT < 3 ? MAXSLOT : 3;  // slots that can hold tiles of column 0 (nt <= 18 < 3 * C2_TW)
+      auto load_slot = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         const int idx = s * C2_TW + tw;
         int i = -1, j = -1;
@@ -371,7 +386,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         j = __builtin_amdgcn_readfirstlane(j);
         ti[s] = i;
         tj[s] = j;
-        // pass 1: raw loads from clamped addresses, nothing uses them yet - all of the wave's tiles are in flight together
+        // raw loads from clamped addresses, nothing uses them yet - all requested tiles of the wave are in flight together
         double4_t t = {0.0, 0.0, 0.0, 0.0};
         if (i >= 0) {
           const int c = 16 * j + lc;
@@ -384,10 +399,9 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           }
         }
         tile[s] = t;
-      });
-      if (tw == 0) C2_STAMP(0, 13);
-      // pass 2: the diagonal tiles (+ I) and the tile rows that hold the border row / the identity padding
-      sfor<MAXSLOT>([&](auto sc) {
+      };
+      // the diagonal tiles (+ I) and the tile rows that hold the border row / the identity padding
+      auto patch_slot = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         const int i = ti[s], j = tj[s];
         if (i >= 0 && (i >= (n >> 4) || i == j)) {
@@ -402,31 +416,24 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
             tile[s][v] = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
           }
         }
-      });
-    }
-    if (tw == 0) C2_STAMP(0, 14);
-    const int s_last = (ntiles - 1 - tw >= 0) ? (ntiles - 1 - tw) / C2_TW : -1;
-    auto put_rowmajor = [&](double* buf, const double4_t& t) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) buf[(lr + 4 * v) * C2_TS + lc] = t[v];
-    };
-    auto get_acc = [&](const double* buf) {
-      double4_t t;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) t[v] = buf[(lr + 4 * v) * C2_TS + lc];
-      return t;
-    };
-    // column 0: diagonal block and panel tiles go to LDS
-    {
-      int lo, hi;
-      c2_col_slots(0, nt, tw, lo, hi);
-      slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
+      };
+      sfor<SC0>(load_slot);
+      if (tw == 0) C2_STAMP(0, 13);
+      sfor<SC0>(patch_slot);
+      if (tw == 0) C2_STAMP(0, 14);
+      // column 0: diagonal block and panel tiles go to LDS
+      sfor<SC0>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if (ti[s] == 0) put_rowmajor(S.Dbuf, tile[s]);
-        else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
+        if (ti[s] >= 0 && tj[s] == 0) {
+          if (ti[s] == 0) put_rowmajor(S.Dbuf, tile[s]);
+          else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
+        }
       });
       c2_signal(cnt_col, lane);
       if (tw == 0) C2_STAMP(0, 15);
+      // the rest of the triangle
+      sfor<MAXSLOT - SC0>([&](auto sc) { load_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
+      sfor<MAXSLOT - SC0>([&](auto sc) { patch_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
     }
     for (int k = 0; k < nt; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
