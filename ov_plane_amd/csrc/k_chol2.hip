@@ -141,19 +141,18 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
   return bad;
 }
 
-// acc -= X Y^T for two row-major LDS tiles (pitch C2_TS): MFMA operand element [row lc][k = lr + 4 s]
+// acc -= X Y^T for two row-major LDS tiles (pitch C2_TS).  The sum over the 16 inner indices is split over the four MFMAs as
+// k = 4 lr + q (q = MFMA, lr = the lane's row group) instead of k = 4 q + lr: both operands use the same assignment, so the product
+// is the same sum, and a lane's four operand values of a tile are 32 contiguous bytes - two 16-byte LDS reads per operand and tile
+// instead of four 8-byte ones (the trailing update of the first tile columns is what the elimination waves wait for).
 __device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* Y, double4_t acc, int lc, int lr) {
-  const double* xp = X + lc * C2_TS + lr;
-  const double* yp = Y + lc * C2_TS + lr;
-  double a0 = -xp[0], b0 = yp[0], a1 = -xp[4], b1 = yp[4];
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-  a0 = -xp[8];
-  b0 = yp[8];
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-  a1 = -xp[12];
-  b1 = yp[12];
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+  const dbl2_t* xp = reinterpret_cast<const dbl2_t*>(X + lc * C2_TS + 4 * lr);
+  const dbl2_t* yp = reinterpret_cast<const dbl2_t*>(Y + lc * C2_TS + 4 * lr);
+  const dbl2_t x0 = xp[0], y0 = yp[0], x1 = xp[1], y1 = yp[1];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[0], y0[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[1], y0[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[0], y1[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[1], y1[1], acc, 0, 0, 0);
   return acc;
 }
 
