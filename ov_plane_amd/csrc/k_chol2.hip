@@ -275,6 +275,9 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   const int tb = n >> 4, rb = n & 15;  // tile row / row inside the tile of the border row
+  // n a multiple of 16: the border row is alone in the last tile row.  Its tiles are panel tiles of every step (that is where z
+  // comes from), but the last tile COLUMN holds nothing anybody reads (the corner of the border) - its step is not taken.
+  const int nst = (nb > n && rb == 0) ? nt - 1 : nt;
   int* cnt_col = S.cnt;
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
@@ -295,7 +298,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
     const int ew = wave, g = lr, r = lc;
     const double floor_eff = J.floor_scale ? J.piv_floor * (*J.floor_scale) : J.piv_floor;
     __builtin_amdgcn_s_setprio(3);  // the serial chain: its instructions go first, the tile waves fill the gaps
-    for (int k = 0; k < nt; ++k) {
+    for (int k = 0; k < nst; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
       if (ew == 0) C2_STAMP(k, 0);
       c2_wait_ge(cnt_col, C2_TW * (k + 1));  // column k is in LDS
@@ -434,7 +437,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       sfor<MAXSLOT - SC0>([&](auto sc) { load_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
       sfor<MAXSLOT - SC0>([&](auto sc) { patch_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
     }
-    for (int k = 0; k < nt; ++k) {
+    for (int k = 0; k < nst; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
       double* pbn = S.PB + ((k + 1) & 1) * nt * C2_TSZ;
       int lo, hi, lo1 = 0, hi1 = -1;
@@ -452,11 +455,11 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         for (int v = 0; v < 4; ++v) t[v] = buf[(lr_k + 4 * v) * C2_TS + lc_k];
         return t;
       };
-      if (k + 1 < nt) c2_col_slots(k + 1, nt, tw, lo1, hi1);
+      if (k + 1 < nst) c2_col_slots(k + 1, nt, tw, lo1, hi1);
       if (tw == 0) C2_STAMP(k, 8);
       c2_wait_ge(cnt_panel, C2_EW * (k + 1));  // panel k (and L_kk) are in LDS
       if (tw == 0) C2_STAMP(k, 9);
-      if (k + 1 < nt) {
+      if (k + 1 < nst) {
         // ---- trailing update, column k + 1 first: it is handed to the elimination waves while the rest is updated ----
         slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
@@ -477,7 +480,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         constexpr int s = decltype(sc)::value;
         tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
       });
-      if (k + 1 < nt) {
+      if (k + 1 < nst) {
         slot_range<MAXSLOT>(hi1 + 1 > lo1 ? hi1 + 1 : lo1, s_last, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
           if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
@@ -490,7 +493,8 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   bad_out = (bad && !(J.piv_floor > 0.0)) ? 1 : 0;
 }
 
-// y = L^-T z on the n x n part of the factor held in tile[] (entries at or behind the border row are zero).
+// y = L^-T z on the n x n part of the factor held in tile[] (entries at or behind the border row are zero); nt = tile rows of that
+// part, ceil(n / 16).
 //
 // Sixteen dependent block steps; what matters is the length of one step, so the chain  y_k = L_kk^-T (z_k - sum_{i>k} L_ik^T y_i)
 // runs inside ONE wave with nothing but DPP-broadcast FMAs on it:
@@ -526,7 +530,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
   if constexpr (ROLE == 1) {
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      if (ti[s] >= 0 && ti[s] == tj[s] + 1) {
+      if (ti[s] >= 0 && ti[s] == tj[s] + 1 && ti[s] < nt) {  // (nt = tile rows of the n x n part: a border-only tile row is not one)
         double* buf = SD + tj[s] * C2_TSZ;
 #pragma unroll
         for (int v = 0; v < 4; ++v) buf[(lr + 4 * v) * C2_TS + lc] = tile[s][v];
@@ -698,7 +702,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = MAXSLOT - 1 - decltype(sc)::value;
       const int i = ti[s], j = tj[s];
-      if (i >= 0) {
+      if (i >= 0 && i < nt) {
         if (j != cur) flush_to(j);
         if (i >= j + 2) {
           if (pub < nt - i) {
@@ -767,7 +771,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
     if (J.z_out)
       for (int i = tid; i < n; i += C2_WAVES * 64) J.z_out[i] = S.zbuf[i];
     if (J.y_out) {  // diagnostics: y = L^-T z
-      chol2_backsolve<NS, ROLE>(S, n, nt, tile, ti, tj, J.stamps);
+      chol2_backsolve<NS, ROLE>(S, n, (n + 15) >> 4, tile, ti, tj, J.stamps);
       for (int i = tid; i < n; i += C2_WAVES * 64) J.y_out[i] = S.ybuf[i];
     }
     if constexpr (ROLE == 1) {
@@ -855,7 +859,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
   if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
   M1_STAMP(1);
 
-  chol2_backsolve<NS, ROLE>(S, n, nt, tile, ti, tj);
+  chol2_backsolve<NS, ROLE>(S, n, (n + 15) >> 4, tile, ti, tj);
   M1_STAMP(2);
   // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
