@@ -282,7 +282,12 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
   if (tid < 4) S.cnt[tid] = 0;
-  for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) S.zbuf[i] = 0.0;
+  for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) {
+    S.zbuf[i] = 0.0;
+    // the border row, staged once (the back substitution's y buffer is free until then): the patch of the border tiles in the
+    // prologue then reads LDS instead of paying a global-memory round trip in front of column 0
+    S.ybuf[i] = (nb > n && i < n) ? J.brow[i] : 0.0;
+  }
   if constexpr (ROLE == 1)
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
@@ -408,7 +413,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         const int i = ti[s], j = tj[s];
         if (i >= 0 && (i >= (n >> 4) || i == j)) {
           const int c = 16 * j + lc;
-          const double brow_c = (nb > n && i == tb) ? J.brow[c < n ? c : n - 1] : 0.0;
+          const double brow_c = (nb > n && i == tb) ? S.ybuf[c < n ? c : n - 1] : 0.0;
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int r = 16 * i + lr + 4 * v;
