@@ -173,8 +173,9 @@ __device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* 
 static constexpr int C2_EW = 4;
 static constexpr int C2_TW = C2_WAVES - C2_EW;
 
+// (busy polling: with s_sleep 1 between two looks a hand-over was noticed ~60 cycles later on average, 1.3 % of the config-3 step)
 __device__ __forceinline__ void c2_wait_ge(int* ctr, int target) {
-  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) asm volatile("s_nop 7");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void c2_signal(int* ctr, int lane) {
@@ -646,7 +647,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
         // column k has nt - k - 2 tiles below the sub-diagonal, dealt out cyclically: that many waves (at most all) report
         const int need = (nt - k - 2 < C2_TW) ? nt - k - 2 : C2_TW;
         while (got < need) {  // (the first read was issued in front of the first product)
-          __builtin_amdgcn_s_sleep(1);
+          asm volatile("s_nop 7");
           got = __hip_atomic_load(cnt_s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
           p0 = sl[0], p1 = sl[16], p2 = sl[32], p3 = sl[48], p4 = sl[64], p5 = sl[80], p6 = sl[96], p7 = sl[112];
