@@ -466,6 +466,8 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       c2_wait_ge(cnt_panel, C2_EW * (k + 1));  // panel k (and L_kk) are in LDS
       if (tw == 0) C2_STAMP(k, 9);
       if (k + 1 < nst) {
+        // the next column is what the elimination waves wait for: above the other tile waves' trailing updates until it is out
+        __builtin_amdgcn_s_setprio(2);
         // ---- trailing update, column k + 1 first: it is handed to the elimination waves while the rest is updated ----
         slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
@@ -479,6 +481,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           else put_rowmajor_k(pbn + ti[s] * C2_TSZ, tile[s]);
         });
         c2_signal(cnt_col, lane);
+        __builtin_amdgcn_s_setprio(0);
         if (tw == 0) C2_STAMP(k, 11);
       }
       // own tiles of column k take their final values (off the critical path: the panel buffer lives two more steps)
