@@ -817,18 +817,30 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
       double pr = 0.0;
       for (int i = lane; i < n; i += 64) pr = fma(S.zbuf[i], S.zbuf[i], pr);
       pr = wave_sum(pr);
-      if (lane == 0) {
-        int ndeg = 0;
-        bool seen = false;
-        for (int i = 0; i < ps.n_involved; ++i) {
-          const double pv = S.pivs[i];
-          if (pv < ps.tol_strict) {
-            ++ndeg;
-            seen = true;
-          } else if (seen && pv < ps.tol_loose) {
-            ++ndeg;
-          }
+      // rank deficiency = pivots below tol_strict + pivots below tol_loose behind the first of those, counted by the whole wave
+      // (one lane walking the ~200 pivots in LDS was 20 K cycles at the end of this workgroup - the gate of the other one waited)
+      int first = 0x7fffffff, n_strict = 0;
+      for (int i = lane; i < ps.n_involved; i += 64) {
+        if (S.pivs[i] < ps.tol_strict) {
+          ++n_strict;
+          first = i < first ? i : first;
         }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        n_strict += __shfl_xor(n_strict, m);
+        const int o = __shfl_xor(first, m);
+        first = o < first ? o : first;
+      }
+      int n_loose = 0;
+      for (int i = lane; i < ps.n_involved; i += 64) {
+        const double pv = S.pivs[i];
+        if (i > first && !(pv < ps.tol_strict) && pv < ps.tol_loose) ++n_loose;
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) n_loose += __shfl_xor(n_loose, m);
+      if (lane == 0) {
+        const int ndeg = n_strict + n_loose;
         ps.scal[1] = pr;
         ps.scal[2] = (double)ndeg;
         __threadfence();
