@@ -117,10 +117,18 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
     bad = bad || !(piv > 0.0);
     // floor > 0: a pivot below it marks a direction the (positive semi-definite) matrix does not determine - the column is
     // dropped (no elimination with it, zero entry in the solution) instead of being divided by
-    const double inv = (floor > 0.0 && !(piv >= floor)) ? 0.0 : rsqrt_nr2(piv);
-    const double l = d[c] * inv;
-    const double q = p[c] * inv;
-    double nl = -l;
+    // 1 / sqrt(pivot): v_rsq_f64 (~2^-26 relative) and ONE Newton step (-> a couple of ulp; the second step of rsqrt_nr2 is
+    // invisible next to the rounding of the updates that follow every pivot - tests: factor against numpy to 1e-13), folded into the
+    // scaling: with y0 = rsq(piv), e = 0.5 - 0.5 piv y0^2 the scaled entries are d y0 (1 + e), and d y0, p y0, -d y0 are formed
+    // beside e.  Dependent f64 operations from the pivot to the first update of the next one: rsq, piv y0 / 2, e, l - four instead
+    // of eight (two Newton steps, then the scaling, then the negation): this chain is what a tile step consists of.
+    const double y0 = (floor > 0.0 && !(piv >= floor)) ? 0.0 : __builtin_amdgcn_rsq(piv);
+    const double hy = (0.5 * piv) * y0;
+    const double ly = d[c] * y0, py = p[c] * y0;
+    const double e = fma(-hy, y0, 0.5);
+    const double l = fma(ly, e, ly);
+    const double q = fma(py, e, py);
+    double nl = fma(-ly, e, -ly);  // == -l
     d[c] = l;
     p[c] = q;
     if constexpr (c + 1 < 16) {
