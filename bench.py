@@ -153,14 +153,27 @@ def time_steps(torch, fn, steps, warmup, barrier=None):
     return time.perf_counter() - t0, out
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sc, name, budget_feats=None):
     """The oracle (oracle/ovp_oracle.c: the reference's algorithm in its own loop order, one thread) on the same frame: plane loop
-    on every plane, point update on the features the planes did not consume (a bounded prefix of them when budget_feats is set)."""
+    on every plane, point update on ALL the features the planes did not consume (a bounded prefix only when budget_feats is set).
+    Returns the bench object and the oracle's outputs (for the accept-set comparison)."""
     from oracle import pyoracle
     from ov_plane_amd.synth import Scene
 
     pyoracle.build()
     t0 = time.perf_counter()
+    pl = None
     if sc.cp.shape[0] > 0:
         pl = pyoracle.msckf_plane_update(sc)
         sc2 = Scene(sc)
@@ -175,15 +188,80 @@ def cpu_baseline(sc, name, budget_feats=None):
     pt = pyoracle.msckf_point_update(sc2, feats=sample)
     t2 = time.perf_counter()
     t_plane, t_pts = t1 - t0, t2 - t1
-    # point part scaled to the whole rest when only a prefix was run (it is linear in the feature count up to the final update)
+    # point part scaled to the whole rest only when a prefix was asked for (it is linear in the feature count up to the final update)
     t_full = t_plane + t_pts * (len(rest) / max(len(sample), 1))
-    return dict(
-        value=sc.F / t_full, unit="features/s", cores=1, kind="port",
+    obj = dict(
+        value=sc.F / t_full, unit="features/s", cores=1, kind="port", cpu=cpu_model(), host_cores=os.cpu_count(),
         sample="oracle/ovp_oracle.c (reference loop order, 1 thread) on the %s frame: plane loop over all planes %.2f s (%d features "
-               "consumed), point update on %d of the %d remaining features %.2f s (feat system %.2f s, compression %.2f s, update "
-               "%.3f s)%s" % (name, t_plane, n_used, len(sample), len(rest), t_pts, pt["timings"][0], pt["timings"][1],
-                             pt["timings"][2], "" if len(sample) == len(rest) else "; scaled linearly to the whole frame"),
+               "consumed, %d planes accepted), point update on %d of the %d remaining features %.2f s (feat system %.2f s, "
+               "compression %.2f s, update %.3f s)%s" % (name, t_plane, n_used, int(pl["plane_ok"].sum()) if pl else 0, len(sample),
+                                                        len(rest), t_pts, pt["timings"][0], pt["timings"][1], pt["timings"][2],
+                                                        "" if len(sample) == len(rest) else "; scaled linearly to the whole frame"),
         ms_per_step=1e3 * t_full)
+    return obj, dict(plane=pl, point=pt, rest=rest, sample=sample)
+
+
+def interbuild_band():
+    """Largest distance between two builds of the oracle on the plane-level statistic (tools/plane_gate_agreement.py, committed)."""
+    for f in ("r03_plane_gate_agreement.json",):
+        p = os.path.join(_ROOT, "profiles", f)
+        if os.path.exists(p):
+            with open(p) as fh:
+                return json.load(fh).get("interbuild_band")
+    return None
+
+
+def accept_set_report(run, sc, dev_pl, dev_pt, ora):
+    """Device decisions on the timed frame against the oracle's (accept sets compared on the bench frame itself).
+    Plane gate: decision per plane, and for every differing plane both statistics and the threshold.  Then the device step is
+    repeated with the oracle's plane decisions imposed (ovp_plane_batch::force_decision) so that both sides hand the same state to
+    the point update: per-feature accept sets must then be identical, corrections and covariance agree to the path's tolerance."""
+    rep = {}
+    opl, opt = ora["plane"], ora["point"]
+    thr_of = lambda dof: run.opts.chi2_multiplier * run.capi.lib().ovp_chi2_quantile_095(int(dof))  # noqa: E731
+    force = None
+    if opl is not None and dev_pl is not None:
+        ok_d, ok_o = np.asarray(dev_pl["ok"]).astype(bool), np.asarray(opl["plane_ok"]).astype(bool)
+        rep["plane_accept_set_equal"] = bool((ok_d == ok_o).all())
+        rep["planes_accepted_device"] = int(ok_d.sum())
+        rep["planes_accepted_oracle"] = int(ok_o.sum())
+        # statistics compared on the common prefix of decisions only (afterwards the two loops see different states)
+        diff = []
+        first = None
+        for k in range(len(ok_o)):
+            if ok_d[k] != ok_o[k]:
+                first = k if first is None else first
+                if k == first:
+                    thr = float(thr_of(opl["plane_rows"][k]))
+                    diff.append(dict(plane=k, chi2_device=float(dev_pl["chi2"][k]), chi2_oracle=float(opl["plane_chi2"][k]), thr=thr,
+                                     oracle_margin=abs(float(opl["plane_chi2"][k]) - thr)))
+        rep["first_differing_plane"] = diff
+        band = interbuild_band()
+        rep["interbuild_band"] = band
+        if diff and band is not None:
+            rep["difference_inside_interbuild_band"] = bool(diff[0]["oracle_margin"] <= band)
+        force = ok_o.astype(np.uint8)
+    # same plane decisions on both sides -> identical inputs of the point update
+    sc_, ctx = sc, run.ctx
+    ctx.cov_set_device(run.P0.data_ptr(), sc_.N, sc_.N)
+    ctx.state_upload(sc_)
+    ctx.batch_upload_scene(sc_)
+    if force is not None:
+        ctx.plane_update(run.opts, sc_.plane_id, sc_.cp, sc_.cp_fej, sc_.plane_state_id, force_decision=force)
+    pt = ctx.msckf_update(run.opts_pts)
+    P = ctx.cov_download()
+    sample = ora["sample"]
+    acc_d = np.asarray(pt["accepted"]).astype(bool)[sample]
+    acc_o = np.asarray(opt["accepted"]).astype(bool)
+    rep["point_accept_set_equal_under_oracle_plane_decisions"] = bool((acc_d == acc_o).all()) if len(sample) == len(ora["rest"]) else None
+    rep["points_accepted_device"] = int(acc_d.sum())
+    rep["points_accepted_oracle"] = int(acc_o.sum())
+    if len(sample) == len(ora["rest"]):
+        d = np.sqrt(np.abs(np.diag(opt["P"])))
+        rep["cov_rel_err_vs_oracle"] = float((np.abs(P - opt["P"]) / np.outer(d, d)).max())
+        rep["dx_abs_err_vs_oracle"] = float(np.abs(np.asarray(pt["dx"])[:sc_.N] - opt["dx"]).max())
+    rep["accept_set_equal"] = bool(rep.get("plane_accept_set_equal", True) and rep["point_accept_set_equal_under_oracle_plane_decisions"])
+    return rep
 
 
 def reexec_under_torchrun(n):
@@ -206,7 +284,7 @@ def main():
     ap.add_argument("--workload", choices=["auto", "config2", "config3", "config4"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (point_config, config4_1gpu, propagation)")
-    ap.add_argument("--cpu-sample-feats", type=int, default=1000)
+    ap.add_argument("--cpu-sample-feats", type=int, default=0, help="0 = the oracle runs every feature of the frame")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "0"))
@@ -327,11 +405,13 @@ def main():
             extras(line, capi, torch, args, local_rank, name)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(sc, name, args.cpu_sample_feats)
+                line["cpu_baseline"], ora = cpu_baseline(sc, name, args.cpu_sample_feats if args.cpu_sample_feats > 0 else None)
                 line["speedup_vs_cpu_baseline"] = line["cpu_baseline"]["ms_per_step"] / ms_per_step
+                with torch.cuda.stream(run.stream):
+                    line["parity_on_timed_frame"] = accept_set_report(run, sc, pl, pt, ora)
             except Exception as e:  # noqa: BLE001
-                line["cpu_baseline"] = None
-                print("cpu baseline skipped: %r" % (e,), file=sys.stderr)
+                line.setdefault("cpu_baseline", None)
+                print("cpu baseline / accept-set comparison skipped: %r" % (e,), file=sys.stderr)
         print(json.dumps(line))
     run.close()
     if world > 1:

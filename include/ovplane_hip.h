@@ -31,7 +31,8 @@ enum {
   OVP_E_NOTSPD = -3,    /* a Cholesky factorisation hit a non-positive pivot */
   OVP_E_NEGDIAG = -4,   /* negative covariance diagonal (reference: std::exit, StateHelper.cpp:177-187) */
   OVP_E_NODEVICE = -5,  /* no HIP device / wrong architecture */
-  OVP_E_STATE = -6      /* call order violated (e.g. update before upload) */
+  OVP_E_STATE = -6,     /* call order violated (e.g. update before upload) */
+  OVP_E_TIMEOUT = -7    /* a device-side hand-over between the two workgroups of the plane solve did not arrive (bounded spin) */
 };
 
 typedef struct ovp_ctx ovp_ctx;
@@ -308,6 +309,9 @@ int ovp_plane_kernel_timer(ovp_ctx *ctx, int enable, int reset, float *avg_ms, i
  * duration over `reps` launches.  n <= 271. */
 int ovp_debug_chol2(ovp_ctx *ctx, const double *A_host, int n, int lda, const double *brow_host, int add_identity, double *L_host,
                     double *z_host, double *y_host, double *piv_host, int reps, float *avg_ms);
+/* pivot floor of the following ovp_debug_chol2 calls (0 = none): a pivot below it drops its column, as the range part of the
+ * plane loop's solve does for the directions a plane's rows do not determine */
+void ovp_debug_chol2_floor(double piv_floor);
 /* per-stage GPU time of the last update in milliseconds: [0]=build/gate, [1]=gram, [2]=ekf, [3]=total */
 int ovp_last_timings(ovp_ctx *ctx, float *ms4);
 /* enables hipEvent timing of the dominant kernel; returns avg ms per launch since last reset */

@@ -675,10 +675,16 @@ void ovo_nullspace_project(double *H_f, int rows, int hf_cols, double *H_x, int 
 }
 
 /* update/UpdaterHelper.cpp:548-579 ; update/UpdaterPlane.cpp:519-552 */
+/* diagnostic tap (tools/plane_gate_study.py): state of the sweep in front of column n; not part of the restated algorithm */
+typedef void (*ovo_compress_tap_fn)(int n, int rows, int cols, int ld, const double *H_x, const double *res);
+static ovo_compress_tap_fn g_compress_tap = NULL;
+void ovo_set_compress_tap(ovo_compress_tap_fn fn) { g_compress_tap = fn; }
+
 int ovo_measurement_compress(double *H_x, int rows, int cols, int ld, double *H_cp, int cp_cols, int ld_cp,
                              double *res) {
   if (rows <= cols) return rows;
   for (int n = 0; n < cols; ++n) {
+    if (g_compress_tap) g_compress_tap(n, rows, cols, ld, H_x, res);
     for (int m = rows - 1; m > n; --m) {
       double c, s;
       ovo_make_givens(CM(H_x, ld, m - 1, n), CM(H_x, ld, m, n), &c, &s);
@@ -1006,6 +1012,18 @@ int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st_in, const ovo_
  * feature has no measurements here, it contributes ONE point-on-plane row (update/UpdaterHelper.cpp:503-505) whose feature
  * Jacobian goes to the landmark's state columns instead of being projected away (:545-552).  slam_p is updated in place after
  * every accepted plane (the landmarks are state variables). */
+/* Diagnostic tap (tools/plane_gate_study.py): called with the stacked system of a plane before the compression (stage 0:
+ * rows x cols Hx, rows x 3 Hcp, res, all of leading dimension ld) and with the system handed to the chi2 test (stage 1: Hcp is
+ * the marginal covariance cols x cols instead).  Not part of the restated algorithm. */
+typedef void (*ovo_plane_tap_fn)(int plane, int stage, int rows, int cols, int ld, const double *Hx, const double *Hcp,
+                                 const double *res);
+static ovo_plane_tap_fn g_plane_tap = NULL;
+void ovo_set_plane_tap(ovo_plane_tap_fn fn) { g_plane_tap = fn; }
+/* Diagnostic: accept / reject sequence imposed from outside (one byte per plane, NULL = the gate decides), so that two builds of
+ * this file can be compared plane by plane on the same sequence of states (tools/plane_gate_agreement.py). */
+static const uint8_t *g_plane_force = NULL;
+void ovo_set_plane_force(const uint8_t *force) { g_plane_force = force; }
+
 int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st_in, const ovo_feats *fb, const int *plane_of_feat,
                                 int n_planes, const double *cp_in, const double *cp_fej, const int *plane_state_id, double *P,
                                 ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows,
@@ -1158,6 +1176,7 @@ int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st_in, const
     for (size_t j = 0; j < ct_jacob; ++j) memcpy(Hc + j * ct_meas, Hx_big + j * max_meas, sizeof(double) * ct_meas);
     double *Hcpc = (double *)malloc(sizeof(double) * ct_meas * 3);
     for (size_t j = 0; j < 3; ++j) memcpy(Hcpc + j * ct_meas, Hcp_big + j * max_meas, sizeof(double) * ct_meas);
+    if (g_plane_tap) g_plane_tap(pl, 0, (int)ct_meas, (int)ct_jacob, (int)ct_meas, Hc, Hcpc, res_big);
     int rows_c = ovo_measurement_compress(Hc, (int)ct_meas, (int)ct_jacob, (int)ct_meas, Hcpc, 3, (int)ct_meas, res_big);
     int rows_u = rows_c;
     int row0 = 0; /* first row of the system handed to the chi2 test / update */
@@ -1192,6 +1211,7 @@ int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st_in, const
     const int hc = (int)hcols;
     double *Pm = (double *)malloc(sizeof(double) * (size_t)hc * hc);
     ovo_marginal_cov(P, n, order_big_id, order_big_size, n_order_big, Pm);
+    if (g_plane_tap) g_plane_tap(pl, 1, rows_u, hc, (int)ct_meas, Hc, Pm, res_big);
     double *HP = (double *)calloc((size_t)rows_u * hc, sizeof(double));
     for (int k = 0; k < hc; ++k)
       for (int j = 0; j < hc; ++j) {
@@ -1217,7 +1237,9 @@ int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st_in, const
     plane_chi2[pl] = chi2;
     plane_rows[pl] = rows_u;
     const double chi2_check = ovo_chi2_quantile_095(rows_u);
-    if (!fail && !(chi2 > o->chi2_multiplier * chi2_check)) {
+    int accept = !fail && !(chi2 > o->chi2_multiplier * chi2_check);
+    if (g_plane_force) accept = !fail && g_plane_force[pl] != 0;
+    if (accept) {
       /* :635-648 */
       plane_ok[pl] = 1;
       for (int f = 0; f < F; ++f)

@@ -63,6 +63,19 @@ def build(force=False):
     return so
 
 
+def build_fma():
+    """Path of the FMA-contracted build of the same source (None when it cannot be built or loaded on this CPU)."""
+    so = os.path.join(_HERE, "libovp_oracle_fma.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ovp_oracle.c", "ovp_oracle.h", "ovp_planefit.c", "ovp_planefit.h")]
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "fma"])
+        C.CDLL(so)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return so
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -225,11 +238,23 @@ class OvoStateValues(C.Structure):
     ]
 
 
-def msckf_plane_update(sc, libpath=None, slam=None):
+def msckf_plane_update(sc, libpath=None, slam=None, force=None):
     """Runs ovo_msckf_plane_update on the scene's planar features.
     slam = dict(plane [k] 1-based, id [k], p [k,3], p_fej [k,3]): SLAM landmarks lying on out-of-state planes.
+    force = accept / reject byte per plane imposed instead of the gate's decision (diagnostic hook of the oracle).
     Returns dict(P, state values after the plane loop, used[F], plane_ok, plane_chi2, plane_rows[, slam_p])."""
     L = lib() if libpath is None else C.CDLL(libpath)
+    if force is not None:
+        force = np.ascontiguousarray(force, dtype=np.uint8)
+        L.ovo_set_plane_force(force.ctypes.data_as(C.POINTER(C.c_uint8)))
+    try:
+        return _msckf_plane_update(L, sc, slam)
+    finally:
+        if force is not None:
+            L.ovo_set_plane_force(None)
+
+
+def _msckf_plane_update(L, sc, slam):
     pk = Packed(sc)
     n_planes = int(sc.cp.shape[0])
     P = np.asfortranarray(sc.P.copy())

@@ -18,13 +18,38 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+OBJ_DIR = os.path.join(CSRC, "_obj")
+
+
 def build_lib(force=False, verbose=False):
+    """One object per translation unit (compiled in parallel, rebuilt only when the source or a header is newer), one link."""
     if not force and not _stale():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I" + os.path.join(_HERE, "..", "include")] + os.environ.get("OVP_EXTRA_HIPCC_FLAGS", "").split() + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+             "-I" + os.path.join(_HERE, "..", "include")] + os.environ.get("OVP_EXTRA_HIPCC_FLAGS", "").split()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    t_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    stamp = os.path.join(OBJ_DIR, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+
+    def one(src):
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if force or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), t_hdr):
+            cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

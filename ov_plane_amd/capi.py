@@ -117,7 +117,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_plane_kernel_timer", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
+    "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
 ]
 
 
@@ -517,8 +517,12 @@ class Context:
         return [dict(ok=bool(ok[k]), cp=cp_out[k].copy(), p_FinG=p_out[fs[k]:fs[k + 1]].copy(),
                      kept=kept[fs[k]:fs[k + 1]].astype(bool), iterations=int(its[k])) for k in range(P)]
 
-    def debug_chol2(self, A, brow=None, add_identity=False, reps=0):
-        """k_chol2 on a host matrix: dict(L [(n+1),(n+1)], z, y, piv, ms, rc)."""
+    def debug_chol2(self, A, brow=None, add_identity=False, reps=0, piv_floor=0.0):
+        """k_chol2 on a host matrix: dict(L [(n+1),(n+1)], z, y, piv, ms, rc).  piv_floor > 0: columns whose pivot falls below it
+        are dropped (zero column in the factor, zero entry in z)."""
+        lib().ovp_debug_chol2_floor.argtypes = [C.c_double]
+        lib().ovp_debug_chol2_floor.restype = None
+        lib().ovp_debug_chol2_floor(float(piv_floor))
         A = np.ascontiguousarray(A, dtype=np.float64)
         n = A.shape[0]
         nb = n + (1 if brow is not None else 0)

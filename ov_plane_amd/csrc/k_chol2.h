@@ -35,7 +35,7 @@ struct PlaneSolve {
   unsigned* range_done;     // sequence word: the range workgroup stores `seq` when scal[1..2] are valid
   unsigned seq;
   double thr;
-  int rows_total, rows_u, n_involved;
+  int rows_live, rows_u, n_involved;  // rows_live: residual directions that can carry energy (2m - 2 per feature, see the gate)
   int force;                // ovp_plane_batch::force_decision (0 / 1), anything else = the gate decides
   double tol_strict, tol_loose;
   double* res_out;          // [4]: chi2, accept, rank deficiency, pr

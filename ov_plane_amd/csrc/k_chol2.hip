@@ -182,8 +182,19 @@ static constexpr int C2_EW = 4;
 static constexpr int C2_TW = C2_WAVES - C2_EW;
 
 // (busy polling: with s_sleep 1 between two looks a hand-over was noticed ~60 cycles later on average, 1.3 % of the config-3 step)
-__device__ __forceinline__ void c2_wait_ge(int* ctr, int target) {
-  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) asm volatile("s_nop 7");
+// Every spin is bounded: a hand-over that never comes (it cannot, as long as every wave walks the same step sequence - a bad pivot
+// does not change it, NaNs just flow through) raises the timeout word instead of hanging the CU until the watchdog; the caller
+// turns it into a failed factorization.  ~100 cycles per look, 2^22 looks = 0.2 s.
+static constexpr int C2_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ void c2_wait_ge(int* ctr, int target, int* tmo) {
+  int spins = 0;
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    asm volatile("s_nop 7");
+    if (__builtin_expect(++spins > C2_SPIN_LIMIT, 0)) {
+      __hip_atomic_store(tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void c2_signal(int* ctr, int lane) {
@@ -219,7 +230,7 @@ struct Chol2Lds {
   double* ybuf;   // back substitution result                     [nt * 16]
   double* pivs;   // pivots before the square root               [nt * 16]
   double* slots;  // [C2_TW][16] partial sums of the back substitution
-  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail
+  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [4] cnt_y, [6] spin timeout
 };
 __host__ __device__ constexpr int chol2_lds_doubles(int nt) { return C2_TSZ * (1 + 3 * nt) + 3 * 16 * nt + C2_TW * 16 + 8; }
 __device__ __forceinline__ Chol2Lds chol2_carve(double* lds, int nt) {
@@ -290,7 +301,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   int* cnt_col = S.cnt;
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
-  if (tid < 4) S.cnt[tid] = 0;
+  if (tid < 8) S.cnt[tid] = 0;
   for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) {
     S.zbuf[i] = 0.0;
     // the border row, staged once (the back substitution's y buffer is free until then): the patch of the border tiles in the
@@ -315,7 +326,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
     for (int k = 0; k < nst; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
       if (ew == 0) C2_STAMP(k, 0);
-      c2_wait_ge(cnt_col, C2_TW * (k + 1));  // column k is in LDS
+      c2_wait_ge(cnt_col, C2_TW * (k + 1), S.cnt + 6);  // column k is in LDS
       if (ew == 0) C2_STAMP(k, 1);
       // panel tiles k+1 .. nt-1 are dealt out over (elimination wave, DPP row): 16 per pass, a second pass only when the
       // column has 17 of them (bordered dimension 273..288, first column)
@@ -471,7 +482,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       };
       if (k + 1 < nst) c2_col_slots(k + 1, nt, tw, lo1, hi1);
       if (tw == 0) C2_STAMP(k, 8);
-      c2_wait_ge(cnt_panel, C2_EW * (k + 1));  // panel k (and L_kk) are in LDS
+      c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // panel k (and L_kk) are in LDS
       if (tw == 0) C2_STAMP(k, 9);
       if (k + 1 < nst) {
         // the next column is what the elimination waves wait for: above the other tile waves' trailing updates until it is out
@@ -482,7 +493,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
         });
         if (tw == 0) C2_STAMP(k, 10);
-        c2_wait_ge(cnt_trail, C2_TW * k);  // every tile wave is done with panel k - 1, whose buffer receives column k + 1
+        c2_wait_ge(cnt_trail, C2_TW * k, S.cnt + 6);  // every tile wave is done with panel k - 1, whose buffer receives column k + 1
         slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
           if (ti[s] == k + 1) put_rowmajor_k(S.Dbuf, tile[s]);
@@ -657,8 +668,13 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
       if (k <= nt - 3) {
         // column k has nt - k - 2 tiles below the sub-diagonal, dealt out cyclically: that many waves (at most all) report
         const int need = (nt - k - 2 < C2_TW) ? nt - k - 2 : C2_TW;
+        int spins = 0;
         while (got < need) {  // (the first read was issued in front of the first product)
           asm volatile("s_nop 7");
+          if (__builtin_expect(++spins > C2_SPIN_LIMIT, 0)) {
+            __hip_atomic_store(S.cnt + 6, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+          }
           got = __hip_atomic_load(cnt_s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
           p0 = sl[0], p1 = sl[16], p2 = sl[32], p3 = sl[48], p4 = sl[64], p5 = sl[80], p6 = sl[96], p7 = sl[112];
@@ -723,7 +739,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
         if (j != cur) flush_to(j);
         if (i >= j + 2) {
           if (pub < nt - i) {
-            c2_wait_ge(cnt_y, nt - i);
+            c2_wait_ge(cnt_y, nt - i, S.cnt + 6);
             pub = nt - i;
           }
 #pragma unroll
@@ -780,8 +796,10 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
   const int lr = lane >> 4, lc = lane & 15;
   if (bad && lane == 0) atomicOr(&sh_bad, 1);  // a wave only sees the pivots of the steps it took part in
   __syncthreads();
+  if (tid == 0 && S.cnt[6]) atomicOr(&sh_bad, 2);  // a hand-over timed out (c2_wait_ge)
+  __syncthreads();
   bad = sh_bad;
-  if (bad && tid == 0 && J.flag) *J.flag = 1;
+  if (bad && tid == 0 && J.flag) atomicOr(J.flag, bad);
 
   if (J.mode == 0) {
     // ---- outputs of a plain factorization ----
@@ -866,15 +884,34 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
     for (int i = lane; i < n; i += 64) zz = fma(S.zbuf[i], S.zbuf[i], zz);
     zz = wave_sum(zz);
     if (lane == 0) {
-      // the other workgroup publishes pr and the rank; both take the same time, this wait is short
-      while (__hip_atomic_load(ps.range_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) __builtin_amdgcn_s_sleep(2);
+      // the other workgroup publishes pr and the rank; both take the same time, this wait is short.  Bounded (~0.3 s): HIP gives
+      // no forward-progress guarantee between two workgroups of a grid (CU masking down to one CU, a scheduler that starts block
+      // 1 only when block 0 retires) - then the plane is rejected and the call fails with OVP_E_TIMEOUT instead of hanging.
+      int spins = 0;
+      bool timed_out = false;
+      while (__hip_atomic_load(ps.range_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 18)) {
+          timed_out = true;
+          break;
+        }
+      }
+      if (timed_out && J.flag) atomicOr(J.flag, 2);
       const double rr = ps.scal[0], pr = ps.scal[1], ndeg = ps.scal[2];
+      // The reference keeps rows_u rows of the Givens-compressed system of which (rows_u - rank) carry no Jacobian: each is a
+      // combination of the rows below it weighted by the ROUNDING NOISE those rows hold in a deficient column.  The m identical
+      // constraint rows of a feature leave m - 1 rows that are zero to the last bit (no noise, no weight), so the retained rows
+      // sample the rows_live = sum(2m - 2) directions that carry residual energy, not all 3m - 3 of them
+      // (tools/plane_gate_study.py: energy per retained junk row 0.98 against 0.64 per stacked row on config-3 planes).
       const double rank = (double)ps.n_involved - ndeg;
       const double noise_rows = fmax((double)ps.rows_u - rank, 0.0);
-      const double denom = (double)ps.rows_total - rank;
-      const double s2 = denom > 0.5 ? fmax(rr - pr, 0.0) / denom : 0.0;
-      const double chi2 = (pr - zz) + noise_rows * s2;
-      const bool fact_ok = (bad == 0);
+      const double denom = (double)ps.rows_live - rank;
+      const double frac = denom > 0.5 ? fmin(noise_rows / denom, 1.0) : 1.0;
+      const double chi2 = (pr - zz) + frac * fmax(rr - pr, 0.0);
+      // any failure upstream (chol(P) of the loop's start, an earlier plane's factorization) rejects this and every later plane
+      // BEFORE anything is committed: with a failed L0 the tables and the covariance would otherwise drift apart
+      const int upstream = J.flag ? __hip_atomic_load(J.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      const bool fact_ok = (bad == 0) && !timed_out && upstream == 0;
       const bool ok = fact_ok && (ps.force == 0 ? false : (ps.force == 1 ? true : (chi2 <= ps.thr)));
       ps.res_out[0] = chi2;
       ps.res_out[1] = ok ? 1.0 : 0.0;
@@ -894,6 +931,13 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
   double* dxs = S.zbuf;  // z is no longer needed
   __syncthreads();
+  if (S.cnt[6]) {  // a hand-over of the back substitution timed out: nothing is committed, the call fails
+    if (tid == 0) {
+      if (J.flag) atomicOr(J.flag, 2);
+      ps.res_out[1] = 0.0;
+    }
+    return;
+  }
   {
     const int half = tid & 1;
     for (int row = tid >> 1; row < ((n + C2_WAVES * 32 - 1) / (C2_WAVES * 32)) * (C2_WAVES * 32); row += C2_WAVES * 32) {

@@ -501,22 +501,23 @@ __global__ __launch_bounds__(1024) void k_dx_from_factor(const double* __restric
 
 // ------------------------------------------------------------------------------------------------
 // plane-level gate (update/UpdaterMSCKF.cpp:606-631) and conditional commit (:646-648 + ext Type::update).
-//   chi2 = (pr - b.dx) + n_deg * (rr - pr) / (rows_total - rank)        [DESIGN.md §3b: deterministic stand-in for the
+//   chi2 = (pr - b.dx) + (rows_u - rank) * (rr - pr) / (rows_live - rank)        [DESIGN.md §3b: deterministic stand-in for the
 //   reference's rounding-dependent statistic], accept iff chi2 <= thr and the factorizations succeeded.
 // On accept: M <- V^T, pose tables / calibration / in-state planes updated with dx, dx stored for the host.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_plane_gate(const double* __restrict__ scal, const int* __restrict__ flags,
-                                                     double thr, int rows_total, int rows_u, int n_involved, int force,
+                                                     double thr, int rows_live, int rows_u, int n_involved, int force,
                                                      double* __restrict__ res_out /* [4]: chi2, accept, n_deg, pr */) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double rr = scal[0], pr = scal[1], ndeg = scal[2], bdx = scal[3];
   // rank of the retained system; pivots of non-involved columns are exactly 1 and never counted as deficient.
   // The reference keeps rows_u rows of which (rows_u - rank) carry no Jacobian, only residual noise.
+  // They sample the rows_live = sum(2m - 2) directions that carry residual energy (k_chol2.hip, mode 1, for the argument).
   const double rank = (double)n_involved - ndeg;
   const double noise_rows = fmax((double)rows_u - rank, 0.0);
-  const double denom = (double)rows_total - rank;
-  const double s2 = denom > 0.5 ? fmax(rr - pr, 0.0) / denom : 0.0;
-  const double chi2 = (pr - bdx) + noise_rows * s2;
+  const double denom = (double)rows_live - rank;
+  const double frac = denom > 0.5 ? fmin(noise_rows / denom, 1.0) : 1.0;
+  const double chi2 = (pr - bdx) + frac * fmax(rr - pr, 0.0);
   // force: 0 / 1 = decision handed over by the caller (ovp_plane_batch::force_decision), anything else = the gate decides
   const bool ok = (flags[0] == 0) && (force == 0 ? false : (force == 1 ? true : (chi2 <= thr)));
   res_out[0] = chi2;
@@ -734,9 +735,9 @@ hipError_t ovp_launch_dx_from_factor(const double* V, int n, int ld, const doubl
   hipLaunchKernelGGL(ovp::k_dx_from_factor, dim3(1), dim3(1024), shmem, stream, V, n, ld, b, dx, scal);
   return hipGetLastError();
 }
-hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
+hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_live, int rows_u,
                                  int n_involved, int force, double* res_out, hipStream_t stream) {
-  hipLaunchKernelGGL(ovp::k_plane_gate, dim3(1), dim3(64), 0, stream, scal, flags, thr, rows_total, rows_u, n_involved,
+  hipLaunchKernelGGL(ovp::k_plane_gate, dim3(1), dim3(64), 0, stream, scal, flags, thr, rows_live, rows_u, n_involved,
                      force, res_out);
   return hipGetLastError();
 }

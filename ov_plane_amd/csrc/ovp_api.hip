@@ -72,7 +72,7 @@ size_t ovp_init_max_lds();
 int ovp_init_max_rows();
 hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                              double* C, int ldc, int add_identity, int symmetric, const int* cancel, hipStream_t stream);
-hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_total, int rows_u,
+hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_live, int rows_u,
                                  int n_involved, int force, double* res_out, hipStream_t stream);
 hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
                                          hipStream_t stream);
@@ -1102,7 +1102,7 @@ extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx
 // Leaves: V in c->Y, dx in c->dx, [chi2, ok, n_deg, pr] in c->pl_res + 4*pl, the extended Gram in c->pl_E.
 static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::FeatParams& fp, int pl, int start, int nf,
                             int in_state, int sid, double white_c, const double* Mf, int factor_dense, double thr,
-                            int rows_total, int rows_u, int n_involved, int force = -1) {
+                            int rows_live, int rows_u, int n_involved, int force = -1) {
   const int n = c->n, ld = c->ld, ldg = c->ldg;
   hipStream_t s = c->stream;
   ovp::PlaneParams pp;
@@ -1149,7 +1149,7 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
   HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
   HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-  HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_total, rows_u, n_involved, force, c->pl_res + 4 * pl, s));
+  HIPCHK(ovp_launch_plane_gate(c->pl_scal, c->flags, thr, rows_live, rows_u, n_involved, force, c->pl_res + 4 * pl, s));
   return 0;
 }
 
@@ -1204,7 +1204,7 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
   if (rc) return rc;
   ovp::FeatParams fp = c->fp;
   // ---- host-side grouping (update/UpdaterMSCKF.cpp:204-229) ----
-  struct PlaneJob { int pl, start, nf, rows_total, rows_u, n_involved, in_state, sid; double thr; };
+  struct PlaneJob { int pl, start, nf, rows_total, rows_live, rows_u, n_involved, in_state, sid; double thr; };
   std::vector<PlaneJob> jobs;
   std::vector<int> featlist;
   const int ncal = (o->do_calib_camera_pose ? 6 : 0) + (o->do_calib_camera_intrinsics ? 8 : 0);
@@ -1215,6 +1215,7 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
     j.start = (int)featlist.size();
     j.nf = 0;
     j.rows_total = 0;
+    j.rows_live = 0;
     j.sid = pb->plane_state_id[pl];
     j.in_state = j.sid >= 0;
     unsigned long long seen = 0ull;
@@ -1226,6 +1227,7 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
       featlist.push_back(f);
       j.nf++;
       j.rows_total += 3 * m - 3;
+      j.rows_live += 2 * m - 2;  // the m identical constraint rows are one direction (k_chol2 gate)
       for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
     }
     int ns_pl = 0;  // SLAM landmarks on this (out-of-state) plane: one row and three involved columns each
@@ -1237,11 +1239,13 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
       continue;
     }
     j.rows_total += ns_pl;
+    j.rows_live += ns_pl;
     const int c_ref = 6 * __builtin_popcountll(seen) + ncal + 3 * ns_pl;
     const int rows_c = j.rows_total > c_ref ? c_ref : j.rows_total;  // UpdaterPlane::measurement_compress_inplace
     j.rows_u = j.in_state ? rows_c : rows_c - 3;
     j.n_involved = c_ref + (j.in_state ? 3 : 0);
     if (!j.in_state) j.rows_total -= 3;
+    if (!j.in_state) j.rows_live -= 3;
     if (j.rows_u < 1) {
       featlist.resize(j.start);
       continue;
@@ -1283,7 +1287,7 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
   }
   double* Mf = c->L;
   for (const PlaneJob& j : jobs) {
-    rc = plane_job_device(c, o, fp, j.pl, j.start, j.nf, j.in_state, j.sid, 1.0 / o->sigma_constraint, Mf, 1, j.thr, j.rows_total,
+    rc = plane_job_device(c, o, fp, j.pl, j.start, j.nf, j.in_state, j.sid, 1.0 / o->sigma_constraint, Mf, 1, j.thr, j.rows_live,
                           j.rows_u, j.n_involved, pb->force_decision ? (int)pb->force_decision[j.pl] : -1);
     if (rc) return rc;
     HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * j.pl, c->Y, Mf, n, ld, c->dx, c->pl_dx + (size_t)j.pl * n, c->clone_R,
@@ -1323,7 +1327,12 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
 // ---- UpdaterMSCKF::update, per-plane loop (second generation) ------------------------------------------------------------
 // See k_plane2.hip for the algebra.  Everything of a call is enqueued without a host synchronisation: the per-call tables go
 // through one pinned staging block, the results come back through one pinned block read after a single stream sync.
-struct PlaneJobH { int pl, start, nf, rows_total, rows_u, n_involved, in_state, sid, n_inv_cols, ns_pl; double thr; };
+struct PlaneJobH { int pl, start, nf, rows_total, rows_live, rows_u, n_involved, in_state, sid, n_inv_cols, ns_pl; double thr; };
+
+static int ensure_pl_used(ovp_ctx* c) {
+  if (!c->pl_used) HIPCHK(hipMalloc((void**)&c->pl_used, (size_t)c->f_max + 16));
+  return 0;
+}
 
 static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_bytes) {
   const int ld = c->ld;
@@ -1335,7 +1344,6 @@ static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_byt
     HIPCHK(hipMalloc((void**)&c->pl_cur, 16));
     HIPCHK(hipMalloc((void**)&c->pl_range_done, 16));
     HIPCHK(hipMemset(c->pl_range_done, 0, 16));
-    HIPCHK(hipMalloc((void**)&c->pl_used, (size_t)c->f_max + 16));
   }
   if (NP > c->pl2_cap) {
     if (c->pl_perm) hipFree(c->pl_perm);
@@ -1365,9 +1373,24 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
   const int n = c->n, ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
-  static const bool force_v1 = getenv("OVP_PLANE_V1") != nullptr;
-  if (n > ovp_chol2_max_n() || force_v1) return plane_update_v1(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
+  // skip_plane_used is an option of the POINT update that follows; the plane loop itself produces the mask
+  ovp_update_opts o_local = *o;
+  o_local.skip_plane_used = 0;
+  o = &o_local;
   c->pl_used_valid = false;
+  int rcu = ensure_pl_used(c);
+  if (rcu) return rcu;
+  static const bool force_v1 = getenv("OVP_PLANE_V1") != nullptr;
+  if (n > ovp_chol2_max_n() || force_v1) {
+    // first generation (no device-side mask of its own): the host mask it reports is mirrored into pl_used
+    std::vector<uint8_t> used_h((size_t)(F > 0 ? F : 1), 0);
+    const int rc1 = plane_update_v1(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, used_h.data());
+    if (rc1) return rc1;
+    if (F) HIPCHK(hipMemcpy(c->pl_used, used_h.data(), (size_t)F, hipMemcpyHostToDevice));
+    if (feat_used && F) memcpy(feat_used, used_h.data(), (size_t)F);
+    c->pl_used_valid = true;
+    return 0;
+  }
   if (feat_used) memset(feat_used, 0, (size_t)F);
   for (int pl = 0; pl < NP; ++pl) {
     if (plane_ok) plane_ok[pl] = 0;
@@ -1375,7 +1398,11 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (plane_dof) plane_dof[pl] = 0;
   }
   if (dx_planes && NP > 0) memset(dx_planes, 0, sizeof(double) * (size_t)n * NP);
-  if (NP == 0) return 0;
+  if (NP == 0) {  // a frame without planes: nothing is consumed, and a point update with skip_plane_used may follow
+    if (F) HIPCHK(hipMemsetAsync(c->pl_used, 0, (size_t)F, c->stream));
+    c->pl_used_valid = true;
+    return 0;
+  }
   for (int k = 0; k < NP; ++k)
     if (pb->plane_state_id[k] >= 0 && pb->plane_state_id[k] + 3 > n) return OVP_E_ARG;
   const int n_slam = pb->n_slam > 0 ? pb->n_slam : 0;
@@ -1397,6 +1424,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     j.start = (int)featlist.size();
     j.nf = 0;
     j.rows_total = 0;
+    j.rows_live = 0;
     j.sid = pb->plane_state_id[pl];
     j.in_state = j.sid >= 0;
     unsigned long long seen = 0ull;
@@ -1408,6 +1436,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       featlist.push_back(f);
       j.nf++;
       j.rows_total += 3 * m - 3;
+      j.rows_live += 2 * m - 2;  // the m identical constraint rows are one direction (k_chol2 gate)
       for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
     }
     int ns_pl = 0;  // SLAM landmarks on this (out-of-state) plane: one row and three involved columns each
@@ -1421,11 +1450,13 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       continue;
     }
     j.rows_total += ns_pl;
+    j.rows_live += ns_pl;
     const int c_ref = 6 * __builtin_popcountll(seen) + ncal + 3 * ns_pl;
     const int rows_c = j.rows_total > c_ref ? c_ref : j.rows_total;  // UpdaterPlane::measurement_compress_inplace
     j.rows_u = j.in_state ? rows_c : rows_c - 3;
     j.n_involved = c_ref + (j.in_state ? 3 : 0);
     if (!j.in_state) j.rows_total -= 3;
+    if (!j.in_state) j.rows_live -= 3;
     if (j.rows_u < 1) {
       featlist.resize(j.start);
       continue;
@@ -1610,7 +1641,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.range_done = c->pl_range_done;
     ps.seq = ++c->pl_seq;
     ps.thr = j.thr;
-    ps.rows_total = j.rows_total;
+    ps.rows_live = j.rows_live;
     ps.rows_u = j.rows_u;
     ps.n_involved = j.n_inv_cols;
     ps.force = pb->force_decision ? (int)pb->force_decision[j.pl] : -1;
@@ -1707,7 +1738,9 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   }
   const int bad = c->h_flags[0] | c->h_flags[2];
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
-  if (bad) return OVP_E_NOTSPD;
+  if (bad & 2) return OVP_E_TIMEOUT;
+  if (bad) return OVP_E_NOTSPD;  // a factorization failed (singular prior: chol(P) of the loop's start): every plane from there
+                                 // on was rejected before anything was committed, state tables and covariance are consistent
   return 0;
 }
 
@@ -1746,7 +1779,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
     const int n = c->n;
     if (n > OVP_TILECHOL_NMAX || n + 3 > c->n_max) return OVP_E_CAPACITY;
     std::vector<int> featlist;
-    int rows_total = 0;
+    int rows_total = 0, rows_live = 0;
     unsigned long long seen = 0ull;
     for (int f = 0; f < F; ++f) {
       if (pb->plane_of_feat[f] != pl + 1) continue;
@@ -1755,6 +1788,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
       if (m > 31) return OVP_E_CAPACITY;
       featlist.push_back(f);
       rows_total += 3 * m - 3;
+      rows_live += 2 * m - 2;
       for (int k = 0; k < m; ++k) seen |= 1ull << c->h_clone_idx[(size_t)f * M + k];
     }
     const int nf = (int)featlist.size();
@@ -1770,7 +1804,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
     rc = chol_of_P(c, s);
     if (rc) return rc;
     ovp::FeatParams fp = c->fp;
-    rc = plane_job_device(c, o, fp, pl, 0, nf, 0, -1, 1.0 / (const_init_multi * o->sigma_constraint), c->L, 0, thr, rows_total - 3,
+    rc = plane_job_device(c, o, fp, pl, 0, nf, 0, -1, 1.0 / (const_init_multi * o->sigma_constraint), c->L, 0, thr, rows_live - 3,
                           rows_c - 3, c_ref);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(res4.data(), c->pl_res + 4 * pl, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
@@ -2135,6 +2169,9 @@ extern "C" long ovp_debug_read(ovp_ctx* c, const char* name, void* host, long ma
 // Diagnostics / micro-benchmark of the second-generation tile Cholesky (k_chol2.hip): factorizes the n x n host matrix A (+ I)
 // bordered with the row brow, returns the dense factor of the bordered matrix ((n+1) x (n+1) row-major, or n x n without a border),
 // z = L^-1 brow, y = L^-T z and the pivots; avg_ms = average duration of `reps` launches (HIP events).
+static double g_dbg_chol2_floor = 0.0;
+extern "C" void ovp_debug_chol2_floor(double piv_floor) { g_dbg_chol2_floor = piv_floor; }
+
 extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda, const double* brow_host, int add_identity,
                                double* L_host, double* z_host, double* y_host, double* piv_host, int reps, float* avg_ms) {
   if (!c || !A_host || n < 1 || lda < n) return OVP_E_ARG;
@@ -2162,6 +2199,7 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
   j.z_out = brow_host ? dv + n : nullptr;
   j.y_out = brow_host ? dv + 2 * n : nullptr;
   j.piv_out = dv + 3 * n;
+  j.piv_floor = g_dbg_chol2_floor;
   HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (getenv("OVP_C2_STAMPS")) {
@@ -2220,7 +2258,7 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
   hipFree(dA);
   hipFree(dL);
   hipFree(dv);
-  return fl[0] ? OVP_E_NOTSPD : 0;
+  return (fl[0] & 2) ? OVP_E_TIMEOUT : (fl[0] ? OVP_E_NOTSPD : 0);
 }
 
 extern "C" int ovp_last_timings(ovp_ctx* c, float* ms4) {

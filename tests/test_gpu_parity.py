@@ -1856,11 +1856,12 @@ def test_plane_gate_at_multiplier_one_over_fifty_scenes(hiplib, oracle):
     (config/euroc_mav/estimator_config.yaml:155) - on >= 50 config-3 sized scenes (30 clones, 20 planes x 50 features, N = 240).
 
     The reference's statistic carries (kept rows - rank) rows of a rank-deficient Givens sweep whose content is decided by rounding
-    (tests/test_oracle_pins.py::test_plane_chi2_*); the device computes its deterministic part plus the expectation of those rows.
-    So the device loop runs with the oracle's accept / reject sequence forced (ovp_plane_batch::force_decision): state and
-    covariance must then agree to the path's tolerances on every scene, and the two statistics are compared plane by plane -
-    bounded mean and spread of the difference, decisions equal except in a band around the threshold that is as wide as the
-    spread of the rounding-dependent part (committed numbers: profiles/r02_plane_gate_agreement.json)."""
+    (tests/test_oracle_pins.py::test_plane_chi2_*); the device computes its deterministic part plus the expectation of those rows
+    (the mean energy of the residual directions that carry energy, k_chol2.hip).  The device loop and a second build of the oracle
+    (fused multiply-adds, oracle/Makefile: fma) run with the plain oracle's accept / reject sequence forced, so all three see the
+    same state at every plane.  Required: covariance agreement on every scene; no bias of the statistic (round 2 had -2.85 from
+    counting the dead copies of the constraint rows); every decision that differs from the oracle's lies closer to the threshold
+    than two builds of the oracle are apart (committed numbers: profiles/r03_plane_gate_agreement.json)."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location(
@@ -1873,9 +1874,17 @@ def test_plane_gate_at_multiplier_one_over_fifty_scenes(hiplib, oracle):
     assert s["dof_mismatch"] == 0                      # same row count in the test as the reference (res_big.rows())
     assert s["relP_max"] < TOL_P                       # covariance after the whole loop, every scene (observed 2e-11)
     assert 0.7 < s["oracle_accept_rate"] < 0.95        # the gate is really deciding at this multiplier
-    assert abs(s["diff_mean"]) < 4.0 and s["diff_std"] < 5.0, s      # observed -2.9 +- 4.1 against a threshold of ~225
-    assert s["disagreement_rate"] < 0.05, s            # observed 2.8 %
-    assert s["disagreement_margin_max"] < 16.0, s      # every disagreement sits within 4 sigma of the threshold (observed 10.8)
+    assert abs(s["diff_mean"]) < 0.5, s                # standard error of the mean over ~1100 planes: 0.12
+    assert abs(s["diff_in_state"]["mean"]) < 1.0 and abs(s["diff_out_of_state"]["mean"]) < 1.0, s
+    assert s["diff_std"] < 5.0, s                      # the rounding-decided rows themselves: ~sqrt(2 x 9) x 0.98
+    if "interbuild_band" in s:                         # the FMA build loads on this CPU
+        assert s["interbuild"]["std"] > 2.0, s         # the reference's own statistic moves between builds ...
+        assert s["interbuild_flips"] >= 1, s           # ... far enough to flip decisions
+        assert s["disagreements_outside_interbuild_band"] == 0, s
+        assert s["disagreement_rate"] < 2.0 * max(s["interbuild_flips"], 5) / s["planes"], s
+    else:
+        assert s["disagreement_margin_max"] < 16.0, s
+    assert s["disagreement_rate"] < 0.05, s
 
 
 @pytest.mark.parametrize("n", [5, 16, 31, 100, 197, 240, 256, 285, 287])
@@ -1905,6 +1914,85 @@ def test_tile_cholesky_with_border_row_matches_numpy(hiplib, n):
     Abad = A.copy()
     Abad[n // 2, n // 2] = -1.0
     assert ctx.debug_chol2(Abad, None)["rc"] == -3  # OVP_E_NOTSPD
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [40, 240, 285])
+def test_tile_cholesky_bad_and_dropped_pivots_terminate(hiplib, n):
+    """The role hand-over of k_chol2 spins on LDS counters: a pivot that is not positive (NaNs from there on) or one that is dropped
+    (pivot floor: the range part of the plane solve on a rank-deficient Gram) must not keep any wave from taking its steps.
+    Positions: first column, inside the first tile column, first column of a later tile, the last tile column and the very last
+    column - with and without the border row.  Not positive -> OVP_E_NOTSPD (and the call returns); dropped -> the factor of the
+    matrix with that direction removed, zero entry in z, against a numpy elimination with the same rule."""
+    rng = np.random.default_rng(1000 + n)
+    ctx = hiplib.Context(288, 30, 8)
+    M = rng.standard_normal((n, n + 7))
+    A = M @ M.T / n + 0.05 * np.eye(n)
+    b = rng.standard_normal(n)
+    for pos in sorted({0, 5, 16, 16 * ((n - 1) // 16), n - 3, n - 1}):
+        Abad = A.copy()
+        Abad[pos, pos] = -2.0
+        assert ctx.debug_chol2(Abad, None)["rc"] == -3, pos
+        assert ctx.debug_chol2(Abad, b)["rc"] == -3, pos
+    # rank-deficient positive semi-definite matrix: the directions completed at columns `null` are dropped
+    null = sorted({0, 7, 16, 16 * ((n - 1) // 16) + 1, n - 2, n - 1})
+    keep = [i for i in range(n) if i not in null]
+    B = rng.standard_normal((n + 3, n))
+    for c in null:  # column c = combination of the columns before it (column 0: zero)
+        B[:, c] = B[:, :c] @ rng.standard_normal(c) / max(c, 1) if c else 0.0
+    G = B.T @ B
+    d = np.sqrt(np.where(np.diag(G) > 0, np.diag(G), 1.0))
+    Gn = G / np.outer(d, d) + 1e-12 * np.eye(n)
+    bn = (B.T @ rng.standard_normal(n + 3)) / d
+
+    def chol_drop(Amat, rhs, floor):
+        Aw, bw = Amat.copy(), rhs.copy()
+        L, z, piv = np.zeros_like(Amat), np.zeros(len(rhs)), np.zeros(len(rhs))
+        for k in range(len(rhs)):
+            piv[k] = Aw[k, k]
+            if not (piv[k] >= floor):
+                continue
+            l = Aw[k:, k] / np.sqrt(piv[k])
+            L[k:, k] = l
+            Aw[k:, k:] -= np.outer(l, l)
+            z[k] = bw[k] / np.sqrt(piv[k])
+            bw[k:] -= l * z[k]
+        return L, z, piv
+
+    Lr, zr, pr = chol_drop(Gn, bn, 1e-5)
+    out = ctx.debug_chol2(Gn, bn, piv_floor=1e-5)
+    assert out["rc"] == 0
+    assert set(np.where(out["piv"] < 1e-5)[0]) == set(null) == set(np.where(pr < 1e-5)[0])
+    assert np.abs(out["piv"][keep] - pr[keep]).max() < 1e-10
+    assert np.abs(out["z"] - zr).max() < 1e-9 and np.abs(out["z"][null]).max() == 0.0
+    assert np.abs(out["L"][:n, :n][np.ix_(keep, keep)] - Lr[np.ix_(keep, keep)]).max() < 1e-9
+    ctx.close()
+
+
+def test_point_update_may_always_ask_for_the_plane_mask(hiplib, oracle):
+    """ovp_update_opts::skip_plane_used is valid behind EVERY ovp_msckf_plane_update of the batch: a frame without planes (nothing
+    consumed) and the flag left set in the options handed to
+    the plane loop itself (ignored there)."""
+    sc = make_scene(C=8, F=60, seed=4, n_planes=2, feats_per_plane=12, chi2_mult=99999.0)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    o = hiplib.opts_from_scene(sc)
+    o.skip_plane_used = 1
+    # (i) no planes in the batch
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    none = ctx.plane_update(o, sc.plane_id, np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0, dtype=np.int32))
+    assert none["rc"] == 0 and not none["used"].any()
+    pt = ctx.msckf_update(o)
+    assert pt["accepted"].sum() > 0.8 * sc.F
+    # (ii) the flag set in the plane loop's own options; the point update then skips exactly the consumed features
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    pl = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert pl["ok"].all() and pl["used"].sum() == 24
+    pt = ctx.msckf_update(o)
+    assert not pt["accepted"][pl["used"]].any() and pt["accepted"][~pl["used"]].sum() > 0.8 * (sc.F - 24)
     ctx.close()
 
 
