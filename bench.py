@@ -14,6 +14,8 @@ covariance and the pose tables are resident in HBM; every step starts from the s
              plane loop is sequential across planes, so every rank runs it on the whole frame (identical replicas, no
              collective); the free points are sharded over the ranks, ONE RCCL all-reduce sums the information pairs, every
              rank applies the identical update.  `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run).
+             `--workload config2 --gpus N` strong-scales the shape without planes (2000 point features split over the ranks) -
+             the part of the path that shards; the line carries the RCCL rank count and rank 0's time per stage.
 
 Prints ONE JSON line on rank 0."""
 from __future__ import annotations
@@ -117,22 +119,25 @@ class StepRunner:
         pt = ctx.msckf_update(self.opts_pts)
         return pl, pt
 
-    def step_sharded(self, rank, world):
+    def step_sharded(self, rank, world, timing=None):
         """Feature-sharded step through the functions of ov_plane_amd.dist that the gloo tests drive: replicated
-        plane loop, the free points split over the ranks, one RCCL all-reduce of the information pair on the context's stream."""
+        plane loop, the free points split over the ranks (one upload of the frame, index ranges + the device-side mask), one RCCL
+        all-reduce of the information pair on the context's stream."""
         from ov_plane_amd.dist import shard_bounds, sharded_plane_then_point_update, sharded_update
 
         sc, ctx = self.sc, self.ctx
         ctx.cov_set_device(self.P0.data_ptr(), sc.N, sc.N)
         ctx.state_upload(sc)
         if self.has_planes:
-            pl, pt, _ = sharded_plane_then_point_update(
+            pl, pt, mine = sharded_plane_then_point_update(
                 ctx, self.opts, lambda idx: ctx.batch_upload_scene(sc, idx), sc.F,
-                (sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id), rank=rank, world=world)
+                (sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id), rank=rank, world=world, timing=timing)
+            self.shard_size = len(mine)
             return pl, pt
         lo, hi = shard_bounds(sc.F, rank, world)
         ctx.batch_upload_scene(sc, np.arange(lo, hi))
-        return None, sharded_update(ctx, self.opts)
+        self.shard_size = hi - lo
+        return None, sharded_update(ctx, self.opts, timing=timing)
 
     def close(self):
         self.ctx.close()
@@ -327,6 +332,14 @@ def main():
         time_steps(torch, fn, max(5, min(args.steps, 20)), 0, barrier)
         k1_ms, k1_n = run.ctx.kernel_timer(enable=False, reset=False)
         c2_ms, c2_n = run.ctx.plane_kernel_timer(enable=False, reset=False)
+        stages = None
+        if world > 1:
+            # where a multi-GPU step spends its time (a pass of its own: the stages are separated by host synchronisations)
+            stages = {}
+            n_diag = 5
+            for _ in range(n_diag):
+                run.step_sharded(rank, world, timing=stages)
+            stages = {k: v / n_diag for k, v in stages.items()}
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -337,7 +350,7 @@ def main():
 
     if rank == 0:
         C = sc.C
-        n_pts_done = int(run.ctx.n_feats) if world > 1 else int((~pl["used"]).sum()) if pl is not None else sc.F
+        n_pts_done = int(run.shard_size) if world > 1 else int((~pl["used"]).sum()) if pl is not None else sc.F
         line = {
             "metric": "MSCKF+plane update-step features/sec at %d clones" % C,
             "value": value,
@@ -401,6 +414,14 @@ def main():
             }
             if "roofline" not in line:
                 line["roofline"] = line["roofline_point_kernel"]
+        if stages is not None:
+            line["multi_gpu"] = {
+                "rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
+                "rank0_stage_ms": stages,
+                "rank0_point_shard": int(run.shard_size),
+                "note": "stage times of rank 0 from a separate pass with a host synchronisation behind every stage (plane loop "
+                        "replicated on every rank; points_build = feature kernel + information pair of the rank's shard; "
+                        "allreduce = one RCCL all-reduce of (N+1) x ld f64; update = EKF update from the summed pair + results)"}
         if world == 1 and not args.no_extras:
             extras(line, capi, torch, args, local_rank, name)
         if world == 1 and not args.no_cpu_baseline:

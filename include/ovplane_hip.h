@@ -93,11 +93,15 @@ typedef struct {
   int reserved[3];
 } ovp_update_info;
 
+#define OVP_PLANE_MAX_SLAM 16 /* SLAM landmarks on ONE out-of-state plane handled by ovp_msckf_plane_update */
+
 /* ---- context --------------------------------------------------------------------------------- */
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create its own.
  * Sizes: n_state_max <= 700 (the feature kernels stage projector rows in LDS); states up to 288 columns take the register-
  * resident factorizations, larger ones the sub-state update (a batch may then touch at most 288 columns to stay fast);
- * ovp_msckf_plane_update / ovp_plane_init are offered up to 288 columns (OVP_E_CAPACITY beyond). */
+ * ovp_msckf_plane_update above 287 columns runs its loop on the columns the planes of the call involve (clones, calibration, the
+ * planes that are state variables, the SLAM landmarks on the others: at most 287 of them, OVP_E_CAPACITY beyond) and carries the
+ * rest of the state along; ovp_plane_init is offered up to 288 columns. */
 int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int n_feats_max, void *stream, ovp_ctx **out);
 int ovp_ctx_destroy(ovp_ctx *ctx);
 int ovp_sync(ovp_ctx *ctx);
@@ -121,6 +125,11 @@ int ovp_state_upload(ovp_ctx *ctx, const ovp_state_tables *st);
 int ovp_batch_upload(ovp_ctx *ctx, const ovp_feature_batch *host_batch);
 /* zero-copy: the pointers inside dev_batch are DEVICE pointers that stay valid until the next bind/upload */
 int ovp_batch_bind_device(ovp_ctx *ctx, const ovp_feature_batch *dev_batch);
+/* Restricts the POINT updates that follow (ovp_msckf_update / ovp_msckf_build_gate_gram_async) to the features [lo, hi) of the
+ * uploaded batch - the shard of one rank when the whole frame is resident on every GPU (the plane loop runs on the
+ * whole frame everywhere, the leftovers are split by index range, no second upload).  lo = hi = -1 lifts the restriction, lo >= hi
+ * >= 0 is an empty shard; every upload / bind lifts it. */
+int ovp_batch_set_range(ovp_ctx *ctx, int lo, int hi);
 
 /* ---- the update step ------------------------------------------------------------------------ */
 /* UpdaterMSCKF::update point-feature path (update/UpdaterMSCKF.cpp:671-814):
@@ -176,7 +185,7 @@ typedef struct {
   /* SLAM landmarks that lie on planes which are NOT in the state (update/UpdaterMSCKF.cpp:232-252), ovp_msckf_plane_update
    * only: each contributes one point-on-plane row whose feature Jacobian stays in the landmark's three state columns
    * (:545-552).  n_slam = 0 / NULL pointers when there are none. */
-  int n_slam;
+  int n_slam;                 /* at most OVP_PLANE_MAX_SLAM of them on one plane (OVP_E_CAPACITY beyond) */
   const int *slam_plane;      /* [n_slam] 1-based plane slot */
   const int *slam_state_id;   /* [n_slam] Type::id() of the landmark */
   const double *slam_p;       /* [n_slam*3] Landmark::get_xyz(false) */

@@ -113,7 +113,7 @@ class PlaneOptBatch(C.Structure):
 EXPORTS = [
     "ovp_ctx_create", "ovp_ctx_destroy", "ovp_sync", "ovp_version", "ovp_error_string", "ovp_cov_upload",
     "ovp_cov_download", "ovp_cov_set_device", "ovp_cov_marginal", "ovp_state_upload", "ovp_batch_upload",
-    "ovp_batch_bind_device", "ovp_msckf_update", "ovp_msckf_build_gate_gram_async", "ovp_gram_buffer",
+    "ovp_batch_bind_device", "ovp_batch_set_range", "ovp_msckf_update", "ovp_msckf_build_gate_gram_async", "ovp_gram_buffer",
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
@@ -335,6 +335,10 @@ class Context:
         if rc != 0 and raise_on_error:
             raise OvpError(rc, "ovp_msckf_update")
         return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
+
+    def batch_set_range(self, lo=-1, hi=-1):
+        """Point updates that follow take the features [lo, hi) of the uploaded batch only (-1, -1 = all of it)."""
+        _chk(lib().ovp_batch_set_range(self._h, int(lo), int(hi)), "ovp_batch_set_range")
 
     def build_gate_gram_async(self, opts: UpdateOpts):
         _chk(lib().ovp_msckf_build_gate_gram_async(self._h, C.byref(opts)), "ovp_msckf_build_gate_gram_async")

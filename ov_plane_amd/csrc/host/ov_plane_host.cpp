@@ -13,6 +13,7 @@ using namespace ov_type;
 namespace ov_plane {
 
 #define PRINT_ERROR(...) fprintf(stderr, __VA_ARGS__)
+#define PRINT_WARNING(...) fprintf(stderr, __VA_ARGS__)
 static void gpu_check(int rc, const char *what) {
   if (rc == 0) return;
   PRINT_ERROR("ov_plane(gpu): %s failed: %s\n", what, ovp_error_string(rc));
@@ -1003,7 +1004,15 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       for (int k = 0; k < NP; ++k) {
         auto itp = plane_slam_kept.find(used_planes[k]);
         if (itp == plane_slam_kept.end() || sid[k] >= 0) continue;
+        int n_on_plane = 0;
         for (size_t fid : itp->second) {
+          // the device loop takes OVP_PLANE_MAX_SLAM landmark rows per plane; a more crowded plane keeps the first ones (the
+          // others stay plain SLAM landmarks of this frame) instead of losing every plane constraint of the frame
+          if (++n_on_plane > OVP_PLANE_MAX_SLAM) {
+            PRINT_WARNING("UpdaterMSCKF::update() - plane %zu: more than %d SLAM landmarks, the rest is not constrained\n",
+                          used_planes[k], OVP_PLANE_MAX_SLAM);
+            break;
+          }
           auto lm = state->_features_SLAM.at(fid);
           double v[3], vf[3];
           lm->get_xyz(false, v);
@@ -1024,9 +1033,10 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       {
         const int rcp = ovp_msckf_plane_update(state->_gpu, &o, &pb, dxp.data(), pok.data(), nullptr, pdof.data(), fused.data());
         if (rcp == OVP_E_CAPACITY) {
-          // state above the plane loop's limit (288 columns): the regularities are not used in this update, every feature takes
-          // the point loop - the filter degrades to plain MSCKF instead of stopping
-          PRINT_ERROR("UpdaterMSCKF::update() - state too large for the plane constraints (%d columns), skipped\n", n);
+          // the planes of this frame involve more than 287 columns (clones + calibration + in-state planes + landmarks on the
+          // others; the state itself may be larger): the regularities are not used in this update, every feature takes the
+          // point loop - the filter degrades to plain MSCKF instead of stopping
+          PRINT_ERROR("UpdaterMSCKF::update() - the planes of this frame involve too many columns (state: %d), skipped\n", n);
           std::fill(pok.begin(), pok.end(), 0);
           std::fill(fused.begin(), fused.end(), 0);
         } else {

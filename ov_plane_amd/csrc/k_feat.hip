@@ -108,7 +108,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   OVP_STAMP(0);
   const bool valid = lane < n;
   // UpdaterMSCKF.cpp:94-96; features used by an accepted plane left feature_vec before the point loop (:657-666)
-  const bool feat_ok = (m >= 2) && (m <= OVP_MAX_MEAS_DEV) && !(p.skip && p.skip[f]);
+  const bool feat_ok = (m >= 2) && (m <= OVP_MAX_MEAS_DEV) && !(p.skip && p.skip[f]) && f >= p.range_lo && f < p.range_hi;
   const int* cidx = p.clone_idx + (size_t)f * p.max_meas;
   const int ci = cidx[valid ? a : 0];
   const int ida = p.clone_id[ci];

@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include "ovp_kernels.h"
 
-#define PA_MAXQ 16  // SLAM landmarks on one out-of-state plane handled per update
+#include "ovplane_hip.h"
+#define PA_MAXQ OVP_PLANE_MAX_SLAM  // SLAM landmarks on one out-of-state plane handled per update
 
 namespace ovp {
 
@@ -45,6 +46,8 @@ extern "C" {
 hipError_t ovp_launch_plane_assemble2(const ovp::PlaneAsm* a, hipStream_t stream);
 hipError_t ovp_launch_plane_dT(int n, const double* L0, int ld, const double* W, const double* b, double* Tbuf, size_t tstride,
                                const int* cur, double* crow, hipStream_t stream);
+hipError_t ovp_launch_plane_sub_accum(const double* res, const double* Ab, double* Asum, const double* dx, double* u, int ns, int ld,
+                                      hipStream_t stream);
 hipError_t ovp_launch_select_copy(double* dst, const double* buf, size_t stride, const int* cur, int n, int ld, int sym,
                                   hipStream_t stream);
 }

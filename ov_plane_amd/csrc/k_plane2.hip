@@ -342,9 +342,45 @@ __global__ __launch_bounds__(256) void k_select_copy(double* __restrict__ dst, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Plane loop on a sub-state (state above the tile factorization's limit, ovp_api.hip: plane_update_substate).  The loop runs on the
+// ns involved columns s; the correction of the WHOLE state for an accepted plane k is dx_k = P0[:, s] u_k with
+//     u_k = (I + A^(k) P0ss)^-1 b_k = b_k - A^(k) dx_k[s],        A^(k) = sum of the pairs accepted so far including plane k,
+// (push-through identity; no solve with P0ss).  One block per row r of the pair: Asum[r, :] += A_k[r, :], u[r] = b_k[r] - Asum[r, :] dx.
+// A rejected plane (res[1] == 0) leaves Asum alone and gets u = 0.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plane_sub_accum(const double* __restrict__ res, const double* __restrict__ Ab,
+                                                          double* __restrict__ Asum, const double* __restrict__ dx,
+                                                          double* __restrict__ u, int ns, int ld) {
+  const int r = blockIdx.x, t = threadIdx.x;
+  __shared__ double red[256];
+  if (!(res[1] > 0.5)) {
+    if (t == 0) u[r] = 0.0;
+    return;
+  }
+  double s = 0.0;
+  for (int c = t; c < ns; c += 256) {
+    const double a = Asum[(size_t)r * ld + c] + Ab[(size_t)r * ld + c];
+    Asum[(size_t)r * ld + c] = a;
+    s = fma(a, dx[c], s);
+  }
+  red[t] = s;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (t < w) red[t] += red[t + w];
+    __syncthreads();
+  }
+  if (t == 0) u[r] = Ab[(size_t)ns * ld + r] - red[0];
+}
+
 }  // namespace ovp
 
 extern "C" {
+hipError_t ovp_launch_plane_sub_accum(const double* res, const double* Ab, double* Asum, const double* dx, double* u, int ns, int ld,
+                                      hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_plane_sub_accum, dim3(ns), dim3(256), 0, stream, res, Ab, Asum, dx, u, ns, ld);
+  return hipGetLastError();
+}
 hipError_t ovp_launch_plane_assemble2(const ovp::PlaneAsm* a, hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_plane_assemble2, dim3(a->n + 1), dim3(ovp::PA_THREADS), 0, stream, *a);
   return hipGetLastError();

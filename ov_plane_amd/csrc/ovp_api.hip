@@ -208,9 +208,15 @@ struct ovp_ctx {
   int *pl_cur = nullptr, *pl_perm = nullptr;
   unsigned* pl_range_done = nullptr;
   unsigned pl_seq = 0;
+  int range_lo = -1, range_hi = -1;   // ovp_batch_set_range (-1, -1 = whole batch)
   unsigned char* pl_used = nullptr;   // [f_max] features consumed by accepted planes (device)
   bool pl_used_valid = false;         // pl_used refers to the uploaded batch
   int pl2_cap = 0;
+  // plane loop on a sub-state (n above the tile factorization's limit): accumulated pair, u rows, remapped id tables
+  double *pl_Asum = nullptr, *pl_U = nullptr;
+  int pl_U_cap = 0;
+  void* pl_sub_tab = nullptr;
+  bool pl_sub_active = false;
   void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
   size_t pl_stage_cap = 0;
   void* pl_hres = nullptr;            // pinned host copy of the plane results
@@ -688,6 +694,19 @@ extern "C" int ovp_batch_upload(ovp_ctx* c, const ovp_feature_batch* b) {
   c->max_meas = b->max_meas;
   c->have_batch = true;
   c->pl_used_valid = false;
+  c->range_lo = c->range_hi = -1;
+  return 0;
+}
+extern "C" int ovp_batch_set_range(ovp_ctx* c, int lo, int hi) {
+  if (!c) return OVP_E_ARG;
+  if (!c->have_batch) return OVP_E_STATE;
+  if (lo == -1 && hi == -1) {
+    c->range_lo = c->range_hi = -1;
+    return 0;
+  }
+  if (lo < 0 || hi < 0 || hi > c->n_feats) return OVP_E_ARG;
+  c->range_lo = lo;
+  c->range_hi = hi < lo ? lo : hi;
   return 0;
 }
 extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
@@ -704,6 +723,7 @@ extern "C" int ovp_batch_bind_device(ovp_ctx* c, const ovp_feature_batch* b) {
   c->max_meas = b->max_meas;
   c->have_batch = true;
   c->pl_used_valid = false;
+  c->range_lo = c->range_hi = -1;
   return 0;
 }
 
@@ -893,6 +913,8 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   fp.accept = (unsigned char*)c->h_res_block_dev + ((char*)c->accept - (char*)c->res_block);
   fp.dbg_cycles = c->dbg_cycles;
   fp.skip = nullptr;
+  fp.range_lo = c->range_lo < 0 ? 0 : c->range_lo;
+  fp.range_hi = c->range_lo < 0 ? 0x7fffffff : c->range_hi;
   if (o->skip_plane_used) {
     if (!c->pl_used_valid || !c->pl_used) return OVP_E_STATE;  // no plane update ran on this batch
     fp.skip = c->pl_used;
@@ -1329,6 +1351,9 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
 // through one pinned staging block, the results come back through one pinned block read after a single stream sync.
 struct PlaneJobH { int pl, start, nf, rows_total, rows_live, rows_u, n_involved, in_state, sid, n_inv_cols, ns_pl; double thr; };
 
+extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
+                                      uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used);
+
 static int ensure_pl_used(ovp_ctx* c) {
   if (!c->pl_used) HIPCHK(hipMalloc((void**)&c->pl_used, (size_t)c->f_max + 16));
   return 0;
@@ -1367,6 +1392,148 @@ static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_byt
   return 0;
 }
 
+// ---- the plane loop of a state above the tile factorization's limit (update/UpdaterMSCKF.cpp:413-649 has no limit) -------------
+// A plane's rows touch the clones, the calibration, its own closest point when it is a state variable and the SLAM landmarks lying
+// on it (out-of-state planes): the union s of these columns over the planes of the call is what the whole sequential loop can
+// change through the information it adds.  With P0 the covariance at the start and ns = |s| <= the factorization's limit the loop
+// runs UNCHANGED on the marginal P0[s, s] - same kernels, the state tables addressed through remapped column ids - and the rest of
+// the state follows from the push-through identity (k_plane_sub_accum for dx, the point path's  P -= G (A - A Pss+ A) G^T  for P).
+static int plane_update_substate(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
+                                 uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
+  const int n = c->n, ld = c->ld, NP = pb->n_planes, C = c->fp.n_clones;
+  const int n_slam = pb->n_slam > 0 ? pb->n_slam : 0;
+  if (n_slam > 0 && (!pb->slam_plane || !pb->slam_state_id || !pb->slam_p || !pb->slam_p_fej)) return OVP_E_ARG;
+  std::vector<char> inv((size_t)n, 0);
+  auto mark = [&](int id, int sz) -> bool {
+    if (id < 0 || id + sz > n) return false;
+    for (int k = 0; k < sz; ++k) inv[id + k] = 1;
+    return true;
+  };
+  for (int i = 0; i < C; ++i)
+    if (!mark(c->h_clone_id[i], 6)) return OVP_E_ARG;
+  if (o->do_calib_camera_pose && !mark(c->calib_id, 6)) return OVP_E_ARG;
+  if (o->do_calib_camera_intrinsics && !mark(c->intr_id, 8)) return OVP_E_ARG;
+  for (int k = 0; k < NP; ++k)
+    if (pb->plane_state_id[k] >= 0 && !mark(pb->plane_state_id[k], 3)) return OVP_E_ARG;
+  for (int q = 0; q < n_slam; ++q) {
+    if (pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP) return OVP_E_ARG;
+    if (pb->plane_state_id[pb->slam_plane[q] - 1] < 0 && !mark(pb->slam_state_id[q], 3)) return OVP_E_ARG;
+  }
+  std::vector<int> ids, pos((size_t)n, -1);
+  for (int col = 0; col < n; ++col)
+    if (inv[col]) {
+      pos[col] = (int)ids.size();
+      ids.push_back(col);
+    }
+  const int ns = (int)ids.size();
+  if (ns > ovp_chol2_max_n()) return OVP_E_CAPACITY;  // the planes of this call involve more columns than one factorization holds
+  hipStream_t s = c->stream;
+  // ---- buffers ----
+  if (!c->sub_ids) HIPCHK(hipMalloc((void**)&c->sub_ids, sizeof(int) * (OVP_TILECHOL_NMAX + 16)));
+  if (!c->pl_Asum) HIPCHK(dalloc(&c->pl_Asum, (size_t)c->n_max * ld));
+  if (NP > c->pl_U_cap) {
+    if (c->pl_U) hipFree(c->pl_U);
+    c->pl_U_cap = NP + 8;
+    HIPCHK(dalloc(&c->pl_U, (size_t)c->pl_U_cap * ld));
+  }
+  const size_t tab_bytes = sizeof(int) * (size_t)(c->c_max + 16) + sizeof(ovp::ColMap) * (size_t)c->n_max;
+  if (!c->pl_sub_tab) HIPCHK(hipMalloc(&c->pl_sub_tab, tab_bytes));
+  // ---- remapped tables ----
+  std::vector<char> tab(tab_bytes, 0);
+  int* t_clone = (int*)tab.data();
+  ovp::ColMap* t_cm = (ovp::ColMap*)(tab.data() + sizeof(int) * (size_t)(c->c_max + 16));
+  std::vector<int> clone_sub(C);
+  for (int i = 0; i < C; ++i) {
+    clone_sub[i] = t_clone[i] = pos[c->h_clone_id[i]];
+    for (int k = 0; k < 6; ++k) {
+      ovp::ColMap& m = t_cm[clone_sub[i] + k];
+      m.kind = 1;
+      m.idx = i;
+      m.off = k;
+    }
+  }
+  const int calib_sub = (c->calib_id >= 0 && c->calib_id + 6 <= n && pos[c->calib_id] >= 0) ? pos[c->calib_id] : -1;
+  const int intr_sub = (c->intr_id >= 0 && c->intr_id + 8 <= n && pos[c->intr_id] >= 0) ? pos[c->intr_id] : -1;
+  if (calib_sub >= 0)
+    for (int k = 0; k < 6; ++k) {
+      t_cm[calib_sub + k].kind = 2;
+      t_cm[calib_sub + k].idx = k;
+    }
+  if (intr_sub >= 0)
+    for (int k = 0; k < 8; ++k) {
+      t_cm[intr_sub + k].kind = 2;
+      t_cm[intr_sub + k].idx = 6 + k;
+    }
+  std::vector<int> sid_sub(NP > 0 ? NP : 1, -1), slam_sub(n_slam > 0 ? n_slam : 1, 0);
+  for (int k = 0; k < NP; ++k) sid_sub[k] = pb->plane_state_id[k] >= 0 ? pos[pb->plane_state_id[k]] : -1;
+  std::vector<int> slam_keep_plane(n_slam > 0 ? n_slam : 1, 0);
+  for (int q = 0; q < n_slam; ++q) {
+    // a landmark listed on a plane that IS in the state takes no part in the loop (UpdaterMSCKF.cpp:240-241): park it on plane 0
+    const bool used = pb->plane_state_id[pb->slam_plane[q] - 1] < 0;
+    slam_sub[q] = used ? pos[pb->slam_state_id[q]] : 0;
+    slam_keep_plane[q] = pb->slam_plane[q];
+  }
+  HIPCHK(hipMemcpyAsync(c->sub_ids, ids.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->pl_sub_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(ovp_launch_gather_block(c->P, ld, c->sub_ids, ns, c->P_tmp, ld, s));
+  HIPCHK(hipMemsetAsync(c->pl_Asum, 0, sizeof(double) * (size_t)ns * ld, s));
+  HIPCHK(hipMemsetAsync(c->pl_U, 0, sizeof(double) * (size_t)NP * ld, s));
+  HIPCHK(hipStreamSynchronize(s));  // ids / tab are temporaries of this frame
+  // ---- the loop on the sub-state ----
+  ovp_plane_batch pbs = *pb;
+  pbs.plane_state_id = sid_sub.data();
+  pbs.slam_state_id = slam_sub.data();
+  std::vector<double> dx_sub((size_t)ns * (NP > 0 ? NP : 1), 0.0);
+  struct Saved {
+    int n, calib_id, intr_id;
+    double* P;
+    int* clone_id;
+    ovp::ColMap* colmap;
+    const int* fp_clone_id;
+    std::vector<int> h_clone_id;
+  } sv{c->n, c->calib_id, c->intr_id, c->P, c->clone_id, c->colmap, c->fp.clone_id, c->h_clone_id};
+  c->n = ns;
+  c->P = c->P_tmp;
+  c->calib_id = calib_sub;
+  c->intr_id = intr_sub;
+  c->clone_id = (int*)c->pl_sub_tab;
+  c->fp.clone_id = c->clone_id;
+  c->colmap = (ovp::ColMap*)((char*)c->pl_sub_tab + sizeof(int) * (size_t)(c->c_max + 16));
+  c->h_clone_id = clone_sub;
+  c->pl_sub_active = true;
+  const int rc = ovp_msckf_plane_update(c, o, &pbs, dx_sub.data(), plane_ok, plane_chi2, plane_dof, feat_used);
+  c->pl_sub_active = false;
+  double* Pss_new = c->P;  // = P_tmp: the marginal after the loop
+  c->n = sv.n;
+  c->P = sv.P;
+  c->calib_id = sv.calib_id;
+  c->intr_id = sv.intr_id;
+  c->clone_id = sv.clone_id;
+  c->fp.clone_id = sv.fp_clone_id;
+  c->colmap = sv.colmap;
+  c->h_clone_id = sv.h_clone_id;
+  if (rc) return rc;  // the resident covariance was not touched
+  // ---- the rest of the state ----
+  // Lambda = Asum - Asum Pss+ Asum ;  P -= G Lambda G^T ;  dx_k = G u_k     (G = P0[:, s] in Y)
+  HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, c->pl_Asum, ld, Pss_new, ld, c->W1, ld, 0, 0, s));
+  HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, c->W1, ld, c->pl_Asum, ld, c->T, ld, 0, 1, s));
+  HIPCHK(ovp_launch_mat_sub(c->pl_Asum, c->T, c->T, ns, ns, ld, s));
+  HIPCHK(ovp_launch_gather_cols(c->P, ld, c->sub_ids, n, ns, c->Y, ld, s));
+  if (dx_planes && NP > 0) {
+    // rows = planes: DX (NP x n) = U (NP x ns) G^T
+    HIPCHK(ovp_launch_gemm4(0, 1, NP, n, ns, c->pl_U, ld, c->Y, ld, c->Lt, ld, 0, 0, s));
+    HIPCHK(hipMemcpy2DAsync(dx_planes, sizeof(double) * n, c->Lt, sizeof(double) * ld, sizeof(double) * n, NP, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(ovp_launch_gemm4(0, 0, n, ns, ns, c->Y, ld, c->T, ld, c->W1, ld, 0, 0, s));
+  HIPCHK(ovp_launch_gemm4(0, 1, n, n, ns, c->W1, ld, c->Y, ld, c->L, ld, 0, 1, s));
+  HIPCHK(ovp_launch_sub_sym(c->P, c->L, n, ld, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (dx_planes)  // the involved entries straight from the loop (the product above agrees with them to rounding)
+    for (int k = 0; k < NP; ++k)
+      for (int i = 0; i < ns; ++i) dx_planes[(size_t)k * n + ids[i]] = dx_sub[(size_t)k * ns + i];
+  return 0;
+}
+
 extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
                                       uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
   if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
@@ -1381,6 +1548,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   int rcu = ensure_pl_used(c);
   if (rcu) return rcu;
   static const bool force_v1 = getenv("OVP_PLANE_V1") != nullptr;
+  if (n > ovp_chol2_max_n() && !force_v1 && !c->pl_sub_active)
+    return plane_update_substate(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
   if (n > ovp_chol2_max_n() || force_v1) {
     // first generation (no device-side mask of its own): the host mask it reports is mirrored into pl_used
     std::vector<uint8_t> used_h((size_t)(F > 0 ? F : 1), 0);
@@ -1413,6 +1582,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (rc) return rc;
   ovp::FeatParams fp = c->fp;
   fp.skip = nullptr;
+  fp.range_lo = 0;  // the plane loop always walks the whole batch
+  fp.range_hi = 0x7fffffff;
   // ---- host-side grouping (update/UpdaterMSCKF.cpp:204-229) ----
   std::vector<PlaneJobH> jobs;
   std::vector<int> featlist;
@@ -1694,6 +1865,9 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     }
     HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
     if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev[2 * jn + 1], s));
+    if (c->pl_sub_active)
+      HIPCHK(ovp_launch_plane_sub_accum(c->pl_res + 4 * j.pl, c->Ab, c->pl_Asum, c->pl_dx + (size_t)j.pl * n,
+                                        c->pl_U + (size_t)j.pl * ld, n, ld, s));
     if (pl_stamps && jn == NJ - 1) {
       long long h[16 * 32];
       HIPCHK(hipStreamSynchronize(s));

@@ -56,6 +56,7 @@ struct FeatParams {
   double* chi2;
   unsigned char* accept;
   const unsigned char* skip;  // optional [n_feats]: 1 = feature was consumed by an accepted plane (not part of this update)
+  int range_lo, range_hi;     // features outside [range_lo, range_hi) are not part of this update (another rank's shard)
   long long* dbg_cycles;  // optional [n_feats][8] phase stamps (diagnostics)
 };
 

@@ -54,6 +54,12 @@ class CpuContext:
     def batch_upload_scene(self, sc, feats=None):
         self.feats = np.arange(sc.F) if feats is None else np.asarray(feats, dtype=np.int64)
         self.n_feats = len(self.feats)
+        self._range = None
+        self._used = None
+        self.uploads = getattr(self, "uploads", 0) + 1
+
+    def batch_set_range(self, lo=-1, hi=-1):
+        self._range = None if (lo == -1 and hi == -1) else (int(lo), int(hi))
 
     def plane_update(self, opts, plane_of_feat, cp, cp_fej, plane_state_id):
         from oracle import pyoracle
@@ -61,18 +67,27 @@ class CpuContext:
         ref = pyoracle.msckf_plane_update(self.sc)
         for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
             self.sc[k] = ref[k]
+        self._used = ref["used"]
         return dict(ok=ref["plane_ok"], used=ref["used"], chi2=ref["plane_chi2"], dof=ref["plane_rows"])
 
     def build_gate_gram_async(self, opts):
         from oracle import pyoracle
 
         N = self.sc.N
-        if self.n_feats:
-            g = pyoracle.msckf_point_update(self.sc, feats=self.feats)  # the gate only reads the prior: decisions are per feature
-            self._acc, self._chi2 = g["accepted"], g["chi2"]
-            A, b = _gram_np(self.sc, self.feats, self._acc)
+        # what the device walks: the uploaded batch, inside the rank's index range, minus the features of accepted planes
+        take = np.ones(self.n_feats, dtype=bool)
+        if self._range is not None:
+            take &= (np.arange(self.n_feats) >= self._range[0]) & (np.arange(self.n_feats) < self._range[1])
+        if getattr(opts, "skip_plane_used", 0):
+            assert self._used is not None
+            take &= ~self._used[self.feats]
+        self._acc, self._chi2 = np.zeros(self.n_feats, dtype=bool), np.zeros(self.n_feats)
+        if take.any():
+            sel = self.feats[take]
+            g = pyoracle.msckf_point_update(self.sc, feats=sel)  # the gate only reads the prior: decisions are per feature
+            self._acc[take], self._chi2[take] = g["accepted"], g["chi2"]
+            A, b = _gram_np(self.sc, sel, g["accepted"])
         else:
-            self._acc, self._chi2 = np.zeros(0, dtype=bool), np.zeros(0)
             A, b = np.zeros((N, N)), np.zeros(N)
         self._Ab = torch.from_numpy(np.concatenate([A.ravel(), b]))
 
@@ -133,6 +148,8 @@ def _worker(rank, world, port, planes, q):
                 ctx, opts, lambda idx: ctx.batch_upload_scene(sc, idx), sc.F, (sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id),
                 rank=rank, world=world)
             used = pl["used"]
+            assert ctx.uploads == 1                      # the frame crosses the bus once per step
+            assert not pt["accepted"][used].any()        # point results are indexed like the frame
         else:
             lo, hi = shard_bounds(sc.F, rank, world)
             mine = np.arange(lo, hi)

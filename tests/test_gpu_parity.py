@@ -515,6 +515,70 @@ def test_plane_loop_with_slam_landmarks_matches_oracle(hiplib, oracle, kw, k_row
     ctx.close()
 
 
+@pytest.mark.parametrize("kw,k_rows", [
+    (dict(C=11, F=200, seed=31, n_planes=16, feats_per_plane=10, planes_in_state_frac=0.75, n_slam=60, chi2_mult=99999.0), 0),
+    (dict(C=11, F=200, seed=32, n_planes=16, feats_per_plane=10, planes_in_state_frac=0.75, n_slam=60, chi2_mult=1.0), 6),
+    (dict(C=30, F=300, seed=33, n_planes=6, feats_per_plane=40, planes_in_state_frac=0.5, n_slam=27, chi2_mult=1.0), 0),
+])
+def test_plane_loop_above_the_factorization_limit_runs_on_the_involved_columns(hiplib, oracle, kw, k_rows):
+    """update/UpdaterMSCKF.cpp:413-649 has no size limit.  States above the tile factorization (config/sim shape: 11 clones, 60
+    landmarks, 12 planes in the state -> N = 312; 30 clones + 27 landmarks -> N = 300) run the plane loop on the columns its planes
+    involve and carry the rest along (ovp_api.hip: plane_update_substate): decisions (the oracle's imposed where the gate is
+    active), state corrections - also of the variables no plane touches (IMU state, free landmarks) -, covariance of the whole
+    state against the oracle."""
+    from ov_plane_amd.synth import slam_rows_on_planes
+
+    sc = make_scene(**kw)
+    assert sc.N > 288
+    slam = slam_rows_on_planes(sc, k_rows) if k_rows else None
+    ref = oracle.msckf_plane_update(sc, slam=slam)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id, slam=slam,
+                           force_decision=ref["plane_ok"].astype(np.uint8))
+    assert out["rc"] == 0
+    assert (out["ok"] == ref["plane_ok"]).all() and ref["plane_ok"].sum() >= 3
+    assert (out["used"] == ref["used"]).all() and (out["dof"] == ref["plane_rows"]).all()
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    if slam is not None:
+        lm = slam["p"].copy()
+        for k in range(out["dx"].shape[0]):
+            if out["ok"][k]:
+                for q, i in enumerate(slam["id"]):
+                    lm[q] += out["dx"][k][i:i + 3]
+        assert np.abs(lm - ref["slam_p"]).max() < TOL_DX
+    P1 = ctx.cov_download()
+    assert relP(P1, ref["P"]) < TOL_P
+    # the variables outside the loop's columns move through their correlation with them: dx = P0[:, s] P0[s, s]^-1 dx[s]
+    inv = np.zeros(sc.N, dtype=bool)
+    for i in range(sc.C):
+        inv[sc.ids["clones"][i]: sc.ids["clones"][i] + 6] = True
+    inv[16:30] = True
+    for sid in sc.plane_state_id:
+        if sid >= 0:
+            inv[sid:sid + 3] = True
+    if slam is not None:
+        for i in slam["id"]:
+            inv[i:i + 3] = True
+    assert inv.sum() <= 287 and (~inv).sum() >= 15
+    Gs = sc.P[:, inv] @ np.linalg.inv(sc.P[np.ix_(inv, inv)])
+    for k in np.where(out["ok"])[0]:
+        full = Gs @ out["dx"][k][inv]
+        assert np.abs(full - out["dx"][k]).max() < 1e-8 * max(1.0, np.abs(full).max()), k
+    assert np.abs(out["dx"][~out["ok"]]).max(initial=0.0) == 0.0
+    # and the point update that follows works on the whole state as before
+    o = hiplib.opts_from_scene(sc)
+    o.chi2_multiplier = 1.0
+    o.skip_plane_used = 1
+    upd = ctx.msckf_update(o)
+    assert not upd["accepted"][out["used"]].any() and upd["accepted"][~out["used"]].mean() > 0.8
+    ctx.close()
+
+
 @pytest.mark.parametrize("kw", [
     dict(C=11, F=120, seed=71, chi2_mult=1.0),                                           # points only
     dict(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0),         # planes + points
@@ -1993,6 +2057,65 @@ def test_point_update_may_always_ask_for_the_plane_mask(hiplib, oracle):
     assert pl["ok"].all() and pl["used"].sum() == 24
     pt = ctx.msckf_update(o)
     assert not pt["accepted"][pl["used"]].any() and pt["accepted"][~pl["used"]].sum() > 0.8 * (sc.F - 24)
+    ctx.close()
+
+
+def test_index_range_shards_of_the_leftovers_sum_to_the_unsharded_pair(hiplib):
+    """Multi-GPU split of SURVEY 8(e) on one device: the frame is uploaded once, the plane loop runs on all of it, and each rank's
+    share of the leftovers is an index range (ovp_batch_set_range via dist.leftover_range) with the consumed features masked on the
+    device.  The information pairs of three such shards sum to the pair of the unsharded point update, the accept decisions are
+    the same feature by feature, an empty shard contributes nothing."""
+    from ov_plane_amd.dist import leftover_range
+
+    sc = make_scene(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    o = hiplib.opts_from_scene(sc)
+    ld = ((sc.N + 15) // 16) * 16
+
+    def after_planes():
+        ctx.cov_upload(sc.P)
+        ctx.state_upload(sc)
+        ctx.batch_upload_scene(sc)
+        return ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+
+    pl = after_planes()
+    assert pl["used"].sum() == 80
+    op = hiplib.opts_from_scene(sc)
+    op.chi2_multiplier = 1.0
+    op.skip_plane_used = 1
+    ctx.build_gate_gram_async(op)
+    ctx.sync()
+    Ab_all = ctx.debug_read("Ab", (sc.N + 1, ld)).copy()
+    full = ctx.msckf_update(op)
+    Ab_sum = np.zeros_like(Ab_all)
+    acc = np.zeros(sc.F, dtype=bool)
+    seen = []
+    world = 3
+    for rank in range(world):
+        pl_r = after_planes()
+        assert (pl_r["used"] == pl["used"]).all()
+        lo, hi, mine = leftover_range(pl_r["used"], rank, world)
+        ctx.batch_set_range(lo, hi)
+        ctx.build_gate_gram_async(op)
+        ctx.sync()
+        Ab_sum += ctx.debug_read("Ab", (sc.N + 1, ld))
+        ctx.ekf_update_from_gram_async()
+        r = ctx.fetch_results()
+        assert not r["accepted"][np.setdiff1d(np.arange(sc.F), mine)].any()
+        acc |= r["accepted"]
+        seen.append(mine)
+    assert (np.sort(np.concatenate(seen)) == np.where(~pl["used"])[0]).all()
+    assert (acc == full["accepted"]).all()
+    scale = np.abs(Ab_all).max()
+    assert np.abs(Ab_sum - Ab_all).max() < 1e-11 * scale
+    # an empty shard (more ranks than leftovers would give one): zero pair, nothing accepted
+    after_planes()
+    ctx.batch_set_range(5, 5)
+    ctx.build_gate_gram_async(op)
+    ctx.sync()
+    assert np.abs(ctx.debug_read("Ab", (sc.N + 1, ld))).max() == 0.0
+    ctx.ekf_update_from_gram_async()
+    assert not ctx.fetch_results()["accepted"].any()
     ctx.close()
 
 
