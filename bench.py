@@ -195,8 +195,22 @@ def cpu_baseline(sc, name, budget_feats=None):
     t_plane, t_pts = t1 - t0, t2 - t1
     # point part scaled to the whole rest only when a prefix was asked for (it is linear in the feature count up to the final update)
     t_full = t_plane + t_pts * (len(rest) / max(len(sample), 1))
+    # all-cores ceiling of the same step (BASELINE.md "CPU-omp"): point update spread over the host cores (OpenMP over the features,
+    # TSQR compression), plane loop unchanged - it is sequential across planes and its retained rows decide its gate
+    omp = None
+    try:
+        t3 = time.perf_counter()
+        po = pyoracle.msckf_point_update_omp(sc2, feats=sample)
+        t4 = time.perf_counter()
+        omp = dict(threads=int(po["threads"]), point_update_ms=1e3 * (t4 - t3), ms_per_step=1e3 * (t_plane + (t4 - t3) * (len(rest) / max(len(sample), 1))),
+                   same_accept_set=bool((po["accepted"] == pt["accepted"]).all()),
+                   dx_diff_vs_1_thread=float(np.abs(po["dx"] - pt["dx"]).max()),
+                   note="oracle/ovp_oracle_omp.c: per-feature stage as an OpenMP loop, compression as a two-level Householder TSQR; "
+                        "plane loop on one thread (sequential by definition)")
+    except Exception as e:  # noqa: BLE001
+        print("all-cores CPU leg skipped: %r" % (e,), file=sys.stderr)
     obj = dict(
-        value=sc.F / t_full, unit="features/s", cores=1, kind="port", cpu=cpu_model(), host_cores=os.cpu_count(),
+        value=sc.F / t_full, unit="features/s", cores=1, kind="port", cpu=cpu_model(), host_cores=os.cpu_count(), all_cores=omp,
         sample="oracle/ovp_oracle.c (reference loop order, 1 thread) on the %s frame: plane loop over all planes %.2f s (%d features "
                "consumed, %d planes accepted), point update on %d of the %d remaining features %.2f s (feat system %.2f s, "
                "compression %.2f s, update %.3f s)%s" % (name, t_plane, n_used, int(pl["plane_ok"].sum()) if pl else 0, len(sample),

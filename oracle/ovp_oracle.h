@@ -154,6 +154,12 @@ void ovo_apply_dx(const ovo_state *st, int n_planes, const int *plane_state_id, 
 int ovo_msckf_plane_update(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat,
                            int n_planes, const double *cp, const double *cp_fej, const int *plane_state_id, double *P,
                            ovo_state_values *val, uint8_t *used, uint8_t *plane_ok, double *plane_chi2, int *plane_rows);
+/* All-cores variant of ovo_msckf_point_update (oracle/ovp_oracle_omp.c: OpenMP over the features, TSQR compression).  Context for
+ * the speed-up figure only (the reference runs on one thread); n_threads <= 0 = OpenMP's default.  Returns the thread count used
+ * (> 0) or < 0 on error. */
+int ovo_msckf_point_update_omp(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, double *P, double *dx,
+                               uint8_t *accepted, double *chi2, double *timings, int n_threads);
+
 /* + SLAM landmarks on planes that are not in the state (update/UpdaterMSCKF.cpp:232-252): slam_plane [n_slam] 1-based plane,
  * slam_id [n_slam] Type::id(), slam_p [n_slam*3] values (updated in place), slam_p_fej [n_slam*3] */
 int ovo_msckf_plane_update_slam(const ovo_opts *o, const ovo_state *st, const ovo_feats *fb, const int *plane_of_feat,

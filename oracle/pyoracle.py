@@ -57,7 +57,7 @@ class OvoFeats(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libovp_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ovp_oracle.c", "ovp_oracle.h", "ovp_planefit.c", "ovp_planefit.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ovp_oracle.c", "ovp_oracle.h", "ovp_planefit.c", "ovp_planefit.h", "ovp_oracle_omp.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -225,6 +225,21 @@ def msckf_point_update(sc, feats=None):
     rc = lib().ovo_msckf_point_update(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), _dp(dx),
                                       acc.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _dp(tim))
     return dict(dx=dx, P=np.ascontiguousarray(P), accepted=acc.astype(bool), chi2=chi2, rows_compressed=rc, timings=tim)
+
+
+def msckf_point_update_omp(sc, feats=None, threads=0):
+    """All-cores variant (ovo_msckf_point_update_omp).  Returns dict(dx, P, accepted, chi2, threads, timings)."""
+    pk = Packed(sc, feats)
+    P = np.asfortranarray(sc.P.copy())
+    N = sc.N
+    F = pk.feats.n_feats
+    dx = np.zeros(N)
+    acc = np.zeros(F, dtype=np.uint8)
+    chi2 = np.zeros(F)
+    tim = np.zeros(4)
+    rc = lib().ovo_msckf_point_update_omp(C.byref(pk.opts), C.byref(pk.state), C.byref(pk.feats), _dp(P), _dp(dx),
+                                          acc.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(chi2), _dp(tim), C.c_int(int(threads)))
+    return dict(dx=dx, P=np.ascontiguousarray(P), accepted=acc.astype(bool), chi2=chi2, threads=rc, timings=tim)
 
 
 class OvoStateValues(C.Structure):

@@ -26,6 +26,11 @@ struct Chol2Job {
   double* piv_out;      // [n] pivots before the square root
   long long* stamps;    // optional [nt + 1][8] cycle stamps of wave 0 (diagnostics)
   int dbg;              // timing experiments only: 1 = skip the fused elimination, 2 = skip the trailing MFMAs, 4 = skip LDS staging
+  // mode 1 on two workgroups (k_chol2.hip, chol2_factor): tile columns < split_h on block 0, the rest on block 2
+  int split_h;          // 0 = one workgroup
+  double* xbuf;         // [split_h][nt][256] exported panel tiles (rows >= split_h), row-major
+  unsigned* xflag;      // [nt] <- xseq when the panel of that step is exported
+  unsigned xseq;
 };
 
 // per-plane arguments of the plane loop's solve (modes 1 and 2)
@@ -39,6 +44,11 @@ struct PlaneSolve {
   int force;                // ovp_plane_batch::force_decision (0 / 1), anything else = the gate decides
   double tol_strict, tol_loose;
   double* res_out;          // [4]: chi2, accept, rank deficiency, pr
+  // split factorization: [0] part A's share of |z|^2, [1] its pivot verdict; y blocks of part B's columns; sequence words
+  // ([0] <- seq: xzz valid, [1] <- 2 seq + accept: decision taken, xy valid)
+  double* xzz;
+  double* xy;
+  unsigned* xsync;
   // solution and commit
   const double* L0;         // factor of the covariance at the start of the loop, dense lower triangular
   int ld0;

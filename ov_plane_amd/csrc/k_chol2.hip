@@ -164,6 +164,25 @@ __device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* 
   return acc;
 }
 
+// 16-byte global store with agent scope (sc1): written through the XCD's L2, visible to the other XCDs once vmcnt has drained
+__device__ __forceinline__ void c2_store_through(double* p, dbl2_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void c2_store_through_sys(double* p, dbl2_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// the matching loads (no wait inside: the caller issues all of them, then waits once)
+__device__ __forceinline__ dbl2_t c2_load_through(const double* p) {
+  dbl2_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ dbl2_t c2_load_through_sys(const double* p) {
+  dbl2_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 #define C2_WSYNC()                                           \
   do {                                                       \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
@@ -264,8 +283,8 @@ __device__ __forceinline__ double c2_elem(const Chol2Job& J, const double* __res
 }
 
 // tile slots of tile wave tw in tile column k (contiguous: the tiles are dealt out cyclically over the column-major list)
-__device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int& hi) {
-  const int cs = k * nt - (k * (k - 1)) / 2;  // list index of tile (k, k)
+__device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int& hi, int off = 0) {
+  const int cs = k * nt - (k * (k - 1)) / 2 - off;  // list index of tile (k, k) (off = list index of the first owned tile)
   const int ce = cs + (nt - k) - 1;           // ... of tile (nt - 1, k)
   lo = (cs - tw + C2_TW - 1) / C2_TW;         // smallest s with s * C2_TW + tw >= cs   (cs >= 0, tw < C2_TW)
   hi = (ce - tw >= 0) ? (ce - tw) / C2_TW : -1;
@@ -284,13 +303,21 @@ __device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int
 // elimination waves' paths too (they merge with the tile waves' behind every role-specific block) and spills them around the
 // dependent chains: 376 spill instructions and 190 KB of scratch writes per launch that carried dead values.  In the ROLE 0
 // instantiation the tile array does not exist (143 spill instructions, all on the tile waves' side; no measurable change in time).
+//
+// Column split (plane loop, J.split_h > 0): the workgroup owns the tile columns [cl, ch) only.  Part A (cl = 0, ch = h) takes the
+// steps 0 .. h-1 on its trapezoid and EXPORTS the rows >= h of every finished panel to global memory (J.xbuf, one flag per step);
+// part B (cl = h, ch = nt) imports them - its first h steps are "remote": the elimination waves copy the panel instead of
+// computing it, the tile waves run the trailing update on the trailing triangle - and then factorizes that triangle itself.
+// Part A's trailing updates shrink to its own columns (its steps become pivot-chain bound), part B's run on a CU of their own,
+// and no workgroup holds more than ~2/3 of the tiles (n = 285: 126 of 171 - they fit the registers again).
 template <int MAXSLOT, int ROLE>
 __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& S, double4_t (&tile)[MAXSLOT], int (&ti)[MAXSLOT],
-                                             int (&tj)[MAXSLOT], int& bad_out) {
+                                             int (&tj)[MAXSLOT], int& bad_out, const int cl, const int ch) {
   const int n = J.n;
   const int nb = J.brow ? n + 1 : n;  // bordered dimension
   const int nt = (nb + 15) >> 4;
-  const int ntiles = nt * (nt + 1) / 2;
+  const int loff = cl * nt - (cl * (cl - 1)) / 2;                    // list index (full triangle) of the first owned tile
+  const int ntiles = (ch * nt - (ch * (ch - 1)) / 2) - loff;         // owned tiles: columns cl .. ch-1, column-major
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
@@ -298,6 +325,9 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   // n a multiple of 16: the border row is alone in the last tile row.  Its tiles are panel tiles of every step (that is where z
   // comes from), but the last tile COLUMN holds nothing anybody reads (the corner of the border) - its step is not taken.
   const int nst = (nb > n && rb == 0) ? nt - 1 : nt;
+  const int kend = ch < nst ? ch : nst;     // steps this workgroup takes part in
+  const bool exporting = ch < nst;          // part A of a split factorization
+  const int xst = (J.dbg >> 4) & 3, xld = (J.dbg >> 6) & 3;  // experiment: flavour of the export stores / import loads
   int* cnt_col = S.cnt;
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
@@ -323,11 +353,50 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
     const int ew = wave, g = lr, r = lc;
     const double floor_eff = J.floor_scale ? J.piv_floor * (*J.floor_scale) : J.piv_floor;
     __builtin_amdgcn_s_setprio(3);  // the serial chain: its instructions go first, the tile waves fill the gaps
-    for (int k = 0; k < nst; ++k) {
+    for (int k = 0; k < kend; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
       if (ew == 0) C2_STAMP(k, 0);
-      c2_wait_ge(cnt_col, C2_TW * (k + 1), S.cnt + 6);  // column k is in LDS
+      if (k < cl) {
+        // ---- remote step: panel k comes from part A (rows cl .. nt-1, row-major 16 x 16 tiles in J.xbuf) ----
+        {
+          int spins = 0;
+          while (__hip_atomic_load(J.xflag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != J.xseq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 19)) {
+              __hip_atomic_store(S.cnt + 6, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              break;
+            }
+          }
+        }
+        if (k >= 2) c2_wait_ge(cnt_trail, C2_TW * (k - 1), S.cnt + 6);  // the tile waves are done with panel k - 2 (same buffer)
+        const double* xk = J.xbuf + (size_t)k * nt * 256;
+        const int row = lane >> 2, c4 = (lane & 3) * 4;
+        for (int i = cl + ew; i < nt; i += C2_EW) {
+          const double* src = xk + (size_t)i * 256 + (c4 >> 1) * 32 + 2 * row;  // columns c4, c4+1 | c4+2, c4+3 of row `row`
+          dbl2_t v0, v1;
+          if (xld == 1) {
+            v0 = c2_load_through(src);
+            v1 = c2_load_through(src + 32);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+          } else if (xld == 2) {
+            v0 = c2_load_through_sys(src);
+            v1 = c2_load_through_sys(src + 32);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+          } else {
+            v0 = *reinterpret_cast<const dbl2_t*>(src);
+            v1 = *reinterpret_cast<const dbl2_t*>(src + 32);
+          }
+          dbl2_t* dst = reinterpret_cast<dbl2_t*>(pbk + i * C2_TSZ + row * C2_TS + c4);
+          dst[0] = v0;
+          dst[1] = v1;
+        }
+        c2_signal(cnt_panel, lane);
+        if (ew == 0) C2_STAMP(k, 3);
+        continue;
+      }
+      c2_wait_ge(cnt_col, C2_TW * (k - cl + 1), S.cnt + 6);  // column k is in LDS
       if (ew == 0) C2_STAMP(k, 1);
+      bool flushed = false;
       // panel tiles k+1 .. nt-1 are dealt out over (elimination wave, DPP row): 16 per pass, a second pass only when the
       // column has 17 of them (bordered dimension 273..288, first column)
       for (int base = 0; base == 0 || k + 1 + base < nt; base += 4 * C2_EW) {
@@ -352,10 +421,32 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           dbl2_t* pw = has_p ? reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS) : nullptr;
           if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, floor_eff, pw) || bad;
           if (ew == 0) C2_STAMP(k, 2);
+          if (exporting && xst != 0 && !flushed) {  // (wave-uniform)
+            // the exports of the PREVIOUS step have long reached memory: confirming that here costs nothing, whereas waiting for
+            // this step's stores (a memory round trip, 3 - 5 K cycles) would sit on the elimination chain
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c2_signal(S.cnt + 5, lane);
+            flushed = true;
+          }
           if (has_p) {
             if (my_i == tb && r == rb && nb > n) {
 #pragma unroll
               for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
+            }
+            if (exporting && my_i >= ch && !(J.dbg & 256)) {  // rows part B needs: the finished panel tile, row r of it from this lane
+
+              // written THROUGH the L2 (agent scope): an agent-scope release fence here instead (write-back of the whole L2 +
+              // wait) cost 3.3 - 5 K cycles per step on the elimination chain
+              // tile layout in xbuf: element (r, 2q + e) at q * 32 + 2 r + e - the 16 lanes of a DPP row write 256 contiguous bytes
+              // per instruction (whole lines; lane-major rows were 64 sixteen-byte pieces in 64 lines, 4 K cycles per step)
+              double* xw = J.xbuf + ((size_t)k * nt + my_i) * 256 + 2 * r;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const dbl2_t pv = dbl2_t{p[2 * q], p[2 * q + 1]};
+                if (xst == 1) c2_store_through(xw + 32 * q, pv);
+                else if (xst == 2) c2_store_through_sys(xw + 32 * q, pv);
+                else *reinterpret_cast<dbl2_t*>(xw + 32 * q) = pv;
+              }
             }
           }
           if (first && ew == 0 && g == 0) {
@@ -370,8 +461,31 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           }
         }
       }
+      if (exporting && xst == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (exporting && xst != 0 && !flushed) {  // (a wave without exported rows in this step still confirms the previous one)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c2_signal(S.cnt + 5, lane);
+      }
       c2_signal(cnt_panel, lane);
+      if (exporting && ew == 0) {
+        // in the gap in front of the next column
+        if (xst == 0) {
+          c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // every elimination wave has fenced: panel k is published
+          if (lane == 0) __hip_atomic_store(J.xflag + k, J.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (k > 0) {
+          c2_wait_ge(S.cnt + 5, C2_EW * (k + 1), S.cnt + 6);  // every wave has seen its exports of step k - 1 complete
+          if (lane == 0) __hip_atomic_store(J.xflag + k - 1, J.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       if (ew == 0) C2_STAMP(k, 3);
+    }
+    if (exporting && xst != 0) {  // the last step's exports: the one memory round trip that is waited for
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      c2_signal(S.cnt + 5, lane);
+      if (ew == 0) {
+        c2_wait_ge(S.cnt + 5, C2_EW * (kend + 1), S.cnt + 6);
+        if (lane == 0) __hip_atomic_store(J.xflag + kend - 1, J.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   } else {
@@ -395,7 +509,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
     };
     {
       const double* Abase = J.A + (J.sel ? (size_t)((*J.sel) ^ J.sel_xor) * J.sel_stride : (size_t)0);
-      int jj = 0, cstart = 0;
+      int jj = cl, cstart = 0;
       constexpr int SC0 = MAXSLOT < 3 ? MAXSLOT : 3;  // slots that can hold tiles of column 0 (nt <= 18 < 3 * C2_TW)
       auto load_slot = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -448,28 +562,31 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (tw == 0) C2_STAMP(0, 13);
       sfor<SC0>(patch_slot);
       if (tw == 0) C2_STAMP(0, 14);
-      // column 0: diagonal block and panel tiles go to LDS
-      sfor<SC0>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (ti[s] >= 0 && tj[s] == 0) {
-          if (ti[s] == 0) put_rowmajor(S.Dbuf, tile[s]);
-          else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
-        }
-      });
-      c2_signal(cnt_col, lane);
+      if (cl == 0) {
+        // column 0: diagonal block and panel tiles go to LDS
+        sfor<SC0>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (ti[s] >= 0 && tj[s] == 0) {
+            if (ti[s] == 0) put_rowmajor(S.Dbuf, tile[s]);
+            else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
+          }
+        });
+        c2_signal(cnt_col, lane);
+      }
       if (tw == 0) C2_STAMP(0, 15);
       // the rest of the triangle
       sfor<MAXSLOT - SC0>([&](auto sc) { load_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
       sfor<MAXSLOT - SC0>([&](auto sc) { patch_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
     }
-    for (int k = 0; k < nst; ++k) {
+    for (int k = 0; k < kend; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
       double* pbn = S.PB + ((k + 1) & 1) * nt * C2_TSZ;
-      int lo, hi, lo1 = 0, hi1 = -1;
+      int lo = 0, hi = -1, lo1 = 0, hi1 = -1;
+      const bool next_own = (k + 1 >= cl) && (k + 1 < kend);  // column k + 1 is this workgroup's to publish
       // per-step opaque copies: otherwise the LDS address arithmetic of every slot is hoisted out of the step loop and spills
       int lc_k = lc, lr_k = lr;
       asm volatile("" : "+v"(lc_k), "+v"(lr_k));
-      c2_col_slots(k, nt, tw, lo, hi);
+      if (k >= cl) c2_col_slots(k, nt, tw, lo, hi, loff);
       auto put_rowmajor_k = [&](double* buf, const double4_t& t) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) buf[(lr_k + 4 * v) * C2_TS + lc_k] = t[v];
@@ -480,11 +597,11 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         for (int v = 0; v < 4; ++v) t[v] = buf[(lr_k + 4 * v) * C2_TS + lc_k];
         return t;
       };
-      if (k + 1 < nst) c2_col_slots(k + 1, nt, tw, lo1, hi1);
+      if (next_own) c2_col_slots(k + 1, nt, tw, lo1, hi1, loff);
       if (tw == 0) C2_STAMP(k, 8);
       c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // panel k (and L_kk) are in LDS
       if (tw == 0) C2_STAMP(k, 9);
-      if (k + 1 < nst) {
+      if (next_own) {
         // the next column is what the elimination waves wait for: above the other tile waves' trailing updates until it is out
         __builtin_amdgcn_s_setprio(2);
         // ---- trailing update, column k + 1 first: it is handed to the elimination waves while the rest is updated ----
@@ -508,7 +625,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         constexpr int s = decltype(sc)::value;
         tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
       });
-      if (k + 1 < nst) {
+      if (k + 1 < nst && k + 1 < ch) {  // owned tiles in columns behind k + 1 (a remote step that is not the last: all of them)
         slot_range<MAXSLOT>(hi1 + 1 > lo1 ? hi1 + 1 : lo1, s_last, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
           if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
@@ -537,7 +654,11 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
 // 16-column substitution chain in between: 29 us at 16 tile columns).
 template <int MAXSLOT, int ROLE>
 __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt, const double4_t (&tile)[MAXSLOT],
-                                                const int (&ti)[MAXSLOT], const int (&tj)[MAXSLOT], long long* stamps = nullptr) {
+                                                const int (&ti)[MAXSLOT], const int (&tj)[MAXSLOT], long long* stamps = nullptr,
+                                                int k_hi = -1, int k_lo = 0) {
+  // Split factorization: this workgroup holds the tile columns [k_lo, k_hi) and runs that part of the recurrence; the y blocks
+  // k_hi .. nt-1 were computed by the other part and are in S.ybuf already.
+  if (k_hi < 0) k_hi = nt;
 #define BS_STAMP(kk, i)                                                                       \
   do {                                                                                        \
     if (stamps && lane == 0) stamps[(kk) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
@@ -552,7 +673,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
                                                 // empty column may run ahead of the others, a single running count would not
                                                 // say WHOSE partial sums are in
   BS_STAMP(nt, 3);
-  if (tid == 0) *cnt_y = 0;
+  if (tid == 0) *cnt_y = nt - k_hi;  // y blocks known from the start
   if (tid < 32) cnt_s[tid] = 0;
   // ---- preparation ----
   if constexpr (ROLE == 1) {
@@ -565,7 +686,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
       }
     });
   } else {
-    for (int k = wave * 4 + lr; k < nt; k += 4 * C2_EW) {
+    for (int k = k_lo + wave * 4 + lr; k < k_hi; k += 4 * C2_EW) {
       double* blk = S.Dsave + k * C2_TSZ;
       // lane r holds row r of L_kk (one batch of 16-byte LDS reads); lane c builds column c of X = L_kk^-1 by forward
       // substitution, x_i = (delta_ic - sum_{j<i} L_ij x_j) / L_ii, with L_ij taken from lane i INSIDE the FMA (DPP row
@@ -614,7 +735,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
   if (wave == 0) {
     // ---- the chain ----
     const int r = lc;
-    double y = 0.0;
+    double y = k_hi < nt ? S.ybuf[16 * k_hi + r] : 0.0;
     double sd[16], di[16];
     // operands of a step are loaded into the registers the previous step has just finished with: the sub-diagonal tile right
     // after the first product, the inverse block right after the second (a second register set for a full prefetch made the
@@ -630,9 +751,9 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
 #pragma unroll
       for (int c = 0; c < 16; ++c) di[c] = dblk[c * C2_TS];
     };
-    load_sd(nt - 1);
-    load_di(nt - 1);
-    for (int k = nt - 1; k >= 0; --k) {
+    load_sd(k_hi - 1);
+    load_di(k_hi - 1);
+    for (int k = k_hi - 1; k >= k_lo; --k) {
       BS_STAMP(k, 4);
       // right-hand side, counter and partial sums in one batch of LDS reads in front of the first product, which does not need
       // them (a wave's LDS operations complete in order: sums read behind a counter that shows everybody are at least that new)
@@ -718,7 +839,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
     // into the unrolled tile sequence once per column, as the factorization does, cost ~17 scalar branches per column here.)
     const int tw = wave - C2_EW;
     int cur = nt;       // column whose partial sum is being accumulated (nt = none yet)
-    int pub = 0;        // y blocks known to be published
+    int pub = nt - k_hi;  // y blocks known to be published
     double part = 0.0;
     bool any = false;   // the wave owns a tile (i >= cur + 2) of column cur
     auto flush_to = [&](int jnew) {  // closes column cur (a wave without tiles in a column says nothing: wave 0 knows how many
@@ -777,9 +898,9 @@ struct Chol2Shared {  // workgroup variables both role instantiations of the bod
 };
 
 template <int MAXSLOT, int ROLE>
-__device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& ps, double* lds, Chol2Shared& sh) {
-  const int n = J.n;
-  const int nb = J.brow ? n + 1 : n;
+__device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve& ps, double* lds, Chol2Shared& sh) {
+  const int n = J0_.n;
+  const int nb = J0_.brow ? n + 1 : n;
   const int nt = (nb + 15) >> 4;
   const Chol2Lds S = chol2_carve(lds, nt);
   constexpr int NS = ROLE == 1 ? MAXSLOT : 1;  // tile registers exist on the tile waves only
@@ -790,7 +911,13 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
   int& sh_ok = sh.ok;
   double& sh_zz = sh.zz;
   if (threadIdx.x == 0) sh_bad = 0;
-  chol2_factor<NS, ROLE>(J, S, tile, ti, tj, bad);
+  // split factorization of the plane update (see chol2_factor): block 0 = part A (tile columns < h), block 2 = part B
+  const int part = (J0_.mode == 1 && J0_.split_h > 0) ? (blockIdx.x == 2 ? 1 : 0) : -1;
+  const int c_lo = part == 1 ? J0_.split_h : 0, c_hi = part == 0 ? J0_.split_h : nt;
+  Chol2Job Jl = J0_;
+  if (part == 1 && Jl.stamps) Jl.stamps += 16 * 32;  // diagnostics: part B stamps into the second half
+  const Chol2Job& J = Jl;
+  chol2_factor<NS, ROLE>(J, S, tile, ti, tj, bad, c_lo, c_hi);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
@@ -883,12 +1010,42 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
     double zz = 0.0;
     for (int i = lane; i < n; i += 64) zz = fma(S.zbuf[i], S.zbuf[i], zz);
     zz = wave_sum(zz);
-    if (lane == 0) {
+    if (lane == 0 && part == 0) {
+      // part A: its share of |z|^2 and the verdict on its pivots go to part B, which decides; then wait for the decision
+      ps.xzz[0] = zz;
+      ps.xzz[1] = (double)bad;
+      __hip_atomic_store(ps.xsync, ps.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      unsigned v = 0u;
+      bool timed_out = false;
+      while (((v = __hip_atomic_load(ps.xsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (ps.seq & 0x7fffffffu)) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 19)) {
+          timed_out = true;
+          break;
+        }
+      }
+      if (timed_out && J.flag) atomicOr(J.flag, 2);
+      sh_zz = zz;
+      sh_ok = (!timed_out && (v & 1u)) ? 1 : 0;
+    } else if (lane == 0) {
       // the other workgroup publishes pr and the rank; both take the same time, this wait is short.  Bounded (~0.3 s): HIP gives
       // no forward-progress guarantee between two workgroups of a grid (CU masking down to one CU, a scheduler that starts block
       // 1 only when block 0 retires) - then the plane is rejected and the call fails with OVP_E_TIMEOUT instead of hanging.
       int spins = 0;
       bool timed_out = false;
+      if (part == 1) {  // the other half of |z|^2
+        while (__hip_atomic_load(ps.xsync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 19)) {
+            timed_out = true;
+            break;
+          }
+        }
+        zz += ps.xzz[0];
+        bad |= (int)ps.xzz[1];
+        spins = 0;
+      }
       while (__hip_atomic_load(ps.range_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 18)) {
@@ -919,14 +1076,48 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
       ps.res_out[3] = pr;
       sh_zz = zz;
       sh_ok = ok ? 1 : 0;
+      if (part == 1 && !ok)  // part A is waiting for the decision
+        __hip_atomic_store(ps.xsync + 1, (ps.seq & 0x7fffffffu) << 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
   if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
   M1_STAMP(1);
 
-  chol2_backsolve<NS, ROLE>(S, n, (n + 15) >> 4, tile, ti, tj);
+  const int ntn = (n + 15) >> 4;           // tile rows of the n x n part
+  const int h_bs = part >= 0 ? (J.split_h < ntn ? J.split_h : ntn) : 0;
+  if (part == 0)  // y blocks of part B's columns (published before its decision)
+    for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) S.ybuf[i] = ps.xy[i];
+  chol2_backsolve<NS, ROLE>(S, n, ntn, tile, ti, tj, nullptr, part == 0 ? h_bs : ntn, part == 1 ? h_bs : 0);
   M1_STAMP(2);
+  if (part == 1) {
+    // ---- part B ends here: its y blocks and the decision go to part A, its share of the factor to the buffers behind the loop ----
+    for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) ps.xy[i] = S.ybuf[i];
+    __syncthreads();
+    if (tid == 0) {
+      const bool fine = S.cnt[6] == 0;  // no hand-over of the back substitution timed out
+      if (!fine) {
+        if (J.flag) atomicOr(J.flag, 2);
+        ps.res_out[1] = 0.0;
+      }
+      __hip_atomic_store(ps.xsync + 1, ((ps.seq & 0x7fffffffu) << 1) | (fine ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ps.cond && ps.emit && S.cnt[6] == 0) {
+      if constexpr (ROLE == 1) {
+        sfor<MAXSLOT>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
+        });
+      } else {
+        for (int e = 256 * h_bs + tid; e < ntn * 256; e += C2_EW * 64) {
+          const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
+          const int gr = 16 * k + i, gc = 16 * k + c;
+          ps.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
+        }
+      }
+    }
+    return;
+  }
   // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
   double* dxs = S.zbuf;  // z is no longer needed
@@ -1022,8 +1213,8 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J, const PlaneSolve& 
         });
       } else {
         // inverses of the diagonal blocks (the back substitution left them in S.Dsave), identity at / behind the border row
-        const int ntn = (n + 15) >> 4;
-        for (int e = tid; e < ntn * 256; e += C2_EW * 64) {
+        // (a split factorization: part B wrote the blocks of its columns)
+        for (int e = tid; e < (part == 0 ? h_bs : ntn) * 256; e += C2_EW * 64) {
           const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
           const int gr = 16 * k + i, gc = 16 * k + c;
           ps.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
@@ -1038,7 +1229,7 @@ template <int MAXSLOT>
 __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, const Chol2Job J1, const PlaneSolve ps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ Chol2Shared sh;
-  const Chol2Job& J = blockIdx.x == 0 ? J0 : J1;
+  const Chol2Job& J = blockIdx.x == 1 ? J1 : J0;  // block 2 = part B of a split plane update (same job as block 0)
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // both instantiations execute the same sequence of workgroup barriers
   if (wave < C2_EW) chol2_body<MAXSLOT, 0>(J, ps, lds, sh);
@@ -1068,25 +1259,39 @@ hipError_t ovp_launch_max_diag(const double* A, int n, int ld, double* out, hipS
   return hipGetLastError();
 }
 
-int ovp_chol2_max_n(void) { return 16 * 18 - 1; }  // bordered dimension n + 1 <= 272 (17 tile rows, 20 tile slots per wave)
+int ovp_chol2_max_n(void) { return 16 * 18 - 1; }  // bordered dimension n + 1 <= 288 (18 tile rows)
 
-// one workgroup (j1 == nullptr) or two (plane loop: update part and range part side by side)
+// one workgroup (j1 == nullptr), two (plane loop: update part and range part side by side) or three (the update part split over
+// two workgroups, j0->split_h > 0: block 0 = tile columns < split_h, block 2 = the rest)
 hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream) {
   using namespace ovp;
   auto ntof = [](const Chol2Job* j) { return ((j->brow ? j->n + 1 : j->n) + 15) / 16; };
   int nt = ntof(j0);
-  if (j1 && ntof(j1) > nt) nt = ntof(j1);
-  const int slots = (nt * (nt + 1) / 2 + C2_TW - 1) / C2_TW;
+  int tiles = nt * (nt + 1) / 2;
+  if (j0->split_h > 0) {
+    const int h = j0->split_h;
+    if (!j1 || !ps || j0->mode != 1 || h >= nt || !j0->xbuf || !j0->xflag || !ps->xzz || !ps->xy || !ps->xsync) return hipErrorInvalidValue;
+    const int ta = h * nt - (h * (h - 1)) / 2;
+    tiles = ta > tiles - ta ? ta : tiles - ta;
+  }
+  if (j1) {
+    const int nt1 = ntof(j1);
+    if (nt1 * (nt1 + 1) / 2 > tiles) tiles = nt1 * (nt1 + 1) / 2;
+    if (nt1 > nt) nt = nt1;
+  }
+  const int slots = (tiles + C2_TW - 1) / C2_TW;
   const size_t shmem = (size_t)chol2_lds_doubles(nt) * sizeof(double);
   Chol2Job dummy = *j0;
   PlaneSolve psd = PlaneSolve();
   const Chol2Job& b = j1 ? *j1 : dummy;
   const PlaneSolve& p = ps ? *ps : psd;
-  const dim3 grid(j1 ? 2 : 1), block(C2_WAVES * 64);
+  const dim3 grid(j0->split_h > 0 ? 3 : (j1 ? 2 : 1)), block(C2_WAVES * 64);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k_chol2<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<22>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1095,8 +1300,12 @@ hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, co
   }
   if (slots <= 10)
     hipLaunchKernelGGL((k_chol2<10>), grid, block, shmem, stream, *j0, b, p);
+  else if (slots <= 13)
+    hipLaunchKernelGGL((k_chol2<13>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 15)
     hipLaunchKernelGGL((k_chol2<15>), grid, block, shmem, stream, *j0, b, p);
+  else if (slots <= 16)
+    hipLaunchKernelGGL((k_chol2<16>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 17)
     hipLaunchKernelGGL((k_chol2<17>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 20)

@@ -213,6 +213,8 @@ struct ovp_ctx {
   bool pl_used_valid = false;         // pl_used refers to the uploaded batch
   int pl2_cap = 0;
   // plane loop on a sub-state (n above the tile factorization's limit): accumulated pair, u rows, remapped id tables
+  double *pl_xbuf = nullptr, *pl_xy = nullptr;   // split plane solve: exported panels, [xzz(2) | y blocks]
+  unsigned* pl_xflag = nullptr;                  // [32 step flags | 2 sync words]
   double *pl_Asum = nullptr, *pl_U = nullptr;
   int pl_U_cap = 0;
   void* pl_sub_tab = nullptr;
@@ -426,7 +428,8 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   void* dev[] = {c->P, c->P_tmp, c->Ab, c->L, c->W1, c->T, c->Lt, c->Y, c->res_block, c->ticket, c->uvn, c->tri_ok, c->state_block, c->batch_block,
                  c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
-                 c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage};
+                 c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage, c->pl_xbuf, c->pl_xy, c->pl_xflag, c->pl_Asum,
+                 c->pl_U, c->pl_sub_tab};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -1369,6 +1372,10 @@ static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_byt
     HIPCHK(hipMalloc((void**)&c->pl_cur, 16));
     HIPCHK(hipMalloc((void**)&c->pl_range_done, 16));
     HIPCHK(hipMemset(c->pl_range_done, 0, 16));
+    HIPCHK(dalloc(&c->pl_xbuf, (size_t)9 * 18 * 256));
+    HIPCHK(dalloc(&c->pl_xy, (size_t)c->n_max + 32));
+    HIPCHK(hipMalloc((void**)&c->pl_xflag, sizeof(unsigned) * 64));
+    HIPCHK(hipMemset(c->pl_xflag, 0, sizeof(unsigned) * 64));
   }
   if (NP > c->pl2_cap) {
     if (c->pl_perm) hipFree(c->pl_perm);
@@ -1811,6 +1818,31 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.scal = c->pl_scal;
     ps.range_done = c->pl_range_done;
     ps.seq = ++c->pl_seq;
+    {
+      // The update part on two workgroups: tile columns < h and the rest (k_chol2.hip).  Measured (r03): at 16 tile columns
+      // (N = 240) one workgroup is faster - its steps are bound by the pivot chain and the hand-over between the roles, not by
+      // the trailing update, and the split pays 1.3 K cycles of exports per step, a second gate hand-over and two back-substitution
+      // preambles (3.22 against 3.17 ms per config-3 plane loop); from 17 tile columns on (N > 255) the tile registers of one
+      // workgroup spill and the split wins (config 4, N = 285: 9.34 against 9.63 ms).  OVP_C2_SPLIT: 0 = never, h = forced.
+      const char* split_s = getenv("OVP_C2_SPLIT");  // (read per call: the tests switch it)
+      const int split_env = split_s ? atoi(split_s) : -1;
+      const int nb = n + 1, ntb = (nb + 15) / 16;
+      const int nst = (nb % 16 == 1) ? ntb - 1 : ntb;  // a border row alone in its tile row takes no step
+      int h = ntb >= 17 ? (nst + 1) / 2 : 0;
+      if (split_env >= 0) h = split_env < ntb - 1 ? split_env : 0;
+      if (h > 9) h = 9;  // pl_xbuf holds nine exported steps
+      // exports: system-scope write-through stores whose completion is confirmed a step later, imports: system-scope loads behind
+      // an agent acquire on the step's flag (the both-sides `sc0 sc1` form of MI355X_MICROARCH.md, inter-workgroup visibility)
+      static const int xmode = getenv("OVP_C2_XMODE") ? atoi(getenv("OVP_C2_XMODE")) : 10;  // store flavour + 4 * load flavour
+      j0.dbg |= (xmode & 31) << 4;
+      j0.split_h = h;
+      j0.xbuf = c->pl_xbuf;
+      j0.xflag = c->pl_xflag;
+      j0.xseq = ps.seq;
+      ps.xzz = c->pl_xy;
+      ps.xy = c->pl_xy + 16;
+      ps.xsync = c->pl_xflag + 32;
+    }
     ps.thr = j.thr;
     ps.rows_live = j.rows_live;
     ps.rows_u = j.rows_u;
@@ -1860,7 +1892,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     static const bool pl_stamps = getenv("OVP_PL_STAMPS") != nullptr;  // diagnostics: cycle stamps of the last plane's tail
     static long long* d_stamps = nullptr;
     if (pl_stamps) {
-      if (!d_stamps) HIPCHK(hipMalloc((void**)&d_stamps, sizeof(long long) * 16 * 32));
+      if (!d_stamps) HIPCHK(hipMalloc((void**)&d_stamps, sizeof(long long) * 2 * 16 * 32));
       j0.stamps = d_stamps;
     }
     HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
@@ -1869,13 +1901,32 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       HIPCHK(ovp_launch_plane_sub_accum(c->pl_res + 4 * j.pl, c->Ab, c->pl_Asum, c->pl_dx + (size_t)j.pl * n,
                                         c->pl_U + (size_t)j.pl * ld, n, ld, s));
     if (pl_stamps && jn == NJ - 1) {
-      long long h[16 * 32];
+      long long h[2 * 16 * 32];
       HIPCHK(hipStreamSynchronize(s));
       HIPCHK(hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost));
       const int ntb = (n + 1 + 15) / 16;
       const long long* e = h + (ntb + 1) * 16;
       fprintf(stderr, "[plane tail, cycles] factor %lld | gate %lld | back substitution %lld | dx = L0 y %lld | commit %lld\n",
               e[0] - h[0], e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]);
+      if (atoi(getenv("OVP_PL_STAMPS")) >= 2) {
+        // per step, both parts of a split factorization, relative to part A's first stamp: elimination wave 0 [start | column
+        // there | eliminated | signalled], tile wave 0 [start | panel there | next column updated | published | step done]
+        const long long t0 = h[0];
+        for (int part = 0; part < (j0.split_h > 0 ? 2 : 1); ++part) {
+          const long long* hp = h + part * 16 * 32;
+          fprintf(stderr, " part %c: prologue stamps %lld %lld %lld\n", part ? 'B' : 'A', hp[13] - t0, hp[14] - t0, hp[15] - t0);
+          for (int k = 0; k < ntb; ++k) {
+            const long long* q = hp + k * 16;
+            if (!q[0] && !q[8]) continue;
+            fprintf(stderr, "  k=%2d E %7lld %7lld %7lld %7lld | T %7lld %7lld %7lld %7lld %7lld\n", k, q[0] - t0, q[1] - t0, q[2] - t0,
+                    q[3] - t0, q[8] - t0, q[9] - t0, q[10] - t0, q[11] - t0, q[12] - t0);
+          }
+          const long long* m = hp + (ntb + 1) * 16;
+          fprintf(stderr, "  tail: factor done %lld, gate %lld, backsolve %lld, dx %lld, commit %lld\n", m[0] - t0, m[1] - t0, m[2] - t0,
+                  m[3] - t0, m[4] - t0);
+        }
+      }
+      HIPCHK(hipMemset(d_stamps, 0, sizeof(long long) * 2 * 16 * 32));
     }
   }
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----

@@ -2209,6 +2209,42 @@ def test_cov_initialize_one_call_matches_separate_calls_and_rejects_cleanly(hipl
     ctx.close()
 
 
+def test_plane_solve_on_two_workgroups_equals_the_one_workgroup_solve(hiplib, oracle):
+    """k_chol2's update part split by tile columns over two workgroups (exported panels, imported by the second one; gate in the
+    second, commit in the first; default from 17 tile columns on, i.e. BASELINE config 4) forced at N = 240 with two split points,
+    against the single-workgroup solve: same decisions at multiplier 1, corrections and covariance equal to rounding, and both
+    match the oracle."""
+    sc = make_scene(C=30, F=360, seed=21, n_planes=6, feats_per_plane=40, planes_in_state_frac=0.5, chi2_mult=1.0)
+    assert sc.N == 219 + 9
+    ref = oracle.msckf_plane_update(sc)
+    outs = []
+    old = os.environ.get("OVP_C2_SPLIT")
+    try:
+        for h in ("0", "5", "8"):
+            os.environ["OVP_C2_SPLIT"] = h
+            ctx = hiplib.Context(sc.N, sc.C, sc.F)
+            ctx.cov_upload(sc.P)
+            ctx.state_upload(sc)
+            ctx.batch_upload_scene(sc)
+            out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id,
+                                   force_decision=ref["plane_ok"].astype(np.uint8))
+            out["P"] = ctx.cov_download()
+            outs.append(out)
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("OVP_C2_SPLIT", None)
+        else:
+            os.environ["OVP_C2_SPLIT"] = old
+    base = outs[0]
+    assert relP(base["P"], ref["P"]) < TOL_P and ref["plane_ok"].sum() >= 3
+    for o in outs[1:]:
+        assert (o["ok"] == base["ok"]).all() and (o["used"] == base["used"]).all()
+        assert np.abs(o["chi2"] - base["chi2"]).max() < 1e-8 * np.abs(base["chi2"]).max()
+        assert np.abs(o["dx"] - base["dx"]).max() < 1e-11
+        assert relP(o["P"], base["P"]) < 1e-11
+
+
 def test_plane_loop_is_bitwise_repeatable(hiplib):
     """The wave roles of k_chol2 hand data over through LDS counters (factorization, back substitution): forty runs of the
     config-3 plane loop on the same frame must give the same bits (dx of every plane, decisions, covariance)."""

@@ -195,6 +195,27 @@ def test_oracle_reproduces_committed_fixtures_of_the_widened_rows(oracle):
                 assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), (name, k)
 
 
+def test_all_cores_variant_of_the_point_update_equals_the_sequential_one(oracle):
+    """oracle/ovp_oracle_omp.c (BASELINE.md "CPU-omp": OpenMP over the features, Householder TSQR instead of the sequential Givens
+    compression) against the one-thread restatement: same accept set, same correction and covariance to rounding - with planes'
+    leftovers as a feature subset and with every feature rejected."""
+    sc = make_scene(C=9, F=120, seed=14, chi2_mult=1.0)
+    sc.uv[:7] += (25.0 * np.random.default_rng(2).standard_normal(sc.uv[:7].shape)).astype(np.float32)  # gross outliers
+    a = oracle.msckf_point_update(sc)
+    for threads in (1, 3):
+        b = oracle.msckf_point_update_omp(sc, threads=threads)
+        assert b["threads"] == threads and (a["accepted"] == b["accepted"]).all() and not a["accepted"][:7].any()
+        assert np.abs(a["chi2"] - b["chi2"]).max() < 1e-9 * np.abs(a["chi2"]).max()
+        assert np.abs(a["dx"] - b["dx"]).max() < 1e-11 and np.abs(a["P"] - b["P"]).max() < 1e-12
+    sub = np.arange(5, 60, 3)
+    a = oracle.msckf_point_update(sc, feats=sub)
+    b = oracle.msckf_point_update_omp(sc, feats=sub, threads=2)
+    assert (a["accepted"] == b["accepted"]).all() and np.abs(a["dx"] - b["dx"]).max() < 1e-11
+    sc2 = make_scene(C=6, F=20, seed=15, chi2_mult=1e-9)
+    b = oracle.msckf_point_update_omp(sc2, threads=2)
+    assert not b["accepted"].any() and np.abs(b["dx"]).max() == 0.0 and np.abs(b["P"] - sc2.P).max() == 0.0
+
+
 def test_propagation_restatement_is_consistent():
     rng = np.random.default_rng(8)
     n = 20
