@@ -164,23 +164,24 @@ __device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* 
   return acc;
 }
 
-// 16-byte global store with agent scope (sc1): written through the XCD's L2, visible to the other XCDs once vmcnt has drained
-__device__ __forceinline__ void c2_store_through(double* p, dbl2_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
+// 16-byte global store with system scope (sc0 sc1): written through the XCD's L2, visible to the other XCDs once vmcnt has drained
+// (`sc1` alone is NOT enough across XCDs on this part: the consumer then reads stale tiles - tried, every flavour of load)
 __device__ __forceinline__ void c2_store_through_sys(double* p, dbl2_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // (s_nop: a VALU write of the data registers of a 16-byte store needs two wait states behind it - the hazard recognizer does
+  //  not see instructions inside an asm statement, and the compiler is free to reuse the registers at once: it did, for the address
+  //  of the next store)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-// the matching loads (no wait inside: the caller issues all of them, then waits once)
-__device__ __forceinline__ dbl2_t c2_load_through(const double* p) {
-  dbl2_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ dbl2_t c2_load_through_sys(const double* p) {
-  dbl2_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// the matching loads: two 16-byte pieces and the wait in ONE asm statement - the compiler does not know that an asm load
+// completes later, with the wait in a statement of its own it is free to copy the destination registers in between
+__device__ __forceinline__ void c2_load2_through_sys(const double* p0, const double* p1, dbl2_t& v0, dbl2_t& v1) {
+  asm volatile(
+      "global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v0), "=&v"(v1)
+      : "v"(p0), "v"(p1)
+      : "memory");
 }
 
 #define C2_WSYNC()                                           \
@@ -310,12 +311,14 @@ __device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int
 // computing it, the tile waves run the trailing update on the trailing triangle - and then factorizes that triangle itself.
 // Part A's trailing updates shrink to its own columns (its steps become pivot-chain bound), part B's run on a CU of their own,
 // and no workgroup holds more than ~2/3 of the tiles (n = 285: 126 of 171 - they fit the registers again).
-template <int MAXSLOT, int ROLE>
+// SPLIT = false compiles the ownership tests away (cl = 0, ch = nt): the single-workgroup kernel is the code it was before.
+template <int MAXSLOT, int ROLE, bool SPLIT>
 __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& S, double4_t (&tile)[MAXSLOT], int (&ti)[MAXSLOT],
-                                             int (&tj)[MAXSLOT], int& bad_out, const int cl, const int ch) {
+                                             int (&tj)[MAXSLOT], int& bad_out, const int cl_arg, const int ch_arg) {
   const int n = J.n;
   const int nb = J.brow ? n + 1 : n;  // bordered dimension
   const int nt = (nb + 15) >> 4;
+  const int cl = SPLIT ? cl_arg : 0, ch = SPLIT ? ch_arg : nt;
   const int loff = cl * nt - (cl * (cl - 1)) / 2;                    // list index (full triangle) of the first owned tile
   const int ntiles = (ch * nt - (ch * (ch - 1)) / 2) - loff;         // owned tiles: columns cl .. ch-1, column-major
   const int tid = threadIdx.x, lane = tid & 63;
@@ -326,8 +329,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   // comes from), but the last tile COLUMN holds nothing anybody reads (the corner of the border) - its step is not taken.
   const int nst = (nb > n && rb == 0) ? nt - 1 : nt;
   const int kend = ch < nst ? ch : nst;     // steps this workgroup takes part in
-  const bool exporting = ch < nst;          // part A of a split factorization
-  const int xst = (J.dbg >> 4) & 3, xld = (J.dbg >> 6) & 3;  // experiment: flavour of the export stores / import loads
+  const bool exporting = SPLIT && ch < nst;  // part A of a split factorization
   int* cnt_col = S.cnt;
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
@@ -373,19 +375,9 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         const int row = lane >> 2, c4 = (lane & 3) * 4;
         for (int i = cl + ew; i < nt; i += C2_EW) {
           const double* src = xk + (size_t)i * 256 + (c4 >> 1) * 32 + 2 * row;  // columns c4, c4+1 | c4+2, c4+3 of row `row`
+          // `sc0 sc1` on both sides (stores in part A, loads here): the form that needs no L2 write-back / invalidate
           dbl2_t v0, v1;
-          if (xld == 1) {
-            v0 = c2_load_through(src);
-            v1 = c2_load_through(src + 32);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
-          } else if (xld == 2) {
-            v0 = c2_load_through_sys(src);
-            v1 = c2_load_through_sys(src + 32);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
-          } else {
-            v0 = *reinterpret_cast<const dbl2_t*>(src);
-            v1 = *reinterpret_cast<const dbl2_t*>(src + 32);
-          }
+          c2_load2_through_sys(src, src + 32, v0, v1);
           dbl2_t* dst = reinterpret_cast<dbl2_t*>(pbk + i * C2_TSZ + row * C2_TS + c4);
           dst[0] = v0;
           dst[1] = v1;
@@ -421,7 +413,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           dbl2_t* pw = has_p ? reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS) : nullptr;
           if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, floor_eff, pw) || bad;
           if (ew == 0) C2_STAMP(k, 2);
-          if (exporting && xst != 0 && !flushed) {  // (wave-uniform)
+          if (exporting && !flushed) {  // (wave-uniform)
             // the exports of the PREVIOUS step have long reached memory: confirming that here costs nothing, whereas waiting for
             // this step's stores (a memory round trip, 3 - 5 K cycles) would sit on the elimination chain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -433,7 +425,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
 #pragma unroll
               for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
             }
-            if (exporting && my_i >= ch && !(J.dbg & 256)) {  // rows part B needs: the finished panel tile, row r of it from this lane
+            if (exporting && my_i >= ch) {  // rows part B needs: the finished panel tile, row r of it from this lane
 
               // written THROUGH the L2 (agent scope): an agent-scope release fence here instead (write-back of the whole L2 +
               // wait) cost 3.3 - 5 K cycles per step on the elimination chain
@@ -441,12 +433,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
               // per instruction (whole lines; lane-major rows were 64 sixteen-byte pieces in 64 lines, 4 K cycles per step)
               double* xw = J.xbuf + ((size_t)k * nt + my_i) * 256 + 2 * r;
 #pragma unroll
-              for (int q = 0; q < 8; ++q) {
-                const dbl2_t pv = dbl2_t{p[2 * q], p[2 * q + 1]};
-                if (xst == 1) c2_store_through(xw + 32 * q, pv);
-                else if (xst == 2) c2_store_through_sys(xw + 32 * q, pv);
-                else *reinterpret_cast<dbl2_t*>(xw + 32 * q) = pv;
-              }
+              for (int q = 0; q < 8; ++q) c2_store_through_sys(xw + 32 * q, dbl2_t{p[2 * q], p[2 * q + 1]});
             }
           }
           if (first && ew == 0 && g == 0) {
@@ -461,25 +448,21 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           }
         }
       }
-      if (exporting && xst == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (exporting && xst != 0 && !flushed) {  // (a wave without exported rows in this step still confirms the previous one)
+      if (exporting && !flushed) {  // (a wave without exported rows in this step still confirms the previous one)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         c2_signal(S.cnt + 5, lane);
       }
       c2_signal(cnt_panel, lane);
       if (exporting && ew == 0) {
         // in the gap in front of the next column
-        if (xst == 0) {
-          c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // every elimination wave has fenced: panel k is published
-          if (lane == 0) __hip_atomic_store(J.xflag + k, J.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (k > 0) {
+        if (k > 0) {
           c2_wait_ge(S.cnt + 5, C2_EW * (k + 1), S.cnt + 6);  // every wave has seen its exports of step k - 1 complete
           if (lane == 0) __hip_atomic_store(J.xflag + k - 1, J.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       if (ew == 0) C2_STAMP(k, 3);
     }
-    if (exporting && xst != 0) {  // the last step's exports: the one memory round trip that is waited for
+    if (exporting) {  // the last step's exports: the one memory round trip that is waited for
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       c2_signal(S.cnt + 5, lane);
       if (ew == 0) {
@@ -897,7 +880,7 @@ struct Chol2Shared {  // workgroup variables both role instantiations of the bod
   double zz;
 };
 
-template <int MAXSLOT, int ROLE>
+template <int MAXSLOT, int ROLE, bool SPLIT>
 __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve& ps, double* lds, Chol2Shared& sh) {
   const int n = J0_.n;
   const int nb = J0_.brow ? n + 1 : n;
@@ -912,12 +895,12 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   double& sh_zz = sh.zz;
   if (threadIdx.x == 0) sh_bad = 0;
   // split factorization of the plane update (see chol2_factor): block 0 = part A (tile columns < h), block 2 = part B
-  const int part = (J0_.mode == 1 && J0_.split_h > 0) ? (blockIdx.x == 2 ? 1 : 0) : -1;
+  const int part = (SPLIT && J0_.mode == 1 && J0_.split_h > 0) ? (blockIdx.x == 2 ? 1 : 0) : -1;
   const int c_lo = part == 1 ? J0_.split_h : 0, c_hi = part == 0 ? J0_.split_h : nt;
   Chol2Job Jl = J0_;
   if (part == 1 && Jl.stamps) Jl.stamps += 16 * 32;  // diagnostics: part B stamps into the second half
   const Chol2Job& J = Jl;
-  chol2_factor<NS, ROLE>(J, S, tile, ti, tj, bad, c_lo, c_hi);
+  chol2_factor<NS, ROLE, SPLIT>(J, S, tile, ti, tj, bad, c_lo, c_hi);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
@@ -1225,15 +1208,15 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   }
 }
 
-template <int MAXSLOT>
+template <int MAXSLOT, bool SPLIT>
 __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, const Chol2Job J1, const PlaneSolve ps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ Chol2Shared sh;
   const Chol2Job& J = blockIdx.x == 1 ? J1 : J0;  // block 2 = part B of a split plane update (same job as block 0)
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // both instantiations execute the same sequence of workgroup barriers
-  if (wave < C2_EW) chol2_body<MAXSLOT, 0>(J, ps, lds, sh);
-  else chol2_body<MAXSLOT, 1>(J, ps, lds, sh);
+  if (wave < C2_EW) chol2_body<MAXSLOT, 0, SPLIT>(J, ps, lds, sh);
+  else chol2_body<MAXSLOT, 1, SPLIT>(J, ps, lds, sh);
 }
 
 // out[0] = max_i A_ii (one workgroup): the scale the drop threshold of a semi-definite factorization refers to
@@ -1288,30 +1271,38 @@ hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, co
   const dim3 grid(j0->split_h > 0 ? 3 : (j1 ? 2 : 1)), block(C2_WAVES * 64);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_chol2<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_chol2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_chol2<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_chol2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_chol2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_chol2<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_chol2<22>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<15, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<17, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<22, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_chol2<22, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr = true;
   }
+  if (j0->split_h > 0) {  // the split kernels: the slot counts of BASELINE config 3 (forced, tests) and config 4, and a catch-all
+    if (slots <= 13)
+      hipLaunchKernelGGL((k_chol2<13, true>), grid, block, shmem, stream, *j0, b, p);
+    else if (slots <= 16)
+      hipLaunchKernelGGL((k_chol2<16, true>), grid, block, shmem, stream, *j0, b, p);
+    else if (slots <= 22)
+      hipLaunchKernelGGL((k_chol2<22, true>), grid, block, shmem, stream, *j0, b, p);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (slots <= 10)
-    hipLaunchKernelGGL((k_chol2<10>), grid, block, shmem, stream, *j0, b, p);
-  else if (slots <= 13)
-    hipLaunchKernelGGL((k_chol2<13>), grid, block, shmem, stream, *j0, b, p);
+    hipLaunchKernelGGL((k_chol2<10, false>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 15)
-    hipLaunchKernelGGL((k_chol2<15>), grid, block, shmem, stream, *j0, b, p);
-  else if (slots <= 16)
-    hipLaunchKernelGGL((k_chol2<16>), grid, block, shmem, stream, *j0, b, p);
+    hipLaunchKernelGGL((k_chol2<15, false>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 17)
-    hipLaunchKernelGGL((k_chol2<17>), grid, block, shmem, stream, *j0, b, p);
+    hipLaunchKernelGGL((k_chol2<17, false>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 20)
-    hipLaunchKernelGGL((k_chol2<20>), grid, block, shmem, stream, *j0, b, p);
+    hipLaunchKernelGGL((k_chol2<20, false>), grid, block, shmem, stream, *j0, b, p);
   else if (slots <= 22)  // n + 1 up to 288: the tile registers no longer fit 168 VGPRs, part of them lives in scratch
-    hipLaunchKernelGGL((k_chol2<22>), grid, block, shmem, stream, *j0, b, p);
+    hipLaunchKernelGGL((k_chol2<22, false>), grid, block, shmem, stream, *j0, b, p);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -1831,10 +1831,6 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       int h = ntb >= 17 ? (nst + 1) / 2 : 0;
       if (split_env >= 0) h = split_env < ntb - 1 ? split_env : 0;
       if (h > 9) h = 9;  // pl_xbuf holds nine exported steps
-      // exports: system-scope write-through stores whose completion is confirmed a step later, imports: system-scope loads behind
-      // an agent acquire on the step's flag (the both-sides `sc0 sc1` form of MI355X_MICROARCH.md, inter-workgroup visibility)
-      static const int xmode = getenv("OVP_C2_XMODE") ? atoi(getenv("OVP_C2_XMODE")) : 10;  // store flavour + 4 * load flavour
-      j0.dbg |= (xmode & 31) << 4;
       j0.split_h = h;
       j0.xbuf = c->pl_xbuf;
       j0.xflag = c->pl_xflag;
