@@ -24,6 +24,8 @@ struct Chol2Job {
   double* z_out;        // [n]
   double* y_out;        // [n] L^-T z
   double* piv_out;      // [n] pivots before the square root
+  double* Dinv_out;     // inverted diagonal blocks of the n x n part, [ceil(n/16)][16][16] (what k_fwdsub reads beside Lpack)
+  const int* skip_cond; // optional {have, want}: return at once when the factor this launch would produce is already there
   long long* stamps;    // optional [nt + 1][8] cycle stamps of wave 0 (diagnostics)
   int dbg;              // timing experiments only: 1 = skip the fused elimination, 2 = skip the trailing MFMAs, 4 = skip LDS staging
   // mode 1 on two workgroups (k_chol2.hip, chol2_factor): tile columns < split_h on block 0, the rest on block 2
@@ -82,5 +84,7 @@ struct PlaneSolve {
 extern "C" {
 int ovp_chol2_max_n(void);
 hipError_t ovp_launch_max_diag(const double* A, int n, int ld, double* out, hipStream_t stream);
+hipError_t ovp_launch_chol2_packed(const double* A, double* Dinv, double* Lpack, int n, int ld, int* flag, int add_identity,
+                                   const int* cond, hipStream_t stream);
 hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream);
 }

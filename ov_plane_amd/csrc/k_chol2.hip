@@ -621,6 +621,50 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   bad_out = (bad && !(J.piv_floor > 0.0)) ? 1 : 0;
 }
 
+// Inverses of the diagonal blocks L_kk, k in [k_lo, k_hi), in place in S.Dsave - elimination waves only (the 16 DPP rows of
+// the four waves take one block each).  Lane r holds row r of L_kk (one batch of 16-byte LDS reads); lane c builds column c of
+// X = L_kk^-1 by forward substitution, x_i = (delta_ic - sum_{j<i} L_ij x_j) / L_ii, with L_ij taken from lane i INSIDE the FMA
+// (DPP row broadcast) - no LDS traffic and one division per lane on the dependent chain.
+__device__ __forceinline__ void c2_invert_diag_blocks(const Chol2Lds& S, int k_lo, int k_hi, int wave, int lr, int lc) {
+  for (int k = k_lo + wave * 4 + lr; k < k_hi; k += 4 * C2_EW) {
+      double* blk = S.Dsave + k * C2_TSZ;
+      // lane r holds row r of L_kk (one batch of 16-byte LDS reads); lane c builds column c of X = L_kk^-1 by forward
+      // substitution, x_i = (delta_ic - sum_{j<i} L_ij x_j) / L_ii, with L_ij taken from lane i INSIDE the FMA (DPP row
+      // broadcast) - no LDS traffic and one division per lane on the dependent chain
+      double l[16];
+      {
+        const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(blk + lc * C2_TS);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const dbl2_t v = lrow[q];
+          l[2 * q] = v[0];
+          l[2 * q + 1] = v[1];
+        }
+      }
+      double dmine = 0.0;
+      sfor<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (lc == i) dmine = l[i];
+      });
+      const double rmine = dmine != 0.0 ? 1.0 / dmine : 0.0;
+      double x[16];
+      sfor<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        double s0 = (i == lc) ? 1.0 : 0.0, s1 = 0.0;
+        sfor<i>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          double nx = -x[j];
+          if constexpr ((j & 1) == 0) fmac_bcast_nop<i>(s0, l[j], nx);  // s += L_ij (lane i's l[j]) * (-x_j)
+          else fmac_bcast_nop<i>(s1, l[j], nx);
+        });
+        x[i] = (s0 + s1) * bcast_row<i>(rmine);
+      });
+      C2_WSYNC();  // every lane of the row has read L_kk
+#pragma unroll
+      for (int i = 0; i < 16; ++i) blk[i * C2_TS + lc] = x[i];
+    }
+}
+
 // y = L^-T z on the n x n part of the factor held in tile[] (entries at or behind the border row are zero); nt = tile rows of that
 // part, ceil(n / 16).
 //
@@ -669,43 +713,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
       }
     });
   } else {
-    for (int k = k_lo + wave * 4 + lr; k < k_hi; k += 4 * C2_EW) {
-      double* blk = S.Dsave + k * C2_TSZ;
-      // lane r holds row r of L_kk (one batch of 16-byte LDS reads); lane c builds column c of X = L_kk^-1 by forward
-      // substitution, x_i = (delta_ic - sum_{j<i} L_ij x_j) / L_ii, with L_ij taken from lane i INSIDE the FMA (DPP row
-      // broadcast) - no LDS traffic and one division per lane on the dependent chain
-      double l[16];
-      {
-        const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(blk + lc * C2_TS);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const dbl2_t v = lrow[q];
-          l[2 * q] = v[0];
-          l[2 * q + 1] = v[1];
-        }
-      }
-      double dmine = 0.0;
-      sfor<16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if (lc == i) dmine = l[i];
-      });
-      const double rmine = dmine != 0.0 ? 1.0 / dmine : 0.0;
-      double x[16];
-      sfor<16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        double s0 = (i == lc) ? 1.0 : 0.0, s1 = 0.0;
-        sfor<i>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          double nx = -x[j];
-          if constexpr ((j & 1) == 0) fmac_bcast_nop<i>(s0, l[j], nx);  // s += L_ij (lane i's l[j]) * (-x_j)
-          else fmac_bcast_nop<i>(s1, l[j], nx);
-        });
-        x[i] = (s0 + s1) * bcast_row<i>(rmine);
-      });
-      C2_WSYNC();  // every lane of the row has read L_kk
-#pragma unroll
-      for (int i = 0; i < 16; ++i) blk[i * C2_TS + lc] = x[i];
-    }
+    c2_invert_diag_blocks(S, k_lo, k_hi, wave, lr, lc);
   }
   if (wave == 1)  // tile slot nt - 1 of SD has no sub-diagonal tile: the first step multiplies it by y = 0
     for (int e = lane; e < C2_TSZ; e += 64) SD[(nt - 1) * C2_TSZ + e] = 0.0;
@@ -887,6 +895,9 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   const int nt = (nb + 15) >> 4;
   const Chol2Lds S = chol2_carve(lds, nt);
   constexpr int NS = ROLE == 1 ? MAXSLOT : 1;  // tile registers exist on the tile waves only
+  // cond = {have, want} on the device: the factor this launch would produce is already there when the two agree (the last
+  // accepted plane of a plane loop left it behind)
+  if (J0_.skip_cond && J0_.skip_cond[0] != 0 && J0_.skip_cond[0] == J0_.skip_cond[1]) return;
   double4_t tile[NS];
   int ti[NS], tj[NS];
   int bad = 0;
@@ -939,6 +950,21 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
     }
     if (J.piv_out)
       for (int i = tid; i < n; i += C2_WAVES * 64) J.piv_out[i] = S.pivs[i];
+    if (J.Dinv_out) {
+      // inverses of the diagonal blocks in the layout k_fwdsub reads (identity at / behind the border row): with Lpack this is
+      // everything the covariance product behind an update needs from chol(T)
+      const int ntn = (n + 15) >> 4;
+      if constexpr (ROLE == 0)
+        if (!J.y_out) c2_invert_diag_blocks(S, 0, ntn, wave, lr, lc);  // (the back substitution has inverted them already)
+      __syncthreads();
+      if constexpr (ROLE == 0) {
+        for (int e = tid; e < ntn * 256; e += C2_EW * 64) {
+          const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
+          const int gr = 16 * k + i, gc = 16 * k + c;
+          J.Dinv_out[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
+        }
+      }
+    }
     return;
   }
 
@@ -1243,6 +1269,24 @@ hipError_t ovp_launch_max_diag(const double* A, int n, int ld, double* out, hipS
 }
 
 int ovp_chol2_max_n(void) { return 16 * 18 - 1; }  // bordered dimension n + 1 <= 288 (18 tile rows)
+
+// chol(T) of an EKF update as k_tilechol delivers it (tile-packed factor + inverted diagonal blocks for k_fwdsub), on the
+// second-generation kernel: fused elimination, role hand-over through LDS counters (74 against 94 us at N = 240)
+hipError_t ovp_launch_chol2_packed(const double* A, double* Dinv, double* Lpack, int n, int ld, int* flag, int add_identity,
+                                   const int* cond, hipStream_t stream) {
+  ovp::Chol2Job j;
+  memset(&j, 0, sizeof(j));
+  j.A = A;
+  j.n = n;
+  j.ld = ld;
+  j.add_identity = add_identity;
+  j.mode = 0;
+  j.flag = flag;
+  j.Lpack = Lpack;
+  j.Dinv_out = Dinv;
+  j.skip_cond = cond;
+  return ovp_launch_chol2(&j, nullptr, nullptr, stream);
+}
 
 // one workgroup (j1 == nullptr), two (plane loop: update part and range part side by side) or three (the update part split over
 // two workgroups, j0->split_h > 0: block 0 = tile columns < split_h, block 2 = the rest)

@@ -755,6 +755,16 @@ static int chol_of_P(ovp_ctx* c, hipStream_t s) {
   return (int)ovp_launch_chol(c->P, c->L, n, ld, c->flags, 0, s);
 }
 
+// chol(T) behind an update: tile-packed factor + inverted diagonal blocks for k_fwdsub.  The second-generation kernel (k_chol2:
+// fused elimination, role hand-over through LDS counters instead of workgroup barriers) took over from k_tilechol in round 3
+// (OVP_TILECHOL_T=1 brings the first generation back for A/B runs).
+static hipError_t chol_of_T(ovp_ctx* c, const double* T, int n, int ld, int add_identity, const int* cond, hipStream_t s) {
+  static const bool first_gen = getenv("OVP_TILECHOL_T") != nullptr;
+  if (first_gen || n > ovp_chol2_max_n() + 1)
+    return ovp_launch_tilechol_unless(T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, add_identity, cond, s);
+  return ovp_launch_chol2_packed(T, c->Dinv, c->Ltp, n, ld, c->flags, add_identity, cond, s);
+}
+
 static int ekf_substate(ovp_ctx* c) {
   const int n = c->n, ld = c->ld, ns = c->sub_ns, lds = OVP_TILECHOL_NMAX;
   const size_t sz = (size_t)OVP_TILECHOL_NMAX * OVP_TILECHOL_NMAX;
@@ -795,7 +805,7 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     // W1 = A L ;  T = I + L^T W1 ;  Lt = chol(T) (+ inverses of its diagonal blocks)
     HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
-    HIPCHK(ovp_launch_tilechol(c->T, nullptr /* dense Lt is not needed */, c->Dinv, c->Ltp, n, ld, c->flags, 0, c->stream));
+    HIPCHK(chol_of_T(c, c->T, n, ld, 0, nullptr, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
     // (skipped on the device when a factorization failed: the resident covariance then stays what it was, OVP_E_NOTSPD)
@@ -1819,16 +1829,16 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.range_done = c->pl_range_done;
     ps.seq = ++c->pl_seq;
     {
-      // The update part on two workgroups: tile columns < h and the rest (k_chol2.hip).  Measured (r03): at 16 tile columns
-      // (N = 240) one workgroup is faster - its steps are bound by the pivot chain and the hand-over between the roles, not by
-      // the trailing update, and the split pays 1.3 K cycles of exports per step, a second gate hand-over and two back-substitution
-      // preambles (3.22 against 3.17 ms per config-3 plane loop); from 17 tile columns on (N > 255) the tile registers of one
-      // workgroup spill and the split wins (config 4, N = 285: 9.34 against 9.63 ms).  OVP_C2_SPLIT: 0 = never, h = forced.
+      // The update part on two workgroups: tile columns < h and the rest (k_chol2.hip).  Measured (r03, A/B in one call): at 16 tile
+      // columns (N = 240) nothing is gained - a step is bound by the pivot chain and the hand-over between the roles, not by the
+      // trailing update (3.10 against 3.09 ms per config-3 plane loop for h = 6 .. 8) - so one workgroup stays the default there;
+      // from 17 tile columns on (N > 255) the tile registers of one workgroup spill and the split wins (config 4, N = 285, h = 7:
+      // 8.91 against 9.43 ms).  OVP_C2_SPLIT: 0 = never, h = forced.
       const char* split_s = getenv("OVP_C2_SPLIT");  // (read per call: the tests switch it)
       const int split_env = split_s ? atoi(split_s) : -1;
       const int nb = n + 1, ntb = (nb + 15) / 16;
       const int nst = (nb % 16 == 1) ? ntb - 1 : ntb;  // a border row alone in its tile row takes no step
-      int h = ntb >= 17 ? (nst + 1) / 2 : 0;
+      int h = ntb >= 17 ? (2 * nst + 2) / 5 : 0;  // part B also runs the back half of the chain: 7 of 18 steps measured best
       if (split_env >= 0) h = split_env < ntb - 1 ? split_env : 0;
       if (h > 9) h = 9;  // pl_xbuf holds nine exported steps
       j0.split_h = h;
@@ -1928,7 +1938,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
   if (NJ > 0) {
     HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
-    HIPCHK(ovp_launch_tilechol_unless(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 1, c->pl_cur + 1, s));
+    HIPCHK(chol_of_T(c, c->T, n, ld, 1, c->pl_cur + 1, s));
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
   }
