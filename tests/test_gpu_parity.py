@@ -236,6 +236,34 @@ def test_config4_on_one_gpu_plane_loop_and_point_update(hiplib, oracle):
     ctx.close()
 
 
+def test_config4_plane_gate_at_multiplier_one(hiplib, oracle):
+    """BASELINE config[3]'s plane loop with the gate deciding (chi2_multipler = 1, the value of the real-data configs): the device
+    loop runs on the oracle's accept / reject sequence, so both see the same state at every one of the 50 planes (N = 285: the
+    two-workgroup solve); state and covariance to the path's tolerances, the device statistic within the rounding-decided band
+    of the reference's (profiles/r03_plane_gate_agreement.json: two builds of the oracle differ by up to 18), the decisions it
+    would have taken equal to the oracle's except next to the threshold."""
+    sc = make_scene(C=30, F=8000, seed=1, n_planes=50, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=1.0)
+    ref = oracle.msckf_plane_update(sc)
+    assert 3 <= (~ref["plane_ok"]).sum() <= 25          # the gate is deciding at this multiplier
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id,
+                           force_decision=ref["plane_ok"].astype(np.uint8))
+    assert (out["ok"] == ref["plane_ok"]).all() and (out["used"] == ref["used"]).all() and (out["dof"] == ref["plane_rows"]).all()
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    d = out["chi2"] - ref["plane_chi2"]
+    assert np.abs(d).max() < 18.2 and abs(d.mean()) < 2.0, (d.mean(), np.abs(d).max())
+    thr = np.array([hiplib.lib().ovp_chi2_quantile_095(int(k)) for k in out["dof"]])
+    differ = (out["chi2"] <= thr) != ref["plane_ok"]
+    assert differ.sum() <= 4 and (np.abs(ref["plane_chi2"] - thr)[differ] < 18.2).all()
+    ctx.close()
+
+
 @pytest.mark.parametrize("case", ["exact_clone", "zero_variance"])
 def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case):
     """state/StateHelper.cpp:159-187 never factors P, so the reference updates a covariance that is only positive SEMI-definite:
