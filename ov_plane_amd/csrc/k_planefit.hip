@@ -6,7 +6,7 @@
 // RANSAC.  The hypothesis sets come from std::shuffle with ONE std::mt19937(8888) per call whose state runs through all 200
 // iterations (:93,:110) - inherently sequential, so the shuffles and the greedy 5-point selection (:113-135) are done while the
 // batch is packed on the host (restated libstdc++ algorithms, see ovp_shuffle below), and the device scores the 200
-// hypotheses in parallel: one wave per hypothesis, lanes over the plane's points.
+// hypotheses in parallel: one lane per hypothesis, points and index sets staged in LDS.
 //
 // Refinement.  The reference hands the problem to Ceres (DENSE_SCHUR, DOGLEG, CauchyLoss(1), <= 12 iterations).  Here one
 // thread owns one feature: it walks the feature's observations in order, keeps the feature's 3x3 blocks of J^T J (own block and
@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);  // ovp_api.hip: pinned host + device block per context
 
 namespace ovp {
 
@@ -148,6 +150,7 @@ struct RansacJob {
 };
 
 static constexpr int RS_ITERS = 200;
+static constexpr int RS_NMAX = 512;  // points of a plane staged in LDS (more: read from global memory)
 
 __global__ __launch_bounds__(256) void k_plane_ransac(const RansacJob j) {
   const int pl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,16 +166,30 @@ __global__ __launch_bounds__(256) void k_plane_ransac(const RansacJob j) {
   const int ratio_n = (int)((double)n * 0.80);
   const int min_on_plane = j.min_inlier_num > ratio_n ? j.min_inlier_num : ratio_n;
 
-  for (int h = wave; h < RS_ITERS; h += 4) {
-    const int* st = sets + 5 * h;
+  // One LANE per hypothesis (round 3).  The first version gave a hypothesis a wave (lanes over the points) and walked 50 of them per
+  // wave, each behind two dependent global round trips (its index set, then the five points): 230 us per plane on average, 46 %
+  // of the GPU time of a closed-loop frame with planes.  Points and index sets are staged in LDS once; the 3 x 3 fit and its
+  // condition check are lane-local arithmetic anyway, and the score of a hypothesis is a walk over the points in index order
+  // (every lane reads the same point: LDS broadcast) - the order in which the reference accumulates it (:147-155).
+  __shared__ double pts_s[3 * RS_NMAX];
+  __shared__ int sets_s[RS_ITERS * 5];
+  const bool staged = n <= RS_NMAX;
+  if (staged)
+    for (int i = tid; i < 3 * n; i += 256) pts_s[i] = pts[i];
+  for (int i = tid; i < RS_ITERS * 5; i += 256) sets_s[i] = sets[i];
+  __syncthreads();
+  const double* P = staged ? pts_s : pts;
+  if (tid < RS_ITERS) {
+    const int h = tid;
+    const int* st = sets_s + 5 * h;
     int cnt = -1;
     double avg = 0.0, abcd[4] = {0.0, 0.0, 0.0, 0.0};
     if (st[0] < 0) {
       cnt = -2;
     } else {
       double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sv[3] = {0, 0, 0};
-      for (int s = 0; s < 5; ++s) {  // wave-uniform, in set order
-        const double* p = pts + 3 * st[s];
+      for (int s = 0; s < 5; ++s) {  // in set order
+        const double* p = P + 3 * st[s];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           sv[a] += p[a];
@@ -183,28 +200,21 @@ __global__ __launch_bounds__(256) void k_plane_ransac(const RansacJob j) {
       if (pf_plane_from_moments(M, sv, j.max_cond, true, abcd)) {  // :144
         int c = 0;
         double e = 0.0;
-        for (int i = lane; i < n; i += 64) {  // :147-155
-          const double d = fabs(pts[3 * i] * abcd[0] + pts[3 * i + 1] * abcd[1] + pts[3 * i + 2] * abcd[2] + abcd[3]);
+        for (int i = 0; i < n; ++i) {  // :147-155
+          const double d = fabs(P[3 * i] * abcd[0] + P[3 * i + 1] * abcd[1] + P[3 * i + 2] * abcd[2] + abcd[3]);
           if (d < max_err) {
             ++c;
             e += d;
           }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          c += __shfl_xor(c, off);
-          e += shfl_xor_f64(e, off);
-        }
         cnt = c;
         avg = e / (double)c;
       }
     }
-    if (lane == 0) {
-      h_cnt[h] = cnt;
-      h_err[h] = avg;
+    h_cnt[h] = cnt;
+    h_err[h] = avg;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) h_abcd[h][k] = abcd[k];
-    }
+    for (int k = 0; k < 4; ++k) h_abcd[h][k] = abcd[k];
   }
   __syncthreads();
   if (tid == 0) {  // the reference's sequential selection rule, :159-166
@@ -900,16 +910,20 @@ extern "C" int ovp_plane_fitting(ovp_ctx* c, const ovp_planefit_batch* b, double
       }
     }
   }
-  char* blob = nullptr;
-  const size_t o_fs = 0, o_pts = o_fs + sizeof(int) * (size_t)(P + 1) + 64, o_sets = o_pts + sizeof(double) * 3 * (size_t)F + 64;
-  const size_t o_abcd = o_sets + sizeof(int) * sets.size() + 64, o_inl = o_abcd + sizeof(double) * 4 * (size_t)P + 64;
-  const size_t o_ok = o_inl + (size_t)F + 64, total = o_ok + (size_t)P + 64;
+  // one pinned block in, one out (ovp_io_arena): [feat_start | points | hypothesis sets | -> abcd | inlier | ok]
   auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
-  const size_t a_pts = al(o_pts), a_sets = al(o_sets), a_abcd = al(o_abcd), a_inl = al(o_inl), a_ok = al(o_ok);
-  PF_HIPCHK(hipMalloc((void**)&blob, total + 64));
-  PF_HIPCHK(hipMemcpyAsync(blob + o_fs, b->feat_start, sizeof(int) * (size_t)(P + 1), hipMemcpyHostToDevice, s));
-  PF_HIPCHK(hipMemcpyAsync(blob + a_pts, b->p_FinG, sizeof(double) * 3 * (size_t)F, hipMemcpyHostToDevice, s));
-  PF_HIPCHK(hipMemcpyAsync(blob + a_sets, sets.data(), sizeof(int) * sets.size(), hipMemcpyHostToDevice, s));
+  const size_t o_fs = 0, a_pts = al(sizeof(int) * (size_t)(P + 1)), a_sets = al(a_pts + sizeof(double) * 3 * (size_t)F);
+  const size_t a_abcd = al(a_sets + sizeof(int) * sets.size()), a_inl = al(a_abcd + sizeof(double) * 4 * (size_t)P);
+  const size_t a_ok = al(a_inl + (size_t)F), total = al(a_ok + (size_t)P);
+  char *hb = nullptr, *blob = nullptr;
+  {
+    const int rca = ovp_io_arena(c, total, (void**)&hb, (void**)&blob);
+    if (rca) return rca;
+  }
+  memcpy(hb + o_fs, b->feat_start, sizeof(int) * (size_t)(P + 1));
+  memcpy(hb + a_pts, b->p_FinG, sizeof(double) * 3 * (size_t)F);
+  memcpy(hb + a_sets, sets.data(), sizeof(int) * sets.size());
+  PF_HIPCHK(hipMemcpyAsync(blob, hb, a_abcd, hipMemcpyHostToDevice, s));
   ovp::RansacJob j;
   j.feat_start = (const int*)(blob + o_fs);
   j.pts = (const double*)(blob + a_pts);
@@ -921,11 +935,11 @@ extern "C" int ovp_plane_fitting(ovp_ctx* c, const ovp_planefit_batch* b, double
   j.ok = (unsigned char*)(blob + a_ok);
   hipLaunchKernelGGL(ovp::k_plane_ransac, dim3(P), dim3(256), 0, s, j);
   PF_HIPCHK(hipGetLastError());
-  PF_HIPCHK(hipMemcpyAsync(abcd, blob + a_abcd, sizeof(double) * 4 * (size_t)P, hipMemcpyDeviceToHost, s));
-  PF_HIPCHK(hipMemcpyAsync(inlier, blob + a_inl, (size_t)F, hipMemcpyDeviceToHost, s));
-  PF_HIPCHK(hipMemcpyAsync(ok, blob + a_ok, (size_t)P, hipMemcpyDeviceToHost, s));
+  PF_HIPCHK(hipMemcpyAsync(hb + a_abcd, blob + a_abcd, total - a_abcd, hipMemcpyDeviceToHost, s));
   PF_HIPCHK(hipStreamSynchronize(s));
-  (void)hipFree(blob);
+  memcpy(abcd, hb + a_abcd, sizeof(double) * 4 * (size_t)P);
+  memcpy(inlier, hb + a_inl, (size_t)F);
+  memcpy(ok, hb + a_ok, (size_t)P);
   return 0;
 }
 
@@ -955,8 +969,13 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   const size_t o_fix = take((size_t)P), o_cpo = take(sizeof(double) * 3 * (size_t)P);
   const size_t o_po = take(sizeof(double) * 3 * (size_t)F), o_kept = take((size_t)F), o_ok = take((size_t)P);
   const size_t o_it = take(sizeof(int) * (size_t)P);
-  PF_HIPCHK(hipMalloc((void**)&blob, off + 64));
-#define PF_UP(o, src, bytes) PF_HIPCHK(hipMemcpyAsync(blob + (o), (src), (bytes), hipMemcpyHostToDevice, s))
+  const size_t in_bytes = o_cpo;  // everything in front of the outputs is input
+  char* hb = nullptr;
+  {
+    const int rca = ovp_io_arena(c, off + 64, (void**)&hb, (void**)&blob);
+    if (rca) return rca;
+  }
+#define PF_UP(o, src, bytes) memcpy(hb + (o), (src), (bytes))
   PF_UP(o_fs, b->feat_start, sizeof(int) * (size_t)(P + 1));
   PF_UP(o_p0, b->p_FinG, sizeof(double) * 3 * (size_t)F);
   PF_UP(o_os, b->obs_start, sizeof(int) * (size_t)F);
@@ -969,6 +988,7 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   PF_UP(o_cp, b->cp, sizeof(double) * 3 * (size_t)P);
   PF_UP(o_fix, b->fix_plane, (size_t)P);
 #undef PF_UP
+  PF_HIPCHK(hipMemcpyAsync(blob, hb, in_bytes, hipMemcpyHostToDevice, s));
   ovp::RefineJob j;
   j.feat_start = (const int*)(blob + o_fs);
   j.p0 = (const double*)(blob + o_p0);
@@ -1001,14 +1021,12 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   int threads = ((std::max(nf_max, 1) + 63) / 64) * 64;
   hipLaunchKernelGGL(ovp::k_plane_refine, dim3(P), dim3(threads), 0, s, j);
   PF_HIPCHK(hipGetLastError());
-  PF_HIPCHK(hipMemcpyAsync(cp_out, blob + o_cpo, sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToHost, s));
-  PF_HIPCHK(hipMemcpyAsync(p_out, blob + o_po, sizeof(double) * 3 * (size_t)F, hipMemcpyDeviceToHost, s));
-  PF_HIPCHK(hipMemcpyAsync(kept, blob + o_kept, (size_t)F, hipMemcpyDeviceToHost, s));
-  PF_HIPCHK(hipMemcpyAsync(ok, blob + o_ok, (size_t)P, hipMemcpyDeviceToHost, s));
-  std::vector<int> its((size_t)P);
-  PF_HIPCHK(hipMemcpyAsync(its.data(), blob + o_it, sizeof(int) * (size_t)P, hipMemcpyDeviceToHost, s));
+  PF_HIPCHK(hipMemcpyAsync(hb + o_cpo, blob + o_cpo, off - o_cpo, hipMemcpyDeviceToHost, s));
   PF_HIPCHK(hipStreamSynchronize(s));
-  if (iterations) memcpy(iterations, its.data(), sizeof(int) * (size_t)P);
-  (void)hipFree(blob);
+  memcpy(cp_out, hb + o_cpo, sizeof(double) * 3 * (size_t)P);
+  memcpy(p_out, hb + o_po, sizeof(double) * 3 * (size_t)F);
+  memcpy(kept, hb + o_kept, (size_t)F);
+  memcpy(ok, hb + o_ok, (size_t)P);
+  if (iterations) memcpy(iterations, hb + o_it, sizeof(int) * (size_t)P);
   return 0;
 }

@@ -213,6 +213,8 @@ struct ovp_ctx {
   bool pl_used_valid = false;         // pl_used refers to the uploaded batch
   int pl2_cap = 0;
   // plane loop on a sub-state (n above the tile factorization's limit): accumulated pair, u rows, remapped id tables
+  void *io_h = nullptr, *io_d = nullptr;         // ovp_io_arena: pinned host block + device block of the small entry points
+  size_t io_cap = 0;
   double *pl_xbuf = nullptr, *pl_xy = nullptr;   // split plane solve: exported panels, [xzz(2) | y blocks]
   unsigned* pl_xflag = nullptr;                  // [32 step flags | 2 sync words]
   double *pl_Asum = nullptr, *pl_U = nullptr;
@@ -439,6 +441,8 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   if (c->ev_batch) hipEventDestroy(c->ev_batch);
   if (c->pl_hstage) hipHostFree(c->pl_hstage);
   if (c->pl_hres) hipHostFree(c->pl_hres);
+  if (c->io_h) hipHostFree(c->io_h);
+  if (c->io_d) hipFree(c->io_d);
   hipEventDestroy(c->ev_fork);
   hipEventDestroy(c->ev_join);
   for (int i = 0; i < 6; ++i) hipEventDestroy(c->ev_t[i]);
@@ -602,6 +606,28 @@ extern "C" int ovp_state_upload(ovp_ctx* c, const ovp_state_tables* st) {
   return 0;
 }
 
+// One pinned host block + one device block per context for the entry points whose arguments are a handful of small host arrays
+// (triangulation, plane fitting, plane refinement): the inputs are packed into the host block and cross the bus in ONE copy, the
+// outputs come back in one.  The first versions issued a pageable copy per array (137 copy kernels per closed-loop frame with
+// planes, a quarter of its GPU time) and, in the plane-fitting entries, a hipMalloc / hipFree pair per call.
+extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev) {
+  if (!c || !host || !dev) return OVP_E_ARG;
+  if (bytes > c->io_cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->io_h) hipHostFree(c->io_h);
+    if (c->io_d) hipFree(c->io_d);
+    c->io_h = c->io_d = nullptr;
+    c->io_cap = 0;
+    const size_t cap = bytes + bytes / 2 + 4096;
+    HIPCHK(hipHostMalloc(&c->io_h, cap, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&c->io_d, cap));
+    c->io_cap = cap;
+  }
+  *host = c->io_h;
+  *dev = c->io_d;
+  return 0;
+}
+
 // ---- triangulation ----------------------------------------------------------------
 extern "C" void ovp_triang_defaults(ovp_triang_opts* o) {
   if (!o) return;
@@ -625,11 +651,18 @@ extern "C" int ovp_triangulate(ovp_ctx* c, const ovp_triang_opts* o, const float
   if (!c->have_state || !c->have_batch) return OVP_E_STATE;
   const size_t F = (size_t)c->n_feats, M = (size_t)c->max_meas;
   if (F == 0) return 0;
-  if (!c->uvn) HIPCHK(hipMalloc((void**)&c->uvn, sizeof(float) * (size_t)c->f_max * OVP_MAX_MEAS * 2));
-  if (!c->tri_ok) HIPCHK(hipMalloc((void**)&c->tri_ok, (size_t)c->f_max));
-  HIPCHK(hipMemcpyAsync(c->uvn, uv_norm, sizeof(float) * F * M * 2, hipMemcpyHostToDevice, c->stream));
+  // arena: [uv_norm | -> p_FinG | ok]
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t b_uv = sizeof(float) * F * M * 2, o_p = al(b_uv), o_ok = al(o_p + sizeof(double) * 3 * F), total = al(o_ok + F);
+  void *ah = nullptr, *ad = nullptr;
+  {
+    const int rca = ovp_io_arena(c, total, &ah, &ad);
+    if (rca) return rca;
+  }
+  memcpy(ah, uv_norm, b_uv);
+  HIPCHK(hipMemcpyAsync(ad, ah, b_uv, hipMemcpyHostToDevice, c->stream));
   ovp::TriParams tp;
-  tp.uvn = c->uvn;
+  tp.uvn = (const float*)ad;
   tp.clone_idx = c->fp.clone_idx;
   tp.n_meas = c->fp.n_meas;
   tp.n_feats = (int)F;
@@ -650,12 +683,15 @@ extern "C" int ovp_triangulate(ovp_ctx* c, const ovp_triang_opts* o, const float
   tp.max_baseline = o->max_baseline;
   tp.max_cond_number = o->max_cond_number;
   tp.p_FinG = c->p_FinG;  // the library's own buffer even when the batch was bound to caller memory
-  tp.ok = c->tri_ok;
+  tp.ok = (unsigned char*)ad + o_ok;
   HIPCHK(ovp_launch_triangulate(&tp, c->stream));
   c->fp.p_FinG = c->p_FinG;
-  if (p_FinG_out) HIPCHK(hipMemcpyAsync(p_FinG_out, c->p_FinG, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(ok, c->tri_ok, F, hipMemcpyDeviceToHost, c->stream));
+  // results into the pinned block (the positions stay in the batch's buffer on the device as linearisation points)
+  HIPCHK(hipMemcpyAsync((char*)ah + o_p, c->p_FinG, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync((char*)ah + o_ok, (char*)ad + o_ok, F, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (p_FinG_out) memcpy(p_FinG_out, (char*)ah + o_p, sizeof(double) * 3 * F);
+  memcpy(ok, (char*)ah + o_ok, F);
   return 0;
 }
 
