@@ -482,11 +482,24 @@ extern "C" int ovp_ctx_stream(ovp_ctx* c, void** stream) {
 extern "C" int ovp_cov_size(ovp_ctx* c) { return c ? c->n : OVP_E_ARG; }
 
 // ---- covariance residency ----------------------------------------------------------------------
+extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);
+
+// (upload / download / marginal / propagate go through the pinned arena: one contiguous copy each way.  A 2-D copy from
+//  pageable memory cost 90 us of host time at N = 130, a pageable copy per small array 8 us each.)
 extern "C" int ovp_cov_upload(ovp_ctx* c, const double* P_host, int n, int ld) {
   if (!c || !P_host || n < 1 || ld < n) return OVP_E_ARG;
   if (n > c->n_max) return OVP_E_CAPACITY;
-  HIPCHK(hipMemcpy2DAsync(c->P, sizeof(double) * c->ld, P_host, sizeof(double) * ld, sizeof(double) * n, n,
-                          hipMemcpyHostToDevice, c->stream));
+  void *ah = nullptr, *ad = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n * c->ld;
+  {
+    const int rca = ovp_io_arena(c, bytes, &ah, &ad);
+    if (rca) return rca;
+  }
+  for (int i = 0; i < n; ++i) {
+    memcpy((double*)ah + (size_t)i * c->ld, P_host + (size_t)i * ld, sizeof(double) * n);
+    if (c->ld > n) memset((double*)ah + (size_t)i * c->ld + n, 0, sizeof(double) * (c->ld - n));
+  }
+  HIPCHK(hipMemcpyAsync(c->P, ah, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->n = n;
   c->have_cov = true;
@@ -503,9 +516,15 @@ extern "C" int ovp_cov_set_device(ovp_ctx* c, const double* P_dev, int n, int ld
 }
 extern "C" int ovp_cov_download(ovp_ctx* c, double* P_host, int n, int ld) {
   if (!c || !P_host || n != c->n || ld < n) return OVP_E_ARG;
-  HIPCHK(hipMemcpy2DAsync(P_host, sizeof(double) * ld, c->P, sizeof(double) * c->ld, sizeof(double) * n, n,
-                          hipMemcpyDeviceToHost, c->stream));
+  void *ah = nullptr, *ad = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n * c->ld;
+  {
+    const int rca = ovp_io_arena(c, bytes, &ah, &ad);
+    if (rca) return rca;
+  }
+  HIPCHK(hipMemcpyAsync(ah, c->P, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i) memcpy(P_host + (size_t)i * ld, (const double*)ah + (size_t)i * c->ld, sizeof(double) * n);
   return 0;
 }
 extern "C" int ovp_cov_marginal(ovp_ctx* c, const int* ids, const int* sizes, int n_vars, double* out_host) {
@@ -518,10 +537,18 @@ extern "C" int ovp_cov_marginal(ovp_ctx* c, const int* ids, const int* sizes, in
     }
   const int m = (int)cols.size();
   if (m > c->n_max || (size_t)m * m > c->small_cap) return OVP_E_CAPACITY;
-  HIPCHK(hipMemcpyAsync(c->idbuf, cols.data(), sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(ovp_launch_gather_marginal(c->P, c->ld, c->idbuf, m, c->smallbuf, c->stream));
-  HIPCHK(hipMemcpyAsync(out_host, c->smallbuf, sizeof(double) * m * m, hipMemcpyDeviceToHost, c->stream));
+  void *ah = nullptr, *ad = nullptr;
+  const size_t o_out = ((sizeof(int) * (size_t)m + 63) / 64) * 64, bytes = o_out + sizeof(double) * (size_t)m * m;
+  {
+    const int rca = ovp_io_arena(c, bytes, &ah, &ad);
+    if (rca) return rca;
+  }
+  memcpy(ah, cols.data(), sizeof(int) * m);
+  HIPCHK(hipMemcpyAsync(ad, ah, sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(ovp_launch_gather_marginal(c->P, c->ld, (const int*)ad, m, (double*)((char*)ad + o_out), c->stream));
+  HIPCHK(hipMemcpyAsync((char*)ah + o_out, (char*)ad + o_out, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(out_host, (char*)ah + o_out, sizeof(double) * (size_t)m * m);
   return 0;
 }
 
@@ -2222,17 +2249,26 @@ extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const 
     }
   const int nold = (int)oldcol.size();
   if (nold > 4 * c->n_max) return OVP_E_CAPACITY;
-  double* dPhi = c->smallbuf;
-  double* dQ = dPhi + (size_t)phi_size * nold;
-  double* dCPT = dQ + (size_t)phi_size * phi_size;
+  double* dCPT = c->smallbuf;
   double* dPCP = dCPT + (size_t)n * phi_size;
   if ((size_t)(dPCP + (size_t)phi_size * phi_size - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
-  HIPCHK(hipMemcpyAsync(c->idbuf, oldcol.data(), sizeof(int) * nold, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dPhi, Phi_host, sizeof(double) * phi_size * nold, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dQ, Q_host, sizeof(double) * phi_size * phi_size, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(ovp_launch_propagate(c->P, c->ld, n, new_start, phi_size, c->idbuf, nold, dPhi, dQ, dCPT, dPCP, c->flags + 1,
-                              c->stream));
+  {
+    // [Phi | Q | ids] packed into the pinned arena, one copy; the kernels read them from the device half of the arena
+    void *ah = nullptr, *ad = nullptr;
+    const size_t b_pq = sizeof(double) * ((size_t)phi_size * nold + (size_t)phi_size * phi_size);
+    const size_t o_id = ((b_pq + 63) / 64) * 64, bytes = o_id + sizeof(int) * (size_t)nold;
+    const int rca = ovp_io_arena(c, bytes, &ah, &ad);
+    if (rca) return rca;
+    memcpy(ah, Phi_host, sizeof(double) * phi_size * nold);
+    memcpy((double*)ah + (size_t)phi_size * nold, Q_host, sizeof(double) * phi_size * phi_size);
+    memcpy((char*)ah + o_id, oldcol.data(), sizeof(int) * nold);
+    HIPCHK(hipMemcpyAsync(ad, ah, bytes, hipMemcpyHostToDevice, c->stream));
+    const double* dPhi = (const double*)ad;
+    const double* dQ = dPhi + (size_t)phi_size * nold;
+    HIPCHK(ovp_launch_propagate(c->P, c->ld, n, new_start, phi_size, (const int*)((char*)ad + o_id), nold, dPhi, dQ, dCPT, dPCP,
+                                c->flags + 1, c->stream));
+  }
   HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (neg_diag) *neg_diag = c->h_flags[1];
