@@ -227,7 +227,8 @@ extern "C" int ovph_session_feed_imu(void *h, int n, const double *imu7) {
 // sees (the distinct values of its feature -> plane map over ALL live tracks, not only the ones used in this frame),
 // merge_pairs[2 * n_merge] = (surviving id, old id) pairs of planes the front end merged.  With active_planes != NULL the step runs
 // StateHelper::merge_planes_and_marginalize like the reference does every frame: merged planes are fused (3-row update) and
-// planes nobody observes any more leave the state.  NULL keeps every plane (the caller guarantees they stay observed).
+// planes nobody observes any more leave the state.  n_active < 0 = no bookkeeping handed over: every plane is kept (the caller
+// guarantees they stay observed); n_active = 0 = the tracker sees no plane at all (every plane leaves) - the pointer may then be NULL.
 extern "C" int ovph_session_step2(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
                                   const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
                                   double *x16, double *posecov36, int slam_cap, long long *slam_ids, const double *truth17,
@@ -237,7 +238,7 @@ extern "C" int ovph_session_step(void *h, double frame_time, int F, int M, const
                                  const int *n_meas, const long long *gfid, const int *kind, const int *plane, int *counts,
                                  double *x16, double *posecov36, int slam_cap, long long *slam_ids, const double *truth17) {
   return ovph_session_step2(h, frame_time, F, M, uv, uv_norm, clone_slot, n_meas, gfid, kind, plane, counts, x16, posecov36, slam_cap,
-                            slam_ids, truth17, 0, nullptr, 0, nullptr);
+                            slam_ids, truth17, -1, nullptr, 0, nullptr);
 }
 
 extern "C" int ovph_session_step2(void *h, double frame_time, int F, int M, const float *uv, const float *uv_norm, const int *clone_slot,
@@ -307,7 +308,7 @@ extern "C" int ovph_session_step2(void *h, double frame_time, int F, int M, cons
     }
   StateHelper::marginalize_slam(state);
   // :513-534 planes the front end merged are fused, planes that are no longer observed leave the state
-  if (active_planes && s->plane_mode == 2) {
+  if (n_active >= 0 && s->plane_mode == 2) {
     std::map<size_t, size_t> f2p_active = feat2plane;
     size_t fake = (size_t)-1;  // ids that cannot collide with tracker ids: only the VALUES of the map are read
     for (int k = 0; k < n_active; ++k) f2p_active[fake--] = (size_t)active_planes[k];

@@ -1669,6 +1669,21 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   std::vector<int> featlist;
   std::vector<int> perms;  // per job: n entries
   const int ncal = (o->do_calib_camera_pose ? 6 : 0) + (o->do_calib_camera_intrinsics ? 8 : 0);
+  // features bucketed by plane in one pass, batch order kept (a scan of the whole batch per plane was 0.4 ms of host time in
+  // front of the first launch at 8000 features x 50 planes)
+  std::vector<int> bucket_start((size_t)NP + 2, 0), bucket((size_t)(F > 0 ? F : 1));
+  for (int f = 0; f < F; ++f) {
+    const int pf = pb->plane_of_feat[f];
+    if (pf >= 1 && pf <= NP) ++bucket_start[pf + 1];
+  }
+  for (int pl = 1; pl <= NP + 1; ++pl) bucket_start[pl] += bucket_start[pl - 1];
+  {
+    std::vector<int> fill(bucket_start.begin(), bucket_start.end());
+    for (int f = 0; f < F; ++f) {
+      const int pf = pb->plane_of_feat[f];
+      if (pf >= 1 && pf <= NP) bucket[fill[pf]++] = f;
+    }
+  }
   for (int pl = 0; pl < NP; ++pl) {
     PlaneJobH j;
     j.pl = pl;
@@ -1679,8 +1694,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     j.sid = pb->plane_state_id[pl];
     j.in_state = j.sid >= 0;
     unsigned long long seen = 0ull;
-    for (int f = 0; f < F; ++f) {
-      if (pb->plane_of_feat[f] != pl + 1) continue;
+    for (int bi = bucket_start[pl + 1]; bi < bucket_start[pl + 2]; ++bi) {
+      const int f = bucket[bi];
       const int m = c->h_n_meas[f];
       if (m < 2) continue;
       if (m > 31) return OVP_E_CAPACITY;  // 2m+1 rows must fit one wavefront

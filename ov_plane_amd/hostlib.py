@@ -527,7 +527,7 @@ class Session:
         rc = self._L.ovph_session_step2(C.c_void_p(self._h), C.c_double(frame_time), C.c_int(F), C.c_int(M), p(uv), p(uvn), p(slot),
                                         p(nm), p(gf), p(kd), p(pl), p(counts), p(x16), p(pc), C.c_int(cap), p(ids),
                                         p(np.ascontiguousarray(truth, dtype=np.float64)) if truth is not None else None,
-                                        C.c_int(0 if act is None else len(act)), p(act) if act is not None else None,
+                                        C.c_int(-1 if act is None else len(act)), p(act) if (act is not None and len(act)) else None,
                                         C.c_int(len(mrg)), p(mrg) if len(mrg) else None)
         if rc != 0:
             raise RuntimeError("ovph_session_step failed with %d" % rc)
