@@ -304,6 +304,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (point_config, config4_1gpu, propagation)")
     ap.add_argument("--cpu-sample-feats", type=int, default=0, help="0 = the oracle runs every feature of the frame")
+    ap.add_argument("--sharded-path", action="store_true",
+                    help="with --gpus 1: take the multi-GPU code path (process group of one rank, dist.sharded_* functions, RCCL "
+                         "all-reduce, stage timing) - a smoke test of it on a one-GPU box")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "0"))
@@ -322,19 +325,27 @@ def main():
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.sharded_path
+    real_stdout = None
+    if sharded:
+        # RCCL writes a version banner to stdout: everything but the JSON line goes to stderr from here on
+        sys.stdout.flush()
+        real_stdout = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29571")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
-    name = args.workload if args.workload != "auto" else ("config3" if world == 1 else "config4")
+    name = args.workload if args.workload != "auto" else ("config4" if sharded else "config3")
     sc = make_workload(name)
     run = StepRunner(capi, torch, sc, local_rank)
-    barrier = (lambda: dist.barrier()) if world > 1 else None
+    barrier = (lambda: dist.barrier()) if sharded else None
 
     with torch.cuda.stream(run.stream):
-        if world > 1:
+        if sharded:
             fn = lambda: run.step_sharded(rank, world)  # noqa: E731
         else:
             fn = run.step
@@ -347,7 +358,7 @@ def main():
         k1_ms, k1_n = run.ctx.kernel_timer(enable=False, reset=False)
         c2_ms, c2_n = run.ctx.plane_kernel_timer(enable=False, reset=False)
         stages = None
-        if world > 1:
+        if sharded:
             # where a multi-GPU step spends its time (a pass of its own: the stages are separated by host synchronisations)
             stages = {}
             n_diag = 5
@@ -355,7 +366,7 @@ def main():
                 run.step_sharded(rank, world, timing=stages)
             stages = {k: v / n_diag for k, v in stages.items()}
 
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -364,7 +375,7 @@ def main():
 
     if rank == 0:
         C = sc.C
-        n_pts_done = int(run.shard_size) if world > 1 else int((~pl["used"]).sum()) if pl is not None else sc.F
+        n_pts_done = int(run.shard_size) if sharded else int((~pl["used"]).sum()) if pl is not None else sc.F
         line = {
             "metric": "MSCKF+plane update-step features/sec at %d clones" % C,
             "value": value,
@@ -382,7 +393,7 @@ def main():
                        "state_dim": int(sc.N), "planes": int(sc.cp.shape[0]),
                        "planes_accepted": int(pl["ok"].sum()) if pl is not None else 0,
                        "points_accepted": int(pt["accepted"].sum()),
-                       "parallelism": "1 GPU" if world == 1 else "plane loop replicated, free points sharded x%d (RCCL ranks: %d)"
+                       "parallelism": "1 GPU" if not sharded else "plane loop replicated, free points sharded x%d (RCCL ranks: %d)"
                                       % (world, dist.get_world_size()),
                        "timed_region": "H2D feature batch + plane loop + point update + D2H results; covariance and pose tables "
                                        "resident (restored on the device at the start of every step)"},
@@ -409,7 +420,7 @@ def main():
             }
         if k1_n:
             m = C
-            per_launch = n_pts_done if world > 1 else sc.F  # features the launch walks (skipped ones exit early)
+            per_launch = sc.F  # features the launch walks (skipped / other ranks' ones exit early)
             alg = algorithmic_flops_per_feature(m) * n_pts_done
             exe = executed_flops_per_feature(m) * n_pts_done
             ks = max(k1_ms, 1e-9) * 1e-3
@@ -436,9 +447,9 @@ def main():
                 "note": "stage times of rank 0 from a separate pass with a host synchronisation behind every stage (plane loop "
                         "replicated on every rank; points_build = feature kernel + information pair of the rank's shard; "
                         "allreduce = one RCCL all-reduce of (N+1) x ld f64; update = EKF update from the summed pair + results)"}
-        if world == 1 and not args.no_extras:
+        if not sharded and not args.no_extras:
             extras(line, capi, torch, args, local_rank, name)
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"], ora = cpu_baseline(sc, name, args.cpu_sample_feats if args.cpu_sample_feats > 0 else None)
                 line["speedup_vs_cpu_baseline"] = line["cpu_baseline"]["ms_per_step"] / ms_per_step
@@ -447,11 +458,19 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line.setdefault("cpu_baseline", None)
                 print("cpu baseline / accept-set comparison skipped: %r" % (e,), file=sys.stderr)
-        print(json.dumps(line))
+        out_line = json.dumps(line)
+    else:
+        out_line = None
     run.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
+    if out_line is not None:
+        if real_stdout is not None:
+            real_stdout.write(out_line + "\n")
+            real_stdout.flush()
+        else:
+            print(out_line)
 
 
 def extras(line, capi, torch, args, device, headline):

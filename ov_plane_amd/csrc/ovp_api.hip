@@ -813,6 +813,19 @@ static int set_substate(ovp_ctx* c, const std::vector<int>& ids) {
 
 static int chol_of_P(ovp_ctx* c, hipStream_t s) {
   const int n = c->n, ld = c->ld;
+  static const bool first_gen = getenv("OVP_TILECHOL_P") != nullptr;  // A/B: the first-generation kernel
+  if (!first_gen && n <= ovp_chol2_max_n() + 1) {  // dense factor from the second-generation kernel
+    ovp::Chol2Job j;
+    memset(&j, 0, sizeof(j));
+    j.A = c->P;
+    j.n = n;
+    j.ld = ld;
+    j.mode = 0;
+    j.flag = c->flags;
+    j.Ldense = c->L;
+    j.ldo = ld;
+    return (int)ovp_launch_chol2(&j, nullptr, nullptr, s);
+  }
   if (n <= OVP_TILECHOL_NMAX) return (int)ovp_launch_tilechol(c->P, c->L, nullptr, nullptr, n, ld, c->flags, 0, s);
   if (substate_ok(c)) return 0;  // the sub-state update factors Pss, not P
   return (int)ovp_launch_chol(c->P, c->L, n, ld, c->flags, 0, s);
