@@ -103,26 +103,33 @@ __device__ __forceinline__ double bcast_row(const double& src) {
 }
 
 // Fused elimination of a 16x16 diagonal block (d: row r = lane & 15, a copy in each DPP row) and of one panel tile per DPP row
-// (p).  On return d = row r of L_kk (entries above the diagonal are garbage), p = row r of A_ik L_kk^-T.  piv_out[c] = pivot of
-// column c before the square root (lane-uniform).  Returns true if a pivot was not positive.
-// pw (null for lanes without a panel tile): row r of the panel tile's LDS image; a pair of columns is stored as soon as it is
-// final, so the publication of the panel rides in the gaps of the chain instead of following it.
-__device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], double* __restrict__ piv_out, const bool write_piv,
-                                             const double floor, dbl2_t* __restrict__ pw) {
-  bool bad = false;
-  double piv = bcast_row<0>(d[0]);
+// (p).  On return d = row r of L_kk (entries above the diagonal are garbage), p = row r of A_ik L_kk^-T, pv[c] = pivot of column c
+// before the square root (lane-uniform).  Returns true if a pivot was not positive.
+// pw: row r of the panel tile's LDS image (EVERY lane has one - lanes without a tile of their own mirror another DPP row's or
+// point at scratch, see the caller); a pair of columns is stored as soon as it is final, so the publication of the panel rides in
+// the gaps of the chain instead of following it.
+// What the chain must not contain (tools/dpp64_bench.hip, cycles per 16 columns on one wave: 2460 for the bare elimination):
+// a store under a lane mask per column (the pivot by lane 0: +240; the panel pairs by the lanes that have a tile: +800 over the
+// unmasked stores - every masked block is an EXEC round trip through the scalar unit), a compare whose result goes through the
+// scalar unit back into a select (the pivot floor test as `floor > 0 && !(piv >= floor)`: +1000 together with the per-column
+// `bad`).  So: the pivots are stored pair by pair by EVERY lane (same words, same values - the waves' copies of the diagonal block
+// are identical; WRITE_PIV - only where somebody reads them), only the last one is tested, the floor test exists only in the HAS_FLOOR instantiation and selects on VCC, the
+// panel stores are unconditional.
+template <bool HAS_FLOOR, bool WRITE_PIV>
+__device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], dbl2_t* __restrict__ pvw, const double floor,
+                                             dbl2_t* __restrict__ pw) {
+  double piv = bcast_row<0>(d[0]), piv_prev = 0.0;
   sfor<16>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    if (write_piv) piv_out[c] = piv;
-    bad = bad || !(piv > 0.0);
-    // floor > 0: a pivot below it marks a direction the (positive semi-definite) matrix does not determine - the column is
+    // floor: a pivot below it marks a direction the (positive semi-definite) matrix does not determine - the column is
     // dropped (no elimination with it, zero entry in the solution) instead of being divided by
-    // 1 / sqrt(pivot): v_rsq_f64 (~2^-26 relative) and ONE Newton step (-> a couple of ulp; the second step of rsqrt_nr2 is
+    // 1 / sqrt(pivot): v_rsq_f64 (~2^-26 relative) and ONE Newton step (-> a couple of ulp; the second step of rsq_nr2 is
     // invisible next to the rounding of the updates that follow every pivot - tests: factor against numpy to 1e-13), folded into the
     // scaling: with y0 = rsq(piv), e = 0.5 - 0.5 piv y0^2 the scaled entries are d y0 (1 + e), and d y0, p y0, -d y0 are formed
     // beside e.  Dependent f64 operations from the pivot to the first update of the next one: rsq, piv y0 / 2, e, l - four instead
     // of eight (two Newton steps, then the scaling, then the negation): this chain is what a tile step consists of.
-    const double y0 = (floor > 0.0 && !(piv >= floor)) ? 0.0 : __builtin_amdgcn_rsq(piv);
+    double y0 = __builtin_amdgcn_rsq(piv);
+    if constexpr (HAS_FLOOR) y0 = (piv >= floor) ? y0 : 0.0;
     const double hy = (0.5 * piv) * y0;
     const double ly = d[c] * y0, py = p[c] * y0;
     const double e = fma(-hy, y0, 0.5);
@@ -131,6 +138,8 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
     double nl = fma(-ly, e, -ly);  // == -l
     d[c] = l;
     p[c] = q;
+    if constexpr (WRITE_PIV && (c & 1) == 1) pvw[c >> 1] = dbl2_t{piv_prev, piv};  // (every lane, the same words, the same values)
+    piv_prev = piv;
     if constexpr (c + 1 < 16) {
       // next pivot first: its broadcast / rsq / Newton chain then overlaps the remaining updates of this column
       fmac_bcast_nop<c + 1>(d[c + 1], nl, l);
@@ -142,11 +151,12 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
         fmac_bcast<j>(p[j], nl, q);
       });
     }
-    if constexpr ((c & 1) == 1) {
-      if (pw) pw[c >> 1] = dbl2_t{p[c - 1], p[c]};
-    }
+    if constexpr ((c & 1) == 1) pw[c >> 1] = dbl2_t{p[c - 1], p[c]};
   });
-  return bad;
+  // a pivot that is not positive (or NaN) turns everything behind it into NaN - 1 / sqrt of it scales the whole column, and every
+  // later update multiplies by an entry of that column - so the last pivot tells for all sixteen.  (With a floor dropped columns
+  // stop the propagation, and the caller does not ask.)
+  return HAS_FLOOR ? false : !(piv > 0.0);
 }
 
 // acc -= X Y^T for two row-major LDS tiles (pitch C2_TS).  The sum over the 16 inner indices is split over the four MFMAs as
@@ -250,7 +260,7 @@ struct Chol2Lds {
   double* ybuf;   // back substitution result                     [nt * 16]
   double* pivs;   // pivots before the square root               [nt * 16]
   double* slots;  // [C2_TW][16] partial sums of the back substitution
-  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [4] cnt_y, [6] spin timeout
+  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [3] cnt_diag, [4] cnt_y, [5] exports confirmed, [6] spin timeout
 };
 __host__ __device__ constexpr int chol2_lds_doubles(int nt) { return C2_TSZ * (1 + 3 * nt) + 3 * 16 * nt + C2_TW * 16 + 8; }
 __device__ __forceinline__ Chol2Lds chol2_carve(double* lds, int nt) {
@@ -333,6 +343,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   int* cnt_col = S.cnt;
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
+  int* cnt_diag = S.cnt + 3;
   if (tid < 8) S.cnt[tid] = 0;
   for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) {
     S.zbuf[i] = 0.0;
@@ -388,7 +399,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       }
       c2_wait_ge(cnt_col, C2_TW * (k - cl + 1), S.cnt + 6);  // column k is in LDS
       if (ew == 0) C2_STAMP(k, 1);
-      bool flushed = false;
+      bool flushed = false, signalled = false;
       // panel tiles k+1 .. nt-1 are dealt out over (elimination wave, DPP row): 16 per pass, a second pass only when the
       // column has 17 of them (bordered dimension 273..288, first column)
       for (int base = 0; base == 0 || k + 1 + base < nt; base += 4 * C2_EW) {
@@ -397,28 +408,44 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         const bool first = (base == 0);
         if ((first && ew == 0) || k + 1 + base + ew < nt) {
           double d[16], p[16];
+          // lanes without a panel tile of their own (DPP rows behind the end of the column) repeat the wave's first tile - same
+          // values into the same LDS words - or, when the wave has none at all (the last step), write into the image of L_kk, which
+          // this wave overwrites with the real block below: the panel stores of the elimination then need no lane mask
+          const bool wave_has = k + 1 + base + ew < nt;  // (wave-uniform)
+          const int src_i = has_p ? my_i : k + 1 + base + ew;
+          dbl2_t* pw = reinterpret_cast<dbl2_t*>((wave_has ? pbk + src_i * C2_TSZ : S.Dsave + k * C2_TSZ) + r * C2_TS);
           {
             const dbl2_t* dr = reinterpret_cast<const dbl2_t*>(S.Dbuf + r * C2_TS);
-            const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(pbk + (has_p ? my_i : 0) * C2_TSZ + r * C2_TS);
+            const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(pbk + (wave_has ? src_i : 0) * C2_TSZ + r * C2_TS);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               const dbl2_t dv = dr[q];
               d[2 * q] = dv[0];
               d[2 * q + 1] = dv[1];
               const dbl2_t pq = pr[q];
-              p[2 * q] = has_p ? pq[0] : 0.0;
-              p[2 * q + 1] = has_p ? pq[1] : 0.0;
+              p[2 * q] = wave_has ? pq[0] : 0.0;
+              p[2 * q + 1] = wave_has ? pq[1] : 0.0;
             }
           }
-          dbl2_t* pw = has_p ? reinterpret_cast<dbl2_t*>(pbk + my_i * C2_TSZ + r * C2_TS) : nullptr;
-          if (!(J.dbg & 1)) bad = fused_elim16(d, p, S.pivs + 16 * k, first && ew == 0 && lane == 0, floor_eff, pw) || bad;
+          if (!(J.dbg & 1)) {
+            dbl2_t* pvw = reinterpret_cast<dbl2_t*>(S.pivs + 16 * k);
+            // (the plane update, mode 1, never looks at its pivots: the stores are 2 us of its 75)
+            if (floor_eff > 0.0) bad = fused_elim16<true, true>(d, p, pvw, floor_eff, pw) || bad;
+            else if (J.mode == 1) bad = fused_elim16<false, false>(d, p, pvw, 0.0, pw) || bad;
+            else bad = fused_elim16<false, true>(d, p, pvw, 0.0, pw) || bad;
+          }
           if (ew == 0) C2_STAMP(k, 2);
-          if (exporting && !flushed) {  // (wave-uniform)
-            // the exports of the PREVIOUS step have long reached memory: confirming that here costs nothing, whereas waiting for
-            // this step's stores (a memory round trip, 3 - 5 K cycles) would sit on the elimination chain
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            c2_signal(S.cnt + 5, lane);
-            flushed = true;
+          // the panel is out: the tile waves start on the next column while the rest of this step's results is put down
+          if (k + 1 + base + 4 * C2_EW >= nt) {  // (last pass of the column)
+            if (exporting && !flushed) {  // (wave-uniform)
+              // the exports of the PREVIOUS step have long reached memory: confirming that here costs nothing, whereas waiting
+              // for this step's stores (a memory round trip, 3 - 5 K cycles) would sit on the elimination chain
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              c2_signal(S.cnt + 5, lane);
+              flushed = true;
+            }
+            c2_signal(cnt_panel, lane);
+            signalled = true;
           }
           if (has_p) {
             if (my_i == tb && r == rb && nb > n) {
@@ -436,23 +463,28 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
               for (int q = 0; q < 8; ++q) c2_store_through_sys(xw + 32 * q, dbl2_t{p[2 * q], p[2 * q + 1]});
             }
           }
-          if (first && ew == 0 && g == 0) {
-            dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
+          if (first && ew == 0) {
+            if (g == 0) {
+              dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dw[q] = dbl2_t{(2 * q <= r) ? d[2 * q] : 0.0, (2 * q + 1 <= r) ? d[2 * q + 1] : 0.0};
-            if (k == tb && r == rb && nb > n) {
+              for (int q = 0; q < 8; ++q) dw[q] = dbl2_t{(2 * q <= r) ? d[2 * q] : 0.0, (2 * q + 1 <= r) ? d[2 * q + 1] : 0.0};
+              if (k == tb && r == rb && nb > n) {
 #pragma unroll
-              for (int c = 0; c < 16; ++c)
-                if (c < rb) S.zbuf[16 * k + c] = d[c];
+                for (int c = 0; c < 16; ++c)
+                  if (c < rb) S.zbuf[16 * k + c] = d[c];
+              }
             }
+            c2_signal(cnt_diag, lane);  // L_kk is in LDS (the owner of tile (k, k) waits for this one)
           }
         }
       }
-      if (exporting && !flushed) {  // (a wave without exported rows in this step still confirms the previous one)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        c2_signal(S.cnt + 5, lane);
+      if (!signalled) {  // a wave without work in this step
+        if (exporting && !flushed) {  // (it still confirms its exports of the previous one)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          c2_signal(S.cnt + 5, lane);
+        }
+        c2_signal(cnt_panel, lane);
       }
-      c2_signal(cnt_panel, lane);
       if (exporting && ew == 0) {
         // in the gap in front of the next column
         if (k > 0) {
@@ -582,7 +614,10 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       };
       if (next_own) c2_col_slots(k + 1, nt, tw, lo1, hi1, loff);
       if (tw == 0) C2_STAMP(k, 8);
-      c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // panel k (and L_kk) are in LDS
+      // every tile wave is done with panel k - 1, whose buffer receives column k + 1 (long true by the time panel k arrives: looked
+      // at here, in the shadow of the elimination, instead of between the update of the next column and its publication)
+      if (next_own) c2_wait_ge(cnt_trail, C2_TW * k, S.cnt + 6);
+      c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // panel k is in LDS
       if (tw == 0) C2_STAMP(k, 9);
       if (next_own) {
         // the next column is what the elimination waves wait for: above the other tile waves' trailing updates until it is out
@@ -593,7 +628,6 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
         });
         if (tw == 0) C2_STAMP(k, 10);
-        c2_wait_ge(cnt_trail, C2_TW * k, S.cnt + 6);  // every tile wave is done with panel k - 1, whose buffer receives column k + 1
         slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
           if (ti[s] == k + 1) put_rowmajor_k(S.Dbuf, tile[s]);
@@ -603,7 +637,9 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         __builtin_amdgcn_s_setprio(0);
         if (tw == 0) C2_STAMP(k, 11);
       }
-      // own tiles of column k take their final values (off the critical path: the panel buffer lives two more steps)
+      // own tiles of column k take their final values (off the critical path: the panel buffer lives two more steps; L_kk is put
+      // down behind the elimination waves' signal, its owner waits for a counter of its own)
+      if (k >= cl && (k * nt - (k * (k - 1)) / 2 - loff) % C2_TW == tw) c2_wait_ge(cnt_diag, k - cl + 1, S.cnt + 6);
       slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
