@@ -25,6 +25,8 @@ namespace ovp {
 static constexpr int C2_TS = 18;             // LDS row pitch of a 16x16 tile (doubles): rows 16-byte aligned
 static constexpr int C2_TSZ = 16 * C2_TS;    // doubles per LDS tile
 static constexpr int C2_WAVES = 12;          // 4 elimination waves + 8 tile waves
+static constexpr int C2_EW = 4;
+static constexpr int C2_TW = C2_WAVES - C2_EW;
 
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 
@@ -115,9 +117,9 @@ __device__ __forceinline__ double bcast_row(const double& src) {
 // `bad`).  So: the pivots are stored pair by pair by EVERY lane (same words, same values - the waves' copies of the diagonal block
 // are identical; WRITE_PIV - only where somebody reads them), only the last one is tested, the floor test exists only in the HAS_FLOOR instantiation and selects on VCC, the
 // panel stores are unconditional.
-template <bool HAS_FLOOR, bool WRITE_PIV>
+template <bool HAS_FLOOR, bool WRITE_PIV, bool WRITE_D>
 __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], dbl2_t* __restrict__ pvw, const double floor,
-                                             dbl2_t* __restrict__ pw) {
+                                             dbl2_t* __restrict__ pw, dbl2_t* __restrict__ dw, const int r) {
   double piv = bcast_row<0>(d[0]), piv_prev = 0.0;
   sfor<16>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
@@ -152,6 +154,9 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
       });
     }
     if constexpr ((c & 1) == 1) pw[c >> 1] = dbl2_t{p[c - 1], p[c]};
+    // WRITE_D (one wave per step): row r of L_kk, zero above the diagonal, pair by pair like the panel (the four DPP rows write the
+    // same words) - behind the chain these stores and their selects were 800 cycles in front of the wave's next step
+    if constexpr (WRITE_D && (c & 1) == 1) dw[c >> 1] = dbl2_t{(c - 1 <= r) ? d[c - 1] : 0.0, (c <= r) ? d[c] : 0.0};
   });
   // a pivot that is not positive (or NaN) turns everything behind it into NaN - 1 / sqrt of it scales the whole column, and every
   // later update multiplies by an entry of that column - so the last pivot tells for all sixteen.  (With a floor dropped columns
@@ -172,6 +177,52 @@ __device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* 
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[0], y1[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[1], y1[1], acc, 0, 0, 0);
   return acc;
+}
+
+// The last update of a column by the wave that eliminates it (chol2_factor, elimination waves): the wave's NH panel tiles
+// (tile rows i0, i0 + 4, ...) and the diagonal block of column k get  -= P_i P_k^T  with panel k - 1 (buffer pbp), in place in their
+// row-major LDS images (the diagonal block: Dbuf -> Dupd).  All operand reads first, then the four MFMAs of every tile round by
+// round: NH + 1 independent accumulation chains, so an MFMA never waits for its predecessor (a dependent f64 MFMA starts ~200
+// cycles behind it, an independent one ~110).  With `if (tile exists)` around each product the chains ran one after the other.
+template <int NH>
+__device__ __forceinline__ void c2_last_update(double* Dbuf, double* Dupd, double* Lim, const double* pbp, int k, int i0, int g, int r,
+                                               bool skip) {
+  const double* Pk = pbp + k * C2_TSZ;
+  const dbl2_t* yp = reinterpret_cast<const dbl2_t*>(Pk + r * C2_TS + 4 * g);
+  const dbl2_t y0 = yp[0], y1 = yp[1];
+  double4_t acc[NH + 1];
+  dbl2_t x0[NH + 1], x1[NH + 1];
+#pragma unroll
+  for (int t = 0; t < NH; ++t) {
+    const double* im = Lim + (i0 + C2_EW * t) * C2_TSZ;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[t][v] = im[(g + 4 * v) * C2_TS + r];
+    const dbl2_t* xp = reinterpret_cast<const dbl2_t*>(pbp + (i0 + C2_EW * t) * C2_TSZ + r * C2_TS + 4 * g);
+    x0[t] = xp[0];
+    x1[t] = xp[1];
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) acc[NH][v] = Dbuf[(g + 4 * v) * C2_TS + r];
+  x0[NH] = y0;
+  x1[NH] = y1;
+  if (!skip) {
+#pragma unroll
+    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[t][0], y0[0], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[t][1], y0[1], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][0], y1[0], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][1], y1[1], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NH; ++t) {
+    double* im = Lim + (i0 + C2_EW * t) * C2_TSZ;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) im[(g + 4 * v) * C2_TS + r] = acc[t][v];
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) Dupd[(g + 4 * v) * C2_TS + r] = acc[NH][v];
 }
 
 // 16-byte global store with system scope (sc0 sc1): written through the XCD's L2, visible to the other XCDs once vmcnt has drained
@@ -203,14 +254,17 @@ __device__ __forceinline__ void c2_load2_through_sys(const double* p0, const dou
 
 // Roles.  Waves 0..3 eliminate (VALU, DPP chains), waves 4..11 hold the tiles and run the trailing update (MFMA): the
 // elimination of panel k + 1 overlaps the trailing update of step k on the other execution pipe of the same SIMDs.
+// Since round 3 the LAST update of a column - panel k into column k + 1 - belongs to the elimination waves too (c2_last_update:
+// their own MFMAs on their own tiles, in the row-major LDS image the tile waves published a step ahead), so the chain
+// elimination -> update of the next column -> elimination never leaves them; the tile waves apply panel k to the columns
+// from k + 2 on and publish column k + 2, complete up to that panel, at the end of the step.
 // Hand-over through LDS counters (a wave's LDS traffic is in order, so data written before the increment is visible to whoever
 // sees the increment):
-//   cnt_col   += 1 per tile wave once its tiles of the NEXT column are in LDS          (tile waves -> elimination waves)
-//   cnt_panel += 1 per elimination wave once its part of the panel is in LDS           (elimination waves -> tile waves)
+//   cnt_col   += 1 per tile wave once its tiles of a column are in LDS (Dbuf + the images of L_ii behind it, free until step i)
+//   cnt_used  += 1 per elimination wave once it has that column in registers: the same LDS words may take the next one
+//   cnt_panel += 1 per elimination wave once its part of the panel is in LDS (tile waves, and the other elimination waves)
 //   cnt_trail += 1 per tile wave at the end of a step: the panel buffer of that step may be overwritten two steps later
-static constexpr int C2_EW = 4;
-static constexpr int C2_TW = C2_WAVES - C2_EW;
-
+//   cnt_diag  += 1 per step once L_kk is in LDS (the tile wave that owns tile (k, k))
 // (busy polling: with s_sleep 1 between two looks a hand-over was noticed ~60 cycles later on average, 1.3 % of the config-3 step)
 // Every spin is bounded: a hand-over that never comes (it cannot, as long as every wave walks the same step sequence - a bad pivot
 // does not change it, NaNs just flow through) raises the timeout word instead of hanging the CU until the watchdog; the caller
@@ -253,20 +307,22 @@ __device__ __forceinline__ void slot_range(int lo, int hi, F&& f) {
 
 // LDS carve-up (doubles)
 struct Chol2Lds {
-  double* Dbuf;   // current diagonal block, row-major
+  double* Dbuf;   // diagonal block of the next column as the tile waves publish it, row-major
+  double* Dupd;   // ... with the last panel applied (every elimination wave writes the same values)
   double* PB;     // 2 x nt panel tiles
   double* Dsave;  // nt finished diagonal blocks L_kk (row-major, zero above the diagonal)
   double* zbuf;   // border row of the factor: z = L^-1 brow^T   [nt * 16]
   double* ybuf;   // back substitution result                     [nt * 16]
   double* pivs;   // pivots before the square root               [nt * 16]
   double* slots;  // [C2_TW][16] partial sums of the back substitution
-  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [3] cnt_diag, [4] cnt_y, [5] exports confirmed, [6] spin timeout
+  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [3] cnt_diag, [4] cnt_y, [5] exports confirmed, [6] spin timeout, [7] cnt_used
 };
-__host__ __device__ constexpr int chol2_lds_doubles(int nt) { return C2_TSZ * (1 + 3 * nt) + 3 * 16 * nt + C2_TW * 16 + 8; }
+__host__ __device__ constexpr int chol2_lds_doubles(int nt) { return C2_TSZ * (2 + 3 * nt) + 3 * 16 * nt + C2_TW * 16 + 8; }
 __device__ __forceinline__ Chol2Lds chol2_carve(double* lds, int nt) {
   Chol2Lds s;
   s.Dbuf = lds;
-  s.PB = s.Dbuf + C2_TSZ;
+  s.Dupd = s.Dbuf + C2_TSZ;
+  s.PB = s.Dupd + C2_TSZ;
   s.Dsave = s.PB + 2 * nt * C2_TSZ;
   s.zbuf = s.Dsave + nt * C2_TSZ;
   s.ybuf = s.zbuf + 16 * nt;
@@ -344,6 +400,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
   int* cnt_diag = S.cnt + 3;
+  int* cnt_used = S.cnt + 7;
   if (tid < 8) S.cnt[tid] = 0;
   for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) {
     S.zbuf[i] = 0.0;
@@ -397,9 +454,30 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         if (ew == 0) C2_STAMP(k, 3);
         continue;
       }
-      c2_wait_ge(cnt_col, C2_TW * (k - cl + 1), S.cnt + 6);  // column k is in LDS
+      double* pbp = S.PB + ((k + 1) & 1) * nt * C2_TSZ;  // panel k - 1
+      // column k is in LDS (without panel k - 1: that one is applied here), panel k - 1 is complete (the other waves' tiles / the
+      // import), and the tile waves are done with panel k - 2, whose buffer receives panel k: one look at the three counters per
+      // round (three waits in a row were three LDS round trips, 700 cycles of a late step)
+      {
+        const int t_col = C2_TW * (k - cl + 1), t_panel = C2_EW * k, t_trail = C2_TW * (k - 1);
+        int spins = 0;
+        for (;;) {
+          const int a = __hip_atomic_load(cnt_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int b = __hip_atomic_load(cnt_panel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int c = __hip_atomic_load(cnt_trail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (J.stamps && spins == 0 && ew == 0 && lane == 0)  // diagnostics: what the step found on arrival
+            J.stamps[k * 16 + 4] = (long long)(a - t_col) * 1000000 + (long long)(b - t_panel) * 1000 + (c - t_trail) + 500500500;
+          if (a >= t_col && b >= t_panel && c >= t_trail) break;
+          asm volatile("s_nop 7");
+          if (__builtin_expect(++spins > C2_SPIN_LIMIT, 0)) {
+            __hip_atomic_store(S.cnt + 6, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
       if (ew == 0) C2_STAMP(k, 1);
-      bool flushed = false, signalled = false;
+      bool flushed = false, signalled = false, used = false;
       // panel tiles k+1 .. nt-1 are dealt out over (elimination wave, DPP row): 16 per pass, a second pass only when the
       // column has 17 of them (bordered dimension 273..288, first column)
       for (int base = 0; base == 0 || k + 1 + base < nt; base += 4 * C2_EW) {
@@ -409,14 +487,32 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         if ((first && ew == 0) || k + 1 + base + ew < nt) {
           double d[16], p[16];
           // lanes without a panel tile of their own (DPP rows behind the end of the column) repeat the wave's first tile - same
-          // values into the same LDS words - or, when the wave has none at all (the last step), write into the image of L_kk, which
-          // this wave overwrites with the real block below: the panel stores of the elimination then need no lane mask
+          // values into the same LDS words - or, when the wave has none at all (the last step: no other wave is at work), write
+          // into Dupd, which it has read by then: the panel stores of the elimination then need no lane mask
           const bool wave_has = k + 1 + base + ew < nt;  // (wave-uniform)
           const int src_i = has_p ? my_i : k + 1 + base + ew;
-          dbl2_t* pw = reinterpret_cast<dbl2_t*>((wave_has ? pbk + src_i * C2_TSZ : S.Dsave + k * C2_TSZ) + r * C2_TS);
+          dbl2_t* pw = reinterpret_cast<dbl2_t*>((wave_has ? pbk + src_i * C2_TSZ : S.Dupd) + r * C2_TS);
+          // ---- the last update of the column, by the waves that eliminate it: tile (i, k) -= P_i P_k^T with panel k - 1 ----
+          // The tile waves hand over column k with the panels up to k - 2 applied, a step ahead; what used to sit between two
+          // eliminations - panel signal, a tile wave's look at it (behind whatever it was updating), its product, publication, the
+          // elimination waves' look at that - is this wave's own product on its own tiles now: no hand-over, and the tile waves'
+          // trailing update never holds up the chain.  The diagonal block is updated by every wave (same values into Dupd).
+          if (k >= 1) {
+            const int i0 = k + 1 + base + ew;  // (wave-uniform: tile rows of the four DPP rows are i0, i0 + 4, i0 + 8, i0 + 12)
+            const int nh = i0 >= nt ? 0 : ((nt - i0 + C2_EW - 1) / C2_EW < 4 ? (nt - i0 + C2_EW - 1) / C2_EW : 4);
+            const bool skip = (J.dbg & 2) != 0;
+            switch (nh) {
+              case 0: c2_last_update<0>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
+              case 1: c2_last_update<1>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
+              case 2: c2_last_update<2>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
+              case 3: c2_last_update<3>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
+              default: c2_last_update<4>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
+            }
+            C2_WSYNC();  // (the rows are read back by other lanes of this wave)
+          }
           {
-            const dbl2_t* dr = reinterpret_cast<const dbl2_t*>(S.Dbuf + r * C2_TS);
-            const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(pbk + (wave_has ? src_i : 0) * C2_TSZ + r * C2_TS);
+            const dbl2_t* dr = reinterpret_cast<const dbl2_t*>((k >= 1 ? S.Dupd : S.Dbuf) + r * C2_TS);
+            const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(S.Dsave + (wave_has ? src_i : k) * C2_TSZ + r * C2_TS);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               const dbl2_t dv = dr[q];
@@ -427,12 +523,26 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
               p[2 * q + 1] = wave_has ? pq[1] : 0.0;
             }
           }
+          if (k + 1 + base + 4 * C2_EW >= nt) {
+            // the column is in registers: its LDS image (Dbuf and the L_ii images behind k) may receive the next one
+#pragma unroll
+            for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(d[c]), "+v"(p[c]));
+            c2_signal(cnt_used, lane);
+            used = true;
+          }
           if (!(J.dbg & 1)) {
             dbl2_t* pvw = reinterpret_cast<dbl2_t*>(S.pivs + 16 * k);
             // (the plane update, mode 1, never looks at its pivots: the stores are 2 us of its 75)
-            if (floor_eff > 0.0) bad = fused_elim16<true, true>(d, p, pvw, floor_eff, pw) || bad;
-            else if (J.mode == 1) bad = fused_elim16<false, false>(d, p, pvw, 0.0, pw) || bad;
-            else bad = fused_elim16<false, true>(d, p, pvw, 0.0, pw) || bad;
+            dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
+            if (first && ew == 0) {  // (this wave also puts L_kk down)
+              if (floor_eff > 0.0) bad = fused_elim16<true, true, true>(d, p, pvw, floor_eff, pw, dw, r) || bad;
+              else if (J.mode == 1) bad = fused_elim16<false, false, true>(d, p, pvw, 0.0, pw, dw, r) || bad;
+              else bad = fused_elim16<false, true, true>(d, p, pvw, 0.0, pw, dw, r) || bad;
+            } else {
+              if (floor_eff > 0.0) bad = fused_elim16<true, true, false>(d, p, pvw, floor_eff, pw, dw, r) || bad;
+              else if (J.mode == 1) bad = fused_elim16<false, false, false>(d, p, pvw, 0.0, pw, dw, r) || bad;
+              else bad = fused_elim16<false, true, false>(d, p, pvw, 0.0, pw, dw, r) || bad;
+            }
           }
           if (ew == 0) C2_STAMP(k, 2);
           // the panel is out: the tile waves start on the next column while the rest of this step's results is put down
@@ -465,9 +575,6 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           }
           if (first && ew == 0) {
             if (g == 0) {
-              dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
-#pragma unroll
-              for (int q = 0; q < 8; ++q) dw[q] = dbl2_t{(2 * q <= r) ? d[2 * q] : 0.0, (2 * q + 1 <= r) ? d[2 * q + 1] : 0.0};
               if (k == tb && r == rb && nb > n) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
@@ -478,6 +585,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           }
         }
       }
+      if (!used) c2_signal(cnt_used, lane);
       if (!signalled) {  // a wave without work in this step
         if (exporting && !flushed) {  // (it still confirms its exports of the previous one)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -522,6 +630,23 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       for (int v = 0; v < 4; ++v) t[v] = buf[(lr + 4 * v) * C2_TS + lc];
       return t;
     };
+    // the diagonal tiles (+ I) and the tile rows that hold the border row / the identity padding
+    auto patch_slot = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      const int i = ti[s], j = tj[s];
+      if (i >= 0 && (i >= (n >> 4) || i == j)) {
+        const int c = 16 * j + lc;
+        const double brow_c = (nb > n && i == tb) ? S.ybuf[c < n ? c : n - 1] : 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * i + lr + 4 * v;
+          double pad = (r == c) ? 1.0 : 0.0;
+          if (nb > n && r == n) pad = (c < n) ? brow_c : (c == n ? 1e300 : 0.0);
+          const double x = tile[s][v];
+          tile[s][v] = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
+        }
+      }
+    };
     {
       const double* Abase = J.A + (J.sel ? (size_t)((*J.sel) ^ J.sel_xor) * J.sel_stride : (size_t)0);
       int jj = cl, cstart = 0;
@@ -556,23 +681,6 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         }
         tile[s] = t;
       };
-      // the diagonal tiles (+ I) and the tile rows that hold the border row / the identity padding
-      auto patch_slot = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        const int i = ti[s], j = tj[s];
-        if (i >= 0 && (i >= (n >> 4) || i == j)) {
-          const int c = 16 * j + lc;
-          const double brow_c = (nb > n && i == tb) ? S.ybuf[c < n ? c : n - 1] : 0.0;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int r = 16 * i + lr + 4 * v;
-            double pad = (r == c) ? 1.0 : 0.0;
-            if (nb > n && r == n) pad = (c < n) ? brow_c : (c == n ? 1e300 : 0.0);
-            const double x = tile[s][v];
-            tile[s][v] = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
-          }
-        }
-      };
       sfor<SC0>(load_slot);
       if (tw == 0) C2_STAMP(0, 13);
       sfor<SC0>(patch_slot);
@@ -583,7 +691,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           constexpr int s = decltype(sc)::value;
           if (ti[s] >= 0 && tj[s] == 0) {
             if (ti[s] == 0) put_rowmajor(S.Dbuf, tile[s]);
-            else put_rowmajor(S.PB + ti[s] * C2_TSZ, tile[s]);
+            else put_rowmajor(S.Dsave + ti[s] * C2_TSZ, tile[s]);
           }
         });
         c2_signal(cnt_col, lane);
@@ -592,12 +700,30 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       // the rest of the triangle
       sfor<MAXSLOT - SC0>([&](auto sc) { load_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
       sfor<MAXSLOT - SC0>([&](auto sc) { patch_slot(std::integral_constant<int, SC0 + decltype(sc)::value>{}); });
+      if (cl == 0 && 1 < kend) {
+        // column 1 receives its only panel from the elimination waves: published as loaded, once they have taken column 0.
+        // (Earlier - in front of the patch above, which waits for the last load of the batch - does not pay: step 2 of the elimination
+        // waves needs the tile waves' step 0 finished, the buffer of panel 0 becomes that of panel 2, and that is ~35 K cycles
+        // away whatever the order: loads, then 105 tiles x 4 MFMAs.)
+        int lo1 = 0, hi1 = -1;
+        c2_col_slots(1, nt, tw, lo1, hi1, loff);
+        c2_wait_ge(cnt_used, C2_EW, S.cnt + 6);
+        slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (ti[s] == 1) put_rowmajor(S.Dbuf, tile[s]);
+          else put_rowmajor(S.Dsave + ti[s] * C2_TSZ, tile[s]);
+        });
+        c2_signal(cnt_col, lane);
+      }
     }
+    // Step k of a tile wave: panel k goes into every owned tile behind column k + 1 - column k + 1 itself gets it from the
+    // elimination waves, who own the chain - and column k + 2, then complete up to that panel, is published for them: a step
+    // ahead of its use, so nothing here is waited for by the chain (the publication only has to follow the elimination waves'
+    // "column k + 1 taken": it goes into the same LDS words - Dbuf and the images of L_ii, i >= k + 3, free until step i).
     for (int k = 0; k < kend; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
-      double* pbn = S.PB + ((k + 1) & 1) * nt * C2_TSZ;
-      int lo = 0, hi = -1, lo1 = 0, hi1 = -1;
-      const bool next_own = (k + 1 >= cl) && (k + 1 < kend);  // column k + 1 is this workgroup's to publish
+      int lo = 0, hi = -1, lo2 = 0, hi2 = -1;
+      const bool pub = (k + 2 >= cl) && (k + 2 < kend);  // column k + 2 is this workgroup's to publish
       // per-step opaque copies: otherwise the LDS address arithmetic of every slot is hoisted out of the step loop and spills
       int lc_k = lc, lr_k = lr;
       asm volatile("" : "+v"(lc_k), "+v"(lr_k));
@@ -612,45 +738,38 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         for (int v = 0; v < 4; ++v) t[v] = buf[(lr_k + 4 * v) * C2_TS + lc_k];
         return t;
       };
-      if (next_own) c2_col_slots(k + 1, nt, tw, lo1, hi1, loff);
+      if (k + 2 >= cl) c2_col_slots(k + 2, nt, tw, lo2, hi2, loff);  // (lo2 = first slot behind column k + 1; 0 = every owned tile)
+      if (hi2 > s_last) hi2 = s_last;  // (a column of the other workgroup: nothing of it is in the list)
       if (tw == 0) C2_STAMP(k, 8);
-      // every tile wave is done with panel k - 1, whose buffer receives column k + 1 (long true by the time panel k arrives: looked
-      // at here, in the shadow of the elimination, instead of between the update of the next column and its publication)
-      if (next_own) c2_wait_ge(cnt_trail, C2_TW * k, S.cnt + 6);
       c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // panel k is in LDS
       if (tw == 0) C2_STAMP(k, 9);
-      if (next_own) {
-        // the next column is what the elimination waves wait for: above the other tile waves' trailing updates until it is out
-        __builtin_amdgcn_s_setprio(2);
-        // ---- trailing update, column k + 1 first: it is handed to the elimination waves while the rest is updated ----
-        slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
-          constexpr int s = decltype(sc)::value;
-          if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
-        });
-        if (tw == 0) C2_STAMP(k, 10);
-        slot_range<MAXSLOT>(lo1, hi1, [&](auto sc) {
-          constexpr int s = decltype(sc)::value;
-          if (ti[s] == k + 1) put_rowmajor_k(S.Dbuf, tile[s]);
-          else put_rowmajor_k(pbn + ti[s] * C2_TSZ, tile[s]);
-        });
-        c2_signal(cnt_col, lane);
-        __builtin_amdgcn_s_setprio(0);
-        if (tw == 0) C2_STAMP(k, 11);
-      }
-      // own tiles of column k take their final values (off the critical path: the panel buffer lives two more steps; L_kk is put
-      // down behind the elimination waves' signal, its owner waits for a counter of its own)
+      // ---- the trailing update (column k + 2 first in the list) ----
+      slot_range<MAXSLOT>(lo2, s_last, [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
+      });
+      if (tw == 0) C2_STAMP(k, 10);
+      // own tiles of column k take their final values (the panel buffer lives until step k + 2; L_kk is put down behind the
+      // elimination waves' signal, its owner waits for a counter of its own)
       if (k >= cl && (k * nt - (k * (k - 1)) / 2 - loff) % C2_TW == tw) c2_wait_ge(cnt_diag, k - cl + 1, S.cnt + 6);
       slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
       });
-      if (k + 1 < nst && k + 1 < ch) {  // owned tiles in columns behind k + 1 (a remote step that is not the last: all of them)
-        slot_range<MAXSLOT>(hi1 + 1 > lo1 ? hi1 + 1 : lo1, s_last, [&](auto sc) {
+      // column k + 2 goes out LAST: the elimination waves need it a whole step of theirs from now, and they have taken column
+      // k + 1 out of the same LDS words by now (publishing right behind its update - the tile wave idled 2 - 10 K cycles for that
+      // in the first steps, where the elimination waves are themselves held up by the tile waves' previous update)
+      if (pub) {
+        c2_wait_ge(cnt_used, C2_EW * (k + 2 - cl), S.cnt + 6);
+        slot_range<MAXSLOT>(lo2, hi2, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
+          if (ti[s] == k + 2) put_rowmajor_k(S.Dbuf, tile[s]);
+          else put_rowmajor_k(S.Dsave + ti[s] * C2_TSZ, tile[s]);
         });
+        c2_signal(cnt_col, lane);
       }
-      c2_signal(cnt_trail, lane);
+      if (tw == 0) C2_STAMP(k, 11);
+      c2_signal(cnt_trail, lane);  // done with panel k
       if (tw == 0) C2_STAMP(k, 12);
     }
   }

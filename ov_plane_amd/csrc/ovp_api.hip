@@ -2552,8 +2552,8 @@ extern "C" int ovp_debug_chol2(ovp_ctx* c, const double* A_host, int n, int lda,
             h[13] - h[16 + 13], h[14] - h[13], h[15] - h[14], h[0] - h[16 + 13]);
     for (int k = 0; k < nt; ++k) {
       const long long* e = h + k * 16;
-      fprintf(stderr, " k=%2d E: %6lld %6lld %6lld | T: %6lld %6lld %6lld %6lld | E step %6lld T step %6lld\n", k, e[1] - e[0], e[2] - e[1],
-              e[3] - e[2], e[9] - e[8], e[10] - e[9], e[11] - e[10], e[12] - e[11], e[3] - e[0], e[12] - e[8]);
+      fprintf(stderr, " k=%2d E: %6lld %6lld %6lld | T: %6lld %6lld %6lld %6lld | E step %6lld T step %6lld | on arrival: column %+lld panel %+lld trail %+lld | E start %lld T start %lld\n", k, e[1] - e[0], e[2] - e[1],
+              e[3] - e[2], e[9] - e[8], e[10] - e[9], e[11] - e[10], e[12] - e[11], e[3] - e[0], e[12] - e[8], e[4] / 1000000 - 500, (e[4] / 1000) % 1000 - 500, e[4] % 1000 - 500, e[0] - h[0], e[8] - h[0]);
     }
     if (jt.y_out) {
       fprintf(stderr, "back substitution: preparation (sub-diagonal tiles to LDS, inverses of the diagonal blocks) %lld cycles + barrier %lld, chain %lld\n",
