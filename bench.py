@@ -62,7 +62,7 @@ def pmc_traffic(kernel_substr, name, world):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this process;
     quoted only for the workload the passes were taken on): 2 x FETCH_SIZE + WRITE_SIZE - the guide's gfx950 correction (wide
     coalesced reads are tallied at half their bytes) applied as the upper bound, WRITE_SIZE as reported."""
-    tp = os.path.join(_ROOT, "profiles", "r03_c_hbm_traffic_pmc.json")
+    tp = os.path.join(_ROOT, "profiles", "r03_e_hbm_traffic_pmc.json")
     if not os.path.exists(tp) or name != "config3" or world != 1:
         return None, None
     with open(tp) as fh:
@@ -71,7 +71,7 @@ def pmc_traffic(kernel_substr, name, world):
     if not hit or "FETCH_SIZE_KB_avg_per_launch" not in hit[0]:
         return None, None
     b = (2.0 * hit[0]["FETCH_SIZE_KB_avg_per_launch"] + hit[0].get("WRITE_SIZE_KB_avg_per_launch", 0.0)) * 1024.0
-    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r03_c_hbm_traffic_pmc.json (separate rocprofv3 --pmc passes over the same step)"
+    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r03_e_hbm_traffic_pmc.json (separate rocprofv3 --pmc passes over the same step)"
 
 
 def make_workload(name, seed=0, feat_seed=None, chi2_mult=1.0):
@@ -143,7 +143,13 @@ class StepRunner:
         self.ctx.close()
 
 
-def time_steps(torch, fn, steps, warmup, barrier=None):
+PREWARM_STEPS = 100  # untimed: a fresh box runs its first ~100 steps at ramping clocks (3.5 against 3.15 ms per config-3 step).
+# A step COUNT, not a duration: in the multi-GPU run every step holds a collective, all ranks must take the same number.
+
+
+def time_steps(torch, fn, steps, warmup, barrier=None, prewarm=0):
+    for _ in range(prewarm):
+        fn()
     for _ in range(warmup):
         out = fn()
     torch.cuda.synchronize()
@@ -349,7 +355,7 @@ def main():
             fn = lambda: run.step_sharded(rank, world)  # noqa: E731
         else:
             fn = run.step
-        elapsed, (pl, pt) = time_steps(torch, fn, args.steps, args.warmup, barrier)
+        elapsed, (pl, pt) = time_steps(torch, fn, args.steps, args.warmup, barrier, prewarm=PREWARM_STEPS)
         # dominant-kernel launch times with HIP events, in a pass of their own (events between dependent launches cost
         # microseconds each, they must not sit in the timed region above)
         run.ctx.kernel_timer(enable=True, reset=True)
@@ -383,6 +389,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": PREWARM_STEPS,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
