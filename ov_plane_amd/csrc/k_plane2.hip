@@ -331,6 +331,19 @@ __global__ __launch_bounds__(256) void k_plane_dT(int n, const double* __restric
   if (gr < n && gc < n) Tt[(size_t)gr * ld + gc] = Tc[(size_t)gr * ld + gc] + sum;
 }
 
+// One launch instead of six fills at the start of a plane loop (each is a kernel of its own on this stack, ~4 us of boundary):
+// up to six regions, sizes in bytes (multiples of 4); region r is cleared by the blocks b = r, r + 6, r + 12, ...
+struct ZeroJob {
+  void* ptr[6];
+  unsigned long long bytes[6];
+};
+__global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob z) {
+  const int r = blockIdx.x % 6, b = blockIdx.x / 6, nb = (gridDim.x + 5 - r) / 6;
+  unsigned int* p = reinterpret_cast<unsigned int*>(z.ptr[r]);
+  const unsigned long long words = z.bytes[r] >> 2;
+  for (unsigned long long i = (unsigned long long)b * 256 + threadIdx.x; i < words; i += (unsigned long long)nb * 256) p[i] = 0u;
+}
+
 // dst <- the half of buf selected by *cur (lower triangle mirrored to a full symmetric matrix when `sym`)
 __global__ __launch_bounds__(256) void k_select_copy(double* __restrict__ dst, const double* __restrict__ buf, size_t stride,
                                                       const int* __restrict__ cur, int n, int ld, int sym) {
@@ -389,6 +402,20 @@ hipError_t ovp_launch_plane_dT(int n, const double* L0, int ld, const double* W,
                                const int* cur, double* crow, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   hipLaunchKernelGGL(ovp::k_plane_dT, dim3(nt, nt + 1), dim3(256), 0, stream, n, L0, ld, W, b, Tbuf, tstride, cur, crow);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_zero_regions(void* const* ptr, const size_t* bytes, int count, hipStream_t stream) {
+  ovp::ZeroJob z;
+  size_t most = 0;
+  for (int i = 0; i < 6; ++i) {
+    z.ptr[i] = i < count ? ptr[i] : nullptr;
+    z.bytes[i] = i < count ? (unsigned long long)bytes[i] : 0ull;
+    if (i < count && bytes[i] > most) most = bytes[i];
+  }
+  int per = (int)((most / 4 + 4 * 256 - 1) / (4 * 256));  // a thread of the largest region clears ~4 words
+  if (per < 1) per = 1;
+  if (per > 512) per = 512;
+  hipLaunchKernelGGL(ovp::k_zero_regions, dim3(6 * per), dim3(256), 0, stream, z);
   return hipGetLastError();
 }
 hipError_t ovp_launch_select_copy(double* dst, const double* buf, size_t stride, const int* cur, int n, int ld, int sym,

@@ -1818,14 +1818,16 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   double* d_cpfej = dd + 3 * NP;
   double* d_slam_p = dd + 6 * NP;
   double* d_slam_pfej = dd + 6 * NP + 3 * n_slam;
-  HIPCHK(hipMemsetAsync(c->pl_res, 0, sizeof(double) * 4 * NP, s));
-  HIPCHK(hipMemsetAsync(c->pl_dx, 0, sizeof(double) * (size_t)n * NP, s));
-  HIPCHK(hipMemsetAsync(c->pl_used, 0, (size_t)F, s));
-  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
   const size_t tstride = (size_t)(c->n_max + 1) * ld;
+  {
+    // results, per-plane corrections, used-feature mask (rounded up to whole words: the buffer is f_max + 64 bytes), flags,
+    // [0] current T buffer + [1..2] factor bookkeeping (PlaneSolve::cond), half 0 of T (sum of the accepted L0^T A L0): one launch
+    void* zp[6] = {c->pl_res, c->pl_dx, c->pl_used, c->flags, c->pl_cur, c->pl_Tbuf};
+    const size_t zb[6] = {sizeof(double) * 4 * NP, sizeof(double) * (size_t)n * NP, ((size_t)F + 3) & ~(size_t)3, sizeof(int) * 4,
+                          NJ > 0 ? 3 * sizeof(int) : 0, NJ > 0 ? sizeof(double) * (size_t)n * ld : 0};
+    HIPCHK(ovp_launch_zero_regions(zp, zb, 6, s));
+  }
   if (NJ > 0) {
-    HIPCHK(hipMemsetAsync(c->pl_cur, 0, 3 * sizeof(int), s));  // [0] current T buffer, [1..2] factor bookkeeping (PlaneSolve::cond)
-    HIPCHK(hipMemsetAsync(c->pl_Tbuf, 0, sizeof(double) * (size_t)n * ld, s));  // half 0: sum of the accepted L0^T A L0
     rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
     if (rc) return rc;
   }
