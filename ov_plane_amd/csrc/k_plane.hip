@@ -16,6 +16,7 @@
 // moments; K2's kernels reduce them; the update reuses K3 with a dense (non-triangular) factor M, P = M M^T,
 // which is chained M <- M Lt^-T from plane to plane without re-factorizing P.
 #include "ovp_feat_model.h"
+#include "k_tile_body.h"
 #include <utility>
 
 namespace ovp {
@@ -48,17 +49,20 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     const double* cpf = pp.in_state ? (pp.cp_fej + 3 * pp.plane) : cp;  // UpdaterMSCKF.cpp:467-475
     const double pf0 = p.p_FinG[3 * f], pf1 = p.p_FinG[3 * f + 1], pf2 = p.p_FinG[3 * f + 2];
     const double sm = sqrt((double)m) * pp.white_c;
+    // (one division per norm: the whole wave waits for this lane's chain of sqrt / div sequences)
     double d = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
-    double n0 = cp[0] / d, n1 = cp[1] / d, n2 = cp[2] / d;
+    double id = 1.0 / d;
+    double n0 = cp[0] * id, n1 = cp[1] * id, n2 = cp[2] * id;
     res = sm * (0.0 - (n0 * pf0 + n1 * pf1 + n2 * pf2 - d));
     if (p.do_fej) {
       d = sqrt(cpf[0] * cpf[0] + cpf[1] * cpf[1] + cpf[2] * cpf[2]);
-      n0 = cpf[0] / d;
-      n1 = cpf[1] / d;
-      n2 = cpf[2] / d;
+      id = 1.0 / d;
+      n0 = cpf[0] * id;
+      n1 = cpf[1] * id;
+      n2 = cpf[2] * id;
     }
     const double ndp = n0 * pf0 + n1 * pf1 + n2 * pf2;  // p_FinG_fej == p_FinG for MSCKF features
-    const double s = sm / d;
+    const double s = sm * id;
     hcp[0] = s * (pf0 - ndp * n0 - d * n0);
     hcp[1] = s * (pf1 - ndp * n1 - d * n1);
     hcp[2] = s * (pf2 - ndp * n2 - d * n2);
@@ -84,12 +88,14 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     const double g00 = readlane_f64(rsum, reduce_owner_lane<8>(0)), g01 = readlane_f64(rsum, reduce_owner_lane<8>(1));
     const double g02 = readlane_f64(rsum, reduce_owner_lane<8>(2)), g11 = readlane_f64(rsum, reduce_owner_lane<8>(3));
     const double g12 = readlane_f64(rsum, reduce_owner_lane<8>(4)), g22 = readlane_f64(rsum, reduce_owner_lane<8>(5));
-    const double r00 = sqrt(g00), r01 = g01 / r00, r02 = g02 / r00;
-    const double r11 = sqrt(g11 - r01 * r01), r12 = (g12 - r01 * r02) / r11;
-    const double r22 = sqrt(g22 - r02 * r02 - r12 * r12);
-    const double a0 = q[0] / r00;
-    const double a1 = (q[1] - a0 * r01) / r11;
-    const double a2 = (q[2] - a0 * r02) / r22 - a1 * r12 / r22;
+    // R^T R = G with the reciprocals of the diagonal (v_rsq_f64 + two Newton steps each): a sqrt and five divisions per pass were
+    // 3.2 K cycles of dependent div / sqrt sequences.  Q1 is orthonormal to rounding after the second pass either way.
+    const double i00 = rsqrt_nr2(g00), r01 = g01 * i00, r02 = g02 * i00;
+    const double i11 = rsqrt_nr2(g11 - r01 * r01), r12 = (g12 - r01 * r02) * i11;
+    const double i22 = rsqrt_nr2(g22 - r02 * r02 - r12 * r12);
+    const double a0 = q[0] * i00;
+    const double a1 = (q[1] - a0 * r01) * i11;
+    const double a2 = (q[2] - a0 * r02 - a1 * r12) * i22;
     q[0] = a0;
     q[1] = a1;
     q[2] = a2;
@@ -111,11 +117,15 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
 #pragma unroll
     for (int k = 46; k < 64; ++k) v[k] = 0.0;
     const double rsum = wave_transpose_reduce<64>(v);
-    if (lane < 42) {
-      const int t = lane / 14, k = lane - 14 * t;
-      if ((p.calmask >> k) & 1) Gst[t * ldg + p.calcol[k]] = rsum;
-    } else if (lane < 45) {
-      Gst[(lane - 42) * ldg + p.n] = rsum;
+    {
+      // where this lane's sum goes: lanes 0..41 = (projector row t, calibration entry k), 42..44 = the residual column.  The column
+      // is picked by a select chain over the table - a kernel-argument array indexed by a lane-dependent k is a waterfall loop
+      const int t = lane < 42 ? lane / 14 : lane - 42, k = lane - 14 * t;
+      int col = -1;
+#pragma unroll
+      for (int kk = 0; kk < 14; ++kk) col = (k == kk && ((p.calmask >> kk) & 1)) ? p.calcol[kk] : col;
+      if (lane >= 42) col = lane < 45 ? p.n : -1;
+      if (col >= 0) Gst[t * ldg + col] = rsum;
     }
     const double g0 = readlane_f64(rsum, 42), g1 = readlane_f64(rsum, 43), g2 = readlane_f64(rsum, 44);
     gsq = g0 * g0 + g1 * g1 + g2 * g2;
@@ -147,14 +157,22 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     }
   }
   // clone columns
+  {
+    double cv[18];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int l = 0; l < 6; ++l) {
-      double v = q[t] * jrow[l];
-      v += shfl_xor_f64(v, 1);
-      if (valid && r == 0) Gst[t * ldg + ida + l] = v;
+      for (int l = 0; l < 6; ++l) {
+        const double v = q[t] * jrow[l];
+        cv[6 * t + l] = v + shfl_xor_f64(v, 1);
+      }
+    if (valid && r == 0) {  // (one masked block: eighteen of them were eighteen EXEC round trips)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int l = 0; l < 6; ++l) Gst[t * ldg + ida + l] = cv[6 * t + l];
     }
+  }
   __syncthreads();
   {
     double* gout = p.G + (size_t)3 * fl * ldg;

@@ -25,6 +25,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// value of lane (lane ^ S), S = 8, 4, 2 or 1, through DPP (plain VALU; ds_bpermute goes through the LDS crossbar, ~130 cycles):
+// row_ror:8 is the exchange of the two halves of a 16-lane row, xor 4 is row_shr:4 into the upper quads of each half and
+// row_shl:4 into the lower ones (bank masks), xor 2 / xor 1 are quad permutations
+template <int S>
+__device__ __forceinline__ int xor_lane_b32(int x) {
+  static_assert(S == 8 || S == 4 || S == 2 || S == 1, "DPP exchange inside a 16-lane row");
+  if constexpr (S == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);
+  else if constexpr (S == 4) {
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xA, false);
+    return __builtin_amdgcn_update_dpp(t, x, 0x104, 0xF, 0x5, false);
+  } else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+  else return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+}
+template <int S>
+__device__ __forceinline__ double xor_lane_f64(double v) {
+  return __hiloint2double(xor_lane_b32<S>(__double2hiint(v)), xor_lane_b32<S>(__double2loint(v)));
+}
+
 // Transpose-reduce: every lane passes v[0..N) (N a power of two <= 64); on return element 0 of lane L holds
 // sum over all 64 lanes of v[k(L)], where k(L) = top log2(N) bits of the lane id (bit 5 most significant).
 // The remaining (64/N)-lane groups are then combined by a plain butterfly, so every lane of a group holds the
@@ -33,12 +51,33 @@ template <int H, int S>
 struct TransposeReduceStep {
   template <int N>
   static __device__ __forceinline__ void run(double (&v)[N], int lane) {
-    const bool up = (lane & S) != 0;
+    if constexpr (S == 32 || S == 16) {
+      // the gfx950 half / row swaps do the exchange AND the selection: with A = v[k], B = v[k + H], v_permlane32_swap leaves
+      // A' = [A(0..31) | B(0..31)], B' = [A(32..63) | B(32..63)], so A' + B' is A's sum in the lower half and B's in the upper one
+      // (v_permlane16_swap: the same per pair of 16-lane rows).  Plain VALU - the ds_bpermute pair + four selects per exchange
+      // went through the LDS crossbar (~130 cycles a round trip); same operands per sum, so the results are bit-identical.
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-      const double keep = up ? v[k + H] : v[k];
-      const double send = up ? v[k] : v[k + H];
-      v[k] = keep + shfl_xor_f64(send, S);
+      for (int k = 0; k < H; ++k) {
+        const unsigned alo = (unsigned)__double2loint(v[k]), ahi = (unsigned)__double2hiint(v[k]);
+        const unsigned blo = (unsigned)__double2loint(v[k + H]), bhi = (unsigned)__double2hiint(v[k + H]);
+        if constexpr (S == 32) {
+          auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+          auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+          v[k] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+        } else {
+          auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+          auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+          v[k] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+        }
+      }
+    } else {
+      const bool up = (lane & S) != 0;
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        const double keep = up ? v[k + H] : v[k];
+        const double send = up ? v[k] : v[k + H];
+        v[k] = keep + xor_lane_f64<S>(send);
+      }
     }
     if constexpr (H > 1) TransposeReduceStep<H / 2, S / 2>::run(v, lane);
   }
