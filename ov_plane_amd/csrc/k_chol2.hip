@@ -137,14 +137,20 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
     const double e = fma(-hy, y0, 0.5);
     const double l = fma(ly, e, ly);
     const double q = fma(py, e, py);
-    double nl = fma(-ly, e, -ly);  // == -l
+    // nl = -l is the DPP operand of every update of this column.  A DPP read of a VGPR needs two wait states behind the VALU
+    // write; the hazard recognizer does not look inside asm statements, and non-volatile asm statements may be emitted in any
+    // order - so the wait states go WITH THE WRITE (they used to sit in front of the first consumer in source order only: a
+    // later consumer hoisted above it read the previous column's value - it happened, in one instantiation, after an unrelated
+    // change of the code behind the chain)
+    double nl;
+    asm("v_fma_f64 %0, -%1, %2, -%1\n\ts_nop 1" : "=v"(nl) : "v"(ly), "v"(e));
     d[c] = l;
     p[c] = q;
     if constexpr (WRITE_PIV && (c & 1) == 1) pvw[c >> 1] = dbl2_t{piv_prev, piv};  // (every lane, the same words, the same values)
     piv_prev = piv;
     if constexpr (c + 1 < 16) {
       // next pivot first: its broadcast / rsq / Newton chain then overlaps the remaining updates of this column
-      fmac_bcast_nop<c + 1>(d[c + 1], nl, l);
+      fmac_bcast<c + 1>(d[c + 1], nl, l);
       piv = bcast_row<c + 1>(d[c + 1]);
       fmac_bcast<c + 1>(p[c + 1], nl, q);
       sfor<14 - c>([&](auto jc) {
@@ -206,14 +212,30 @@ __device__ __forceinline__ void c2_last_update(double* Dbuf, double* Dupd, doubl
   x0[NH] = y0;
   x1[NH] = y1;
   if (!skip) {
+    // The diagonal block (index NH) is computed by EVERY elimination wave and the copies must agree to the bit (they all go into
+    // Dupd, and each wave reads its rows back from whatever landed last): it always takes two accumulation chains of two MFMAs,
+    // whatever NH is.  A wave with at most one panel tile (the last steps, where the chain is all there is) splits that tile's
+    // sum the same way, so that four independent MFMAs are in flight there as well; a tile belongs to one wave, so its
+    // rounding is a function of the step only.
+    constexpr int NS = NH <= 1 ? NH + 1 : 1;   // tiles with a second chain: the panel tile (if split) and the diagonal block
+    constexpr int S0 = NH + 1 - NS;            // ... are the last NS entries of acc[]
+    double4_t acc2[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) acc2[t] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[t][0], y0[0], acc[t], 0, 0, 0);
 #pragma unroll
+    for (int t = 0; t < NS; ++t) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[S0 + t][0], y1[0], acc2[t], 0, 0, 0);
+#pragma unroll
     for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[t][1], y0[1], acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][0], y1[0], acc[t], 0, 0, 0);
+    for (int t = 0; t < NS; ++t) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[S0 + t][1], y1[1], acc2[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][1], y1[1], acc[t], 0, 0, 0);
+    for (int t = 0; t < S0; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][0], y1[0], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < S0; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][1], y1[1], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) acc[S0 + t] = acc[S0 + t] + acc2[t];
   }
 #pragma unroll
   for (int t = 0; t < NH; ++t) {
@@ -264,7 +286,6 @@ __device__ __forceinline__ void c2_load2_through_sys(const double* p0, const dou
 //   cnt_used  += 1 per elimination wave once it has that column in registers: the same LDS words may take the next one
 //   cnt_panel += 1 per elimination wave once its part of the panel is in LDS (tile waves, and the other elimination waves)
 //   cnt_trail += 1 per tile wave at the end of a step: the panel buffer of that step may be overwritten two steps later
-//   cnt_diag  += 1 per step once L_kk is in LDS (the tile wave that owns tile (k, k))
 // (busy polling: with s_sleep 1 between two looks a hand-over was noticed ~60 cycles later on average, 1.3 % of the config-3 step)
 // Every spin is bounded: a hand-over that never comes (it cannot, as long as every wave walks the same step sequence - a bad pivot
 // does not change it, NaNs just flow through) raises the timeout word instead of hanging the CU until the watchdog; the caller
@@ -315,7 +336,7 @@ struct Chol2Lds {
   double* ybuf;   // back substitution result                     [nt * 16]
   double* pivs;   // pivots before the square root               [nt * 16]
   double* slots;  // [C2_TW][16] partial sums of the back substitution
-  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [3] cnt_diag, [4] cnt_y, [5] exports confirmed, [6] spin timeout, [7] cnt_used
+  int* cnt;       // [0] cnt_col, [1] cnt_panel, [2] cnt_trail, [4] cnt_y, [5] exports confirmed, [6] spin timeout, [7] cnt_used
 };
 __host__ __device__ constexpr int chol2_lds_doubles(int nt) { return C2_TSZ * (2 + 3 * nt) + 3 * 16 * nt + C2_TW * 16 + 8; }
 __device__ __forceinline__ Chol2Lds chol2_carve(double* lds, int nt) {
@@ -399,7 +420,6 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
   int* cnt_col = S.cnt;
   int* cnt_panel = S.cnt + 1;
   int* cnt_trail = S.cnt + 2;
-  int* cnt_diag = S.cnt + 3;
   int* cnt_used = S.cnt + 7;
   if (tid < 8) S.cnt[tid] = 0;
   for (int i = tid; i < 16 * nt; i += C2_WAVES * 64) {
@@ -558,10 +578,8 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
             signalled = true;
           }
           if (has_p) {
-            if (my_i == tb && r == rb && nb > n) {
-#pragma unroll
-              for (int c = 0; c < 16; ++c) S.zbuf[16 * k + c] = p[c];
-            }
+            // (the border row z: its entries are taken from the finished tiles by the tile wave that owns them - sixteen stores
+            //  under a one-lane mask here were in front of this wave's next step)
             if (exporting && my_i >= ch) {  // rows part B needs: the finished panel tile, row r of it from this lane
 
               // written THROUGH the L2 (agent scope): an agent-scope release fence here instead (write-back of the whole L2 +
@@ -573,16 +591,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
               for (int q = 0; q < 8; ++q) c2_store_through_sys(xw + 32 * q, dbl2_t{p[2 * q], p[2 * q + 1]});
             }
           }
-          if (first && ew == 0) {
-            if (g == 0) {
-              if (k == tb && r == rb && nb > n) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                  if (c < rb) S.zbuf[16 * k + c] = d[c];
-              }
-            }
-            c2_signal(cnt_diag, lane);  // L_kk is in LDS (the owner of tile (k, k) waits for this one)
-          }
+          // (L_kk went into LDS inside the chain, in front of this wave's panel signal: whoever has seen panel k has it)
         }
       }
       if (!used) c2_signal(cnt_used, lane);
@@ -751,10 +760,14 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (tw == 0) C2_STAMP(k, 10);
       // own tiles of column k take their final values (the panel buffer lives until step k + 2; L_kk is put down behind the
       // elimination waves' signal, its owner waits for a counter of its own)
-      if (k >= cl && (k * nt - (k * (k - 1)) / 2 - loff) % C2_TW == tw) c2_wait_ge(cnt_diag, k - cl + 1, S.cnt + 6);
       slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
+        // the border row of the factor, z = L^-1 brow^T: row rb of the tiles of tile row tb (columns behind the border are not z)
+        if (nb > n && ti[s] == tb && lr_k == (rb & 3)) {
+          const int col = 16 * k + lc_k;
+          if (col < n) S.zbuf[col] = tile[s][rb >> 2];
+        }
       });
       // column k + 2 goes out LAST: the elimination waves need it a whole step of theirs from now, and they have taken column
       // k + 1 out of the same LDS words by now (publishing right behind its update - the tile wave idled 2 - 10 K cycles for that
