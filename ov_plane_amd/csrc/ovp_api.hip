@@ -1923,15 +1923,16 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.seq = ++c->pl_seq;
     {
       // The update part on two workgroups: tile columns < h and the rest (k_chol2.hip).  Measured (r03, A/B in one call): at 16 tile
-      // columns (N = 240) nothing is gained - a step is bound by the pivot chain and the hand-over between the roles, not by the
-      // trailing update (3.10 against 3.09 ms per config-3 plane loop for h = 6 .. 8) - so one workgroup stays the default there;
-      // from 17 tile columns on (N > 255) the tile registers of one workgroup spill and the split wins (config 4, N = 285, h = 7:
-      // 8.91 against 9.43 ms).  OVP_C2_SPLIT: 0 = never, h = forced.
+      // columns (N = 240) nothing is gained (2.91 against 2.81 ms per config-3 plane loop for h = 5 .. 8: exports + a second gate
+      // hand-over cost what the second CU's f64 pipe gives), so one workgroup stays the default there; from 17 tile columns on
+      // (N > 255) the tile registers of one workgroup spill and the split wins (config 4, N = 285: 7.91 ms for h = 5 or 6, 8.10 for
+      // 7 or 8, 8.69 unsplit).  OVP_C2_SPLIT: 0 = never, h = forced.
       const char* split_s = getenv("OVP_C2_SPLIT");  // (read per call: the tests switch it)
       const int split_env = split_s ? atoi(split_s) : -1;
       const int nb = n + 1, ntb = (nb + 15) / 16;
       const int nst = (nb % 16 == 1) ? ntb - 1 : ntb;  // a border row alone in its tile row takes no step
-      int h = ntb >= 17 ? (2 * nst + 2) / 5 : 0;  // part B also runs the back half of the chain: 7 of 18 steps measured best
+      int h = ntb >= 17 ? nst / 3 : 0;  // part B also runs the back half of the chain: 5 - 6 of 18 steps measured best (7.91 ms per
+                                        // config-4 plane loop against 8.10 for 7 or 8 and 8.69 unsplit)
       if (split_env >= 0) h = split_env < ntb - 1 ? split_env : 0;
       if (h > 9) h = 9;  // pl_xbuf holds nine exported steps
       j0.split_h = h;
