@@ -46,14 +46,11 @@ __global__ __launch_bounds__(PA_THREADS) void k_plane_assemble2(const PlaneAsm a
   //   round 2 (needs the classification): the per-clone Gram entries
   //   then LDS-only steps: 3x3 inverse of the plane block, this row's diagonal, the Schur complement, normalisation.
   // Entries of the extended pair a thread needs: E(r,c), E(p0..2,c), E(c,c) and one of the 13 block-shared ones.
-  auto part_term = [&](int row, int col) {
+  // offset of entry (row, col) of the extended pair inside one split of the G^T G partials (lower tile triangle, 16 x 16 tiles)
+  auto part_off = [&](int row, int col) {
     const int I = max(row, col), J = min(row, col);
     const int ti = I >> 4, tj = J >> 4;
-    const int tile = ti * (ti + 1) / 2 + tj;
-    const int e = (I & 15) * 16 + (J & 15);
-    double d = 0.0;
-    for (int sp = 0; sp < a.n_split; ++sp) d += a.part[((size_t)sp * a.ntile + tile) * 256 + e];
-    return d;
+    return (size_t)(ti * (ti + 1) / 2 + tj) * 256 + (I & 15) * 16 + (J & 15);
   };
   // the block-shared entry of this thread (if any): (row, col) in the extended index space
   int sh_row = -1, sh_col_ = -1, sh_kind = -1;
@@ -71,34 +68,83 @@ __global__ __launch_bounds__(PA_THREADS) void k_plane_assemble2(const PlaneAsm a
   const bool colv = c < n;
   const int cq = colv ? c : 0;
   // ---- round 1 ----
-  const double d_rc = part_term(r, cq), d_cc = part_term(cq, cq);
+  // Everything this thread needs whose address is known up front is requested BEFORE anything is consumed - the first batch of
+  // every sum below is the only one in the shapes that matter (30 clones x 1 chunk, <= 2 splits, <= 100 features); written as one
+  // load-add loop per quantity the kernel was a chain of ~12 memory round trips (16.5 K of its 26 K cycles), the loops that remain
+  // take what a first batch does not cover.  Sums are formed in the same order as before (split by split, clone by clone).
+  double d_rc = 0.0, d_cc = 0.0, d_sh = 0.0;
   double d_pc[3] = {0.0, 0.0, 0.0};
-  if (!a.in_state)
-    for (int k = 0; k < 3; ++k) d_pc[k] = part_term(n + 1 + k, cq);
-  const double d_sh = sh_kind >= 0 ? part_term(sh_row, sh_col_) : 0.0;
-  for (int i = t; i < n; i += PA_THREADS) cm_sh[i] = a.colmap[i];
-  if (t < OVP_GRAM_ELEMS) {
-    // sum over clones x chunks in a fixed order, eight loads in flight at a time (a rolled loop of dependent adds made every
-    // load a round trip of its own: 30 x 0.5 us)
-    const int total = a.n_clones * a.n_chunks;
-    double g = 0.0;
-    int k = 0;
-    for (; k + 8 <= total; k += 8) {
-      double v[8];
+  const bool ext = !a.in_state, shv = sh_kind >= 0;
+  const size_t o_rc = part_off(r, cq), o_cc = part_off(cq, cq);
+  const size_t o_p0 = ext ? part_off(n + 1, cq) : o_rc, o_p1 = ext ? part_off(n + 2, cq) : o_rc, o_p2 = ext ? part_off(n + 3, cq) : o_rc;
+  const size_t o_sh = shv ? part_off(sh_row, sh_col_) : o_rc;
+  auto part_loads = [&](int sp, double (&v)[2][6]) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = a.gramS[(size_t)(k + u) * OVP_GRAM_ELEMS + t];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) g += v[u];
+    for (int u = 0; u < 2; ++u) {
+      const double* pb = a.part + (size_t)(sp + u < a.n_split ? sp + u : a.n_split - 1) * a.ntile * 256;
+      v[u][0] = pb[o_rc];
+      v[u][1] = pb[o_cc];
+      v[u][2] = pb[o_p0];
+      v[u][3] = pb[o_p1];
+      v[u][4] = pb[o_p2];
+      v[u][5] = pb[o_sh];
     }
-    for (; k < total; ++k) g += a.gramS[(size_t)k * OVP_GRAM_ELEMS + t];
+  };
+  auto part_adds = [&](int sp, const double (&v)[2][6]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (sp + u < a.n_split) {
+        d_rc += v[u][0];
+        d_cc += v[u][1];
+        if (ext) d_pc[0] += v[u][2], d_pc[1] += v[u][3], d_pc[2] += v[u][4];
+        if (shv) d_sh += v[u][5];
+      }
+  };
+  constexpr int GB = 32;  // Gram sums: clones x chunks in flight together
+  const int total = a.n_clones * a.n_chunks;
+  const bool gthread = t < OVP_GRAM_ELEMS, cthread = t < 250;
+  const int ce = t % 10, cpart = t / 10;
+  double pv[2][6], gv[GB], cv[4];
+  part_loads(0, pv);
+#pragma unroll
+  for (int u = 0; u < GB; ++u) gv[u] = gthread ? a.gramS[(size_t)(u < total ? u : total - 1) * OVP_GRAM_ELEMS + t] : 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) cv[u] = (cthread && a.nf > 0) ? a.cst[(size_t)(cpart + 25 * u < a.nf ? cpart + 25 * u : 0) * 10 + ce] : 0.0;
+  ColMap cmv;
+  cmv.kind = 0;
+  cmv.idx = cmv.off = cmv.pad = 0;
+  if (t < n) cmv = a.colmap[t];
+  // ---- consume ----
+  part_adds(0, pv);
+  for (int sp = 2; sp < a.n_split; sp += 2) {
+    part_loads(sp, pv);
+    part_adds(sp, pv);
+  }
+  if (t < n) cm_sh[t] = cmv;
+  for (int i = t + PA_THREADS; i < n; i += PA_THREADS) cm_sh[i] = a.colmap[i];
+  if (gthread) {
+    double g = 0.0;
+#pragma unroll
+    for (int u = 0; u < GB; ++u)
+      if (u < total) g += gv[u];
+    for (int k = GB; k < total; k += GB) {
+#pragma unroll
+      for (int u = 0; u < GB; ++u) gv[u] = a.gramS[(size_t)(k + u < total ? k + u : total - 1) * OVP_GRAM_ELEMS + t];
+#pragma unroll
+      for (int u = 0; u < GB; ++u)
+        if (k + u < total) g += gv[u];
+    }
     gsum[t] = g;
   }
   {
-    const int e = t % 10, part = t / 10;
     double sacc = 0.0;
-    if (t < 250)
-      for (int f = part; f < a.nf; f += 25) sacc += a.cst[(size_t)f * 10 + e];
-    if (t < 256) red[t] = (t < 250) ? sacc : 0.0;
+    if (cthread) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (cpart + 25 * u < a.nf) sacc += cv[u];
+      for (int f = cpart + 100; f < a.nf; f += 25) sacc += a.cst[(size_t)f * 10 + ce];
+    }
+    if (t < 256) red[t] = cthread ? sacc : 0.0;
   }
   // SLAM landmarks lying on this (out-of-state) plane: one point-on-plane row each (UpdaterMSCKF.cpp:545-552)
   if (t == 255) {
