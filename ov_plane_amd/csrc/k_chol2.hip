@@ -30,15 +30,17 @@ static constexpr int C2_TW = C2_WAVES - C2_EW;
 
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 
-// d[j] += bcast_j(nl) * l   (lane j of the own 16-lane row supplies nl); `first` inserts the two wait states a DPP read of a
-// VGPR written by the previous VALU instruction needs (inline asm is invisible to the hazard recognizer)
+// d[j] += bcast_j(nl) * l   (lane j of the own 16-lane row supplies nl).  A DPP read of a VGPR needs two wait states behind the
+// VALU write of that register, and inline asm is invisible to the hazard recognizer: the plain form may only be used where the
+// wait states are guaranteed otherwise (they came with the write, or a data dependency orders this statement behind one that
+// carries them) - source order guarantees nothing, asm statements without `volatile` may be emitted in any order.
 #define C2_FMAC_DPP(acc, src_dpp, mul, J)                                                                      \
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src_dpp), "v"(mul))
 
 #define C2_FMAC_DPP_NOP(acc, src_dpp, mul, J)                                                                       \
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src_dpp), "v"(mul))
 
-// same, preceded by the two wait states (use it for the first consumer of a freshly computed DPP source)
+// same, preceded by the two wait states
 template <int J>
 __device__ __forceinline__ void fmac_bcast_nop(double& acc, const double& src_dpp, const double& mul) {
   if constexpr (J == 0) C2_FMAC_DPP_NOP(acc, src_dpp, mul, 0);
