@@ -3,7 +3,7 @@
 //   * the elimination as k_chol2 has it (a copy of the diagonal block in every DPP row, broadcast inside the FMA)
 //   * the same elimination with the diagonal block in lanes 0..15 only, three panel tiles in the other DPP rows and the column of L
 //     broadcast through SGPRs (v_readlane): one FMA per column serves the diagonal block AND the panel tiles
-// hipcc --offload-arch=gfx950 -O3 -w tools/dpp64_bench.hip -o /tmp/dpp64_bench
+// hipcc --offload-arch=gfx950 -O3 -w -std=c++20 tools/dpp64_bench.hip -o /tmp/dpp64_bench   (output of the final tree: profiles/r03_e_dpp64_bench.txt)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
