@@ -14,6 +14,7 @@
 // Q1 an orthonormal basis of range(H_f).  The kernel emits the sparse rows (rec) and G|g; K2 reduces them.
 #include "ovp_feat_model.h"
 #include "k_tile_body.h"
+#include "k_dpp.h"
 #include <utility>
 #include <cstdlib>
 
@@ -50,6 +51,43 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 }
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// The 16 columns of a block of the bordered factorization, all rows at once (k_chol2.hip: fused_elim16): d = row r = lane & 15 of
+// the diagonal tile, a copy in every 16-lane DPP row; p = this lane's row of the matrix (DPP row g = row tile g), the block's 16
+// entries.  Columns c < ncol are pivots: both are scaled by 1 / sqrt(pivot) (v_rsq_f64 + one Newton step folded into the scaling)
+// and the later columns updated with the column of L broadcast INSIDE the FMA (v_fmac_f64_dpp row_newbcast) - no LDS round trip and
+// no VALU -> SGPR -> VALU hop per column, which is what the column loop this replaces consisted of (a v_readlane pair for the
+// pivot, another for the next column's multiplier, the column exchanged through LDS).  Columns >= ncol (the corner of the border)
+// are only updated.  A row tile above the diagonal one holds zeros and keeps them.
+__device__ __forceinline__ void k1_elim16(double (&d)[16], double (&p)[16], const int ncol, bool& spd) {
+  double piv = bcast_row<0>(d[0]);
+  static_for<16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (c < ncol) {  // (wave-uniform)
+      spd = spd && (piv > 0.0);
+      const double y0 = __builtin_amdgcn_rsq(piv);
+      const double hy = (0.5 * piv) * y0;
+      const double ly = d[c] * y0, py = p[c] * y0;
+      const double e = fma(-hy, y0, 0.5);
+      const double l = fma(ly, e, ly);
+      const double q = fma(py, e, py);
+      double nl;  // -l, the DPP operand of the updates: its two wait states go with the write (k_dpp.h)
+      asm("v_fma_f64 %0, -%1, %2, -%1\n\ts_nop 1" : "=v"(nl) : "v"(ly), "v"(e));
+      d[c] = l;
+      p[c] = q;
+      if constexpr (c + 1 < 16) {
+        fmac_bcast<c + 1>(d[c + 1], nl, l);
+        piv = bcast_row<c + 1>(d[c + 1]);
+        fmac_bcast<c + 1>(p[c + 1], nl, q);
+        static_for<14 - c>([&](auto jc) {
+          constexpr int j = c + 2 + decltype(jc)::value;
+          fmac_bcast<j>(d[j], nl, l);
+          fmac_bcast<j>(p[j], nl, q);
+        });
+      }
+    }
+  });
+}
 
 // phase stamps (s_memtime) for the "cycles" debug read: compiled in only with -DOVP_K1_STAMPS (they cost 20 VGPRs)
 #ifdef OVP_K1_STAMPS
@@ -348,39 +386,37 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
             }
           }
         }
-        // factor the block's columns < n (right-looking inside the registers, column exchange through LDS); the border
-        // rows take part like any other row, the corner columns are never pivots
-        double piv = readlane_f64(ab[0], j0);
-        double inv = rsqrt_nr(piv);
-        static_for<16>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          const int kg = j0 + c;  // global column, wave-uniform
-          if (kg < n) {
-            spd = spd && (piv > 0.0);
-            double l = ab[c] * inv;
-            if (lane < kg) l = 0.0;  // rows above the diagonal do not belong to column kg
-            ab[c] = l;
-            double* cb = sB + (c & 1) * NR;
-            cb[lane] = l;
-            if constexpr (c + 1 < 16) {
-              const double l1 = readlane_f64(l, kg + 1);
-              ab[c + 1] = fma(-l, l1, ab[c + 1]);
-              piv = readlane_f64(ab[c + 1], kg + 1);
-              inv = rsqrt_nr(piv);
-            }
-            if constexpr (c + 2 < 16) {
-              constexpr int e0 = (c + 2) & ~1;
-              const double2_t* cbv = reinterpret_cast<const double2_t*>(cb + j0 + e0);
-              double2_t lv[(16 - e0) / 2];
+        // factor the block's columns < n: the border rows take part like any other row, the corner columns are never pivots.
+        // The diagonal tile's rows go to every DPP row through the transpose scratch, then one fused elimination (k1_elim16).
+        const int ncol = n - j0 < 16 ? (n - j0 > 0 ? n - j0 : 0) : 16;  // (wave-uniform)
+        if (ncol > 0) {
+          __builtin_amdgcn_wave_barrier();
+          if ((lane >> 4) == jb) {
+            double2_t* dst = reinterpret_cast<double2_t*>(sT + lc * 18);
 #pragma unroll
-              for (int q = 0; q < (16 - e0) / 2; ++q) lv[q] = cbv[q];
-              static_for<14 - c>([&](auto jc) {
-                constexpr int j = c + 2 + decltype(jc)::value;
-                ab[j] = fma(-l, lv[(j - e0) >> 1][(j - e0) & 1], ab[j]);
-              });
+            for (int q = 0; q < 8; ++q) dst[q] = double2_t{ab[2 * q], ab[2 * q + 1]};
+          }
+          OVP_WSYNC();
+          double dd[16];
+          {
+            const double2_t* src = reinterpret_cast<const double2_t*>(sT + lc * 18);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const double2_t v = src[q];
+              dd[2 * q] = v[0];
+              dd[2 * q + 1] = v[1];
             }
           }
-        });
+          k1_elim16(dd, ab, ncol, spd);
+          // rows above the diagonal do not belong to a column: the diagonal tile's own rows end with garbage there
+          if ((lane >> 4) == jb) {
+            static_for<16>([&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              if (t > lc && t < ncol) ab[t] = 0.0;
+            });
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
         // publish the block (factor columns, and for the last block the corner)
         static_for<16>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
