@@ -315,7 +315,7 @@ long ovp_debug_read(ovp_ctx *ctx, const char *name, void *host, long max_bytes);
 int ovp_plane_kernel_timer(ovp_ctx *ctx, int enable, int reset, float *avg_ms, int *n_launches);
 /* tile Cholesky (the factorization every EKF update and every plane of the plane loop runs) on a host matrix: dense factor of the
  * matrix bordered with brow ((n+1) x (n+1), row-major; brow may be NULL), z = L^-1 brow, y = L^-T z, pivots; avg_ms = average
- * duration over `reps` launches.  n <= 271. */
+ * duration over `reps` launches.  n <= ovp_chol2_max_n() (287). */
 int ovp_debug_chol2(ovp_ctx *ctx, const double *A_host, int n, int lda, const double *brow_host, int add_identity, double *L_host,
                     double *z_host, double *y_host, double *piv_host, int reps, float *avg_ms);
 /* pivot floor of the following ovp_debug_chol2 calls (0 = none): a pivot below it drops its column, as the range part of the

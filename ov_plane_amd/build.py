@@ -33,7 +33,8 @@ def build_lib(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     t_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     stamp = os.path.join(OBJ_DIR, "flags.txt")
-    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    flag_key = " ".join(flags).replace(_HERE, ".")  # checkout-independent
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flag_key
 
     def one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
@@ -48,8 +49,8 @@ def build_lib(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(one, SOURCES))
     with open(stamp, "w") as f:
-        f.write(" ".join(flags))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", OUT]
+        f.write(flag_key)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + os.environ.get("OVP_EXTRA_HIPCC_FLAGS", "").split() + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OVP_LIB_AB") or os.path.join(_HERE, "libovplane_hip.so")  # OVP_LIB_AB: another build of the same library (A/B timing runs)
 OVP_MAX_MEAS = 32
-OVP_E_ARG, OVP_E_CAPACITY, OVP_E_NOTSPD, OVP_E_NEGDIAG, OVP_E_NODEVICE, OVP_E_STATE = -1, -2, -3, -4, -5, -6
+OVP_E_ARG, OVP_E_CAPACITY, OVP_E_NOTSPD, OVP_E_NEGDIAG, OVP_E_NODEVICE, OVP_E_STATE, OVP_E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
 
 
 class OvpError(RuntimeError):

@@ -277,6 +277,7 @@ extern "C" const char* ovp_error_string(int code) {
     case OVP_E_NEGDIAG: return "negative covariance diagonal";
     case OVP_E_NODEVICE: return "no usable HIP device";
     case OVP_E_STATE: return "call order violated";
+    case OVP_E_TIMEOUT: return "device-side hand-over timed out (workgroups of the plane solve not co-resident)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown";
   }
 }
