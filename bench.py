@@ -143,25 +143,90 @@ class StepRunner:
         self.ctx.close()
 
 
-PREWARM_STEPS = 100  # untimed: a fresh box runs its first ~100 steps at ramping clocks (3.5 against 3.15 ms per config-3 step).
-# A step COUNT, not a duration: in the multi-GPU run every step holds a collective, all ranks must take the same number.
+PREWARM_MIN_STEPS = 100   # untimed: a fresh box runs its first steps at ramping clocks (3.5 against 3.15 ms per config-3 step)
+PREWARM_BLOCK = 25
+PREWARM_MAX_S = 6.0       # the untimed settling phase ends when two consecutive blocks agree to 2 % (or after this many seconds)
 
 
-def time_steps(torch, fn, steps, warmup, barrier=None, prewarm=0):
-    for _ in range(prewarm):
-        fn()
+class GcWatch:
+    """Pauses of the Python garbage collector (gc.callbacks): with torch imported the heap holds ~1e6 objects and a generation-2
+    collection is a pause of tens of milliseconds in the middle of whichever step triggers it."""
+
+    def __init__(self):
+        self.events, self._t0 = [], None
+
+    def __call__(self, phase, info):
+        if phase == "start":
+            self._t0 = time.perf_counter()
+        elif self._t0 is not None:
+            self.events.append((int(info.get("generation", -1)), 1e3 * (time.perf_counter() - self._t0)))
+
+    def take(self):
+        ev, self.events = self.events, []
+        return {"collections": len(ev), "total_ms": round(sum(e[1] for e in ev), 3),
+                "longest": [list(map(lambda x: round(x, 3), e)) for e in sorted(ev, key=lambda e: -e[1])[:3]]}
+
+
+def run_block(fn, steps):
+    """`steps` calls of fn; every step ends in a host-visible completion (results read from the pinned block), so the wall time
+    of each one is free.  Returns (per-step seconds, last output)."""
+    ts, out = [], None
+    t_prev = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+        t = time.perf_counter()
+        ts.append(t - t_prev)
+        t_prev = t
+    return ts, out
+
+
+def settle(torch, fn, dist=None):
+    """Untimed steps until the step time has settled: blocks of PREWARM_BLOCK steps until the medians of two consecutive blocks
+    agree to 2 %, at least PREWARM_MIN_STEPS, at most PREWARM_MAX_S seconds.  With several ranks the decision to go on is taken
+    collectively (every step holds a collective: all ranks must take the same number)."""
+    n_done, prev, t0, blocks = 0, None, time.perf_counter(), []
+    while True:
+        ts, _ = run_block(fn, PREWARM_BLOCK)
+        n_done += PREWARM_BLOCK
+        med = sorted(ts)[len(ts) // 2]
+        blocks.append(1e3 * med)
+        settled = prev is not None and abs(med - prev) <= 0.02 * prev and n_done >= PREWARM_MIN_STEPS
+        go_on = (not settled) and (time.perf_counter() - t0 < PREWARM_MAX_S)
+        if dist is not None:
+            flag = torch.tensor([1 if go_on else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            go_on = bool(flag.item())
+        if not go_on:
+            return n_done, blocks
+        prev = med
+
+
+def time_steps(torch, fn, steps, warmup, barrier=None):
+    """`warmup` untimed steps, then EXACTLY `steps` timed ones between barrier + synchronize on both sides.
+    Returns (elapsed seconds, last output, per-step seconds)."""
+    out = None
     for _ in range(warmup):
         out = fn()
     torch.cuda.synchronize()
     if barrier:
         barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = fn()
+    ts, out2 = run_block(fn, steps)
     torch.cuda.synchronize()
     if barrier:
         barrier()
-    return time.perf_counter() - t0, out
+    return time.perf_counter() - t0, (out2 if steps else out), ts
+
+
+def step_stats(ts):
+    """Distribution of the per-step wall times of a timed window (ms) and the steps that stand out."""
+    a = sorted(ts)
+    n = len(a)
+    med = a[n // 2]
+    slow = [[i, round(1e3 * t, 3)] for i, t in enumerate(ts) if t > 1.5 * med]
+    return {"median_ms": 1e3 * med, "p90_ms": 1e3 * a[min(n - 1, int(0.9 * n))], "min_ms": 1e3 * a[0], "max_ms": 1e3 * a[-1],
+            "mean_ms": 1e3 * sum(ts) / n, "steps_over_1p5x_median": slow,
+            "excess_over_median_ms": 1e3 * sum(t - med for t in ts if t > 1.5 * med)}
 
 
 def cpu_model():
@@ -310,6 +375,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (point_config, config4_1gpu, propagation)")
     ap.add_argument("--cpu-sample-feats", type=int, default=0, help="0 = the oracle runs every feature of the frame")
+    ap.add_argument("--python-gc", choices=["off", "on"], default="off",
+                    help="off (default): the Python collector is disabled inside the timed windows (the harness is Python, the path "
+                         "under test is a C library: a generation-2 collection of the torch-sized heap is a ~40 ms pause that lands "
+                         "in one step); on: left running, its pauses are reported")
     ap.add_argument("--sharded-path", action="store_true",
                     help="with --gpus 1: take the multi-GPU code path (process group of one rank, dist.sharded_* functions, RCCL "
                          "all-reduce, stage timing) - a smoke test of it on a one-GPU box")
@@ -355,14 +424,50 @@ def main():
             fn = lambda: run.step_sharded(rank, world)  # noqa: E731
         else:
             fn = run.step
-        elapsed, (pl, pt) = time_steps(torch, fn, args.steps, args.warmup, barrier, prewarm=PREWARM_STEPS)
+        import gc
+
+        gcw = GcWatch()
+        gc.callbacks.append(gcw)
+        n_prewarm, prewarm_blocks = settle(torch, fn, dist if sharded else None)
+        gc_prewarm = gcw.take()
+        if args.python_gc == "off":
+            gc.collect()
+            gc.disable()
+            gcw.take()  # (the collection just asked for)
+        run.ctx.host_timing(reset=True)
+        elapsed, (pl, pt), per_step = time_steps(torch, fn, args.steps, args.warmup, barrier)
+        host_acc = run.ctx.host_timing(reset=True)
+        gc_w1 = gcw.take()
+        # a second window of the same length right behind the first (reported beside it, never `value`)
+        elapsed2, _, per_step2 = time_steps(torch, fn, args.steps, 0, barrier)
+        gc_w2 = gcw.take()
+        gc.enable()
+        gc.callbacks.remove(gcw)
         # dominant-kernel launch times with HIP events, in a pass of their own (events between dependent launches cost
         # microseconds each, they must not sit in the timed region above)
         run.ctx.kernel_timer(enable=True, reset=True)
-        run.ctx.plane_kernel_timer(enable=True, reset=True)
+        run.ctx.plane_kernel_timer(enable=1, reset=True)
         time_steps(torch, fn, max(5, min(args.steps, 20)), 0, barrier)
         k1_ms, k1_n = run.ctx.kernel_timer(enable=False, reset=False)
-        c2_ms, c2_n = run.ctx.plane_kernel_timer(enable=False, reset=False)
+        c2_ms, c2_n = run.ctx.plane_kernel_timer(enable=0, reset=False)
+        # device clock of the two halves of a step (a pass of its own: one event pair around the plane loop, K1 start .. last
+        # kernel of the point update) - what the step would take with a host that is never late
+        dev_ms = None
+        if not sharded:
+            n_ev = max(5, min(args.steps, 20))
+            run.ctx.kernel_timer(enable=True, reset=True)
+            run.ctx.plane_kernel_timer(enable=2, reset=True)
+            run.ctx.host_timing(reset=True)
+            pt_ms = []
+            for _ in range(n_ev):
+                fn()
+                pt_ms.append(float(run.ctx.timings_ms()[3]))
+            acc = run.ctx.host_timing(reset=True)
+            run.ctx.kernel_timer(enable=False, reset=False)
+            run.ctx.plane_kernel_timer(enable=0, reset=False)
+            dev_ms = {"plane_loop_ms": acc["plane_loop_device_ms"] / n_ev if run.has_planes else 0.0,
+                      "point_update_ms": sorted(pt_ms)[len(pt_ms) // 2], "steps": n_ev}
+            dev_ms["sum_ms"] = dev_ms["plane_loop_ms"] + dev_ms["point_update_ms"]
         stages = None
         if sharded:
             # where a multi-GPU step spends its time (a pass of its own: the stages are separated by host synchronisations)
@@ -389,7 +494,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm_steps": PREWARM_STEPS,
+            "prewarm_steps": n_prewarm,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
@@ -405,6 +510,30 @@ def main():
                        "timed_region": "H2D feature batch + plane loop + point update + D2H results; covariance and pose tables "
                                        "resident (restored on the device at the start of every step)"},
         }
+        # ---- where the wall time of the timed window went ----
+        st1 = step_stats(per_step)
+        line["step_times"] = dict(st1, note="wall time of each of the timed steps (every step ends in a host-visible completion); "
+                                            "ms_per_step above is total / steps and includes the closing synchronize + barrier")
+        line["second_window"] = dict(step_stats(per_step2), ms_per_step=1e3 * elapsed2 / args.steps,
+                                     note="the same number of steps timed again right behind the first window")
+        line["prewarm"] = {"steps": n_prewarm, "block_medians_ms": [round(b, 4) for b in prewarm_blocks],
+                           "rule": "blocks of %d untimed steps until two consecutive block medians agree to 2 %% (>= %d steps, <= %.0f s)"
+                                   % (PREWARM_BLOCK, PREWARM_MIN_STEPS, PREWARM_MAX_S)}
+        line["python_gc"] = {"inside_timed_windows": args.python_gc, "prewarm": gc_prewarm, "window_1_incl_warmup": gc_w1, "window_2": gc_w2,
+                             "note": "pauses of the harness's garbage collector (gc.callbacks); `off` = gc.collect() + gc.disable() in "
+                                     "front of the warm-up steps, re-enabled behind the second window"}
+        k = max(args.steps, 1)
+        line["host"] = {
+            "plane_pre_launch_ms": host_acc["plane_pre_ms"] / k, "plane_enqueue_ms": host_acc["plane_enqueue_ms"] / k,
+            "plane_wait_ms": host_acc["plane_wait_ms"] / k, "point_enqueue_ms": host_acc["point_enqueue_ms"] / k,
+            "point_wait_ms": host_acc["point_wait_ms"] / k,
+            "note": "host clock inside the two update entry points per timed step: plane loop entry -> first launch (grouping, staging "
+                    "tables), entry -> last launch enqueued, wait for the device; point update enqueue, wait for the published results"}
+        if dev_ms is not None:
+            line["device_clock"] = dict(dev_ms, step_median_minus_device_ms=st1["median_ms"] - dev_ms["sum_ms"],
+                                        note="HIP events in a pass of their own: plane loop (first launch .. covariance product) and "
+                                             "point update (feature kernel .. last kernel); the rest of a step is the H2D of the frame, "
+                                             "the restore of the prior and the host turn-around")
         # ---- roofline of the dominant kernel ----
         if run.has_planes and c2_n:
             n_inv_avg = 6 * C + 14 + 1.5  # involved columns of a plane: clones + calibration (+3 when the plane is in the state)
@@ -493,7 +622,7 @@ def extras(line, capi, torch, args, device, headline):
                 # figure would otherwise be its whole value
                 els = []
                 for blk in range(5):
-                    el_b, (pl, pt) = time_steps(torch, r.step, 10, 3 if blk == 0 else 0)
+                    el_b, (pl, pt), _ = time_steps(torch, r.step, 10, 3 if blk == 0 else 0)
                     els.append(el_b / 10)
                 el = 20 * sorted(els)[2]
             line[key] = {"workload": describe(wname, sc), "ms_per_step": 1e3 * el / 20, "features_per_s": sc.F * 20 / el,

@@ -313,6 +313,11 @@ long ovp_debug_read(ovp_ctx *ctx, const char *name, void *host, long max_bytes);
 /* like ovp_kernel_timer, for the dominant kernel of the plane loop (k_chol2: both factorizations, gate, solve and commit of one
  * plane): HIP events around every launch of ovp_msckf_plane_update while enabled */
 int ovp_plane_kernel_timer(ovp_ctx *ctx, int enable, int reset, float *avg_ms, int *n_launches);
+/* host clock of the two update entry points, accumulated since the last reset (ms): ovp_msckf_plane_update [0] entry -> first
+ * launch (grouping of the features by plane, staging tables), [1] entry -> last launch enqueued, [2] wait for the device, [3] calls;
+ * ovp_msckf_update [4] enqueue, [5] wait for the published results, [6] calls; [7] the plane loop on the DEVICE clock (HIP events around the whole loop,
+ * accumulated only while ovp_plane_kernel_timer is enabled).  bench.py reports them per step. */
+int ovp_host_timing(ovp_ctx *ctx, int reset, double *out8);
 /* tile Cholesky (the factorization every EKF update and every plane of the plane loop runs) on a host matrix: dense factor of the
  * matrix bordered with brow ((n+1) x (n+1), row-major; brow may be NULL), z = L^-1 brow, y = L^-T z, pivots; avg_ms = average
  * duration over `reps` launches.  n <= ovp_chol2_max_n() (287). */

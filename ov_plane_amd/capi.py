@@ -117,7 +117,7 @@ EXPORTS = [
     "ovp_ekf_update_from_gram_async", "ovp_msckf_fetch_results", "ovp_ekf_update", "ovp_cov_propagate",
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
-    "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
+    "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
 ]
 
 
@@ -171,6 +171,7 @@ def lib():
         L.ovp_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.ovp_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.ovp_plane_kernel_timer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.ovp_host_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ovp_triang_defaults.argtypes = [C.POINTER(TriangOpts)]
         L.ovp_triang_defaults.restype = None
         L.ovp_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangOpts), C.c_void_p, C.c_void_p, C.c_void_p]
@@ -564,6 +565,14 @@ class Context:
         ms, nl = C.c_float(0), C.c_int(0)
         lib().ovp_plane_kernel_timer(self._h, int(enable), int(reset), C.byref(ms), C.byref(nl))
         return ms.value, nl.value
+
+    def host_timing(self, reset=False):
+        """Accumulated host clock of the update entry points (ms): plane loop entry -> first launch, entry -> last launch
+        enqueued, wait for the device, calls; point update enqueue, wait, calls."""
+        t = np.zeros(8)
+        lib().ovp_host_timing(self._h, int(reset), t.ctypes.data)
+        return dict(plane_pre_ms=t[0], plane_enqueue_ms=t[1], plane_wait_ms=t[2], plane_calls=int(t[3]),
+                    point_enqueue_ms=t[4], point_wait_ms=t[5], point_calls=int(t[6]), plane_loop_device_ms=t[7])
 
     def debug_read(self, name, shape, dtype=np.float64):
         out = np.zeros(shape, dtype=dtype)

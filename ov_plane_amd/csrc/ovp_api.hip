@@ -230,8 +230,8 @@ struct ovp_ctx {
   size_t state_bytes = 0, batch_cap = 0;
   size_t so_R = 0, so_Rf = 0, so_p = 0, so_pf = 0, so_cal = 0, so_id = 0, so_cm = 0;
   hipEvent_t ev_state = nullptr, ev_batch = nullptr;
-  bool pl_ktimer = false;
-  std::vector<hipEvent_t> pl_ev;
+  int pl_ktimer = 0;  // 1 = events around every k_chol2 launch and around the loop, 2 = around the loop only
+  std::vector<hipEvent_t> pl_ev, pl_ev_loop;
   double pl_ktime_ms = 0.0;
   int pl_klaunches = 0;
   int* idbuf = nullptr;      // scratch ints (ids)
@@ -264,7 +264,14 @@ struct ovp_ctx {
   double ktime_ms = 0.0;
   int klaunches = 0;
   bool kpending = false;
+  // host-side clock of the two update entry points, accumulated (ovp_host_timing): plane loop [entry -> first launch | entry -> last
+  // launch enqueued | wait for the device | calls], point update [enqueue | wait | calls]
+  double host_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+static inline double host_now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 extern "C" const char* ovp_version(void) { return "ovplane_hip 0.2 (gfx950)"; }
 
@@ -1202,11 +1209,24 @@ extern "C" int ovp_msckf_fetch_results(ovp_ctx* c, double* dx_host, uint8_t* acc
 
 extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx_host, uint8_t* accepted_host,
                                 double* chi2_host, ovp_update_info* info) {
+  const double t0 = host_now_ms();
   int rc = ovp_msckf_build_gate_gram_async(c, o);
   if (rc) return rc;
   rc = ovp_ekf_update_from_gram_async(c);
   if (rc) return rc;
-  return ovp_msckf_fetch_results(c, dx_host, accepted_host, chi2_host, info);
+  const double t1 = host_now_ms();
+  rc = ovp_msckf_fetch_results(c, dx_host, accepted_host, chi2_host, info);
+  c->host_acc[4] += t1 - t0;
+  c->host_acc[5] += host_now_ms() - t1;
+  c->host_acc[6] += 1.0;
+  return rc;
+}
+
+extern "C" int ovp_host_timing(ovp_ctx* c, int reset, double* out8) {
+  if (!c) return OVP_E_ARG;
+  if (out8) memcpy(out8, c->host_acc, sizeof(c->host_acc));
+  if (reset) memset(c->host_acc, 0, sizeof(c->host_acc));
+  return 0;
 }
 
 // device sequence shared by the plane update and the plane initialisation: feature kernel, Gram reduction, reduction to the
@@ -1633,6 +1653,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
+  const double t_entry = host_now_ms();
   const int n = c->n, ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
   // skip_plane_used is an option of the POINT update that follows; the plane loop itself produces the mask
   ovp_update_opts o_local = *o;
@@ -1809,6 +1830,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     memcpy(hd + 6 * NP + 3 * n_slam, pb->slam_p_fej, sizeof(double) * 3 * n_slam);
   }
   hipStream_t s = c->stream;
+  const double t_first = host_now_ms();
   HIPCHK(hipMemcpyAsync(c->pl_dstage, c->pl_hstage, stage_bytes, hipMemcpyHostToDevice, s));
   const int* d_feat = di + o_feat;
   const int* d_sid = di + o_sid;
@@ -1827,6 +1849,14 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     const size_t zb[6] = {sizeof(double) * 4 * NP, sizeof(double) * (size_t)n * NP, ((size_t)F + 3) & ~(size_t)3, sizeof(int) * 4,
                           NJ > 0 ? 3 * sizeof(int) : 0, NJ > 0 ? sizeof(double) * (size_t)n * ld : 0};
     HIPCHK(ovp_launch_zero_regions(zp, zb, 6, s));
+  }
+  if (c->pl_ktimer) {  // [0 | 1] = the whole loop on the device clock (first launch .. covariance product), then a pair per plane
+    while (c->pl_ev_loop.size() < 2) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->pl_ev_loop.push_back(e);
+    }
+    HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));
   }
   if (NJ > 0) {
     rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
@@ -1982,7 +2012,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.n_slam = n_slam;
     ps.slam_id = d_sidx;
     ps.slam_p = d_slam_p;
-    if (c->pl_ktimer) {
+    if (c->pl_ktimer == 1) {
       while ((int)c->pl_ev.size() < 2 * (jn + 1)) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
@@ -1997,7 +2027,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       j0.stamps = d_stamps;
     }
     HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
-    if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev[2 * jn + 1], s));
+    if (c->pl_ktimer == 1) HIPCHK(hipEventRecord(c->pl_ev[2 * jn + 1], s));
     if (c->pl_sub_active)
       HIPCHK(ovp_launch_plane_sub_accum(c->pl_res + 4 * j.pl, c->Ab, c->pl_Asum, c->pl_dx + (size_t)j.pl * n,
                                         c->pl_U + (size_t)j.pl * ld, n, ld, s));
@@ -2037,6 +2067,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
   }
+  if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev_loop[1], s));
   // ---- results: one pinned block, one synchronisation ----
   double* hres = (double*)c->pl_hres;
   double* hdx = hres + 4 * (size_t)NP;
@@ -2045,8 +2076,19 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (dx_planes) HIPCHK(hipMemcpyAsync(hdx, c->pl_dx, sizeof(double) * (size_t)n * NP, hipMemcpyDeviceToHost, s));
   if (F) HIPCHK(hipMemcpyAsync(hused, c->pl_used, (size_t)F, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  const double t_enq = host_now_ms();
   HIPCHK(hipStreamSynchronize(s));
-  if (c->pl_ktimer)
+  if (!c->pl_sub_active) {
+    c->host_acc[0] += t_first - t_entry;
+    c->host_acc[1] += t_enq - t_entry;
+    c->host_acc[2] += host_now_ms() - t_enq;
+    c->host_acc[3] += 1.0;
+  }
+  if (c->pl_ktimer && !c->pl_sub_active) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->pl_ev_loop[0], c->pl_ev_loop[1]) == hipSuccess) c->host_acc[7] += ms;
+  }
+  if (c->pl_ktimer == 1)
     for (int jn = 0; jn < NJ; ++jn) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, c->pl_ev[2 * jn], c->pl_ev[2 * jn + 1]) == hipSuccess) {
@@ -2610,7 +2652,7 @@ extern "C" int ovp_plane_kernel_timer(ovp_ctx* c, int enable, int reset, float* 
     c->pl_ktime_ms = 0.0;
     c->pl_klaunches = 0;
   }
-  c->pl_ktimer = enable != 0;
+  c->pl_ktimer = enable;
   return 0;
 }
 
