@@ -54,6 +54,9 @@ struct PlaneSolve {
   // solution and commit
   const double* L0;         // factor of the covariance at the start of the loop, dense lower triangular
   int ld0;
+  int n_full;               // rows of L0 / of the correction (0 = the factorized dimension): the factorization may run on the LEADING
+                            // n < n_full columns when everything behind them has never been involved (T = blockdiag(T_lead, I));
+                            // dx = L0[:, 0:n] y, the tile-packed factor is laid out for n_full with the identity behind n
   double* dx_out;           // [n] correction of this plane (for the host)
   double* dx_last;          // [n] scratch copy on the device
   int* cur;                 // index of the current accumulated-T buffer, toggled on accept

@@ -963,8 +963,9 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
 // ------------------------------------------------------------------------------------------------------------------------
 // tile-packed copy of a factor tile for k_fwdsub: tile index over the n x n part (nt_n tile rows), column-major inside the tile;
 // rows / columns at or behind the border row are replaced by the identity
-__device__ __forceinline__ void c2_pack_tile(double* __restrict__ Lpack, const double4_t& t, int i, int j, int n, int lr, int lc) {
-  const int ntn = (n + 15) >> 4;
+__device__ __forceinline__ void c2_pack_tile(double* __restrict__ Lpack, const double4_t& t, int i, int j, int n, int lr, int lc,
+                                             int n_layout = 0) {
+  const int ntn = ((n_layout > 0 ? n_layout : n) + 15) >> 4;  // the packed layout may belong to a larger matrix (leading-block factor)
   const int tidx = j * ntn - (j * (j - 1)) / 2 + (i - j);
   double* pk = Lpack + (size_t)tidx * 256;
 #pragma unroll
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
       if constexpr (ROLE == 1) {
         sfor<MAXSLOT>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
+          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc, ps.n_full);
         });
       } else {
         for (int e = 256 * h_bs + tid; e < ntn * 256; e += C2_EW * 64) {
@@ -1224,7 +1225,9 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   }
   // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
-  double* dxs = S.zbuf;  // z is no longer needed
+  const int nfull = ps.n_full > n ? ps.n_full : n;  // rows of L0 (the factorization may have run on the leading n columns only)
+  double* dxs = nfull > n ? S.PB : S.zbuf;  // z is no longer needed; the panel buffers (free behind the back substitution) when
+                                            // the correction is longer than the factorized dimension
   __syncthreads();
   if (S.cnt[6]) {  // a hand-over of the back substitution timed out: nothing is committed, the call fails
     if (tid == 0) {
@@ -1235,10 +1238,11 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   }
   {
     const int half = tid & 1;
-    for (int row = tid >> 1; row < ((n + C2_WAVES * 32 - 1) / (C2_WAVES * 32)) * (C2_WAVES * 32); row += C2_WAVES * 32) {
+    for (int row = tid >> 1; row < ((nfull + C2_WAVES * 32 - 1) / (C2_WAVES * 32)) * (C2_WAVES * 32); row += C2_WAVES * 32) {
     double s = 0.0;
-    if (row < n) {
-      const int npair = (row + 2) >> 1;            // 16-byte pairs covering columns 0..row (ld is even, rows are 16-byte aligned)
+    if (row < nfull) {
+      const int lastc = row < n ? row : n - 1;     // last column of the row's non-zeros that meets y
+      const int npair = (lastc + 2) >> 1;          // 16-byte pairs covering columns 0..lastc (ld is even, rows are 16-byte aligned)
       const int p0 = half ? (npair >> 1) : 0, p1 = half ? npair : (npair >> 1);
       const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(ps.L0 + (size_t)row * ps.ld0);
       double s1 = 0.0;
@@ -1247,18 +1251,18 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
         const dbl2_t v = lrow[q];
         const int c0 = 2 * q;
         s = fma(v[0], S.ybuf[c0], s);
-        s1 = fma(c0 + 1 <= row ? v[1] : 0.0, S.ybuf[c0 + 1], s1);
+        s1 = fma(c0 + 1 <= lastc ? v[1] : 0.0, c0 + 1 <= lastc ? S.ybuf[c0 + 1] : 0.0, s1);
       }
       s += s1;
     }
     s += swap_pair_f64(s);
-    if (row < n && half == 0) dxs[row] = s;
+    if (row < nfull && half == 0) dxs[row] = s;
     }
   }
   __syncthreads();
   M1_STAMP(3);
   // ---- commit (ext Type::update on the device tables, update/UpdaterMSCKF.cpp:646-648) ----
-  for (int i = tid; i < n; i += C2_WAVES * 64) {
+  for (int i = tid; i < nfull; i += C2_WAVES * 64) {
     ps.dx_out[i] = dxs[i];
     ps.dx_last[i] = dxs[i];
   }
@@ -1313,7 +1317,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
       if constexpr (ROLE == 1) {
         sfor<MAXSLOT>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
+          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc, ps.n_full);
         });
       } else {
         // inverses of the diagonal blocks (the back substitution left them in S.Dsave), identity at / behind the border row

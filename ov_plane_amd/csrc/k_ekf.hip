@@ -185,6 +185,13 @@ __global__ void k_gather_block(const double* __restrict__ P, int ldp, const int*
   const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (k < m) out[(size_t)i * ldo + k] = P[(size_t)ids[i] * ldp + ids[k]];
 }
+// ... unless *cancel != 0 (a failed factorization upstream: the destination keeps what it holds, cf. ovp_launch_gemm4c)
+__global__ void k_gather_block_unless(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int m,
+                                      double* __restrict__ out, int ldo, const int* __restrict__ cancel) {
+  if (*cancel != 0) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k < m) out[(size_t)i * ldo + k] = P[(size_t)ids[i] * ldp + ids[k]];
+}
 __global__ void k_gather_cols(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int n, int m,
                               double* __restrict__ G, int ldg) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
@@ -396,6 +403,11 @@ hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols,
 
 hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_gather_block, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
+                                          hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_gather_block_unless, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo, cancel);
   return hipGetLastError();
 }
 hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream) {

@@ -48,8 +48,10 @@ hipError_t ovp_launch_plane_dT(int n, const double* L0, int ld, const double* W,
                                const int* cur, double* crow, hipStream_t stream);
 hipError_t ovp_launch_plane_sub_accum(const double* res, const double* Ab, double* Asum, const double* dx, double* u, int ns, int ld,
                                       hipStream_t stream);
-// clears up to six device regions (sizes in bytes, multiples of 4) in ONE launch
+// clears up to eight device regions (sizes in bytes, multiples of 4) in ONE launch; fill_regions: pattern[i] 0 = zeros, 1 = 16 x 16
+// identity blocks, 2 = tile-packed lower triangle (ntn tile rows) with identity diagonal tiles (doubles)
 hipError_t ovp_launch_zero_regions(void* const* ptr, const size_t* bytes, int count, hipStream_t stream);
+hipError_t ovp_launch_fill_regions(void* const* ptr, const size_t* bytes, const int* pattern, int count, int ntn, hipStream_t stream);
 hipError_t ovp_launch_select_copy(double* dst, const double* buf, size_t stride, const int* cur, int n, int ld, int sym,
                                   hipStream_t stream);
 }

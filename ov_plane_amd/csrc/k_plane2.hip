@@ -377,17 +377,36 @@ __global__ __launch_bounds__(256) void k_plane_dT(int n, const double* __restric
   if (gr < n && gc < n) Tt[(size_t)gr * ld + gc] = Tc[(size_t)gr * ld + gc] + sum;
 }
 
-// One launch instead of six fills at the start of a plane loop (each is a kernel of its own on this stack, ~4 us of boundary):
-// up to six regions, sizes in bytes (multiples of 4); region r is cleared by the blocks b = r, r + 6, r + 12, ...
+// One launch instead of a fill per buffer at the start of a plane loop (each is a kernel of its own on this stack, ~4 us of
+// boundary): up to eight regions, sizes in bytes (multiples of 4); region r is cleared by the blocks b = r, r + 8, r + 16, ...
+// Two regions may ask for an identity pattern instead of zeros (doubles): 1 = [k][16][16] blocks with a unit diagonal (the inverted
+// diagonal blocks k_fwdsub reads), 2 = the tile-packed lower triangle of an n x n matrix with identity diagonal tiles (its packed
+// factor) - what a plane of the loop that factorized only a leading block leaves untouched behind that block.
 struct ZeroJob {
-  void* ptr[6];
-  unsigned long long bytes[6];
+  void* ptr[8];
+  unsigned long long bytes[8];
+  int pattern[8];
+  int ntn;  // tile rows of the packed factor (pattern 2)
 };
 __global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob z) {
-  const int r = blockIdx.x % 6, b = blockIdx.x / 6, nb = (gridDim.x + 5 - r) / 6;
-  unsigned int* p = reinterpret_cast<unsigned int*>(z.ptr[r]);
+  const int r = blockIdx.x % 8, b = blockIdx.x / 8, nb = (gridDim.x + 7 - r) / 8;
   const unsigned long long words = z.bytes[r] >> 2;
-  for (unsigned long long i = (unsigned long long)b * 256 + threadIdx.x; i < words; i += (unsigned long long)nb * 256) p[i] = 0u;
+  if (z.pattern[r] == 0) {
+    unsigned int* p = reinterpret_cast<unsigned int*>(z.ptr[r]);
+    for (unsigned long long i = (unsigned long long)b * 256 + threadIdx.x; i < words; i += (unsigned long long)nb * 256) p[i] = 0u;
+    return;
+  }
+  double* p = reinterpret_cast<double*>(z.ptr[r]);
+  const unsigned long long dbl = words >> 1;
+  for (unsigned long long i = (unsigned long long)b * 256 + threadIdx.x; i < dbl; i += (unsigned long long)nb * 256) {
+    const int e = (int)(i & 255), tile = (int)(i >> 8);
+    bool diag_tile = true;
+    if (z.pattern[r] == 2) {  // tile (i, j) of the packed triangle sits at j * ntn - j (j - 1) / 2 + (i - j)
+      diag_tile = false;
+      for (int j = 0; j < z.ntn; ++j) diag_tile |= (tile == j * z.ntn - (j * (j - 1)) / 2);
+    }
+    p[i] = (diag_tile && (e >> 4) == (e & 15)) ? 1.0 : 0.0;
+  }
 }
 
 // dst <- the half of buf selected by *cur (lower triangle mirrored to a full symmetric matrix when `sym`)
@@ -451,17 +470,23 @@ hipError_t ovp_launch_plane_dT(int n, const double* L0, int ld, const double* W,
   return hipGetLastError();
 }
 hipError_t ovp_launch_zero_regions(void* const* ptr, const size_t* bytes, int count, hipStream_t stream) {
+  return ovp_launch_fill_regions(ptr, bytes, nullptr, count, 0, stream);
+}
+hipError_t ovp_launch_fill_regions(void* const* ptr, const size_t* bytes, const int* pattern, int count, int ntn, hipStream_t stream) {
   ovp::ZeroJob z;
   size_t most = 0;
-  for (int i = 0; i < 6; ++i) {
+  if (count > 8) return hipErrorInvalidValue;
+  for (int i = 0; i < 8; ++i) {
     z.ptr[i] = i < count ? ptr[i] : nullptr;
     z.bytes[i] = i < count ? (unsigned long long)bytes[i] : 0ull;
+    z.pattern[i] = (i < count && pattern) ? pattern[i] : 0;
     if (i < count && bytes[i] > most) most = bytes[i];
   }
+  z.ntn = ntn;
   int per = (int)((most / 4 + 4 * 256 - 1) / (4 * 256));  // a thread of the largest region clears ~4 words
   if (per < 1) per = 1;
   if (per > 512) per = 512;
-  hipLaunchKernelGGL(ovp::k_zero_regions, dim3(6 * per), dim3(256), 0, stream, z);
+  hipLaunchKernelGGL(ovp::k_zero_regions, dim3(8 * per), dim3(256), 0, stream, z);
   return hipGetLastError();
 }
 hipError_t ovp_launch_select_copy(double* dst, const double* buf, size_t stride, const int* cur, int n, int ld, int sym,

@@ -22,6 +22,8 @@ hipError_t ovp_launch_scatter_gram(const double* Acc, const double* bcc, int col
                                    int lda, int n, hipStream_t stream);
 hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out, hipStream_t stream);
 hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream);
+hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
+                                          hipStream_t stream);
 hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream);
 hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream);
 hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream);
@@ -219,8 +221,14 @@ struct ovp_ctx {
   unsigned* pl_xflag = nullptr;                  // [32 step flags | 2 sync words]
   double *pl_Asum = nullptr, *pl_U = nullptr;
   int pl_U_cap = 0;
-  void* pl_sub_tab = nullptr;
-  bool pl_sub_active = false;
+  void *pl_sub_tab = nullptr, *pl_sub_htab = nullptr;  // [ids | inverse | clone ids | column map] of the loop's column order
+  bool pl_sub_active = false;   // ovp_msckf_plane_update runs inside plane_update_ordered (remapped tables, c->P = permuted copy)
+  bool pl_sub_rest = false;     // ... on a marginal: the rest of the state follows by push-through (k_plane_sub_accum per plane)
+  std::vector<int> pl_nl;       // [plane] leading columns involved up to and including that plane (loop order)
+  double* pl_scatter_dst = nullptr;   // full order: where the covariance product of the loop is un-permuted to
+  const int* pl_scatter_ids = nullptr;
+  double pl_t_entry = 0.0;
+  hipEvent_t ev_subtab = nullptr;     // behind the upload of pl_sub_htab (the pinned block is rewritten by the next call)
   void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
   size_t pl_stage_cap = 0;
   void* pl_hres = nullptr;            // pinned host copy of the plane results
@@ -449,6 +457,10 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   if (c->ev_batch) hipEventDestroy(c->ev_batch);
   if (c->pl_hstage) hipHostFree(c->pl_hstage);
   if (c->pl_hres) hipHostFree(c->pl_hres);
+  if (c->pl_sub_htab) hipHostFree(c->pl_sub_htab);
+  if (c->ev_subtab) hipEventDestroy(c->ev_subtab);
+  for (hipEvent_t e : c->pl_ev) hipEventDestroy(e);
+  for (hipEvent_t e : c->pl_ev_loop) hipEventDestroy(e);
   if (c->io_h) hipHostFree(c->io_h);
   if (c->io_d) hipFree(c->io_d);
   hipEventDestroy(c->ev_fork);
@@ -1506,56 +1518,91 @@ static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_byt
   return 0;
 }
 
-// ---- the plane loop of a state above the tile factorization's limit (update/UpdaterMSCKF.cpp:413-649 has no limit) -------------
+// ---- the plane loop in the loop's own column order (update/UpdaterMSCKF.cpp:413-649 has no size limit) --------------------------
 // A plane's rows touch the clones, the calibration, its own closest point when it is a state variable and the SLAM landmarks lying
-// on it (out-of-state planes): the union s of these columns over the planes of the call is what the whole sequential loop can
-// change through the information it adds.  With P0 the covariance at the start and ns = |s| <= the factorization's limit the loop
-// runs UNCHANGED on the marginal P0[s, s] - same kernels, the state tables addressed through remapped column ids - and the rest of
-// the state follows from the push-through identity (k_plane_sub_accum for dx, the point path's  P -= G (A - A Pss+ A) G^T  for P).
-static int plane_update_substate(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
-                                 uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
+// on it (out-of-state planes).  Two things follow:
+//  (1) LEADING BLOCK.  With P0 = L0 L0^T in the order [clones + calibration | the planes' own columns in processing order |
+//      everything no plane of the call involves (IMU, dt, other landmarks)], A_k is zero outside the columns involved so far and L0
+//      is lower triangular, so L0^T A_k L0 is zero outside that LEADING block: T_k = blockdiag(T_lead, I).  Plane k's products and
+//      its factorization run on nl_k = 6 C + calibration + (own columns of the planes up to k) columns instead of n (config 3:
+//      194 .. 224 of 240 - 13 to 14 tile steps of k_chol2 instead of 15, and shorter ones); only dx = L0[:, 0:nl] y and the commit
+//      see all n rows.  The covariance is permuted once in front of the loop and once behind it.
+//  (2) SUB-STATE.  Above the factorization's limit (n > 287) the loop runs on the marginal P0[s, s] of the involved columns s
+//      (ns <= 287; same order) - same kernels, the state tables addressed through remapped column ids - and the rest of the state
+//      follows from the push-through identity (k_plane_sub_accum for dx, the point path's  P -= G (A - A Pss+ A) G^T  for P).
+static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
+                                uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used) {
+  const double t_entry = host_now_ms();
   const int n = c->n, ld = c->ld, NP = pb->n_planes, C = c->fp.n_clones;
   const int n_slam = pb->n_slam > 0 ? pb->n_slam : 0;
   if (n_slam > 0 && (!pb->slam_plane || !pb->slam_state_id || !pb->slam_p || !pb->slam_p_fej)) return OVP_E_ARG;
-  std::vector<char> inv((size_t)n, 0);
-  auto mark = [&](int id, int sz) -> bool {
-    if (id < 0 || id + sz > n) return false;
-    for (int k = 0; k < sz; ++k) inv[id + k] = 1;
-    return true;
-  };
-  for (int i = 0; i < C; ++i)
-    if (!mark(c->h_clone_id[i], 6)) return OVP_E_ARG;
-  if (o->do_calib_camera_pose && !mark(c->calib_id, 6)) return OVP_E_ARG;
-  if (o->do_calib_camera_intrinsics && !mark(c->intr_id, 8)) return OVP_E_ARG;
-  for (int k = 0; k < NP; ++k)
-    if (pb->plane_state_id[k] >= 0 && !mark(pb->plane_state_id[k], 3)) return OVP_E_ARG;
-  for (int q = 0; q < n_slam; ++q) {
-    if (pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP) return OVP_E_ARG;
-    if (pb->plane_state_id[pb->slam_plane[q] - 1] < 0 && !mark(pb->slam_state_id[q], 3)) return OVP_E_ARG;
-  }
+  // ---- column order: first involvement ----
   std::vector<int> ids, pos((size_t)n, -1);
-  for (int col = 0; col < n; ++col)
-    if (inv[col]) {
-      pos[col] = (int)ids.size();
-      ids.push_back(col);
+  ids.reserve((size_t)n);
+  bool bad_id = false;
+  auto place = [&](int id, int sz) {
+    if (id < 0 || id + sz > n) {
+      bad_id = true;
+      return;
     }
-  const int ns = (int)ids.size();
-  if (ns > ovp_chol2_max_n()) return OVP_E_CAPACITY;  // the planes of this call involve more columns than one factorization holds
-  hipStream_t s = c->stream;
-  // ---- buffers ----
-  if (!c->sub_ids) HIPCHK(hipMalloc((void**)&c->sub_ids, sizeof(int) * (OVP_TILECHOL_NMAX + 16)));
-  if (!c->pl_Asum) HIPCHK(dalloc(&c->pl_Asum, (size_t)c->n_max * ld));
-  if (NP > c->pl_U_cap) {
-    if (c->pl_U) hipFree(c->pl_U);
-    c->pl_U_cap = NP + 8;
-    HIPCHK(dalloc(&c->pl_U, (size_t)c->pl_U_cap * ld));
+    for (int k = 0; k < sz; ++k)
+      if (pos[id + k] < 0) {
+        pos[id + k] = (int)ids.size();
+        ids.push_back(id + k);
+      }
+  };
+  for (int i = 0; i < C; ++i) place(c->h_clone_id[i], 6);
+  if (o->do_calib_camera_pose) place(c->calib_id, 6);
+  if (o->do_calib_camera_intrinsics) place(c->intr_id, 8);
+  for (int q = 0; q < n_slam; ++q)
+    if (pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP) return OVP_E_ARG;
+  c->pl_nl.assign((size_t)(NP > 0 ? NP : 1), 0);
+  for (int k = 0; k < NP; ++k) {
+    if (pb->plane_state_id[k] >= 0) place(pb->plane_state_id[k], 3);
+    else
+      for (int q = 0; q < n_slam; ++q)
+        if (pb->slam_plane[q] == k + 1) place(pb->slam_state_id[q], 3);
+    c->pl_nl[k] = (int)ids.size();
   }
+  if (bad_id) return OVP_E_ARG;
+  const int n_inv = (int)ids.size();
+  const bool full = n <= ovp_chol2_max_n();  // the whole state fits one factorization: the rest rides along behind the leading block
+  if (!full && n_inv > ovp_chol2_max_n()) return OVP_E_CAPACITY;  // the planes of this call involve more columns than one factorization holds
+  if (full)
+    for (int col = 0; col < n; ++col)
+      if (pos[col] < 0) {
+        pos[col] = (int)ids.size();
+        ids.push_back(col);
+      }
+  const int ns = (int)ids.size();
+  hipStream_t s = c->stream;
+  // ---- buffers: one pinned host block + one device block for [ids | inverse | clone ids | column map] ----
+  const size_t o_ids = 0, o_inv = sizeof(int) * (size_t)(c->n_max + 16), o_tab = 2 * o_inv;
   const size_t tab_bytes = sizeof(int) * (size_t)(c->c_max + 16) + sizeof(ovp::ColMap) * (size_t)c->n_max;
-  if (!c->pl_sub_tab) HIPCHK(hipMalloc(&c->pl_sub_tab, tab_bytes));
+  const size_t blk_bytes = o_tab + tab_bytes;
+  if (!c->pl_sub_tab) {
+    HIPCHK(hipMalloc(&c->pl_sub_tab, blk_bytes));
+    HIPCHK(hipHostMalloc(&c->pl_sub_htab, blk_bytes, hipHostMallocDefault));
+  }
+  if (!full) {
+    if (!c->pl_Asum) HIPCHK(dalloc(&c->pl_Asum, (size_t)c->n_max * ld));
+    if (NP > c->pl_U_cap) {
+      if (c->pl_U) hipFree(c->pl_U);
+      c->pl_U_cap = NP + 8;
+      HIPCHK(dalloc(&c->pl_U, (size_t)c->pl_U_cap * ld));
+    }
+  }
   // ---- remapped tables ----
-  std::vector<char> tab(tab_bytes, 0);
-  int* t_clone = (int*)tab.data();
-  ovp::ColMap* t_cm = (ovp::ColMap*)(tab.data() + sizeof(int) * (size_t)(c->c_max + 16));
+  if (c->ev_subtab) HIPCHK(hipEventSynchronize(c->ev_subtab));  // the pinned block fed the copy of the previous call (long done)
+  else HIPCHK(hipEventCreateWithFlags(&c->ev_subtab, hipEventDisableTiming));
+  char* hb = (char*)c->pl_sub_htab;
+  memset(hb, 0, blk_bytes);
+  int* h_ids = (int*)(hb + o_ids);
+  int* h_inv = (int*)(hb + o_inv);
+  int* t_clone = (int*)(hb + o_tab);
+  ovp::ColMap* t_cm = (ovp::ColMap*)(hb + o_tab + sizeof(int) * (size_t)(c->c_max + 16));
+  memcpy(h_ids, ids.data(), sizeof(int) * (size_t)ns);
+  for (int col = 0; col < n; ++col) h_inv[col] = pos[col] >= 0 ? pos[col] : 0;
   std::vector<int> clone_sub(C);
   for (int i = 0; i < C; ++i) {
     clone_sub[i] = t_clone[i] = pos[c->h_clone_id[i]];
@@ -1568,32 +1615,43 @@ static int plane_update_substate(ovp_ctx* c, const ovp_update_opts* o, const ovp
   }
   const int calib_sub = (c->calib_id >= 0 && c->calib_id + 6 <= n && pos[c->calib_id] >= 0) ? pos[c->calib_id] : -1;
   const int intr_sub = (c->intr_id >= 0 && c->intr_id + 8 <= n && pos[c->intr_id] >= 0) ? pos[c->intr_id] : -1;
-  if (calib_sub >= 0)
+  if (calib_sub >= 0 && o->do_calib_camera_pose)
     for (int k = 0; k < 6; ++k) {
       t_cm[calib_sub + k].kind = 2;
       t_cm[calib_sub + k].idx = k;
     }
-  if (intr_sub >= 0)
+  if (intr_sub >= 0 && o->do_calib_camera_intrinsics)
     for (int k = 0; k < 8; ++k) {
       t_cm[intr_sub + k].kind = 2;
       t_cm[intr_sub + k].idx = 6 + k;
     }
   std::vector<int> sid_sub(NP > 0 ? NP : 1, -1), slam_sub(n_slam > 0 ? n_slam : 1, 0);
   for (int k = 0; k < NP; ++k) sid_sub[k] = pb->plane_state_id[k] >= 0 ? pos[pb->plane_state_id[k]] : -1;
-  std::vector<int> slam_keep_plane(n_slam > 0 ? n_slam : 1, 0);
   for (int q = 0; q < n_slam; ++q) {
-    // a landmark listed on a plane that IS in the state takes no part in the loop (UpdaterMSCKF.cpp:240-241): park it on plane 0
-    const bool used = pb->plane_state_id[pb->slam_plane[q] - 1] < 0;
-    slam_sub[q] = used ? pos[pb->slam_state_id[q]] : 0;
-    slam_keep_plane[q] = pb->slam_plane[q];
+    // a landmark listed on a plane that IS in the state takes no part in the loop (UpdaterMSCKF.cpp:240-241): park it on column 0
+    // (in the full order every column has a position; on a marginal the landmark's columns may be absent)
+    const int p0 = (pb->slam_state_id[q] >= 0 && pb->slam_state_id[q] + 3 <= n) ? pos[pb->slam_state_id[q]] : -1;
+    if (p0 < 0 && pb->plane_state_id[pb->slam_plane[q] - 1] < 0) return OVP_E_ARG;
+    slam_sub[q] = p0 >= 0 ? p0 : 0;
   }
-  HIPCHK(hipMemcpyAsync(c->sub_ids, ids.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(c->pl_sub_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s));
-  HIPCHK(ovp_launch_gather_block(c->P, ld, c->sub_ids, ns, c->P_tmp, ld, s));
-  HIPCHK(hipMemsetAsync(c->pl_Asum, 0, sizeof(double) * (size_t)ns * ld, s));
-  HIPCHK(hipMemsetAsync(c->pl_U, 0, sizeof(double) * (size_t)NP * ld, s));
-  HIPCHK(hipStreamSynchronize(s));  // ids / tab are temporaries of this frame
-  // ---- the loop on the sub-state ----
+  if (c->pl_ktimer) {
+    while (c->pl_ev_loop.size() < 2) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->pl_ev_loop.push_back(e);
+    }
+    HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));
+  }
+  HIPCHK(hipMemcpyAsync(c->pl_sub_tab, hb, blk_bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(c->ev_subtab, s));
+  const int* d_ids = (const int*)((char*)c->pl_sub_tab + o_ids);
+  const int* d_inv = (const int*)((char*)c->pl_sub_tab + o_inv);
+  HIPCHK(ovp_launch_gather_block(c->P, ld, d_ids, ns, c->P_tmp, ld, s));
+  if (!full) {
+    HIPCHK(hipMemsetAsync(c->pl_Asum, 0, sizeof(double) * (size_t)ns * ld, s));
+    HIPCHK(hipMemsetAsync(c->pl_U, 0, sizeof(double) * (size_t)NP * ld, s));
+  }
+  // ---- the loop in the new order ----
   ovp_plane_batch pbs = *pb;
   pbs.plane_state_id = sid_sub.data();
   pbs.slam_state_id = slam_sub.data();
@@ -1610,13 +1668,19 @@ static int plane_update_substate(ovp_ctx* c, const ovp_update_opts* o, const ovp
   c->P = c->P_tmp;
   c->calib_id = calib_sub;
   c->intr_id = intr_sub;
-  c->clone_id = (int*)c->pl_sub_tab;
+  c->clone_id = (int*)((char*)c->pl_sub_tab + o_tab);
   c->fp.clone_id = c->clone_id;
-  c->colmap = (ovp::ColMap*)((char*)c->pl_sub_tab + sizeof(int) * (size_t)(c->c_max + 16));
+  c->colmap = (ovp::ColMap*)((char*)c->pl_sub_tab + o_tab + sizeof(int) * (size_t)(c->c_max + 16));
   c->h_clone_id = clone_sub;
   c->pl_sub_active = true;
+  c->pl_sub_rest = !full;
+  c->pl_scatter_dst = full ? sv.P : nullptr;  // full order: the loop's covariance product is un-permuted straight into the resident P
+  c->pl_scatter_ids = d_inv;
+  c->pl_t_entry = t_entry;
   const int rc = ovp_msckf_plane_update(c, o, &pbs, dx_sub.data(), plane_ok, plane_chi2, plane_dof, feat_used);
   c->pl_sub_active = false;
+  c->pl_sub_rest = false;
+  c->pl_scatter_dst = nullptr;
   double* Pss_new = c->P;  // = P_tmp: the marginal after the loop
   c->n = sv.n;
   c->P = sv.P;
@@ -1627,12 +1691,18 @@ static int plane_update_substate(ovp_ctx* c, const ovp_update_opts* o, const ovp
   c->colmap = sv.colmap;
   c->h_clone_id = sv.h_clone_id;
   if (rc) return rc;  // the resident covariance was not touched
+  if (full) {
+    if (dx_planes)
+      for (int k = 0; k < NP; ++k)
+        for (int i = 0; i < ns; ++i) dx_planes[(size_t)k * n + ids[i]] = dx_sub[(size_t)k * ns + i];
+    return 0;
+  }
   // ---- the rest of the state ----
   // Lambda = Asum - Asum Pss+ Asum ;  P -= G Lambda G^T ;  dx_k = G u_k     (G = P0[:, s] in Y)
   HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, c->pl_Asum, ld, Pss_new, ld, c->W1, ld, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, c->W1, ld, c->pl_Asum, ld, c->T, ld, 0, 1, s));
   HIPCHK(ovp_launch_mat_sub(c->pl_Asum, c->T, c->T, ns, ns, ld, s));
-  HIPCHK(ovp_launch_gather_cols(c->P, ld, c->sub_ids, n, ns, c->Y, ld, s));
+  HIPCHK(ovp_launch_gather_cols(c->P, ld, d_ids, n, ns, c->Y, ld, s));
   if (dx_planes && NP > 0) {
     // rows = planes: DX (NP x n) = U (NP x ns) G^T
     HIPCHK(ovp_launch_gemm4(0, 1, NP, n, ns, c->pl_U, ld, c->Y, ld, c->Lt, ld, 0, 0, s));
@@ -1653,7 +1723,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
-  const double t_entry = host_now_ms();
+  const double t_entry = c->pl_sub_active ? c->pl_t_entry : host_now_ms();
   const int n = c->n, ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
   // skip_plane_used is an option of the POINT update that follows; the plane loop itself produces the mask
   ovp_update_opts o_local = *o;
@@ -1663,8 +1733,9 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   int rcu = ensure_pl_used(c);
   if (rcu) return rcu;
   static const bool force_v1 = getenv("OVP_PLANE_V1") != nullptr;
-  if (n > ovp_chol2_max_n() && !force_v1 && !c->pl_sub_active)
-    return plane_update_substate(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
+  static const bool natural_order = getenv("OVP_PL_NATURAL_ORDER") != nullptr;  // A/B: the loop on all n columns in the state's order
+  if (!force_v1 && !c->pl_sub_active && NP > 0 && (n > ovp_chol2_max_n() || !natural_order))
+    return plane_update_ordered(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
   if (n > ovp_chol2_max_n() || force_v1) {
     // first generation (no device-side mask of its own): the host mask it reports is mirrored into pl_used
     std::vector<uint8_t> used_h((size_t)(F > 0 ? F : 1), 0);
@@ -1845,10 +1916,16 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   {
     // results, per-plane corrections, used-feature mask (rounded up to whole words: the buffer is f_max + 64 bytes), flags,
     // [0] current T buffer + [1..2] factor bookkeeping (PlaneSolve::cond), half 0 of T (sum of the accepted L0^T A L0): one launch
-    void* zp[6] = {c->pl_res, c->pl_dx, c->pl_used, c->flags, c->pl_cur, c->pl_Tbuf};
-    const size_t zb[6] = {sizeof(double) * 4 * NP, sizeof(double) * (size_t)n * NP, ((size_t)F + 3) & ~(size_t)3, sizeof(int) * 4,
-                          NJ > 0 ? 3 * sizeof(int) : 0, NJ > 0 ? sizeof(double) * (size_t)n * ld : 0};
-    HIPCHK(ovp_launch_zero_regions(zp, zb, 6, s));
+    // both halves of T: a plane writes its candidate only inside its leading block, the rest of either half must read as zero;
+    // the packed factor / inverted diagonal blocks behind the loop start out as the identity for the same reason
+    const int ntn = (n + 15) / 16;
+    void* zp[8] = {c->pl_res, c->pl_dx, c->pl_used, c->flags, c->pl_cur, c->pl_Tbuf, c->Ltp, c->Dinv};
+    const size_t zb[8] = {sizeof(double) * 4 * NP, sizeof(double) * (size_t)n * NP, ((size_t)F + 3) & ~(size_t)3, sizeof(int) * 4,
+                          NJ > 0 ? 3 * sizeof(int) : 0, NJ > 0 ? sizeof(double) * (tstride + (size_t)n * ld) : 0,
+                          (NJ > 0 && c->pl_sub_active) ? sizeof(double) * 256 * (size_t)(ntn * (ntn + 1) / 2) : 0,
+                          (NJ > 0 && c->pl_sub_active) ? sizeof(double) * 256 * (size_t)ntn : 0};
+    const int zpat[8] = {0, 0, 0, 0, 0, 0, 2, 1};
+    HIPCHK(ovp_launch_fill_regions(zp, zb, zpat, 8, ntn, s));
   }
   if (c->pl_ktimer) {  // [0 | 1] = the whole loop on the device clock (first launch .. covariance product), then a pair per plane
     while (c->pl_ev_loop.size() < 2) {
@@ -1856,7 +1933,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       HIPCHK(hipEventCreate(&e));
       c->pl_ev_loop.push_back(e);
     }
-    HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));
+    if (!c->pl_sub_active) HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));  // (plane_update_ordered: in front of its permutation)
   }
   if (NJ > 0) {
     rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
@@ -1865,6 +1942,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   const double white_c = 1.0 / o->sigma_constraint;
   for (int jn = 0; jn < NJ; ++jn) {
     const PlaneJobH& j = jobs[jn];
+    // leading block this plane's products and factorization run on (plane_update_ordered): every column involved so far
+    const int nk = c->pl_sub_active ? c->pl_nl[j.pl] : n;
     // (1) per-feature rows
     ovp::PlaneParams pp;
     pp.feat_list = d_feat + j.start;
@@ -1877,13 +1956,13 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     pp.cp_fej = d_cpfej;
     pp.cst = c->pl_cst;
     ovp::FeatParams fpl = fp;
-    fpl.n = n;
+    fpl.n = nk;
     fpl.P = c->P;
     HIPCHK(ovp_launch_plane_feat(&fpl, &pp, j.nf, s));
     // (2) Gram products
     const int chunks = (2 * j.nf + c->rows_per_chunk - 1) / c->rows_per_chunk;
     int nsplit = 1;
-    HIPCHK(ovp_launch_gram_pair(c->rec, fp.n_clones, j.nf, c->rows_per_chunk, chunks, c->gramS, c->G, 3 * j.nf, c->ldg, n + 4,
+    HIPCHK(ovp_launch_gram_pair(c->rec, fp.n_clones, j.nf, c->rows_per_chunk, chunks, c->gramS, c->G, 3 * j.nf, c->ldg, nk + 4,
                                 c->n_split, c->part, &nsplit, s));
     // (3) pair on the state columns, normalised Gram, residual energy
     ovp::PlaneAsm pa;
@@ -1894,11 +1973,11 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     pa.part = c->part;
     pa.n_split = nsplit;
     {
-      const int nt16 = (n + 4 + 15) / 16;
+      const int nt16 = (nk + 4 + 15) / 16;
       pa.ntile = nt16 * (nt16 + 1) / 2;
     }
     pa.colmap = c->colmap;
-    pa.n = n;
+    pa.n = nk;
     pa.plane_sid = j.sid;
     pa.in_state = j.in_state;
     pa.cst = c->pl_cst;
@@ -1923,8 +2002,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     pa.scal = c->pl_scal;
     HIPCHK(ovp_launch_plane_assemble2(&pa, s));
     // (4) W = A L0 ;  T_try = T_cur + L0^T W ;  c = L0^T b
-    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, s));
-    HIPCHK(ovp_launch_plane_dT(n, c->L, ld, c->W1, c->Ab + (size_t)n * ld, c->pl_Tbuf, tstride, c->pl_cur, c->pl_crow, s));
+    HIPCHK(ovp_launch_gemm4(0, 0, nk, nk, nk, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, s));
+    HIPCHK(ovp_launch_plane_dT(nk, c->L, ld, c->W1, c->Ab + (size_t)nk * ld, c->pl_Tbuf, tstride, c->pl_cur, c->pl_crow, s));
     // (5) both factorizations, gate, solve, commit
     ovp::Chol2Job j0, j1;
     memset(&j0, 0, sizeof(j0));
@@ -1933,7 +2012,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     j0.sel = c->pl_cur;
     j0.sel_xor = 1;
     j0.sel_stride = tstride;
-    j0.n = n;
+    j0.n = nk;
     j0.ld = ld;
     j0.add_identity = 1;
     j0.mode = 1;
@@ -1960,7 +2039,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       // 7 or 8, 8.69 unsplit).  OVP_C2_SPLIT: 0 = never, h = forced.
       const char* split_s = getenv("OVP_C2_SPLIT");  // (read per call: the tests switch it)
       const int split_env = split_s ? atoi(split_s) : -1;
-      const int nb = n + 1, ntb = (nb + 15) / 16;
+      const int nb = nk + 1, ntb = (nb + 15) / 16;
       const int nst = (nb % 16 == 1) ? ntb - 1 : ntb;  // a border row alone in its tile row takes no step
       int h = ntb >= 17 ? nst / 3 : 0;  // part B also runs the back half of the chain: 5 - 6 of 18 steps measured best (7.91 ms per
                                         // config-4 plane loop against 8.10 for 7 or 8 and 8.69 unsplit)
@@ -1984,6 +2063,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.res_out = c->pl_res + 4 * j.pl;
     ps.L0 = c->L;
     ps.ld0 = ld;
+    ps.n_full = n;
     ps.dx_out = c->pl_dx + (size_t)j.pl * n;
     ps.dx_last = c->pl_dxlast;
     ps.cur = c->pl_cur;
@@ -2028,14 +2108,14 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     }
     HIPCHK(ovp_launch_chol2(&j0, &j1, &ps, s));
     if (c->pl_ktimer == 1) HIPCHK(hipEventRecord(c->pl_ev[2 * jn + 1], s));
-    if (c->pl_sub_active)
+    if (c->pl_sub_rest)
       HIPCHK(ovp_launch_plane_sub_accum(c->pl_res + 4 * j.pl, c->Ab, c->pl_Asum, c->pl_dx + (size_t)j.pl * n,
-                                        c->pl_U + (size_t)j.pl * ld, n, ld, s));
+                                        c->pl_U + (size_t)j.pl * ld, nk, ld, s));
     if (pl_stamps && jn == NJ - 1) {
       long long h[2 * 16 * 32];
       HIPCHK(hipStreamSynchronize(s));
       HIPCHK(hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost));
-      const int ntb = (n + 1 + 15) / 16;
+      const int ntb = (nk + 1 + 15) / 16;
       const long long* e = h + (ntb + 1) * 16;
       fprintf(stderr, "[plane tail, cycles] factor %lld | gate %lld | back substitution %lld | dx = L0 y %lld | commit %lld\n",
               e[0] - h[0], e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]);
@@ -2066,6 +2146,8 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     HIPCHK(chol_of_T(c, c->T, n, ld, 1, c->pl_cur + 1, s));
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
+    if (c->pl_scatter_dst)  // back into the state's own column order (unless a factorization failed: the resident P stays)
+      HIPCHK(ovp_launch_gather_block_unless(c->P, ld, c->pl_scatter_ids, n, c->pl_scatter_dst, ld, c->flags, s));
   }
   if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev_loop[1], s));
   // ---- results: one pinned block, one synchronisation ----
@@ -2078,13 +2160,13 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
   const double t_enq = host_now_ms();
   HIPCHK(hipStreamSynchronize(s));
-  if (!c->pl_sub_active) {
+  {
     c->host_acc[0] += t_first - t_entry;
     c->host_acc[1] += t_enq - t_entry;
     c->host_acc[2] += host_now_ms() - t_enq;
     c->host_acc[3] += 1.0;
   }
-  if (c->pl_ktimer && !c->pl_sub_active) {
+  if (c->pl_ktimer) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->pl_ev_loop[0], c->pl_ev_loop[1]) == hipSuccess) c->host_acc[7] += ms;
   }
