@@ -477,6 +477,23 @@ def main():
                 run.step_sharded(rank, world, timing=stages)
             stages = {k: v / n_diag for k, v in stages.items()}
 
+    point_only = None
+    if sharded and name != "config2":
+        # the part of the path that shards, on the same ranks: BASELINE config 2's shape (2000 point features, no planes) strong-scaled
+        sc2 = make_workload("config2")
+        r2 = StepRunner(capi, torch, sc2, local_rank)
+        with torch.cuda.stream(r2.stream):
+            blocks = []
+            for blk in range(5):
+                el_b, _, _ = time_steps(torch, lambda: r2.step_sharded(rank, world), 10, 3 if blk == 0 else 0, barrier)
+                blocks.append(el_b / 10)
+        tb = torch.tensor(blocks, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        med = float(sorted(tb.tolist())[2])
+        point_only = {"workload": describe("config2", sc2), "ms_per_step": 1e3 * med, "features_per_s": sc2.F / med,
+                      "rank0_point_shard": int(r2.shard_size),
+                      "timing": "median of 5 blocks of 10 steps, max over ranks per block"}
+        r2.close()
     if sharded:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -576,9 +593,15 @@ def main():
             if "roofline" not in line:
                 line["roofline"] = line["roofline_point_kernel"]
         if stages is not None:
+            tot_st = sum(stages.values()) or 1.0
             line["multi_gpu"] = {
                 "rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
                 "rank0_stage_ms": stages,
+                "serial_fraction": stages.get("plane_loop_ms", 0.0) / tot_st,
+                "serial_fraction_note": "plane loop (replicated on every rank, sequential across planes: update/UpdaterMSCKF.cpp:413-649) / "
+                                        "sum of rank 0's stages; Amdahl bound of the step at this rank count = 1 / (s + (1 - s) / N)",
+                "amdahl_bound_speedup": 1.0 / (stages.get("plane_loop_ms", 0.0) / tot_st + (1.0 - stages.get("plane_loop_ms", 0.0) / tot_st) / world),
+                "point_only_scaling": point_only,
                 "rank0_point_shard": int(run.shard_size),
                 "note": "stage times of rank 0 from a separate pass with a host synchronisation behind every stage (plane loop "
                         "replicated on every rank; points_build = feature kernel + information pair of the rank's shard; "

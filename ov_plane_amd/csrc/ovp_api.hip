@@ -2188,9 +2188,17 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   }
   const int bad = c->h_flags[0] | c->h_flags[2];
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  if (bad) {
+    // A failed factorization / timed-out hand-over rejects its plane and every later one before anything is committed, and the
+    // covariance product behind the loop is cancelled (the resident P is the prior).  Planes accepted BEFORE the failure have
+    // committed their corrections to the device tables: those no longer belong to the resident covariance - the caller must
+    // upload the state again (OVP_E_STATE until then).  chol(P) itself failing (singular prior) happens in front of every plane.
+    bool any_committed = false;
+    for (const PlaneJobH& j : jobs) any_committed |= hres[4 * j.pl + 1] > 0.5;
+    if (any_committed) c->have_state = false;
+  }
   if (bad & 2) return OVP_E_TIMEOUT;
-  if (bad) return OVP_E_NOTSPD;  // a factorization failed (singular prior: chol(P) of the loop's start): every plane from there
-                                 // on was rejected before anything was committed, state tables and covariance are consistent
+  if (bad) return OVP_E_NOTSPD;
   return 0;
 }
 

@@ -156,6 +156,81 @@ def test_full_size_properties(hiplib):
     ctx.close()
 
 
+def _whole_step_against_oracle(hiplib, oracle, sc):
+    """One UpdaterMSCKF::update downstream of triangulation at full size, device against oracle: the plane loop with the gate at
+    chi2_multipler = 1 (the device loop runs on the oracle's accept / reject sequence - ovp_plane_batch::force_decision - so both
+    hand the same state to what follows; the plane statistic itself is covered by the plane-gate tests), then the point update on
+    every feature no accepted plane consumed (device-side mask) against the all-cores oracle (oracle/ovp_oracle_omp.c, pinned
+    against the one-thread restatement in test_oracle_pins) at the state the oracle's plane loop left.  Returns the report."""
+    from ov_plane_amd.synth import Scene
+
+    has_planes = sc.cp.shape[0] > 0
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    o = hiplib.opts_from_scene(sc)
+    rep = {}
+    if has_planes:
+        ref_pl = oracle.msckf_plane_update(sc)
+        pl = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id, force_decision=ref_pl["plane_ok"].astype(np.uint8))
+        assert (pl["ok"] == ref_pl["plane_ok"]).all() and (pl["used"] == ref_pl["used"]).all()
+        assert (pl["dof"] == ref_pl["plane_rows"]).all()
+        rep["planes_rejected"] = int((~ref_pl["plane_ok"]).sum())
+        # the decisions the device's own statistic would have taken: equal to the oracle's except next to the threshold
+        thr = np.array([hiplib.lib().ovp_chi2_quantile_095(int(k)) for k in pl["dof"]])
+        differ = (pl["chi2"] <= thr) != ref_pl["plane_ok"]
+        assert differ.sum() <= max(2, len(thr) // 12) and (np.abs(ref_pl["plane_chi2"] - thr)[differ] < 18.2).all()
+        sc2 = Scene(sc)
+        for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
+            sc2[k] = ref_pl[k]
+        rest = np.where(~ref_pl["used"])[0]
+        o.skip_plane_used = 1
+    else:
+        sc2, rest = sc, np.arange(sc.F)
+    ref = oracle.msckf_point_update_omp(sc2, feats=rest)
+    out = ctx.msckf_update(o)
+    P = ctx.cov_download()
+    ctx.close()
+    acc_d = np.asarray(out["accepted"]).astype(bool)
+    assert (acc_d[rest] == ref["accepted"]).all(), np.where(acc_d[rest] != ref["accepted"])[0]
+    if has_planes:
+        assert not acc_d[ref_pl["used"]].any()
+    assert np.abs(out["chi2"][rest] - ref["chi2"]).max() <= 1e-7 * max(1.0, np.abs(ref["chi2"]).max())
+    rep["dx_err"] = float(np.abs(out["dx"] - ref["dx"]).max())
+    rep["P_err"] = relP(P, ref["P"])
+    rep["points_gated"] = int(len(rest))
+    rep["points_accepted"] = int(ref["accepted"].sum())
+    assert rep["dx_err"] < TOL_DX and rep["P_err"] < TOL_P, rep
+    return rep
+
+
+def test_config2_full_step_matches_oracle(hiplib, oracle):
+    """BASELINE config[1] at full size (30 clones, 2000 MSCKF point features, gate at multiplier 1) against the oracle: accept set,
+    chi2 of every feature, correction and covariance."""
+    sc = make_scene(C=30, F=2000, seed=0, chi2_mult=1.0)
+    assert sc.N == 210
+    rep = _whole_step_against_oracle(hiplib, oracle, sc)
+    assert rep["points_gated"] == 2000 and 1900 < rep["points_accepted"] < 2000
+
+
+def test_config3_whole_step_matches_oracle(hiplib, oracle):
+    """BASELINE config[2] at full size - the bench's timed frame: 20 planes x 50 features + 1000 free points, gate at multiplier 1
+    on both levels - plane loop AND the point update on the leftovers against the oracle."""
+    sc = make_scene(C=30, F=2000, seed=0, n_planes=20, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=1.0)
+    assert sc.N == 240
+    rep = _whole_step_against_oracle(hiplib, oracle, sc)
+    assert rep["planes_rejected"] >= 1 and rep["points_gated"] >= 1000 + 50 * rep["planes_rejected"]
+
+
+def test_config4_whole_step_matches_oracle(hiplib, oracle):
+    """BASELINE config[3] on one GPU at full size (8000 features of which 2500 on 50 planes, N = 285), whole step against the oracle."""
+    sc = make_scene(C=30, F=8000, seed=0, n_planes=50, feats_per_plane=50, planes_in_state_frac=0.5, chi2_mult=1.0)
+    assert sc.N == 285
+    rep = _whole_step_against_oracle(hiplib, oracle, sc)
+    assert rep["points_gated"] >= 5500
+
+
 def test_config3_plane_loop_at_full_size_matches_oracle(hiplib, oracle):
     """BASELINE config[2]: 30 clones, 2000 features of which 1000 lie on 20 planes (10 of them in the state, N = 240).  The plane
     loop is cheap enough for the oracle at full size (about a second); the point update on the 1000 free points is checked
