@@ -185,6 +185,22 @@ __global__ void k_gather_block(const double* __restrict__ P, int ldp, const int*
   const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (k < m) out[(size_t)i * ldo + k] = P[(size_t)ids[i] * ldp + ids[k]];
 }
+// Positive SEMI-definite covariance in front of a pivot-dropping factorization: C = D^-1 P D^-1 with D = sqrt(diag P) (unit diagonal,
+// so ONE absolute pivot floor separates the directions P does not determine - pivots of rounding size - from the regular ones,
+// whatever the units of the variables); a variable with zero variance gets a zero row / column.  dvec <- D.
+__global__ void k_unit_diag(const double* __restrict__ P, int n, int ld, double* __restrict__ C, double* __restrict__ dvec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k >= n) return;
+  const double pi = P[(size_t)i * ld + i], pk = P[(size_t)k * ld + k];
+  const double si = pi > 0.0 ? 1.0 / sqrt(pi) : 0.0, sk = pk > 0.0 ? 1.0 / sqrt(pk) : 0.0;
+  C[(size_t)i * ld + k] = (i == k) ? (pi > 0.0 ? 1.0 : 0.0) : P[(size_t)i * ld + k] * si * sk;
+  if (i == 0) dvec[k] = pk > 0.0 ? sqrt(pk) : 0.0;
+}
+// L <- D L (rows scaled): the factor of P from the factor of its unit-diagonal form
+__global__ void k_scale_rows(double* __restrict__ L, int n, int ld, const double* __restrict__ dvec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k < n) L[(size_t)i * ld + k] *= dvec[i];
+}
 // ... unless *cancel != 0 (a failed factorization upstream: the destination keeps what it holds, cf. ovp_launch_gemm4c)
 __global__ void k_gather_block_unless(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int m,
                                       double* __restrict__ out, int ldo, const int* __restrict__ cancel) {
@@ -203,7 +219,8 @@ __global__ void k_mat_sub(const double* __restrict__ A, const double* __restrict
   if (k < cols && i < rows) C[(size_t)i * ld + k] = A[(size_t)i * ld + k] - B[(size_t)i * ld + k];
 }
 // P -= D on the lower triangle, mirrored (the reference mirrors its upper triangle the same way, StateHelper.cpp:171-172)
-__global__ void k_sub_sym(double* __restrict__ P, const double* __restrict__ D, int n, int ld) {
+__global__ void k_sub_sym(double* __restrict__ P, const double* __restrict__ D, int n, int ld, const int* __restrict__ cancel) {
+  if (cancel && *cancel != 0) return;  // a factorization upstream failed: the covariance keeps what it holds
   const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (k <= i && i < n) {
     const double v = P[(size_t)i * ld + k] - D[(size_t)i * ld + k];
@@ -405,6 +422,14 @@ hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int
   hipLaunchKernelGGL(ovp::k_gather_block, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo);
   return hipGetLastError();
 }
+hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_unit_diag, dim3((n + 127) / 128, n), dim3(128), 0, stream, P, n, ld, C, dvec);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_scale_rows(double* L, int n, int ld, const double* dvec, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_scale_rows, dim3((n + 127) / 128, n), dim3(128), 0, stream, L, n, ld, dvec);
+  return hipGetLastError();
+}
 hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
                                           hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_gather_block_unless, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo, cancel);
@@ -414,9 +439,12 @@ hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int 
   hipLaunchKernelGGL(ovp::k_gather_cols, dim3((m + 127) / 128, n), dim3(128), 0, stream, P, ldp, ids, n, m, G, ldg);
   return hipGetLastError();
 }
-hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream) {
-  hipLaunchKernelGGL(ovp::k_sub_sym, dim3((n + 127) / 128, n), dim3(128), 0, stream, P, D, n, ld);
+hipError_t ovp_launch_sub_sym_unless(double* P, const double* D, int n, int ld, const int* cancel, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_sub_sym, dim3((n + 127) / 128, n), dim3(128), 0, stream, P, D, n, ld, cancel);
   return hipGetLastError();
+}
+hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream) {
+  return ovp_launch_sub_sym_unless(P, D, n, ld, nullptr, stream);
 }
 hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_mat_sub, dim3((cols + 127) / 128, rows), dim3(128), 0, stream, A, B, C, rows, cols, ld);

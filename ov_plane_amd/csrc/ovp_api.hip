@@ -24,9 +24,12 @@ hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols,
 hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream);
 hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
                                           hipStream_t stream);
+hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream);
+hipError_t ovp_launch_scale_rows(double* L, int n, int ld, const double* dvec, hipStream_t stream);
 hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream);
 hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream);
 hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream);
+hipError_t ovp_launch_sub_sym_unless(double* P, const double* D, int n, int ld, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, hipStream_t stream);
 hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, int n_old, int id, int sz,
                                       hipStream_t stream);
@@ -228,6 +231,7 @@ struct ovp_ctx {
   double* pl_scatter_dst = nullptr;   // full order: where the covariance product of the loop is un-permuted to
   const int* pl_scatter_ids = nullptr;
   double pl_t_entry = 0.0;
+  bool pl_psd = false;          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
   hipEvent_t ev_subtab = nullptr;     // behind the upload of pl_sub_htab (the pinned block is rewritten by the next call)
   void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
   size_t pl_stage_cap = 0;
@@ -833,6 +837,26 @@ static int set_substate(ovp_ctx* c, const std::vector<int>& ids) {
 
 static int chol_of_P(ovp_ctx* c, hipStream_t s) {
   const int n = c->n, ld = c->ld;
+  if (c->pl_psd && n <= ovp_chol2_max_n() + 1) {
+    // Positive SEMI-definite prior (plane loop, second attempt: state/StateHelper.cpp:159-187 never factors P, so the reference
+    // updates such a covariance - right after StateHelper::clone the newest pose is an exact copy, :346-396).  ANY factor with
+    // L0 L0^T = P serves the loop (P_k = L0 (I + L0^T A L0)^-1 L0^T is the matrix inversion lemma, no inverse of P in it): the
+    // pivot-dropping Cholesky of the unit-diagonal form, L0 = D Lc with zero columns where P determines nothing.
+    HIPCHK(ovp_launch_unit_diag(c->P, n, ld, c->W1, c->pl_crow, s));
+    ovp::Chol2Job j;
+    memset(&j, 0, sizeof(j));
+    j.A = c->W1;
+    j.n = n;
+    j.ld = ld;
+    j.mode = 0;
+    j.flag = c->flags;
+    j.piv_floor = 1e-12;  // regular pivots of the unit-diagonal form are >= 1 / cond (1e-8 at worst), dropped ones rounding noise
+    j.Ldense = c->L;
+    j.ldo = ld;
+    HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, s));
+    HIPCHK(ovp_launch_scale_rows(c->L, n, ld, c->pl_crow, s));
+    return 0;
+  }
   static const bool first_gen = getenv("OVP_TILECHOL_P") != nullptr;  // A/B: the first-generation kernel
   if (!first_gen && n <= ovp_chol2_max_n() + 1) {  // dense factor from the second-generation kernel
     ovp::Chol2Job j;
@@ -861,7 +885,7 @@ static hipError_t chol_of_T(ovp_ctx* c, const double* T, int n, int ld, int add_
   return ovp_launch_chol2_packed(T, c->Dinv, c->Ltp, n, ld, c->flags, add_identity, cond, s);
 }
 
-static int ekf_substate(ovp_ctx* c) {
+static int ekf_substate(ovp_ctx* c, bool psd = false) {
   const int n = c->n, ld = c->ld, ns = c->sub_ns, lds = OVP_TILECHOL_NMAX;
   const size_t sz = (size_t)OVP_TILECHOL_NMAX * OVP_TILECHOL_NMAX;
   double *S_P = c->sub_buf, *S_A = S_P + sz, *S_L = S_A + sz, *S_W = S_L + sz, *S_T = S_W + sz, *S_Y = S_T + sz;
@@ -869,7 +893,25 @@ static int ekf_substate(ovp_ctx* c) {
   HIPCHK(ovp_launch_gather_block(c->P, ld, c->sub_ids, ns, S_P, lds, s));
   HIPCHK(ovp_launch_gather_block(c->Ab, ld, c->sub_ids, ns, S_A, lds, s));
   // Pss+ = Ls (I + Ls^T A Ls)^-1 Ls^T exactly as the full-state path does it
-  HIPCHK(ovp_launch_tilechol(S_P, S_L, nullptr, nullptr, ns, lds, c->flags, 0, s));
+  if (psd) {
+    // second attempt behind a failed chol(Pss): positive SEMI-definite prior (an exact stochastic clone) - any factor with
+    // Ls Ls^T = Pss serves the identity above; the pivot-dropping Cholesky of the unit-diagonal form (cf. chol_of_P)
+    HIPCHK(ovp_launch_unit_diag(S_P, ns, lds, S_W, c->dx, s));
+    ovp::Chol2Job j;
+    memset(&j, 0, sizeof(j));
+    j.A = S_W;
+    j.n = ns;
+    j.ld = lds;
+    j.mode = 0;
+    j.flag = c->flags;
+    j.piv_floor = 1e-12;
+    j.Ldense = S_L;
+    j.ldo = lds;
+    HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, s));
+    HIPCHK(ovp_launch_scale_rows(S_L, ns, lds, c->dx, s));
+  } else {
+    HIPCHK(ovp_launch_tilechol(S_P, S_L, nullptr, nullptr, ns, lds, c->flags, 0, s));
+  }
   HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, S_A, lds, S_L, lds, S_W, lds, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(1, 0, ns, ns, ns, S_L, lds, S_W, lds, S_T, lds, 1, 1, s));
   HIPCHK(ovp_launch_tilechol(S_T, nullptr, c->Dinv, c->Ltp, ns, lds, c->flags, 0, s));
@@ -883,7 +925,7 @@ static int ekf_substate(ovp_ctx* c) {
   HIPCHK(ovp_launch_gather_cols(c->P, ld, c->sub_ids, n, ns, c->Y, ld, s));
   HIPCHK(ovp_launch_gemm4(0, 0, n, ns, ns, c->Y, ld, S_T, lds, c->W1, ld, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(0, 1, n, n, ns, c->W1, ld, c->Y, ld, c->T, ld, 0, 1, s));
-  HIPCHK(ovp_launch_sub_sym(c->P, c->T, n, ld, s));
+  HIPCHK(ovp_launch_sub_sym_unless(c->P, c->T, n, ld, c->flags, s));  // (a failed factorization leaves the resident covariance alone)
   return 0;
 }
 
@@ -948,8 +990,20 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
 // Runs after a failed chol(P) (flags[0]): the pair [A | b] is still in c->Ab, P was not touched (ovp_launch_gemm4c cancel flag).
 static int ekf_sform(ovp_ctx* c) {
   const int n = c->n, ld = c->ld;
-  if (n > OVP_TILECHOL_NMAX || n > ovp_chol2_max_n()) return OVP_E_NOTSPD;
   hipStream_t s = c->stream;
+  if (n > OVP_TILECHOL_NMAX || n > ovp_chol2_max_n()) {
+    // above the tile factorization: the sub-state update once more, on the pivot-dropping factor of the involved block
+    if (!substate_ok(c) || c->sub_ns > ovp_chol2_max_n()) return OVP_E_NOTSPD;
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+    const int rs = ekf_substate(c, true);
+    if (rs) return rs;
+    HIPCHK(ovp_launch_dx_rows(c->P, n, ld, c->Ab + (size_t)n * ld, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, s));
+    HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+    return 0;
+  }
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
   HIPCHK(hipMemsetAsync(c->W1, 0, sizeof(double) * (size_t)n * ld, s));
   HIPCHK(ovp_launch_max_diag(c->Ab, n, ld, c->smallbuf, s));
@@ -2196,6 +2250,14 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     bool any_committed = false;
     for (const PlaneJobH& j : jobs) any_committed |= hres[4 * j.pl + 1] > 0.5;
     if (any_committed) c->have_state = false;
+    if (bad == 1 && !any_committed && !c->pl_psd) {
+      // chol(P) hit a non-positive pivot: the prior is only positive SEMI-definite.  Nothing was committed and the resident
+      // covariance was not written - the same loop once more on the pivot-dropping factor (chol_of_P).
+      c->pl_psd = true;
+      const int rc2 = ovp_msckf_plane_update(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
+      c->pl_psd = false;
+      return rc2;
+    }
   }
   if (bad & 2) return OVP_E_TIMEOUT;
   if (bad) return OVP_E_NOTSPD;

@@ -371,6 +371,56 @@ def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case
     out["ctx"].close()
 
 
+@pytest.mark.parametrize("case", ["exact_clone", "zero_variance"])
+@pytest.mark.parametrize("big", [False, True])
+def test_plane_loop_on_a_positive_semidefinite_prior(hiplib, oracle, case, big):
+    """The plane loop on the covariance StateHelper::clone leaves (state/StateHelper.cpp:346-396: the newest pose an EXACT copy,
+    P singular) - the reference never factors P (:159-187) and updates it as it is (update/UpdaterMSCKF.cpp:413-649).  The device
+    loop factors P0 once; when that fails it runs the same loop on the pivot-dropping factor of the unit-diagonal form
+    (P_k = L0 (I + L0^T A L0)^-1 L0^T holds for any L0 L0^T = P0) instead of returning OVP_E_NOTSPD.  `big`: above the
+    factorization's limit, where the loop runs on the marginal of the involved columns."""
+    kw = dict(C=9, F=150, seed=43, n_planes=3, feats_per_plane=25, planes_in_state_frac=0.67, chi2_mult=99999.0)
+    if big:
+        kw.update(n_slam=70)  # 70 free landmarks in the state: N = 300
+    sc = make_scene(**kw)
+    assert (sc.N > 288) == big
+    P = sc.P.copy()
+    if case == "exact_clone":
+        a, b = sc.ids["clones"][-2], sc.ids["clones"][-1]
+        idx = np.arange(sc.N)
+        idx[b:b + 6] = np.arange(a, a + 6)
+        P = P[np.ix_(idx, idx)]
+        sc["clone_q"][-1], sc["clone_p"][-1] = sc["clone_q"][-2], sc["clone_p"][-2]
+        sc["clone_q_fej"][-1], sc["clone_p_fej"][-1] = sc["clone_q_fej"][-2], sc["clone_p_fej"][-2]
+    else:
+        k = sc.ids["intr"] + 4  # first distortion coefficient known exactly
+        P[k, :] = 0.0
+        P[:, k] = 0.0
+    assert np.linalg.eigvalsh(P).min() < 1e-12 * np.linalg.eigvalsh(P).max()
+    sc["P"] = P
+    ref = oracle.msckf_plane_update(sc)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert (out["ok"] == ref["plane_ok"]).all() and out["ok"].all()
+    assert (out["used"] == ref["used"]).all()
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    d = np.sqrt(np.abs(np.diag(ref["P"])))
+    d[d == 0] = 1.0
+    assert (np.abs(ctx.cov_download() - ref["P"]) / np.outer(d, d)).max() < TOL_P
+    # the point update on the rest follows on the same singular covariance (its own S-form fallback)
+    o = hiplib.opts_from_scene(sc)
+    o.chi2_multiplier = 1.0
+    o.skip_plane_used = 1
+    upd = ctx.msckf_update(o)
+    assert upd["rc"] == 0 and upd["accepted"][~out["used"]].mean() >= 0.5
+    ctx.close()
+
+
 @pytest.mark.parametrize("info_form", ["0", "1"])
 def test_dense_ekf_update_matches_reference_form(hiplib, info_form, monkeypatch):
     """ovp_ekf_update == StateHelper::EKFUpdate (state/StateHelper.cpp:121-202) for an arbitrary dense H: the S-form kernels
