@@ -229,6 +229,9 @@ def step_stats(ts):
             "excess_over_median_ms": 1e3 * sum(t - med for t in ts if t > 1.5 * med)}
 
 
+CPU_BASELINE_RUNS = 3  # 3.7 s (one core) + 1.4 s (all cores) per run of the config-3 frame: ~15 s of CPU work in the default bench
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -248,32 +251,39 @@ def cpu_baseline(sc, name, budget_feats=None):
     from ov_plane_amd.synth import Scene
 
     pyoracle.build()
-    t0 = time.perf_counter()
-    pl = None
-    if sc.cp.shape[0] > 0:
-        pl = pyoracle.msckf_plane_update(sc)
-        sc2 = Scene(sc)
-        for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
-            sc2[k] = pl[k]
-        rest = np.where(~pl["used"])[0]
-        n_used = int(pl["used"].sum())
-    else:
-        sc2, rest, n_used = sc, np.arange(sc.F), 0
-    t1 = time.perf_counter()
-    sample = rest if budget_feats is None else rest[:budget_feats]
-    pt = pyoracle.msckf_point_update(sc2, feats=sample)
-    t2 = time.perf_counter()
-    t_plane, t_pts = t1 - t0, t2 - t1
+    runs = []
+    for _rep in range(CPU_BASELINE_RUNS):  # median of the runs (same inputs, same outputs every time)
+        t0 = time.perf_counter()
+        pl = None
+        if sc.cp.shape[0] > 0:
+            pl = pyoracle.msckf_plane_update(sc)
+            sc2 = Scene(sc)
+            for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
+                sc2[k] = pl[k]
+            rest = np.where(~pl["used"])[0]
+            n_used = int(pl["used"].sum())
+        else:
+            sc2, rest, n_used = sc, np.arange(sc.F), 0
+        t1 = time.perf_counter()
+        sample = rest if budget_feats is None else rest[:budget_feats]
+        pt = pyoracle.msckf_point_update(sc2, feats=sample)
+        t2 = time.perf_counter()
+        runs.append((t2 - t0, t1 - t0, t2 - t1))
+    runs.sort()
+    _, t_plane, t_pts = runs[len(runs) // 2]
     # point part scaled to the whole rest only when a prefix was asked for (it is linear in the feature count up to the final update)
     t_full = t_plane + t_pts * (len(rest) / max(len(sample), 1))
     # all-cores ceiling of the same step (BASELINE.md "CPU-omp"): point update spread over the host cores (OpenMP over the features,
     # TSQR compression), plane loop unchanged - it is sequential across planes and its retained rows decide its gate
     omp = None
     try:
-        t3 = time.perf_counter()
-        po = pyoracle.msckf_point_update_omp(sc2, feats=sample)
-        t4 = time.perf_counter()
-        omp = dict(threads=int(po["threads"]), point_update_ms=1e3 * (t4 - t3), ms_per_step=1e3 * (t_plane + (t4 - t3) * (len(rest) / max(len(sample), 1))),
+        tt = []
+        for _rep in range(CPU_BASELINE_RUNS):
+            t3 = time.perf_counter()
+            po = pyoracle.msckf_point_update_omp(sc2, feats=sample)
+            tt.append(time.perf_counter() - t3)
+        t3, t4 = 0.0, sorted(tt)[len(tt) // 2]
+        omp = dict(runs=len(tt), threads=int(po["threads"]), point_update_ms=1e3 * (t4 - t3), ms_per_step=1e3 * (t_plane + (t4 - t3) * (len(rest) / max(len(sample), 1))),
                    same_accept_set=bool((po["accepted"] == pt["accepted"]).all()),
                    dx_diff_vs_1_thread=float(np.abs(po["dx"] - pt["dx"]).max()),
                    note="oracle/ovp_oracle_omp.c: per-feature stage as an OpenMP loop, compression as a two-level Householder TSQR; "
@@ -281,7 +291,8 @@ def cpu_baseline(sc, name, budget_feats=None):
     except Exception as e:  # noqa: BLE001
         print("all-cores CPU leg skipped: %r" % (e,), file=sys.stderr)
     obj = dict(
-        value=sc.F / t_full, unit="features/s", cores=1, kind="port", cpu=cpu_model(), host_cores=os.cpu_count(), all_cores=omp,
+        value=sc.F / t_full, unit="features/s", cores=1, kind="port", runs=len(runs), runs_ms=[round(1e3 * r[0], 1) for r in runs],
+        timing="median of %d runs" % len(runs), cpu=cpu_model(), host_cores=os.cpu_count(), all_cores=omp,
         sample="oracle/ovp_oracle.c (reference loop order, 1 thread) on the %s frame: plane loop over all planes %.2f s (%d features "
                "consumed, %d planes accepted), point update on %d of the %d remaining features %.2f s (feat system %.2f s, "
                "compression %.2f s, update %.3f s)%s" % (name, t_plane, n_used, int(pl["plane_ok"].sum()) if pl else 0, len(sample),

@@ -95,3 +95,38 @@ def test_host_givens_operations_match_restatement():
     # rows <= cols: untouched (UpdaterHelper.cpp:551-552)
     Hx, _, r = hostlib.run_plane_givens(1, None, H_x[:10], None, res[:10])
     assert Hx.shape == (10, cols) and np.abs(Hx - H_x[:10]).max() == 0.0 and np.abs(r - res[:10]).max() == 0.0
+
+
+def test_no_dpp_read_after_valu_write_hazard_in_the_built_kernels():
+    """The broadcast-in-FMA chains of k_chol2 / K1 are inline asm: the compiler's hazard recognizer does not see them, so the two
+    wait states a DPP read needs behind a VALU write of its operand are checked in the final machine code of every build
+    (tools/check_dpp_hazard.py)."""
+    import importlib.util
+    import glob
+
+    from ov_plane_amd.build import OBJ_DIR, build_lib
+
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    # the checker itself: a producer one wait state in front of the DPP read is found, two (s_nop 1) are fine, another register is fine
+    fn = ["0000000000001000 <k>:"]
+    bad, n = chk.check_disassembly(fn + ["\tv_fma_f64 v[4:5], v[0:1], v[2:3], v[0:1]// 0", "\ts_nop 0// 0",
+                                        "\tv_fmac_f64_dpp v[10:11], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf// 0"], "t")
+    assert n == 1 and len(bad) == 1
+    bad, n = chk.check_disassembly(fn + ["\tv_fma_f64 v[4:5], v[0:1], v[2:3], v[0:1]// 0", "\ts_nop 1// 0",
+                                        "\tv_fmac_f64_dpp v[10:11], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf// 0"], "t")
+    assert n == 1 and not bad
+    bad, n = chk.check_disassembly(fn + ["\tv_mov_b32_e32 v5, v9// 0", "\tv_mov_b32_dpp v1, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf// 0"], "t")
+    assert len(bad) == 1
+    bad, n = chk.check_disassembly(fn + ["\tv_mov_b32_e32 v6, v9// 0", "\tv_mov_b32_dpp v1, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf// 0"], "t")
+    assert not bad
+    build_lib()
+    objs = sorted(glob.glob(os.path.join(OBJ_DIR, "*.o")))
+    assert objs
+    n_total = 0
+    for o in objs:
+        bad, n, ncos = chk.check_object(o)
+        assert ncos >= 1 and not bad, bad
+        n_total += n
+    assert n_total > 10000  # the chains are there (k_chol2 alone holds ~16 K DPP instructions)
