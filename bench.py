@@ -31,6 +31,7 @@ sys.path.insert(0, _ROOT)
 
 import numpy as np  # noqa: E402
 
+PMC_TRAFFIC_FILE = "r04_b_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/pmc_summary.py)
 F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §5
 WORKLOADS = {
     "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
@@ -62,7 +63,7 @@ def pmc_traffic(kernel_substr, name, world):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this process;
     quoted only for the workload the passes were taken on): 2 x FETCH_SIZE + WRITE_SIZE - the guide's gfx950 correction (wide
     coalesced reads are tallied at half their bytes) applied as the upper bound, WRITE_SIZE as reported."""
-    tp = os.path.join(_ROOT, "profiles", "r03_e_hbm_traffic_pmc.json")
+    tp = os.path.join(_ROOT, "profiles", PMC_TRAFFIC_FILE)
     if not os.path.exists(tp) or name != "config3" or world != 1:
         return None, None
     with open(tp) as fh:
@@ -71,7 +72,7 @@ def pmc_traffic(kernel_substr, name, world):
     if not hit or "FETCH_SIZE_KB_avg_per_launch" not in hit[0]:
         return None, None
     b = (2.0 * hit[0]["FETCH_SIZE_KB_avg_per_launch"] + hit[0].get("WRITE_SIZE_KB_avg_per_launch", 0.0)) * 1024.0
-    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r03_e_hbm_traffic_pmc.json (separate rocprofv3 --pmc passes over the same step)"
+    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/%s (separate rocprofv3 --pmc passes over the same step)" % PMC_TRAFFIC_FILE
 
 
 def make_workload(name, seed=0, feat_seed=None, chi2_mult=1.0):
