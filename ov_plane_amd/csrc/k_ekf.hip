@@ -201,6 +201,22 @@ __global__ void k_scale_rows(double* __restrict__ L, int n, int ld, const double
   const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (k < n) L[(size_t)i * ld + k] *= dvec[i];
 }
+// out[r][k] = V[k][ids ? ids[r] : r]: the (dense) factor M = V^T of P = V^T V, rows back in the state's own order when V was
+// formed in a permuted one (plane loop) - any M with M M^T = P serves the next update's  P+ = M (I + M^T A M)^-1 M^T
+__global__ void k_factor_from_V(const double* __restrict__ V, int ld, const int* __restrict__ ids, int n, double* __restrict__ out,
+                                int ldo) {
+  __shared__ double tile[16][17];
+  const int r0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  // read V[k0 + ty][col(r0 + tx)] (rows of V contiguous in tx when the order is the identity), write out[r0 + ty][k0 + tx]
+  const int r = r0 + tx, k = k0 + ty;
+  double v = 0.0;
+  if (r < n && k < n) v = V[(size_t)k * ld + (ids ? ids[r] : r)];
+  tile[ty][tx] = v;
+  __syncthreads();
+  const int ro = r0 + ty, ko = k0 + tx;
+  if (ro < n && ko < n) out[(size_t)ro * ldo + ko] = tile[tx][ty];
+}
 // ... unless *cancel != 0 (a failed factorization upstream: the destination keeps what it holds, cf. ovp_launch_gemm4c)
 __global__ void k_gather_block_unless(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int m,
                                       double* __restrict__ out, int ldo, const int* __restrict__ cancel) {
@@ -420,6 +436,11 @@ hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols,
 
 hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream) {
   hipLaunchKernelGGL(ovp::k_gather_block, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_factor_from_V(const double* V, int ld, const int* ids, int n, double* out, int ldo, hipStream_t stream) {
+  const int nt = (n + 15) / 16;
+  hipLaunchKernelGGL(ovp::k_factor_from_V, dim3(nt, nt), dim3(256), 0, stream, V, ld, ids, n, out, ldo);
   return hipGetLastError();
 }
 hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream) {

@@ -25,6 +25,7 @@ hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int
 hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
                                           hipStream_t stream);
 hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream);
+hipError_t ovp_launch_factor_from_V(const double* V, int ld, const int* ids, int n, double* out, int ldo, hipStream_t stream);
 hipError_t ovp_launch_scale_rows(double* L, int n, int ld, const double* dvec, hipStream_t stream);
 hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream);
 hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream);
@@ -231,7 +232,12 @@ struct ovp_ctx {
   double* pl_scatter_dst = nullptr;   // full order: where the covariance product of the loop is un-permuted to
   const int* pl_scatter_ids = nullptr;
   double pl_t_entry = 0.0;
-  bool pl_psd = false;          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
+  bool pl_psd = false;
+  // A factor of the RESIDENT covariance left behind by the plane loop (P = V^T V, Lkeep = V^T in the state's column order): the point
+  // update that follows needs some M with M M^T = P, not the Cholesky factor - chol(P) (the longer branch of the fused feature
+  // launch at N = 240) is skipped.  Cleared by everything that writes P.
+  double* Lkeep = nullptr;
+  bool have_factor = false, use_kept_factor = false;          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
   hipEvent_t ev_subtab = nullptr;     // behind the upload of pl_sub_htab (the pinned block is rewritten by the next call)
   void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
   size_t pl_stage_cap = 0;
@@ -451,7 +457,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
                  c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
                  c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage, c->pl_xbuf, c->pl_xy, c->pl_xflag, c->pl_Asum,
-                 c->pl_U, c->pl_sub_tab};
+                 c->pl_U, c->pl_sub_tab, c->Lkeep};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -511,6 +517,7 @@ extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);
 // (upload / download / marginal / propagate go through the pinned arena: one contiguous copy each way.  A 2-D copy from
 //  pageable memory cost 90 us of host time at N = 130, a pageable copy per small array 8 us each.)
 extern "C" int ovp_cov_upload(ovp_ctx* c, const double* P_host, int n, int ld) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !P_host || n < 1 || ld < n) return OVP_E_ARG;
   if (n > c->n_max) return OVP_E_CAPACITY;
   void *ah = nullptr, *ad = nullptr;
@@ -530,6 +537,7 @@ extern "C" int ovp_cov_upload(ovp_ctx* c, const double* P_host, int n, int ld) {
   return 0;
 }
 extern "C" int ovp_cov_set_device(ovp_ctx* c, const double* P_dev, int n, int ld) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !P_dev || n < 1 || ld < n) return OVP_E_ARG;
   if (n > c->n_max) return OVP_E_CAPACITY;
   HIPCHK(hipMemcpy2DAsync(c->P, sizeof(double) * c->ld, P_dev, sizeof(double) * ld, sizeof(double) * n, n,
@@ -940,12 +948,17 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
   }
   const double* b = c->Ab + (size_t)n * ld;
   if (n <= OVP_TILECHOL_NMAX) {
-    // W1 = A L ;  T = I + L^T W1 ;  Lt = chol(T) (+ inverses of its diagonal blocks)
-    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, c->stream));
-    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->L, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
+    // W1 = A L ;  T = I + L^T W1 ;  Lt = chol(T) (+ inverses of its diagonal blocks).  L: chol(P), or the dense factor the plane
+    // loop left (any M with M M^T = P gives P+ = M (I + M^T A M)^-1 M^T)
+    const bool kept = c->use_kept_factor;
+    const double* Lf = kept ? c->Lkeep : c->L;
+    c->use_kept_factor = false;
+    c->have_factor = false;  // P is about to change
+    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Lf, ld, c->W1, ld, 0, 0, c->stream));
+    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Lf, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
     HIPCHK(chol_of_T(c, c->T, n, ld, 0, nullptr, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
-    HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, c->stream));
+    HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Lf, c->Y, n, ld, kept ? 1 : 0, c->stream));
     // (skipped on the device when a factorization failed: the resident covariance then stays what it was, OVP_E_NOTSPD)
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, c->stream));
     if (publish) {
@@ -1121,8 +1134,13 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // K1.  Events on the main stream are kept to a minimum (each one costs microseconds between dependent kernels): with
   // the kernel timer on, ev_k0 / ev_k1 bracket K1 and ev_k1 doubles as the fork point; otherwise one untimed fork event.
   if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
+  c->use_kept_factor = false;
   if (overlap_mode == 3) {
     ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags};
+    if (c->have_factor && c->Lkeep) {  // the plane loop left M with M M^T = P: no chol(P) (cj.n = 0), the update runs on M
+      cj.n = 0;
+      c->use_kept_factor = true;
+    }
     HIPCHK(ovp_launch_feat_chol(&fp, &cj, c->stream));
   } else {
     HIPCHK(ovp_launch_feat_gate(&fp, c->stream));
@@ -1778,6 +1796,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;  // needs ovp_batch_upload (host copy of the layout)
   const double t_entry = c->pl_sub_active ? c->pl_t_entry : host_now_ms();
+  c->have_factor = false;
   const int n = c->n, ld = c->ld, F = c->n_feats, NP = pb->n_planes, M = c->max_meas;
   // skip_plane_used is an option of the POINT update that follows; the plane loop itself produces the mask
   ovp_update_opts o_local = *o;
@@ -2195,6 +2214,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     }
   }
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
+  bool factor_enqueued = false;
   if (NJ > 0) {
     HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
     HIPCHK(chol_of_T(c, c->T, n, ld, 1, c->pl_cur + 1, s));
@@ -2202,6 +2222,13 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
     if (c->pl_scatter_dst)  // back into the state's own column order (unless a factorization failed: the resident P stays)
       HIPCHK(ovp_launch_gather_block_unless(c->P, ld, c->pl_scatter_ids, n, c->pl_scatter_dst, ld, c->flags, s));
+    // the factor of the covariance just formed, for the point update behind the loop (P = V^T V: M = V^T, rows in state order)
+    static const bool keep_factor = getenv("OVP_NO_KEPT_FACTOR") == nullptr;
+    if (keep_factor && !c->pl_sub_rest && n <= OVP_TILECHOL_NMAX) {
+      if (!c->Lkeep) HIPCHK(dalloc(&c->Lkeep, (size_t)c->n_max * ld));
+      HIPCHK(ovp_launch_factor_from_V(c->Y, ld, c->pl_scatter_dst ? c->pl_scatter_ids : nullptr, n, c->Lkeep, ld, s));
+      factor_enqueued = true;
+    }
   }
   if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev_loop[1], s));
   // ---- results: one pinned block, one synchronisation ----
@@ -2261,6 +2288,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   }
   if (bad & 2) return OVP_E_TIMEOUT;
   if (bad) return OVP_E_NOTSPD;
+  c->have_factor = factor_enqueued;
   return 0;
 }
 
@@ -2268,6 +2296,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
 extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double const_init_multi,
                               double const_init_chi2, double* dx_planes, int dx_stride, uint8_t* plane_ok, double* plane_chi2,
                               int* plane_dof, int* new_ids, double* cp_new, uint8_t* feat_used) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;
@@ -2359,6 +2388,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
 // ---- StateHelper::EKFUpdate with a dense host H ------------------------------------------------
 extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int cols, int ld, const int* col_ids,
                               const double* res_host, double* dx_host, ovp_update_info* info) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !H_host || !col_ids || !res_host || rows < 1 || cols < 1 || ld < rows) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (cols > c->n) return OVP_E_ARG;
@@ -2463,6 +2493,7 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
 // ---- propagation / clone / marginalise ---------------------------------------------------------
 extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const int* old_ids, const int* old_sizes,
                                  int n_old, const double* Phi_host, const double* Q_host, int* neg_diag) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !old_ids || !old_sizes || !Phi_host || !Q_host || phi_size < 1 || n_old < 1) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   const int n = c->n;
@@ -2502,6 +2533,7 @@ extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const 
 }
 
 extern "C" int ovp_cov_clone(ovp_ctx* c, int src_id, int size) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || size < 1 || src_id < 0) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (src_id + size > c->n) return OVP_E_ARG;
@@ -2512,6 +2544,7 @@ extern "C" int ovp_cov_clone(ovp_ctx* c, int src_id, int size) {
 }
 
 extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || size < 1 || id < 0) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (id + size > c->n) return OVP_E_ARG;
@@ -2525,6 +2558,7 @@ extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
 
 extern "C" int ovp_cov_initialize_invertible(ovp_ctx* c, const double* H_R, int k, int cols, int ld, const int* col_ids,
                                              const double* H_Linv, const double* R) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !H_R || !col_ids || !H_Linv || !R || k < 1 || k > 6 || cols < 1 || ld < k) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   const int n = c->n;
@@ -2557,6 +2591,7 @@ extern "C" int ovp_cov_initialize_invertible(ovp_ctx* c, const double* H_R, int 
 }
 
 extern "C" int ovp_cov_augment_dt(ovp_ctx* c, int pose_id, int dt_id, const double dnc_dt[6]) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !dnc_dt) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (pose_id < 0 || pose_id + 6 > c->n || dt_id < 0 || dt_id >= c->n) return OVP_E_ARG;
@@ -2569,6 +2604,7 @@ extern "C" int ovp_cov_augment_dt(ovp_ctx* c, int pose_id, int dt_id, const doub
 extern "C" int ovp_cov_initialize(ovp_ctx* c, const double* Hx_init, const double* H_up, int k, int rup, int cols, const int* col_ids,
                                   const double* H_Linv, const double* R_init, const double* res_up, double r_iso,
                                   double chi2_threshold, int do_update, int* accepted, double* chi2, double* dx_host) {
+  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !Hx_init || !col_ids || !H_Linv || !R_init || k < 1 || k > 6 || cols < 1 || rup < 0) return OVP_E_ARG;
   if (rup > 0 && (!H_up || !res_up || !(r_iso > 0.0))) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
