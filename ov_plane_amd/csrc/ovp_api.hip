@@ -1843,6 +1843,45 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   fp.skip = nullptr;
   fp.range_lo = 0;  // the plane loop always walks the whole batch
   fp.range_hi = 0x7fffffff;
+  // ---- what does not depend on the grouping goes to the device first: the fills and chol(P) (~70 us) run while the host sorts the
+  // features by plane and builds the per-plane tables (~40 us at config 3, during which the stream used to be idle) ----
+  const size_t res_bytes = sizeof(double) * (4 * (size_t)NP + (size_t)n * NP) + (size_t)F + 64;
+  rc = plane_buffers(c, NP);  // shared with the first generation: pl_res, pl_dx, pl_cst, pl_An, ...
+  if (rc) return rc;
+  rc = plane2_buffers(c, NP, 0, res_bytes);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const double t_first = host_now_ms();
+  const size_t tstride = (size_t)(c->n_max + 1) * ld;
+  {
+    // results, per-plane corrections, used-feature mask (rounded up to whole words: the buffer is f_max + 64 bytes), flags,
+    // [0] current T buffer + [1..2] factor bookkeeping (PlaneSolve::cond), half 0 of T (sum of the accepted L0^T A L0): one launch
+    // both halves of T: a plane writes its candidate only inside its leading block, the rest of either half must read as zero;
+    // the packed factor / inverted diagonal blocks behind the loop start out as the identity for the same reason
+    const int ntn = (n + 15) / 16;
+    void* zp[8] = {c->pl_res, c->pl_dx, c->pl_used, c->flags, c->pl_cur, c->pl_Tbuf, c->Ltp, c->Dinv};
+    const size_t zb[8] = {sizeof(double) * 4 * NP, sizeof(double) * (size_t)n * NP, ((size_t)F + 3) & ~(size_t)3, sizeof(int) * 4,
+                          3 * sizeof(int), sizeof(double) * (tstride + (size_t)n * ld),
+                          c->pl_sub_active ? sizeof(double) * 256 * (size_t)(ntn * (ntn + 1) / 2) : 0,
+                          c->pl_sub_active ? sizeof(double) * 256 * (size_t)ntn : 0};
+    const int zpat[8] = {0, 0, 0, 0, 0, 0, 2, 1};
+    HIPCHK(ovp_launch_fill_regions(zp, zb, zpat, 8, ntn, s));
+  }
+  if (c->pl_ktimer) {  // [0 | 1] = the whole loop on the device clock (first launch .. covariance product), then a pair per plane
+    while (c->pl_ev_loop.size() < 2) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->pl_ev_loop.push_back(e);
+    }
+    if (!c->pl_sub_active) HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));  // (plane_update_ordered: in front of its permutation)
+  }
+  rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
+  if (rc) return rc;
+  // a refusal from here on: chol(P) has run - a flag it may have raised (singular prior) must not outlive the call
+  auto bail = [&](int code) {
+    (void)hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s);
+    return code;
+  };
   // ---- host-side grouping (update/UpdaterMSCKF.cpp:204-229) ----
   std::vector<PlaneJobH> jobs;
   std::vector<int> featlist;
@@ -1877,7 +1916,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       const int f = bucket[bi];
       const int m = c->h_n_meas[f];
       if (m < 2) continue;
-      if (m > 31) return OVP_E_CAPACITY;  // 2m+1 rows must fit one wavefront
+      if (m > 31) return bail(OVP_E_CAPACITY);  // 2m+1 rows must fit one wavefront
       featlist.push_back(f);
       j.nf++;
       j.rows_total += 3 * m - 3;
@@ -1888,7 +1927,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (!j.in_state)
       for (int q = 0; q < n_slam; ++q)
         if (pb->slam_plane[q] == pl + 1) ++ns_pl;
-    if (ns_pl > PA_MAXQ) return OVP_E_CAPACITY;
+    if (ns_pl > PA_MAXQ) return bail(OVP_E_CAPACITY);
     j.ns_pl = ns_pl;
     if (j.nf == 0 || (!j.in_state && j.nf + ns_pl < 4)) {  // update/UpdaterMSCKF.cpp:316-317,384-396
       featlist.resize(j.start);
@@ -1942,10 +1981,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
   const size_t n_dbl = 6 * (size_t)NP + 6 * (size_t)n_slam;
   const size_t stage_bytes = int_bytes + n_dbl * sizeof(double);
-  const size_t res_bytes = sizeof(double) * (4 * (size_t)NP + (size_t)n * NP) + (size_t)F + 64;
-  rc = plane_buffers(c, NP);  // shared with the first generation: pl_res, pl_dx, pl_cst, pl_An, ...
-  if (rc) return rc;
-  rc = plane2_buffers(c, NP, stage_bytes, res_bytes);
+  rc = plane2_buffers(c, NP, stage_bytes, res_bytes);  // (grows the staging block when this frame needs more)
   if (rc) return rc;
   int* hi = (int*)c->pl_hstage;
   double* hd = (double*)((char*)c->pl_hstage + int_bytes);
@@ -1973,8 +2009,6 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     memcpy(hd + 6 * NP, pb->slam_p, sizeof(double) * 3 * n_slam);
     memcpy(hd + 6 * NP + 3 * n_slam, pb->slam_p_fej, sizeof(double) * 3 * n_slam);
   }
-  hipStream_t s = c->stream;
-  const double t_first = host_now_ms();
   HIPCHK(hipMemcpyAsync(c->pl_dstage, c->pl_hstage, stage_bytes, hipMemcpyHostToDevice, s));
   const int* d_feat = di + o_feat;
   const int* d_sid = di + o_sid;
@@ -1985,33 +2019,6 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   double* d_cpfej = dd + 3 * NP;
   double* d_slam_p = dd + 6 * NP;
   double* d_slam_pfej = dd + 6 * NP + 3 * n_slam;
-  const size_t tstride = (size_t)(c->n_max + 1) * ld;
-  {
-    // results, per-plane corrections, used-feature mask (rounded up to whole words: the buffer is f_max + 64 bytes), flags,
-    // [0] current T buffer + [1..2] factor bookkeeping (PlaneSolve::cond), half 0 of T (sum of the accepted L0^T A L0): one launch
-    // both halves of T: a plane writes its candidate only inside its leading block, the rest of either half must read as zero;
-    // the packed factor / inverted diagonal blocks behind the loop start out as the identity for the same reason
-    const int ntn = (n + 15) / 16;
-    void* zp[8] = {c->pl_res, c->pl_dx, c->pl_used, c->flags, c->pl_cur, c->pl_Tbuf, c->Ltp, c->Dinv};
-    const size_t zb[8] = {sizeof(double) * 4 * NP, sizeof(double) * (size_t)n * NP, ((size_t)F + 3) & ~(size_t)3, sizeof(int) * 4,
-                          NJ > 0 ? 3 * sizeof(int) : 0, NJ > 0 ? sizeof(double) * (tstride + (size_t)n * ld) : 0,
-                          (NJ > 0 && c->pl_sub_active) ? sizeof(double) * 256 * (size_t)(ntn * (ntn + 1) / 2) : 0,
-                          (NJ > 0 && c->pl_sub_active) ? sizeof(double) * 256 * (size_t)ntn : 0};
-    const int zpat[8] = {0, 0, 0, 0, 0, 0, 2, 1};
-    HIPCHK(ovp_launch_fill_regions(zp, zb, zpat, 8, ntn, s));
-  }
-  if (c->pl_ktimer) {  // [0 | 1] = the whole loop on the device clock (first launch .. covariance product), then a pair per plane
-    while (c->pl_ev_loop.size() < 2) {
-      hipEvent_t e;
-      HIPCHK(hipEventCreate(&e));
-      c->pl_ev_loop.push_back(e);
-    }
-    if (!c->pl_sub_active) HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));  // (plane_update_ordered: in front of its permutation)
-  }
-  if (NJ > 0) {
-    rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
-    if (rc) return rc;
-  }
   const double white_c = 1.0 / o->sigma_constraint;
   for (int jn = 0; jn < NJ; ++jn) {
     const PlaneJobH& j = jobs[jn];
