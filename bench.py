@@ -565,17 +565,24 @@ def main():
                                              "the restore of the prior and the host turn-around")
         # ---- roofline of the dominant kernel ----
         if run.has_planes and c2_n:
-            n_inv_avg = 6 * C + 14 + 1.5  # involved columns of a plane: clones + calibration (+3 when the plane is in the state)
-            fl = chol2_flops(sc.N, int(n_inv_avg))
+            # per plane: the update part factorizes the leading block of the loop's column order (clones + calibration + the own
+            # columns of the planes processed so far), the range part the plane's involved columns
+            base = 6 * C + 14
+            in_state = (np.asarray(sc.plane_state_id) >= 0).astype(int)
+            nl = base + 3 * np.cumsum(in_state)
+            n_inv = base + 3 * in_state
+            fl = float(np.mean([chol2_flops(int(a), int(b)) for a, b in zip(nl, n_inv)]))
+            n_inv_avg, nl_avg = float(n_inv.mean()), float(nl.mean())
             ks = c2_ms * 1e-3
             line["roofline"] = {
                 "bound": "mfma",
-                "kernel": "k_chol2 (one launch per plane: bordered tile Cholesky of T = I + L0^T A L0 and of the normalised Gram "
-                          "side by side on two CUs, gate, back substitution, dx, commit) - a latency-bound serial chain, the "
-                          "plane loop is %d of these in sequence" % int(sc.cp.shape[0]),
+                "kernel": "k_chol2 (one launch per plane: bordered tile Cholesky of the leading block of T = I + L0^T A L0 and of the "
+                          "normalised Gram side by side on two CUs, gate, back substitution, dx, commit) - a latency-bound serial "
+                          "chain, the plane loop is %d of these in sequence" % int(sc.cp.shape[0]),
                 "achieved": fl / ks / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / ks / 1e12 / F64_PEAK_TFLOPS,
                 "traffic": pmc_traffic("k_chol2", name, world)[0], "traffic_note": pmc_traffic("k_chol2", name, world)[1],
-                "algorithmic_bytes_per_launch": 8.0 * ((sc.N + 1) ** 2 / 2 + (n_inv_avg + 1) ** 2 / 2 + sc.N ** 2 / 2),
+                "algorithmic_bytes_per_launch": 8.0 * ((nl_avg + 1) ** 2 / 2 + (n_inv_avg + 1) ** 2 / 2 + sc.N * nl_avg - nl_avg ** 2 / 2),
+                "leading_block_avg": nl_avg,
                 "avg_launch_ms": c2_ms, "launches_timed": c2_n, "algorithmic_flops_per_launch": fl,
                 "share_of_step": c2_ms * int(sc.cp.shape[0]) / ms_per_step,
                 "cus_occupied": 2, "frac_of_occupied_cus": fl / ks / 1e12 / (F64_PEAK_TFLOPS * 2.0 / 256.0),

@@ -296,6 +296,23 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gra
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;  // 0..n  (n = b row)
   if (c >= n) return;
+  // The kernel is a chain of memory round trips, so everything whose address is known is requested before anything is consumed
+  // (it used to be ~10 dependent rounds - colmap, the clone sums eight at a time, the split sums eight at a time - at ~1 us each):
+  // first the dense partials of (r, c) (addresses from r, c alone), then - behind the column map - the structured entries.
+  // Sums are formed in the same order as before (split by split, slot by slot): bit-identical results.
+  constexpr int NB = 32;
+  double dv[NB];
+  const int I = max(r, c), J = min(r, c);
+  const double* pp;
+  const size_t st = (size_t)ntile * 256;
+  {
+    const int ti = I >> 4, tj = J >> 4;
+    const int tile = ti * (ti + 1) / 2 + tj;
+    const int e = (I & 15) * 16 + (J & 15);
+    pp = part + (size_t)tile * 256 + e;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) dv[u] = pp[(size_t)(u < n_split ? u : n_split - 1) * st];
+  }
   const ColMap mc = colmap[c];
   ColMap mr;
   if (r < n) {
@@ -328,32 +345,26 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gra
   }
   if (p >= 0) {
     const int gi = gram_index(p, q);
-    if (allslots) {
-#pragma unroll 8
-      for (int sl = 0; sl < n_clones * n_chunks; ++sl) s += gramS[(size_t)sl * OVP_GRAM_ELEMS + gi];
-    } else if (slot >= 0) {
-      for (int ch = 0; ch < n_chunks; ++ch) s += gramS[((size_t)slot * n_chunks + ch) * OVP_GRAM_ELEMS + gi];
+    // one list for both cases: entries first .. first + count - 1 of gramS (all slots and chunks, or the chunks of one slot)
+    const int first = allslots ? 0 : slot * n_chunks;
+    const int count = allslots ? n_clones * n_chunks : (slot >= 0 ? n_chunks : 0);
+    if (count > 0) {
+      double gv[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) gv[u] = gramS[(size_t)(first + (u < count ? u : count - 1)) * OVP_GRAM_ELEMS + gi];
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        if (u < count) s += gv[u];
+      for (int sl = NB; sl < count; ++sl) s += gramS[(size_t)(first + sl) * OVP_GRAM_ELEMS + gi];
     }
   }
-  // dense downdate: element (I,J) = (max,min) of (r,c) in the lower tile triangle
+  // dense downdate: element (I,J) = (max,min) of (r,c) in the lower tile triangle, fixed order
   {
-    const int I = max(r, c), J = min(r, c);
-    const int ti = I >> 4, tj = J >> 4;
-    const int tile = ti * (ti + 1) / 2 + tj;
-    const int e = (I & 15) * 16 + (J & 15);
     double d = 0.0;
-    // fixed order, eight loads in flight
-    const double* pp = part + (size_t)tile * 256 + e;
-    const size_t st = (size_t)ntile * 256;
-    int sp = 0;
-    for (; sp + 8 <= n_split; sp += 8) {
-      double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(sp + u) * st];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) d += v[u];
-    }
-    for (; sp < n_split; ++sp) d += pp[(size_t)sp * st];
+    for (int u = 0; u < NB; ++u)
+      if (u < n_split) d += dv[u];
+    for (int sp = NB; sp < n_split; ++sp) d += pp[(size_t)sp * st];
     s -= d;
   }
   Ab[(size_t)r * lda + c] = s;
