@@ -311,7 +311,9 @@ int ovp_plane_optimize(ovp_ctx *ctx, const ovp_planeopt_batch *batch, double *cp
  * "gramS","syrk"}; returns the byte count copied (or <0). */
 long ovp_debug_read(ovp_ctx *ctx, const char *name, void *host, long max_bytes);
 /* like ovp_kernel_timer, for the dominant kernel of the plane loop (k_chol2: both factorizations, gate, solve and commit of one
- * plane): HIP events around every launch of ovp_msckf_plane_update while enabled */
+ * plane): enable = 1: HIP events around every k_chol2 launch of ovp_msckf_plane_update AND around the whole loop; enable = 2: around
+ * the whole loop only (first launch .. covariance product; read through ovp_host_timing [7]) - events between dependent launches
+ * cost microseconds each, so the loop's own time is taken without the per-launch ones */
 int ovp_plane_kernel_timer(ovp_ctx *ctx, int enable, int reset, float *avg_ms, int *n_launches);
 /* host clock of the two update entry points, accumulated since the last reset (ms): ovp_msckf_plane_update [0] entry -> first
  * launch (grouping of the features by plane, staging tables), [1] entry -> last launch enqueued, [2] wait for the device, [3] calls;
