@@ -986,9 +986,9 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
         auto it = feat2plane.find(feature_vec[f]->featid);
         if (it == feat2plane.end()) continue;
         if (fitted_planes.count(it->second) && !plane_feat_kept.count(feature_vec[f]->featid)) continue;  // not an inlier of the fit
-        // the plane kernels take a feature's 2 m + 1 rows in one wavefront: a track with more than 31 observations keeps its
-        // bearing measurements but not the plane constraint (it goes through the point loop below)
-        if (feature_vec[f]->timestamps.size() > 31) continue;
+        // the plane kernels take a feature's 2 m bearing rows in one wavefront (the constraint row is wave-uniform): a track with
+        // more than 32 observations keeps its bearing measurements but not the plane constraint (it goes through the point loop)
+        if (feature_vec[f]->timestamps.size() > 32) continue;
         auto pos = std::find(used_planes.begin(), used_planes.end(), it->second);
         if (pos != used_planes.end()) pof[f] = 1 + (int)(pos - used_planes.begin());
       }

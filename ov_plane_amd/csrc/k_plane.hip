@@ -24,7 +24,7 @@ namespace ovp {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// K1p: one wave per on-plane feature. lanes 0..2m-1 bearing rows, lane 2m the merged constraint row.
+// K1p: one wave per on-plane feature. lanes 0..2m-1 bearing rows; the merged constraint row is wave-uniform (an extra term of the sums).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const PlaneParams pp) {
   const int fl = blockIdx.x;                 // local feature index within this plane
@@ -42,18 +42,21 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
   double jrow[6], crow[14], hf[3], res;
   build_bearing_row(p, f, a, r, valid, ci, jrow, crow, hf, res);
 
-  // constraint row (update/UpdaterHelper.cpp:450-497), merged: m identical rows == one row scaled by sqrt(m)
-  double hcp[3] = {0.0, 0.0, 0.0};
-  if (lane == n) {
+  // constraint row (update/UpdaterHelper.cpp:450-497), merged: m identical rows == one row scaled by sqrt(m).  Its entries
+  // depend on the feature and the plane only, not on an observation: every lane computes them (wave-uniform) and the row
+  // takes part in the sums below as an extra term instead of occupying lane 2m - a track of 32 observations (64 bearing rows)
+  // keeps its constraint (round 4; until then 2m + 1 rows had to fit the wavefront: OVP_E_CAPACITY above 31 observations,
+  // update/UpdaterMSCKF.cpp:413-649 has no such limit)
+  double hcp[3], hfc[3], resc;
+  {
     const double* cp = pp.cp + 3 * pp.plane;
     const double* cpf = pp.in_state ? (pp.cp_fej + 3 * pp.plane) : cp;  // UpdaterMSCKF.cpp:467-475
     const double pf0 = p.p_FinG[3 * f], pf1 = p.p_FinG[3 * f + 1], pf2 = p.p_FinG[3 * f + 2];
     const double sm = sqrt((double)m) * pp.white_c;
-    // (one division per norm: the whole wave waits for this lane's chain of sqrt / div sequences)
     double d = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
     double id = 1.0 / d;
     double n0 = cp[0] * id, n1 = cp[1] * id, n2 = cp[2] * id;
-    res = sm * (0.0 - (n0 * pf0 + n1 * pf1 + n2 * pf2 - d));
+    resc = sm * (0.0 - (n0 * pf0 + n1 * pf1 + n2 * pf2 - d));
     if (p.do_fej) {
       d = sqrt(cpf[0] * cpf[0] + cpf[1] * cpf[1] + cpf[2] * cpf[2]);
       id = 1.0 / d;
@@ -66,13 +69,14 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     hcp[0] = s * (pf0 - ndp * n0 - d * n0);
     hcp[1] = s * (pf1 - ndp * n1 - d * n1);
     hcp[2] = s * (pf2 - ndp * n2 - d * n2);
-    hf[0] = sm * n0;
-    hf[1] = sm * n1;
-    hf[2] = sm * n2;
+    hfc[0] = sm * n0;
+    hfc[1] = sm * n1;
+    hfc[2] = sm * n2;
   }
 
   // Q1 by CholeskyQR2 on H_f (2m+1 rows)
   double q[3] = {hf[0], hf[1], hf[2]};
+  double qc[3] = {hfc[0], hfc[1], hfc[2]};  // the constraint row's part of Q1 (wave-uniform)
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     double v[8];
@@ -85,9 +89,9 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     v[6] = 0.0;
     v[7] = 0.0;
     const double rsum = wave_transpose_reduce<8>(v);
-    const double g00 = readlane_f64(rsum, reduce_owner_lane<8>(0)), g01 = readlane_f64(rsum, reduce_owner_lane<8>(1));
-    const double g02 = readlane_f64(rsum, reduce_owner_lane<8>(2)), g11 = readlane_f64(rsum, reduce_owner_lane<8>(3));
-    const double g12 = readlane_f64(rsum, reduce_owner_lane<8>(4)), g22 = readlane_f64(rsum, reduce_owner_lane<8>(5));
+    const double g00 = readlane_f64(rsum, reduce_owner_lane<8>(0)) + qc[0] * qc[0], g01 = readlane_f64(rsum, reduce_owner_lane<8>(1)) + qc[0] * qc[1];
+    const double g02 = readlane_f64(rsum, reduce_owner_lane<8>(2)) + qc[0] * qc[2], g11 = readlane_f64(rsum, reduce_owner_lane<8>(3)) + qc[1] * qc[1];
+    const double g12 = readlane_f64(rsum, reduce_owner_lane<8>(4)) + qc[1] * qc[2], g22 = readlane_f64(rsum, reduce_owner_lane<8>(5)) + qc[2] * qc[2];
     // R^T R = G with the reciprocals of the diagonal (v_rsq_f64 + two Newton steps each): a sqrt and five divisions per pass were
     // 3.2 K cycles of dependent div / sqrt sequences.  Q1 is orthonormal to rounding after the second pass either way.
     const double i00 = rsqrt_nr2(g00), r01 = g01 * i00, r02 = g02 * i00;
@@ -99,6 +103,12 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     q[0] = a0;
     q[1] = a1;
     q[2] = a2;
+    const double c0 = qc[0] * i00;
+    const double c1 = (qc[1] - c0 * r01) * i11;
+    const double c2 = (qc[2] - c0 * r02 - c1 * r12) * i22;
+    qc[0] = c0;
+    qc[1] = c1;
+    qc[2] = c2;
   }
 
   const int ldg = p.ldg;
@@ -116,7 +126,9 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     v[45] = res * res;
 #pragma unroll
     for (int k = 46; k < 64; ++k) v[k] = 0.0;
-    const double rsum = wave_transpose_reduce<64>(v);
+    double rsum = wave_transpose_reduce<64>(v);
+    // the constraint row's terms of Q1^T r (lanes 42..44) and of r^T r (lane 45); its calibration / clone entries are zero
+    rsum += lane == 42 ? qc[0] * resc : (lane == 43 ? qc[1] * resc : (lane == 44 ? qc[2] * resc : (lane == 45 ? resc * resc : 0.0)));
     {
       // where this lane's sum goes: lanes 0..41 = (projector row t, calibration entry k), 42..44 = the residual column.  The column
       // is picked by a select chain over the table - a kernel-argument array indexed by a lane-dependent k is a waterfall loop
@@ -131,8 +143,8 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
     gsq = g0 * g0 + g1 * g1 + g2 * g2;
     const double rr = readlane_f64(rsum, 45);
     // constraint-row moments (already scaled by m): hh (6), h*res (3), projected residual energy
-    const double h0 = readlane_f64(hcp[0], n), h1 = readlane_f64(hcp[1], n), h2 = readlane_f64(hcp[2], n);
-    const double rc = readlane_f64(res, n);
+    const double h0 = hcp[0], h1 = hcp[1], h2 = hcp[2];
+    const double rc = resc;
     if (lane == 0) {
       double* o = pp.cst + (size_t)fl * 10;
       o[0] = h0 * h0;
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(64) void k_plane_feat(const FeatParams p, const Pla
       o[9] = rr - gsq;
     }
     // plane columns of G: only the constraint lane has a non-zero H_cp row
-    const double qc0 = readlane_f64(q[0], n), qc1 = readlane_f64(q[1], n), qc2 = readlane_f64(q[2], n);
+    const double qc0 = qc[0], qc1 = qc[1], qc2 = qc[2];
     if (lane < 9) {
       const int t = lane / 3, k = lane - 3 * t;
       const double qt = t == 0 ? qc0 : (t == 1 ? qc1 : qc2);

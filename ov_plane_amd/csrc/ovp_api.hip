@@ -1439,7 +1439,7 @@ static int plane_update_v1(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane
       if (pb->plane_of_feat[f] != pl + 1) continue;
       const int m = c->h_n_meas[f];
       if (m < 2) continue;
-      if (m > 31) return OVP_E_CAPACITY;  // 2m+1 rows must fit one wavefront
+      if (m > OVP_MAX_MEAS_DEV) return OVP_E_CAPACITY;  // 2m bearing rows = one wavefront
       featlist.push_back(f);
       j.nf++;
       j.rows_total += 3 * m - 3;
@@ -1916,7 +1916,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       const int f = bucket[bi];
       const int m = c->h_n_meas[f];
       if (m < 2) continue;
-      if (m > 31) return bail(OVP_E_CAPACITY);  // 2m+1 rows must fit one wavefront
+      if (m > OVP_MAX_MEAS_DEV) return bail(OVP_E_CAPACITY);  // 2m bearing rows = one wavefront (the constraint row is wave-uniform)
       featlist.push_back(f);
       j.nf++;
       j.rows_total += 3 * m - 3;
@@ -2341,7 +2341,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
       if (pb->plane_of_feat[f] != pl + 1) continue;
       const int m = c->h_n_meas[f];
       if (m < 2) continue;
-      if (m > 31) return OVP_E_CAPACITY;
+      if (m > OVP_MAX_MEAS_DEV) return OVP_E_CAPACITY;
       featlist.push_back(f);
       rows_total += 3 * m - 3;
       rows_live += 2 * m - 2;

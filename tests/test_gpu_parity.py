@@ -231,6 +231,30 @@ def test_config4_whole_step_matches_oracle(hiplib, oracle):
     assert rep["points_gated"] >= 5500
 
 
+@pytest.mark.parametrize("C", [31, 32])
+def test_plane_constraint_of_a_full_length_track(hiplib, oracle, C):
+    """On-plane features observed from 31 / 32 clones (62 / 64 bearing rows: the wavefront is full, the merged point-on-plane row
+    update/UpdaterHelper.cpp:503-511 is carried as a wave-uniform term of the sums, not in a lane of its own): plane loop
+    against the oracle.  update/UpdaterMSCKF.cpp:413-649 has no limit on the track length; until round 4 32 observations were
+    OVP_E_CAPACITY."""
+    sc = make_scene(C=C, F=120, seed=50 + C, n_planes=3, feats_per_plane=20, planes_in_state_frac=0.67, chi2_mult=99999.0)
+    assert int(sc.n_meas.max()) == C
+    ref = oracle.msckf_plane_update(sc)
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    assert out["rc"] == 0 and (out["ok"] == ref["plane_ok"]).all() and out["ok"].all()
+    assert (out["used"] == ref["used"]).all() and (out["dof"] == ref["plane_rows"]).all()
+    assert np.abs(out["chi2"] - ref["plane_chi2"]).max() < 18.2
+    cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    ctx.close()
+
+
 def test_config3_plane_loop_at_full_size_matches_oracle(hiplib, oracle):
     """BASELINE config[2]: 30 clones, 2000 features of which 1000 lie on 20 planes (10 of them in the state, N = 240).  The plane
     loop is cheap enough for the oracle at full size (about a second); the point update on the 1000 free points is checked
