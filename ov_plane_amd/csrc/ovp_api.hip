@@ -1627,7 +1627,7 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
   if (o->do_calib_camera_pose) place(c->calib_id, 6);
   if (o->do_calib_camera_intrinsics) place(c->intr_id, 8);
   for (int q = 0; q < n_slam; ++q)
-    if (pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP) return OVP_E_ARG;
+    if (pb->slam_plane[q] < 1 || pb->slam_plane[q] > NP || pb->slam_state_id[q] < 0 || pb->slam_state_id[q] + 3 > n) return OVP_E_ARG;
   c->pl_nl.assign((size_t)(NP > 0 ? NP : 1), 0);
   for (int k = 0; k < NP; ++k) {
     if (pb->plane_state_id[k] >= 0) place(pb->plane_state_id[k], 3);
