@@ -289,46 +289,45 @@ __device__ __forceinline__ int gram_index(int p, int q) {  // packed upper trian
   return p * OVP_REC - (p * (p - 1)) / 2 + (q - p);
 }
 
+// One block per 16 x 16 tile of the LOWER tile triangle of the (n + 1) x (n + 1) pair (row n = b): the partials of a tile are
+// 2 KB contiguous per split (until round 4 a block owned a ROW of Ab and looked every element up at (max, min): the upper half
+// of a row then reads one double per 128-byte line - 22.7 MB fetched for 0.45 MB of output, `profiles/r04_c_hbm_traffic_pmc.json`),
+// the mirror image of an off-diagonal tile goes out through an LDS transpose.  Same sums in the same order as before.
 __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gramS, int n_clones, int n_chunks,
                                                    const double* __restrict__ part, int n_split, int ntile,
                                                    const ColMap* __restrict__ colmap, int n, double* __restrict__ Ab,
                                                    int lda) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;  // 0..n  (n = b row)
-  if (c >= n) return;
-  // The kernel is a chain of memory round trips, so everything whose address is known is requested before anything is consumed
-  // (it used to be ~10 dependent rounds - colmap, the clone sums eight at a time, the split sums eight at a time - at ~1 us each):
-  // first the dense partials of (r, c) (addresses from r, c alone), then - behind the column map - the structured entries.
-  // Sums are formed in the same order as before (split by split, slot by slot): bit-identical results.
+  __shared__ double tr[16][17];
+  // tile (ti, tj), ti >= tj, from the list index ti (ti + 1) / 2 + tj
+  int ti = 0;
+  {
+    const int b = blockIdx.x;
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+  }
+  const int tj = blockIdx.x - ti * (ti + 1) / 2;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int r = 16 * ti + ty, c = 16 * tj + tx;  // element (r, c) of the pair; r <= n is a row of Ab, c < n a column
+  const bool live = r <= n && c < n;
+  // everything whose address is known is requested before anything is consumed; sums in a fixed order (split by split, slot by slot)
   constexpr int NB = 32;
   double dv[NB];
-  const int I = max(r, c), J = min(r, c);
-  const double* pp;
+  const int I = max(r, c), J = min(r, c);  // (a diagonal tile holds its lower half)
   const size_t st = (size_t)ntile * 256;
-  {
-    const int ti = I >> 4, tj = J >> 4;
-    const int tile = ti * (ti + 1) / 2 + tj;
-    const int e = (I & 15) * 16 + (J & 15);
-    pp = part + (size_t)tile * 256 + e;
+  const double* pp = part + (size_t)blockIdx.x * 256 + (I & 15) * 16 + (J & 15);
 #pragma unroll
-    for (int u = 0; u < NB; ++u) dv[u] = pp[(size_t)(u < n_split ? u : n_split - 1) * st];
-  }
-  const ColMap mc = colmap[c];
-  ColMap mr;
-  if (r < n) {
-    mr = colmap[r];
-  } else {
-    mr.kind = 3;  // residual "column" 20
-    mr.idx = 0;
-    mr.off = 0;
-    mr.pad = 0;
-  }
+  for (int u = 0; u < NB; ++u) dv[u] = pp[(size_t)(u < n_split ? u : n_split - 1) * st];
+  ColMap mc, mr;
+  mc.kind = mr.kind = 0;
+  mc.idx = mc.off = mc.pad = mr.idx = mr.off = mr.pad = 0;
+  if (c < n) mc = colmap[c];
+  if (r < n) mr = colmap[r];
+  else if (r == n) mr.kind = 3;  // residual "column" 20
   double s = 0.0;
   // structured part
   int slot = -1, p = -1, q = -1;  // single-slot contribution
   bool allslots = false;
   auto gcol = [](const ColMap& m) { return m.kind == 1 ? m.off : (m.kind == 2 ? 6 + m.idx : 20); };
-  if (mr.kind != 0 && mc.kind != 0) {
+  if (live && mr.kind != 0 && mc.kind != 0) {
     const int gr = gcol(mr), gc = gcol(mc);
     p = min(gr, gc);
     q = max(gr, gc);
@@ -358,7 +357,6 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gra
       for (int sl = NB; sl < count; ++sl) s += gramS[(size_t)(first + sl) * OVP_GRAM_ELEMS + gi];
     }
   }
-  // dense downdate: element (I,J) = (max,min) of (r,c) in the lower tile triangle, fixed order
   {
     double d = 0.0;
 #pragma unroll
@@ -367,7 +365,13 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gra
     for (int sp = NB; sp < n_split; ++sp) d += pp[(size_t)sp * st];
     s -= d;
   }
-  Ab[(size_t)r * lda + c] = s;
+  if (live) Ab[(size_t)r * lda + c] = s;
+  if (ti != tj) {  // the mirror image: element (c, r) = row 16 tj + .., column 16 ti + .. (a column of Ab: < n)
+    tr[ty][tx] = s;
+    __syncthreads();
+    const int rm = 16 * tj + ty, cm = 16 * ti + tx;
+    if (rm < n && cm < n) Ab[(size_t)rm * lda + cm] = tr[tx][ty];
+  }
 }
 
 // scatter a dense (cols x cols) Gram and (cols) vector given per-column state ids into Ab (zero elsewhere)
@@ -458,8 +462,8 @@ hipError_t ovp_launch_assemble(const double* gramS, int n_clones, int n_chunks, 
                                const ovp::ColMap* colmap, int n, double* Ab, int lda, hipStream_t stream) {
   const int nt = (n + 1 + 15) / 16;
   const int ntile = nt * (nt + 1) / 2;
-  hipLaunchKernelGGL(ovp::k_assemble, dim3((n + 255) / 256, n + 1), dim3(256), 0, stream, gramS, n_clones, n_chunks,
-                     part, n_split, ntile, colmap, n, Ab, lda);
+  hipLaunchKernelGGL(ovp::k_assemble, dim3(ntile), dim3(256), 0, stream, gramS, n_clones, n_chunks, part, n_split, ntile, colmap, n,
+                     Ab, lda);
   return hipGetLastError();
 }
 
