@@ -291,7 +291,7 @@ static inline double host_now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-extern "C" const char* ovp_version(void) { return "ovplane_hip 0.2 (gfx950)"; }
+extern "C" const char* ovp_version(void) { return "ovplane_hip 0.4 (gfx950)"; }
 
 extern "C" const char* ovp_error_string(int code) {
   switch (code) {
