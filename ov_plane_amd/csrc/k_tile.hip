@@ -43,14 +43,17 @@ static constexpr int FW_ROWS = 5;  // tile rows per wave: nt <= 20
 
 __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, const double* __restrict__ Dinv,
                                                  const double* __restrict__ Lmat, double* __restrict__ V, int n,
-                                                 int ld, int dense) {
+                                                 int ld, int dense, int n_lead) {
+  // n_lead < n: Lt = blockdiag(Lt_lead, I) - the packed factor and the inverted diagonal blocks belong to the leading n_lead
+  // columns (laid out for them), the rows behind are copied
   __shared__ __attribute__((aligned(16))) double vt[2][TSZ];
   const int nt = (n + 15) >> 4;
+  const int ntl = (n_lead > 0 && n_lead < n) ? ((n_lead + 15) >> 4) : nt;
   const int cblk = blockIdx.x;  // column tile of V
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
-  auto tile_index = [&](int i, int k) { return k * nt - (k * (k - 1)) / 2 + (i - k); };
+  auto tile_index = [&](int i, int k) { return k * ntl - (k * (k - 1)) / 2 + (i - k); };
 
   // accumulators = right-hand side tiles: element [row][col] of tile i is M[16 i + row][16 cblk + col];
   // for M = L^T (dense == 0) that is L[16 cblk + col][16 i + row], zero for i > cblk
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
     sfor<FW_ROWS>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       const int i = wave + 4 * r;
-      if (i < nt && i > k && k < nt) {
+      if (i < ntl && i > k && k < ntl) {
         const double* tp = Ltp + (size_t)tile_index(i, k) * 256;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[r][q] = tp[q * 64 + lane];
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
     double* vk = vt[k & 1];
     // diagonal solve by the owner of row k
     if ((k & 3) == wave) {
-      const double* di = Dinv + (size_t)k * 256;
+      const double* di = Dinv + (size_t)(k < ntl ? k : 0) * 256;
       double dq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) dq[q] = di[lc * 16 + lr + 4 * q];
@@ -97,8 +100,12 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
       sfor<FW_ROWS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if (wave + 4 * r == k) {
+          if (k < ntl) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) vi = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[q], acc[r][q], vi, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) vi = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[q], acc[r][q], vi, 0, 0, 0);
+          } else {
+            vi = acc[r];  // behind the leading block Lt is the identity
+          }
         }
       });
 #pragma unroll
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
     sfor<FW_ROWS>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       const int i = wave + 4 * r;
-      if (i < nt && i > k) {
+      if (i < ntl && i > k && k < ntl) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][q], b[q], acc[r], 0, 0, 0);
       }
@@ -251,12 +258,16 @@ hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, 
   return hipGetLastError();
 }
 
-hipError_t ovp_launch_fwdsub(const double* Ltp, const double* Dinv, const double* Lmat, double* V, int n, int ld,
-                             int dense, hipStream_t stream) {
+hipError_t ovp_launch_fwdsub_lead(const double* Ltp, const double* Dinv, const double* Lmat, double* V, int n, int ld,
+                                  int dense, int n_lead, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   if (nt > 4 * ovp::FW_ROWS) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), 0, stream, Ltp, Dinv, Lmat, V, n, ld, dense);
+  hipLaunchKernelGGL(ovp::k_fwdsub, dim3(nt), dim3(256), 0, stream, Ltp, Dinv, Lmat, V, n, ld, dense, n_lead);
   return hipGetLastError();
+}
+hipError_t ovp_launch_fwdsub(const double* Ltp, const double* Dinv, const double* Lmat, double* V, int n, int ld,
+                             int dense, hipStream_t stream) {
+  return ovp_launch_fwdsub_lead(Ltp, Dinv, Lmat, V, n, ld, dense, 0, stream);
 }
 
 hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,

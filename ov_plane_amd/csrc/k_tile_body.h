@@ -164,7 +164,13 @@ __host__ __device__ constexpr int tilechol_lds_doubles(int nt) { return (2 + nt 
 template <int MAXSLOT>
 __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, double* __restrict__ L,
                                               double* __restrict__ Dinv, double* __restrict__ Lpack, int n, int ld,
-                                              int* __restrict__ flag, int add_identity, int dbg_skip, double* lds) {
+                                              int* __restrict__ flag, int add_identity, int dbg_skip, double* lds,
+                                              const int flip = 0) {
+  // flip: factorize the matrix in REVERSED index order and store the dense factor with its rows reversed back,
+  // Lr[n - 1 - r][c] = chol(J A J)[r][c] (J = exchange matrix): Lr Lr^T = A, and column j of Lr is zero below row n - 1 - j.
+  // A point update whose information matrix lives on the TRAILING columns [s0, n) of the state (clones and calibration behind
+  // the IMU block) then has  T = I + Lr^T A Lr = blockdiag(T_lead, I)  with a leading block of n - s0 columns - in the state's
+  // own order, without a permutation of P (ovp_api.hip: ekf_from_gram).
   const int nt = (n + 15) >> 4;
   const int ntiles = nt * (nt + 1) / 2;
   double* Dbuf = lds;
@@ -231,7 +237,7 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
         for (int v = 0; v < 4; ++v) {
           const int r = 16 * i + lr + 4 * v;
           const int rc = r < n ? r : n - 1;
-          double x = A[(size_t)rc * ld + cc];
+          double x = flip ? A[(size_t)(n - 1 - rc) * ld + (n - 1 - cc)] : A[(size_t)rc * ld + cc];
           if (i >= nfull) x = (r < n && c < n) ? x : 0.0;  // i >= j: a partial tile is always in the last tile row
           if (r == c) x = (r < n) ? (add_identity ? x + 1.0 : x) : 1.0;  // identity padding keeps the matrix SPD
           t[v] = x;
@@ -284,9 +290,10 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
           for (int h = 0; h < 2; ++h) {
             const int e = l2 + 128 * h;  // row-major inside the tile
             const int row = e >> 4, col = e & 15;
-            *reinterpret_cast<dbl2s*>(L + (size_t)(16 * ti[s] + row) * ld + 16 * tj[s] + col) =
+            const int ro = 16 * ti[s] + row, rz = 16 * tj[s] + row;
+            *reinterpret_cast<dbl2s*>(L + (size_t)(flip ? n - 1 - ro : ro) * ld + 16 * tj[s] + col) =
                 dbl2s{sw[row * TS + col], sw[row * TS + col + 1]};
-            if (ti[s] != tj[s]) *reinterpret_cast<dbl2s*>(L + (size_t)(16 * tj[s] + row) * ld + 16 * ti[s] + col) = dbl2s{0.0, 0.0};
+            if (ti[s] != tj[s]) *reinterpret_cast<dbl2s*>(L + (size_t)(flip ? n - 1 - rz : rz) * ld + 16 * ti[s] + col) = dbl2s{0.0, 0.0};
           }
         } else {
           const int c = 16 * tj[s] + lc;
@@ -294,13 +301,13 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int r = 16 * ti[s] + lr + 4 * v;
-            if (r < n && c < n) L[(size_t)r * ld + c] = tile[s][v];
+            if (r < n && c < n) L[(size_t)(flip ? n - 1 - r : r) * ld + c] = tile[s][v];
           }
           if (ti[s] != tj[s]) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
               const int r2 = 16 * tj[s] + lr + 4 * v;
-              if (r2 < n && c2 < n) L[(size_t)r2 * ld + c2] = 0.0;
+              if (r2 < n && c2 < n) L[(size_t)(flip ? n - 1 - r2 : r2) * ld + c2] = 0.0;
             }
           }
         }

@@ -44,6 +44,8 @@ hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, 
                                       int add_identity, const int* cond, hipStream_t stream);
 hipError_t ovp_launch_tilechol(const double* A, double* L, double* Dinv, double* Lpack, int n, int ld, int* flag, int add_identity,
                                hipStream_t stream);
+hipError_t ovp_launch_fwdsub_lead(const double* Ltp, const double* Dinv, const double* Lmat, double* V, int n, int ld, int dense,
+                                  int n_lead, hipStream_t stream);
 hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double* Lmat, double* V, int n, int ld,
                              int dense, hipStream_t stream);
 hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
@@ -237,7 +239,9 @@ struct ovp_ctx {
   // update that follows needs some M with M M^T = P, not the Cholesky factor - chol(P) (the longer branch of the fused feature
   // launch at N = 240) is skipped.  Cleared by everything that writes P.
   double* Lkeep = nullptr;
-  bool have_factor = false, use_kept_factor = false;          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
+  bool have_factor = false, use_kept_factor = false;
+  int point_nl = 0;  // > 0: chol(P) of the running point update was taken in reversed index order (CholJob::flip) and the update's
+                     // T = I + L^T A L is the identity outside its leading point_nl columns          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
   hipEvent_t ev_subtab = nullptr;     // behind the upload of pl_sub_htab (the pinned block is rewritten by the next call)
   void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
   size_t pl_stage_cap = 0;
@@ -952,13 +956,17 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     // loop left (any M with M M^T = P gives P+ = M (I + M^T A M)^-1 M^T)
     const bool kept = c->use_kept_factor;
     const double* Lf = kept ? c->Lkeep : c->L;
+    // leading block of T (reversed-order factor of P, see ovp_build_gate_gram_tail): n when the factor is the plain one
+    const int nl = (!kept && chol_p_done_on_stream2 && c->point_nl > 0 && c->point_nl < n) ? c->point_nl : n;
+    const bool general = kept || nl < n;  // the factor is not lower triangular
     c->use_kept_factor = false;
+    c->point_nl = 0;
     c->have_factor = false;  // P is about to change
-    HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Lf, ld, c->W1, ld, 0, 0, c->stream));
-    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Lf, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
-    HIPCHK(chol_of_T(c, c->T, n, ld, 0, nullptr, c->stream));
+    HIPCHK(ovp_launch_gemm4(0, 0, n, nl, n, c->Ab, ld, Lf, ld, c->W1, ld, 0, 0, c->stream));
+    HIPCHK(ovp_launch_gemm4(1, 0, nl, nl, n, Lf, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
+    HIPCHK(chol_of_T(c, c->T, nl, ld, 0, nullptr, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
-    HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Lf, c->Y, n, ld, kept ? 1 : 0, c->stream));
+    HIPCHK(ovp_launch_fwdsub_lead(c->Ltp, c->Dinv, Lf, c->Y, n, ld, general ? 1 : 0, nl, c->stream));
     // (skipped on the device when a factorization failed: the resident covariance then stays what it was, OVP_E_NOTSPD)
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, c->stream));
     if (publish) {
@@ -1135,11 +1143,26 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // the kernel timer on, ev_k0 / ev_k1 bracket K1 and ev_k1 doubles as the fork point; otherwise one untimed fork event.
   if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
   c->use_kept_factor = false;
+  c->point_nl = 0;
   if (overlap_mode == 3) {
-    ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags};
+    ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags, 0};
     if (c->have_factor && c->Lkeep) {  // the plane loop left M with M M^T = P: no chol(P) (cj.n = 0), the update runs on M
       cj.n = 0;
       c->use_kept_factor = true;
+    } else {
+      // The batch's information matrix lives on the clones and the estimated calibration.  When everything in front of the first
+      // of those columns (the IMU block, dt) is untouched, the factor of P is taken in reversed index order: T = I + L^T A L is
+      // then the identity outside its leading n - s0 columns, and both products, chol(T) and the substitution shrink with it
+      // (config 2: 194 of 210 - 13 tile columns instead of 14) without a permutation of P.
+      static const bool no_flip = getenv("OVP_POINT_NO_FLIP") != nullptr;
+      int s0 = c->n;
+      for (int cid : c->h_clone_id) s0 = cid < s0 ? cid : s0;
+      if (fp.calmask & 0x3Fu) s0 = c->calib_id < s0 ? c->calib_id : s0;
+      if (fp.calmask & (0xFFu << 6)) s0 = c->intr_id < s0 ? c->intr_id : s0;
+      if (!no_flip && s0 >= 8 && s0 < c->n) {
+        cj.flip = 1;
+        c->point_nl = c->n - s0;
+      }
     }
     HIPCHK(ovp_launch_feat_chol(&fp, &cj, c->stream));
   } else {

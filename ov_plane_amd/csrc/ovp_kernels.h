@@ -23,6 +23,7 @@ struct CholJob {
   double* Lpack;
   int n, ld;
   int* flag;
+  int flip;  // dense factor of the index-reversed matrix, rows reversed back (k_tile_body.h): L = Lr with Lr Lr^T = A
 };
 
 struct FeatParams {
