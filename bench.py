@@ -312,7 +312,7 @@ def cpu_baseline(sc, name, budget_feats=None):
 
 def interbuild_band():
     """Largest distance between two builds of the oracle on the plane-level statistic (tools/plane_gate_agreement.py, committed)."""
-    for f in ("r03_plane_gate_agreement.json",):
+    for f in ("r04_plane_gate_agreement.json", "r03_plane_gate_agreement.json"):
         p = os.path.join(_ROOT, "profiles", f)
         if os.path.exists(p):
             with open(p) as fh:
