@@ -1,6 +1,6 @@
 """Numerics of the plane loop in accumulated-information form against the T-form, truth = x87 long double."""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ov_plane_amd.synth import make_scene
 from oracle import np_ref
