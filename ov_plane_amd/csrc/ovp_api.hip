@@ -1154,7 +1154,7 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
       // of those columns (the IMU block, dt) is untouched, the factor of P is taken in reversed index order: T = I + L^T A L is
       // then the identity outside its leading n - s0 columns, and both products, chol(T) and the substitution shrink with it
       // (config 2: 194 of 210 - 13 tile columns instead of 14) without a permutation of P.
-      static const bool no_flip = getenv("OVP_POINT_NO_FLIP") != nullptr;
+      const bool no_flip = getenv("OVP_POINT_NO_FLIP") != nullptr;  // (read per call: the tests switch it)
       int s0 = c->n;
       for (int cid : c->h_clone_id) s0 = cid < s0 ? cid : s0;
       if (fp.calmask & 0x3Fu) s0 = c->calib_id < s0 ? c->calib_id : s0;
@@ -1829,7 +1829,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   int rcu = ensure_pl_used(c);
   if (rcu) return rcu;
   static const bool force_v1 = getenv("OVP_PLANE_V1") != nullptr;
-  static const bool natural_order = getenv("OVP_PL_NATURAL_ORDER") != nullptr;  // A/B: the loop on all n columns in the state's order
+  const bool natural_order = getenv("OVP_PL_NATURAL_ORDER") != nullptr;  // A/B: the loop on all n columns in the state's order
   if (!force_v1 && !c->pl_sub_active && NP > 0 && (n > ovp_chol2_max_n() || !natural_order))
     return plane_update_ordered(c, o, pb, dx_planes, plane_ok, plane_chi2, plane_dof, feat_used);
   if (n > ovp_chol2_max_n() || force_v1) {
@@ -2253,7 +2253,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (c->pl_scatter_dst)  // back into the state's own column order (unless a factorization failed: the resident P stays)
       HIPCHK(ovp_launch_gather_block_unless(c->P, ld, c->pl_scatter_ids, n, c->pl_scatter_dst, ld, c->flags, s));
     // the factor of the covariance just formed, for the point update behind the loop (P = V^T V: M = V^T, rows in state order)
-    static const bool keep_factor = getenv("OVP_NO_KEPT_FACTOR") == nullptr;
+    const bool keep_factor = getenv("OVP_NO_KEPT_FACTOR") == nullptr;  // (read per call: the tests switch it)
     if (keep_factor && !c->pl_sub_rest && n <= OVP_TILECHOL_NMAX) {
       if (!c->Lkeep) HIPCHK(dalloc(&c->Lkeep, (size_t)c->n_max * ld));
       HIPCHK(ovp_launch_factor_from_V(c->Y, ld, c->pl_scatter_dst ? c->pl_scatter_ids : nullptr, n, c->Lkeep, ld, s));

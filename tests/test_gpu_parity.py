@@ -255,6 +255,52 @@ def test_plane_constraint_of_a_full_length_track(hiplib, oracle, C):
     ctx.close()
 
 
+def _frame_through_the_two_updates(hiplib, sc):
+    ctx = hiplib.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    o = hiplib.opts_from_scene(sc)
+    pl = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id) if sc.cp.shape[0] else None
+    o.skip_plane_used = 1 if pl is not None else 0
+    pt = ctx.msckf_update(o)
+    P = ctx.cov_download()
+    ht = ctx.host_timing()
+    ctx.close()
+    return pl, pt, P, ht
+
+
+@pytest.mark.parametrize("switch,kw", [
+    # plane loop in the state's own column order on all n columns against the loop's order / leading blocks
+    ("OVP_PL_NATURAL_ORDER", dict(C=12, F=260, seed=61, n_planes=6, feats_per_plane=25, planes_in_state_frac=0.5, chi2_mult=1.0)),
+    # point update behind a plane loop: chol(P) again against the factor the loop left
+    ("OVP_NO_KEPT_FACTOR", dict(C=12, F=260, seed=62, n_planes=5, feats_per_plane=30, planes_in_state_frac=0.6, chi2_mult=1.0)),
+    # point update: chol(P) in the state's index order (full-size T) against the reversed-order factor (leading block of T)
+    ("OVP_POINT_NO_FLIP", dict(C=20, F=400, seed=63, chi2_mult=1.0)),
+    ("OVP_POINT_NO_FLIP", dict(C=7, F=90, seed=64, ragged=True, chi2_mult=1.0, n_slam=5)),   # landmarks behind the clones: the block grows
+])
+def test_round4_shortcuts_change_nothing_but_rounding(hiplib, monkeypatch, switch, kw):
+    """The three shortcuts of round 4 - the plane loop on the leading block of its own column order, the point update on the
+    factor that loop left, the point update's T on its leading block through a reversed-order factor of P - are algebraic
+    identities: each against its switched-off form on the same frame (same decisions, corrections and covariance to rounding)."""
+    sc = make_scene(**kw)
+    monkeypatch.delenv(switch, raising=False)
+    pl1, pt1, P1, ht1 = _frame_through_the_two_updates(hiplib, sc)
+    monkeypatch.setenv(switch, "1")
+    pl0, pt0, P0, ht0 = _frame_through_the_two_updates(hiplib, sc)
+    if pl1 is not None:
+        assert (pl1["ok"] == pl0["ok"]).all() and (pl1["used"] == pl0["used"]).all() and pl1["ok"].any()
+        assert np.abs(pl1["chi2"] - pl0["chi2"]).max() < 1e-6 * max(1.0, np.abs(pl0["chi2"]).max())
+        assert np.abs(pl1["dx"] - pl0["dx"]).max() < 1e-9
+    assert (pt1["accepted"] == pt0["accepted"]).all() and pt1["accepted"].sum() > 10
+    assert np.abs(pt1["dx"] - pt0["dx"]).max() < 1e-9
+    assert relP(P1, P0) < 1e-8
+    # the host clocks of the entry points are there and make sense
+    assert ht1["point_calls"] == 1 and ht1["point_enqueue_ms"] > 0 and ht1["point_wait_ms"] >= 0
+    if pl1 is not None:
+        assert ht1["plane_calls"] >= 1 and ht1["plane_enqueue_ms"] >= ht1["plane_pre_ms"] >= 0
+
+
 def test_config3_plane_loop_at_full_size_matches_oracle(hiplib, oracle):
     """BASELINE config[2]: 30 clones, 2000 features of which 1000 lie on 20 planes (10 of them in the state, N = 240).  The plane
     loop is cheap enough for the oracle at full size (about a second); the point update on the 1000 free points is checked
