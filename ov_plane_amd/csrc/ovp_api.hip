@@ -1785,7 +1785,8 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
   c->fp.clone_id = sv.fp_clone_id;
   c->colmap = sv.colmap;
   c->h_clone_id = sv.h_clone_id;
-  if (rc) return rc;  // the resident covariance was not touched
+  if (rc) return rc;  // the resident covariance was not touched (the device tables may have been: a loop that fails after
+                      // accepting planes has marked them invalid, have_state = false - INTEGRATION.md section 5)
   if (full) {
     if (dx_planes)
       for (int k = 0; k < NP; ++k)
