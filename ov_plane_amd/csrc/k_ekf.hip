@@ -217,6 +217,24 @@ __global__ void k_factor_from_V(const double* __restrict__ V, int ld, const int*
   const int ro = r0 + ty, ko = k0 + tx;
   if (ro < n && ko < n) out[(size_t)ro * ldo + ko] = tile[tx][ty];
 }
+// Both of the above behind a plane loop that ran in its own column order, in one launch: Pout[r][k] = Pperm[ids[r]][ids[k]]
+// (unless *cancel: a failed factorization leaves the resident covariance alone) and Lout[r][k] = V[k][ids[r]].
+__global__ void k_unpermute_pair(const double* __restrict__ Pperm, const double* __restrict__ V, int ld, const int* __restrict__ ids,
+                                 int n, double* __restrict__ Pout, double* __restrict__ Lout, int ldo, const int* __restrict__ cancel) {
+  __shared__ double tile[16][17];
+  const int r0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int r = r0 + tx, k = k0 + ty;
+  double v = 0.0;
+  if (r < n && k < n) v = V[(size_t)k * ld + ids[r]];
+  tile[ty][tx] = v;
+  __syncthreads();
+  const int ro = r0 + ty, ko = k0 + tx;
+  if (ro < n && ko < n) {
+    if (Lout) Lout[(size_t)ro * ldo + ko] = tile[tx][ty];
+    if (*cancel == 0) Pout[(size_t)ro * ldo + ko] = Pperm[(size_t)ids[ro] * ld + ids[ko]];
+  }
+}
 // ... unless *cancel != 0 (a failed factorization upstream: the destination keeps what it holds, cf. ovp_launch_gemm4c)
 __global__ void k_gather_block_unless(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int m,
                                       double* __restrict__ out, int ldo, const int* __restrict__ cancel) {
@@ -441,6 +459,12 @@ hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int
 hipError_t ovp_launch_factor_from_V(const double* V, int ld, const int* ids, int n, double* out, int ldo, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   hipLaunchKernelGGL(ovp::k_factor_from_V, dim3(nt, nt), dim3(256), 0, stream, V, ld, ids, n, out, ldo);
+  return hipGetLastError();
+}
+hipError_t ovp_launch_unpermute_pair(const double* Pperm, const double* V, int ld, const int* ids, int n, double* Pout, double* Lout,
+                                     int ldo, const int* cancel, hipStream_t stream) {
+  const int nt = (n + 15) / 16;
+  hipLaunchKernelGGL(ovp::k_unpermute_pair, dim3(nt, nt), dim3(256), 0, stream, Pperm, V, ld, ids, n, Pout, Lout, ldo, cancel);
   return hipGetLastError();
 }
 hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream) {

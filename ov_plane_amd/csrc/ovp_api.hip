@@ -25,6 +25,8 @@ hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int
 hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
                                           hipStream_t stream);
 hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream);
+hipError_t ovp_launch_unpermute_pair(const double* Pperm, const double* V, int ld, const int* ids, int n, double* Pout, double* Lout,
+                                     int ldo, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_factor_from_V(const double* V, int ld, const int* ids, int n, double* out, int ldo, hipStream_t stream);
 hipError_t ovp_launch_scale_rows(double* L, int n, int ld, const double* dvec, hipStream_t stream);
 hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream);
@@ -2247,19 +2249,45 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   // ---- the covariance, once:  P = L0 T^-1 L0^T = V^T V,  V = Lt^-1 L0^T ----
   bool factor_enqueued = false;
   if (NJ > 0) {
-    HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
-    HIPCHK(chol_of_T(c, c->T, n, ld, 1, c->pl_cur + 1, s));
+    {
+      // chol of the accepted T (+ I) unless the last accepted plane left its factor behind; the second-generation kernel reads the
+      // current half of the double buffer itself (Chol2Job::sel) - no copy into c->T in front of it
+      const bool first_gen_T = getenv("OVP_TILECHOL_T") != nullptr;
+      if (!first_gen_T && n <= ovp_chol2_max_n() + 1) {
+        ovp::Chol2Job jt;
+        memset(&jt, 0, sizeof(jt));
+        jt.A = c->pl_Tbuf;
+        jt.sel = c->pl_cur;
+        jt.sel_xor = 0;
+        jt.sel_stride = tstride;
+        jt.n = n;
+        jt.ld = ld;
+        jt.add_identity = 1;
+        jt.mode = 0;
+        jt.flag = c->flags;
+        jt.Lpack = c->Ltp;
+        jt.Dinv_out = c->Dinv;
+        jt.skip_cond = c->pl_cur + 1;
+        HIPCHK(ovp_launch_chol2(&jt, nullptr, nullptr, s));
+      } else {
+        HIPCHK(ovp_launch_select_copy(c->T, c->pl_Tbuf, tstride, c->pl_cur, n, ld, 1, s));
+        HIPCHK(chol_of_T(c, c->T, n, ld, 1, c->pl_cur + 1, s));
+      }
+    }
     HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, c->L, c->Y, n, ld, 0, s));
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, s));
-    if (c->pl_scatter_dst)  // back into the state's own column order (unless a factorization failed: the resident P stays)
-      HIPCHK(ovp_launch_gather_block_unless(c->P, ld, c->pl_scatter_ids, n, c->pl_scatter_dst, ld, c->flags, s));
-    // the factor of the covariance just formed, for the point update behind the loop (P = V^T V: M = V^T, rows in state order)
+    // back into the state's own column order (unless a factorization failed: the resident P stays), and the factor of the
+    // covariance just formed for the point update behind the loop (P = V^T V: M = V^T, rows in state order) - one launch for both
     const bool keep_factor = getenv("OVP_NO_KEPT_FACTOR") == nullptr;  // (read per call: the tests switch it)
-    if (keep_factor && !c->pl_sub_rest && n <= OVP_TILECHOL_NMAX) {
-      if (!c->Lkeep) HIPCHK(dalloc(&c->Lkeep, (size_t)c->n_max * ld));
-      HIPCHK(ovp_launch_factor_from_V(c->Y, ld, c->pl_scatter_dst ? c->pl_scatter_ids : nullptr, n, c->Lkeep, ld, s));
-      factor_enqueued = true;
+    const bool want_factor = keep_factor && !c->pl_sub_rest && n <= OVP_TILECHOL_NMAX;
+    if (want_factor && !c->Lkeep) HIPCHK(dalloc(&c->Lkeep, (size_t)c->n_max * ld));
+    if (c->pl_scatter_dst) {
+      HIPCHK(ovp_launch_unpermute_pair(c->P, c->Y, ld, c->pl_scatter_ids, n, c->pl_scatter_dst, want_factor ? c->Lkeep : nullptr, ld,
+                                       c->flags, s));
+    } else if (want_factor) {
+      HIPCHK(ovp_launch_factor_from_V(c->Y, ld, nullptr, n, c->Lkeep, ld, s));
     }
+    factor_enqueued = want_factor;
   }
   if (c->pl_ktimer) HIPCHK(hipEventRecord(c->pl_ev_loop[1], s));
   // ---- results: one pinned block, one synchronisation ----
