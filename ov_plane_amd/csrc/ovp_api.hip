@@ -1386,7 +1386,7 @@ static int plane_job_device(ovp_ctx* c, const ovp_update_opts* o, const ovp::Fea
   // EKF update in information form with the chained factor
   HIPCHK(ovp_launch_gemm4(0, 0, n, n, n, c->Ab, ld, Mf, ld, c->W1, ld, 0, 0, s));
   HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, Mf, ld, c->W1, ld, c->T, ld, 1, 1, s));
-  HIPCHK(ovp_launch_tilechol(c->T, nullptr, c->Dinv, c->Ltp, n, ld, c->flags, 0, s));
+  HIPCHK(chol_of_T(c, c->T, n, ld, 0, nullptr, s));  // (second-generation factorization where it fits, like every other chol(T))
   HIPCHK(ovp_launch_fwdsub(c->Ltp, c->Dinv, Mf, c->Y, n, ld, factor_dense, s));
   HIPCHK(ovp_launch_dx_from_factor(c->Y, n, ld, c->Ab + (size_t)n * ld, c->dx, c->pl_scal, s));
   HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
