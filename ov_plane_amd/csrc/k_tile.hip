@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
     constexpr int r = decltype(rc)::value;
     const int i = wave + 4 * r;
     double4_t t = {0.0, 0.0, 0.0, 0.0};
-    if (i < nt && (dense || i <= cblk)) {
+    // dense: 0 = M = L^T with L lower triangular (tiles below the diagonal of M are zero), 1 = a general factor, 2 = L^T of the
+    // row-reversed factor of a reversed-order Cholesky (k_tile_body.h: flip): M[r][c] = 0 for r + c > n - 1
+    if (i < nt && (dense == 1 || (dense == 0 && i <= cblk) || (dense == 2 && 16 * (i + cblk) <= n - 1))) {
       const int gr = 16 * cblk + lc;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {

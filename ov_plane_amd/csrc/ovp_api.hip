@@ -960,7 +960,6 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     const double* Lf = kept ? c->Lkeep : c->L;
     // leading block of T (reversed-order factor of P, see ovp_build_gate_gram_tail): n when the factor is the plain one
     const int nl = (!kept && chol_p_done_on_stream2 && c->point_nl > 0 && c->point_nl < n) ? c->point_nl : n;
-    const bool general = kept || nl < n;  // the factor is not lower triangular
     c->use_kept_factor = false;
     c->point_nl = 0;
     c->have_factor = false;  // P is about to change
@@ -968,7 +967,7 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     HIPCHK(ovp_launch_gemm4(1, 0, nl, nl, n, Lf, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
     HIPCHK(chol_of_T(c, c->T, nl, ld, 0, nullptr, c->stream));
     // V = Lt^-1 L^T ;  P+ = V^T V ;  dx = P+ b
-    HIPCHK(ovp_launch_fwdsub_lead(c->Ltp, c->Dinv, Lf, c->Y, n, ld, general ? 1 : 0, nl, c->stream));
+    HIPCHK(ovp_launch_fwdsub_lead(c->Ltp, c->Dinv, Lf, c->Y, n, ld, kept ? 1 : (nl < n ? 2 : 0), nl, c->stream));
     // (skipped on the device when a factorization failed: the resident covariance then stays what it was, OVP_E_NOTSPD)
     HIPCHK(ovp_launch_gemm4c(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, c->flags, c->stream));
     if (publish) {
