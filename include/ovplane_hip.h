@@ -225,6 +225,41 @@ int ovp_plane_init(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_plane_ba
 int ovp_ekf_update(ovp_ctx *ctx, const double *H_host, int rows, int cols, int ld, const int *col_ids,
                    const double *res_host, double *dx_host, ovp_update_info *info);
 
+/* Landmarks of the state that were re-observed (UpdaterSLAM::update, update/UpdaterSLAM.cpp:424-673), host pointers.
+ * The measurement arrays are laid out as in ovp_feature_batch (one "feature" per landmark).  A landmark held in GLOBAL_3D
+ * (feat_rep_slam of every shipped configuration) has its rows built on the device from the tables of ovp_state_upload; one held in
+ * an anchored / inverse-depth representation arrives with the dense block [H_x | H_f] the host built (the representation Jacobians
+ * of update/UpdaterHelper.cpp:35-193 are host scalar code; for the single inverse depth AFTER the bearing projection of
+ * UpdaterSLAM.cpp:499-515) - pre_rows[l] > 0 marks it, the gate and the update are the same. */
+typedef struct {
+  int n_landmarks;
+  int max_meas;               /* row pitch of uv / clone_idx, <= OVP_MAX_MEAS */
+  const float *uv;            /* [n_landmarks*max_meas*2] raw pixels of the new observations (Feature::uvs) */
+  const int *clone_idx;       /* [n_landmarks*max_meas] clone slot of every observation */
+  const int *n_meas;          /* [n_landmarks] */
+  const double *p_FinG;       /* [n_landmarks*3] Landmark::get_xyz(false) */
+  const double *p_FinG_fej;   /* [n_landmarks*3] Landmark::get_xyz(true) */
+  const int *landmark_id;     /* [n_landmarks] Type::id() */
+  /* point-on-plane rows (:465-475): Type::id() of the plane of the STATE the landmark lies on, -1 = none; NULL = no planes */
+  const int *plane_state_id;  /* [n_landmarks] */
+  const double *cp;           /* [n_landmarks*3] State::_features_PLANE.at(..)->value() of that plane */
+  const double *cp_fej;       /* [n_landmarks*3] ->fej() */
+  /* host-built blocks, NULL when every landmark is GLOBAL_3D */
+  const int *pre_rows;        /* [n_landmarks] 0 = rows built on the device */
+  const int *pre_cols;        /* [n_landmarks] */
+  const double *pre_H;        /* blocks of the marked landmarks in order: [rows x cols] column-major, then res [rows] */
+  const int *pre_ids;         /* their state columns, cols per block, in order */
+} ovp_slam_batch;
+
+/* UpdaterSLAM::update (update/UpdaterSLAM.cpp:424-673) on the resident covariance: get_feature_jacobian_full for a landmark of the
+ * state (UpdaterHelper.cpp:195-513, bearing rows + the point-on-plane rows of :448-512), chi2 test against the marginal covariance
+ * (:526-547), the no-plane fallback for a landmark whose plane rows fail (:547-609), stacking (:627-651) and ONE
+ * StateHelper::EKFUpdate (:673).  All gates see the covariance in front of the call, as in the reference.
+ * status[l]: 0 = rejected (reference: should_marg + to_delete), 1 = accepted, 2 = accepted without its plane
+ * (_features_SLAM_to_PLANE[featid] = 0); chi2[l] = statistic of the stage that decided.  dx_host[n_state] for Type::update. */
+int ovp_slam_update(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_slam_batch *batch, double *dx_host, uint8_t *status,
+                    double *chi2, ovp_update_info *info);
+
 /* StateHelper::EKFPropagation (state/StateHelper.cpp:41-119): new variables occupy [new_start, new_start+phi_size),
  * Phi is [phi_size x sum(old_sizes)] column-major, Q is [phi_size x phi_size] (upper triangle read). */
 int ovp_cov_propagate(ovp_ctx *ctx, int new_start, int phi_size, const int *old_ids, const int *old_sizes, int n_old,

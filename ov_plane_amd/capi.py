@@ -82,6 +82,26 @@ class PlaneBatch(C.Structure):
     ]
 
 
+class SlamBatch(C.Structure):
+    _fields_ = [
+        ("n_landmarks", C.c_int),
+        ("max_meas", C.c_int),
+        ("uv", C.c_void_p),
+        ("clone_idx", C.c_void_p),
+        ("n_meas", C.c_void_p),
+        ("p_FinG", C.c_void_p),
+        ("p_FinG_fej", C.c_void_p),
+        ("landmark_id", C.c_void_p),
+        ("plane_state_id", C.c_void_p),
+        ("cp", C.c_void_p),
+        ("cp_fej", C.c_void_p),
+        ("pre_rows", C.c_void_p),
+        ("pre_cols", C.c_void_p),
+        ("pre_H", C.c_void_p),
+        ("pre_ids", C.c_void_p),
+    ]
+
+
 class UpdateInfo(C.Structure):
     _fields_ = [
         ("n_accepted", C.c_int),
@@ -118,6 +138,7 @@ EXPORTS = [
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
     "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
+    "ovp_slam_update",
 ]
 
 
@@ -154,6 +175,8 @@ def lib():
         L.ovp_msckf_fetch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateInfo)]
         L.ovp_ekf_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(UpdateInfo)]
+        L.ovp_slam_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(SlamBatch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(UpdateInfo)]
         L.ovp_msckf_plane_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(PlaneBatch), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ovp_plane_init.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(PlaneBatch), C.c_double, C.c_double,
@@ -465,6 +488,57 @@ class Context:
         _chk(lib().ovp_ekf_update(self._h, H.ctypes.data, H.shape[0], H.shape[1], H.shape[0], col_ids.ctypes.data,
                                   res.ctypes.data, dx.ctypes.data, C.byref(info)), "ovp_ekf_update")
         return dx, info
+
+    def slam_update(self, opts: UpdateOpts, uv, clone_idx, n_meas, p_FinG, p_FinG_fej, landmark_id, plane_state_id=None, cp=None,
+                    cp_fej=None, pre=None, raise_on_error=True):
+        """ovp_slam_update (UpdaterSLAM::update on the device).  pre: optional list with one entry per landmark, None (rows built
+        on the device) or (H [rows x cols], col_ids [cols], res [rows]) for a block the host built.
+        Returns dict(dx, status [L] (0 rejected / 1 accepted / 2 accepted without its plane), chi2 [L], info, rc)."""
+        n_meas = np.ascontiguousarray(n_meas, dtype=np.int32)
+        L = int(n_meas.shape[0])
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(L, -1, 2)
+        M = uv.shape[1]
+        ci = np.ascontiguousarray(clone_idx, dtype=np.int32).reshape(L, M)
+        p = np.ascontiguousarray(p_FinG, dtype=np.float64).reshape(L, 3)
+        pf = np.ascontiguousarray(p_FinG_fej, dtype=np.float64).reshape(L, 3)
+        lm = np.ascontiguousarray(landmark_id, dtype=np.int32)
+        sb = SlamBatch()
+        sb.n_landmarks, sb.max_meas = L, M
+        sb.uv, sb.clone_idx, sb.n_meas = uv.ctypes.data, ci.ctypes.data, n_meas.ctypes.data
+        sb.p_FinG, sb.p_FinG_fej, sb.landmark_id = p.ctypes.data, pf.ctypes.data, lm.ctypes.data
+        keep = [uv, ci, p, pf, lm]
+        if plane_state_id is not None:
+            ps = np.ascontiguousarray(plane_state_id, dtype=np.int32)
+            cpa = np.ascontiguousarray(cp, dtype=np.float64).reshape(L, 3)
+            cpf = np.ascontiguousarray(cp_fej, dtype=np.float64).reshape(L, 3)
+            sb.plane_state_id, sb.cp, sb.cp_fej = ps.ctypes.data, cpa.ctypes.data, cpf.ctypes.data
+            keep += [ps, cpa, cpf]
+        if pre is not None and any(e is not None for e in pre):
+            pr = np.zeros(L, dtype=np.int32)
+            pc = np.zeros(L, dtype=np.int32)
+            hh, ii = [], []
+            for l, e in enumerate(pre):
+                if e is None:
+                    continue
+                H, ids, res = e
+                H = np.asfortranarray(H, dtype=np.float64)
+                pr[l], pc[l] = H.shape
+                hh += [H.ravel(order="F"), np.asarray(res, dtype=np.float64).ravel()]
+                ii.append(np.asarray(ids, dtype=np.int32).ravel())
+            ph = np.ascontiguousarray(np.concatenate(hh))
+            pi = np.ascontiguousarray(np.concatenate(ii))
+            sb.pre_rows, sb.pre_cols, sb.pre_H, sb.pre_ids = pr.ctypes.data, pc.ctypes.data, ph.ctypes.data, pi.ctypes.data
+            keep += [pr, pc, ph, pi]
+        n = self.cov_size()
+        dx = np.zeros(n)
+        status = np.zeros(max(L, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(L, 1))
+        info = UpdateInfo()
+        rc = lib().ovp_slam_update(self._h, C.byref(opts), C.byref(sb), dx.ctypes.data, status.ctypes.data, chi2.ctypes.data,
+                                   C.byref(info))
+        if raise_on_error:
+            _chk(rc, "ovp_slam_update")
+        return dict(dx=dx, status=status[:L], chi2=chi2[:L], info=info, rc=rc)
 
     def cov_initialize(self, Hx_init, H_up, col_ids, H_Linv, R_init, res_up, r_iso, chi2_threshold, do_update=True):
         """StateHelper::initialize downstream of its Givens split as one device sequence (state/StateHelper.cpp:448-487):

@@ -15,6 +15,7 @@
 #include "ovp_kernels.h"
 #include "k_chol2.h"
 #include "k_plane2.h"
+#include "k_slam.h"
 
 extern "C" int ovp_dbg_tilechol_skip;
 extern "C" {
@@ -199,6 +200,9 @@ struct ovp_ctx {
   double* dx = nullptr;
   int* flags = nullptr;  // [0] not spd, [1] neg diag
   double *Hd = nullptr, *Acc = nullptr, *bcc = nullptr, *resd = nullptr;  // dense-H path
+  void* slam_res = nullptr;        // ovp_slam_update: per-landmark [chi2 | status]
+  double* slam_hscr = nullptr;     // ... blocks that do not fit LDS
+  size_t slam_res_cap = 0, slam_hscr_cap = 0;
   size_t Hd_cap = 0, res_cap = 0;
   int calib_id = -1, intr_id = -1;
   long long* dbg_cycles = nullptr;
@@ -463,7 +467,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
                  c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
                  c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage, c->pl_xbuf, c->pl_xy, c->pl_xflag, c->pl_Asum,
-                 c->pl_U, c->pl_sub_tab, c->Lkeep};
+                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -2540,6 +2544,302 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
     memset(info, 0, sizeof(*info));
     info->n_rows = rows;
     info->n_cols = cols;
+    info->not_spd = c->h_flags[0];
+    info->neg_diag = c->h_flags[1];
+  }
+  if (c->h_flags[0]) return OVP_E_NOTSPD;
+  if (c->h_flags[1]) return OVP_E_NEGDIAG;
+  return 0;
+}
+
+// ---- UpdaterSLAM::update on the device (update/UpdaterSLAM.cpp:424-673; csrc/k_slam.hip) ------------------------------------
+// Rows and gate of every landmark in ONE launch against the resident covariance (no download of P, no host gate), the accepted rows
+// stacked on the device, StateHelper::EKFUpdate on that stack (S-form up to 80 rows, information form above), one synchronisation.
+extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_slam_batch* b, double* dx_host, uint8_t* status_host,
+                               double* chi2_host, ovp_update_info* info) {
+  if (c) {
+    c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+    c->use_kept_factor = false;
+    c->point_nl = 0;
+  }
+  if (!c || !o || !b || b->n_landmarks < 0) return OVP_E_ARG;
+  if (!c->have_state || !c->have_cov) return OVP_E_STATE;
+  const int L = b->n_landmarks, n = c->n, M = b->max_meas;
+  if (info) memset(info, 0, sizeof(*info));
+  if (dx_host) memset(dx_host, 0, sizeof(double) * n);
+  if (L == 0) return 0;
+  if (M < 1 || M > OVP_MAX_MEAS || !b->n_meas || !b->landmark_id) return OVP_E_ARG;
+  const bool any_pre = b->pre_rows != nullptr;
+  if (any_pre && (!b->pre_cols || !b->pre_H || !b->pre_ids)) return OVP_E_ARG;
+  const unsigned calmask = (o->do_calib_camera_pose ? 0x3Fu : 0u) | (o->do_calib_camera_intrinsics ? (0xFFu << 6) : 0u);
+  int calcol[14];
+  for (int k = 0; k < 14; ++k) {
+    calcol[k] = (k < 6) ? c->calib_id + k : c->intr_id + (k - 6);
+    if (!((calmask >> k) & 1)) calcol[k] = 0;
+    else if (calcol[k] < 0 || calcol[k] >= n) return OVP_E_ARG;
+  }
+  const int C = (int)c->h_clone_id.size();
+  // ---- host: the call's column list (first-seen order, as Hx_order_big of :634-646), row offsets, kernel geometry
+  std::vector<int> gpos(n, -1), gids, row0(L), pre_off(L, 0), pre_ids_off(L, 0);
+  auto touch = [&](int col) {
+    if (gpos[col] < 0) {
+      gpos[col] = (int)gids.size();
+      gids.push_back(col);
+    }
+  };
+  int m_total = 0, rows_max = 1, cols_max = 1;
+  size_t preH = 0, preI = 0;
+  bool any_built = false;
+  for (int l = 0; l < L; ++l) {
+    row0[l] = m_total;
+    int rows, cols;
+    if (any_pre && b->pre_rows[l] > 0) {
+      rows = b->pre_rows[l];
+      cols = b->pre_cols[l];
+      if (cols < 1 || cols > n) return OVP_E_ARG;
+      pre_off[l] = (int)preH;
+      pre_ids_off[l] = (int)preI;
+      for (int k = 0; k < cols; ++k) {
+        const int id = b->pre_ids[preI + k];
+        if (id < 0 || id >= n) return OVP_E_ARG;
+        touch(id);
+      }
+      preH += (size_t)rows * cols + rows;
+      preI += cols;
+    } else {
+      if (!b->uv || !b->clone_idx || !b->p_FinG || !b->p_FinG_fej) return OVP_E_ARG;
+      const int m = b->n_meas[l];
+      if (m < 0 || m > M) return OVP_E_ARG;
+      const bool plane = b->plane_state_id && b->plane_state_id[l] >= 0;
+      if (plane && (!b->cp || !b->cp_fej || b->plane_state_id[l] + 3 > n)) return OVP_E_ARG;
+      if (b->landmark_id[l] < 0 || b->landmark_id[l] + 3 > n) return OVP_E_ARG;
+      rows = plane ? 3 * m : 2 * m;
+      cols = 6 * m + __builtin_popcount(calmask) + 3 + (plane ? 3 : 0);
+      for (int a = 0; a < m; ++a) {
+        const int ci = b->clone_idx[(size_t)l * M + a];
+        if (ci < 0 || ci >= C) return OVP_E_ARG;
+        for (int k = 0; k < 6; ++k) touch(c->h_clone_id[ci] + k);
+      }
+      if (m > 0) {
+        for (int k = 0; k < 14; ++k)
+          if ((calmask >> k) & 1) touch(calcol[k]);
+        for (int k = 0; k < 3; ++k) touch(b->landmark_id[l] + k);
+        if (plane)
+          for (int k = 0; k < 3; ++k) touch(b->plane_state_id[l] + k);
+      }
+      any_built = any_built || m > 0;
+    }
+    m_total += rows;
+    rows_max = std::max(rows_max, rows);
+    cols_max = std::max(cols_max, cols);
+  }
+  if (m_total < 1) {  // nothing to update with (:661-663)
+    if (status_host) memset(status_host, 0, L);
+    if (chi2_host) memset(chi2_host, 0, sizeof(double) * L);
+    return 0;
+  }
+  const int gcols = (int)gids.size();
+  if (ovp_slam_gate_lds(rows_max, cols_max, 0) > 150 * 1024) return OVP_E_CAPACITY;
+  const int h_in_lds = ovp_slam_gate_lds(rows_max, cols_max, 1) <= 150 * 1024 ? 1 : 0;
+  hipStream_t s = c->stream;
+  // ---- one pinned staging block -> one copy
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o0 = off;
+    off = al(off + bytes);
+    return o0;
+  };
+  const size_t o_p = take(sizeof(double) * 3 * L), o_pf = take(sizeof(double) * 3 * L), o_cp = take(sizeof(double) * 3 * L),
+               o_cpf = take(sizeof(double) * 3 * L), o_preH = take(sizeof(double) * (preH + 1)), o_uv = take(sizeof(float) * 2 * (size_t)L * M),
+               o_ci = take(sizeof(int) * (size_t)L * M), o_nm = take(sizeof(int) * L), o_lm = take(sizeof(int) * L),
+               o_ps = take(sizeof(int) * L), o_r0 = take(sizeof(int) * L), o_gp = take(sizeof(int) * n),
+               o_gi = take(sizeof(int) * gcols), o_pr = take(sizeof(int) * L), o_pc = take(sizeof(int) * L),
+               o_po = take(sizeof(int) * L), o_pio = take(sizeof(int) * L), o_pid = take(sizeof(int) * (preI + 1));
+  const size_t stage_bytes = off;
+  const size_t res_doubles = 4 + (size_t)c->n_max + 8;
+  const size_t lres_bytes = al(sizeof(double) * L) + al((size_t)L);
+  int rc = plane2_buffers(c, 0, stage_bytes, res_doubles * sizeof(double) + lres_bytes + 64);
+  if (rc) return rc;
+  char* h = (char*)c->pl_hstage;
+  char* d = (char*)c->pl_dstage;
+  memset(h, 0, stage_bytes);
+  if (any_built) {
+    memcpy(h + o_p, b->p_FinG, sizeof(double) * 3 * L);
+    memcpy(h + o_pf, b->p_FinG_fej, sizeof(double) * 3 * L);
+    memcpy(h + o_uv, b->uv, sizeof(float) * 2 * (size_t)L * M);
+    memcpy(h + o_ci, b->clone_idx, sizeof(int) * (size_t)L * M);
+  }
+  if (b->cp) memcpy(h + o_cp, b->cp, sizeof(double) * 3 * L);
+  if (b->cp_fej) memcpy(h + o_cpf, b->cp_fej, sizeof(double) * 3 * L);
+  memcpy(h + o_nm, b->n_meas, sizeof(int) * L);
+  memcpy(h + o_lm, b->landmark_id, sizeof(int) * L);
+  for (int l = 0; l < L; ++l) ((int*)(h + o_ps))[l] = b->plane_state_id ? b->plane_state_id[l] : -1;
+  memcpy(h + o_r0, row0.data(), sizeof(int) * L);
+  memcpy(h + o_gp, gpos.data(), sizeof(int) * n);
+  memcpy(h + o_gi, gids.data(), sizeof(int) * gcols);
+  if (any_pre) {
+    memcpy(h + o_pr, b->pre_rows, sizeof(int) * L);
+    memcpy(h + o_pc, b->pre_cols, sizeof(int) * L);
+    memcpy(h + o_po, pre_off.data(), sizeof(int) * L);
+    memcpy(h + o_pio, pre_ids_off.data(), sizeof(int) * L);
+    memcpy(h + o_preH, b->pre_H, sizeof(double) * preH);
+    memcpy(h + o_pid, b->pre_ids, sizeof(int) * preI);
+  }
+  // ---- device buffers: the stacked system (Hd = H^T [gcols][m_total], resd), per-landmark results, block scratch
+  const size_t need = (size_t)gcols * m_total;
+  if (need > c->Hd_cap) {
+    if (c->Hd) hipFree(c->Hd);
+    c->Hd = nullptr;
+    c->Hd_cap = 0;
+    HIPCHK(dalloc(&c->Hd, need + 64));
+    c->Hd_cap = need + 64;
+  }
+  if ((size_t)m_total > c->res_cap) {
+    if (c->resd) hipFree(c->resd);
+    c->resd = nullptr;
+    c->res_cap = 0;
+    HIPCHK(dalloc(&c->resd, (size_t)m_total + 64));
+    c->res_cap = (size_t)m_total + 64;
+  }
+  if (lres_bytes > c->slam_res_cap) {
+    if (c->slam_res) hipFree(c->slam_res);
+    c->slam_res = nullptr;
+    c->slam_res_cap = 0;
+    HIPCHK(hipMalloc(&c->slam_res, lres_bytes + 4096));
+    c->slam_res_cap = lres_bytes + 4096;
+  }
+  if (!h_in_lds) {
+    const size_t hs = (size_t)L * rows_max * cols_max;
+    if (hs > c->slam_hscr_cap) {
+      if (c->slam_hscr) hipFree(c->slam_hscr);
+      c->slam_hscr = nullptr;
+      c->slam_hscr_cap = 0;
+      HIPCHK(dalloc(&c->slam_hscr, hs + 64));
+      c->slam_hscr_cap = hs + 64;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(d, h, stage_bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(c->Hd, 0, sizeof(double) * need, s));
+  HIPCHK(hipMemsetAsync(c->resd, 0, sizeof(double) * m_total, s));
+  ovp::SlamParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.fp = c->fp;
+  sp.fp.uv = (const float*)(d + o_uv);
+  sp.fp.clone_idx = (const int*)(d + o_ci);
+  sp.fp.n_meas = (const int*)(d + o_nm);
+  sp.fp.p_FinG = (const double*)(d + o_p);
+  sp.fp.n_feats = L;
+  sp.fp.max_meas = M;
+  sp.fp.do_fej = o->do_fej;
+  sp.fp.calmask = calmask;
+  for (int k = 0; k < 14; ++k) sp.fp.calcol[k] = calcol[k];
+  sp.fp.white_px = 1.0 / o->sigma_px;
+  sp.fp.chi2_mult = o->chi2_multiplier;
+  sp.fp.chi2_table = c->chi2_table;
+  sp.fp.P = c->P;
+  sp.fp.n = n;
+  sp.fp.ldp = c->ld;
+  sp.p_fej = (const double*)(d + o_pf);
+  sp.lm_id = (const int*)(d + o_lm);
+  sp.plane_sid = (const int*)(d + o_ps);
+  sp.cp = (const double*)(d + o_cp);
+  sp.cp_fej = (const double*)(d + o_cpf);
+  sp.white_c = 1.0 / o->sigma_constraint;
+  if (any_pre) {
+    sp.pre_rows = (const int*)(d + o_pr);
+    sp.pre_cols = (const int*)(d + o_pc);
+    sp.pre_off = (const int*)(d + o_po);
+    sp.pre_ids_off = (const int*)(d + o_pio);
+    sp.pre_H = (const double*)(d + o_preH);
+    sp.pre_ids = (const int*)(d + o_pid);
+  }
+  sp.row0 = (const int*)(d + o_r0);
+  sp.gpos = (const int*)(d + o_gp);
+  sp.Ht = c->Hd;
+  sp.m_total = m_total;
+  sp.res_out = c->resd;
+  sp.Hscr = c->slam_hscr;
+  sp.rows_max = rows_max;
+  sp.cols_max = cols_max;
+  sp.h_in_lds = h_in_lds;
+  sp.chi2 = (double*)c->slam_res;
+  sp.status = (unsigned char*)c->slam_res + al(sizeof(double) * L);
+  HIPCHK(ovp_launch_slam_gate(&sp, L, ovp_slam_gate_lds(rows_max, cols_max, h_in_lds), s));
+  const int* dgid = (const int*)(d + o_gi);
+  char* hres = (char*)c->pl_hres;
+  double* hres_d = (double*)hres;
+  char* hl = hres + res_doubles * sizeof(double);  // [chi2 L | status L]
+  auto finish_landmarks = [&]() {
+    if (chi2_host) memcpy(chi2_host, hl, sizeof(double) * L);
+    if (status_host) memcpy(status_host, hl + al(sizeof(double) * L), L);
+    if (info) {
+      info->n_cols = gcols;
+      for (int l = 0; l < L; ++l) {
+        const unsigned char st = ((unsigned char*)(hl + al(sizeof(double) * L)))[l];
+        if (!st) continue;
+        info->n_accepted++;
+        const int rows_l = (l + 1 < L ? row0[l + 1] : m_total) - row0[l];
+        const bool pre = any_pre && b->pre_rows[l] > 0;
+        info->n_rows += (st == 2 && !pre) ? 2 * b->n_meas[l] : rows_l;
+      }
+    }
+  };
+  const char* form_env = getenv("OVP_EKF_INFO_FORM");
+  const bool info_form_only = form_env && form_env[0] == '1';
+  if (!info_form_only && m_total <= ovp_init_max_rows() && ovp_init_core_lds(0, m_total, gcols) <= ovp_init_max_lds()) {
+    const int rows = m_total;
+    double* dres = c->smallbuf;
+    double* dM = dres + res_doubles;
+    double* dLi = dM + (size_t)n * rows;
+    double* dy = dLi + (size_t)rows * rows;
+    if ((size_t)(dy + rows + 8 - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
+    HIPCHK(ovp_launch_init_m(c->P, c->ld, n, dgid, gcols, c->Hd, rows, dM, s));
+    HIPCHK(ovp_launch_init_core(c->P, c->ld, n, dgid, gcols, c->Hd, 0, rows, dM, c->resd /* unused: k = 0 */, c->resd, c->resd, 1.0, 1e300,
+                                dLi, dy, dres, s));
+    HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, c->ld, n, dM, rows, 0, rows, dLi, dy, dres, dres + 4, s));
+    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * (4 + (size_t)n), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hl, c->slam_res, lres_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    finish_landmarks();
+    if (info) {
+      info->not_spd = hres_d[1] > 0.5 ? 0 : 1;
+      info->neg_diag = hres_d[2] != 0.0;
+    }
+    if (!(hres_d[1] > 0.5)) return OVP_E_NOTSPD;  // S = H P H^T + I lost definiteness: P is not a covariance; nothing was written
+    double* t = c->P;
+    c->P = c->P_tmp;
+    c->P_tmp = t;
+    if (dx_host) memcpy(dx_host, hres_d + 4, sizeof(double) * n);
+    return hres_d[2] != 0.0 ? OVP_E_NEGDIAG : 0;
+  }
+  // information form: A = H^T H, b = H^T r on the call's columns, scattered to the state
+  if (!c->Acc) HIPCHK(dalloc(&c->Acc, (size_t)c->n_max * c->n_max));
+  if (!c->bcc) HIPCHK(dalloc(&c->bcc, (size_t)c->n_max));
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  HIPCHK(ovp_launch_gemm(0, 1, gcols, gcols, m_total, c->Hd, m_total, c->Hd, m_total, c->Acc, gcols, 0, s));
+  HIPCHK(ovp_launch_gemm(0, 0, gcols, 1, m_total, c->Hd, m_total, c->resd, 1, c->bcc, 1, 0, s));
+  HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, s));
+  HIPCHK(ovp_launch_scatter_gram(c->Acc, c->bcc, gcols, dgid, c->Ab, c->ld, n, s));
+  {
+    std::vector<int> ids(gids);
+    std::sort(ids.begin(), ids.end());
+    int rs = set_substate(c, ids);
+    if (rs) return rs;
+  }
+  rc = ekf_from_gram(c, false);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(c->h_dx, c->dx, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(hl, c->slam_res, lres_bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  finish_landmarks();
+  if (c->h_flags[0]) {  // positive semi-definite prior: S-form instead of the factor of P
+    int rs = ekf_sform(c);
+    if (rs) return rs;
+  }
+  if (dx_host) memcpy(dx_host, c->h_dx, sizeof(double) * n);
+  if (info) {
     info->not_spd = c->h_flags[0];
     info->neg_diag = c->h_flags[1];
   }

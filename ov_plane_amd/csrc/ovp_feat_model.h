@@ -7,8 +7,12 @@
 namespace ovp {
 
 // lane <-> (observation a, row r); ci = clone slot of the observation.  Invalid lanes return zeros.
+// LM_FEJ: the feature is a landmark of the state with a first estimate of its own (pf_fej, update/UpdaterHelper.cpp:300-303, :381);
+// MSCKF features linearise at their value (fej == value, update/UpdaterMSCKF.cpp:499-500) and take the default instantiation.
+template <bool LM_FEJ = false>
 __device__ __forceinline__ void build_bearing_row(const FeatParams& p, int f, int a, int r, bool valid, int ci,
-                                                  double (&jrow)[6], double (&crow)[14], double (&hf)[3], double& res) {
+                                                  double (&jrow)[6], double (&crow)[14], double (&hf)[3], double& res,
+                                                  const double* pf_fej = nullptr) {
   const double* __restrict__ cal = p.cal;  // [0..8] R_ItoC, [9..11] p_IinC, [12..19] intrinsics (device memory)
   const double* Rc = cal;
   const double pIC0 = cal[9], pIC1 = cal[10], pIC2 = cal[11];
@@ -62,9 +66,15 @@ __device__ __forceinline__ void build_bearing_row(const FeatParams& p, int f, in
     if (p.do_fej) {
       R = p.clone_R_fej + 9 * ci;
       pp = p.clone_p_fej + 3 * ci;
-      d0 = pf0 - pp[0];
-      d1 = pf1 - pp[1];
-      d2 = pf2 - pp[2];
+      if constexpr (LM_FEJ) {
+        d0 = pf_fej[0] - pp[0];
+        d1 = pf_fej[1] - pp[1];
+        d2 = pf_fej[2] - pp[2];
+      } else {
+        d0 = pf0 - pp[0];
+        d1 = pf1 - pp[1];
+        d2 = pf2 - pp[2];
+      }
       pI0 = R[0] * d0 + R[1] * d1 + R[2] * d2;
       pI1 = R[3] * d0 + R[4] * d1 + R[5] * d2;
       pI2 = R[6] * d0 + R[7] * d1 + R[8] * d2;

@@ -2550,3 +2550,82 @@ def test_few_row_updates_on_a_singular_covariance_and_at_the_row_limit(hiplib):
         assert np.abs(dx - K @ res).max() < TOL_DX
         assert relP(ctx.cov_download(), sc.P - K @ Hf @ sc.P) < TOL_P
         ctx.close()
+
+
+def _slam_plane_args(sc, use_planes):
+    if not use_planes:
+        return None, None, None
+    pid = np.asarray(sc.plane_id, dtype=np.int64)
+    sid = np.where(pid > 0, np.asarray(sc.plane_state_id)[np.maximum(pid, 1) - 1], -1).astype(np.int32)
+    return sid, np.asarray(sc.cp)[np.maximum(pid, 1) - 1], np.asarray(sc.cp_fej)[np.maximum(pid, 1) - 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(C=11, n_slam=12, seed=3, outliers=2),
+    dict(C=11, n_slam=14, seed=4, n_planes=3, outliers=2, wrong_plane=3),   # plane rows + the no-plane fallback
+    dict(C=6, n_slam=5, seed=5, do_fej=False),
+    dict(C=8, n_slam=8, seed=6, fisheye=True),
+    dict(C=5, n_slam=20, seed=8, ragged=False, outliers=1),                 # 200 stacked rows: information form behind the gate
+    dict(C=4, n_slam=9, seed=9, ragged=False, n_planes=2, wrong_plane=2),   # <= 80 stacked rows with plane rows: S-form
+    dict(C=30, n_slam=6, seed=10, ragged=False, n_planes=2, wrong_plane=1, outliers=1),  # 90-row blocks (full-length tracks)
+])
+def test_slam_update_on_the_device_matches_oracle(hiplib, oracle, kw):
+    """ovp_slam_update (csrc/k_slam.hip) = UpdaterSLAM::update (update/UpdaterSLAM.cpp:424-673) without the covariance leaving the
+    device: rows of a landmark of the state, chi2 against the resident P, the no-plane fallback, stacking, EKFUpdate - statuses,
+    statistics, correction and covariance against ovo_slam_update."""
+    from ov_plane_amd.synth import make_slam_scene
+
+    capi = hiplib
+    sc = make_slam_scene(**kw)
+    use_planes = kw.get("n_planes", 0) > 0
+    ref = oracle.slam_update(sc, sc.lm_id, use_planes=use_planes)
+    assert ref["rc"] == 0
+    ctx = capi.Context(sc.N, sc.C, sc.F, device=0)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    sid, cp, cpf = _slam_plane_args(sc, use_planes)
+    out = ctx.slam_update(capi.opts_from_scene(sc), sc.uv, sc.clone_idx, sc.n_meas, sc.p_FinG, sc.p_FinG_fej, sc.lm_id, sid, cp, cpf)
+    assert ((out["status"] > 0) == ref["accepted"]).all()
+    assert ((out["status"] == 2) == (ref["fellback"] & ref["accepted"])).all()
+    if kw.get("wrong_plane", 0):
+        assert (out["status"] == 2).any()
+    if kw.get("outliers", 0):
+        assert (out["status"] == 0).any()
+    big = ref["chi2"] < 1e200
+    assert np.abs(out["chi2"][big] - ref["chi2"][big]).max() <= 1e-8 * max(1.0, np.abs(ref["chi2"][big]).max())
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    assert out["info"].n_accepted == int(ref["accepted"].sum())
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rep", [1, 2, 3, 4])
+def test_slam_update_on_the_device_with_host_built_blocks(hiplib, oracle, rep):
+    """Landmarks in an anchored / inverse-depth representation hand their dense block [H_x | H_f] to ovp_slam_update (pre_*), the
+    gate against the resident covariance and the update are the device's: against ovo_slam_update_rep; one GLOBAL_3D landmark
+    built on the device rides in the same call."""
+    from ov_plane_amd.synth import make_slam_scene
+
+    capi = hiplib
+    sc = make_slam_scene(C=8, n_slam=8, seed=6, outliers=1)
+    anchor = 2
+    reps = np.full(sc.F, rep)
+    reps[0] = 0
+    ref = oracle.slam_update(sc, sc.lm_id, rep=reps, anchor=np.full(sc.F, anchor))
+    assert ref["rc"] == 0 and not ref["accepted"].all()
+    pre = [None]
+    for f in range(1, sc.F):
+        Hf, Hx, res, order = oracle.feature_jacobian_full_rep(sc, f, rep, anchor)
+        ids = [i + k for (i, s) in order for k in range(s)] + [int(sc.lm_id[f]) + k for k in range(Hf.shape[1])]
+        pre.append((np.hstack([Hx, Hf]), ids, res))
+    ctx = capi.Context(sc.N, sc.C, sc.F, device=0)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    out = ctx.slam_update(capi.opts_from_scene(sc), sc.uv, sc.clone_idx, sc.n_meas, sc.p_FinG, sc.p_FinG_fej, sc.lm_id, pre=pre)
+    assert ((out["status"] > 0) == ref["accepted"]).all()
+    assert np.abs(out["chi2"] - ref["chi2"]).max() <= 1e-8 * max(1.0, np.abs(ref["chi2"]).max())
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    ctx.close()
