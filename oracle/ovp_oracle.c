@@ -1663,7 +1663,8 @@ int ovo_slam_update_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats 
     accepted[f] = 0;
     chi2_out[f] = 0.0;
     fellback[f] = 0;
-    if (fb->n_meas[f] < 1) continue; /* :416-418 */
+    if (fb->n_meas[f] < 1) continue; /* :412-415 */
+    if (lm_rep && lm_rep[f] == 5 && fb->n_meas[f] < 2) continue; /* :409-410, :416-418 required_meas = 2 */
     int planeid = 0, psid = -1;
     const double *cpv = NULL, *cpf = NULL;
     if (n_planes > 0 && plane_of_feat && plane_of_feat[f] > 0 && plane_state_id[plane_of_feat[f] - 1] >= 0) { /* :465-475 */
@@ -1678,7 +1679,22 @@ int ovo_slam_update_rep(const ovo_opts *o, const ovo_state *st, const ovo_feats 
     if (rep != 0 && planeid != 0) return -30;
     for (int attempt = 0; attempt < 2; ++attempt) {
       int nlm = 3;
-      if (rep != 0) {
+      if (rep == 5) {
+        /* :478-481 linearised as the MSCKF inverse depth; :499-515 the depth column joins the state side and the two bearing
+         * columns are projected out of [H_x | depth | res] (UpdaterHelper::nullspace_project_inplace) */
+        ovo_feature_jacobian_full_rep(o, st, fb, f, 4, lm_anchor[f], H_f, H_x, res, &rows, &cols, &hfc, oid, osz, &no);
+        for (int i = 0; i < rows; ++i) CM(H_x, rows, i, cols) = CM(H_f, rows, i, 2);
+        ovo_nullspace_project(H_f, rows, 2, H_x, cols + 1, NULL, 0, res);
+        const int r2 = rows - 2;
+        for (int j = 0; j <= cols; ++j)
+          for (int i = 0; i < r2; ++i) CM(H_xf, r2, i, j) = CM(H_x, rows, i + 2, j);
+        for (int j = 0; j < cols; ++j)
+          for (int i = 0; i < r2; ++i) H_x[(size_t)j * r2 + i] = CM(H_xf, r2, i, j);
+        for (int i = 0; i < r2; ++i) H_f[i] = CM(H_xf, r2, i, cols);
+        for (int i = 0; i < r2; ++i) res[i] = res[i + 2];
+        rows = r2;
+        nlm = 1;
+      } else if (rep != 0) {
         ovo_feature_jacobian_full_rep(o, st, fb, f, rep, lm_anchor[f], H_f, H_x, res, &rows, &cols, &hfc, oid, osz, &no);
         nlm = hfc;
       } else {

@@ -224,6 +224,9 @@ public:
                     const std::map<size_t, size_t> &feat2plane);
   // update/UpdaterSLAM.cpp:684-706: landmarks anchored in the clone that is about to be marginalised move to the newest one
   void change_anchors(std::shared_ptr<State> state);
+  // pose tables of the clone window + camera calibration -> device (ovp_state_upload); clone_slot: timestamp -> clone slot
+  static void upload_state_tables(std::shared_ptr<State> state, std::map<double, int> &clone_slot,
+                                  std::vector<std::shared_ptr<ov_type::PoseJPL>> &clones);
 
 protected:
   // update/UpdaterSLAM.cpp:708-850: new anchor-frame value of the landmark and covariance propagation with the

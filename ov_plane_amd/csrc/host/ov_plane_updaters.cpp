@@ -444,6 +444,44 @@ void UpdaterHelper::measurement_compress_inplace(MatrixXd &H_x, VectorXd &res) {
   res = res.block(0, 0, r, 1);
 }
 
+// Pose tables of the clone window + camera calibration -> device (ovp_state_upload); clone_slot: timestamp -> clone slot
+void UpdaterSLAM::upload_state_tables(std::shared_ptr<State> state, std::map<double, int> &clone_slot,
+                                      std::vector<std::shared_ptr<PoseJPL>> &clones) {
+  clone_slot.clear();
+  clones.clear();
+  for (const auto &c : state->_clones_IMU) {
+    clone_slot[c.first] = (int)clones.size();
+    clones.push_back(c.second);
+  }
+  const int C = (int)clones.size();
+  std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
+  std::vector<int> cid(C);
+  for (int i = 0; i < C; ++i) {
+    memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
+    memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
+    memcpy(&cqf[4 * i], clones[i]->quat_fej(), 4 * sizeof(double));
+    memcpy(&cpf[3 * i], clones[i]->pos_fej(), 3 * sizeof(double));
+    cid[i] = clones[i]->id();
+  }
+  ovp_state_tables st;
+  st.n_state = ovp_cov_size(state->_gpu);
+  st.n_clones = C;
+  st.clone_q = cq.data();
+  st.clone_p = cp.data();
+  st.clone_q_fej = cqf.data();
+  st.clone_p_fej = cpf.data();
+  st.clone_id = cid.data();
+  auto calib = state->_calib_IMUtoCAM.at(0);
+  auto intr = state->_cam_intrinsics.at(0);
+  memcpy(st.calib_q, calib->quat(), 4 * sizeof(double));
+  memcpy(st.calib_p, calib->pos(), 3 * sizeof(double));
+  st.calib_id = calib->id();
+  memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
+  st.intr_id = intr->id();
+  st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
+  gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");  // (the tables are staged inside the call)
+}
+
 // ---- update/UpdaterSLAM.cpp ----------------------------------------------------------------------
 UpdaterSLAM::UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_aruco, ov_core::FeatureInitializerOptions &fio)
     : _options_slam(options_slam), _options_aruco(options_aruco), _featinit(fio) {
@@ -470,101 +508,89 @@ static void clean_old_measurements(ov_core::Feature &ft, const std::map<double, 
   ft.uvs_norm = uvn2;
 }
 
-// P_full: the covariance downloaded once by the caller (it does not change inside UpdaterSLAM::update's gate loop, so the
-// per-feature StateHelper::get_marginal_covariance of :526 becomes a host-side gather instead of a device round trip each)
-static double chi2_host(const MatrixXd &P_full, const std::vector<std::shared_ptr<Type>> &order, const MatrixXd &H, const VectorXd &res) {
-  std::vector<int> gid;
-  for (const auto &v : order)
-    for (int k = 0; k < v->size(); ++k) gid.push_back(v->id() + k);
-  MatrixXd P_marg((int)gid.size(), (int)gid.size());
-  for (size_t b = 0; b < gid.size(); ++b)
-    for (size_t a = 0; a < gid.size(); ++a) P_marg((int)a, (int)b) = P_full(gid[a], gid[b]);
-  const int rows = H.rows(), cols = H.cols();
-  MatrixXd HP(rows, cols);
-  for (int k = 0; k < cols; ++k)
-    for (int j = 0; j < cols; ++j) {
-      const double pv = P_marg(k, j);
-      for (int i = 0; i < rows; ++i) HP(i, j) += H(i, k) * pv;
-    }
-  MatrixXd S = MatrixXd::Identity(rows, rows);
-  for (int k = 0; k < cols; ++k)
-    for (int j = 0; j < rows; ++j) {
-      const double hv = H(j, k);
-      for (int i = 0; i < rows; ++i) S(i, j) += HP(i, k) * hv;
-    }
-  // LLT
-  for (int j = 0; j < rows; ++j) {
-    double d = S(j, j);
-    for (int k = 0; k < j; ++k) d -= S(j, k) * S(j, k);
-    if (!(d > 0)) return 1e300;
-    d = std::sqrt(d);
-    S(j, j) = d;
-    for (int i = j + 1; i < rows; ++i) {
-      double s = S(i, j);
-      for (int k = 0; k < j; ++k) s -= S(i, k) * S(j, k);
-      S(i, j) = s / d;
-    }
-  }
-  double chi2 = 0.0;
-  VectorXd y = res;
-  for (int i = 0; i < rows; ++i) {
-    double s = y(i);
-    for (int k = 0; k < i; ++k) s -= S(i, k) * y(k);
-    y(i) = s / S(i, i);
-    chi2 += y(i) * y(i);
-  }
-  return chi2;
-}
-
+// update/UpdaterSLAM.cpp:376-682.  The rows of a GLOBAL_3D landmark, every chi2 test (against the RESIDENT covariance), the
+// no-plane fallback, the stacking and StateHelper::EKFUpdate are one device call (ovp_slam_update, csrc/k_slam.hip); what stays
+// here is the bookkeeping of the feature vector and the representation Jacobians of landmarks that are not GLOBAL_3D
+// (update/UpdaterHelper.cpp:35-193), whose dense blocks ride in the same call.
 void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                          const std::map<size_t, size_t> &feat2plane) {
   if (feature_vec.empty()) return;
+  typedef LandmarkRepresentation LR;
   // :391-419
   auto it0 = feature_vec.begin();
   while (it0 != feature_vec.end()) {
     clean_old_measurements(**it0, state->_clones_IMU);
-    if ((*it0)->timestamps.size() < 1) {
+    const int ct_meas = (int)(*it0)->timestamps.size();
+    std::shared_ptr<Landmark> landmark = state->_features_SLAM.at((*it0)->featid);
+    const int required_meas = (landmark->_feat_representation == LR::ANCHORED_INVERSE_DEPTH_SINGLE) ? 2 : 1;  // :409-410
+    if (ct_meas < 1) {
       (*it0)->to_delete = true;
       it0 = feature_vec.erase(it0);
+    } else if (ct_meas < required_meas) {
+      it0 = feature_vec.erase(it0);  // :416-418 (not flagged)
     } else {
       it0++;
     }
   }
-  std::vector<std::pair<std::shared_ptr<Type>, size_t>> Hx_mapping;
-  std::vector<std::shared_ptr<Type>> Hx_order_big;
-  size_t ct_jacob = 0, ct_meas = 0;
-  struct Blk {
-    MatrixXd H;
-    VectorXd r;
-    std::vector<std::shared_ptr<Type>> order;
-  };
-  std::vector<Blk> blocks;
   if (feature_vec.empty()) return;
-  const MatrixXd P_full = StateHelper::get_full_covariance(state);  // one download serves every gate below
-  auto it2 = feature_vec.begin();
-  while (it2 != feature_vec.end()) {
-    std::shared_ptr<Landmark> landmark = state->_features_SLAM.at((*it2)->featid);
-    UpdaterHelper::UpdaterHelperFeature feat;
-    feat.featid = (*it2)->featid;
-    feat.uvs = (*it2)->uvs;
-    feat.timestamps = (*it2)->timestamps;
+  std::map<double, int> clone_slot;
+  std::vector<std::shared_ptr<PoseJPL>> clones;
+  UpdaterSLAM::upload_state_tables(state, clone_slot, clones);
+  const int L = (int)feature_vec.size();
+  int M = 1;
+  for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
+  if (M > OVP_MAX_MEAS) {
+    fprintf(stderr, "UpdaterSLAM::update() - more than %d observations of a landmark are not supported\n", OVP_MAX_MEAS);
+    std::exit(EXIT_FAILURE);
+  }
+  std::vector<float> uv((size_t)L * M * 2, 0.f);
+  std::vector<int> cidx((size_t)L * M, -1), nm(L), lmid(L), psid(L, -1), pre_rows(L, 0), pre_cols(L, 0), pre_ids;
+  std::vector<double> pv((size_t)L * 3, 0.0), pf((size_t)L * 3, 0.0), cpv((size_t)L * 3, 0.0), cpf((size_t)L * 3, 0.0), pre_H;
+  std::vector<size_t> planeid(L, 0);
+  bool any_pre = false, any_plane = false;
+  const double sigma_c = state->_options.sigma_constraint;
+  for (int l = 0; l < L; ++l) {
+    ov_core::Feature &ft = *feature_vec[l];
+    std::shared_ptr<Landmark> landmark = state->_features_SLAM.at(ft.featid);
+    nm[l] = (int)ft.timestamps.size();
+    lmid[l] = landmark->id();
+    for (int k = 0; k < nm[l]; ++k) {
+      cidx[(size_t)l * M + k] = clone_slot.at(ft.timestamps[k]);
+      uv[((size_t)l * M + k) * 2] = ft.uvs[2 * k];
+      uv[((size_t)l * M + k) * 2 + 1] = ft.uvs[2 * k + 1];
+    }
     // :465-475
-    if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamu &&
-        feat2plane.find((*it2)->featid) != feat2plane.end() &&
-        state->_features_PLANE.find(feat2plane.at((*it2)->featid)) != state->_features_PLANE.end()) {
-      if (state->_features_SLAM_to_PLANE.find((*it2)->featid) == state->_features_SLAM_to_PLANE.end() ||
-          state->_features_SLAM_to_PLANE.at((*it2)->featid) != 0) {
-        feat.planeid = feat2plane.at((*it2)->featid);
-        auto pl = state->_features_PLANE.at(feat.planeid);
+    if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamu && feat2plane.find(ft.featid) != feat2plane.end() &&
+        state->_features_PLANE.find(feat2plane.at(ft.featid)) != state->_features_PLANE.end()) {
+      if (state->_features_SLAM_to_PLANE.find(ft.featid) == state->_features_SLAM_to_PLANE.end() ||
+          state->_features_SLAM_to_PLANE.at(ft.featid) != 0) {
+        planeid[l] = feat2plane.at(ft.featid);
+        auto pl = state->_features_PLANE.at(planeid[l]);
+        psid[l] = pl->id();
         for (int k = 0; k < 3; ++k) {
-          feat.cp_FinG[k] = pl->value()(k);
-          feat.cp_FinG_fej[k] = pl->fej()(k);
+          cpv[3 * l + k] = pl->value()(k);
+          cpf[3 * l + k] = pl->fej()(k);
         }
+        any_plane = true;
       }
     }
-    // :478-493 the landmark in its own representation
-    feat.feat_representation = landmark->_feat_representation;
-    if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
+    if (landmark->_feat_representation == LR::GLOBAL_3D) {
+      landmark->get_xyz(false, &pv[3 * l]);
+      landmark->get_xyz(true, &pf[3 * l]);
+      continue;
+    }
+    // :478-522 the landmark in its own representation: dense block [H_x | H_f] from the host
+    if (planeid[l] != 0) {  // update/UpdaterHelper.cpp:455-456 asserts GLOBAL_3D for the point-on-plane rows
+      fprintf(stderr, "UpdaterSLAM::update() - point-on-plane rows need a GLOBAL_3D landmark\n");
+      std::exit(EXIT_FAILURE);
+    }
+    UpdaterHelper::UpdaterHelperFeature feat;
+    feat.featid = ft.featid;
+    feat.uvs = ft.uvs;
+    feat.timestamps = ft.timestamps;
+    const bool single = landmark->_feat_representation == LR::ANCHORED_INVERSE_DEPTH_SINGLE;
+    feat.feat_representation = single ? LR::ANCHORED_MSCKF_INVERSE_DEPTH : landmark->_feat_representation;  // :478-481
+    if (LR::is_relative_representation(feat.feat_representation)) {
       feat.anchor_cam_id = landmark->_anchor_cam_id;
       feat.anchor_clone_timestamp = landmark->_anchor_clone_timestamp;
       landmark->get_xyz(false, feat.p_FinA);
@@ -573,72 +599,93 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
       landmark->get_xyz(false, feat.p_FinG);
       landmark->get_xyz(true, feat.p_FinG_fej);
     }
-    MatrixXd H_f, H_x, H_xf;
+    MatrixXd H_f, H_x;
     VectorXd res;
-    std::vector<std::shared_ptr<Type>> Hx_order, Hxf_order;
-    const double sigma_c = state->_options.sigma_constraint;
-    const double sigma_px = _options_slam.sigma_pix;
-    const double chi2_multipler = _options_slam.chi2_multipler;
-    auto build = [&]() {
-      UpdaterHelper::get_feature_jacobian_full(state, feat, sigma_px, sigma_c, H_f, H_x, res, Hx_order);
-      H_xf = MatrixXd(H_x.rows(), H_x.cols() + H_f.cols());  // :517-522
+    std::vector<std::shared_ptr<Type>> Hx_order;
+    UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
+    MatrixXd H_xf;
+    if (single) {  // :499-515 the depth column joins the state side, the bearing is projected out
+      H_xf = MatrixXd(H_x.rows(), H_x.cols() + 1);
+      for (int j = 0; j < H_x.cols(); ++j)
+        for (int i = 0; i < H_x.rows(); ++i) H_xf(i, j) = H_x(i, j);
+      for (int i = 0; i < H_x.rows(); ++i) H_xf(i, H_x.cols()) = H_f(i, H_f.cols() - 1);
+      MatrixXd H_b = H_f.block(0, 0, H_f.rows(), H_f.cols() - 1);
+      UpdaterHelper::nullspace_project_inplace(H_b, H_xf, res);
+    } else {  // :517-522
+      H_xf = MatrixXd(H_x.rows(), H_x.cols() + H_f.cols());
       for (int j = 0; j < H_x.cols(); ++j)
         for (int i = 0; i < H_x.rows(); ++i) H_xf(i, j) = H_x(i, j);
       for (int j = 0; j < H_f.cols(); ++j)
         for (int i = 0; i < H_x.rows(); ++i) H_xf(i, H_x.cols() + j) = H_f(i, j);
-      Hxf_order = Hx_order;
-      Hxf_order.push_back(landmark);
-    };
-    build();
-    double chi2 = chi2_host(P_full, Hxf_order, H_xf, res);  // :529-532
-    double chi2_check = ovp_chi2_quantile_095(res.rows());
-    if (feat.planeid != 0 && chi2 > chi2_multipler * chi2_check) {  // :547-609 fallback without the plane
-      feat.planeid = 0;
-      state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;
-      build();
-      chi2 = chi2_host(P_full, Hxf_order, H_xf, res);
-      chi2_check = ovp_chi2_quantile_095(res.rows());
     }
-    if (chi2 > chi2_multipler * chi2_check) {  // :596-619
-      landmark->should_marg = true;
+    pre_rows[l] = H_xf.rows();
+    pre_cols[l] = H_xf.cols();
+    for (int j = 0; j < H_xf.cols(); ++j)
+      for (int i = 0; i < H_xf.rows(); ++i) pre_H.push_back(H_xf(i, j));
+    for (int i = 0; i < res.rows(); ++i) pre_H.push_back(res(i));
+    for (const auto &v : Hx_order)
+      for (int k = 0; k < v->size(); ++k) pre_ids.push_back(v->id() + k);
+    for (int k = 0; k < landmark->size(); ++k) pre_ids.push_back(landmark->id() + k);
+    any_pre = true;
+  }
+  ovp_slam_batch sb;
+  memset(&sb, 0, sizeof(sb));
+  sb.n_landmarks = L;
+  sb.max_meas = M;
+  sb.uv = uv.data();
+  sb.clone_idx = cidx.data();
+  sb.n_meas = nm.data();
+  sb.p_FinG = pv.data();
+  sb.p_FinG_fej = pf.data();
+  sb.landmark_id = lmid.data();
+  if (any_plane) {
+    sb.plane_state_id = psid.data();
+    sb.cp = cpv.data();
+    sb.cp_fej = cpf.data();
+  }
+  if (any_pre) {
+    sb.pre_rows = pre_rows.data();
+    sb.pre_cols = pre_cols.data();
+    sb.pre_H = pre_H.data();
+    sb.pre_ids = pre_ids.data();
+  }
+  ovp_update_opts uo;
+  memset(&uo, 0, sizeof(uo));
+  uo.sigma_px = _options_slam.sigma_pix;
+  uo.chi2_multiplier = _options_slam.chi2_multipler;
+  uo.sigma_constraint = sigma_c;
+  uo.do_fej = state->_options.do_fej ? 1 : 0;
+  uo.do_calib_camera_pose = state->_options.do_calib_camera_pose ? 1 : 0;
+  uo.do_calib_camera_intrinsics = state->_options.do_calib_camera_intrinsics ? 1 : 0;
+  const int n = ovp_cov_size(state->_gpu);
+  std::vector<double> dx(n, 0.0);
+  std::vector<uint8_t> status(L, 0);
+  ovp_update_info info;
+  const int rc = ovp_slam_update(state->_gpu, &uo, &sb, dx.data(), status.data(), nullptr, &info);
+  if (rc == OVP_E_NEGDIAG) {
+    fprintf(stderr, "StateHelper::EKFUpdate() - negative covariance diagonal\n");
+    std::exit(EXIT_FAILURE);
+  }
+  gpu_check2(rc, "ovp_slam_update");
+  // :547-624 side effects of the gate, in the order of the vector
+  size_t l = 0;
+  auto it2 = feature_vec.begin();
+  while (it2 != feature_vec.end()) {
+    const uint8_t st = status[l];
+    const size_t pid = planeid[l];
+    ++l;
+    if (st == 2 || (st == 0 && pid != 0)) state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;  // :551 (set before the second test)
+    if (st == 0) {  // :596-619
+      state->_features_SLAM.at((*it2)->featid)->should_marg = true;
       (*it2)->to_delete = true;
       it2 = feature_vec.erase(it2);
       continue;
     }
-    if (feat.planeid != 0) state->_features_SLAM_to_PLANE[(*it2)->featid] = feat.planeid;  // :623-624
-    for (const auto &var : Hxf_order) {  // :634-646
-      bool found = false;
-      for (auto &p : Hx_mapping) found = found || (p.first == var);
-      if (!found) {
-        Hx_mapping.push_back({var, ct_jacob});
-        Hx_order_big.push_back(var);
-        ct_jacob += var->size();
-      }
-    }
-    blocks.push_back({H_xf, res, Hxf_order});
-    ct_meas += res.rows();
+    if (st == 1 && pid != 0) state->_features_SLAM_to_PLANE[(*it2)->featid] = pid;  // :623-624
     it2++;
   }
   for (size_t f = 0; f < feature_vec.size(); f++) feature_vec[f]->to_delete = true;  // :657-659
-  if (ct_meas < 1) return;
-  MatrixXd Hx_big = MatrixXd::Zero((int)ct_meas, (int)ct_jacob);
-  VectorXd res_big = VectorXd::Zero((int)ct_meas, 1);
-  int r0 = 0;
-  for (auto &b : blocks) {
-    int ct_hx = 0;
-    for (const auto &var : b.order) {
-      size_t col = 0;
-      for (auto &p : Hx_mapping)
-        if (p.first == var) col = p.second;
-      for (int j = 0; j < var->size(); ++j)
-        for (int i = 0; i < b.H.rows(); ++i) Hx_big(r0 + i, (int)col + j) = b.H(i, ct_hx + j);
-      ct_hx += var->size();
-    }
-    for (int i = 0; i < b.r.rows(); ++i) res_big(r0 + i) = b.r(i);
-    r0 += b.r.rows();
-  }
-  MatrixXd R_big = MatrixXd::Identity((int)ct_meas, (int)ct_meas);
-  StateHelper::EKFUpdate(state, Hx_order_big, Hx_big, res_big, R_big);  // :673
+  if (info.n_accepted > 0) StateHelper::apply_correction(state, dx.data());  // :673 Type::update of every variable
 }
 
 // update/UpdaterSLAM.cpp:120-166 (the same block opens UpdaterMSCKF::update and UpdaterPlane::init_vio_plane): features that
@@ -651,37 +698,8 @@ void UpdaterSLAM::triangulate_on_device(std::shared_ptr<State> state, const ov_c
   if (!any_norm) return;
   std::map<double, int> clone_slot;
   std::vector<std::shared_ptr<PoseJPL>> clones;
-  for (const auto &c : state->_clones_IMU) {
-    clone_slot[c.first] = (int)clones.size();
-    clones.push_back(c.second);
-  }
+  UpdaterSLAM::upload_state_tables(state, clone_slot, clones);
   const int C = (int)clones.size(), F = (int)feature_vec.size();
-  std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
-  std::vector<int> cid(C);
-  for (int i = 0; i < C; ++i) {
-    memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
-    memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
-    memcpy(&cqf[4 * i], clones[i]->quat_fej(), 4 * sizeof(double));
-    memcpy(&cpf[3 * i], clones[i]->pos_fej(), 3 * sizeof(double));
-    cid[i] = clones[i]->id();
-  }
-  ovp_state_tables st;
-  st.n_state = ovp_cov_size(state->_gpu);
-  st.n_clones = C;
-  st.clone_q = cq.data();
-  st.clone_p = cp.data();
-  st.clone_q_fej = cqf.data();
-  st.clone_p_fej = cpf.data();
-  st.clone_id = cid.data();
-  auto calib = state->_calib_IMUtoCAM.at(0);
-  auto intr = state->_cam_intrinsics.at(0);
-  memcpy(st.calib_q, calib->quat(), 4 * sizeof(double));
-  memcpy(st.calib_p, calib->pos(), 3 * sizeof(double));
-  st.calib_id = calib->id();
-  memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
-  st.intr_id = intr->id();
-  st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
-  gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
   int M = 1;
   for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
   std::vector<float> uv((size_t)F * M * 2, 0.f), uvn((size_t)F * M * 2, 0.f);
@@ -1051,37 +1069,10 @@ void UpdaterPlane::init_vio_plane(std::shared_ptr<State> state, std::vector<std:
   if (feature_vec.empty() || feat2plane.empty()) return;
   std::map<double, int> clone_slot;
   std::vector<std::shared_ptr<PoseJPL>> clones;
-  for (const auto &c : state->_clones_IMU) {
-    clone_slot[c.first] = (int)clones.size();
-    clones.push_back(c.second);
-  }
-  const int C = (int)clones.size();
-  std::vector<double> cq(4 * C), cp(3 * C), cqf(4 * C), cpf(3 * C);
-  std::vector<int> cid(C);
-  for (int i = 0; i < C; ++i) {
-    memcpy(&cq[4 * i], clones[i]->quat(), 4 * sizeof(double));
-    memcpy(&cp[3 * i], clones[i]->pos(), 3 * sizeof(double));
-    memcpy(&cqf[4 * i], clones[i]->quat_fej(), 4 * sizeof(double));
-    memcpy(&cpf[3 * i], clones[i]->pos_fej(), 3 * sizeof(double));
-    cid[i] = clones[i]->id();
-  }
-  ovp_state_tables st;
-  st.n_state = ovp_cov_size(state->_gpu);
-  st.n_clones = C;
-  st.clone_q = cq.data();
-  st.clone_p = cp.data();
-  st.clone_q_fej = cqf.data();
-  st.clone_p_fej = cpf.data();
-  st.clone_id = cid.data();
+  UpdaterSLAM::upload_state_tables(state, clone_slot, clones);
   auto calib = state->_calib_IMUtoCAM.at(0);
   auto intr = state->_cam_intrinsics.at(0);
-  memcpy(st.calib_q, calib->quat(), 4 * sizeof(double));
-  memcpy(st.calib_p, calib->pos(), 3 * sizeof(double));
-  st.calib_id = calib->id();
-  memcpy(st.intrinsics, intr->value().data(), 8 * sizeof(double));
-  st.intr_id = intr->id();
-  st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
-  gpu_check2(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
+  const int C = (int)clones.size();
   auto upload = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv, int &M_out) {
     const int Fn = (int)fv.size();
     int Mx = 1;

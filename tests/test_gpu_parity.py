@@ -2629,3 +2629,37 @@ def test_slam_update_on_the_device_with_host_built_blocks(hiplib, oracle, rep):
     assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
     assert relP(ctx.cov_download(), ref["P"]) < TOL_P
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_slam_update_on_the_device_single_inverse_depth(hiplib, oracle):
+    """ANCHORED_INVERSE_DEPTH_SINGLE landmarks (update/UpdaterSLAM.cpp:478-515): linearised as the MSCKF inverse depth, the depth
+    column moved to the state side, the bearing projected out - here with a Householder basis of the left nullspace instead of the
+    reference's Givens sweep (same row space: the statistic, the correction and the covariance do not depend on the basis).  A
+    landmark with one observation is left out (required_meas = 2, :409-418)."""
+    from ov_plane_amd.synth import make_slam_scene
+
+    capi = hiplib
+    sc = make_slam_scene(C=8, n_slam=8, seed=6, outliers=1)
+    sc.n_meas[3] = 1
+    anchor = 2
+    ref = oracle.slam_update(sc, sc.lm_id, rep=np.full(sc.F, 5), anchor=np.full(sc.F, anchor))
+    assert ref["rc"] == 0 and not ref["accepted"][3] and ref["accepted"].sum() >= 5 and not ref["accepted"][-1]
+    keep = [f for f in range(sc.F) if sc.n_meas[f] >= 2]
+    pre = []
+    for f in keep:
+        Hf, Hx, res, order = oracle.feature_jacobian_full_rep(sc, f, 4, anchor)
+        Q, _ = np.linalg.qr(Hf[:, :2], mode="complete")
+        N = Q[:, 2:]
+        ids = [i + k for (i, s) in order for k in range(s)] + [int(sc.lm_id[f])]
+        pre.append((N.T @ np.hstack([Hx, Hf[:, 2:3]]), ids, N.T @ res))
+    ctx = capi.Context(sc.N, sc.C, sc.F, device=0)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    out = ctx.slam_update(capi.opts_from_scene(sc), sc.uv[keep], sc.clone_idx[keep], sc.n_meas[keep], sc.p_FinG[keep],
+                          sc.p_FinG_fej[keep], sc.lm_id[keep], pre=pre)
+    assert ((out["status"] > 0) == ref["accepted"][keep]).all()
+    assert np.abs(out["chi2"] - ref["chi2"][keep]).max() <= 1e-8 * max(1.0, np.abs(ref["chi2"]).max())
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    ctx.close()
