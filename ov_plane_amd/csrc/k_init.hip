@@ -16,6 +16,8 @@
 namespace ovp {
 
 #define IM_ROWS 8
+#define IC_MAX_COLS 704  // = OVP_LDG_CAP: columns of one dense block
+#define IC_MAXE 13  // elements of [S | res | I] a thread of k_init_core owns: ceil(80 * 161 / 1024)
 // grid = ceil(n / 8), 256 threads = 8 rows x 32 column lanes; dynamic LDS: 8 x cols doubles (+ cols x m for H^T, hs_in_lds)
 __global__ __launch_bounds__(256) void k_init_m(const double* __restrict__ P, int ldp, int n, const int* __restrict__ ids, int cols,
                                                  const double* __restrict__ Ht, int m, double* __restrict__ Mall, int hs_in_lds) {
@@ -49,6 +51,34 @@ __global__ __launch_bounds__(256) void k_init_m(const double* __restrict__ P, in
   }
 }
 
+template <int NE>
+__device__ __forceinline__ void ic_eliminate(double* Wm, int ldw, int rup, int W, int t, int* bad) {
+  const int tot = rup * W;
+  double v[NE];
+  int ei[NE], ej[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    const int e = t + 1024 * q;
+    ei[q] = e < tot ? e / W : 0;      // (an element of row 0 is never touched: i > c fails for every c)
+    ej[q] = e < tot ? e - ei[q] * W : 0;
+    v[q] = Wm[ei[q] * ldw + ej[q]];
+  }
+  for (int c = 0; c < rup; ++c) {
+    const double* rc = Wm + c * ldw;
+    const double piv = rc[c];
+    if (t == 0 && !(piv > 0.0)) *bad = 1;
+    const double ip = 1.0 / piv;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      if (ei[q] > c && ej[q] > c) {
+        v[q] = fma(-(rc[ei[q]] * ip), rc[ej[q]], v[q]);
+        if (ei[q] == c + 1) Wm[(c + 1) * ldw + ej[q]] = v[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // One workgroup of 1024.  Dynamic LDS: Mg [cols][m] | Wm [rup][2 rup + 2] | Hs [cols][m] (only when it fits, hs_in_lds).
 //   res[0] = chi2, res[1] = 1 accept / 0 reject (a non-positive pivot of S rejects), res[2] = 0 (the update's negative-diagonal
 //   mark).  With rup == 0 there is no gate: res = {0, 1, 0}.
@@ -72,9 +102,13 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
   __shared__ int bad;
   if (t == 0) bad = 0;
   if (t < k * k) Hi[t] = Hinv[t];
+  __shared__ int ids_s[IC_MAX_COLS];  // (the gather below then has ONE global load per element, not a dependent pair)
+  for (int e = t; e < cols; e += 1024) ids_s[e] = ids[e];
+  __syncthreads();
+#pragma unroll 4
   for (int e = t; e < cols * m; e += 1024) {
     const int a = e / m, j = e - a * m;
-    Mg[e] = Mall[(size_t)ids[a] * m + j];
+    Mg[e] = Mall[(size_t)ids_s[a] * m + j];
     if (hs_in_lds) Hl[e] = Ht[e];
   }
   for (int e = t; e < rup * (rup + 1); e += 1024) {  // [res | I]
@@ -85,7 +119,32 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
   const double* Hs = hs_in_lds ? Hl : Ht;
   // S = H_up M_up[ids] + r I ;  Minit = H_init M_init[ids] + R (upper triangle mirrored, selfadjointView<Upper>) ;
   // X = H_init M_up[ids]  (k x rup)
-  for (int e = t; e < rup * rup + k * k + k * rup; e += 1024) {
+  // many update rows (a frame's landmark re-observations): S in 2 x 2 register blocks - four LDS reads per four FMAs instead of
+  // eight (the element-per-thread loop below is bound by the LDS bandwidth at 50 rows x 95 columns: 15 us)
+  const bool blocked = rup >= 24;
+  if (blocked) {
+    const int rb = (rup + 1) >> 1;
+    for (int e = t; e < rb * rb; e += 1024) {
+      const int i2 = e / rb, j2 = e - i2 * rb;
+      const int i0 = 2 * i2, j0 = 2 * j2;
+      const int i1 = i0 + 1 < rup ? i0 + 1 : i0, j1 = j0 + 1 < rup ? j0 + 1 : j0;
+      double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+#pragma unroll 4
+      for (int a = 0; a < cols; ++a) {
+        const double h0 = Hs[(size_t)a * m + k + i0], h1 = Hs[(size_t)a * m + k + i1];
+        const double m0 = Mg[a * m + k + j0], m1 = Mg[a * m + k + j1];
+        s00 = fma(h0, m0, s00);
+        s01 = fma(h0, m1, s01);
+        s10 = fma(h1, m0, s10);
+        s11 = fma(h1, m1, s11);
+      }
+      Wm[i0 * ldw + j0] = s00 + (i0 == j0 ? r_iso : 0.0);
+      if (j1 != j0) Wm[i0 * ldw + j1] = s01 + (i0 == j1 ? r_iso : 0.0);
+      if (i1 != i0) Wm[i1 * ldw + j0] = s10 + (i1 == j0 ? r_iso : 0.0);
+      if (i1 != i0 && j1 != j0) Wm[i1 * ldw + j1] = s11 + (i1 == j1 ? r_iso : 0.0);
+    }
+  }
+  for (int e = t + (blocked ? rup * rup : 0); e < rup * rup + k * k + k * rup; e += 1024) {
     int hi, mj;      // row of H_all, column of M_all
     double s;
     double* dst;
@@ -136,24 +195,19 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
     if (t == 0) res[0] = 0.0, res[1] = 1.0, res[2] = 0.0;
     return;
   }
-  // elimination: Wm[i][j] -= Wm[i][c] Wm[c][j] / Wm[c][c] for i, j > c.  The first two elements of a thread keep their
-  // coordinates in registers (all of them when rup <= 31)
-  const int tot = rup * W;
-  const int i0 = t / W, j0 = t - i0 * W;
-  const int i1 = (t + 1024) / W, j1 = (t + 1024) - i1 * W;
-  for (int c = 0; c < rup; ++c) {
-    const double* rc = Wm + c * ldw;
-    const double piv = rc[c];
-    if (t == 0 && !(piv > 0.0)) bad = 1;
-    const double ip = 1.0 / piv;
-    if (t < tot && i0 > c && j0 > c) Wm[i0 * ldw + j0] = fma(-(Wm[i0 * ldw + c] * ip), rc[j0], Wm[i0 * ldw + j0]);
-    if (t + 1024 < tot && i1 > c && j1 > c) Wm[i1 * ldw + j1] = fma(-(Wm[i1 * ldw + c] * ip), rc[j1], Wm[i1 * ldw + j1]);
-    for (int e = t + 2048; e < tot; e += 1024) {
-      const int i = e / W, j = e - i * W;
-      if (i > c && j > c) Wm[i * ldw + j] = fma(-(Wm[i * ldw + c] * ip), rc[j], Wm[i * ldw + j]);
-    }
-    __syncthreads();
-  }
+  // elimination: Wm[i][j] -= Wm[i][c] Wm[c][j] / Wm[c][c] for i, j > c, with the matrix in REGISTERS (a thread owns the elements
+  // t, t + 1024, ... - at most 13 of the 80 x 161) and only the pivot row in LDS: row c + 1 is final after step c and its owners
+  // publish it, everybody reads its two operands from the published row c - the multiplier S[i][c] is taken as S[c][i], which the
+  // elimination of a symmetric S keeps equal up to rounding.  One barrier, two LDS reads and one FMA per element and step (the
+  // first version walked the LDS copy with a division per element: 1.2 us per step at 50 rows, 87 us per SLAM update).
+  const int ne = (rup * W + 1023) >> 10;  // elements per thread: the loop is instantiated per count (a fixed 13-fold unrolled one made
+                                          // the compiler issue all 26 LDS reads of a step speculatively, whatever the guards said)
+  if (ne <= 1) ic_eliminate<1>(Wm, ldw, rup, W, t, &bad);
+  else if (ne <= 2) ic_eliminate<2>(Wm, ldw, rup, W, t, &bad);
+  else if (ne <= 3) ic_eliminate<3>(Wm, ldw, rup, W, t, &bad);
+  else if (ne <= 5) ic_eliminate<5>(Wm, ldw, rup, W, t, &bad);
+  else if (ne <= 8) ic_eliminate<8>(Wm, ldw, rup, W, t, &bad);
+  else ic_eliminate<IC_MAXE>(Wm, ldw, rup, W, t, &bad);
   // rows scaled by 1 / sqrt(pivot): y and L^-1
   for (int e = t; e < rup * (rup + 1); e += 1024) {
     const int i = e / (rup + 1), q = e - i * (rup + 1);

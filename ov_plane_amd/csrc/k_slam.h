@@ -23,9 +23,10 @@ struct SlamParams {
   // the stacked system
   const int* row0;           // [L] first stacked row of the landmark
   const int* gpos;           // [n] state column -> row of Ht (position in the call's column list)
-  double* Ht;                // [columns of the call][m_total], zeroed by the caller
-  int m_total;
-  double* res_out;           // [m_total], zeroed by the caller
+  double* Ht;                // [gcols = columns of the call][m_total]; every row of the stack is written by its landmark's block
+  int m_total, gcols;
+  double* res_out;           // [m_total]
+  double* Mall;              // [n][m_total] = P[:, columns] H^T for the S-form update (k_init.hip), nullptr = not needed
   // scratch / geometry
   double* Hscr;              // [L][rows_max * cols_max] when the block does not fit LDS (h_in_lds = 0)
   int rows_max, cols_max, h_in_lds;

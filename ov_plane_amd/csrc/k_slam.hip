@@ -191,12 +191,43 @@ __global__ __launch_bounds__(256) void k_slam_gate(SlamParams sp) {
   __syncthreads();
   const int keep = st_sh == 1 ? rows : (st_sh == 2 ? nb : 0);
   const int row0 = sp.row0[l];
+  // the landmark owns its rows of the stacked system: zero them, then drop the accepted rows in (no memset in front of the launch)
+  for (int e = t; e < sp.gcols * rows; e += 256) {
+    const int g = e / rows, i = e - g * rows;
+    sp.Ht[(size_t)g * sp.m_total + row0 + i] = 0.0;
+  }
+  for (int e = t; e < rows; e += 256) sp.res_out[row0 + e] = e < keep ? r0[e] : 0.0;
+  __syncthreads();
   for (int e = t; e < keep * cols; e += 256) {
     const int i = e / cols, k = e - i * cols;
     const double v = H[e];
     if (v != 0.0) sp.Ht[(size_t)sp.gpos[ids[k]] * sp.m_total + row0 + i] = v;
   }
-  for (int e = t; e < keep; e += 256) sp.res_out[row0 + e] = r0[e];
+  // its columns of M = P H^T (the S-form update's first product, k_init_m): P[:, ids] H_l^T, zero for rows that were dropped
+  if (sp.Mall) {
+    // thread <-> state row r, four stacked rows at a time: P[r][ids[k]] is read as P[ids[k]][r] (symmetric) so that the threads of a
+    // wave walk one row of P together
+    const int n = p.n;
+    for (int i0 = 0; i0 < rows; i0 += 4) {
+      for (int r = t; r < n; r += 256) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        if (i0 < keep) {
+          const double* h = H + (size_t)i0 * cols;
+          const int ni = min(4, keep - i0);
+#pragma unroll 8
+          for (int k = 0; k < cols; ++k) {
+            const double pv = p.P[(size_t)ids[k] * p.ldp + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < ni) s[q] = fma(pv, h[(size_t)q * cols + k], s[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (i0 + q < rows) sp.Mall[(size_t)r * sp.m_total + row0 + i0 + q] = s[q];
+      }
+    }
+  }
 }
 
 }  // namespace ovp

@@ -2720,8 +2720,6 @@ extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_s
     }
   }
   HIPCHK(hipMemcpyAsync(d, h, stage_bytes, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemsetAsync(c->Hd, 0, sizeof(double) * need, s));
-  HIPCHK(hipMemsetAsync(c->resd, 0, sizeof(double) * m_total, s));
   ovp::SlamParams sp;
   memset(&sp, 0, sizeof(sp));
   sp.fp = c->fp;
@@ -2758,13 +2756,30 @@ extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_s
   sp.gpos = (const int*)(d + o_gp);
   sp.Ht = c->Hd;
   sp.m_total = m_total;
+  sp.gcols = gcols;
   sp.res_out = c->resd;
   sp.Hscr = c->slam_hscr;
   sp.rows_max = rows_max;
   sp.cols_max = cols_max;
   sp.h_in_lds = h_in_lds;
-  sp.chi2 = (double*)c->slam_res;
-  sp.status = (unsigned char*)c->slam_res + al(sizeof(double) * L);
+  const char* form_env = getenv("OVP_EKF_INFO_FORM");
+  const bool info_form_only = form_env && form_env[0] == '1';
+  // S-form (k_init.hip) up to 80 stacked rows: scratch [res 4 | dx n_max | 8 | chi2 L | status L] M_all | Linv | y in smallbuf, so
+  // that everything the host wants comes back in ONE copy
+  const bool sform = !info_form_only && m_total <= ovp_init_max_rows() && ovp_init_core_lds(0, m_total, gcols) <= ovp_init_max_lds();
+  double* dres = c->smallbuf;
+  double* dM = (double*)((char*)(dres + res_doubles) + lres_bytes);
+  double* dLi = dM + (size_t)n * m_total;
+  double* dy = dLi + (size_t)m_total * m_total;
+  const bool sform_fits = (size_t)(dy + m_total + 8 - c->smallbuf) <= c->small_cap;
+  if (sform && sform_fits) {
+    sp.chi2 = dres + res_doubles;
+    sp.status = (unsigned char*)(dres + res_doubles) + al(sizeof(double) * L);
+    sp.Mall = dM;
+  } else {
+    sp.chi2 = (double*)c->slam_res;
+    sp.status = (unsigned char*)c->slam_res + al(sizeof(double) * L);
+  }
   HIPCHK(ovp_launch_slam_gate(&sp, L, ovp_slam_gate_lds(rows_max, cols_max, h_in_lds), s));
   const int* dgid = (const int*)(d + o_gi);
   char* hres = (char*)c->pl_hres;
@@ -2785,21 +2800,12 @@ extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_s
       }
     }
   };
-  const char* form_env = getenv("OVP_EKF_INFO_FORM");
-  const bool info_form_only = form_env && form_env[0] == '1';
-  if (!info_form_only && m_total <= ovp_init_max_rows() && ovp_init_core_lds(0, m_total, gcols) <= ovp_init_max_lds()) {
+  if (sform && sform_fits) {
     const int rows = m_total;
-    double* dres = c->smallbuf;
-    double* dM = dres + res_doubles;
-    double* dLi = dM + (size_t)n * rows;
-    double* dy = dLi + (size_t)rows * rows;
-    if ((size_t)(dy + rows + 8 - c->smallbuf) > c->small_cap) return OVP_E_CAPACITY;
-    HIPCHK(ovp_launch_init_m(c->P, c->ld, n, dgid, gcols, c->Hd, rows, dM, s));
     HIPCHK(ovp_launch_init_core(c->P, c->ld, n, dgid, gcols, c->Hd, 0, rows, dM, c->resd /* unused: k = 0 */, c->resd, c->resd, 1.0, 1e300,
                                 dLi, dy, dres, s));
     HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, c->ld, n, dM, rows, 0, rows, dLi, dy, dres, dres + 4, s));
-    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * (4 + (size_t)n), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hl, c->slam_res, lres_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hres, dres, res_doubles * sizeof(double) + lres_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     finish_landmarks();
     if (info) {
