@@ -125,12 +125,58 @@ class StepRunner:
         return self  # (the outputs live in the prepared frame: results())
 
     def results(self):
-        return self.frame.results()
+        pl, pt = self.frame.results()
+        return (pl, self._sharded_pt) if getattr(self, "_sharded_pt", None) is not None else (pl, pt)
+
+    def step_sharded_native(self, comm, rank, world, timing=None):
+        """Feature-sharded step through the C-ABI alone: replicated plane loop, then ovp_msckf_update_sharded (this
+        rank's index range of the resident frame -> pair -> ncclAllReduce on the context's stream -> update).  torch is not on
+        this path (it only started the ranks and carried the communicator id)."""
+        import time as _t
+
+        sc, ctx, fr = self.sc, self.ctx, self.frame
+        self._lib.ovp_cov_set_device(ctx._h, self._P0_ptr, sc.N, sc.N)
+        fr.upload()
+        t0 = _t.perf_counter()
+        if self.has_planes:
+            fr.plane_update()
+            if timing is not None:
+                timing["plane_loop_ms"] = timing.get("plane_loop_ms", 0.0) + 1e3 * (_t.perf_counter() - t0)
+        o = self.opts_pts if self.has_planes else self.opts
+        if timing is None:
+            pt = ctx.msckf_update_sharded(o, comm, rank, world)
+        else:
+            # the same stages one by one with a host synchronisation behind each (diagnostic pass)
+            from ov_plane_amd.dist import leftover_range, shard_bounds
+
+            if self.has_planes:
+                lo, hi, _ = leftover_range(fr.pl_used[: sc.F] != 0, rank, world)
+            else:
+                lo, hi = shard_bounds(sc.F, rank, world)
+            t1 = _t.perf_counter()
+            ctx.batch_set_range(lo, hi)
+            ctx.build_gate_gram_async(o)
+            ctx.sync()
+            t2 = _t.perf_counter()
+            if comm:
+                ctx.rccl_allreduce_gram(comm)
+                ctx.sync()
+            t3 = _t.perf_counter()
+            ctx.ekf_update_from_gram_async()
+            pt = ctx.fetch_results()
+            ctx.batch_set_range(-1, -1)
+            t4 = _t.perf_counter()
+            pt["shard"] = (lo, hi)
+            for k, v in (("points_build_ms", t2 - t1), ("allreduce_ms", t3 - t2), ("update_ms", t4 - t3)):
+                timing[k] = timing.get(k, 0.0) + 1e3 * v
+        lo, hi = pt["shard"]
+        self.shard_size = int((fr.pl_used[lo:hi] == 0).sum()) if self.has_planes else hi - lo
+        self._sharded_pt = pt
+        return self  # (results(): the plane outputs live in the prepared frame)
 
     def step_sharded(self, rank, world, timing=None):
-        """Feature-sharded step through the functions of ov_plane_amd.dist that the gloo tests drive: replicated
-        plane loop, the free points split over the ranks (one upload of the frame, index ranges + the device-side mask), one RCCL
-        all-reduce of the information pair on the context's stream."""
+        """The same step through the functions of ov_plane_amd.dist that the gloo tests drive (torch.distributed carries the
+        all-reduce): the reference implementation of the split, and the fallback when the native communicator cannot be created."""
         from ov_plane_amd.dist import shard_bounds, sharded_plane_then_point_update, sharded_update
 
         sc, ctx = self.sc, self.ctx
@@ -398,6 +444,9 @@ def main():
                     help="off (default): the Python collector is disabled inside the timed windows (the harness is Python, the path "
                          "under test is a C library: a generation-2 collection of the torch-sized heap is a ~40 ms pause that lands "
                          "in one step); on: left running, its pauses are reported")
+    ap.add_argument("--collective", choices=["native", "torch"], default="native",
+                    help="multi-GPU step: native = the C entry ovp_msckf_update_sharded on an RCCL communicator of the library's own "
+                         "binding (default); torch = ov_plane_amd.dist over torch.distributed (the gloo-tested reference of the split)")
     ap.add_argument("--sharded-path", action="store_true",
                     help="with --gpus 1: take the multi-GPU code path (process group of one rank, dist.sharded_* functions, RCCL "
                          "all-reduce, stage timing) - a smoke test of it on a one-GPU box")
@@ -433,6 +482,25 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29571")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
+    # the product path of a multi-GPU step is the C entry (ovp_msckf_update_sharded) on a communicator created through the library's
+    # own RCCL binding; torch.distributed only carries the 128-byte id to the ranks.  --collective torch (or a failure to create the
+    # communicator, reported in the line) takes ov_plane_amd.dist instead
+    native_comm, collective = None, "none"
+    if sharded:
+        collective = "torch.distributed"
+        if args.collective == "native":
+            try:
+                uid = [capi.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                native_comm = capi.rccl_comm_create(uid[0], rank, world, local_rank)
+                collective = "rccl-native (ovp_msckf_update_sharded)"
+            except Exception as e:  # noqa: BLE001
+                print("native RCCL communicator not created (%r): falling back to torch.distributed" % (e,), file=sys.stderr)
+                native_comm = None
+            ok = torch.tensor([1 if native_comm else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not bool(ok.item()):
+                native_comm, collective = None, "torch.distributed"
     name = args.workload if args.workload != "auto" else ("config4" if sharded else "config3")
     sc = make_workload(name)
     run = StepRunner(capi, torch, sc, local_rank)
@@ -440,7 +508,9 @@ def main():
 
     with torch.cuda.stream(run.stream):
         if sharded:
-            fn = lambda: run.step_sharded(rank, world)  # noqa: E731
+            sharded_step = (lambda r, timing=None: r.step_sharded_native(native_comm, rank, world, timing)) if native_comm else \
+                           (lambda r, timing=None: r.step_sharded(rank, world, timing))
+            fn = lambda: sharded_step(run)  # noqa: E731
         else:
             fn = run.step
         import gc
@@ -494,7 +564,7 @@ def main():
             stages = {}
             n_diag = 5
             for _ in range(n_diag):
-                run.step_sharded(rank, world, timing=stages)
+                sharded_step(run, stages)
             stages = {k: v / n_diag for k, v in stages.items()}
 
     point_only = None
@@ -505,7 +575,7 @@ def main():
         with torch.cuda.stream(r2.stream):
             blocks = []
             for blk in range(5):
-                el_b, _, _ = time_steps(torch, lambda: r2.step_sharded(rank, world), 10, 3 if blk == 0 else 0, barrier)
+                el_b, _, _ = time_steps(torch, lambda: sharded_step(r2), 10, 3 if blk == 0 else 0, barrier)
                 blocks.append(el_b / 10)
         tb = torch.tensor(blocks, dtype=torch.float64, device="cuda")
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
@@ -559,12 +629,12 @@ def main():
         line["python_gc"] = {"inside_timed_windows": args.python_gc, "prewarm": gc_prewarm, "window_1_incl_warmup": gc_w1, "window_2": gc_w2,
                              "note": "pauses of the harness's garbage collector (gc.callbacks); `off` = gc.collect() + gc.disable() in "
                                      "front of the warm-up steps, re-enabled behind the second window"}
-        k = max(args.steps, 1)
+        kp, kq = max(host_acc["plane_calls"], 1), max(host_acc["point_calls"], 1)  # (the accumulators also cover the warm-up steps)
         line["host"] = {
-            "plane_pre_launch_ms": host_acc["plane_pre_ms"] / k, "plane_enqueue_ms": host_acc["plane_enqueue_ms"] / k,
-            "plane_wait_ms": host_acc["plane_wait_ms"] / k, "point_enqueue_ms": host_acc["point_enqueue_ms"] / k,
-            "point_wait_ms": host_acc["point_wait_ms"] / k,
-            "note": "host clock inside the two update entry points per timed step: plane loop entry -> first launch (grouping, staging "
+            "plane_pre_launch_ms": host_acc["plane_pre_ms"] / kp, "plane_enqueue_ms": host_acc["plane_enqueue_ms"] / kp,
+            "plane_wait_ms": host_acc["plane_wait_ms"] / kp, "point_enqueue_ms": host_acc["point_enqueue_ms"] / kq,
+            "point_wait_ms": host_acc["point_wait_ms"] / kq, "plane_calls": host_acc["plane_calls"], "point_calls": host_acc["point_calls"],
+            "note": "host clock inside the two update entry points per CALL: plane loop entry -> first launch (grouping, staging "
                     "tables), entry -> last launch enqueued, wait for the device; point update enqueue, wait for the published results"}
         if dev_ms is not None:
             line["device_clock"] = dict(dev_ms, step_median_minus_device_ms=st1["median_ms"] - dev_ms["sum_ms"],
@@ -622,7 +692,7 @@ def main():
         if stages is not None:
             tot_st = sum(stages.values()) or 1.0
             line["multi_gpu"] = {
-                "rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
+                "rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(), "collective": collective,
                 "rank0_stage_ms": stages,
                 "serial_fraction": stages.get("plane_loop_ms", 0.0) / tot_st,
                 "serial_fraction_note": "plane loop (replicated on every rank, sequential across planes: update/UpdaterMSCKF.cpp:413-649) / "
@@ -648,6 +718,8 @@ def main():
     else:
         out_line = None
     run.close()
+    if native_comm:
+        capi.rccl_comm_destroy(native_comm)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,7 +32,8 @@ enum {
   OVP_E_NEGDIAG = -4,   /* negative covariance diagonal (reference: std::exit, StateHelper.cpp:177-187) */
   OVP_E_NODEVICE = -5,  /* no HIP device / wrong architecture */
   OVP_E_STATE = -6,     /* call order violated (e.g. update before upload) */
-  OVP_E_TIMEOUT = -7    /* a device-side hand-over between the two workgroups of the plane solve did not arrive (bounded spin) */
+  OVP_E_TIMEOUT = -7,   /* a device-side hand-over between the two workgroups of the plane solve did not arrive (bounded spin) */
+  OVP_E_RCCL = -8       /* librccl could not be loaded, or an RCCL call failed (message on stderr) */
 };
 
 typedef struct ovp_ctx ovp_ctx;
@@ -148,11 +149,36 @@ int ovp_msckf_update(ovp_ctx *ctx, const ovp_update_opts *opts, double *dx_host,
  *            written to the device buffer returned by ovp_gram_buffer() (f64, (n_state+1) * ld_gram);
  *   (caller all-reduces that buffer over RCCL)
  *   stage 2 (every rank or rank 0): EKF update from the summed pair. */
+/* NOTE for callers that touch the pair between the two stages: the update reads Ab only on the columns a point batch involves
+ * (the clone poses and the estimated calibration; everything in front of the first of those columns is taken to be zero - the
+ * factor of P is then formed in reversed index order and the update runs on the trailing block).  Summing pairs of the same
+ * kind over ranks keeps that property; writing other columns does not, and such contributions would be dropped silently -
+ * set OVP_POINT_NO_FLIP=1 in the environment (full-width update) for a caller that needs them. */
 int ovp_msckf_build_gate_gram_async(ovp_ctx *ctx, const ovp_update_opts *opts);
 int ovp_gram_buffer(ovp_ctx *ctx, double **Ab_dev, int *n_rows, int *ld);
 int ovp_ekf_update_from_gram_async(ovp_ctx *ctx);
 int ovp_msckf_fetch_results(ovp_ctx *ctx, double *dx_host, uint8_t *accepted_host, double *chi2_host,
                             ovp_update_info *info);
+
+/* ---- feature-sharded update over RCCL (no counterpart in the reference, which runs on one core) -----------------
+ * One process per GPU, every rank with the same covariance, pose tables and frame resident.  ovp_msckf_update_sharded =
+ * ovp_batch_set_range(this rank's balanced share of the features the update is about) -> ovp_msckf_build_gate_gram_async ->
+ * ncclAllReduce(sum, f64) of [A | b] on the context's stream -> ovp_ekf_update_from_gram_async -> ovp_msckf_fetch_results: every
+ * rank ends with the same covariance and correction (the all-reduced pair is bit-identical on all ranks, the update is
+ * deterministic).  nccl_comm is an ncclComm_t of the caller (a C++ host links RCCL itself and owns the communicator); the three
+ * helpers below create one for callers that do not (bench.py, the tests): the id of rank 0 travels by whatever means the launcher
+ * has.  RCCL is bound with dlopen at first use (OVP_RCCL_LIB overrides the name).  world = 1 / comm = NULL: no collective.
+ * accepted / chi2 are filled for this rank's share [*shard_lo, *shard_hi) only (zero elsewhere); with opts->skip_plane_used the
+ * share is taken from the features the preceding ovp_msckf_plane_update left. */
+typedef struct { char internal[128]; } ovp_rccl_id; /* = ncclUniqueId */
+int ovp_rccl_unique_id(ovp_rccl_id *id);
+int ovp_rccl_comm_create(const ovp_rccl_id *id, int rank, int world, int device, void **nccl_comm);
+int ovp_rccl_comm_destroy(void *nccl_comm);
+/* ncclAllReduce(sum, f64) of the pair of ovp_gram_buffer() on the context's stream: the collective between
+ * ovp_msckf_build_gate_gram_async and ovp_ekf_update_from_gram_async for callers that drive the stages themselves */
+int ovp_rccl_allreduce_gram(ovp_ctx *ctx, void *nccl_comm);
+int ovp_msckf_update_sharded(ovp_ctx *ctx, const ovp_update_opts *opts, void *nccl_comm, int rank, int world, double *dx_host,
+                             uint8_t *accepted_host, double *chi2_host, ovp_update_info *info, int *shard_lo, int *shard_hi);
 
 /* ext ov_core::FeatureInitializerOptions (open_vins ov_core/src/feat/FeatureInitializerOptions.h; not in the reference tree) */
 typedef struct {
@@ -265,10 +291,13 @@ int ovp_slam_update(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_slam_ba
 int ovp_cov_propagate(ovp_ctx *ctx, int new_start, int phi_size, const int *old_ids, const int *old_sizes, int n_old,
                       const double *Phi_host, const double *Q_host, int *neg_diag);
 
-/* StateHelper::clone (state/StateHelper.cpp:346-396): appends a copy of [src_id, src_id+size) at the end.  The diagonal of
- * the new block is stored 1e-11 (relative) above the copied value: an exact copy leaves P singular, and the update path
- * factors P.  A covariance handed to ovp_cov_upload / ovp_cov_set_device must be positive definite. */
+/* StateHelper::clone (state/StateHelper.cpp:346-396): appends an exact copy of [src_id, src_id+size) at the end, bit for bit
+ * as the reference.  The covariance is then positive SEMI-definite until the next propagation; the update entry points fall back
+ * to their pivot-dropping / S-form paths when chol(P) meets the zero pivot.
+ * ovp_cov_clone_jitter(ctx, rel) > 0 restores the round-2 behaviour (diagonal of the new block stored rel above the copied
+ * value, default 0 = off): it keeps such a prior on the fast path at the price of a 1e-11-level departure from the reference. */
 int ovp_cov_clone(ovp_ctx *ctx, int src_id, int size);
+int ovp_cov_clone_jitter(ovp_ctx *ctx, double relative_inflation);
 /* StateHelper::marginalize (state/StateHelper.cpp:276-344): removes rows/cols [id, id+size). */
 int ovp_cov_marginalize(ovp_ctx *ctx, int id, int size);
 /* StateHelper::augment_clone, time-offset part (state/StateHelper.cpp:613-624):

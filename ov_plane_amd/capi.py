@@ -138,7 +138,8 @@ EXPORTS = [
     "ovp_cov_clone", "ovp_cov_marginalize", "ovp_cov_size", "ovp_chi2_quantile_095", "ovp_debug_read",
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
     "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
-    "ovp_slam_update",
+    "ovp_slam_update", "ovp_cov_clone_jitter", "ovp_rccl_unique_id", "ovp_rccl_comm_create", "ovp_rccl_comm_destroy",
+    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded",
 ]
 
 
@@ -175,6 +176,13 @@ def lib():
         L.ovp_msckf_fetch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateInfo)]
         L.ovp_ekf_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(UpdateInfo)]
+        L.ovp_cov_clone_jitter.argtypes = [C.c_void_p, C.c_double]
+        L.ovp_rccl_unique_id.argtypes = [C.c_void_p]
+        L.ovp_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.ovp_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.ovp_rccl_allreduce_gram.argtypes = [C.c_void_p, C.c_void_p]
+        L.ovp_msckf_update_sharded.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.POINTER(UpdateInfo), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ovp_slam_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(SlamBatch), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(UpdateInfo)]
         L.ovp_msckf_plane_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(PlaneBatch), C.c_void_p,
@@ -208,6 +216,26 @@ def lib():
 def _chk(code, where):
     if code != 0:
         raise OvpError(code, where)
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library's own binding of RCCL (128 bytes, to be handed to every rank)."""
+    buf = C.create_string_buffer(128)
+    _chk(lib().ovp_rccl_unique_id(buf), "ovp_rccl_unique_id")
+    return buf.raw
+
+
+def rccl_comm_create(uid: bytes, rank: int, world: int, device: int = 0) -> int:
+    """ncclCommInitRank (collective over all ranks); returns the ncclComm_t as an integer handle."""
+    assert len(uid) == 128
+    comm = C.c_void_p()
+    _chk(lib().ovp_rccl_comm_create(C.create_string_buffer(uid, 128), int(rank), int(world), int(device), C.byref(comm)),
+         "ovp_rccl_comm_create")
+    return comm.value
+
+
+def rccl_comm_destroy(comm: int):
+    _chk(lib().ovp_rccl_comm_destroy(C.c_void_p(comm)), "ovp_rccl_comm_destroy")
 
 
 def opts_from_scene(sc) -> UpdateOpts:
@@ -297,6 +325,10 @@ class Context:
 
     def cov_clone(self, src_id, size):
         _chk(lib().ovp_cov_clone(self._h, int(src_id), int(size)), "ovp_cov_clone")
+
+    def cov_clone_jitter(self, rel):
+        """relative inflation of a cloned block's diagonal (0 = exact copy as the reference, the default)"""
+        _chk(lib().ovp_cov_clone_jitter(self._h, float(rel)), "ovp_cov_clone_jitter")
 
     def cov_marginalize(self, vid, size):
         _chk(lib().ovp_cov_marginalize(self._h, int(vid), int(size)), "ovp_cov_marginalize")
@@ -393,6 +425,24 @@ class Context:
         if rc != 0 and raise_on_error:
             raise OvpError(rc, "ovp_msckf_update")
         return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
+
+    def msckf_update_sharded(self, opts: UpdateOpts, comm, rank=0, world=1, raise_on_error=True):
+        """ovp_msckf_update_sharded: this rank's share of the point features -> pair -> ncclAllReduce -> update (comm: handle from
+        rccl_comm_create or None for a single rank).  Results as msckf_update plus the shard's index range."""
+        n, F = self.cov_size(), self.n_feats
+        dx = np.zeros(n)
+        acc = np.zeros(max(F, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(F, 1))
+        info = UpdateInfo()
+        lo, hi = C.c_int(0), C.c_int(0)
+        rc = lib().ovp_msckf_update_sharded(self._h, C.byref(opts), C.c_void_p(comm) if comm else None, int(rank), int(world),
+                                            dx.ctypes.data, acc.ctypes.data, chi2.ctypes.data, C.byref(info), C.byref(lo), C.byref(hi))
+        if raise_on_error:
+            _chk(rc, "ovp_msckf_update_sharded")
+        return dict(dx=dx, accepted=acc[:F].astype(bool), chi2=chi2[:F], info=info, rc=rc, shard=(lo.value, hi.value))
+
+    def rccl_allreduce_gram(self, comm):
+        _chk(lib().ovp_rccl_allreduce_gram(self._h, C.c_void_p(comm)), "ovp_rccl_allreduce_gram")
 
     def batch_set_range(self, lo=-1, hi=-1):
         """Point updates that follow take the features [lo, hi) of the uploaded batch only (-1, -1 = all of it)."""

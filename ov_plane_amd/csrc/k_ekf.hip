@@ -264,7 +264,7 @@ __global__ void k_sub_sym(double* __restrict__ P, const double* __restrict__ D, 
 }
 
 // StateHelper::clone: P[new..new+sz) rows/cols = copies of [src..src+sz)
-__global__ void k_cov_clone(double* __restrict__ P, int ldp, int n_old, int src, int sz) {
+__global__ void k_cov_clone(double* __restrict__ P, int ldp, int n_old, int src, int sz, double jitter) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_new = n_old + sz;
   if (idx >= n_new * sz) return;
@@ -275,11 +275,11 @@ __global__ void k_cov_clone(double* __restrict__ P, int ldp, int n_old, int src,
     P[(size_t)(n_old + k) * ldp + r] = P[(size_t)(src + k) * ldp + r];
   } else {
     double v = P[(size_t)(src + (r - n_old)) * ldp + src + k];
-    // The clone is an exact copy, so P is only positive SEMI-definite from here until a propagation puts process noise on
-    // the source - but every update of this path factors P (P+ = L (I + L^T A L)^-1 L^T, L L^T = P).  The diagonal of the
-    // new block is therefore stored as (1 + 1e-11) x the copied value: the zero-variance directions get a pivot four orders
-    // of magnitude above the rounding noise of the Schur complement, seven orders below the tolerance of the path (1e-4).
-    if (r - n_old == k) v *= (1.0 + OVP_CLONE_JITTER);
+    // The clone is an exact copy (state/StateHelper.cpp:346-396), so P is only positive SEMI-definite from here until a
+    // propagation puts process noise on the source; the update entry points then leave chol(P) for their pivot-dropping / S-form
+    // paths.  jitter > 0 (ovp_cov_clone_jitter, off by default) stores the diagonal of the new block (1 + jitter) x the copied
+    // value instead, which keeps such a prior on the fast path at the price of that departure from the reference.
+    if (r - n_old == k) v *= (1.0 + jitter);
     P[(size_t)r * ldp + n_old + k] = v;
   }
 }
@@ -496,9 +496,9 @@ hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int r
   return hipGetLastError();
 }
 
-hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, hipStream_t stream) {
+hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, double jitter, hipStream_t stream) {
   const int total = (n_old + sz) * sz;
-  hipLaunchKernelGGL(ovp::k_cov_clone, dim3((total + 255) / 256), dim3(256), 0, stream, P, ldp, n_old, src, sz);
+  hipLaunchKernelGGL(ovp::k_cov_clone, dim3((total + 255) / 256), dim3(256), 0, stream, P, ldp, n_old, src, sz, jitter);
   return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -34,7 +35,7 @@ hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int 
 hipError_t ovp_launch_mat_sub(const double* A, const double* B, double* C, int rows, int cols, int ld, hipStream_t stream);
 hipError_t ovp_launch_sub_sym(double* P, const double* D, int n, int ld, hipStream_t stream);
 hipError_t ovp_launch_sub_sym_unless(double* P, const double* D, int n, int ld, const int* cancel, hipStream_t stream);
-hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, hipStream_t stream);
+hipError_t ovp_launch_cov_clone(double* P, int ldp, int n_old, int src, int sz, double jitter, hipStream_t stream);
 hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, int n_old, int id, int sz,
                                       hipStream_t stream);
 hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, const int* oldcol, int nold,
@@ -224,6 +225,7 @@ struct ovp_ctx {
   unsigned pl_seq = 0;
   int range_lo = -1, range_hi = -1;   // ovp_batch_set_range (-1, -1 = whole batch)
   unsigned char* pl_used = nullptr;   // [f_max] features consumed by accepted planes (device)
+  std::vector<unsigned char> h_pl_used;  // host copy of it behind the last plane loop (ovp_msckf_update_sharded splits the leftovers)
   bool pl_used_valid = false;         // pl_used refers to the uploaded batch
   int pl2_cap = 0;
   // plane loop on a sub-state (n above the tile factorization's limit): accumulated pair, u rows, remapped id tables
@@ -246,6 +248,7 @@ struct ovp_ctx {
   // launch at N = 240) is skipped.  Cleared by everything that writes P.
   double* Lkeep = nullptr;
   bool have_factor = false, use_kept_factor = false;
+  double clone_jitter = 0.0;  // ovp_cov_clone_jitter: relative inflation of a cloned block's diagonal (0 = exact copy, the reference)
   int point_nl = 0;  // > 0: chol(P) of the running point update was taken in reversed index order (CholJob::flip) and the update's
                      // T = I + L^T A L is the identity outside its leading point_nl columns          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
   hipEvent_t ev_subtab = nullptr;     // behind the upload of pl_sub_htab (the pinned block is rewritten by the next call)
@@ -297,6 +300,15 @@ struct ovp_ctx {
   double host_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// Everything that writes the covariance calls this: the factor the plane loop left (Lkeep) and the bookkeeping of a staged point
+// update that was built but never applied (use_kept_factor / point_nl, set by ovp_msckf_build_gate_gram_async) no longer belong to P.
+static inline void drop_kept_factor(ovp_ctx* c) {
+  if (!c) return;
+  c->have_factor = false;
+  c->use_kept_factor = false;
+  c->point_nl = 0;
+}
+
 static inline double host_now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -313,6 +325,7 @@ extern "C" const char* ovp_error_string(int code) {
     case OVP_E_NODEVICE: return "no usable HIP device";
     case OVP_E_STATE: return "call order violated";
     case OVP_E_TIMEOUT: return "device-side hand-over timed out (workgroups of the plane solve not co-resident)";
+    case OVP_E_RCCL: return "RCCL not loadable or a collective call failed";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown";
   }
 }
@@ -527,7 +540,7 @@ extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);
 // (upload / download / marginal / propagate go through the pinned arena: one contiguous copy each way.  A 2-D copy from
 //  pageable memory cost 90 us of host time at N = 130, a pageable copy per small array 8 us each.)
 extern "C" int ovp_cov_upload(ovp_ctx* c, const double* P_host, int n, int ld) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !P_host || n < 1 || ld < n) return OVP_E_ARG;
   if (n > c->n_max) return OVP_E_CAPACITY;
   void *ah = nullptr, *ad = nullptr;
@@ -547,7 +560,7 @@ extern "C" int ovp_cov_upload(ovp_ctx* c, const double* P_host, int n, int ld) {
   return 0;
 }
 extern "C" int ovp_cov_set_device(ovp_ctx* c, const double* P_dev, int n, int ld) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !P_dev || n < 1 || ld < n) return OVP_E_ARG;
   if (n > c->n_max) return OVP_E_CAPACITY;
   HIPCHK(hipMemcpy2DAsync(c->P, sizeof(double) * c->ld, P_dev, sizeof(double) * ld, sizeof(double) * n, n,
@@ -1334,6 +1347,123 @@ extern "C" int ovp_msckf_update(ovp_ctx* c, const ovp_update_opts* o, double* dx
   return rc;
 }
 
+// ---- feature-sharded point update over RCCL ---------------------------------------------------------------------
+// One process per GPU; every rank holds the same covariance, pose tables and frame; a rank builds the information pair of its
+// share of the point features, ONE ncclAllReduce(sum, f64) of [A | b] on the context's stream puts the summed pair on every rank,
+// and every rank applies the identical update to its replica (no broadcast of P+).  RCCL is bound at first use with dlopen: a
+// process that already carries an RCCL (torch ships one) shares it instead of loading a second copy, and the library itself keeps
+// no link-time dependency on it.
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ovp_rccl_id, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool tried = false;
+};
+RcclApi g_rccl;
+const int kNcclFloat64 = 8, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t of rccl.h (ncclFloat64 = ncclDouble = 8, ncclSum = 0)
+
+bool rccl_load() {
+  if (g_rccl.tried) return g_rccl.AllReduce != nullptr;
+  g_rccl.tried = true;
+  const char* names[] = {getenv("OVP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    if (!nm || !*nm) continue;
+    void* h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (!h) continue;
+    g_rccl.h = h;
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, ovp_rccl_id, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce) return true;
+    g_rccl = RcclApi();
+    g_rccl.tried = true;
+  }
+  return false;
+}
+int rccl_rc(int r, const char* what) {
+  if (r == 0) return 0;
+  fprintf(stderr, "ovplane_hip: %s failed: %s\n", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  return OVP_E_RCCL;
+}
+}  // namespace
+
+extern "C" int ovp_rccl_unique_id(ovp_rccl_id* id) {
+  if (!id) return OVP_E_ARG;
+  if (!rccl_load()) return OVP_E_RCCL;
+  return rccl_rc(g_rccl.GetUniqueId(id), "ncclGetUniqueId");
+}
+
+extern "C" int ovp_rccl_comm_create(const ovp_rccl_id* id, int rank, int world, int device, void** comm) {
+  if (!id || !comm || world < 1 || rank < 0 || rank >= world) return OVP_E_ARG;
+  if (!rccl_load()) return OVP_E_RCCL;
+  HIPCHK(hipSetDevice(device));
+  *comm = nullptr;
+  return rccl_rc(g_rccl.CommInitRank(comm, world, *id, rank), "ncclCommInitRank");
+}
+
+extern "C" int ovp_rccl_comm_destroy(void* comm) {
+  if (!comm) return OVP_E_ARG;
+  if (!rccl_load()) return OVP_E_RCCL;
+  return rccl_rc(g_rccl.CommDestroy(comm), "ncclCommDestroy");
+}
+
+// the collective alone, on the context's stream: for callers that drive the staged entry points themselves
+extern "C" int ovp_rccl_allreduce_gram(ovp_ctx* c, void* nccl_comm) {
+  if (!c || !nccl_comm) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  if (!rccl_load()) return OVP_E_RCCL;
+  return rccl_rc(g_rccl.AllReduce(c->Ab, c->Ab, (size_t)(c->n + 1) * c->ld, kNcclFloat64, kNcclSum, nccl_comm, c->stream), "ncclAllReduce");
+}
+
+extern "C" int ovp_msckf_update_sharded(ovp_ctx* c, const ovp_update_opts* o, void* nccl_comm, int rank, int world, double* dx_host,
+                                        uint8_t* accepted_host, double* chi2_host, ovp_update_info* info, int* shard_lo,
+                                        int* shard_hi) {
+  if (!c || !o || world < 1 || rank < 0 || rank >= world) return OVP_E_ARG;
+  if (world > 1 && !nccl_comm) return OVP_E_ARG;
+  if (!c->have_batch) return OVP_E_STATE;
+  const int F = c->n_feats;
+  // this rank's balanced share of the features the update is about (the ones no accepted plane consumed when skip_plane_used is
+  // set): an index range of the resident batch - consecutive ranks tile it, consumed features inside are masked on the device
+  int lo = 0, hi = 0;
+  {
+    std::vector<int> rest;
+    rest.reserve((size_t)F);
+    const bool masked = o->skip_plane_used && c->pl_used_valid && (int)c->h_pl_used.size() == F;
+    if (o->skip_plane_used && !masked) return OVP_E_STATE;  // no plane update ran on this batch
+    for (int f = 0; f < F; ++f)
+      if (!masked || !c->h_pl_used[f]) rest.push_back(f);
+    const int nr = (int)rest.size(), base = nr / world, rem = nr % world;
+    const int a = rank * base + (rank < rem ? rank : rem), b = a + base + (rank < rem ? 1 : 0);
+    if (b > a) lo = rest[a], hi = rest[b - 1] + 1;
+  }
+  if (shard_lo) *shard_lo = lo;
+  if (shard_hi) *shard_hi = hi;
+  const double t0 = host_now_ms();
+  int rc = ovp_batch_set_range(c, lo, hi);
+  if (rc) return rc;
+  rc = ovp_msckf_build_gate_gram_async(c, o);
+  if (!rc && nccl_comm) {
+    if (!rccl_load()) rc = OVP_E_RCCL;
+    else
+      rc = rccl_rc(g_rccl.AllReduce(c->Ab, c->Ab, (size_t)(c->n + 1) * c->ld, kNcclFloat64, kNcclSum, nccl_comm, c->stream),
+                   "ncclAllReduce");
+  }
+  if (!rc) rc = ovp_ekf_update_from_gram_async(c);
+  const double t1 = host_now_ms();
+  if (!rc) rc = ovp_msckf_fetch_results(c, dx_host, accepted_host, chi2_host, info);
+  c->host_acc[4] += t1 - t0;
+  c->host_acc[5] += host_now_ms() - t1;
+  c->host_acc[6] += 1.0;
+  c->range_lo = c->range_hi = -1;
+  return rc;
+}
+
 extern "C" int ovp_host_timing(ovp_ctx* c, int reset, double* out8) {
   if (!c) return OVP_E_ARG;
   if (out8) memcpy(out8, c->host_acc, sizeof(c->host_acc));
@@ -1904,8 +2034,23 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     }
     if (!c->pl_sub_active) HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));  // (plane_update_ordered: in front of its permutation)
   }
-  rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
-  if (rc) return rc;
+  // (a cheap look at the batch first: when no plane can qualify - update/UpdaterMSCKF.cpp:316-317, 384-396 - nothing below needs the
+  // factor, and a singular prior must not fail a call that has nothing to update)
+  bool any_candidate = false;
+  {
+    std::vector<int> cnt((size_t)NP + 1, 0);
+    for (int f = 0; f < F; ++f) {
+      const int pf = pb->plane_of_feat[f];
+      if (pf >= 1 && pf <= NP && c->h_n_meas[f] >= 2) ++cnt[pf];
+    }
+    for (int q = 0; q < n_slam; ++q) ++cnt[pb->slam_plane[q]];
+    for (int pl = 1; pl <= NP && !any_candidate; ++pl)
+      any_candidate = cnt[pl] >= (pb->plane_state_id[pl - 1] >= 0 ? 1 : 4);
+  }
+  if (any_candidate) {
+    rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
+    if (rc) return rc;
+  }
   // a refusal from here on: chol(P) has run - a flag it may have raised (singular prior) must not outlive the call
   auto bail = [&](int code) {
     (void)hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s);
@@ -2005,6 +2150,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     jobs.push_back(j);
   }
   const int NJ = (int)jobs.size();
+  if (NJ == 0 && any_candidate) HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));  // chol(P)'s verdict concerns nobody
   // ---- staging layout: ints [featlist | sid NP | perms NJ*n | slam_plane | slam_id], doubles [cp | cp_fej | slam_p | slam_p_fej] ----
   const size_t n_int = featlist.size() + (size_t)NP + perms.size() + 2 * (size_t)n_slam;
   const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
@@ -2322,6 +2468,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       }
     }
   c->pl_used_valid = true;
+  c->h_pl_used.assign(hused, hused + F);
   if (dx_planes) memcpy(dx_planes, hdx, sizeof(double) * (size_t)n * NP);
   if (feat_used && F) memcpy(feat_used, hused, (size_t)F);
   for (const PlaneJobH& j : jobs) {
@@ -2358,7 +2505,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
 extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double const_init_multi,
                               double const_init_chi2, double* dx_planes, int dx_stride, uint8_t* plane_ok, double* plane_chi2,
                               int* plane_dof, int* new_ids, double* cp_new, uint8_t* feat_used) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !o || !pb || pb->n_planes < 0) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov || !c->have_batch) return OVP_E_STATE;
   if (c->h_n_meas.empty() && c->n_feats > 0) return OVP_E_STATE;
@@ -2378,6 +2525,8 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
   if (rc) return rc;
   rc = plane_buffers(c, NP);
   if (rc) return rc;
+  rc = plane2_buffers(c, NP, 0, 0);  // (pl_crow: scale vector of the pivot-dropping factor, chol_of_P on a semi-definite prior)
+  if (rc) return rc;
   hipStream_t s = c->stream;
   const int ncal = (o->do_calib_camera_pose ? 6 : 0) + (o->do_calib_camera_intrinsics ? 8 : 0);
   std::vector<int> sid(NP, -1);
@@ -2386,6 +2535,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
   HIPCHK(hipMemcpyAsync(c->pl_cp_fej, pb->cp, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
   std::vector<double> res4(4), dxh(c->n_max), dcp(3);
+  bool psd_prior = false;
   for (int pl = 0; pl < NP; ++pl) {
     const int n = c->n;
     if (n > OVP_TILECHOL_NMAX || n + 3 > c->n_max) return OVP_E_CAPACITY;
@@ -2410,18 +2560,30 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
     // the chi2 of StateHelper::initialize covers the rows that do not involve the plane, with dof = all rows (:471)
     const double thr = const_init_chi2 * ovp_chi2_quantile_095(rows_c);
     HIPCHK(hipMemcpyAsync(c->pl_featlist, featlist.data(), sizeof(int) * nf, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
-    HIPCHK(hipMemsetAsync(c->pl_res + 4 * pl, 0, sizeof(double) * 4, s));
-    rc = chol_of_P(c, s);
-    if (rc) return rc;
     ovp::FeatParams fp = c->fp;
-    rc = plane_job_device(c, o, fp, pl, 0, nf, 0, -1, 1.0 / (const_init_multi * o->sigma_constraint), c->L, 0, thr, rows_live - 3,
-                          rows_c - 3, c_ref);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(res4.data(), c->pl_res + 4 * pl, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (c->h_flags[0]) return OVP_E_NOTSPD;
+    // A prior that is only positive SEMI-definite (an exact stochastic clone in front of the next propagation: every frame of a
+    // running filter) fails chol(P) before anything is committed: the plane runs once more on the pivot-dropping factor of the
+    // unit-diagonal form (chol_of_P, as the plane loop does), and so do the planes behind it.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      c->pl_psd = psd_prior;
+      HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+      HIPCHK(hipMemsetAsync(c->pl_res + 4 * pl, 0, sizeof(double) * 4, s));
+      rc = chol_of_P(c, s);
+      if (!rc)
+        rc = plane_job_device(c, o, fp, pl, 0, nf, 0, -1, 1.0 / (const_init_multi * o->sigma_constraint), c->L, 0, thr, rows_live - 3,
+                              rows_c - 3, c_ref);
+      c->pl_psd = false;
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(res4.data(), c->pl_res + 4 * pl, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (!c->h_flags[0] || psd_prior || n > ovp_chol2_max_n() + 1) break;
+      psd_prior = true;
+    }
+    if (c->h_flags[0]) {
+      (void)hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s);
+      return OVP_E_NOTSPD;
+    }
     if (plane_chi2) plane_chi2[pl] = res4[0];
     if (plane_dof) plane_dof[pl] = rows_c;
     if (res4[1] < 0.5) continue;  // chi2 rejected: StateHelper::initialize returns false
@@ -2450,7 +2612,7 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
 // ---- StateHelper::EKFUpdate with a dense host H ------------------------------------------------
 extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int cols, int ld, const int* col_ids,
                               const double* res_host, double* dx_host, ovp_update_info* info) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !H_host || !col_ids || !res_host || rows < 1 || cols < 1 || ld < rows) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (cols > c->n) return OVP_E_ARG;
@@ -2557,11 +2719,7 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
 // stacked on the device, StateHelper::EKFUpdate on that stack (S-form up to 80 rows, information form above), one synchronisation.
 extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_slam_batch* b, double* dx_host, uint8_t* status_host,
                                double* chi2_host, ovp_update_info* info) {
-  if (c) {
-    c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
-    c->use_kept_factor = false;
-    c->point_nl = 0;
-  }
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !o || !b || b->n_landmarks < 0) return OVP_E_ARG;
   if (!c->have_state || !c->have_cov) return OVP_E_STATE;
   const int L = b->n_landmarks, n = c->n, M = b->max_meas;
@@ -2857,7 +3015,7 @@ extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_s
 // ---- propagation / clone / marginalise ---------------------------------------------------------
 extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const int* old_ids, const int* old_sizes,
                                  int n_old, const double* Phi_host, const double* Q_host, int* neg_diag) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !old_ids || !old_sizes || !Phi_host || !Q_host || phi_size < 1 || n_old < 1) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   const int n = c->n;
@@ -2897,18 +3055,24 @@ extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const 
 }
 
 extern "C" int ovp_cov_clone(ovp_ctx* c, int src_id, int size) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || size < 1 || src_id < 0) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (src_id + size > c->n) return OVP_E_ARG;
   if (c->n + size > c->n_max) return OVP_E_CAPACITY;
-  HIPCHK(ovp_launch_cov_clone(c->P, c->ld, c->n, src_id, size, c->stream));
+  HIPCHK(ovp_launch_cov_clone(c->P, c->ld, c->n, src_id, size, c->clone_jitter, c->stream));
   c->n += size;
   return 0;
 }
 
+extern "C" int ovp_cov_clone_jitter(ovp_ctx* c, double relative_inflation) {
+  if (!c || !(relative_inflation >= 0.0) || relative_inflation > 1e-6) return OVP_E_ARG;
+  c->clone_jitter = relative_inflation;
+  return 0;
+}
+
 extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || size < 1 || id < 0) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (id + size > c->n) return OVP_E_ARG;
@@ -2922,7 +3086,7 @@ extern "C" int ovp_cov_marginalize(ovp_ctx* c, int id, int size) {
 
 extern "C" int ovp_cov_initialize_invertible(ovp_ctx* c, const double* H_R, int k, int cols, int ld, const int* col_ids,
                                              const double* H_Linv, const double* R) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !H_R || !col_ids || !H_Linv || !R || k < 1 || k > 6 || cols < 1 || ld < k) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   const int n = c->n;
@@ -2955,7 +3119,7 @@ extern "C" int ovp_cov_initialize_invertible(ovp_ctx* c, const double* H_R, int 
 }
 
 extern "C" int ovp_cov_augment_dt(ovp_ctx* c, int pose_id, int dt_id, const double dnc_dt[6]) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !dnc_dt) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;
   if (pose_id < 0 || pose_id + 6 > c->n || dt_id < 0 || dt_id >= c->n) return OVP_E_ARG;
@@ -2968,7 +3132,7 @@ extern "C" int ovp_cov_augment_dt(ovp_ctx* c, int pose_id, int dt_id, const doub
 extern "C" int ovp_cov_initialize(ovp_ctx* c, const double* Hx_init, const double* H_up, int k, int rup, int cols, const int* col_ids,
                                   const double* H_Linv, const double* R_init, const double* res_up, double r_iso,
                                   double chi2_threshold, int do_update, int* accepted, double* chi2, double* dx_host) {
-  if (c) c->have_factor = false;  // (writes the covariance: a kept factor no longer belongs to it)
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
   if (!c || !Hx_init || !col_ids || !H_Linv || !R_init || k < 1 || k > 6 || cols < 1 || rup < 0) return OVP_E_ARG;
   if (rup > 0 && (!H_up || !res_up || !(r_iso > 0.0))) return OVP_E_ARG;
   if (!c->have_cov) return OVP_E_STATE;

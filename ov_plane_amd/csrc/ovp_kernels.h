@@ -7,7 +7,6 @@
 #define OVP_CHI2_TABLE 1024  // chi2_table[k] for k = 0..OVP_CHI2_TABLE (k=0 unused)
 #define OVP_MAX_CLONES 64
 #define OVP_GRAM_ELEMS 231   // 21*22/2: packed upper triangle of the per-clone 21x21 Gram
-#define OVP_CLONE_JITTER 1e-11  // relative inflation of the diagonal of a cloned covariance block (k_cov_clone)
 #define OVP_TC_MAX_TILES 18  // tile rows the register-resident Cholesky handles (N <= 288)
 #define OVP_BSCR 2112        // doubles of per-feature scratch for B (k_feat.hip LCOLS)
 #define OVP_LDG_CAP 704      // max leading dimension of the projector-row buffer G (LDS staging in the feature kernels)

@@ -122,8 +122,13 @@ def test_no_dpp_read_after_valu_write_hazard_in_the_built_kernels():
     bad, n = chk.check_disassembly(fn + ["\tv_mov_b32_e32 v6, v9// 0", "\tv_mov_b32_dpp v1, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf// 0"], "t")
     assert not bad
     build_lib()
+    from ov_plane_amd.build import SOURCES
+
+    want = sorted(os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES)
+    if not all(os.path.exists(o) for o in want):  # a library that is up to date beside a cleaned object directory
+        build_lib(force=True)
     objs = sorted(glob.glob(os.path.join(OBJ_DIR, "*.o")))
-    assert objs
+    assert objs == want, (objs, want)   # exactly the translation units the shipped library is linked from
     n_total = 0
     for o in objs:
         bad, n, ncos = chk.check_object(o)
