@@ -286,6 +286,21 @@ typedef struct {
 int ovp_slam_update(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_slam_batch *batch, double *dx_host, uint8_t *status,
                     double *chi2, ovp_update_info *info);
 
+/* UpdaterSLAM::delayed_init downstream of triangulation (update/UpdaterSLAM.cpp:204-364) for GLOBAL_3D landmarks without plane rows:
+ * the candidates of the batch one after the other - get_feature_jacobian_full at the pose tables as the previous candidate left
+ * them, StateHelper::initialize (Givens split :434-446, chi2 of the update rows with dof = all rows :464-475,
+ * initialize_invertible :489-586, EKFUpdate with the update rows :483-485) - as ONE enqueue with one synchronisation: the loop
+ * runs on the device (csrc/k_dinit.hip), three launches per candidate, the device pose tables are updated on the way.
+ * Every accepted candidate appends a 3-dof landmark: new_id[l] = its Type::id() after the call (ids are handed out in order over
+ * the accepted ones, as the reference does), else -1.  delta_init[3l..] = H_L^-1 res_init, which the caller adds to the new
+ * landmark's value (:577); dx[l*dx_stride ..] = the correction of candidate l's EKF update for every variable that was in the
+ * state at that point (the landmarks initialised earlier in the call and its own included, at their final ids), to be applied
+ * in order with Type::update; zeros for a rejected candidate.  dx_stride >= state size + 3 * n_feats.
+ * OVP_E_CAPACITY (nothing touched): the state would outgrow the context, or a track is too long for the one-workgroup S-form -
+ * the caller then takes ovp_cov_initialize candidate by candidate. */
+int ovp_slam_delayed_init(ovp_ctx *ctx, const ovp_update_opts *opts, const ovp_feature_batch *candidates, uint8_t *ok,
+                          double *chi2, int *new_id, double *delta_init, double *dx, int dx_stride);
+
 /* StateHelper::EKFPropagation (state/StateHelper.cpp:41-119): new variables occupy [new_start, new_start+phi_size),
  * Phi is [phi_size x sum(old_sizes)] column-major, Q is [phi_size x phi_size] (upper triangle read). */
 int ovp_cov_propagate(ovp_ctx *ctx, int new_start, int phi_size, const int *old_ids, const int *old_sizes, int n_old,

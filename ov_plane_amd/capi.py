@@ -139,7 +139,7 @@ EXPORTS = [
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
     "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
     "ovp_slam_update", "ovp_cov_clone_jitter", "ovp_rccl_unique_id", "ovp_rccl_comm_create", "ovp_rccl_comm_destroy",
-    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded",
+    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded", "ovp_slam_delayed_init",
 ]
 
 
@@ -177,6 +177,8 @@ def lib():
         L.ovp_ekf_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(UpdateInfo)]
         L.ovp_cov_clone_jitter.argtypes = [C.c_void_p, C.c_double]
+        L.ovp_slam_delayed_init.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(FeatureBatch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int]
         L.ovp_rccl_unique_id.argtypes = [C.c_void_p]
         L.ovp_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.ovp_rccl_comm_destroy.argtypes = [C.c_void_p]
@@ -589,6 +591,28 @@ class Context:
         if raise_on_error:
             _chk(rc, "ovp_slam_update")
         return dict(dx=dx, status=status[:L], chi2=chi2[:L], info=info, rc=rc)
+
+    def slam_delayed_init(self, opts: UpdateOpts, uv, clone_idx, n_meas, p_FinG, raise_on_error=True):
+        """ovp_slam_delayed_init: the candidate loop of UpdaterSLAM::delayed_init on the device.  Returns dict(ok [L], chi2 [L],
+        new_id [L], delta_init [L,3], dx [L, stride] in the final column layout, rc)."""
+        n_meas = np.ascontiguousarray(n_meas, dtype=np.int32)
+        L = int(n_meas.shape[0])
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(L, -1, 2)
+        M = uv.shape[1]
+        ci = np.ascontiguousarray(clone_idx, dtype=np.int32).reshape(L, M)
+        p = np.ascontiguousarray(p_FinG, dtype=np.float64).reshape(L, 3)
+        fb = FeatureBatch(L, M, uv.ctypes.data, ci.ctypes.data, n_meas.ctypes.data, p.ctypes.data)
+        stride = self.cov_size() + 3 * L
+        ok = np.zeros(max(L, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(L, 1))
+        nid = -np.ones(max(L, 1), dtype=np.int32)
+        dl = np.zeros((max(L, 1), 3))
+        dx = np.zeros((max(L, 1), stride))
+        rc = lib().ovp_slam_delayed_init(self._h, C.byref(opts), C.byref(fb), ok.ctypes.data, chi2.ctypes.data, nid.ctypes.data,
+                                         dl.ctypes.data, dx.ctypes.data, stride)
+        if raise_on_error:
+            _chk(rc, "ovp_slam_delayed_init")
+        return dict(ok=ok[:L].astype(bool), chi2=chi2[:L], new_id=nid[:L], delta_init=dl[:L], dx=dx[:L], rc=rc)
 
     def cov_initialize(self, Hx_init, H_up, col_ids, H_Linv, R_init, res_up, r_iso, chi2_threshold, do_update=True):
         """StateHelper::initialize downstream of its Givens split as one device sequence (state/StateHelper.cpp:448-487):

@@ -224,6 +224,10 @@ public:
                     const std::map<size_t, size_t> &feat2plane);
   // update/UpdaterSLAM.cpp:684-706: landmarks anchored in the clone that is about to be marginalised move to the newest one
   void change_anchors(std::shared_ptr<State> state);
+  // the per-candidate form of delayed_init (host Jacobians, one StateHelper::initialize each): representations other than
+  // GLOBAL_3D and candidates with plane rows; delayed_init itself runs GLOBAL_3D candidates as one device loop
+  void delayed_init_host_loop(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                              const std::map<size_t, size_t> &feat2plane);
   // pose tables of the clone window + camera calibration -> device (ovp_state_upload); clone_slot: timestamp -> clone slot
   static void upload_state_tables(std::shared_ptr<State> state, std::map<double, int> &clone_slot,
                                   std::vector<std::shared_ptr<ov_type::PoseJPL>> &clones);

@@ -764,6 +764,11 @@ DelayedInitProfile g_diprof;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
+static bool fused_initialize_on() {  // OVP_HOST_INIT_SPLIT=1: the three separate device calls per candidate (A/B runs, tests)
+  const char *e = getenv("OVP_HOST_INIT_SPLIT");
+  return !(e && e[0] == '1');
+}
+
 void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                                const std::map<size_t, size_t> &feat2plane) {
   if (feature_vec.empty()) return;
@@ -800,6 +805,128 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     m3v(cal->Rot(), t, ft.p_FinA);
     for (int k = 0; k < 3; ++k) ft.p_FinA[k] += cal->pos()[k];
   }
+  // ---- the candidate loop on the device (ovp_slam_delayed_init, csrc/k_dinit.hip): GLOBAL_3D landmarks without plane rows -
+  // every shipped configuration's feat_rep_slam - run as ONE enqueue: rows at the device tables, split, gate, augmentation,
+  // update and the Type::update of the device tables per candidate without the host in between.  Candidates that carry plane
+  // rows (use_plane_constraint_slamd with the plane in the state) and the other representations take the per-candidate path
+  // below (dense Jacobians on the host); the order of the vector is kept (every initialisation moves the state of the next).
+  auto wants_plane = [&](const ov_core::Feature &ft) {
+    if (!(state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamd)) return false;
+    auto fp2 = feat2plane.find(ft.featid);
+    if (fp2 == feat2plane.end() || state->_features_PLANE.find(fp2->second) == state->_features_PLANE.end()) return false;
+    auto s2p = state->_features_SLAM_to_PLANE.find(ft.featid);
+    return s2p == state->_features_SLAM_to_PLANE.end() || s2p->second != 0;
+  };
+  static const bool no_device_loop = getenv("OVP_HOST_DINIT_LOOP") != nullptr;  // A/B: the per-candidate path for everything
+  const bool device_rep = state->_options.feat_rep_slam == LandmarkRepresentation::Representation::GLOBAL_3D && !no_device_loop &&
+                          fused_initialize_on();
+  // flushes the run [run_begin, it) of device candidates; returns the iterator behind the run (erased entries accounted for)
+  auto flush_run = [&](size_t run_begin, size_t run_end) -> size_t {
+    const int L = (int)(run_end - run_begin);
+    if (L <= 0) return run_end;
+    std::map<double, int> clone_slot;
+    std::vector<std::shared_ptr<PoseJPL>> clones;
+    upload_state_tables(state, clone_slot, clones);
+    int M = 2;
+    for (int l = 0; l < L; ++l) M = std::max(M, (int)feature_vec[run_begin + l]->timestamps.size());
+    if (M > OVP_MAX_MEAS) return (size_t)-1;
+    std::vector<float> uv((size_t)L * M * 2, 0.f);
+    std::vector<int> cidx((size_t)L * M, -1), nm(L);
+    std::vector<double> pf((size_t)L * 3);
+    for (int l = 0; l < L; ++l) {
+      ov_core::Feature &ft = *feature_vec[run_begin + l];
+      nm[l] = (int)ft.timestamps.size();
+      for (int k = 0; k < nm[l]; ++k) {
+        cidx[(size_t)l * M + k] = clone_slot.at(ft.timestamps[k]);
+        uv[((size_t)l * M + k) * 2] = ft.uvs[2 * k];
+        uv[((size_t)l * M + k) * 2 + 1] = ft.uvs[2 * k + 1];
+      }
+      memcpy(&pf[3 * l], ft.p_FinG, 3 * sizeof(double));
+    }
+    ovp_feature_batch fb{L, M, uv.data(), cidx.data(), nm.data(), pf.data()};
+    ovp_update_opts uo;
+    memset(&uo, 0, sizeof(uo));
+    uo.sigma_px = _options_slam.sigma_pix;
+    uo.chi2_multiplier = _options_slam.chi2_multipler;
+    uo.sigma_constraint = state->_options.sigma_constraint;
+    uo.do_fej = state->_options.do_fej ? 1 : 0;
+    uo.do_calib_camera_pose = state->_options.do_calib_camera_pose ? 1 : 0;
+    uo.do_calib_camera_intrinsics = state->_options.do_calib_camera_intrinsics ? 1 : 0;
+    const int stride = ovp_cov_size(state->_gpu) + 3 * L;
+    std::vector<uint8_t> okv(L, 0);
+    std::vector<int> nid(L, -1);
+    std::vector<double> dl((size_t)3 * L, 0.0), dxs((size_t)L * stride, 0.0);
+    const double t_c = now_s();
+    const int rc = ovp_slam_delayed_init(state->_gpu, &uo, &fb, okv.data(), nullptr, nid.data(), dl.data(), dxs.data(), stride);
+    if (rc == OVP_E_CAPACITY) return (size_t)-1;  // nothing was touched: the caller takes these candidates one by one
+    if (rc == OVP_E_NEGDIAG) {
+      fprintf(stderr, "StateHelper::EKFUpdate() - negative covariance diagonal\n");
+      std::exit(EXIT_FAILURE);
+    }
+    gpu_check2(rc, "ovp_slam_delayed_init");
+    g_diprof.t_init += now_s() - t_c;
+    g_diprof.cands += L;
+    size_t pos = run_begin;
+    for (int l = 0; l < L; ++l) {
+      ov_core::Feature &ft = *feature_vec[pos];
+      ft.to_delete = true;
+      if (!okv[l]) {  // :360-363
+        feature_vec.erase(feature_vec.begin() + (long)pos);
+        continue;
+      }
+      auto landmark = std::make_shared<Landmark>(3);  // :285-296
+      landmark->_featid = ft.featid;
+      landmark->_feat_representation = LandmarkRepresentation::Representation::GLOBAL_3D;
+      landmark->_unique_camera_id = ft.anchor_cam_id;
+      landmark->set_from_xyz(ft.p_FinG, false);
+      landmark->set_from_xyz(ft.p_FinG, true);
+      VectorXd d(3, 1);
+      for (int k = 0; k < 3; ++k) d(k) = dl[3 * l + k];
+      landmark->update(d);  // state/StateHelper.cpp:577
+      landmark->set_local_id(nid[l]);
+      state->_variables.push_back(landmark);
+      StateHelper::apply_correction(state, &dxs[(size_t)l * stride]);  // :483-485 Type::update of every variable
+      state->_features_SLAM.insert({ft.featid, landmark});
+      g_diprof.accepted++;
+      ++pos;
+    }
+    return pos;
+  };
+  if (device_rep) {
+    size_t i = 0;
+    bool all_done = true;
+    while (i < feature_vec.size()) {
+      size_t j = i;
+      while (j < feature_vec.size() && !wants_plane(*feature_vec[j])) ++j;
+      if (j > i) {
+        const size_t behind = flush_run(i, j);
+        if (behind == (size_t)-1) {
+          all_done = false;
+          break;
+        }
+        i = behind;
+      }
+      if (i < feature_vec.size() && wants_plane(*feature_vec[i])) {
+        all_done = false;  // a candidate with plane rows: the per-candidate path takes over from here
+        break;
+      }
+    }
+    if (all_done) return;
+    // (what is left - from position i on - goes through the loop below; the accepted ones in front of it are done and flagged)
+    std::vector<std::shared_ptr<ov_core::Feature>> rest(feature_vec.begin() + (long)i, feature_vec.end());
+    std::vector<std::shared_ptr<ov_core::Feature>> head(feature_vec.begin(), feature_vec.begin() + (long)i);
+    delayed_init_host_loop(state, rest, feat2plane);
+    feature_vec = head;
+    feature_vec.insert(feature_vec.end(), rest.begin(), rest.end());
+    return;
+  }
+  delayed_init_host_loop(state, feature_vec, feat2plane);
+}
+
+// update/UpdaterSLAM.cpp:204-364 candidate by candidate: dense Jacobians on the host (every representation, plane rows with their
+// fallback), StateHelper::initialize on the device per candidate
+void UpdaterSLAM::delayed_init_host_loop(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                                         const std::map<size_t, size_t> &feat2plane) {
   auto it2 = feature_vec.begin();
   while (it2 != feature_vec.end()) {
     UpdaterHelper::UpdaterHelperFeature feat;

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
 // Grid (T, T), T = ceil(n2 / 16); 256 threads.  Dynamic LDS: Li [rup][rup] | Mi, Mj [16][rup] | Wi, Wj [16][rup + 1].
 // Pdst[tile] = Psrc[tile] - W_I W_J^T; the tiles of block column 0 also leave dx = W y.  Nothing is written when the gate said
 // no (res[1] == 0): the caller then keeps Psrc.
-__global__ __launch_bounds__(256) void k_init_update(const double* __restrict__ Psrc, double* __restrict__ Pdst, int ldp, int n2,
+__global__ __launch_bounds__(256) void k_init_update(const double* Psrc, double* Pdst /* may be Psrc: an element is read and written by its own thread only */, int ldp, int n2,
                                                       const double* __restrict__ Mall, int m, int k, int rup,
                                                       const double* __restrict__ Linv, const double* __restrict__ y,
                                                       double* __restrict__ res, double* __restrict__ dx) {

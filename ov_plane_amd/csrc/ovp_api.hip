@@ -17,6 +17,7 @@
 #include "k_chol2.h"
 #include "k_plane2.h"
 #include "k_slam.h"
+#include "k_dinit.h"
 
 extern "C" int ovp_dbg_tilechol_skip;
 extern "C" {
@@ -204,6 +205,8 @@ struct ovp_ctx {
   void* slam_res = nullptr;        // ovp_slam_update: per-landmark [chi2 | status]
   double* slam_hscr = nullptr;     // ... blocks that do not fit LDS
   size_t slam_res_cap = 0, slam_hscr_cap = 0;
+  double* dinit_buf = nullptr;     // ovp_slam_delayed_init: result blocks + shared scratch of the candidate loop
+  size_t dinit_cap = 0;
   size_t Hd_cap = 0, res_cap = 0;
   int calib_id = -1, intr_id = -1;
   long long* dbg_cycles = nullptr;
@@ -480,7 +483,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
                  c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
                  c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage, c->pl_xbuf, c->pl_xy, c->pl_xflag, c->pl_Asum,
-                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr};
+                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr, c->dinit_buf};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -3010,6 +3013,182 @@ extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_s
   if (c->h_flags[0]) return OVP_E_NOTSPD;
   if (c->h_flags[1]) return OVP_E_NEGDIAG;
   return 0;
+}
+
+// ---- UpdaterSLAM::delayed_init, candidate loop on the device (update/UpdaterSLAM.cpp:204-364; csrc/k_dinit.hip) -----------------
+extern "C" int ovp_slam_delayed_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_feature_batch* b, uint8_t* ok_host,
+                                     double* chi2_host, int* new_id, double* delta_init, double* dx_host, int dx_stride) {
+  drop_kept_factor(c);  // (writes the covariance: a kept factor no longer belongs to it)
+  if (!c || !o || !b || b->n_feats < 0) return OVP_E_ARG;
+  if (!c->have_state || !c->have_cov) return OVP_E_STATE;
+  const int L = b->n_feats, M = b->max_meas, n0 = c->n, ld = c->ld;
+  if (L == 0) return 0;
+  if (M < 2 || M > OVP_MAX_MEAS || !b->uv || !b->clone_idx || !b->n_meas || !b->p_FinG) return OVP_E_ARG;
+  if (dx_host && dx_stride < n0 + 3 * L) return OVP_E_ARG;
+  if (n0 + 3 * L > c->n_max) return OVP_E_CAPACITY;
+  const unsigned calmask = (o->do_calib_camera_pose ? 0x3Fu : 0u) | (o->do_calib_camera_intrinsics ? (0xFFu << 6) : 0u);
+  const int ncal = __builtin_popcount(calmask);
+  int calcol[14];
+  for (int k = 0; k < 14; ++k) {
+    calcol[k] = (k < 6) ? c->calib_id + k : c->intr_id + (k - 6);
+    if (!((calmask >> k) & 1)) calcol[k] = 0;
+    else if (calcol[k] < 0 || calcol[k] >= n0) return OVP_E_ARG;
+  }
+  const int C = (int)c->h_clone_id.size();
+  int cols_max = 1, rows_max = 4;
+  for (int l = 0; l < L; ++l) {
+    const int m = b->n_meas[l];
+    if (m < 2 || m > M) return OVP_E_ARG;  // (update/UpdaterSLAM.cpp:112-118: the caller drops shorter tracks)
+    for (int a = 0; a < m; ++a) {
+      const int ci = b->clone_idx[(size_t)l * M + a];
+      if (ci < 0 || ci >= C) return OVP_E_ARG;
+    }
+    const int cols = 6 * m + ncal, rup = 2 * m - 3;
+    // outside the one-workgroup S-form (k_init.hip): the caller takes StateHelper::initialize candidate by candidate; nothing touched
+    if (rup > ovp_init_max_rows() || ovp_init_core_lds(3, rup, cols) > ovp_init_max_lds() ||
+        ovp_dinit_rows_lds(m, ncal, (n0 + 3 * L) | 1, 0) > OVP_DINIT_DYN_LDS) return OVP_E_CAPACITY;
+    cols_max = std::max(cols_max, cols);
+    rows_max = std::max(rows_max, 2 * m);
+  }
+  hipStream_t s = c->stream;
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  // staging: the candidates as a feature batch + their column lists
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o0 = off;
+    off = al(off + bytes);
+    return o0;
+  };
+  const size_t o_p = take(sizeof(double) * 3 * L), o_uv = take(sizeof(float) * 2 * (size_t)L * M), o_ci = take(sizeof(int) * (size_t)L * M),
+               o_nm = take(sizeof(int) * L), o_id = take(sizeof(int) * (size_t)L * cols_max);
+  const size_t stage_bytes = off;
+  const size_t res_doubles = 4 + (size_t)c->n_max + 8;
+  int rc = plane2_buffers(c, 0, stage_bytes, sizeof(double) * res_doubles * L + 64);
+  if (rc) return rc;
+  char* h = (char*)c->pl_hstage;
+  char* d = (char*)c->pl_dstage;
+  memcpy(h + o_p, b->p_FinG, sizeof(double) * 3 * L);
+  memcpy(h + o_uv, b->uv, sizeof(float) * 2 * (size_t)L * M);
+  memcpy(h + o_ci, b->clone_idx, sizeof(int) * (size_t)L * M);
+  memcpy(h + o_nm, b->n_meas, sizeof(int) * L);
+  for (int l = 0; l < L; ++l) {
+    int* ids = (int*)(h + o_id) + (size_t)l * cols_max;
+    const int m = b->n_meas[l];
+    for (int a = 0; a < m; ++a)
+      for (int k = 0; k < 6; ++k) ids[6 * a + k] = c->h_clone_id[b->clone_idx[(size_t)l * M + a]] + k;
+    int q = 6 * m;
+    for (int k = 0; k < 14; ++k)
+      if ((calmask >> k) & 1) ids[q++] = calcol[k];
+  }
+  // device scratch: [result blocks L x res_doubles | Ht | Mall | Linv | y | Hinv 9 | Rk 9 | resid]
+  const size_t n_end = (size_t)n0 + 3 * L;
+  const size_t need = res_doubles * L + (size_t)cols_max * rows_max + n_end * rows_max + (size_t)rows_max * rows_max + rows_max + 32 +
+                      rows_max + 64;
+  if (need > c->dinit_cap) {
+    if (c->dinit_buf) hipFree(c->dinit_buf);
+    c->dinit_buf = nullptr;
+    c->dinit_cap = 0;
+    HIPCHK(dalloc(&c->dinit_buf, need + 1024));
+    c->dinit_cap = need + 1024;
+  }
+  double* dres0 = c->dinit_buf;
+  double* dHt = dres0 + res_doubles * L;
+  double* dM = dHt + (size_t)cols_max * rows_max;
+  double* dLi = dM + n_end * rows_max;
+  double* dy = dLi + (size_t)rows_max * rows_max;
+  double* dHinv = dy + rows_max + 8;
+  double* dRk = dHinv + 12;
+  double* dresid = dRk + 12;
+  HIPCHK(hipMemcpyAsync(d, h, stage_bytes, hipMemcpyHostToDevice, s));
+  ovp::DinitParams dp;
+  memset(&dp, 0, sizeof(dp));
+  dp.fp = c->fp;
+  dp.fp.uv = (const float*)(d + o_uv);
+  dp.fp.clone_idx = (const int*)(d + o_ci);
+  dp.fp.n_meas = (const int*)(d + o_nm);
+  dp.fp.p_FinG = (const double*)(d + o_p);
+  dp.fp.n_feats = L;
+  dp.fp.max_meas = M;
+  dp.fp.do_fej = o->do_fej;
+  dp.fp.calmask = calmask;
+  for (int k = 0; k < 14; ++k) dp.fp.calcol[k] = calcol[k];
+  dp.fp.white_px = 1.0 / o->sigma_px;
+  dp.fp.ldp = ld;
+  dp.n_max = c->n_max;
+  dp.n_pad = (n0 + 3 * L) | 1;
+  dp.P = c->P;
+  dp.clone_R = c->clone_R;
+  dp.clone_p = c->clone_p;
+  dp.cal = c->cal;
+  dp.Ht = dHt;
+  dp.Mall = dM;
+  dp.Hinv = dHinv;
+  dp.Rk = dRk;
+  dp.resid = dresid;
+  for (int l = 0; l < L; ++l) {
+    const int m = b->n_meas[l], cols = 6 * m + ncal, rows = 2 * m, rup = rows - 3, n = n0 + 3 * l;
+    dp.cand = l;
+    dp.m_obs = m;
+    // M = P[:, ids] H_all^T: inside the rows kernel (one workgroup, MFMA from LDS: 3 launches per candidate) or by k_init_m on many
+    // workgroups (4 launches); OVP_DINIT_FUSED_M=1 selects the former
+    static const bool fused_m = getenv("OVP_DINIT_FUSED_M") != nullptr;
+    dp.skip_m = fused_m ? 0 : 1;
+    dp.full = fused_m ? ovp_dinit_full_stage(m, ncal, n, dp.n_pad) : 0;
+    dp.n = n;
+    dp.prev_res = l ? dres0 + res_doubles * (l - 1) : nullptr;
+    dp.ids = (const int*)(d + o_id) + (size_t)l * cols_max;
+    memcpy(dp.idv, (const int*)(h + o_id) + (size_t)l * cols_max, sizeof(int) * cols);
+    dp.res = dres0 + res_doubles * l;
+    HIPCHK(ovp_launch_dinit_rows(&dp, ovp_dinit_rows_lds(m, ncal, dp.n_pad, dp.full), s));
+    if (dp.skip_m) HIPCHK(ovp_launch_init_m(c->P, ld, n, dp.ids, cols, dHt, rows, dM, s));
+    // chi2 of the update rows with dof = all rows (StateHelper.cpp:471), initialize_invertible, update in place
+    const double thr = o->chi2_multiplier * ovp_chi2_quantile_095(rows);
+    HIPCHK(ovp_launch_init_core(c->P, ld, n, dp.ids, cols, dHt, 3, rup, dM, dHinv, dRk, dresid, 1.0, thr, dLi, dy, dp.res, s));
+    HIPCHK(ovp_launch_init_update(c->P, c->P, ld, n + 3, dM, rows, 3, rup, dLi, dy, dp.res, dp.res + 4, s));
+  }
+  dp.cand = -1;
+  dp.skip_m = 1;
+  dp.full = 0;
+  dp.n = (int)n_end;
+  dp.prev_res = dres0 + res_doubles * (L - 1);
+  HIPCHK(ovp_launch_dinit_rows(&dp, 64, s));
+  double* hres = (double*)c->pl_hres;
+  HIPCHK(hipMemcpyAsync(hres, dres0, sizeof(double) * res_doubles * L, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  c->n = (int)n_end;
+  // final layout: the inert blocks of the rejected candidates go (last first), the accepted ones move up
+  std::vector<int> final_id(L, -1);
+  int n_acc = 0, negdiag = 0;
+  for (int l = 0; l < L; ++l) {
+    const double* r = hres + res_doubles * l;
+    if (r[1] > 0.5) final_id[l] = n0 + 3 * n_acc++;
+    if (r[1] > 0.5 && r[2] != 0.0) negdiag = 1;
+  }
+  for (int l = L - 1; l >= 0; --l)
+    if (final_id[l] < 0) {
+      rc = ovp_cov_marginalize(c, n0 + 3 * l, 3);
+      if (rc) return rc;
+    }
+  for (int l = 0; l < L; ++l) {
+    const double* r = hres + res_doubles * l;
+    const bool ok = r[1] > 0.5;
+    if (ok_host) ok_host[l] = ok ? 1 : 0;
+    if (chi2_host) chi2_host[l] = r[0];
+    if (new_id) new_id[l] = final_id[l];
+    if (delta_init)
+      for (int k = 0; k < 3; ++k) delta_init[3 * l + k] = ok ? r[4 + c->n_max + k] : 0.0;
+    if (dx_host) {
+      double* dx = dx_host + (size_t)l * dx_stride;
+      memset(dx, 0, sizeof(double) * dx_stride);
+      if (ok) {
+        memcpy(dx, r + 4, sizeof(double) * n0);
+        for (int g = 0; g <= l; ++g)  // the landmarks that were state variables at that point, at their final ids
+          if (final_id[g] >= 0)
+            for (int k = 0; k < 3; ++k) dx[final_id[g] + k] = r[4 + n0 + 3 * g + k];
+      }
+    }
+  }
+  return negdiag ? OVP_E_NEGDIAG : 0;
 }
 
 // ---- propagation / clone / marginalise ---------------------------------------------------------

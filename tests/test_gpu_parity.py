@@ -2778,3 +2778,55 @@ def test_native_rccl_sharded_update_on_one_rank_is_the_plain_update(hiplib, orac
             assert np.array_equal(a["dx"], b["dx"]) and np.array_equal(a["P"], b["P"]) and np.array_equal(a["chi2"], b["chi2"])
     finally:
         capi.rccl_comm_destroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(C=11, F=8, seed=5, ragged=True),
+    dict(C=8, F=6, seed=6, ragged=True, chi2_mult=0.6),   # two candidates fail the gate: inert blocks, removed behind the loop
+    dict(C=14, F=12, seed=7, ragged=True, do_fej=False),
+    dict(C=9, F=5, seed=8, ragged=False, fisheye=True),
+])
+def test_slam_delayed_init_loop_on_the_device_matches_oracle(hiplib, oracle, kw):
+    """ovp_slam_delayed_init (csrc/k_dinit.hip): the candidate loop of UpdaterSLAM::delayed_init (update/UpdaterSLAM.cpp:204-364) as
+    one enqueue - rows at the device tables the previous candidate left, Householder split, chi2, initialize_invertible, update in
+    place, commit - against ovo_slam_delayed_init: decisions, ids, landmark values, pose tables and covariance."""
+    from ov_plane_amd.synth import quat_boxplus
+
+    capi = hiplib
+    sc = make_scene(**kw)
+    ref = oracle.slam_delayed_init(sc)
+    assert ref["ok"].any()
+    if "chi2_mult" in kw:
+        assert not ref["ok"].all()
+    cap = sc.N + 3 * sc.F
+    ctx = capi.Context(cap, sc.C, sc.F, device=0)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    out = ctx.slam_delayed_init(capi.opts_from_scene(sc), sc.uv, sc.clone_idx, sc.n_meas, sc.p_FinG)
+    assert (out["ok"] == ref["ok"]).all() and (out["new_id"] == ref["new_id"]).all()
+    assert np.abs(out["chi2"] - ref["chi2"]).max() <= 1e-7 * max(1.0, np.abs(ref["chi2"]).max())
+    assert ctx.cov_size() == ref["n"]
+    # the caller's side: Type::update in order (landmark value = triangulated point + H_L^-1 res_init + every later correction)
+    cq, cpos, intr = sc.clone_q.copy(), sc.clone_p.copy(), sc.intr.copy()
+    p = sc.p_FinG.copy()
+    for l in range(sc.F):
+        if not out["ok"][l]:
+            continue
+        dx = out["dx"][l]
+        p[l] += out["delta_init"][l]
+        for g in range(l + 1):
+            if out["ok"][g]:
+                i = int(out["new_id"][g])
+                p[g] += dx[i:i + 3]
+        for i in range(sc.C):
+            cid = sc.ids["clones"][i]
+            cq[i] = quat_boxplus(cq[i], dx[cid:cid + 3])
+            cpos[i] = cpos[i] + dx[cid + 3:cid + 6]
+        intr = intr + dx[22:30]
+    ok = ref["ok"]
+    assert np.abs(p[ok] - ref["p"][ok]).max() < TOL_DX
+    assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
+    assert np.abs(intr - ref["intr"]).max() < TOL_DX
+    assert relP(ctx.cov_download(), ref["P"]) < TOL_P
+    ctx.close()
