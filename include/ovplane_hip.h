@@ -94,7 +94,9 @@ typedef struct {
   int reserved[3];
 } ovp_update_info;
 
-#define OVP_PLANE_MAX_SLAM 16 /* SLAM landmarks on ONE out-of-state plane handled by ovp_msckf_plane_update */
+#define OVP_PLANE_MAX_SLAM 80 /* SLAM landmarks on ONE out-of-state plane handled by ovp_msckf_plane_update: above every
+                                 max_slam_features of the shipped configurations (25 .. 75), so that no plane of a real frame meets it;
+                                 each landmark also adds three involved columns to the loop's 287-column budget */
 
 /* ---- context --------------------------------------------------------------------------------- */
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create its own.
