@@ -716,7 +716,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ __attribute__((aligned(16))) double smem[8 * 2560];
   static_assert(tilechol_lds_doubles(OVP_TC_MAX_TILES) <= 8 * 2560, "chol(P) must fit in the workgroup's LDS");
   if (blockIdx.x == 0) {
-    if (c.n > 0) tilechol_body<MAXSLOT>(c.A, c.L, c.Dinv, c.Lpack, c.n, c.ld, c.flag, 0, 0, smem, c.flip);  // (n = 0: a factor of P is at hand)
+    if (c.n > 0) tilechol_body<MAXSLOT>(c.A, c.L, c.Dinv, c.Lpack, c.n, c.ld, c.flag, 0, 0, smem, c.flip, c.boost, c.boost_n, c.boost_rel);  // (n = 0: a factor of P is at hand)
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -186,21 +186,30 @@ __global__ __launch_bounds__(256) void k_gemm4(int M, int N, int K, const double
 // dx = P b (one wave per row), negative-diagonal flag.  Optionally the LAST block to finish (ticket counter) publishes the
 // result block [flags | dx] = `pub_words` 8-byte words into mapped pinned host memory, then the sequence word the host
 // spins on, and clears the flags and the ticket for the next update - the update then ends without a separate publish launch.
-__global__ __launch_bounds__(256) void k_dx_rows(const double* __restrict__ P, int n, int ldp,
+// boost / boost_n / cancel: CholJob::boost - the amounts chol(P) added to the diagonal of the first boost_n columns come off the
+// updated diagonal again (b is zero on those columns, so dx does not see them); nothing is touched when the update was
+// cancelled (*cancel != 0: a failed factorization left the resident covariance alone)
+__global__ __launch_bounds__(256) void k_dx_rows(double* P, int n, int ldp,
                                                   const double* __restrict__ b, double* __restrict__ dx,
                                                   int* __restrict__ negdiag, unsigned* __restrict__ ticket,
                                                   unsigned long long* __restrict__ res_block,
                                                   unsigned long long* __restrict__ host_block, int pub_words,
-                                                  volatile unsigned* seq_host, unsigned seq) {
+                                                  volatile unsigned* seq_host, unsigned seq, const double* __restrict__ boost,
+                                                  int boost_n, const int* __restrict__ cancel) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row < n) {
-    const double* pr = P + (size_t)row * ldp;
+    double* pr = P + (size_t)row * ldp;
     double s = 0.0;
     for (int c = lane; c < n; c += 64) s = fma(pr[c], b[c], s);
     s = wave_sum(s);
     if (lane == 0) {
       dx[row] = s;
-      if (pr[row] < 0.0) *negdiag = 1;
+      double d = pr[row];
+      if (row < boost_n && !(cancel && *cancel)) {
+        d -= boost[row];
+        pr[row] = d;
+      }
+      if (d < 0.0) *negdiag = 1;
     }
   }
   if (!ticket) return;
@@ -297,12 +306,18 @@ hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const 
   return hipGetLastError();
 }
 
+hipError_t ovp_launch_dx_rows_boost(double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
+                                    unsigned* ticket, void* res_block, void* host_block, int pub_words, void* seq_host,
+                                    unsigned seq, const double* boost, int boost_n, const int* cancel, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_dx_rows, dim3((n + 3) / 4), dim3(256), 0, stream, P, n, ldp, b, dx, negdiag, ticket,
+                     (unsigned long long*)res_block, (unsigned long long*)host_block, pub_words,
+                     (volatile unsigned*)seq_host, seq, boost, boost_n, cancel);
+  return hipGetLastError();
+}
 hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
                               unsigned* ticket, void* res_block, void* host_block, int pub_words, void* seq_host,
                               unsigned seq, hipStream_t stream) {
-  hipLaunchKernelGGL(ovp::k_dx_rows, dim3((n + 3) / 4), dim3(256), 0, stream, P, n, ldp, b, dx, negdiag, ticket,
-                     (unsigned long long*)res_block, (unsigned long long*)host_block, pub_words,
-                     (volatile unsigned*)seq_host, seq);
-  return hipGetLastError();
+  return ovp_launch_dx_rows_boost(const_cast<double*>(P), n, ldp, b, dx, negdiag, ticket, res_block, host_block, pub_words, seq_host,
+                                  seq, nullptr, 0, nullptr, stream);
 }
 }

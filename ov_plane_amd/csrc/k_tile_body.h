@@ -165,7 +165,8 @@ template <int MAXSLOT>
 __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, double* __restrict__ L,
                                               double* __restrict__ Dinv, double* __restrict__ Lpack, int n, int ld,
                                               int* __restrict__ flag, int add_identity, int dbg_skip, double* lds,
-                                              const int flip = 0) {
+                                              const int flip = 0, double* __restrict__ boost = nullptr, const int boost_n = 0,
+                                              const double boost_rel = 0.0) {
   // flip: factorize the matrix in REVERSED index order and store the dense factor with its rows reversed back,
   // Lr[n - 1 - r][c] = chol(J A J)[r][c] (J = exchange matrix): Lr Lr^T = A, and column j of Lr is zero below row n - 1 - j.
   // A point update whose information matrix lives on the TRAILING columns [s0, n) of the state (clones and calibration behind
@@ -240,6 +241,11 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
           double x = flip ? A[(size_t)(n - 1 - rc) * ld + (n - 1 - cc)] : A[(size_t)rc * ld + cc];
           if (i >= nfull) x = (r < n && c < n) ? x : 0.0;  // i >= j: a partial tile is always in the last tile row
           if (r == c) x = (r < n) ? (add_identity ? x + 1.0 : x) : 1.0;  // identity padding keeps the matrix SPD
+          if (flip && r == c && r < n && r >= n - boost_n) {  // CholJob::boost: state column n - 1 - r < boost_n
+            const double add = x * boost_rel;
+            boost[n - 1 - r] = add;
+            x += add;
+          }
           t[v] = x;
         }
       }

@@ -55,6 +55,9 @@ hipError_t ovp_launch_fwdsub(const double* Lt, const double* Dinv, const double*
                              int dense, hipStream_t stream);
 hipError_t ovp_launch_gemm4(int transA, int transB, int M, int N, int K, const double* A, int lda, const double* B,
                             int ldb, double* C, int ldc, int add_identity, int symmetric, hipStream_t stream);
+hipError_t ovp_launch_dx_rows_boost(double* P, int n, int ldp, const double* b, double* dx, int* negdiag, unsigned* ticket,
+                                    void* res_block, void* host_block, int pub_words, void* seq_host, unsigned seq,
+                                    const double* boost, int boost_n, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_dx_rows(const double* P, int n, int ldp, const double* b, double* dx, int* negdiag,
                               unsigned* ticket, void* res_block, void* host_block, int pub_words, void* seq_host,
                               unsigned seq,
@@ -252,6 +255,8 @@ struct ovp_ctx {
   double* Lkeep = nullptr;
   bool have_factor = false, use_kept_factor = false;
   double clone_jitter = 0.0;  // ovp_cov_clone_jitter: relative inflation of a cloned block's diagonal (0 = exact copy, the reference)
+  double* boost = nullptr;   // CholJob::boost: the amounts the reversed-order chol(P) added to the diagonal in front of the batch's columns
+  int point_boost_n = 0;
   int point_nl = 0;  // > 0: chol(P) of the running point update was taken in reversed index order (CholJob::flip) and the update's
                      // T = I + L^T A L is the identity outside its leading point_nl columns          // second attempt of a plane loop whose chol(P) failed: pivot-dropping factor of the PSD prior
   hipEvent_t ev_subtab = nullptr;     // behind the upload of pl_sub_htab (the pinned block is rewritten by the next call)
@@ -310,6 +315,7 @@ static inline void drop_kept_factor(ovp_ctx* c) {
   c->have_factor = false;
   c->use_kept_factor = false;
   c->point_nl = 0;
+  c->point_boost_n = 0;
 }
 
 static inline double host_now_ms() {
@@ -483,7 +489,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
                  c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
                  c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage, c->pl_xbuf, c->pl_xy, c->pl_xflag, c->pl_Asum,
-                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr, c->dinit_buf};
+                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr, c->dinit_buf, c->boost};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -980,8 +986,10 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     const double* Lf = kept ? c->Lkeep : c->L;
     // leading block of T (reversed-order factor of P, see ovp_build_gate_gram_tail): n when the factor is the plain one
     const int nl = (!kept && chol_p_done_on_stream2 && c->point_nl > 0 && c->point_nl < n) ? c->point_nl : n;
+    const int boost_n = nl < n ? c->point_boost_n : 0;  // (CholJob::boost: set together with the reversed-order factor)
     c->use_kept_factor = false;
     c->point_nl = 0;
+    c->point_boost_n = 0;
     c->have_factor = false;  // P is about to change
     HIPCHK(ovp_launch_gemm4(0, 0, n, nl, n, c->Ab, ld, Lf, ld, c->W1, ld, 0, 0, c->stream));
     HIPCHK(ovp_launch_gemm4(1, 0, nl, nl, n, Lf, ld, c->W1, ld, c->T, ld, 1, 1, c->stream));
@@ -994,11 +1002,13 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
       // the last block of the dx kernel also publishes [flags | dx] to the pinned host block (no separate launch)
       const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
       c->pub_seq = ++c->seq;
-      HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, c->ticket, c->res_block, c->h_res_block_dev, words,
-                                (char*)c->h_res_block_dev + ((char*)c->h_seq - (char*)c->h_res_block), c->pub_seq, c->stream));
+      HIPCHK(ovp_launch_dx_rows_boost(c->P, n, ld, b, c->dx, c->flags + 1, c->ticket, c->res_block, c->h_res_block_dev, words,
+                                      (char*)c->h_res_block_dev + ((char*)c->h_seq - (char*)c->h_res_block), c->pub_seq, c->boost,
+                                      boost_n, c->flags, c->stream));
       c->pub_pending = true;
     } else {
-      HIPCHK(ovp_launch_dx_rows(c->P, n, ld, b, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, c->stream));
+      HIPCHK(ovp_launch_dx_rows_boost(c->P, n, ld, b, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, c->boost, boost_n,
+                                      c->flags, c->stream));
     }
     return 0;
   }
@@ -1165,8 +1175,9 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   if (c->ktimer) HIPCHK(hipEventRecord(c->ev_k0, c->stream));
   c->use_kept_factor = false;
   c->point_nl = 0;
+  c->point_boost_n = 0;
   if (overlap_mode == 3) {
-    ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags, 0};
+    ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags, 0, nullptr, 0, 0.0};
     if (c->have_factor && c->Lkeep) {  // the plane loop left M with M M^T = P: no chol(P) (cj.n = 0), the update runs on M
       cj.n = 0;
       c->use_kept_factor = true;
@@ -1183,6 +1194,16 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
       if (!no_flip && s0 >= 8 && s0 < c->n) {
         cj.flip = 1;
         c->point_nl = c->n - s0;
+        // the columns in front of the batch's take a relative diagonal boost inside the factorization that the end of the update
+        // takes off again (CholJob::boost): exact, and an exact stochastic clone (IMU pose == newest clone) factors on this path
+        static const bool no_boost = getenv("OVP_POINT_NO_BOOST") != nullptr;
+        if (!no_boost && s0 <= 64) {
+          if (!c->boost) HIPCHK(dalloc(&c->boost, 64));
+          cj.boost = c->boost;
+          cj.boost_n = s0;
+          cj.boost_rel = 1e-9;
+          c->point_boost_n = s0;
+        }
       }
     }
     HIPCHK(ovp_launch_feat_chol(&fp, &cj, c->stream));

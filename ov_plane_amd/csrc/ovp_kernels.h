@@ -23,6 +23,14 @@ struct CholJob {
   int n, ld;
   int* flag;
   int flip;  // dense factor of the index-reversed matrix, rows reversed back (k_tile_body.h): L = Lr with Lr Lr^T = A
+  // flip only: the diagonal of the first boost_n state columns (the ones in front of the batch's columns: IMU, dt) is read as
+  // (1 + boost_rel) x its value and the added amounts are left in boost[0 .. boost_n).  An update whose information matrix is zero
+  // on those columns returns exactly P+ + diag(boost) there (H D = 0  =>  (P + D)+ = P+ + D), so the caller subtracts them again:
+  // the result is the exact update, and the exact stochastic clone - IMU pose == newest clone, a zero pivot in exactly these
+  // columns of the reversed order - factors without a fallback.
+  double* boost;
+  int boost_n;
+  double boost_rel;
 };
 
 struct FeatParams {
