@@ -185,6 +185,23 @@ __global__ void k_gather_block(const double* __restrict__ P, int ldp, const int*
   const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (k < m) out[(size_t)i * ldo + k] = P[(size_t)ids[i] * ldp + ids[k]];
 }
+// the same with a relative boost of the diagonal from position `from` on: out[i][i] = (1 + rel) P[ids[i]][ids[i]], the added amounts
+// left in boost[state column] (zero for the columns in front of `from`).  The plane loop's order ends with the columns no plane
+// of the call involves (IMU, dt, ...): every A_k is zero there, so the loop returns exactly P+ + diag(boost) on them
+// ((P + D)+ = P+ + D when H D = 0) and k_unpermute_pair takes the amounts off again - and an exact stochastic clone (IMU pose ==
+// newest clone: the conditional covariance of the IMU pose given the clones is exactly zero) factors without a second attempt.
+__global__ void k_gather_block_boost(const double* __restrict__ P, int ldp, const int* __restrict__ ids, int m,
+                                     double* __restrict__ out, int ldo, int from, double rel, double* __restrict__ boost) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k >= m) return;
+  double v = P[(size_t)ids[i] * ldp + ids[k]];
+  if (i == k) {
+    const double add = i >= from ? v * rel : 0.0;
+    boost[ids[i]] = add;
+    v += add;
+  }
+  out[(size_t)i * ldo + k] = v;
+}
 // Positive SEMI-definite covariance in front of a pivot-dropping factorization: C = D^-1 P D^-1 with D = sqrt(diag P) (unit diagonal,
 // so ONE absolute pivot floor separates the directions P does not determine - pivots of rounding size - from the regular ones,
 // whatever the units of the variables); a variable with zero variance gets a zero row / column.  dvec <- D.
@@ -220,7 +237,8 @@ __global__ void k_factor_from_V(const double* __restrict__ V, int ld, const int*
 // Both of the above behind a plane loop that ran in its own column order, in one launch: Pout[r][k] = Pperm[ids[r]][ids[k]]
 // (unless *cancel: a failed factorization leaves the resident covariance alone) and Lout[r][k] = V[k][ids[r]].
 __global__ void k_unpermute_pair(const double* __restrict__ Pperm, const double* __restrict__ V, int ld, const int* __restrict__ ids,
-                                 int n, double* __restrict__ Pout, double* __restrict__ Lout, int ldo, const int* __restrict__ cancel) {
+                                 int n, double* __restrict__ Pout, double* __restrict__ Lout, int ldo, const int* __restrict__ cancel,
+                                 const double* __restrict__ boost) {
   __shared__ double tile[16][17];
   const int r0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -232,7 +250,8 @@ __global__ void k_unpermute_pair(const double* __restrict__ Pperm, const double*
   const int ro = r0 + ty, ko = k0 + tx;
   if (ro < n && ko < n) {
     if (Lout) Lout[(size_t)ro * ldo + ko] = tile[tx][ty];
-    if (*cancel == 0) Pout[(size_t)ro * ldo + ko] = Pperm[(size_t)ids[ro] * ld + ids[ko]];
+    if (*cancel == 0)
+      Pout[(size_t)ro * ldo + ko] = Pperm[(size_t)ids[ro] * ld + ids[ko]] - ((boost && ro == ko) ? boost[ro] : 0.0);  // (k_gather_block_boost)
   }
 }
 // ... unless *cancel != 0 (a failed factorization upstream: the destination keeps what it holds, cf. ovp_launch_gemm4c)
@@ -456,15 +475,20 @@ hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int
   hipLaunchKernelGGL(ovp::k_gather_block, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo);
   return hipGetLastError();
 }
+hipError_t ovp_launch_gather_block_boost(const double* P, int ldp, const int* ids, int m, double* out, int ldo, int from, double rel,
+                                         double* boost, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_gather_block_boost, dim3((m + 127) / 128, m), dim3(128), 0, stream, P, ldp, ids, m, out, ldo, from, rel, boost);
+  return hipGetLastError();
+}
 hipError_t ovp_launch_factor_from_V(const double* V, int ld, const int* ids, int n, double* out, int ldo, hipStream_t stream) {
   const int nt = (n + 15) / 16;
   hipLaunchKernelGGL(ovp::k_factor_from_V, dim3(nt, nt), dim3(256), 0, stream, V, ld, ids, n, out, ldo);
   return hipGetLastError();
 }
 hipError_t ovp_launch_unpermute_pair(const double* Pperm, const double* V, int ld, const int* ids, int n, double* Pout, double* Lout,
-                                     int ldo, const int* cancel, hipStream_t stream) {
+                                     int ldo, const int* cancel, const double* boost, hipStream_t stream) {
   const int nt = (n + 15) / 16;
-  hipLaunchKernelGGL(ovp::k_unpermute_pair, dim3(nt, nt), dim3(256), 0, stream, Pperm, V, ld, ids, n, Pout, Lout, ldo, cancel);
+  hipLaunchKernelGGL(ovp::k_unpermute_pair, dim3(nt, nt), dim3(256), 0, stream, Pperm, V, ld, ids, n, Pout, Lout, ldo, cancel, boost);
   return hipGetLastError();
 }
 hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream) {

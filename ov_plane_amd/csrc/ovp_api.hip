@@ -25,11 +25,13 @@ hipError_t ovp_launch_scatter_gram(const double* Acc, const double* bcc, int col
                                    int lda, int n, hipStream_t stream);
 hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out, hipStream_t stream);
 hipError_t ovp_launch_gather_block(const double* P, int ldp, const int* ids, int m, double* out, int ldo, hipStream_t stream);
+hipError_t ovp_launch_gather_block_boost(const double* P, int ldp, const int* ids, int m, double* out, int ldo, int from, double rel,
+                                         double* boost, hipStream_t stream);
 hipError_t ovp_launch_gather_block_unless(const double* P, int ldp, const int* ids, int m, double* out, int ldo, const int* cancel,
                                           hipStream_t stream);
 hipError_t ovp_launch_unit_diag(const double* P, int n, int ld, double* C, double* dvec, hipStream_t stream);
 hipError_t ovp_launch_unpermute_pair(const double* Pperm, const double* V, int ld, const int* ids, int n, double* Pout, double* Lout,
-                                     int ldo, const int* cancel, hipStream_t stream);
+                                     int ldo, const int* cancel, const double* boost, hipStream_t stream);
 hipError_t ovp_launch_factor_from_V(const double* V, int ld, const int* ids, int n, double* out, int ldo, hipStream_t stream);
 hipError_t ovp_launch_scale_rows(double* L, int n, int ld, const double* dvec, hipStream_t stream);
 hipError_t ovp_launch_gather_cols(const double* P, int ldp, const int* ids, int n, int m, double* G, int ldg, hipStream_t stream);
@@ -255,6 +257,8 @@ struct ovp_ctx {
   double* Lkeep = nullptr;
   bool have_factor = false, use_kept_factor = false;
   double clone_jitter = 0.0;  // ovp_cov_clone_jitter: relative inflation of a cloned block's diagonal (0 = exact copy, the reference)
+  double* boost_vec = nullptr;  // [n_max] k_gather_block_boost: the plane loop's diagonal boost by STATE column (zero where none)
+  bool pl_boost_active = false, kept_boost = false;
   double* boost = nullptr;   // CholJob::boost: the amounts the reversed-order chol(P) added to the diagonal in front of the batch's columns
   int point_boost_n = 0;
   int point_nl = 0;  // > 0: chol(P) of the running point update was taken in reversed index order (CholJob::flip) and the update's
@@ -316,6 +320,7 @@ static inline void drop_kept_factor(ovp_ctx* c) {
   c->use_kept_factor = false;
   c->point_nl = 0;
   c->point_boost_n = 0;
+  c->kept_boost = false;
 }
 
 static inline double host_now_ms() {
@@ -489,7 +494,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
                  c->chi2_table, c->G, c->Bscr, c->rec, c->gramS, c->gramR, c->Dinv, c->Ltp, c->part, c->idbuf, c->smallbuf, c->Hd, c->Acc,
                  c->bcc, c->resd, c->pl_slam_i, c->pl_slam_d, c->sub_ids, c->sub_buf, c->pl_Tbuf, c->pl_crow, c->pl_dxlast,
                  c->pl_cur, c->pl_perm, c->pl_range_done, c->pl_used, c->pl_dstage, c->pl_xbuf, c->pl_xy, c->pl_xflag, c->pl_Asum,
-                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr, c->dinit_buf, c->boost};
+                 c->pl_U, c->pl_sub_tab, c->Lkeep, c->slam_res, c->slam_hscr, c->dinit_buf, c->boost, c->boost_vec};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
@@ -986,7 +991,11 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
     const double* Lf = kept ? c->Lkeep : c->L;
     // leading block of T (reversed-order factor of P, see ovp_build_gate_gram_tail): n when the factor is the plain one
     const int nl = (!kept && chol_p_done_on_stream2 && c->point_nl > 0 && c->point_nl < n) ? c->point_nl : n;
-    const int boost_n = nl < n ? c->point_boost_n : 0;  // (CholJob::boost: set together with the reversed-order factor)
+    // diagonal amounts to take off at the end: CholJob::boost of the reversed-order factor (the first point_boost_n columns), or -
+    // on the factor the plane loop left, which is a factor of P + diag(boost_vec) - the loop's own (all n entries, zero where none)
+    const double* boost_ptr = kept ? (c->kept_boost ? c->boost_vec : nullptr) : c->boost;
+    const int boost_n = kept ? (c->kept_boost ? n : 0) : (nl < n ? c->point_boost_n : 0);
+    c->kept_boost = false;
     c->use_kept_factor = false;
     c->point_nl = 0;
     c->point_boost_n = 0;
@@ -1003,11 +1012,11 @@ static int ekf_from_gram(ovp_ctx* c, bool chol_p_done_on_stream2, bool publish =
       const int words = (int)((16 + sizeof(double) * (size_t)n + 7) / 8);
       c->pub_seq = ++c->seq;
       HIPCHK(ovp_launch_dx_rows_boost(c->P, n, ld, b, c->dx, c->flags + 1, c->ticket, c->res_block, c->h_res_block_dev, words,
-                                      (char*)c->h_res_block_dev + ((char*)c->h_seq - (char*)c->h_res_block), c->pub_seq, c->boost,
+                                      (char*)c->h_res_block_dev + ((char*)c->h_seq - (char*)c->h_res_block), c->pub_seq, boost_ptr,
                                       boost_n, c->flags, c->stream));
       c->pub_pending = true;
     } else {
-      HIPCHK(ovp_launch_dx_rows_boost(c->P, n, ld, b, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, c->boost, boost_n,
+      HIPCHK(ovp_launch_dx_rows_boost(c->P, n, ld, b, c->dx, c->flags + 1, nullptr, nullptr, nullptr, 0, nullptr, 0u, boost_ptr, boost_n,
                                       c->flags, c->stream));
     }
     return 0;
@@ -1900,7 +1909,16 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
   HIPCHK(hipEventRecord(c->ev_subtab, s));
   const int* d_ids = (const int*)((char*)c->pl_sub_tab + o_ids);
   const int* d_inv = (const int*)((char*)c->pl_sub_tab + o_inv);
-  HIPCHK(ovp_launch_gather_block(c->P, ld, d_ids, ns, c->P_tmp, ld, s));
+  // full order: the columns behind the involved ones take a diagonal boost that the un-permutation behind the loop takes off
+  // again (k_gather_block_boost) - an exact stochastic clone then factors at the first attempt
+  static const bool no_boost = getenv("OVP_PL_NO_BOOST") != nullptr;
+  c->pl_boost_active = full && n_inv < ns && !no_boost;
+  if (c->pl_boost_active) {
+    if (!c->boost_vec) HIPCHK(dalloc(&c->boost_vec, (size_t)c->n_max + 16));
+    HIPCHK(ovp_launch_gather_block_boost(c->P, ld, d_ids, ns, c->P_tmp, ld, n_inv, 1e-9, c->boost_vec, s));
+  } else {
+    HIPCHK(ovp_launch_gather_block(c->P, ld, d_ids, ns, c->P_tmp, ld, s));
+  }
   if (!full) {
     HIPCHK(hipMemsetAsync(c->pl_Asum, 0, sizeof(double) * (size_t)ns * ld, s));
     HIPCHK(hipMemsetAsync(c->pl_U, 0, sizeof(double) * (size_t)NP * ld, s));
@@ -2456,7 +2474,9 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (want_factor && !c->Lkeep) HIPCHK(dalloc(&c->Lkeep, (size_t)c->n_max * ld));
     if (c->pl_scatter_dst) {
       HIPCHK(ovp_launch_unpermute_pair(c->P, c->Y, ld, c->pl_scatter_ids, n, c->pl_scatter_dst, want_factor ? c->Lkeep : nullptr, ld,
-                                       c->flags, s));
+                                       c->flags, c->pl_boost_active ? c->boost_vec : nullptr, s));
+      c->kept_boost = want_factor && c->pl_boost_active;  // Lkeep is a factor of P + diag(boost_vec): the point update on it
+                                                          // takes the amounts off at its end (ekf_from_gram)
     } else if (want_factor) {
       HIPCHK(ovp_launch_factor_from_V(c->Y, ld, nullptr, n, c->Lkeep, ld, s));
     }
