@@ -1205,7 +1205,7 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
         c->point_nl = c->n - s0;
         // the columns in front of the batch's take a relative diagonal boost inside the factorization that the end of the update
         // takes off again (CholJob::boost): exact, and an exact stochastic clone (IMU pose == newest clone) factors on this path
-        static const bool no_boost = getenv("OVP_POINT_NO_BOOST") != nullptr;
+        const bool no_boost = getenv("OVP_POINT_NO_BOOST") != nullptr;  // (read per call: the tests switch it)
         if (!no_boost && s0 <= 64) {
           if (!c->boost) HIPCHK(dalloc(&c->boost, 64));
           cj.boost = c->boost;
@@ -1911,7 +1911,7 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
   const int* d_inv = (const int*)((char*)c->pl_sub_tab + o_inv);
   // full order: the columns behind the involved ones take a diagonal boost that the un-permutation behind the loop takes off
   // again (k_gather_block_boost) - an exact stochastic clone then factors at the first attempt
-  static const bool no_boost = getenv("OVP_PL_NO_BOOST") != nullptr;
+  const bool no_boost = getenv("OVP_PL_NO_BOOST") != nullptr;  // (read per call)
   c->pl_boost_active = full && n_inv < ns && !no_boost;
   if (c->pl_boost_active) {
     if (!c->boost_vec) HIPCHK(dalloc(&c->boost_vec, (size_t)c->n_max + 16));

@@ -409,15 +409,26 @@ def test_config4_plane_gate_at_multiplier_one(hiplib, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["exact_clone", "zero_variance"])
-def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case):
+@pytest.mark.parametrize("case", ["exact_clone", "zero_variance", "stochastic_clone", "stochastic_clone_no_boost"])
+def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case, monkeypatch):
     """state/StateHelper.cpp:159-187 never factors P, so the reference updates a covariance that is only positive SEMI-definite:
     right after StateHelper::clone the new pose is an exact copy of the IMU pose (:346-396), and a variable may carry a
     zero-variance prior.  The device's fast path factors P; when that fails it falls back to the S-form on the Cholesky factor of the
     batch's information matrix (ekf_sform) instead of returning OVP_E_NOTSPD.  Both priors below are exactly singular."""
     sc = make_scene(C=9, F=80, seed=41, chi2_mult=1.0)
     P = sc.P.copy()
-    if case == "exact_clone":
+    if case.startswith("stochastic_clone"):
+        # what every frame of a running filter sees: the newest clone is an exact copy of the IMU pose (columns 0..5), which lies
+        # in FRONT of the batch's columns.  Round 5: the reversed-order chol(P) boosts the diagonal there and the update's last kernel
+        # takes the amounts off again ((P + D)+ = P+ + D for H D = 0), so this prior stays on the fast path; with the boost switched
+        # off the S-form retry gives the same answer
+        if case.endswith("no_boost"):
+            monkeypatch.setenv("OVP_POINT_NO_BOOST", "1")
+        b = sc.ids["clones"][-1]
+        idx = np.arange(sc.N)
+        idx[b:b + 6] = np.arange(0, 6)
+        P = P[np.ix_(idx, idx)]
+    elif case == "exact_clone":
         a, b = sc.ids["clones"][-2], sc.ids["clones"][-1]  # the newest clone becomes an exact copy of the one before it
         idx = np.arange(sc.N)
         idx[b:b + 6] = np.arange(a, a + 6)
@@ -441,7 +452,7 @@ def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case
     out["ctx"].close()
 
 
-@pytest.mark.parametrize("case", ["exact_clone", "zero_variance"])
+@pytest.mark.parametrize("case", ["exact_clone", "zero_variance", "stochastic_clone"])
 @pytest.mark.parametrize("big", [False, True])
 def test_plane_loop_on_a_positive_semidefinite_prior(hiplib, oracle, case, big):
     """The plane loop on the covariance StateHelper::clone leaves (state/StateHelper.cpp:346-396: the newest pose an EXACT copy,
@@ -455,7 +466,14 @@ def test_plane_loop_on_a_positive_semidefinite_prior(hiplib, oracle, case, big):
     sc = make_scene(**kw)
     assert (sc.N > 288) == big
     P = sc.P.copy()
-    if case == "exact_clone":
+    if case == "stochastic_clone":
+        # newest clone == IMU pose (columns 0..5, which no plane involves): the loop's diagonal boost on the uninvolved columns keeps
+        # this prior - the one a running filter has in every frame - on the first attempt
+        b = sc.ids["clones"][-1]
+        idx = np.arange(sc.N)
+        idx[b:b + 6] = np.arange(0, 6)
+        P = P[np.ix_(idx, idx)]
+    elif case == "exact_clone":
         a, b = sc.ids["clones"][-2], sc.ids["clones"][-1]
         idx = np.arange(sc.N)
         idx[b:b + 6] = np.arange(a, a + 6)
