@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ovp_dev.h"
+
 namespace ovp {
 
 #define IM_ROWS 8
@@ -94,6 +96,14 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
                                                      int hs_in_lds) {
   extern __shared__ double sm[];
   const int t = threadIdx.x;
+#ifdef OVP_IC_STAMPS
+  long long st[10];
+  int sti = 0;
+#define IC_STAMP() do { if (t == 0) st[sti++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define IC_STAMP() do { } while (0)
+#endif
+  IC_STAMP();
   const int m = k + rup, W = 2 * rup + 1, ldw = W + 1;
   double* Mg = sm;                       // [cols][m]: row ids[a] of M_all
   double* Wm = Mg + (size_t)cols * m;    // [rup][2 rup + 2]: S | res | I
@@ -103,8 +113,18 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
   if (t == 0) bad = 0;
   if (t < k * k) Hi[t] = Hinv[t];
   __shared__ int ids_s[IC_MAX_COLS];  // (the gather below then has ONE global load per element, not a dependent pair)
+  // the init columns of M that the new rows / columns of P are made of (step further down) are requested now: by then the round trip
+  // (2-3 us behind a kernel boundary) is over instead of starting
+  double pm[2][6];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = t + 1024 * q, r = k > 0 ? e / k : 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) pm[q][a] = (k > 0 && e < n * k && a < k) ? Mall[(size_t)r * m + a] : 0.0;
+  }
   for (int e = t; e < cols; e += 1024) ids_s[e] = ids[e];
   __syncthreads();
+  IC_STAMP();
 #pragma unroll 4
   for (int e = t; e < cols * m; e += 1024) {
     const int a = e / m, j = e - a * m;
@@ -116,6 +136,7 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
     Wm[i * ldw + rup + q] = q == 0 ? resid[i] : (q - 1 == i ? 1.0 : 0.0);
   }
   __syncthreads();
+  IC_STAMP();
   const double* Hs = hs_in_lds ? Hl : Ht;
   // S = H_up M_up[ids] + r I ;  Minit = H_init M_init[ids] + R (upper triangle mirrored, selfadjointView<Upper>) ;
   // X = H_init M_up[ids]  (k x rup)
@@ -170,6 +191,7 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
     *dst = s + s1;
   }
   __syncthreads();
+  IC_STAMP();
   // P_LL = Hinv Minit Hinv^T ; P[0:n, n:n+k] = -M_init Hinv^T and its transpose ; rows n .. n + k of M_up = -Hinv X
   if (t < k * k) {
     const int i = t / k, j = t - i * k;
@@ -178,7 +200,20 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
       for (int b = 0; b < k; ++b) s = fma(Hi[i * k + a] * Minit[a * k + b], Hi[j * k + b], s);
     P[(size_t)(n + i) * ldp + n + j] = s;
   }
-  for (int e = t; e < n * k; e += 1024) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = t + 1024 * q;
+    if (k > 0 && e < n * k) {
+      const int r = e / k, j = e - r * k;
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        if (a < k) s = fma(pm[q][a], Hi[j * k + a], s);
+      P[(size_t)r * ldp + n + j] = -s;
+      P[(size_t)(n + j) * ldp + r] = -s;
+    }
+  }
+  for (int e = t + 2048; e < n * k; e += 1024) {
     const int r = e / k, j = e - r * k;
     double s = 0.0;
     for (int a = 0; a < k; ++a) s = fma(Mall[(size_t)r * m + a], Hi[j * k + a], s);
@@ -195,6 +230,7 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
     if (t == 0) res[0] = 0.0, res[1] = 1.0, res[2] = 0.0;
     return;
   }
+  IC_STAMP();
   // elimination: Wm[i][j] -= Wm[i][c] Wm[c][j] / Wm[c][c] for i, j > c, with the matrix in REGISTERS (a thread owns the elements
   // t, t + 1024, ... - at most 13 of the 80 x 161) and only the pivot row in LDS: row c + 1 is final after step c and its owners
   // publish it, everybody reads its two operands from the published row c - the multiplier S[i][c] is taken as S[c][i], which the
@@ -208,6 +244,7 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
   else if (ne <= 5) ic_eliminate<5>(Wm, ldw, rup, W, t, &bad);
   else if (ne <= 8) ic_eliminate<8>(Wm, ldw, rup, W, t, &bad);
   else ic_eliminate<IC_MAXE>(Wm, ldw, rup, W, t, &bad);
+  IC_STAMP();
   // rows scaled by 1 / sqrt(pivot): y and L^-1
   for (int e = t; e < rup * (rup + 1); e += 1024) {
     const int i = e / (rup + 1), q = e - i * (rup + 1);
@@ -218,13 +255,26 @@ __global__ __launch_bounds__(1024) void k_init_core(double* __restrict__ P, int 
     if (q == 0) Wm[i * ldw + rup] = v;
   }
   __syncthreads();
-  if (t == 0) {
-    double chi2 = 0.0;
-    for (int j = 0; j < rup; ++j) chi2 = fma(Wm[j * ldw + rup], Wm[j * ldw + rup], chi2);
+  if (t < 64) {  // |y|^2 by wave 0 (rup <= 80: two entries per lane), DPP + row swaps
+    double part = 0.0;
+    for (int j = t; j < rup; j += 64) part = fma(Wm[j * ldw + rup], Wm[j * ldw + rup], part);
+    part += xor_lane_f64<1>(part);
+    part += xor_lane_f64<2>(part);
+    part += xor_lane_f64<4>(part);
+    part += xor_lane_f64<8>(part);
+    const double chi2 = rows_sum_f64(part);
+    if (t == 0) {
     res[0] = chi2;
     res[1] = (!bad && !(chi2 > thr)) ? 1.0 : 0.0;
     res[2] = 0.0;
+    }
   }
+#ifdef OVP_IC_STAMPS
+  IC_STAMP();
+  if (t == 0)
+    printf("[k_init_core k=%d rup=%d cols=%d n=%d] ids %lld | gather %lld | S %lld | new rows %lld | eliminate %lld | finalize %lld\n", k, rup, cols, n,
+           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5]);
+#endif
 }
 
 #define IU_T 16
