@@ -201,7 +201,11 @@ __global__ __launch_bounds__(256) void k_dx_rows(double* P, int n, int ldp,
     double* pr = P + (size_t)row * ldp;
     double s = 0.0;
     for (int c = lane; c < n; c += 64) s = fma(pr[c], b[c], s);
-    s = wave_sum(s);
+    s += xor_lane_f64<1>(s);  // (DPP + row swaps; wave_sum's six ds_bpermute round trips were the longest thing in this kernel)
+    s += xor_lane_f64<2>(s);
+    s += xor_lane_f64<4>(s);
+    s += xor_lane_f64<8>(s);
+    s = rows_sum_f64(s);
     if (lane == 0) {
       dx[row] = s;
       double d = pr[row];
