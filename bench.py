@@ -32,7 +32,7 @@ sys.path.insert(0, _ROOT)
 import numpy as np  # noqa: E402
 
 PMC_TRAFFIC_FILE = "r05_z_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/prof_round.sh, tools/pmc_summary.py)
-F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §5
+F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §6, NOTES.md §5
 WORKLOADS = {
     "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
     "config3": dict(C=30, F=2000, n_planes=20, feats_per_plane=50),
@@ -48,7 +48,7 @@ def algorithmic_flops_per_feature(m: int, calib: bool = True) -> float:
 
 
 def executed_flops_per_feature(m: int) -> float:
-    """FLOPs the structured feature kernel issues per feature."""
+    """FLOPs the structured feature kernel issues per feature (NOTES.md §4)."""
     n = 2 * m
     return 450.0 * n + n * (14 * 6 + 14 * 14) * 2.0 + n * m * 2 * (36 + 2 * 34) + (64**3 / 3.0 * 2.0 * (n / 64.0) + 4 * n * 64.0) + 64.0 * 93 * 2
 
@@ -644,7 +644,7 @@ def main():
         # ---- roofline of the dominant kernel ----
         if run.has_planes and c2_n:
             # per plane: the update part factorizes the leading block of the loop's column order (clones + calibration + the own
-            # columns of the planes processed so far), the range part the plane's involved columns
+            # columns of the planes processed so far, NOTES.md section 3b), the range part the plane's involved columns
             base = 6 * C + 14
             in_state = (np.asarray(sc.plane_state_id) >= 0).astype(int)
             nl = base + 3 * np.cumsum(in_state)
@@ -666,7 +666,7 @@ def main():
                 "cus_occupied": 2, "frac_of_occupied_cus": fl / ks / 1e12 / (F64_PEAK_TFLOPS * 2.0 / 256.0),
                 "note": "f64 MFMA + DPP-broadcast FMA chains on 2 of 256 CUs: the fraction of the chip's peak is by construction "
                         "tiny; what bounds the kernel is the dependent pivot chain (n sequential pivots) and the f64 pipe of one "
-                        "CU (DESIGN.md section 4)",
+                        "CU (NOTES.md section 4)",
             }
         if k1_n:
             m = C

@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path (through the C-ABI) against the oracle on identical seeded inputs.
 
 Tolerances (BASELINE.json north_star): |d state| <= 1e-6 ; covariance 1e-4 relative, measured as
-max_ij |dP_ij| / sqrt(P_ii P_jj) (correlation-normalised).  Observed errors are ~1e-10."""
+max_ij |dP_ij| / sqrt(P_ii P_jj) (correlation-normalised, NOTES.md §6).  Observed errors are ~1e-10."""
 import importlib.util
 import os
 
@@ -2698,7 +2698,7 @@ def test_slam_update_on_the_device_single_inverse_depth(hiplib, oracle):
 def test_whole_step_under_the_devices_own_plane_decisions(hiplib, oracle, cfg):
     """BASELINE configs 3 and 4 with chi2_multipler = 1 on both levels and NOBODY imposing decisions: the device's plane loop takes
     its own accept / reject sequence (five seeds each).  Wherever that sequence equals the oracle's - which it must wherever the
-    oracle's statistic is further from the threshold than two builds of the oracle are from each other (18.2) - the
+    oracle's statistic is further from the threshold than two builds of the oracle are from each other (18.2, NOTES.md §3b) - the
     state and covariance behind the loop and the point update on the leftovers are compared with the oracle in full."""
     from ov_plane_amd.synth import Scene
 

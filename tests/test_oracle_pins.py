@@ -233,7 +233,7 @@ def test_propagation_restatement_is_consistent():
 
 
 def test_plane_loop_state_is_well_posed_but_its_chi2_is_rounding_dependent(oracle, tmp_path):
-    """Evidence for DESIGN.md §3b: compiling the SAME restatement with FMA contraction changes the plane-level chi2 of
+    """Evidence for NOTES.md §3b: compiling the SAME restatement with FMA contraction changes the plane-level chi2 of
     the reference algorithm by O(1..10) (it keeps ~6 rank-deficient rows after compression whose residual entries are
     determined by rounding noise), while the state / covariance it produces agree to ~1e-12."""
     import shutil
