@@ -179,6 +179,10 @@ int ovp_rccl_comm_destroy(void *nccl_comm);
 /* ncclAllReduce(sum, f64) of the pair of ovp_gram_buffer() on the context's stream: the collective between
  * ovp_msckf_build_gate_gram_async and ovp_ekf_update_from_gram_async for callers that drive the stages themselves */
 int ovp_rccl_allreduce_gram(ovp_ctx *ctx, void *nccl_comm);
+/* the index range [*lo, *hi) of the resident batch that ovp_msckf_update_sharded gives to `rank` of `world` (for callers that drive the
+ * staged entries and ovp_batch_set_range themselves): balanced over the features of the update, consecutive ranks tile the batch,
+ * lo == hi = an empty share */
+int ovp_shard_range(ovp_ctx *ctx, const ovp_update_opts *opts, int rank, int world, int *lo, int *hi);
 int ovp_msckf_update_sharded(ovp_ctx *ctx, const ovp_update_opts *opts, void *nccl_comm, int rank, int world, double *dx_host,
                              uint8_t *accepted_host, double *chi2_host, ovp_update_info *info, int *shard_lo, int *shard_hi);
 

@@ -139,7 +139,7 @@ EXPORTS = [
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
     "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
     "ovp_slam_update", "ovp_cov_clone_jitter", "ovp_rccl_unique_id", "ovp_rccl_comm_create", "ovp_rccl_comm_destroy",
-    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded", "ovp_slam_delayed_init",
+    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded", "ovp_slam_delayed_init", "ovp_shard_range",
 ]
 
 
@@ -183,6 +183,7 @@ def lib():
         L.ovp_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.ovp_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.ovp_rccl_allreduce_gram.argtypes = [C.c_void_p, C.c_void_p]
+        L.ovp_shard_range.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ovp_msckf_update_sharded.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.POINTER(UpdateInfo), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ovp_slam_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(SlamBatch), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -443,6 +444,11 @@ class Context:
             _chk(rc, "ovp_msckf_update_sharded")
         return dict(dx=dx, accepted=acc[:F].astype(bool), chi2=chi2[:F], info=info, rc=rc, shard=(lo.value, hi.value))
 
+    def shard_range(self, opts: UpdateOpts, rank, world):
+        lo, hi = C.c_int(0), C.c_int(0)
+        _chk(lib().ovp_shard_range(self._h, C.byref(opts), int(rank), int(world), C.byref(lo), C.byref(hi)), "ovp_shard_range")
+        return lo.value, hi.value
+
     def rccl_allreduce_gram(self, comm):
         _chk(lib().ovp_rccl_allreduce_gram(self._h, C.c_void_p(comm)), "ovp_rccl_allreduce_gram")
 
@@ -548,7 +554,8 @@ class Context:
         Returns dict(dx, status [L] (0 rejected / 1 accepted / 2 accepted without its plane), chi2 [L], info, rc)."""
         n_meas = np.ascontiguousarray(n_meas, dtype=np.int32)
         L = int(n_meas.shape[0])
-        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(L, -1, 2)
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        uv = uv.reshape(L, -1, 2) if L else uv.reshape(0, 1, 2)
         M = uv.shape[1]
         ci = np.ascontiguousarray(clone_idx, dtype=np.int32).reshape(L, M)
         p = np.ascontiguousarray(p_FinG, dtype=np.float64).reshape(L, 3)

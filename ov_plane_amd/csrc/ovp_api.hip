@@ -327,7 +327,7 @@ static inline double host_now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-extern "C" const char* ovp_version(void) { return "ovplane_hip 0.4 (gfx950)"; }
+extern "C" const char* ovp_version(void) { return "ovplane_hip 0.5 (gfx950)"; }
 
 extern "C" const char* ovp_error_string(int code) {
   switch (code) {
@@ -1454,26 +1454,35 @@ extern "C" int ovp_rccl_allreduce_gram(ovp_ctx* c, void* nccl_comm) {
   return rccl_rc(g_rccl.AllReduce(c->Ab, c->Ab, (size_t)(c->n + 1) * c->ld, kNcclFloat64, kNcclSum, nccl_comm, c->stream), "ncclAllReduce");
 }
 
+// this rank's balanced share of the features the update is about (the ones no accepted plane consumed when skip_plane_used is set):
+// an index range of the resident batch - consecutive ranks tile it, consumed features inside are masked on the device
+extern "C" int ovp_shard_range(ovp_ctx* c, const ovp_update_opts* o, int rank, int world, int* shard_lo, int* shard_hi) {
+  if (!c || !o || !shard_lo || !shard_hi || world < 1 || rank < 0 || rank >= world) return OVP_E_ARG;
+  if (!c->have_batch) return OVP_E_STATE;
+  const int F = c->n_feats;
+  std::vector<int> rest;
+  rest.reserve((size_t)F);
+  const bool masked = o->skip_plane_used && c->pl_used_valid && (int)c->h_pl_used.size() == F;
+  if (o->skip_plane_used && !masked) return OVP_E_STATE;  // no plane update ran on this batch
+  for (int f = 0; f < F; ++f)
+    if (!masked || !c->h_pl_used[f]) rest.push_back(f);
+  const int nr = (int)rest.size(), base = nr / world, rem = nr % world;
+  const int a = rank * base + (rank < rem ? rank : rem), b = a + base + (rank < rem ? 1 : 0);
+  *shard_lo = *shard_hi = 0;
+  if (b > a) *shard_lo = rest[a], *shard_hi = rest[b - 1] + 1;
+  return 0;
+}
+
 extern "C" int ovp_msckf_update_sharded(ovp_ctx* c, const ovp_update_opts* o, void* nccl_comm, int rank, int world, double* dx_host,
                                         uint8_t* accepted_host, double* chi2_host, ovp_update_info* info, int* shard_lo,
                                         int* shard_hi) {
   if (!c || !o || world < 1 || rank < 0 || rank >= world) return OVP_E_ARG;
   if (world > 1 && !nccl_comm) return OVP_E_ARG;
   if (!c->have_batch) return OVP_E_STATE;
-  const int F = c->n_feats;
-  // this rank's balanced share of the features the update is about (the ones no accepted plane consumed when skip_plane_used is
-  // set): an index range of the resident batch - consecutive ranks tile it, consumed features inside are masked on the device
   int lo = 0, hi = 0;
   {
-    std::vector<int> rest;
-    rest.reserve((size_t)F);
-    const bool masked = o->skip_plane_used && c->pl_used_valid && (int)c->h_pl_used.size() == F;
-    if (o->skip_plane_used && !masked) return OVP_E_STATE;  // no plane update ran on this batch
-    for (int f = 0; f < F; ++f)
-      if (!masked || !c->h_pl_used[f]) rest.push_back(f);
-    const int nr = (int)rest.size(), base = nr / world, rem = nr % world;
-    const int a = rank * base + (rank < rem ? rank : rem), b = a + base + (rank < rem ? 1 : 0);
-    if (b > a) lo = rest[a], hi = rest[b - 1] + 1;
+    const int rs = ovp_shard_range(c, o, rank, world, &lo, &hi);
+    if (rs) return rs;
   }
   if (shard_lo) *shard_lo = lo;
   if (shard_hi) *shard_hi = hi;

@@ -2851,3 +2851,65 @@ def test_slam_delayed_init_loop_on_the_device_matches_oracle(hiplib, oracle, kw)
     assert np.abs(intr - ref["intr"]).max() < TOL_DX
     assert relP(ctx.cov_download(), ref["P"]) < TOL_P
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_round5_entry_points_edge_cases(hiplib, oracle):
+    """Empty and ragged inputs of the round-5 entries: no landmarks, a landmark without observations among others (left alone like
+    the reference's clean-up would, update/UpdaterSLAM.cpp:412-415), a delayed initialisation that would outgrow the context
+    (OVP_E_CAPACITY, nothing touched), and index ranges of a sharded update that tile the batch - an empty share included."""
+    from ov_plane_amd.synth import make_slam_scene
+
+    capi = hiplib
+    sc = make_slam_scene(C=8, n_slam=6, seed=21)
+    ctx = capi.Context(sc.N, sc.C, sc.F, device=0)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    o = capi.opts_from_scene(sc)
+    # no landmarks at all
+    out = ctx.slam_update(o, np.zeros((0, 1, 2), np.float32), np.zeros((0, 1), np.int32), np.zeros(0, np.int32), np.zeros((0, 3)),
+                          np.zeros((0, 3)), np.zeros(0, np.int32))
+    assert out["rc"] == 0 and np.abs(out["dx"]).max() == 0.0 and np.array_equal(ctx.cov_download(), sc.P)
+    # one landmark lost all its observations: it takes no part, the others are updated as if it were not in the call
+    nm = sc.n_meas.copy()
+    nm[2] = 0
+    keep = np.array([0, 1, 3, 4, 5])
+    a = ctx.slam_update(o, sc.uv, sc.clone_idx, nm, sc.p_FinG, sc.p_FinG_fej, sc.lm_id)
+    Pa = ctx.cov_download()
+    ctx.cov_upload(sc.P)
+    b = ctx.slam_update(o, sc.uv[keep], sc.clone_idx[keep], sc.n_meas[keep], sc.p_FinG[keep], sc.p_FinG_fej[keep], sc.lm_id[keep])
+    assert a["status"][2] == 0 and (a["status"][keep] == b["status"]).all() and b["status"].all()
+    assert np.abs(a["dx"] - b["dx"]).max() < 1e-12 and relP(Pa, ctx.cov_download()) < 1e-12
+    ctx.close()
+    # delayed initialisation: no room for the new landmarks -> OVP_E_CAPACITY and an untouched covariance
+    sc2 = make_scene(C=8, F=5, seed=6, ragged=True)
+    ctx = capi.Context(sc2.N + 6, sc2.C, sc2.F, device=0)   # room for two of the five candidates
+    ctx.cov_upload(sc2.P)
+    ctx.state_upload(sc2)
+    r = ctx.slam_delayed_init(capi.opts_from_scene(sc2), sc2.uv, sc2.clone_idx, sc2.n_meas, sc2.p_FinG, raise_on_error=False)
+    assert r["rc"] == capi.OVP_E_CAPACITY and ctx.cov_size() == sc2.N and np.array_equal(ctx.cov_download(), sc2.P)
+    ok2 = ctx.slam_delayed_init(capi.opts_from_scene(sc2), sc2.uv[:2], sc2.clone_idx[:2], sc2.n_meas[:2], sc2.p_FinG[:2])
+    assert ok2["rc"] == 0 and ctx.cov_size() == sc2.N + 3 * int(ok2["ok"].sum())
+    ctx.close()
+    # sharded update without a communicator: the shares of the ranks tile the batch, a rank may get nothing
+    sc3 = make_scene(C=6, F=5, seed=9, chi2_mult=1.0)
+    ctx = capi.Context(sc3.N, sc3.C, sc3.F, device=0)
+    ctx.state_upload(sc3)
+    ctx.batch_upload_scene(sc3)
+    seen = np.zeros(sc3.F, dtype=int)
+    o3 = capi.opts_from_scene(sc3)
+    for rank in range(7):
+        lo, hi = ctx.shard_range(o3, rank, 7)
+        seen[lo:hi] += 1
+        ctx.cov_upload(sc3.P)
+        ctx.batch_set_range(lo, hi)
+        out = ctx.msckf_update(o3)
+        assert not out["accepted"][:lo].any() and not out["accepted"][hi:].any()
+        if hi == lo:
+            assert np.abs(out["dx"]).max() == 0.0 and relP(ctx.cov_download(), sc3.P) < 1e-12
+    ctx.batch_set_range(-1, -1)
+    ctx.cov_upload(sc3.P)
+    one = ctx.msckf_update_sharded(o3, None, 0, 1)
+    assert one["shard"] == (0, sc3.F) and one["accepted"].sum() >= 3
+    assert (seen == 1).all()
+    ctx.close()
