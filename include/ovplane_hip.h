@@ -104,7 +104,7 @@ typedef struct {
  * resident factorizations, larger ones the sub-state update (a batch may then touch at most 288 columns to stay fast);
  * ovp_msckf_plane_update above 287 columns runs its loop on the columns the planes of the call involve (clones, calibration, the
  * planes that are state variables, the SLAM landmarks on the others: at most 287 of them, OVP_E_CAPACITY beyond) and carries the
- * rest of the state along; ovp_plane_init is offered up to 288 columns. */
+ * rest of the state along; ovp_plane_init runs on the marginal of the clone and calibration columns at any state size. */
 int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int n_feats_max, void *stream, ovp_ctx **out);
 int ovp_ctx_destroy(ovp_ctx *ctx);
 int ovp_sync(ovp_ctx *ctx);

@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void k_plane_commit(const double* __restrict__
   const int nthreads = gridDim.x * blockDim.x;
   for (int i = gid; i < n; i += nthreads) dx_out[i] = ok ? dx[i] : 0.0;
   if (!ok) return;
-  // M <- V^T
-  for (int idx = gid; idx < n * n; idx += nthreads) {
+  // M <- V^T (first-generation loop: the chained factor; V == nullptr when nothing is chained)
+  for (int idx = gid; V && idx < n * n; idx += nthreads) {
     const int r = idx / n, c = idx - r * n;
     M[(size_t)r * ld + c] = V[(size_t)c * ld + r];
   }
@@ -622,19 +622,21 @@ __global__ __launch_bounds__(256) void k_plane_commit(const double* __restrict__
 // (x, cp) given the extended pair E = [[Exx Exc][Ecx Ecc]], [bx; bc] is
 //   Sigma_xx = P+ (already resident),  Sigma_xc = -P+ Z,  Sigma_cc = Ecc^-1 + Z^T P+ Z,  Z = Exc Ecc^-1,
 //   d cp = Ecc^-1 (bc - Ecx dx).
-// One workgroup; P already holds P+ (n x n); rows/columns n..n+2 are appended.
+// One workgroup; P already holds P+ (n x n); rows/columns n..n+2 are appended.  The pair may live on a SELECTION of ns state columns
+// (ids != nullptr: E is (ns + 4) wide, its row / column i stands for state column ids[i], every other column of the state has a zero
+// row in Exc): the sums then run over the selection only.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_plane_init_augment(const double* __restrict__ E, int lde, int n,
-                                                             double* __restrict__ P, int ldp,
+__global__ __launch_bounds__(256) void k_plane_init_augment(const double* __restrict__ E, int lde, int ns,
+                                                             const int* __restrict__ ids, int n, double* __restrict__ P, int ldp,
                                                              const double* __restrict__ dx,
                                                              double* __restrict__ out /* [3] d cp */) {
-  extern __shared__ double Z[];  // n x 3
+  extern __shared__ double Z[];  // ns x 3
   __shared__ double Ai[9], red[256 * 3];
   const int t = threadIdx.x;
   if (t == 0) {
-    const double a00 = E[(size_t)(n + 1) * lde + n + 1], a01 = E[(size_t)(n + 1) * lde + n + 2];
-    const double a02 = E[(size_t)(n + 1) * lde + n + 3], a11 = E[(size_t)(n + 2) * lde + n + 2];
-    const double a12 = E[(size_t)(n + 2) * lde + n + 3], a22 = E[(size_t)(n + 3) * lde + n + 3];
+    const double a00 = E[(size_t)(ns + 1) * lde + ns + 1], a01 = E[(size_t)(ns + 1) * lde + ns + 2];
+    const double a02 = E[(size_t)(ns + 1) * lde + ns + 3], a11 = E[(size_t)(ns + 2) * lde + ns + 2];
+    const double a12 = E[(size_t)(ns + 2) * lde + ns + 3], a22 = E[(size_t)(ns + 3) * lde + ns + 3];
     const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
     const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
     Ai[0] = c00 * id;
@@ -648,20 +650,19 @@ __global__ __launch_bounds__(256) void k_plane_init_augment(const double* __rest
     Ai[8] = (a00 * a11 - a01 * a01) * id;
   }
   __syncthreads();
-  for (int r = t; r < n; r += 256) {
-    const double x0 = E[(size_t)r * lde + n + 1], x1 = E[(size_t)r * lde + n + 2], x2 = E[(size_t)r * lde + n + 3];
+  for (int r = t; r < ns; r += 256) {
+    const double x0 = E[(size_t)r * lde + ns + 1], x1 = E[(size_t)r * lde + ns + 2], x2 = E[(size_t)r * lde + ns + 3];
     Z[3 * r + 0] = x0 * Ai[0] + x1 * Ai[3] + x2 * Ai[6];
     Z[3 * r + 1] = x0 * Ai[1] + x1 * Ai[4] + x2 * Ai[7];
     Z[3 * r + 2] = x0 * Ai[2] + x1 * Ai[5] + x2 * Ai[8];
   }
   __syncthreads();
-  // Sigma_xc rows and the partial sums of Z^T Sigma_xc (3x3) and Ecx dx (3)
-  double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Sigma_xc rows
   for (int r = t; r < n; r += 256) {
     const double* pr = P + (size_t)r * ldp;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < n; ++c) {
-      const double pv = pr[c];
+    for (int c = 0; c < ns; ++c) {
+      const double pv = pr[ids ? ids[c] : c];
       s0 = fma(pv, Z[3 * c + 0], s0);
       s1 = fma(pv, Z[3 * c + 1], s1);
       s2 = fma(pv, Z[3 * c + 2], s2);
@@ -671,12 +672,20 @@ __global__ __launch_bounds__(256) void k_plane_init_augment(const double* __rest
       P[(size_t)r * ldp + n + k] = v[k];
       P[(size_t)(n + k) * ldp + r] = v[k];
     }
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) acc[3 * i + j] += Z[3 * r + i] * v[j];
+  }
+  __syncthreads();  // (the rows just written are read back below, by other threads of this workgroup)
+  // the partial sums of Z^T Sigma_xc (3x3) and Ecx dx (3): over the selection
+  double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = t; i < ns; i += 256) {
+    const int r = ids ? ids[i] : i;
+    double v[3];
+    for (int k = 0; k < 3; ++k) v[k] = P[(size_t)(n + k) * ldp + r];
+    for (int a = 0; a < 3; ++a)
+      for (int j = 0; j < 3; ++j) acc[3 * a + j] += Z[3 * i + a] * v[j];
     const double dxr = dx[r];
-    acc[9] += E[(size_t)r * lde + n + 1] * dxr;
-    acc[10] += E[(size_t)r * lde + n + 2] * dxr;
-    acc[11] += E[(size_t)r * lde + n + 3] * dxr;
+    acc[9] += E[(size_t)i * lde + ns + 1] * dxr;
+    acc[10] += E[(size_t)i * lde + ns + 2] * dxr;
+    acc[11] += E[(size_t)i * lde + ns + 3] * dxr;
   }
   __shared__ double tot[12];
   for (int q = 0; q < 12; q += 3) {
@@ -706,8 +715,8 @@ __global__ __launch_bounds__(256) void k_plane_init_augment(const double* __rest
     P[(size_t)(n + i) * ldp + n + j] = v;
   }
   if (t < 3) {
-    const double b0 = E[(size_t)n * lde + n + 1] - tot[9], b1 = E[(size_t)n * lde + n + 2] - tot[10];
-    const double b2 = E[(size_t)n * lde + n + 3] - tot[11];
+    const double b0 = E[(size_t)ns * lde + ns + 1] - tot[9], b1 = E[(size_t)ns * lde + ns + 2] - tot[10];
+    const double b2 = E[(size_t)ns * lde + ns + 3] - tot[11];
     out[t] = Ai[3 * t] * b0 + Ai[3 * t + 1] * b1 + Ai[3 * t + 2] * b2;
   }
 }
@@ -716,10 +725,10 @@ __global__ __launch_bounds__(256) void k_plane_init_augment(const double* __rest
 
 extern "C" {
 
-hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
-                                         hipStream_t stream) {
-  hipLaunchKernelGGL(ovp::k_plane_init_augment, dim3(1), dim3(256), (size_t)3 * n * sizeof(double), stream, E, lde, n, P, ldp,
-                     dx, out);
+hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int ns, const int* ids, int n, double* P, int ldp, const double* dx,
+                                         double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_plane_init_augment, dim3(1), dim3(256), (size_t)3 * ns * sizeof(double), stream, E, lde, ns, ids, n, P,
+                     ldp, dx, out);
   return hipGetLastError();
 }
 

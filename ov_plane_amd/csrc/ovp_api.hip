@@ -92,7 +92,7 @@ hipError_t ovp_launch_gemm4c(int transA, int transB, int M, int N, int K, const 
                              double* C, int ldc, int add_identity, int symmetric, const int* cancel, hipStream_t stream);
 hipError_t ovp_launch_plane_gate(const double* scal, const int* flags, double thr, int rows_live, int rows_u,
                                  int n_involved, int force, double* res_out, hipStream_t stream);
-hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int n, double* P, int ldp, const double* dx, double* out,
+hipError_t ovp_launch_plane_init_augment(const double* E, int lde, int ns, const int* ids, int n, double* P, int ldp, const double* dx, double* out,
                                          hipStream_t stream);
 hipError_t ovp_launch_plane_slam_rows(double* E, int lde, int n, int plane1, int n_slam, const int* slam_plane, const int* slam_id,
                                       const double* slam_p, const double* slam_p_fej, const double* cp, const double* cp_fej,
@@ -1790,6 +1790,99 @@ static int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_byt
   return 0;
 }
 
+// ---- a selection of state columns as a state of its own (plane loop in its own order, plane initialisation on the marginal) ----
+// Device block [ids | inverse | clone ids | column map] of the selection `ids` (pos = its inverse, -1 = not selected), staged in the
+// context's pinned block and sent on stream s; the kernels then address the selection through these tables instead of the state's.
+struct SubTables {
+  const int* d_ids = nullptr;
+  const int* d_inv = nullptr;
+  int* d_clone_id = nullptr;
+  ovp::ColMap* d_colmap = nullptr;
+  int calib_sub = -1, intr_sub = -1;
+  std::vector<int> clone_sub;
+};
+static int sub_tables_upload(ovp_ctx* c, const ovp_update_opts* o, const std::vector<int>& ids, const std::vector<int>& pos,
+                             SubTables* t, hipStream_t s) {
+  const int n = c->n, C = c->fp.n_clones, ns = (int)ids.size();
+  const size_t o_ids = 0, o_inv = sizeof(int) * (size_t)(c->n_max + 16), o_tab = 2 * o_inv;
+  const size_t tab_bytes = sizeof(int) * (size_t)(c->c_max + 16) + sizeof(ovp::ColMap) * (size_t)c->n_max;
+  const size_t blk_bytes = o_tab + tab_bytes;
+  if (!c->pl_sub_tab) {
+    HIPCHK(hipMalloc(&c->pl_sub_tab, blk_bytes));
+    HIPCHK(hipHostMalloc(&c->pl_sub_htab, blk_bytes, hipHostMallocDefault));
+  }
+  if (c->ev_subtab) HIPCHK(hipEventSynchronize(c->ev_subtab));  // the pinned block fed the copy of the previous call (long done)
+  else HIPCHK(hipEventCreateWithFlags(&c->ev_subtab, hipEventDisableTiming));
+  char* hb = (char*)c->pl_sub_htab;
+  memset(hb, 0, blk_bytes);
+  int* h_ids = (int*)(hb + o_ids);
+  int* h_inv = (int*)(hb + o_inv);
+  int* t_clone = (int*)(hb + o_tab);
+  ovp::ColMap* t_cm = (ovp::ColMap*)(hb + o_tab + sizeof(int) * (size_t)(c->c_max + 16));
+  memcpy(h_ids, ids.data(), sizeof(int) * (size_t)ns);
+  for (int col = 0; col < n; ++col) h_inv[col] = pos[col] >= 0 ? pos[col] : 0;
+  t->clone_sub.assign((size_t)C, 0);
+  for (int i = 0; i < C; ++i) {
+    t->clone_sub[i] = t_clone[i] = pos[c->h_clone_id[i]];
+    for (int k = 0; k < 6; ++k) {
+      ovp::ColMap& m = t_cm[t->clone_sub[i] + k];
+      m.kind = 1;
+      m.idx = i;
+      m.off = k;
+    }
+  }
+  t->calib_sub = (c->calib_id >= 0 && c->calib_id + 6 <= n && pos[c->calib_id] >= 0) ? pos[c->calib_id] : -1;
+  t->intr_sub = (c->intr_id >= 0 && c->intr_id + 8 <= n && pos[c->intr_id] >= 0) ? pos[c->intr_id] : -1;
+  if (t->calib_sub >= 0 && o->do_calib_camera_pose)
+    for (int k = 0; k < 6; ++k) {
+      t_cm[t->calib_sub + k].kind = 2;
+      t_cm[t->calib_sub + k].idx = k;
+    }
+  if (t->intr_sub >= 0 && o->do_calib_camera_intrinsics)
+    for (int k = 0; k < 8; ++k) {
+      t_cm[t->intr_sub + k].kind = 2;
+      t_cm[t->intr_sub + k].idx = 6 + k;
+    }
+  HIPCHK(hipMemcpyAsync(c->pl_sub_tab, hb, blk_bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(c->ev_subtab, s));
+  t->d_ids = (const int*)((char*)c->pl_sub_tab + o_ids);
+  t->d_inv = (const int*)((char*)c->pl_sub_tab + o_inv);
+  t->d_clone_id = (int*)((char*)c->pl_sub_tab + o_tab);
+  t->d_colmap = (ovp::ColMap*)((char*)c->pl_sub_tab + o_tab + sizeof(int) * (size_t)(c->c_max + 16));
+  return 0;
+}
+// the context's view of the state while a selection stands in for it, and back
+struct SubSaved {
+  int n, calib_id, intr_id;
+  double* P;
+  int* clone_id;
+  ovp::ColMap* colmap;
+  const int* fp_clone_id;
+  std::vector<int> h_clone_id;
+};
+static SubSaved sub_enter(ovp_ctx* c, const SubTables& t, int ns, double* Psub) {
+  SubSaved sv{c->n, c->calib_id, c->intr_id, c->P, c->clone_id, c->colmap, c->fp.clone_id, c->h_clone_id};
+  c->n = ns;
+  c->P = Psub;
+  c->calib_id = t.calib_sub;
+  c->intr_id = t.intr_sub;
+  c->clone_id = t.d_clone_id;
+  c->fp.clone_id = c->clone_id;
+  c->colmap = t.d_colmap;
+  c->h_clone_id = t.clone_sub;
+  return sv;
+}
+static void sub_leave(ovp_ctx* c, const SubSaved& sv) {
+  c->n = sv.n;
+  c->P = sv.P;
+  c->calib_id = sv.calib_id;
+  c->intr_id = sv.intr_id;
+  c->clone_id = sv.clone_id;
+  c->fp.clone_id = sv.fp_clone_id;
+  c->colmap = sv.colmap;
+  c->h_clone_id = sv.h_clone_id;
+}
+
 // ---- the plane loop in the loop's own column order (update/UpdaterMSCKF.cpp:413-649 has no size limit) --------------------------
 // A plane's rows touch the clones, the calibration, its own closest point when it is a state variable and the SLAM landmarks lying
 // on it (out-of-state planes).  Two things follow:
@@ -1848,14 +1941,6 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
       }
   const int ns = (int)ids.size();
   hipStream_t s = c->stream;
-  // ---- buffers: one pinned host block + one device block for [ids | inverse | clone ids | column map] ----
-  const size_t o_ids = 0, o_inv = sizeof(int) * (size_t)(c->n_max + 16), o_tab = 2 * o_inv;
-  const size_t tab_bytes = sizeof(int) * (size_t)(c->c_max + 16) + sizeof(ovp::ColMap) * (size_t)c->n_max;
-  const size_t blk_bytes = o_tab + tab_bytes;
-  if (!c->pl_sub_tab) {
-    HIPCHK(hipMalloc(&c->pl_sub_tab, blk_bytes));
-    HIPCHK(hipHostMalloc(&c->pl_sub_htab, blk_bytes, hipHostMallocDefault));
-  }
   if (!full) {
     if (!c->pl_Asum) HIPCHK(dalloc(&c->pl_Asum, (size_t)c->n_max * ld));
     if (NP > c->pl_U_cap) {
@@ -1864,39 +1949,6 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
       HIPCHK(dalloc(&c->pl_U, (size_t)c->pl_U_cap * ld));
     }
   }
-  // ---- remapped tables ----
-  if (c->ev_subtab) HIPCHK(hipEventSynchronize(c->ev_subtab));  // the pinned block fed the copy of the previous call (long done)
-  else HIPCHK(hipEventCreateWithFlags(&c->ev_subtab, hipEventDisableTiming));
-  char* hb = (char*)c->pl_sub_htab;
-  memset(hb, 0, blk_bytes);
-  int* h_ids = (int*)(hb + o_ids);
-  int* h_inv = (int*)(hb + o_inv);
-  int* t_clone = (int*)(hb + o_tab);
-  ovp::ColMap* t_cm = (ovp::ColMap*)(hb + o_tab + sizeof(int) * (size_t)(c->c_max + 16));
-  memcpy(h_ids, ids.data(), sizeof(int) * (size_t)ns);
-  for (int col = 0; col < n; ++col) h_inv[col] = pos[col] >= 0 ? pos[col] : 0;
-  std::vector<int> clone_sub(C);
-  for (int i = 0; i < C; ++i) {
-    clone_sub[i] = t_clone[i] = pos[c->h_clone_id[i]];
-    for (int k = 0; k < 6; ++k) {
-      ovp::ColMap& m = t_cm[clone_sub[i] + k];
-      m.kind = 1;
-      m.idx = i;
-      m.off = k;
-    }
-  }
-  const int calib_sub = (c->calib_id >= 0 && c->calib_id + 6 <= n && pos[c->calib_id] >= 0) ? pos[c->calib_id] : -1;
-  const int intr_sub = (c->intr_id >= 0 && c->intr_id + 8 <= n && pos[c->intr_id] >= 0) ? pos[c->intr_id] : -1;
-  if (calib_sub >= 0 && o->do_calib_camera_pose)
-    for (int k = 0; k < 6; ++k) {
-      t_cm[calib_sub + k].kind = 2;
-      t_cm[calib_sub + k].idx = k;
-    }
-  if (intr_sub >= 0 && o->do_calib_camera_intrinsics)
-    for (int k = 0; k < 8; ++k) {
-      t_cm[intr_sub + k].kind = 2;
-      t_cm[intr_sub + k].idx = 6 + k;
-    }
   std::vector<int> sid_sub(NP > 0 ? NP : 1, -1), slam_sub(n_slam > 0 ? n_slam : 1, 0);
   for (int k = 0; k < NP; ++k) sid_sub[k] = pb->plane_state_id[k] >= 0 ? pos[pb->plane_state_id[k]] : -1;
   for (int q = 0; q < n_slam; ++q) {
@@ -1914,10 +1966,14 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
     }
     HIPCHK(hipEventRecord(c->pl_ev_loop[0], s));
   }
-  HIPCHK(hipMemcpyAsync(c->pl_sub_tab, hb, blk_bytes, hipMemcpyHostToDevice, s));
-  HIPCHK(hipEventRecord(c->ev_subtab, s));
-  const int* d_ids = (const int*)((char*)c->pl_sub_tab + o_ids);
-  const int* d_inv = (const int*)((char*)c->pl_sub_tab + o_inv);
+  // ---- remapped tables: [ids | inverse | clone ids | column map] ----
+  SubTables st;
+  {
+    const int rt = sub_tables_upload(c, o, ids, pos, &st, s);
+    if (rt) return rt;
+  }
+  const int* d_ids = st.d_ids;
+  const int* d_inv = st.d_inv;
   // full order: the columns behind the involved ones take a diagonal boost that the un-permutation behind the loop takes off
   // again (k_gather_block_boost) - an exact stochastic clone then factors at the first attempt
   const bool no_boost = getenv("OVP_PL_NO_BOOST") != nullptr;  // (read per call)
@@ -1937,22 +1993,7 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
   pbs.plane_state_id = sid_sub.data();
   pbs.slam_state_id = slam_sub.data();
   std::vector<double> dx_sub((size_t)ns * (NP > 0 ? NP : 1), 0.0);
-  struct Saved {
-    int n, calib_id, intr_id;
-    double* P;
-    int* clone_id;
-    ovp::ColMap* colmap;
-    const int* fp_clone_id;
-    std::vector<int> h_clone_id;
-  } sv{c->n, c->calib_id, c->intr_id, c->P, c->clone_id, c->colmap, c->fp.clone_id, c->h_clone_id};
-  c->n = ns;
-  c->P = c->P_tmp;
-  c->calib_id = calib_sub;
-  c->intr_id = intr_sub;
-  c->clone_id = (int*)((char*)c->pl_sub_tab + o_tab);
-  c->fp.clone_id = c->clone_id;
-  c->colmap = (ovp::ColMap*)((char*)c->pl_sub_tab + o_tab + sizeof(int) * (size_t)(c->c_max + 16));
-  c->h_clone_id = clone_sub;
+  SubSaved sv = sub_enter(c, st, ns, c->P_tmp);
   c->pl_sub_active = true;
   c->pl_sub_rest = !full;
   c->pl_scatter_dst = full ? sv.P : nullptr;  // full order: the loop's covariance product is un-permuted straight into the resident P
@@ -1963,14 +2004,7 @@ static int plane_update_ordered(ovp_ctx* c, const ovp_update_opts* o, const ovp_
   c->pl_sub_rest = false;
   c->pl_scatter_dst = nullptr;
   double* Pss_new = c->P;  // = P_tmp: the marginal after the loop
-  c->n = sv.n;
-  c->P = sv.P;
-  c->calib_id = sv.calib_id;
-  c->intr_id = sv.intr_id;
-  c->clone_id = sv.clone_id;
-  c->fp.clone_id = sv.fp_clone_id;
-  c->colmap = sv.colmap;
-  c->h_clone_id = sv.h_clone_id;
+  sub_leave(c, sv);
   if (rc) return rc;  // the resident covariance was not touched (the device tables may have been: a loop that fails after
                       // accepting planes has marked them invalid, have_state = false - INTEGRATION.md section 5)
   if (full) {
@@ -2589,9 +2623,48 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
   HIPCHK(hipStreamSynchronize(s));
   std::vector<double> res4(4), dxh(c->n_max), dcp(3);
   bool psd_prior = false;
+  // The plane runs on the MARGINAL of the columns its rows can touch (clones and calibration: at most 6 * 32 + 14 of them) and the
+  // rest of the state follows from the push-through identity, like the plane loop's sub-state (plane_update_ordered):
+  // update/UpdaterPlane.cpp:296-481 has no size limit, the factorizations are those of ~80 columns instead of the state's, and the
+  // marginal of a prior with an exact stochastic clone is positive definite (no second attempt).  Closed-loop session with two
+  // planes, per frame: 0.198 ms against 0.216 on the whole state.  OVP_PLANE_INIT_SUB=0: the whole state (<= 288 columns; A/B, tests).
+  const char* sub_env = getenv("OVP_PLANE_INIT_SUB");  // (read per call)
+  const bool whole_state = sub_env && sub_env[0] == '0' && c->n <= OVP_TILECHOL_NMAX;
+  std::vector<int> sub_ids, sub_pos;
+  SubTables sub_t;
+  int ns = 0;
+  if (!whole_state) {
+    const int n = c->n;
+    sub_pos.assign((size_t)c->n_max, -1);
+    bool bad_id = false;
+    auto place = [&](int id, int sz) {
+      if (id < 0 || id + sz > n) {
+        bad_id = true;
+        return;
+      }
+      for (int k = 0; k < sz; ++k)
+        if (sub_pos[id + k] < 0) {
+          sub_pos[id + k] = (int)sub_ids.size();
+          sub_ids.push_back(id + k);
+        }
+    };
+    for (int i = 0; i < c->fp.n_clones; ++i) place(c->h_clone_id[i], 6);
+    if (o->do_calib_camera_pose) place(c->calib_id, 6);
+    if (o->do_calib_camera_intrinsics) place(c->intr_id, 8);
+    if (bad_id) return OVP_E_ARG;
+    ns = (int)sub_ids.size();
+    if (ns > OVP_TILECHOL_NMAX) return OVP_E_CAPACITY;
+    rc = sub_tables_upload(c, o, sub_ids, sub_pos, &sub_t, s);
+    if (rc) return rc;
+    if (!c->pl_Asum) HIPCHK(dalloc(&c->pl_Asum, (size_t)c->n_max * ld));
+    if (c->pl_U_cap < 1) {
+      c->pl_U_cap = 8;
+      HIPCHK(dalloc(&c->pl_U, (size_t)c->pl_U_cap * ld));
+    }
+  }
   for (int pl = 0; pl < NP; ++pl) {
     const int n = c->n;
-    if (n > OVP_TILECHOL_NMAX || n + 3 > c->n_max) return OVP_E_CAPACITY;
+    if ((n > OVP_TILECHOL_NMAX && !ns) || n + 3 > c->n_max) return OVP_E_CAPACITY;
     std::vector<int> featlist;
     int rows_total = 0, rows_live = 0;
     unsigned long long seen = 0ull;
@@ -2617,22 +2690,42 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
     // A prior that is only positive SEMI-definite (an exact stochastic clone in front of the next propagation: every frame of a
     // running filter) fails chol(P) before anything is committed: the plane runs once more on the pivot-dropping factor of the
     // unit-diagonal form (chol_of_P, as the plane loop does), and so do the planes behind it.
+    const int nj = ns ? ns : n;  // the size the plane's kernels run on
+    SubSaved sub_sv;
+    if (ns) {  // the marginal of the selection stands in for the state
+      HIPCHK(ovp_launch_gather_block(c->P, ld, sub_t.d_ids, ns, c->P_tmp, ld, s));
+      sub_sv = sub_enter(c, sub_t, ns, c->P_tmp);
+      rc = fill_feat_params(c, o);  // (the calibration columns of the selection)
+      if (rc) {
+        sub_leave(c, sub_sv);
+        (void)fill_feat_params(c, o);
+        return rc;
+      }
+      fp = c->fp;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
       c->pl_psd = psd_prior;
-      HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
-      HIPCHK(hipMemsetAsync(c->pl_res + 4 * pl, 0, sizeof(double) * 4, s));
-      rc = chol_of_P(c, s);
+      rc = (int)hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s);
+      if (!rc) rc = (int)hipMemsetAsync(c->pl_res + 4 * pl, 0, sizeof(double) * 4, s);
+      if (!rc) rc = chol_of_P(c, s);
       if (!rc)
         rc = plane_job_device(c, o, fp, pl, 0, nf, 0, -1, 1.0 / (const_init_multi * o->sigma_constraint), c->L, 0, thr, rows_live - 3,
                               rows_c - 3, c_ref);
       c->pl_psd = false;
-      if (rc) return rc;
-      HIPCHK(hipMemcpyAsync(res4.data(), c->pl_res + 4 * pl, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      if (!c->h_flags[0] || psd_prior || n > ovp_chol2_max_n() + 1) break;
+      if (!rc) rc = (int)hipMemcpyAsync(res4.data(), c->pl_res + 4 * pl, sizeof(double) * 4, hipMemcpyDeviceToHost, s);
+      if (!rc) rc = (int)hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s);
+      if (!rc) rc = (int)hipStreamSynchronize(s);
+      if (rc) break;  // (the selection's tables are taken off below before the error goes out)
+      if (!c->h_flags[0] || psd_prior || nj > ovp_chol2_max_n() + 1) break;
       psd_prior = true;
     }
+    if (ns) {
+      sub_leave(c, sub_sv);
+      const int rf = fill_feat_params(c, o);
+      if (!rc) rc = rf;
+      fp = c->fp;
+    }
+    if (rc) return rc;
     if (c->h_flags[0]) {
       (void)hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s);
       return OVP_E_NOTSPD;
@@ -2641,9 +2734,27 @@ extern "C" int ovp_plane_init(ovp_ctx* c, const ovp_update_opts* o, const ovp_pl
     if (plane_dof) plane_dof[pl] = rows_c;
     if (res4[1] < 0.5) continue;  // chi2 rejected: StateHelper::initialize returns false
     // accepted: P <- P+ = V^T V, append the plane, update the device tables like Type::update would
-    HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, s));
-    HIPCHK(ovp_launch_plane_init_augment(c->pl_E, c->ldg, n, c->P, ld, c->dx, c->pl_scal + 4, s));
-    HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * pl, c->Y, c->W1 /* factor not chained here */, n, ld, c->dx,
+    if (ns) {
+      // the selection's posterior Pss+ = V^T V; the whole state by the push-through identity (G = P[:, s], A|b = the plane's pair on s):
+      //   u = b - A dx_s,  dx = G u ;  Lambda = A - A Pss+ A,  P -= G Lambda G^T
+      HIPCHK(ovp_launch_gemm4(1, 0, ns, ns, ns, c->Y, ld, c->Y, ld, c->P_tmp, ld, 0, 1, s));
+      HIPCHK(hipMemsetAsync(c->pl_Asum, 0, sizeof(double) * (size_t)ns * ld, s));
+      HIPCHK(ovp_launch_plane_sub_accum(c->pl_res + 4 * pl, c->Ab, c->pl_Asum, c->dx, c->pl_U, ns, ld, s));  // (Asum = A from here)
+      HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, c->pl_Asum, ld, c->P_tmp, ld, c->W1, ld, 0, 0, s));
+      HIPCHK(ovp_launch_gemm4(0, 0, ns, ns, ns, c->W1, ld, c->pl_Asum, ld, c->T, ld, 0, 1, s));
+      HIPCHK(ovp_launch_mat_sub(c->pl_Asum, c->T, c->T, ns, ns, ld, s));
+      HIPCHK(ovp_launch_gather_cols(c->P, ld, sub_t.d_ids, n, ns, c->Y, ld, s));
+      HIPCHK(ovp_launch_gemm4(0, 1, 1, n, ns, c->pl_U, ld, c->Y, ld, c->Lt, ld, 0, 0, s));
+      HIPCHK(hipMemcpyAsync(c->dx, c->Lt, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+      HIPCHK(ovp_launch_gemm4(0, 0, n, ns, ns, c->Y, ld, c->T, ld, c->W1, ld, 0, 0, s));
+      HIPCHK(ovp_launch_gemm4(0, 1, n, n, ns, c->W1, ld, c->Y, ld, c->L, ld, 0, 1, s));
+      HIPCHK(ovp_launch_sub_sym(c->P, c->L, n, ld, s));
+      HIPCHK(ovp_launch_plane_init_augment(c->pl_E, c->ldg, ns, sub_t.d_ids, n, c->P, ld, c->dx, c->pl_scal + 4, s));
+    } else {
+      HIPCHK(ovp_launch_gemm4(1, 0, n, n, n, c->Y, ld, c->Y, ld, c->P, ld, 0, 1, s));
+      HIPCHK(ovp_launch_plane_init_augment(c->pl_E, c->ldg, n, nullptr, n, c->P, ld, c->dx, c->pl_scal + 4, s));
+    }
+    HIPCHK(ovp_launch_plane_commit(c->pl_res + 4 * pl, nullptr /* no factor is chained here */, nullptr, n, ld, c->dx,
                                    c->pl_dx + (size_t)pl * c->n_max, c->clone_R, c->clone_p, c->clone_id, fp.n_clones, c->cal,
                                    o->do_calib_camera_pose ? c->calib_id : -1, o->do_calib_camera_intrinsics ? c->intr_id : -1,
                                    c->pl_cp, c->pl_sid, 0, s));

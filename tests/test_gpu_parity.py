@@ -991,14 +991,24 @@ def test_host_cpp_initialize_matches_oracle(hiplib, oracle, r_iso, chi2_mult, ex
         assert np.abs(out["clone_q"][i] - quat_boxplus(sc.clone_q[i], dx[cid:cid + 3])).max() < TOL_DX
 
 
-@pytest.mark.parametrize("kw,chi2", [
-    (dict(C=11, F=140, seed=15, n_planes=3, feats_per_plane=30, planes_in_state_frac=0.0, chi2_mult=1.0), 1e9),
-    (dict(C=8, F=80, seed=16, n_planes=2, feats_per_plane=25, planes_in_state_frac=0.0, chi2_mult=1.0, ragged=True), 1e9),
+@pytest.mark.parametrize("kw,chi2,on_marginal", [
+    # on the marginal of the clone / calibration columns, the rest of the state by the push-through identity (the default) ...
+    (dict(C=11, F=140, seed=15, n_planes=3, feats_per_plane=30, planes_in_state_frac=0.0, chi2_mult=1.0), 1e9, True),
+    (dict(C=8, F=80, seed=16, n_planes=2, feats_per_plane=25, planes_in_state_frac=0.0, chi2_mult=1.0, ragged=True), 1e9, True),
+    # ... and with every kernel on the whole state (OVP_PLANE_INIT_SUB=0)
+    (dict(C=11, F=140, seed=15, n_planes=3, feats_per_plane=30, planes_in_state_frac=0.0, chi2_mult=1.0), 1e9, False),
+    (dict(C=8, F=80, seed=16, n_planes=2, feats_per_plane=25, planes_in_state_frac=0.0, chi2_mult=1.0, ragged=True), 1e9, False),
+    # a state above the register-resident factorizations' 288 columns (N = 300, 306 after the two planes)
+    (dict(C=30, F=150, seed=17, n_planes=2, feats_per_plane=35, planes_in_state_frac=0.0, chi2_mult=1.0, n_slam=30), 1e9, True),
 ])
-def test_plane_initialisation_matches_oracle(hiplib, oracle, kw, chi2):
+def test_plane_initialisation_matches_oracle(hiplib, oracle, monkeypatch, kw, chi2, on_marginal):
     """UpdaterPlane::init_vio_plane core (update/UpdaterPlane.cpp:296-481) -> StateHelper::initialize: every accepted plane
     appends 3 columns; state correction, plane value and the augmented covariance against the restatement."""
+    if not on_marginal:
+        monkeypatch.setenv("OVP_PLANE_INIT_SUB", "0")
     sc = make_scene(**kw)
+    if kw.get("n_slam"):
+        assert sc.N > 288
     ref = oracle.plane_init(sc, const_init_multi=5.0, const_init_chi2=chi2)
     ctx = hiplib.Context(sc.N + 3 * sc.cp.shape[0], sc.C, sc.F)
     ctx.cov_upload(sc.P)
