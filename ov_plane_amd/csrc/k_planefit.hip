@@ -290,6 +290,12 @@ struct RefineJob {
   const double* pc;        // [O][3]
   const double* cp0;       // [n_planes][3]
   const unsigned char* fix_plane;  // [n_planes]
+  // the observations of a plane as one list, feature by feature in the features' order (built by the launcher): the evaluation of
+  // the cost runs over this list with one thread per OBSERVATION, the feature's own thread then adds the pieces up in its order
+  const int* item_start;   // [n_planes + 1]
+  const int* item_ob;      // [items] observation index (into uv / Rc / pc)
+  const int* item_lf;      // [items] feature of the observation, local index within its plane
+  const int* feat_item0;   // [F] first item of the feature, relative to its plane's first
   double sigma_px_norm, sigma_c;
   double R_GtoC[9], p_CinG[3];     // current camera (from stateI, calib0: PlaneFitting.cpp:444-453)
   double* cp_out;          // [n_planes][3]
@@ -308,9 +314,123 @@ struct FeatBlocks {
   double gp[3], gc[3];
 };
 
+// One point-on-plane residual block at (p, cp) (ceres/Factor_PointOnPlane.cpp:41-71, CauchyLoss(1) corrector): every observation of a
+// feature adds the SAME block (PlaneFitting.cpp:366-368), so the feature's thread forms it once per evaluation and adds it m times.
+struct ConsBlock {
+  double cost;
+  double JpJp[6], JcJc[6], JpJc[9], gp[3], gc[3];
+};
 template <bool WITH_J>
-__device__ __forceinline__ void pf_eval_feature(const RefineJob& j, int f, int m, const double (&p)[3], const double (&cp)[3],
-                                                FeatBlocks& o) {
+__device__ __forceinline__ void pf_constraint_block(const double (&p)[3], const double (&cp)[3], double sigma, ConsBlock& o) {
+  const double d = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+  const double nv[3] = {cp[0] / d, cp[1] / d, cp[2] / d};
+  const double np = nv[0] * p[0] + nv[1] * p[1] + nv[2] * p[2];
+  const double w = 1.0 / sigma;
+  const double r = -1.0 * w * (0.0 - (np - d));
+  const double s = r * r;
+  o.cost = 0.5 * log(1.0 + s);
+  if (WITH_J) {
+    const double a = sqrt(1.0 / (1.0 + s));
+    const double ra = a * r;
+    double Jp[3], Jc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      Jp[k] = a * (w * nv[k]);
+      Jc[k] = a * (w * 1.0 / d * (p[k] - np * nv[k] - d * nv[k]));
+    }
+    o.JpJp[0] = Jp[0] * Jp[0];
+    o.JpJp[1] = Jp[0] * Jp[1];
+    o.JpJp[2] = Jp[0] * Jp[2];
+    o.JpJp[3] = Jp[1] * Jp[1];
+    o.JpJp[4] = Jp[1] * Jp[2];
+    o.JpJp[5] = Jp[2] * Jp[2];
+    o.JcJc[0] = Jc[0] * Jc[0];
+    o.JcJc[1] = Jc[0] * Jc[1];
+    o.JcJc[2] = Jc[0] * Jc[2];
+    o.JcJc[3] = Jc[1] * Jc[1];
+    o.JcJc[4] = Jc[1] * Jc[2];
+    o.JcJc[5] = Jc[2] * Jc[2];
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_) {
+      o.gp[a_] = Jp[a_] * ra;
+      o.gc[a_] = Jc[a_] * ra;
+#pragma unroll
+      for (int b_ = 0; b_ < 3; ++b_) o.JpJc[3 * a_ + b_] = Jp[a_] * Jc[b_];
+    }
+  }
+}
+template <bool WITH_J>
+__device__ __forceinline__ void pf_add_constraint(FeatBlocks& o, const ConsBlock& c) {
+  o.cost += c.cost;
+  if (WITH_J) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.Hpp[k] += c.JpJp[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.Hcc[k] += c.JcJc[k];
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_) {
+      o.gp[a_] += c.gp[a_];
+      o.gc[a_] += c.gc[a_];
+#pragma unroll
+      for (int b_ = 0; b_ < 3; ++b_) o.Hpc[3 * a_ + b_] += c.JpJc[3 * a_ + b_];
+    }
+  }
+}
+
+// The reprojection block of ONE observation of a point p (PlaneFitting.cpp:330-364, CauchyLoss(1) corrector):
+// out = [cost, Hpp (6), gp (3)].
+static constexpr int PF_OB = 10;
+template <bool WITH_J>
+__device__ __forceinline__ void pf_reproj_block(const RefineJob& j, int ob, const double (&p)[3], double* out) {
+  const double* R = j.Rc + (size_t)9 * ob;
+  const double* c = j.pc + (size_t)3 * ob;
+  const double dd[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+  const double x = R[0] * dd[0] + R[1] * dd[1] + R[2] * dd[2];
+  const double y = R[3] * dd[0] + R[4] * dd[1] + R[5] * dd[2];
+  const double z = R[6] * dd[0] + R[7] * dd[1] + R[8] * dd[2];
+  const double w = 1.0 / j.sigma_px_norm;
+  const double r0 = w * (x / z - j.uv[2 * ob]), r1 = w * (y / z - j.uv[2 * ob + 1]);
+  const double s = r0 * r0 + r1 * r1;
+  out[0] = 0.5 * log(1.0 + s);
+  if (WITH_J) {
+    const double a = sqrt(1.0 / (1.0 + s));
+    const double a0 = 1.0 / z, a2 = -x / (z * z), b2 = -y / (z * z);
+    double J0[3], J1[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      J0[q] = a * (w * (a0 * R[q] + a2 * R[6 + q]));
+      J1[q] = a * (w * (a0 * R[3 + q] + b2 * R[6 + q]));
+    }
+    const double ra0 = a * r0, ra1 = a * r1;
+    out[1] = J0[0] * J0[0] + J1[0] * J1[0];
+    out[2] = J0[0] * J0[1] + J1[0] * J1[1];
+    out[3] = J0[0] * J0[2] + J1[0] * J1[2];
+    out[4] = J0[1] * J0[1] + J1[1] * J1[1];
+    out[5] = J0[1] * J0[2] + J1[1] * J1[2];
+    out[6] = J0[2] * J0[2] + J1[2] * J1[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[7 + q] = J0[q] * ra0 + J1[q] * ra1;
+  }
+}
+
+// What every feature of the plane contributes at the points (p, cp): the threads of the workgroup take the plane's observations
+// one each (a pass of blockDim.x observations at a time, their blocks staged in LDS), then the feature's own thread adds its
+// observations' blocks and its constraint block in the order the sequential loop visits them (observation 0, constraint,
+// observation 1, constraint, ...; PlaneFitting.cpp:330-368) - same sums, to the bit, as one thread walking its feature's list.
+#ifdef OVP_PF_STAMPS
+__device__ long long g_pf_stamps[64 * 12];
+#define PF_T() __builtin_readcyclecounter()
+#endif
+struct EvalCtx {
+  int tid, nthreads, nitems, it0;  // workgroup geometry; the plane's item range
+  int my_item0, m;                 // this thread's feature: first item (relative), observations
+  bool act, contrib;
+  double* xs;   // [256][3] the features' points of this evaluation
+  double* obs;  // [blockDim.x][PF_OB] one pass of observation blocks
+};
+template <bool WITH_J>
+__device__ __forceinline__ void pf_eval_plane(const RefineJob& j, const EvalCtx& e, const double (&p)[3], const double (&cp)[3],
+                                              FeatBlocks& o) {
   o.cost = 0.0;
   if (WITH_J) {
 #pragma unroll
@@ -320,78 +440,46 @@ __device__ __forceinline__ void pf_eval_feature(const RefineJob& j, int f, int m
 #pragma unroll
     for (int k = 0; k < 3; ++k) o.gp[k] = 0.0, o.gc[k] = 0.0;
   }
-  const double d = sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
-  const double nv[3] = {cp[0] / d, cp[1] / d, cp[2] / d};
-  const double np = nv[0] * p[0] + nv[1] * p[1] + nv[2] * p[2];
-  auto constraint = [&](double sigma) {  // ceres/Factor_PointOnPlane.cpp:41-71, CauchyLoss(1) corrector
-    const double w = 1.0 / sigma;
-    const double r = -1.0 * w * (0.0 - (np - d));
-    const double s = r * r;
-    o.cost += 0.5 * log(1.0 + s);
-    if (WITH_J) {
-      const double a = sqrt(1.0 / (1.0 + s));
-      const double ra = a * r;
-      double Jp[3], Jc[3];
+  ConsBlock cb;
+  if (e.contrib) {
+    if (e.m == 0) {  // :276-279
+      pf_constraint_block<WITH_J>(p, cp, 2.00 * j.sigma_c, cb);
+      pf_add_constraint<WITH_J>(o, cb);
+    } else {
+      pf_constraint_block<WITH_J>(p, cp, j.sigma_c, cb);
+    }
+  }
+  __syncthreads();  // (xs / obs may still be read from the previous evaluation)
+  if (e.act) {
+    e.xs[3 * e.tid] = p[0];
+    e.xs[3 * e.tid + 1] = p[1];
+    e.xs[3 * e.tid + 2] = p[2];
+  }
+  __syncthreads();
+  for (int base = 0; base < e.nitems; base += e.nthreads) {
+    const int i = base + e.tid;
+    if (i < e.nitems) {
+      const int ob = j.item_ob[e.it0 + i], lf = j.item_lf[e.it0 + i];
+      const double pp[3] = {e.xs[3 * lf], e.xs[3 * lf + 1], e.xs[3 * lf + 2]};
+      pf_reproj_block<WITH_J>(j, ob, pp, e.obs + (size_t)PF_OB * e.tid);
+    }
+    __syncthreads();
+    if (e.contrib && e.m > 0) {
+      const int lo = e.my_item0 > base ? e.my_item0 : base;
+      const int hi = (e.my_item0 + e.m) < (base + e.nthreads) ? (e.my_item0 + e.m) : (base + e.nthreads);
+      for (int i2 = lo; i2 < hi; ++i2) {
+        const double* b = e.obs + (size_t)PF_OB * (i2 - base);
+        o.cost += b[0];
+        if (WITH_J) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Jp[k] = a * (w * nv[k]);
-        Jc[k] = a * (w * 1.0 / d * (p[k] - np * nv[k] - d * nv[k]));
-      }
-      o.Hpp[0] += Jp[0] * Jp[0];
-      o.Hpp[1] += Jp[0] * Jp[1];
-      o.Hpp[2] += Jp[0] * Jp[2];
-      o.Hpp[3] += Jp[1] * Jp[1];
-      o.Hpp[4] += Jp[1] * Jp[2];
-      o.Hpp[5] += Jp[2] * Jp[2];
-      o.Hcc[0] += Jc[0] * Jc[0];
-      o.Hcc[1] += Jc[0] * Jc[1];
-      o.Hcc[2] += Jc[0] * Jc[2];
-      o.Hcc[3] += Jc[1] * Jc[1];
-      o.Hcc[4] += Jc[1] * Jc[2];
-      o.Hcc[5] += Jc[2] * Jc[2];
+          for (int k = 0; k < 6; ++k) o.Hpp[k] += b[1 + k];
 #pragma unroll
-      for (int a_ = 0; a_ < 3; ++a_) {
-        o.gp[a_] += Jp[a_] * ra;
-        o.gc[a_] += Jc[a_] * ra;
-#pragma unroll
-        for (int b_ = 0; b_ < 3; ++b_) o.Hpc[3 * a_ + b_] += Jp[a_] * Jc[b_];
+          for (int q = 0; q < 3; ++q) o.gp[q] += b[7 + q];
+        }
+        pf_add_constraint<WITH_J>(o, cb);
       }
     }
-  };
-  if (m == 0) constraint(2.00 * j.sigma_c);  // :276-279
-  const int ob0 = j.obs_start[f];
-  for (int k = 0; k < m; ++k) {
-    const int ob = ob0 + k;
-    const double* R = j.Rc + (size_t)9 * ob;
-    const double* c = j.pc + (size_t)3 * ob;
-    const double dd[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
-    const double x = R[0] * dd[0] + R[1] * dd[1] + R[2] * dd[2];
-    const double y = R[3] * dd[0] + R[4] * dd[1] + R[5] * dd[2];
-    const double z = R[6] * dd[0] + R[7] * dd[1] + R[8] * dd[2];
-    const double w = 1.0 / j.sigma_px_norm;
-    const double r0 = w * (x / z - j.uv[2 * ob]), r1 = w * (y / z - j.uv[2 * ob + 1]);
-    const double s = r0 * r0 + r1 * r1;
-    o.cost += 0.5 * log(1.0 + s);
-    if (WITH_J) {
-      const double a = sqrt(1.0 / (1.0 + s));
-      const double a0 = 1.0 / z, a2 = -x / (z * z), b2 = -y / (z * z);
-      double J0[3], J1[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        J0[q] = a * (w * (a0 * R[q] + a2 * R[6 + q]));
-        J1[q] = a * (w * (a0 * R[3 + q] + b2 * R[6 + q]));
-      }
-      const double ra0 = a * r0, ra1 = a * r1;
-      o.Hpp[0] += J0[0] * J0[0] + J1[0] * J1[0];
-      o.Hpp[1] += J0[0] * J0[1] + J1[0] * J1[1];
-      o.Hpp[2] += J0[0] * J0[2] + J1[0] * J1[2];
-      o.Hpp[3] += J0[1] * J0[1] + J1[1] * J1[1];
-      o.Hpp[4] += J0[1] * J0[2] + J1[1] * J1[2];
-      o.Hpp[5] += J0[2] * J0[2] + J1[2] * J1[2];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) o.gp[q] += J0[q] * ra0 + J1[q] * ra1;
-    }
-    constraint(j.sigma_c);  // :366-368
+    __syncthreads();
   }
 }
 
@@ -405,11 +493,29 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
   const int f0 = j.feat_start[pl], nf = j.feat_start[pl + 1] - f0;
   const bool fix = j.fix_plane[pl] != 0;
   __shared__ double red[16 * 16];
+  __shared__ double xs_s[256 * 3];
+  __shared__ double obs_s[256 * PF_OB];
   const bool act = tid < nf;            // this thread owns feature f0 + tid
   const int f = f0 + (act ? tid : 0);
   const int m = act ? j.n_obs[f] : 0;
   const bool freef = act && m > 0;      // free parameter block
   const bool contrib = act && (freef || !fix);  // has residual blocks with a free parameter
+#ifdef OVP_PF_STAMPS
+  long long t_evalj = 0, t_evalc = 0, tp[6] = {0, 0, 0, 0, 0, 0};
+  long long t_mark = 0;
+  const long long t_begin = PF_T();
+#endif
+  EvalCtx ev;
+  ev.tid = tid;
+  ev.nthreads = blockDim.x;
+  ev.it0 = j.item_start[pl];
+  ev.nitems = j.item_start[pl + 1] - ev.it0;
+  ev.my_item0 = act ? j.feat_item0[f] : 0;
+  ev.m = m;
+  ev.act = act;
+  ev.contrib = contrib;
+  ev.xs = xs_s;
+  ev.obs = obs_s;
   double x[3], cp[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -448,7 +554,13 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
     double gn[3], gnc[3], alpha = 0.0, dogleg_norm = 0.0;
 
     auto linearise = [&](bool first) {
-      if (contrib) pf_eval_feature<true>(j, f, m, x, cp, B);
+#ifdef OVP_PF_STAMPS
+      const long long te0 = PF_T();
+#endif
+      pf_eval_plane<true>(j, ev, x, cp, B);
+#ifdef OVP_PF_STAMPS
+      t_evalj += PF_T() - te0;
+#endif
       double v[13];
       v[0] = contrib ? B.cost : 0.0;
 #pragma unroll
@@ -496,6 +608,9 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
       }
       ++iter;
       bool step_ok = true;
+#ifdef OVP_PF_STAMPS
+      t_mark = PF_T();
+#endif
       if (!reuse) {
         reuse = true;
         // scaled blocks, diag, gradient
@@ -518,6 +633,10 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
           qc = fmin(fmax(qc, 1e-6), 1e32);
           dgc[a] = sqrt(qc);
         }
+#ifdef OVP_PF_STAMPS
+        tp[0] += PF_T() - t_mark;
+        t_mark = PF_T();
+#endif
         // Cauchy point: alpha = |g/d|^2 / (v^T H v), v = g / d^2
         {
           double vv[3], vc[3];
@@ -546,9 +665,16 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
           }
           alpha = r2[0] / r2[1];
         }
+#ifdef OVP_PF_STAMPS
+        tp[1] += PF_T() - t_mark;
+        t_mark = PF_T();
+#endif
         // Gauss-Newton step: (H + mu D^2) y = g through the Schur complement on cp; mu grows on failure
         bool solved = false;
         while (mu < max_mu) {
+#ifdef OVP_PF_STAMPS
+          tp[4] += 1;
+#endif
           double A[9], yf[3] = {0.0, 0.0, 0.0}, W[9];  // W = A^-1 Hsc (3x3), yf = A^-1 gs
           bool okf = true;
           if (freef) {
@@ -623,7 +749,13 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
           mu *= mu_inc;
         }
         if (!solved) step_ok = false;
+#ifdef OVP_PF_STAMPS
+        tp[2] += PF_T() - t_mark;
+#endif
       }
+#ifdef OVP_PF_STAMPS
+      t_mark = PF_T();
+#endif
       double st[3] = {0.0, 0.0, 0.0}, stc[3] = {0.0, 0.0, 0.0};
       double model_change = 0.0;
       if (step_ok) {
@@ -702,6 +834,9 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
         }
         if (need_norm) dogleg_norm = sqrt(r4[0]);
         model_change = -(r4[1] + 0.5 * r4[2]);
+#ifdef OVP_PF_STAMPS
+        tp[3] += PF_T() - t_mark;
+#endif
         if (!(model_change > 0.0)) step_ok = false;
         if (step_ok) {
           const double snorm = sqrt(r4[3]);
@@ -712,7 +847,13 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
             cpc[a] = cp[a] + stc[a] * sc[a];
           }
           FeatBlocks Bc;
-          if (contrib) pf_eval_feature<false>(j, f, m, xc, cpc, Bc);
+#ifdef OVP_PF_STAMPS
+          const long long tc0 = PF_T();
+#endif
+          pf_eval_plane<false>(j, ev, xc, cpc, Bc);
+#ifdef OVP_PF_STAMPS
+          t_evalc += PF_T() - tc0;
+#endif
           double cv[1] = {contrib ? Bc.cost : 0.0};
           pf_block_sum<1>(cv, red, tid, nwaves);
           const double cand = cv[0];
@@ -773,6 +914,22 @@ __global__ __launch_bounds__(256) void k_plane_refine(const RefineJob j) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) j.p_out[3 * (size_t)f + a] = k ? x[a] : p_old[a];
   }
+#ifdef OVP_PF_STAMPS
+  if (tid == 0 && pl < 64) {
+    long long* o = g_pf_stamps + 8 * pl;
+    o[0] = t_evalj;
+    o[1] = t_evalc;
+    o[2] = PF_T() - t_begin;
+    o[3] = iter;
+    o[4] = nf;
+    o[5] = ev.nitems;
+    o[6] = tp[4];
+    g_pf_stamps[64 * 8 + 4 * pl + 0] = tp[0];
+    g_pf_stamps[64 * 8 + 4 * pl + 1] = tp[1];
+    g_pf_stamps[64 * 8 + 4 * pl + 2] = tp[2];
+    g_pf_stamps[64 * 8 + 4 * pl + 3] = tp[3];
+  }
+#endif
   if (tid == 0) {
     j.ok[pl] = fail ? 0 : 1;
     j.iterations[pl] = iter;
@@ -966,7 +1123,17 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   const size_t o_os = take(sizeof(int) * (size_t)F), o_no = take(sizeof(int) * (size_t)F);
   const size_t o_uv = take(sizeof(double) * 2 * (size_t)O), o_R = take(sizeof(double) * 9 * (size_t)O);
   const size_t o_pc = take(sizeof(double) * 3 * (size_t)O), o_cp = take(sizeof(double) * 3 * (size_t)P);
-  const size_t o_fix = take((size_t)P), o_cpo = take(sizeof(double) * 3 * (size_t)P);
+  // (the observation list of every plane: validated and counted first)
+  size_t n_items = 0;
+  for (int f = 0; f < F; ++f) {
+    const int m = b->n_obs[f];
+    if (m < 0 || (m > 0 && (b->obs_start[f] < 0 || b->obs_start[f] + m > O))) return OVP_E_ARG;
+    n_items += (size_t)m;
+  }
+  const size_t o_fix = take((size_t)P);
+  const size_t o_is = take(sizeof(int) * (size_t)(P + 1)), o_iob = take(sizeof(int) * (n_items + 1));
+  const size_t o_ilf = take(sizeof(int) * (n_items + 1)), o_fi0 = take(sizeof(int) * (size_t)(F + 1));
+  const size_t o_cpo = take(sizeof(double) * 3 * (size_t)P);
   const size_t o_po = take(sizeof(double) * 3 * (size_t)F), o_kept = take((size_t)F), o_ok = take((size_t)P);
   const size_t o_it = take(sizeof(int) * (size_t)P);
   const size_t in_bytes = o_cpo;  // everything in front of the outputs is input
@@ -988,6 +1155,25 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   PF_UP(o_cp, b->cp, sizeof(double) * 3 * (size_t)P);
   PF_UP(o_fix, b->fix_plane, (size_t)P);
 #undef PF_UP
+  {
+    int* is = (int*)(hb + o_is);
+    int* iob = (int*)(hb + o_iob);
+    int* ilf = (int*)(hb + o_ilf);
+    int* fi0 = (int*)(hb + o_fi0);
+    int it = 0;
+    for (int pl = 0; pl < P; ++pl) {
+      is[pl] = it;
+      for (int f = b->feat_start[pl]; f < b->feat_start[pl + 1]; ++f) {
+        fi0[f] = it - is[pl];
+        for (int k = 0; k < b->n_obs[f]; ++k) {
+          iob[it] = b->obs_start[f] + k;
+          ilf[it] = f - b->feat_start[pl];
+          ++it;
+        }
+      }
+    }
+    is[P] = it;
+  }
   PF_HIPCHK(hipMemcpyAsync(blob, hb, in_bytes, hipMemcpyHostToDevice, s));
   ovp::RefineJob j;
   j.feat_start = (const int*)(blob + o_fs);
@@ -999,6 +1185,10 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   j.pc = (const double*)(blob + o_pc);
   j.cp0 = (const double*)(blob + o_cp);
   j.fix_plane = (const unsigned char*)(blob + o_fix);
+  j.item_start = (const int*)(blob + o_is);
+  j.item_ob = (const int*)(blob + o_iob);
+  j.item_lf = (const int*)(blob + o_ilf);
+  j.feat_item0 = (const int*)(blob + o_fi0);
   j.sigma_px_norm = b->sigma_px_norm;
   j.sigma_c = b->sigma_c;
   // current camera: R_GtoC = R_ItoC R_GtoI, p_CinG = p_IinG - R_GtoC^T p_IinC   (PlaneFitting.cpp:444-453)
@@ -1018,11 +1208,23 @@ extern "C" int ovp_plane_optimize(ovp_ctx* c, const ovp_planeopt_batch* b, doubl
   j.kept = (unsigned char*)(blob + o_kept);
   j.ok = (unsigned char*)(blob + o_ok);
   j.iterations = (int*)(blob + o_it);
-  int threads = ((std::max(nf_max, 1) + 63) / 64) * 64;
-  hipLaunchKernelGGL(ovp::k_plane_refine, dim3(P), dim3(threads), 0, s, j);
+  // (a full workgroup whatever the number of features: the threads beyond them take observations in the evaluations)
+  hipLaunchKernelGGL(ovp::k_plane_refine, dim3(P), dim3(256), 0, s, j);
   PF_HIPCHK(hipGetLastError());
   PF_HIPCHK(hipMemcpyAsync(hb + o_cpo, blob + o_cpo, off - o_cpo, hipMemcpyDeviceToHost, s));
   PF_HIPCHK(hipStreamSynchronize(s));
+#ifdef OVP_PF_STAMPS
+  {
+    long long h[64 * 12];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(ovp::g_pf_stamps), sizeof(h));
+    for (int pl = 0; pl < P && pl < 64; ++pl)
+      fprintf(stderr,
+              "refine plane %d: nf %lld items %lld iterations %lld | eval+J %lld  eval cost %lld  scale %lld  cauchy %lld  solve %lld (%lld "
+              "tries)  dogleg %lld  total %lld (clock ticks)\n",
+              pl, h[8 * pl + 4], h[8 * pl + 5], h[8 * pl + 3], h[8 * pl], h[8 * pl + 1], h[512 + 4 * pl], h[512 + 4 * pl + 1],
+              h[512 + 4 * pl + 2], h[8 * pl + 6], h[512 + 4 * pl + 3], h[8 * pl + 2]);
+  }
+#endif
   memcpy(cp_out, hb + o_cpo, sizeof(double) * 3 * (size_t)P);
   memcpy(p_out, hb + o_po, sizeof(double) * 3 * (size_t)F);
   memcpy(kept, hb + o_kept, (size_t)F);
