@@ -126,9 +126,244 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
   } while (0)
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the bordered factorization with B built block by block INSIDE the factorization - no per-feature scratch in device
+// memory (Bscr: 17 KB per feature written and read back by the same wave, 34 MB per launch at 2000 features).
+//
+// What made the scratch necessary was the LDS budget (20 KB per feature wave, two waves per SIMD): the operand rows [J | C | E]
+// of all 60 measurement rows (2040 doubles) and the packed factor (2112) do not fit side by side.  They do not have to:
+//   * the operand rows of a 16-row tile are only read as the COLUMN side of block jb = tile (row side = registers), i.e. they are
+//     dead once the block's 16 columns of B have been built;
+//   * of the factor, a later block reads only the tiles BELOW the diagonal tile of a finished block column (left-looking update of
+//     rows >= j0 with columns < j0); the diagonal tiles live and die in registers (k1_elim16), the corner is read from registers.
+// So the six sub-diagonal 16 x 16 tiles of L move into the space the operand rows free, at fixed addresses (doubles):
+//     rows of tile t   [544 t, 544 t + 544)      J 16x6 at +0, C 16x14 at +96, E 16x14 at +320   (tile 3: 12 rows packed as
+//                                                 J 12x6 at +0, C at +72, E at +240 - it ends at 2040)
+//     exchange tile    [2040, 2296)               256 doubles, XOR-swizzled (transposition of MFMA results, diagonal-tile
+//                                                 broadcast, border staging; P_cc in phase A2)
+//     L(1,0) 0   L(2,0) 256   L(3,0) 2296   |   L(2,1) 544   L(3,1) 800   |   L(3,2) 1088         (column-major 16 x 16)
+//     corner           [1056, 1072)               the 4 x 4 Schur corner, column by column as the blocks finish
+// L(rt,0) are written behind block 0's build (tile-0 rows dead; L(3,0) sits in the free tail), L(rt,1) behind block 1's, L(3,2)
+// behind block 2's; the corner words lie in tile 1's rows, which are dead - or were never written - when the first corner
+// column finishes (block n >> 4).  2552 of the 2560 doubles are spoken for at the worst moment.
+static constexpr int V3_ROWT = 544;
+static constexpr int V3_ST = 2040;
+static constexpr int V3_CORNER = 1056;
+__device__ __forceinline__ int v3_ltile(int rt, int ct) {
+  return ct == 0 ? (rt == 1 ? 0 : (rt == 2 ? 256 : 2296)) : (ct == 1 ? (rt == 2 ? 544 : 800) : 1088);
+}
+
+// Phases B + C of a bordered feature (n = 2m <= 60 rows + 4 border rows): returns the gate's sums (sums[0] = y^T y, [1..3] = Z^T y,
+// [4..9] = Z^T Z upper by rows) and spd.  jrow / crow / u: this lane's row of J, C and of E + C P_cc; the operand rows are in LDS.
+__device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P, const int ldp, const int lane, const int n, const int m,
+                                                    const bool valid, const int ida, const double (&jrow)[6], const double (&crow)[14],
+                                                    const double (&u)[14], const double res, const double (&hf)[3],
+                                                    double* const smem, bool& spd, double (&sums)[10]) {
+  const int r = lane & 1;
+  const int nb4 = n + 4;
+  const int nblk = (nb4 + 15) >> 4;
+  const int lr = lane >> 4, lc = lane & 15;
+  double* const sT = smem + V3_ST;
+  const int rowoff = 3 * r * ldp + ida;
+  // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads rows 3r..3r+2 (only the lanes
+  // of the lower triangle: the vector memory path's access rate bounds this phase).  ONE buffer: the next observation's block is
+  // requested as soon as this one's has been folded into t, and arrives behind the 68 FMAs of the LDS operands.
+  double pc[18];
+  auto fetch = [&](int b) {
+    const int idb = __builtin_amdgcn_readlane(ida, 2 * b);  // lane 2b holds clone_id of observation b
+    const double* src = P + (idb * ldp + rowoff);
+    if (lane >= 2 * b && valid) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 6; ++l) pc[6 * k + l] = src[k * ldp + l];
+    }
+  };
+  fetch(0);
+#pragma nounroll
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = __builtin_amdgcn_readfirstlane(16 * jb);
+    double ab[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) ab[t] = 0.0;  // upper triangle, corner columns, rows past the border
+    // ---- columns j0 .. j0+15 of B = H_x P H_x^T + I, this lane's row (observations 8 jb .. 8 jb + 7)
+    const double* const rows = smem + V3_ROWT * jb;
+    const int offC = jb == 3 ? 72 : 96, offE = jb == 3 ? 240 : 320;  // (tile 3 holds 12 rows)
+    static_for<8>([&](auto oc) {
+      constexpr int o = decltype(oc)::value;
+      const int b = 8 * jb + o;
+      if (b < m) {  // (wave-uniform)
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double ta = 0.0, tb = 0.0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) {
+            const double other = swap_pair_f64(pc[6 * k + l]);
+            ta = fma(jrow[l], pc[6 * k + l], ta);
+            tb = fma(jrow[l], other, tb);
+          }
+          t[k] = r ? tb : ta;
+          t[k + 3] = r ? ta : tb;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(t[k]));  // t complete before the buffer is refilled
+        if (b + 1 < m) fetch(b + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool own = valid && lane >= 2 * b;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int col = 2 * b + rr;
+          // the operand row in two portions (C, then J and E): all 17 broadcast reads in flight at once cost 68 registers, and this
+          // loop lives next to ab[16] and the covariance buffer; the SIMD's other wave covers the second round trip
+          double s0 = 0.0, s1 = 0.0;
+          {
+            const double2_t* pcv = reinterpret_cast<const double2_t*>(rows + offC + 14 * (2 * o + rr));
+            double2_t vc[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) vc[q] = pcv[q];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) s1 = fma(u[k], vc[k >> 1][k & 1], s1);
+          }
+          asm volatile("" : "+v"(s1));
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const double2_t* pj = reinterpret_cast<const double2_t*>(rows + 6 * (2 * o + rr));
+            const double2_t* pev = reinterpret_cast<const double2_t*>(rows + offE + 14 * (2 * o + rr));
+            double2_t vj[3], ve[7];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vj[q] = pj[q];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) ve[q] = pev[q];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s0 = fma(t[k], vj[k >> 1][k & 1], s0);
+#pragma unroll
+            for (int k = 0; k < 14; ++k) s0 = fma(crow[k], ve[k >> 1][k & 1], s0);
+          }
+          double bv = (s0 + s1) + (col == lane ? 1.0 : 0.0);
+          asm volatile("" : "+v"(bv));  // finish this column before the next one's broadcast reads are issued (registers)
+          __builtin_amdgcn_sched_barrier(0);
+          ab[2 * o + rr] = own ? bv : 0.0;
+        }
+      }
+    });
+    // ---- border rows n..n+3 of the block's columns: [r | H_f] of measurement row `col`, handed over through the exchange tile
+    if (j0 < n) {
+      if (valid && lr == jb) {
+        double2_t* d = reinterpret_cast<double2_t*>(sT + 4 * lc);
+        d[0] = double2_t{res, hf[0]};
+        d[1] = double2_t{hf[1], hf[2]};
+      }
+      OVP_WSYNC();
+      if (lane >= n && lane < nb4) {
+        const double* s = sT + (lane - n);
+        static_for<16>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if (j0 + t < n) ab[t] = s[4 * t];
+        });
+      }
+      OVP_WSYNC();
+    }
+    // ---- left-looking update of rows >= j0 with the finished columns 0..j0-1 (f64 MFMA over the sub-diagonal tiles)
+    if (jb > 0) {
+      double4_t acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = double4_t{0.0, 0.0, 0.0, 0.0};
+      const int kend = j0 < n ? j0 : n;  // only factor columns (< n) contribute, never the corner columns
+#pragma nounroll
+      for (int kk = 0; kk < kend; kk += 4) {
+        const int cb = kk >> 4;
+        const int off = (((kk & 15) + lr) << 4) + lc;  // column (kk & 15) + lr of the tile, row lc
+        const bool on = kk + lr < n;
+        const double bv = on ? smem[v3_ltile(jb, cb) + off] : 0.0;
+        double av[4];
+#pragma unroll
+        for (int rt = 1; rt < 4; ++rt) av[rt] = (rt > jb && rt < nblk && on) ? smem[v3_ltile(rt, cb) + off] : 0.0;
+#pragma unroll
+        for (int rt = 1; rt < 4; ++rt) {
+          if (rt == jb) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, bv, acc[rt], 0, 0, 0);
+          else if (rt > jb && rt < nblk) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv, acc[rt], 0, 0, 0);
+        }
+      }
+      // C layout (row lr + 4 v, column lc) -> row-per-lane through the exchange tile, one row tile at a time; element (i, j) of the
+      // tile sits at 16 i + (j ^ i): conflict-free both ways
+#pragma unroll
+      for (int rt = 1; rt < 4; ++rt) {
+        if (rt >= jb && rt < nblk) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) sT[((lr + 4 * v) << 4) + (lc ^ (lr + 4 * v))] = acc[rt][v];
+          OVP_WSYNC();
+          if (lr == rt) {
+            static_for<16>([&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              ab[t] -= sT[(lc << 4) + (t ^ lc)];
+            });
+          }
+          OVP_WSYNC();
+        }
+      }
+    }
+    // ---- factor the block's columns < n (the border rows take part like any other row, the corner columns are never pivots):
+    // the diagonal tile's rows go to every DPP row through the exchange tile, then one fused elimination
+    const int ncol = n - j0 < 16 ? (n - j0 > 0 ? n - j0 : 0) : 16;  // (wave-uniform)
+    if (ncol > 0) {
+      if (lr == jb) {
+        double2_t* dst = reinterpret_cast<double2_t*>(sT + (lc << 4));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q ^ (lc & 7)] = double2_t{ab[2 * q], ab[2 * q + 1]};
+      }
+      OVP_WSYNC();
+      double dd[16];
+      {
+        const double2_t* src = reinterpret_cast<const double2_t*>(sT + (lc << 4));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const double2_t v = src[q ^ (lc & 7)];
+          dd[2 * q] = v[0];
+          dd[2 * q + 1] = v[1];
+        }
+      }
+      k1_elim16(dd, ab, ncol, spd);
+      OVP_WSYNC();
+    }
+    // ---- publish: the block's tiles below the diagonal one (later blocks read nothing else), the corner columns' border rows
+    if (jb + 1 < nblk && lr > jb) {
+      double* const dst = smem + v3_ltile(lr, jb) + lc;
+      static_for<16>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        dst[16 * t] = ab[t];
+      });
+    }
+    if (j0 + 16 > n) {
+      static_for<16>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int q = j0 + t - n;  // (wave-uniform) corner column
+        if (q >= 0 && q < 4 && lane >= n && lane < nb4) smem[V3_CORNER + 4 * q + (lane - n)] = ab[t];
+      });
+    }
+    OVP_WSYNC();
+  }
+  {
+    auto corner = [&](int q, int qq) { return -smem[V3_CORNER + 4 * qq + q]; };  // q >= qq
+    sums[0] = corner(0, 0);
+    sums[1] = corner(1, 0);
+    sums[2] = corner(2, 0);
+    sums[3] = corner(3, 0);
+    sums[4] = corner(1, 1);
+    sums[5] = corner(2, 1);
+    sums[6] = corner(3, 1);
+    sums[7] = corner(2, 2);
+    sums[8] = corner(3, 2);
+    sums[9] = corner(3, 3);
+  }
+}
+
+
 // The work of one wave on feature f; smem = this wave's 20480 bytes of LDS.
-template <bool BORDERED>
+// LDSB (bordered only): B is built block by block inside the factorization (bordered_factor_lds) - nothing goes through Bscr.
+template <bool BORDERED, bool LDSB = false>
 __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, const int lane, double* const smem) {
+  static_assert(BORDERED || !LDSB, "the LDS-resident build exists for the bordered factorization only");
   const int m = p.n_meas[f];
   const int n = 2 * m;
 
@@ -136,7 +371,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   double* const sC = smem + NR * 6;        // [64][14]
   double* const sE = sC + NR * 14;         // [64][14]   (ends at 2176)
   double* const sL = smem;                 // [LCOLS] factor, valid from phase C on (aliases sJ/sC/sE)
-  double* const sY = smem + 2176;          // [64][4]
+  double* const sY = smem + (LDSB ? V3_ST : 2176);  // [64][4]   (LDSB: only P_cc of phase A2 lives here)
   double* const sB = sY + NR * 4;          // [2][64]
   static_assert(LCOLS <= 2176, "factor must fit in the [J|C|E] region");
   double* const Bg = p.Bscr + (size_t)f * LCOLS;  // B = H_x P H_x^T + I, packed like sL
@@ -219,12 +454,28 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
       // pin u here: otherwise the FMAs are sunk behind the barrier into phase B and all of P_cc stays live in registers
 #pragma unroll
       for (int k = 0; k < 14; ++k) asm volatile("" : "+v"(u[k]));
+      if constexpr (LDSB) {
+        // operand rows by 16-row tile (a tile dies with its block, see bordered_factor_lds); rows >= n have no storage
+        if (valid) {
+          double* const rt = smem + V3_ROWT * (lane >> 4);
+          const int rl = lane & 15;
+          const int offC = (lane >> 4) == 3 ? 72 : 96, offE = (lane >> 4) == 3 ? 240 : 320;  // (tile 3 holds 12 rows)
 #pragma unroll
-      for (int l = 0; l < 6; ++l) sJ[lane * 6 + l] = jrow[l];
+          for (int l = 0; l < 6; ++l) rt[6 * rl + l] = jrow[l];
 #pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        sC[lane * 14 + k] = crow[k];
-        sE[lane * 14 + k] = e[k];
+          for (int k = 0; k < 14; ++k) {
+            rt[offC + 14 * rl + k] = crow[k];
+            rt[offE + 14 * rl + k] = e[k];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < 6; ++l) sJ[lane * 6 + l] = jrow[l];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+          sC[lane * 14 + k] = crow[k];
+          sE[lane * 14 + k] = e[k];
+        }
       }
     }
     OVP_WSYNC();
@@ -233,7 +484,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
     // ----------------------------------------------------------------------------------------
     // Phase B: row `lane` of B = H_x P H_x^T + I, lower triangle, packed in LDS
     // ----------------------------------------------------------------------------------------
-    {
+    if constexpr (!LDSB) {
       // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads rows 3r..3r+2.
       // The block of observation b+1 is fetched while b is processed; the loop is unrolled by two over a pair of
       // buffers so that the prefetch needs no register copies.
@@ -327,7 +578,10 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
     // (an earlier fully unrolled 64-step version was instruction-fetch bound).
     bool spd = true;
     double sums[10];
-    if constexpr (BORDERED) {
+    if constexpr (LDSB) {
+      bordered_factor_lds(P, ldp, lane, n, m, valid, ida, jrow, crow, u, res, hf, smem, spd, sums);
+      OVP_STAMP(4);
+    } else if constexpr (BORDERED) {
       const int nb4 = n + 4;                      // rows of the bordered matrix
       const bool brow = lane < nb4;               // this lane holds one of them
       const int nblk = (nb4 + 15) >> 4;
@@ -697,11 +951,11 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   }
 }
 
-template <bool BORDERED>
+template <bool BORDERED, bool LDSB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_gate(const FeatParams p) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ __attribute__((aligned(16))) double smem[2560];
-  feat_body<BORDERED>(p, blockIdx.x, threadIdx.x, smem);
+  feat_body<BORDERED, LDSB>(p, blockIdx.x, threadIdx.x, smem);
 }
 
 // Fused launch: workgroup 0 factorizes P (chol(P) does not depend on the measurements, but its eight latency-bound waves
@@ -710,7 +964,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // CU either).  Every workgroup asks for all 160 KB of LDS, hence owns a CU: workgroup 0 has one to itself, the others run
 // eight feature waves (two per SIMD, 20 KB of LDS each) exactly as the one-wave blocks did.  Feature f is handled by wave
 // f / nwg of workgroup 1 + f % nwg, so small batches spread one wave per SIMD before they double up.
-template <int MAXSLOT>
+template <int MAXSLOT, bool LDSB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_chol(const FeatParams p,
                                                                                              const CholJob c) {
   __shared__ __attribute__((aligned(16))) double smem[8 * 2560];
@@ -724,17 +978,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int f = wave * nwg + (blockIdx.x - 1);
   if (f >= p.n_feats) return;
   __builtin_amdgcn_s_setprio(3);
-  feat_body<true>(p, f, threadIdx.x & 63, smem + wave * 2560);
+  feat_body<true, LDSB>(p, f, threadIdx.x & 63, smem + wave * 2560);
 }
 
 }  // namespace ovp
 
+// OVP_K1_BSCR=1: the bordered factorization with B through the per-feature scratch in device memory (rounds 1-4), for A/B runs
+static bool k1_through_scratch() { return getenv("OVP_K1_BSCR") != nullptr; }  // (read per call: the tests switch it)
+
 extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream) {
   if (p->n_feats <= 0) return hipSuccess;
-  if (p->max_meas <= 30 && !getenv("OVP_K1_LEGACY"))
-    hipLaunchKernelGGL(ovp::k_feat_gate<true>, dim3(p->n_feats), dim3(64), 0, stream, *p);
-  else
-    hipLaunchKernelGGL(ovp::k_feat_gate<false>, dim3(p->n_feats), dim3(64), 0, stream, *p);
+  if (p->max_meas <= 30 && !getenv("OVP_K1_LEGACY")) {
+    if (k1_through_scratch())
+      hipLaunchKernelGGL((ovp::k_feat_gate<true, false>), dim3(p->n_feats), dim3(64), 0, stream, *p);
+    else
+      hipLaunchKernelGGL((ovp::k_feat_gate<true, true>), dim3(p->n_feats), dim3(64), 0, stream, *p);
+  } else {
+    hipLaunchKernelGGL((ovp::k_feat_gate<false, false>), dim3(p->n_feats), dim3(64), 0, stream, *p);
+  }
   return hipGetLastError();
 }
 
@@ -759,11 +1020,20 @@ extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::
   const int nwg = F <= cus ? F : (F <= 8 * cus ? cus : (F + 7) / 8);
   const int nt = (c_in->n + 15) >> 4;
   const int slots = (nt * (nt + 1) / 2 + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
-  if (slots <= 15)
-    hipLaunchKernelGGL(ovp::k_feat_chol<15>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
-  else if (slots <= 18)
-    hipLaunchKernelGGL(ovp::k_feat_chol<18>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
-  else
-    hipLaunchKernelGGL(ovp::k_feat_chol<25>, dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+  if (k1_through_scratch()) {
+    if (slots <= 15)
+      hipLaunchKernelGGL((ovp::k_feat_chol<15, false>), dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+    else if (slots <= 18)
+      hipLaunchKernelGGL((ovp::k_feat_chol<18, false>), dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+    else
+      hipLaunchKernelGGL((ovp::k_feat_chol<25, false>), dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+  } else {
+    if (slots <= 15)
+      hipLaunchKernelGGL((ovp::k_feat_chol<15, true>), dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+    else if (slots <= 18)
+      hipLaunchKernelGGL((ovp::k_feat_chol<18, true>), dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+    else
+      hipLaunchKernelGGL((ovp::k_feat_chol<25, true>), dim3(nwg + 1), dim3(512), 0, stream, *p, *c);
+  }
   return hipGetLastError();
 }
