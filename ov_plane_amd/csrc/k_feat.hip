@@ -89,16 +89,6 @@ __device__ __forceinline__ void k1_elim16(double (&d)[16], double (&p)[16], cons
   });
 }
 
-// phase stamps (s_memtime) for the "cycles" debug read: compiled in only with -DOVP_K1_STAMPS (they cost 20 VGPRs)
-#ifdef OVP_K1_STAMPS
-#define OVP_STAMP_DECL long long tstamp[8]
-#define OVP_STAMP(i) tstamp[i] = __builtin_readcyclecounter()
-#define OVP_STAMP_ONLY(...) __VA_ARGS__
-#else
-#define OVP_STAMP_DECL
-#define OVP_STAMP(i)
-#define OVP_STAMP_ONLY(...)
-#endif
 
 // One wave per block.  LDS budget is exactly 160 KB / 8 = 20480 B per block so that 8 blocks (2 waves per SIMD) are
 // resident per CU and one feature's dependent chains (the Cholesky) overlap another's:
@@ -125,6 +115,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_wave_barrier();                         \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
   } while (0)
+
+// phase stamps (s_memtime) for the "cycles" debug read: compiled in only with -DOVP_K1_STAMPS (they cost 20 VGPRs)
+#ifdef OVP_K1_STAMPS
+#define OVP_STAMP_DECL long long tstamp[8]
+#define OVP_STAMP(i) tstamp[i] = __builtin_readcyclecounter()
+#define OVP_STAMP_ONLY(...) __VA_ARGS__
+#else
+#define OVP_STAMP_DECL
+#define OVP_STAMP(i)
+#define OVP_STAMP_ONLY(...)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Round 5: the bordered factorization with B built block by block INSIDE the factorization - no per-feature scratch in device
@@ -158,27 +159,40 @@ __device__ __forceinline__ int v3_ltile(int rt, int ct) {
 __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P, const int ldp, const int lane, const int n, const int m,
                                                     const bool valid, const int ida, const double (&jrow)[6], const double (&crow)[14],
                                                     const double (&u)[14], const double res, const double (&hf)[3],
-                                                    double* const smem, bool& spd, double (&sums)[10]) {
+                                                    double* const smem, bool& spd, double (&sums)[10], long long* const dbg2) {
   const int r = lane & 1;
+  OVP_STAMP_ONLY(long long t_build = 0, t_elim = 0;)
   const int nb4 = n + 4;
   const int nblk = (nb4 + 15) >> 4;
   const int lr = lane >> 4, lc = lane & 15;
   double* const sT = smem + V3_ST;
-  const int rowoff = 3 * r * ldp + ida;
-  // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads rows 3r..3r+2 (only the lanes
-  // of the lower triangle: the vector memory path's access rate bounds this phase).  ONE buffer: the next observation's block is
-  // requested as soon as this one's has been folded into t, and arrives behind the 68 FMAs of the LDS operands.
+  // the 6 x 6 block P[clone(b), clone(a)] is shared by the two lanes of observation a: lane r loads columns 3r..3r+2 of all six
+  // rows, so that the PAIR reads one 48-byte row segment per request - half the cache lines per vector-memory instruction of a
+  // split by rows (this phase is bound by the access rate of the vector L1, NOTES 5) - and only the lanes of the lower triangle
+  // ask.  ONE buffer: the next observation's block is requested as soon as this one's has been folded into t, and arrives behind
+  // the 68 FMAs of the LDS operands.
   double pc[18];
   auto fetch = [&](int b) {
     const int idb = __builtin_amdgcn_readlane(ida, 2 * b);  // lane 2b holds clone_id of observation b
-    const double* src = P + (idb * ldp + rowoff);
+    int coloff = ida + 3 * r;
+    asm volatile("" : "+v"(coloff));  // recomputed per request: kept across the loop it is the one value the allocator spills
+    const double* src = P + (idb * ldp + coloff);  // 32-bit element offsets: (idb + k) * ldp + ida + l < 2^31
     if (lane >= 2 * b && valid) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int l = 0; l < 6; ++l) pc[6 * k + l] = src[k * ldp + l];
+        for (int l = 0; l < 3; ++l) pc[3 * k + l] = src[k * ldp + l];
     }
   };
+  // t = P[clone(b), clone(a)] j^T: each lane folds ITS three columns into both rows of the pair (its own j and the partner's,
+  // fetched once) and the pair exchanges six partial sums - not eighteen covariance entries - per observation
+  double jown[3], jpar[3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const double lo = swap_pair_f64(jrow[l]), hi = swap_pair_f64(jrow[3 + l]);
+    jown[l] = r ? jrow[3 + l] : jrow[l];
+    jpar[l] = r ? hi : lo;
+  }
   fetch(0);
 #pragma nounroll
   for (int jb = 0; jb < nblk; ++jb) {
@@ -187,6 +201,7 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
 #pragma unroll
     for (int t = 0; t < 16; ++t) ab[t] = 0.0;  // upper triangle, corner columns, rows past the border
     // ---- columns j0 .. j0+15 of B = H_x P H_x^T + I, this lane's row (observations 8 jb .. 8 jb + 7)
+    OVP_STAMP_ONLY(const long long tq0 = __builtin_readcyclecounter();)
     const double* const rows = smem + V3_ROWT * jb;
     const int offC = jb == 3 ? 72 : 96, offE = jb == 3 ? 240 : 320;  // (tile 3 holds 12 rows)
     static_for<8>([&](auto oc) {
@@ -195,16 +210,14 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
       if (b < m) {  // (wave-uniform)
         double t[6];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          double ta = 0.0, tb = 0.0;
+        for (int k = 0; k < 6; ++k) {
+          double ta = 0.0, tp = 0.0;
 #pragma unroll
-          for (int l = 0; l < 6; ++l) {
-            const double other = swap_pair_f64(pc[6 * k + l]);
-            ta = fma(jrow[l], pc[6 * k + l], ta);
-            tb = fma(jrow[l], other, tb);
+          for (int l = 0; l < 3; ++l) {
+            ta = fma(jown[l], pc[3 * k + l], ta);
+            tp = fma(jpar[l], pc[3 * k + l], tp);
           }
-          t[k] = r ? tb : ta;
-          t[k + 3] = r ? ta : tb;
+          t[k] = ta + swap_pair_f64(tp);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(t[k]));  // t complete before the buffer is refilled
@@ -247,6 +260,7 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
         }
       }
     });
+    OVP_STAMP_ONLY(t_build += __builtin_readcyclecounter() - tq0;)
     // ---- border rows n..n+3 of the block's columns: [r | H_f] of measurement row `col`, handed over through the exchange tile
     if (j0 < n) {
       if (valid && lr == jb) {
@@ -287,16 +301,21 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
       }
       // C layout (row lr + 4 v, column lc) -> row-per-lane through the exchange tile, one row tile at a time; element (i, j) of the
       // tile sits at 16 i + (j ^ i): conflict-free both ways
+      // (the swizzled addresses are formed where they are used, from laundered lane coordinates: as loop invariants they would
+      // occupy 28 registers across the whole block loop)
 #pragma unroll
       for (int rt = 1; rt < 4; ++rt) {
         if (rt >= jb && rt < nblk) {
+          int lcv = lc, lrv = lr;
+          asm volatile("" : "+v"(lcv), "+v"(lrv));
 #pragma unroll
-          for (int v = 0; v < 4; ++v) sT[((lr + 4 * v) << 4) + (lc ^ (lr + 4 * v))] = acc[rt][v];
+          for (int v = 0; v < 4; ++v) sT[((lrv + 4 * v) << 4) + (lcv ^ (lrv + 4 * v))] = acc[rt][v];
           OVP_WSYNC();
           if (lr == rt) {
+            const int x = (lcv << 4) | lcv;  // (lc << 4) + (t ^ lc) == x ^ t
             static_for<16>([&](auto tc) {
               constexpr int t = decltype(tc)::value;
-              ab[t] -= sT[(lc << 4) + (t ^ lc)];
+              ab[t] -= sT[x ^ t];
             });
           }
           OVP_WSYNC();
@@ -306,19 +325,23 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
     // ---- factor the block's columns < n (the border rows take part like any other row, the corner columns are never pivots):
     // the diagonal tile's rows go to every DPP row through the exchange tile, then one fused elimination
     const int ncol = n - j0 < 16 ? (n - j0 > 0 ? n - j0 : 0) : 16;  // (wave-uniform)
+    OVP_STAMP_ONLY(const long long tq1 = __builtin_readcyclecounter();)
     if (ncol > 0) {
+      int lcv = lc;
+      asm volatile("" : "+v"(lcv));
+      const int xq = (lcv << 3) | (lcv & 7);  // 16-byte unit (lc << 3) + (q ^ (lc & 7)) == xq ^ q
       if (lr == jb) {
-        double2_t* dst = reinterpret_cast<double2_t*>(sT + (lc << 4));
+        double2_t* dst = reinterpret_cast<double2_t*>(sT);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dst[q ^ (lc & 7)] = double2_t{ab[2 * q], ab[2 * q + 1]};
+        for (int q = 0; q < 8; ++q) dst[xq ^ q] = double2_t{ab[2 * q], ab[2 * q + 1]};
       }
       OVP_WSYNC();
       double dd[16];
       {
-        const double2_t* src = reinterpret_cast<const double2_t*>(sT + (lc << 4));
+        const double2_t* src = reinterpret_cast<const double2_t*>(sT);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const double2_t v = src[q ^ (lc & 7)];
+          const double2_t v = src[xq ^ q];
           dd[2 * q] = v[0];
           dd[2 * q + 1] = v[1];
         }
@@ -326,6 +349,7 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
       k1_elim16(dd, ab, ncol, spd);
       OVP_WSYNC();
     }
+    OVP_STAMP_ONLY(t_elim += __builtin_readcyclecounter() - tq1;)
     // ---- publish: the block's tiles below the diagonal one (later blocks read nothing else), the corner columns' border rows
     if (jb + 1 < nblk && lr > jb) {
       double* const dst = smem + v3_ltile(lr, jb) + lc;
@@ -356,6 +380,10 @@ __device__ __forceinline__ void bordered_factor_lds(const double* __restrict__ P
     sums[8] = corner(3, 2);
     sums[9] = corner(3, 3);
   }
+  OVP_STAMP_ONLY(if (dbg2 && lane == 0) {
+    dbg2[0] = t_build;
+    dbg2[1] = t_elim;
+  })
 }
 
 
@@ -579,7 +607,9 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
     bool spd = true;
     double sums[10];
     if constexpr (LDSB) {
-      bordered_factor_lds(P, ldp, lane, n, m, valid, ida, jrow, crow, u, res, hf, smem, spd, sums);
+      bordered_factor_lds(P, ldp, lane, n, m, valid, ida, jrow, crow, u, res, hf, smem, spd, sums,
+                          p.dbg_cycles ? p.dbg_cycles + (size_t)p.n_feats * 8 + 2 * f : nullptr);
+      OVP_STAMP(3);
       OVP_STAMP(4);
     } else if constexpr (BORDERED) {
       const int nb4 = n + 4;                      // rows of the bordered matrix
