@@ -33,6 +33,14 @@ struct Chol2Job {
   double* xbuf;         // [split_h][nt][256] exported panel tiles (rows >= split_h), row-major
   unsigned* xflag;      // [nt] <- xseq when the panel of that step is exported
   unsigned xseq;
+  // mode 0, no border row: factorize the matrix in REVERSED index order and write the dense factor with its rows reversed back
+  // (Ldense = Lr, Lr Lr^T = A, columns in the reversed order - what CholJob::flip of the first-generation body produces, see
+  // ovp_kernels.h); the diagonal of the first boost_n state columns is read as (1 + boost_rel) x its value, the added amounts left
+  // in boost[0 .. boost_n)
+  int flip;
+  double* boost;
+  int boost_n;
+  double boost_rel;
 };
 
 // per-plane arguments of the plane loop's solve (modes 1 and 2)

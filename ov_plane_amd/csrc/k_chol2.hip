@@ -578,7 +578,12 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           const int r = 16 * i + lr + 4 * v;
           double pad = (r == c) ? 1.0 : 0.0;
           if (nb > n && r == n) pad = (c < n) ? brow_c : (c == n ? 1e300 : 0.0);
-          const double x = tile[s][v];
+          double x = tile[s][v];
+          if (J.flip && J.boost && r == c && r < n && r >= n - J.boost_n) {  // state column n - 1 - r < boost_n
+            const double add = x * J.boost_rel;
+            J.boost[n - 1 - r] = add;
+            x += add;
+          }
           tile[s][v] = (r < n && c < n) ? ((r == c && J.add_identity) ? x + 1.0 : x) : pad;
         }
       }
@@ -612,7 +617,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           for (int v = 0; v < 4; ++v) {
             const int r = 16 * i + lr + 4 * v;
             const int rc = r < n ? r : n - 1;
-            t[v] = Abase[(size_t)rc * J.ld + cc];
+            t[v] = J.flip ? Abase[(size_t)(n - 1 - rc) * J.ld + (n - 1 - cc)] : Abase[(size_t)rc * J.ld + cc];
           }
         }
         tile[s] = t;
@@ -1035,8 +1040,9 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
           for (int v = 0; v < 4; ++v) {
             const int rr = 16 * ti[s] + lr + 4 * v, cc = 16 * tj[s] + lc;
             if (rr < nb && cc < nb) {
-              J.Ldense[(size_t)rr * J.ldo + cc] = (cc <= rr) ? tile[s][v] : 0.0;
-              if (ti[s] != tj[s]) J.Ldense[(size_t)cc * J.ldo + rr] = 0.0;
+              const int ro = J.flip ? n - 1 - rr : rr, rz = J.flip ? n - 1 - cc : cc;  // (flip: no border row, nb == n)
+              J.Ldense[(size_t)ro * J.ldo + cc] = (cc <= rr) ? tile[s][v] : 0.0;
+              if (ti[s] != tj[s]) J.Ldense[(size_t)rz * J.ldo + rr] = 0.0;
             }
           }
         }

@@ -1036,6 +1036,9 @@ extern "C" int ovp_feat_chol_supported(const ovp::FeatParams* p, int n) {
   return !off && p->n_feats > 0 && p->max_meas <= 30 && nt <= OVP_TC_MAX_TILES;
 }
 
+// features the fused-shape launch takes in ONE round while leaving a CU per XCD to a kernel on another stream
+extern "C" int ovp_feat_chol_side_capacity(void) { return 247 * 8; }
+
 extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c_in, hipStream_t stream) {
   static const bool dbg_nochol = getenv("OVP_DBG_FUSED_NOCHOL") != nullptr;  // timing experiment only (results are wrong)
   ovp::CholJob cj = *c_in;
@@ -1046,7 +1049,11 @@ extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::
   if (dbg_nofeat) pf.n_feats = 1;
   p = &pf;
   const int F = p->n_feats;
-  const int cus = 255;  // feature workgroups of one round (256 CUs, one of them factorizes)
+  // feature workgroups of one round: 256 CUs, one of them factorizes.  Without a factorization in workgroup 0 (c_in->n == 0 while the
+  // caller runs chol(P) as a kernel of its own on a side stream, see ovp_feat_chol_side_capacity) the round is 247 workgroups:
+  // workgroups go to the eight XCDs in turn from an offset that changes between launches, so 248 of them leave every XCD a CU
+  // for the other kernel's workgroup wherever it lands - 255 leave one CU on one XCD, and the two launches run one after the other
+  const int cus = c_in->n == 0 && F <= ovp_feat_chol_side_capacity() ? 247 : 255;
   const int nwg = F <= cus ? F : (F <= 8 * cus ? cus : (F + 7) / 8);
   const int nt = (c_in->n + 15) >> 4;
   const int slots = (nt * (nt + 1) / 2 + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;

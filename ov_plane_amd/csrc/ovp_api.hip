@@ -1168,9 +1168,18 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // OVP_OVERLAP_MODE: 0 = no overlap, 1 = side stream beside K1, 2 = main stream after K1 with K2 beside it on the side
   // stream (the fallback when the fused kernel cannot take the batch), 3 (default) = fused.  (Also tried: chol(P) as its own
   // 160 KB-LDS launch on the side stream beside an 8-wave-workgroup K1 - the two launches did not overlap, K1 145 us.)
-  static const int overlap_env = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 3;
+  // Round 5, mode 4 (default up to 1976 features): the features keep the fused kernel's shape - eight feature waves per workgroup,
+  // each workgroup a CU of its own - but workgroup 0 factorizes nothing and returns at once; chol(P) runs as the second-generation
+  // kernel (k_chol2, mode 0, reversed order / diagonal boost as CholJob has them) on the side stream, on a CU the features leave
+  // free: 160 KB of LDS per feature workgroup keep the two off each other's SIMDs, and a round of 247 feature workgroups leaves a
+  // CU on EVERY XCD (ovp_launch_feat_chol) - with 255 the side kernel's workgroup finds no CU on the XCD it is sent to and the
+  // launches serialise (config 2, 2000 features: 316 against 274 us per update, measured), so above 1976 features mode 3 stays.
+  // Closed-loop session (11 clones, ~100 features): msckf update 0.276 -> 0.260 ms per frame.
+  static const int overlap_env = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 4;
   int overlap_mode = overlap_env;
-  if (overlap_mode == 3 && !(c->n <= OVP_TILECHOL_NMAX && ovp_feat_chol_supported(&fp, c->n))) overlap_mode = 2;
+  const bool fused_ok = c->n <= OVP_TILECHOL_NMAX && ovp_feat_chol_supported(&fp, c->n);
+  if (overlap_mode == 4 && !(fused_ok && c->n <= ovp_chol2_max_n() && F <= ovp_feat_chol_side_capacity())) overlap_mode = 3;
+  if (overlap_mode == 3 && !fused_ok) overlap_mode = 2;
   c->need_join = (overlap_mode == 1 || overlap_mode == 2);
   if (overlap_mode == 1) {
     HIPCHK(hipEventRecord(c->ev_fork, c->stream));
@@ -1185,7 +1194,7 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   c->use_kept_factor = false;
   c->point_nl = 0;
   c->point_boost_n = 0;
-  if (overlap_mode == 3) {
+  if (overlap_mode == 3 || overlap_mode == 4) {
     ovp::CholJob cj{c->P, c->L, nullptr, nullptr, c->n, c->ld, c->flags, 0, nullptr, 0, 0.0};
     if (c->have_factor && c->Lkeep) {  // the plane loop left M with M M^T = P: no chol(P) (cj.n = 0), the update runs on M
       cj.n = 0;
@@ -1214,6 +1223,27 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
           c->point_boost_n = s0;
         }
       }
+    }
+    if (overlap_mode == 4 && cj.n > 0) {
+      ovp::Chol2Job j;
+      memset(&j, 0, sizeof(j));
+      j.A = c->P;
+      j.n = c->n;
+      j.ld = c->ld;
+      j.mode = 0;
+      j.flag = c->flags;
+      j.Ldense = c->L;
+      j.ldo = c->ld;
+      j.flip = cj.flip;
+      j.boost = cj.boost;
+      j.boost_n = cj.boost_n;
+      j.boost_rel = cj.boost_rel;
+      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, c->stream2));
+      HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+      c->need_join = true;
+      cj.n = 0;
     }
     HIPCHK(ovp_launch_feat_chol(&fp, &cj, c->stream));
   } else {

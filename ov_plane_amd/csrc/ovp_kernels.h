@@ -111,6 +111,7 @@ struct ColMap {
 extern "C" {
 hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream);
 int ovp_feat_chol_supported(const ovp::FeatParams* p, int n);
+int ovp_feat_chol_side_capacity(void);
 hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c, hipStream_t stream);
 hipError_t ovp_launch_triangulate(const ovp::TriParams* p, hipStream_t stream);
 

@@ -30,6 +30,7 @@ def run(capi, sc, scratch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--time-feats", type=int, default=2000)
     args = ap.parse_args()
     from ov_plane_amd.build import build_lib
 
@@ -69,7 +70,7 @@ def main():
                 print("   m=%2d: %3d features, worst chi2 rel err new %.3e old %.3e, first chi2 new/ref %s / %s" %
                       (mm, sel.sum(), np.nanmax(e_new[sel]), np.nanmax(e_old[sel]), new["chi2"][sel][:2], ref["chi2"][sel][:2]))
     if args.time:
-        sc = make_scene(C=30, F=2000, seed=0, chi2_mult=1.0)
+        sc = make_scene(C=30, F=args.time_feats, seed=0, chi2_mult=1.0)
         for scratch in (True, False, True, False):
             if scratch:
                 os.environ["OVP_K1_BSCR"] = "1"
@@ -86,7 +87,7 @@ def main():
                 ctx.msckf_update(o)
                 ts.append(time.perf_counter() - t0)
             ctx.close()
-            print("config-2 update, %s: median %.1f us (min %.1f)" % ("B through scratch" if scratch else "B in LDS", 1e6 * np.median(ts[5:]), 1e6 * min(ts[5:])))
+            print("config-2 update (%d features), %s: median %.1f us (min %.1f)" % (sc.F, "B through scratch" if scratch else "B in LDS", 1e6 * np.median(ts[5:]), 1e6 * min(ts[5:])))
     return 1 if bad else 0
 
 
