@@ -31,7 +31,7 @@ sys.path.insert(0, _ROOT)
 
 import numpy as np  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r05_z_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/prof_round.sh, tools/pmc_summary.py)
+PMC_TRAFFIC_FILE = "r05_w_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/prof_round.sh, tools/pmc_summary.py)
 F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §6, NOTES.md §5
 WORKLOADS = {
     "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
@@ -677,9 +677,12 @@ def main():
             line["roofline_point_kernel"] = {
                 "bound": "mfma",
                 "kernel": "k_feat_chol (per-feature build + nullspace projection + chi2 gate of the point update; chol(P) rides "
-                          "on one CU of the same launch)",
+                          "on one CU of the same launch, or runs beside it as k_chol2 on a side stream up to 1976 features)",
                 "achieved": exe / ks / 1e12, "peak": F64_PEAK_TFLOPS, "peak_measured": 59.5, "unit": "TFLOP/s",
                 "frac": exe / ks / 1e12 / F64_PEAK_TFLOPS, "traffic": pmc_traffic("k_feat_chol", name, world)[0],
+                "traffic_note": "of which the kernel's OUTPUTS to K2: rec[C][F][2][21] %.1f MB + G[3F][ldg] %.1f MB (zeros for rejected / "
+                                "plane-consumed features included); B = H_x P H_x^T + I never leaves the CU since round 5" % (
+                                    C * sc.F * 2 * 21 * 8 / 1e6, 3 * sc.F * (((sc.N + 4 + 15) // 16) * 16) * 8 / 1e6),
                 "avg_launch_ms": k1_ms, "launches_timed": k1_n,
                 "features_gated_per_launch": n_pts_done, "features_walked_per_launch": per_launch,
                 "executed_flops_per_launch": exe, "reference_algorithm_flops_per_launch": alg,
