@@ -1175,8 +1175,8 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   // CU on EVERY XCD (ovp_launch_feat_chol) - with 255 the side kernel's workgroup finds no CU on the XCD it is sent to and the
   // launches serialise (config 2, 2000 features: 316 against 274 us per update, measured), so above 1976 features mode 3 stays.
   // Closed-loop session (11 clones, ~100 features): msckf update 0.276 -> 0.260 ms per frame.
-  static const int overlap_env = getenv("OVP_OVERLAP_MODE") ? atoi(getenv("OVP_OVERLAP_MODE")) : 4;
-  int overlap_mode = overlap_env;
+  const char* overlap_env = getenv("OVP_OVERLAP_MODE");  // (read per call: the tests switch it)
+  int overlap_mode = overlap_env ? atoi(overlap_env) : 4;
   const bool fused_ok = c->n <= OVP_TILECHOL_NMAX && ovp_feat_chol_supported(&fp, c->n);
   if (overlap_mode == 4 && !(fused_ok && c->n <= ovp_chol2_max_n() && F <= ovp_feat_chol_side_capacity())) overlap_mode = 3;
   if (overlap_mode == 3 && !fused_ok) overlap_mode = 2;

@@ -452,6 +452,74 @@ def test_positive_semidefinite_priors_are_updated_in_s_form(hiplib, oracle, case
     out["ctx"].close()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(C=30, F=300, seed=71, ragged=True, min_meas=2, chi2_mult=1.0),    # every track length 2..30: one to four 16-column blocks
+    dict(C=30, F=120, seed=72, chi2_mult=0.8),                               # full-length tracks (60 rows + border = 64), rejections
+    dict(C=15, F=90, seed=73, ragged=True, min_meas=2, chi2_mult=1.0),     # corner columns that straddle two blocks (n = 14, 30)
+    dict(C=8, F=60, seed=74, chi2_mult=1.0, calib=False),                    # no calibration columns
+])
+def test_k1_with_b_in_lds_and_through_the_scratch_agree(hiplib, oracle, monkeypatch, kw):
+    """Round 5: K1 builds B = H_x P H_x^T + I block by block inside the bordered factorization (operand rows and the factor's
+    sub-diagonal tiles share the wave's LDS); OVP_K1_BSCR=1 is the form of rounds 1-4 that sends B through a per-feature scratch in
+    device memory.  Same decisions, chi2 to 1e-8 of the oracle in both, and the two forms agree with each other to rounding."""
+    sc = make_scene(**kw)
+    assert len(set(np.asarray(sc.n_meas).tolist())) > (3 if kw.get("ragged") else 0)
+    ref = oracle.msckf_point_update(sc)
+    monkeypatch.delenv("OVP_K1_BSCR", raising=False)
+    new = run_gpu(hiplib, sc)
+    monkeypatch.setenv("OVP_K1_BSCR", "1")
+    old = run_gpu(hiplib, sc)
+    scale = np.maximum(1.0, np.abs(ref["chi2"]))
+    for out in (new, old):
+        assert (out["accepted"] == ref["accepted"]).all()
+        assert (np.abs(out["chi2"] - ref["chi2"]) / scale).max() <= 1e-8
+        assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX
+        assert relP(out["P"], ref["P"]) < TOL_P
+    assert (np.abs(new["chi2"] - old["chi2"]) / scale).max() <= 1e-10
+    assert np.abs(new["dx"] - old["dx"]).max() < 1e-9 and relP(new["P"], old["P"]) < 1e-8
+    new["ctx"].close()
+    old["ctx"].close()
+
+
+@pytest.mark.parametrize("case", ["regular", "stochastic_clone", "many_features"])
+def test_chol_p_on_the_side_stream_equals_the_fused_launch(hiplib, oracle, monkeypatch, case):
+    """Round 5: up to 1976 features chol(P) of the point update is a k_chol2 launch (mode 0 with the reversed order and the diagonal
+    boost of CholJob) on the side stream, beside feature workgroups that leave a CU on every XCD (OVP_OVERLAP_MODE=4, default);
+    mode 3 keeps the factorization in workgroup 0 of the fused launch.  Same update to rounding - including on the prior every frame
+    of a running filter sees (newest clone == IMU pose: exactly singular, factored through the boost) - and the oracle's answer."""
+    if case == "many_features":
+        sc = make_scene(C=12, F=1900, seed=76, ragged=True, min_meas=3, chi2_mult=1.0)  # a round of 247 workgroups, eight waves each
+    else:
+        sc = make_scene(C=9, F=80, seed=75, chi2_mult=1.0)
+    if case == "stochastic_clone":
+        b = sc.ids["clones"][-1]
+        idx = np.arange(sc.N)
+        idx[b:b + 6] = np.arange(0, 6)
+        sc["P"] = sc.P[np.ix_(idx, idx)]
+        assert np.linalg.eigvalsh(sc.P).min() < 1e-12 * np.linalg.eigvalsh(sc.P).max()
+    ref = oracle.msckf_point_update(sc) if case != "many_features" else None
+    outs = {}
+    for mode in ("4", "3"):
+        monkeypatch.setenv("OVP_OVERLAP_MODE", mode)
+        outs[mode] = run_gpu(hiplib, sc)
+        assert outs[mode]["rc"] == 0
+    a, b_ = outs["4"], outs["3"]
+    assert (a["accepted"] == b_["accepted"]).all() and a["accepted"].sum() > 10
+    assert np.abs(a["dx"] - b_["dx"]).max() < 1e-9
+    d = np.sqrt(np.abs(np.diag(b_["P"])))
+    d[d == 0] = 1.0
+    assert (np.abs(a["P"] - b_["P"]) / np.outer(d, d)).max() < 1e-8
+    assert np.abs(a["P"] - a["P"].T).max() == 0.0
+    if ref is not None:
+        assert (a["accepted"] == ref["accepted"]).all()
+        assert np.abs(a["dx"] - ref["dx"]).max() < TOL_DX
+        dr = np.sqrt(np.abs(np.diag(ref["P"])))
+        dr[dr == 0] = 1.0
+        assert (np.abs(a["P"] - ref["P"]) / np.outer(dr, dr)).max() < TOL_P
+    for o in outs.values():
+        o["ctx"].close()
+
+
 @pytest.mark.parametrize("case", ["exact_clone", "zero_variance", "stochastic_clone"])
 @pytest.mark.parametrize("big", [False, True])
 def test_plane_loop_on_a_positive_semidefinite_prior(hiplib, oracle, case, big):

@@ -36,5 +36,16 @@ for scratch in (False, True):
         print("   %-18s %8.0f %8.0f" % (nm, np.median(d[:, k]), d[:, k].max()))
     if not scratch:
         print("   inside the blocks: build %.0f, elimination %.0f (median)" % (np.median(ex[:, 0]), np.median(ex[:, 1])))
-    print("   launch span: %.0f cycles from the first wave's start to the last wave's end" % (st[:, 7].max() - st[:, 0].min()))
+    tot = (st[:, 7] - st[:, 0]).astype(float)
+    print("   total, percentiles 5/25/50/75/95/100: %s" % " ".join("%.0f" % np.percentile(tot, q) for q in (5, 25, 50, 75, 95, 100)))
+    nwg = sc.F if sc.F <= 255 else (255 if sc.F <= 8 * 255 else (sc.F + 7) // 8)
+    f = np.arange(sc.F)
+    wave, wg = f // nwg, f % nwg
+    print("   mean total by wave slot of the workgroup: %s" % " ".join("%.0f" % tot[wave == w].mean() for w in range(wave.max() + 1)))
+    print("   mean total by workgroup index mod 8 (XCD turn): %s" % " ".join("%.0f" % tot[wg % 8 == x].mean() for x in range(8)))
+    print("   mean start offset by wave slot (cycles after the earliest start of the same counter domain is not comparable across XCDs)")
+    for k, nm in enumerate(names):
+        dd = d[:, k].astype(float)
+        print("   %-18s p5 %7.0f p95 %7.0f  by wave slot: %s" % (nm, np.percentile(dd, 5), np.percentile(dd, 95),
+              " ".join("%.0f" % dd[wave == w].mean() for w in range(wave.max() + 1))))
     ctx.close()
