@@ -1243,27 +1243,63 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
     return;
   }
   {
-    const int half = tid & 1;
-    for (int row = tid >> 1; row < ((nfull + C2_WAVES * 32 - 1) / (C2_WAVES * 32)) * (C2_WAVES * 32); row += C2_WAVES * 32) {
-    double s = 0.0;
-    if (row < nfull) {
-      const int lastc = row < n ? row : n - 1;     // last column of the row's non-zeros that meets y
-      const int npair = (lastc + 2) >> 1;          // 16-byte pairs covering columns 0..lastc (ld is even, rows are 16-byte aligned)
-      const int p0 = half ? (npair >> 1) : 0, p1 = half ? npair : (npair >> 1);
-      const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(ps.L0 + (size_t)row * ps.ld0);
-      double s1 = 0.0;
-#pragma unroll 8
-      for (int q = p0; q < p1; ++q) {
-        const dbl2_t v = lrow[q];
-        const int c0 = 2 * q;
-        s = fma(v[0], S.ybuf[c0], s);
-        s1 = fma(c0 + 1 <= lastc ? v[1] : 0.0, c0 + 1 <= lastc ? S.ybuf[c0 + 1] : 0.0, s1);
+    // Round 5: wave w owns rows w, w + 12, ...; a row's non-zeros are read as 1 KB pieces (64 lanes x 16 bytes: eight cache lines per
+    // vector-memory instruction - the two-threads-per-row form this replaces touched 64 lines per instruction and was bound by the
+    // access rate of the CU's vector L1: 15.2 K cycles for 230 KB), every piece of a batch of rows in flight together, the lane's own
+    // pairs of y in registers, one transposed reduction per batch.  Batches by row length (rows < 120: one piece, < 252: two, < 288:
+    // three) so that the register arrays are static.
+    const int wv = tid >> 6, ln = tid & 63;
+    dbl2_t yp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c0 = 2 * (ln + 64 * k);
+      yp[k][0] = c0 < n ? S.ybuf[c0] : 0.0;
+      yp[k][1] = c0 + 1 < n ? S.ybuf[c0 + 1] : 0.0;
+    }
+    auto batch = [&](auto jlo_c, auto cnt_c, auto k_c) {
+      constexpr int JLO = decltype(jlo_c)::value, CNT = decltype(cnt_c)::value, K = decltype(k_c)::value;
+      constexpr int NP = CNT <= 2 ? 2 : (CNT <= 4 ? 4 : (CNT <= 8 ? 8 : 16));
+      if (12 * JLO >= nfull) return;  // (uniform: no row of this batch exists)
+      dbl2_t v[CNT][K];
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) {
+        const int row = wv + 12 * (JLO + j);
+        const int lastc = row < n ? row : n - 1;  // last column of the row's non-zeros that meets y
+        const int npair = (lastc + 2) >> 1;       // 16-byte pairs covering columns 0..lastc (ld is even, rows are 16-byte aligned)
+        const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(ps.L0 + (size_t)row * ps.ld0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int q = ln + 64 * k;
+          v[j][k] = (row < nfull && q < npair) ? lrow[q] : dbl2_t{0.0, 0.0};
+        }
       }
-      s += s1;
-    }
-    s += swap_pair_f64(s);
-    if (row < nfull && half == 0) dxs[row] = s;
-    }
+      double part[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) part[j] = 0.0;
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) {
+        const int row = wv + 12 * (JLO + j);
+        const int lastc = row < n ? row : n - 1;
+        double sa = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int c0 = 2 * (ln + 64 * k);
+          sa = fma(v[j][k][0], yp[k][0], sa);
+          sa = fma(c0 + 1 <= lastc ? v[j][k][1] : 0.0, yp[k][1], sa);
+        }
+        part[j] = sa;
+      }
+      const double tot = wave_transpose_reduce<NP>(part);  // lane L: the sum of part[L / (64 / NP)] over the wave
+      const int jo = ln / (64 / NP);
+      const int row = wv + 12 * (JLO + jo);
+      if ((ln % (64 / NP)) == 0 && jo < CNT && row < nfull) dxs[row] = tot;
+    };
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+    batch(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    batch(std::integral_constant<int, 10>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+    batch(std::integral_constant<int, 14>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+    batch(std::integral_constant<int, 18>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+    batch(std::integral_constant<int, 21>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
   }
   __syncthreads();
   M1_STAMP(3);
