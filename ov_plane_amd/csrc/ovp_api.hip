@@ -2162,12 +2162,32 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     for (int pl = 1; pl <= NP && !any_candidate; ++pl)
       any_candidate = cnt[pl] >= (pb->plane_state_id[pl - 1] >= 0 ? 1 : 4);
   }
+  // L0 = chol(P), dense lower triangular in c->L.  Nothing needs it before the first plane's W = A L0, so it runs on the side
+  // stream beside that plane's rows / Gram pair / assembly (round 5; one workgroup - the small kernels of the front end leave it a
+  // CU on every XCD) and is joined in front of that product.  OVP_PL_CHOL_SIDE=0: on the loop's own stream, in front of everything.
+  bool chol_forked = false;
   if (any_candidate) {
-    rc = chol_of_P(c, s);  // L0 = chol(P), dense lower triangular in c->L
-    if (rc) return rc;
+    const char* side_env = getenv("OVP_PL_CHOL_SIDE");  // (read per call: the tests switch it)
+    if (!(side_env && side_env[0] == '0') && s == c->stream) {
+      HIPCHK(hipEventRecord(c->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      rc = chol_of_P(c, c->stream2);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+      chol_forked = true;
+    } else {
+      rc = chol_of_P(c, s);
+      if (rc) return rc;
+    }
   }
+  auto join_chol = [&]() -> hipError_t {
+    if (!chol_forked) return hipSuccess;
+    chol_forked = false;
+    return hipStreamWaitEvent(s, c->ev_join, 0);
+  };
   // a refusal from here on: chol(P) has run - a flag it may have raised (singular prior) must not outlive the call
   auto bail = [&](int code) {
+    (void)join_chol();
     (void)hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s);
     return code;
   };
@@ -2265,7 +2285,10 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     jobs.push_back(j);
   }
   const int NJ = (int)jobs.size();
-  if (NJ == 0 && any_candidate) HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));  // chol(P)'s verdict concerns nobody
+  if (NJ == 0 && any_candidate) {  // chol(P)'s verdict concerns nobody
+    HIPCHK(join_chol());
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  }
   // ---- staging layout: ints [featlist | sid NP | perms NJ*n | slam_plane | slam_id], doubles [cp | cp_fej | slam_p | slam_p_fej] ----
   const size_t n_int = featlist.size() + (size_t)NP + perms.size() + 2 * (size_t)n_slam;
   const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
@@ -2372,6 +2395,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     pa.scal = c->pl_scal;
     HIPCHK(ovp_launch_plane_assemble2(&pa, s));
     // (4) W = A L0 ;  T_try = T_cur + L0^T W ;  c = L0^T b
+    HIPCHK(join_chol());  // (first plane: L0 comes from the side stream)
     HIPCHK(ovp_launch_gemm4(0, 0, nk, nk, nk, c->Ab, ld, c->L, ld, c->W1, ld, 0, 0, s));
     HIPCHK(ovp_launch_plane_dT(nk, c->L, ld, c->W1, c->Ab + (size_t)nk * ld, c->pl_Tbuf, tstride, c->pl_cur, c->pl_crow, s));
     // (5) both factorizations, gate, solve, commit

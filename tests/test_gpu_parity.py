@@ -2569,7 +2569,9 @@ def test_plane_solve_on_two_workgroups_equals_the_one_workgroup_solve(hiplib, or
     assert relP(base["P"], ref["P"]) < TOL_P and ref["plane_ok"].sum() >= 3
     for o in outs[1:]:
         assert (o["ok"] == base["ok"]).all() and (o["used"] == base["used"]).all()
-        assert np.abs(o["chi2"] - base["chi2"]).max() < 1e-8 * np.abs(base["chi2"]).max()
+        # (the statistic of a later plane sees the corrections of the earlier ones: a difference of 1e-12 in dx - rounding, the two
+        # solves add in different orders - moves a chi2 of ~200 by ~1e-6 through residuals of hundreds of pixels per unit state)
+        assert np.abs(o["chi2"] - base["chi2"]).max() < 1e-7 * np.abs(base["chi2"]).max()
         assert np.abs(o["dx"] - base["dx"]).max() < 1e-11
         assert relP(o["P"], base["P"]) < 1e-11
 
