@@ -814,6 +814,10 @@ class PreparedFrame:
         _chk(self._L.ovp_batch_upload(h, C.byref(self.fb)), "ovp_batch_upload")
         self.ctx.n_feats = self.F
 
+    def upload_state(self):
+        """ovp_state_upload alone (the pose / calibration tables: a plane loop commits its corrections to them)."""
+        _chk(self._L.ovp_state_upload(self.ctx._h, C.byref(self.st)), "ovp_state_upload")
+
     def plane_update(self):
         rc = self._L.ovp_msckf_plane_update(self.ctx._h, C.byref(self.opts_plane), C.byref(self.pb), self.pl_dx.ctypes.data,
                                             self.pl_ok.ctypes.data, self.pl_chi2.ctypes.data, self.pl_dof.ctypes.data, self.pl_used.ctypes.data)
