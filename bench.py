@@ -9,7 +9,8 @@ covariance and the pose tables are resident in HBM; every step starts from the s
 
   --gpus 1  (default): BASELINE.json configs[2] - 30 clones, 2000 features of which 1000 lie on 20 planes (10 of them state
              variables, N = 240).  This is the configuration the metric's target is quoted on; configs[1] (2000 point features,
-             0 planes) is reported beside it as `point_config`, configs[3] on one GPU as `config4_1gpu`.
+             0 planes) is reported beside it as `point_config`, configs[3] on one GPU as `config4_1gpu`, the headline frame with
+             its feature batch uploaded once outside the timed steps as `inputs_resident` (`value` itself carries the H2D).
   --gpus N>1: BASELINE.json configs[3] - 30 clones, 8000 features of which 2500 lie on 50 planes (N = 285), STRONG scaling: the
              plane loop is sequential across planes, so every rank runs it on the whole frame (identical replicas, no
              collective); the free points are sharded over the ranks, ONE RCCL all-reduce sums the information pairs, every
