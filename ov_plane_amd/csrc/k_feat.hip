@@ -394,6 +394,8 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   static_assert(BORDERED || !LDSB, "the LDS-resident build exists for the bordered factorization only");
   const int m = p.n_meas[f];
   const int n = 2 * m;
+  const int so = p.slot ? p.slot[f] : f;            // where this feature's rows go in rec / G (-1: nowhere, it is not part of the update)
+  const int nout = p.slot ? p.n_out : p.n_feats;
 
   double* const sJ = smem;                 // [64][6]
   double* const sC = smem + NR * 6;        // [64][14]
@@ -945,8 +947,8 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   }
   OVP_WSYNC();
   OVP_STAMP(6);
-  {
-    double* gout = p.G + (size_t)3 * f * ldg;
+  if (so >= 0) {
+    double* gout = p.G + (size_t)3 * so * ldg;
     for (int idx = lane; idx < 3 * ldg; idx += 64) gout[idx] = Gst[idx];
   }
 
@@ -957,7 +959,7 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
   if (accept) {
     seen = wave_or_u64(valid ? (1ull << ci) : 0ull);  // (a rolled loop over cidx[] was m dependent loads)
     if (valid) {
-      double* ro = p.rec + (((size_t)ci * p.n_feats + f) * 2 + r) * OVP_REC;
+      double* ro = p.rec + (((size_t)ci * nout + so) * 2 + r) * OVP_REC;  // (accepted: so >= 0)
 #pragma unroll
       for (int l = 0; l < 6; ++l) ro[l] = jrow[l];
 #pragma unroll
@@ -965,10 +967,12 @@ __device__ __forceinline__ void feat_body(const FeatParams& p, const int f, cons
       ro[20] = res;
     }
   }
-  for (int cc = 0; cc < p.n_clones; ++cc) {
-    if (!((seen >> cc) & 1ull)) {
-      double* ro = p.rec + (((size_t)cc * p.n_feats + f) * 2) * OVP_REC;
-      if (lane < 2 * OVP_REC) ro[lane] = 0.0;
+  if (so >= 0) {
+    for (int cc = 0; cc < p.n_clones; ++cc) {
+      if (!((seen >> cc) & 1ull)) {
+        double* ro = p.rec + (((size_t)cc * nout + so) * 2) * OVP_REC;
+        if (lane < 2 * OVP_REC) ro[lane] = 0.0;
+      }
     }
   }
   OVP_STAMP(7);

@@ -234,6 +234,8 @@ struct ovp_ctx {
   int range_lo = -1, range_hi = -1;   // ovp_batch_set_range (-1, -1 = whole batch)
   unsigned char* pl_used = nullptr;   // [f_max] features consumed by accepted planes (device)
   std::vector<unsigned char> h_pl_used;  // host copy of it behind the last plane loop (ovp_msckf_update_sharded splits the leftovers)
+  int* h_slot = nullptr;              // [f_max] host-mapped: row block of a feature in the compacted rec / G of a point update (-1: none)
+  int* d_slot = nullptr;              // its device address
   bool pl_used_valid = false;         // pl_used refers to the uploaded batch
   int pl2_cap = 0;
   // plane loop on a sub-state (n above the tile factorization's limit): accumulated pair, u rows, remapped id tables
@@ -469,6 +471,8 @@ extern "C" int ovp_ctx_create(int device, int n_state_max, int n_clones_max, int
   HIPCHK(hipHostMalloc((void**)&c->h_res_block, c->res_bytes + 64, hipHostMallocMapped));  // pinned mirror of res_block
   memset(c->h_res_block, 0, c->res_bytes + 64);
   HIPCHK(hipHostGetDevicePointer(&c->h_res_block_dev, c->h_res_block, 0));
+  HIPCHK(hipHostMalloc((void**)&c->h_slot, sizeof(int) * (size_t)(n_feats_max + 16), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&c->d_slot, c->h_slot, 0));
   c->h_seq = (volatile unsigned*)((char*)c->h_res_block + ((c->res_bytes + 15) & ~(size_t)15));
   c->h_flags = (int*)c->h_res_block;
   c->h_dx = (double*)((char*)c->h_res_block + 16);
@@ -498,6 +502,7 @@ extern "C" int ovp_ctx_destroy(ovp_ctx* c) {
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_res_block) hipHostFree(c->h_res_block);
+  if (c->h_slot) hipHostFree(c->h_slot);
   if (c->h_state_stage) hipHostFree(c->h_state_stage);
   if (c->h_batch_stage) hipHostFree(c->h_batch_stage);
   if (c->ev_state) hipEventDestroy(c->ev_state);
@@ -1136,6 +1141,8 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   fp.chi2 = (double*)((char*)c->h_res_block_dev + ((char*)c->chi2 - (char*)c->res_block));
   fp.accept = (unsigned char*)c->h_res_block_dev + ((char*)c->accept - (char*)c->res_block);
   fp.dbg_cycles = c->dbg_cycles;
+  fp.slot = nullptr;
+  fp.n_out = 0;
   fp.skip = nullptr;
   fp.range_lo = c->range_lo < 0 ? 0 : c->range_lo;
   fp.range_hi = c->range_lo < 0 ? 0x7fffffff : c->range_hi;
@@ -1148,6 +1155,23 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
 
 static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
   ovp::FeatParams& fp = c->fp;
+  // Round 5: the features that are not part of this update - consumed by an accepted plane (skip mask), outside this rank's index
+  // range - no longer occupy rows of rec / G (they used to write 16 KB of zeros each, which K2 then read): the host knows both sets,
+  // numbers the others in batch order and K1 reads its slot from host-mapped memory at the start of the feature wave; K2 runs on Fa
+  // features.  Same sums over the same rows in the same order, the chunks / splits of K2 group fewer of them (OVP_NO_COMPACT=1: off).
+  int Fa = F;
+  {
+    const bool ranged = c->range_lo >= 0;
+    const bool masked = fp.skip != nullptr && c->pl_used_valid && (int)c->h_pl_used.size() == F;
+    if ((ranged || masked) && F > 0 && !getenv("OVP_NO_COMPACT")) {
+      const int lo = ranged ? c->range_lo : 0, hi = ranged ? (c->range_hi < F ? c->range_hi : F) : F;
+      int k = 0;
+      for (int f = 0; f < F; ++f) c->h_slot[f] = (f >= lo && f < hi && !(masked && c->h_pl_used[f])) ? k++ : -1;
+      Fa = k;
+      fp.slot = c->d_slot;
+      fp.n_out = Fa;
+    }
+  }
   if (n > OVP_TILECHOL_NMAX) {  // the columns a point-feature batch can touch: clones, and calibration when it is estimated
     std::vector<int> ids;
     for (int cid : c->h_clone_id)
@@ -1271,18 +1295,18 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
       HIPCHK(hipEventRecord(c->ev_join, c->stream));
     }
   }
-  // K2
-  const int used_chunks = F > 0 ? (2 * F + c->rows_per_chunk - 1) / c->rows_per_chunk : 0;
-  if (F > 0) {
-    int nsplit = (3 * F + 511) / 512;
+  // K2 (on the Fa features that own rows of rec / G)
+  const int used_chunks = Fa > 0 ? (2 * Fa + c->rows_per_chunk - 1) / c->rows_per_chunk : 0;
+  if (Fa > 0) {
+    int nsplit = (3 * Fa + 511) / 512;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > c->n_split) nsplit = c->n_split;
     static const bool k2_split = getenv("OVP_K2_SPLIT") != nullptr;  // first version: two VALU / narrow-tile launches
     if (k2_split) {
-      HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, s2k));
-      HIPCHK(ovp_launch_syrk(c->G, 3 * F, c->ldg, n + 1, nsplit, c->part, s2k));
+      HIPCHK(ovp_launch_struct_gram(c->rec, fp.n_clones, Fa, c->rows_per_chunk, used_chunks, c->gramS, s2k));
+      HIPCHK(ovp_launch_syrk(c->G, 3 * Fa, c->ldg, n + 1, nsplit, c->part, s2k));
     } else {
-      HIPCHK(ovp_launch_gram_pair(c->rec, fp.n_clones, F, c->rows_per_chunk, used_chunks, c->gramS, c->G, 3 * F, c->ldg,
+      HIPCHK(ovp_launch_gram_pair(c->rec, fp.n_clones, Fa, c->rows_per_chunk, used_chunks, c->gramS, c->G, 3 * Fa, c->ldg,
                                   n + 1, c->n_split, c->part, &nsplit, s2k));
     }
     HIPCHK(ovp_launch_reduce_gram(c->gramS, fp.n_clones, used_chunks, c->gramR, s2k));
@@ -2090,6 +2114,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (rc1) return rc1;
     if (F) HIPCHK(hipMemcpy(c->pl_used, used_h.data(), (size_t)F, hipMemcpyHostToDevice));
     if (feat_used && F) memcpy(feat_used, used_h.data(), (size_t)F);
+    c->h_pl_used.assign(used_h.begin(), used_h.begin() + F);
     c->pl_used_valid = true;
     return 0;
   }
@@ -2102,6 +2127,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   if (dx_planes && NP > 0) memset(dx_planes, 0, sizeof(double) * (size_t)n * NP);
   if (NP == 0) {  // a frame without planes: nothing is consumed, and a point update with skip_plane_used may follow
     if (F) HIPCHK(hipMemsetAsync(c->pl_used, 0, (size_t)F, c->stream));
+    c->h_pl_used.assign((size_t)F, 0);
     c->pl_used_valid = true;
     return 0;
   }

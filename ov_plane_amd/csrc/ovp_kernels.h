@@ -66,6 +66,11 @@ struct FeatParams {
   const unsigned char* skip;  // optional [n_feats]: 1 = feature was consumed by an accepted plane (not part of this update)
   int range_lo, range_hi;     // features outside [range_lo, range_hi) are not part of this update (another rank's shard)
   long long* dbg_cycles;  // optional [n_feats][8] phase stamps (diagnostics)
+  // compacted outputs (round 5): slot[f] = row block of feature f in rec / G, or -1 = the feature is not part of this update (consumed
+  // by a plane, another rank's share) and writes nothing; rec is then [n_clones][n_out][2][OVP_REC], G [3 n_out][ldg].  NULL: slot = f,
+  // n_out = n_feats.  The array may live in host-mapped memory (read once per feature wave, long before it is needed).
+  const int* slot;
+  int n_out;
 };
 
 // arguments of the triangulation kernel (ext FeatureInitializerOptions + the feature batch + the clone tables)
