@@ -32,7 +32,7 @@ sys.path.insert(0, _ROOT)
 
 import numpy as np  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r05_x_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/prof_round.sh, tools/pmc_summary.py)
+PMC_TRAFFIC_FILE = "r05_y_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/prof_round.sh, tools/pmc_summary.py)
 F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §6, NOTES.md §5
 WORKLOADS = {
     "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
