@@ -10,7 +10,9 @@
  *     with an explicit leading dimension;
  *   - `id` always means Type::id() = column offset of a variable in State::_Cov;
  *   - every function returns 0 on success, a positive hipError_t, or a negative OVP_E_* code;
- *   - one context per filter, not thread-safe (matches the reference: at most one update in flight);
+ *   - one context per filter, not thread-safe (matches the reference: at most one update in flight - the staged entry points keep
+ *     per-update words in host-mapped memory that the kernels read, e.g. the output slots of the features of a point update, so
+ *     ovp_msckf_fetch_results must have returned before the next update of the same context is enqueued);
  *   - work is enqueued on the context's stream; functions that return results to host memory
  *     synchronise that stream unless their name ends in _async (then call ovp_sync()).
  */
