@@ -92,8 +92,115 @@ def describe(name, sc):
     w = WORKLOADS[name]
     if w["n_planes"]:
         return "%d clones, %d feats of which %d on %d planes (%d of them in the state), calib on (N=%d)" % (
-            w["C"], w["F"], w["n_planes"] * w["feats_per_plane"], w["n_planes"], int((np.asarray(sc.plane_state_id) >= 0).sum()), sc.N)
-    return "%d clones, %d MSCKF point feats, 0 planes, calib on (N=%d)" % (w["C"], w["F"], sc.N)
+            sc.C, sc.F, int((np.asarray(sc.plane_id) > 0).sum()), int(sc.cp.shape[0]), int((np.asarray(sc.plane_state_id) >= 0).sum()), sc.N)
+    return "%d clones, %d MSCKF point feats, 0 planes, calib on (N=%d)" % (sc.C, sc.F, sc.N)
+
+
+class HipBackend:
+    """What bench.py's rank code path needs from the machine: the product backend (one MI355X per rank, RCCL).  The path itself -
+    launcher, process group, communicator id exchange, collective settle decision, timed windows, max over ranks, rank-0-only JSON
+    line - is written against this object so that tests/test_bench_rank_path_cpu.py can run THE SAME main() on two gloo ranks
+    with a stand-in (tests/bench_standin.py, test infrastructure built on the oracle; selected with --standin, never the default,
+    and a line produced that way says so in `data` and carries no `value`)."""
+
+    name = "hip"
+    dist_backend = "nccl"
+    data = "synthetic"
+
+    def __init__(self, torch):
+        self.torch = torch
+        from ov_plane_amd import capi
+
+        self.capi = capi
+
+    def available(self):
+        return self.torch.cuda.is_available()
+
+    def set_device(self, local_rank):
+        self.torch.cuda.set_device(local_rank)
+
+    @property
+    def device(self):
+        return "cuda"
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def stream_ctx(self, run):
+        return self.torch.cuda.stream(run.stream)
+
+    def make_workload(self, name):
+        return make_workload(name)
+
+    def make_runner(self, sc, local_rank):
+        return StepRunner(self.capi, self.torch, sc, local_rank)
+
+    # communicator of the C entry ovp_msckf_update_sharded (the library's own RCCL binding)
+    def unique_id(self):
+        return self.capi.rccl_unique_id()
+
+    def comm_preflight(self, local_rank):
+        """Raises when this rank could not enter ncclCommInitRank: binds RCCL (dlopen inside ovp_rccl_unique_id; the id is dropped)
+        and touches the device."""
+        self.capi.rccl_unique_id()
+        self.torch.zeros(1, device="cuda:%d" % local_rank)
+
+    def comm_create(self, uid, rank, world, local_rank):
+        return self.capi.rccl_comm_create(uid, rank, world, local_rank)
+
+    def comm_destroy(self, comm):
+        self.capi.rccl_comm_destroy(comm)
+
+
+def load_backend(torch, standin):
+    if not standin:
+        return HipBackend(torch)
+    import importlib
+
+    return importlib.import_module(standin).make_backend(torch, sys.modules[__name__])
+
+
+def create_native_comm(be, dist, rank, world, local_rank):
+    """Communicator for the C entry, created so that a failure on ANY rank cannot leave the others inside ncclCommInitRank: rank 0
+    draws the id (or fails) and broadcasts id-or-None - everybody sees the same thing and skips together; the collective
+    ncclCommInitRank is entered by all ranks or by none; afterwards a MIN over the ranks decides whether all of them got one.
+    Returns (comm or None, reason when None)."""
+    torch = be.torch
+    uid, why = [None], [None]
+    if rank == 0:
+        try:
+            uid[0] = be.unique_id()
+        except Exception as e:  # noqa: BLE001
+            why[0] = "ncclGetUniqueId on rank 0: %r" % (e,)
+    box = [uid[0], why[0]]
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return None, box[1]
+    # everything a rank can fail at BEFORE it would enter the collective ncclCommInitRank (RCCL not loadable, device not usable)
+    # is probed and agreed on first: a rank that cannot go in must keep the others out
+    comm, err = None, None
+    try:
+        be.comm_preflight(local_rank)
+    except Exception as e:  # noqa: BLE001
+        err = "preflight on rank %d: %r" % (rank, e)
+    ready = torch.tensor([0 if err else 1], dtype=torch.int32, device=be.device)
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+    if not bool(ready.item()):
+        return None, err or "another rank is not able to create a communicator"
+    try:
+        comm = be.comm_create(box[0], rank, world, local_rank)
+    except Exception as e:  # noqa: BLE001
+        err = "ncclCommInitRank on rank %d: %r" % (rank, e)
+    ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device=be.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if bool(ok.item()):
+        return comm, None
+    if comm:
+        try:
+            be.comm_destroy(comm)
+        except Exception:  # noqa: BLE001
+            pass
+    return None, err or "another rank could not create its communicator"
 
 
 class StepRunner:
@@ -246,7 +353,7 @@ def run_block(fn, steps):
     return ts, out
 
 
-def settle(torch, fn, dist=None):
+def settle(be, fn, dist=None):
     """Untimed steps until the step time has settled: blocks of PREWARM_BLOCK steps until the medians of two consecutive blocks
     agree to 2 %, at least PREWARM_MIN_STEPS, at most PREWARM_MAX_S seconds.  With several ranks the decision to go on is taken
     collectively (every step holds a collective: all ranks must take the same number)."""
@@ -259,7 +366,7 @@ def settle(torch, fn, dist=None):
         settled = prev is not None and abs(med - prev) <= 0.02 * prev and n_done >= PREWARM_MIN_STEPS
         go_on = (not settled) and (time.perf_counter() - t0 < PREWARM_MAX_S)
         if dist is not None:
-            flag = torch.tensor([1 if go_on else 0], dtype=torch.int32, device="cuda")
+            flag = be.torch.tensor([1 if go_on else 0], dtype=be.torch.int32, device=be.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             go_on = bool(flag.item())
         if not go_on:
@@ -267,18 +374,18 @@ def settle(torch, fn, dist=None):
         prev = med
 
 
-def time_steps(torch, fn, steps, warmup, barrier=None):
+def time_steps(be, fn, steps, warmup, barrier=None):
     """`warmup` untimed steps, then EXACTLY `steps` timed ones between barrier + synchronize on both sides.
     Returns (elapsed seconds, last output, per-step seconds)."""
     out = None
     for _ in range(warmup):
         out = fn()
-    torch.cuda.synchronize()
+    be.synchronize()
     if barrier:
         barrier()
     t0 = time.perf_counter()
     ts, out2 = run_block(fn, steps)
-    torch.cuda.synchronize()
+    be.synchronize()
     if barrier:
         barrier()
     return time.perf_counter() - t0, (out2 if steps else out), ts
@@ -459,6 +566,11 @@ def main():
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="multi-GPU step: native = the C entry ovp_msckf_update_sharded on an RCCL communicator of the library's own "
                          "binding (default); torch = ov_plane_amd.dist over torch.distributed (the gloo-tested reference of the split)")
+    ap.add_argument("--standin", default="", metavar="MODULE",
+                    help="TEST HARNESS ONLY (tests/test_bench_rank_path_cpu.py): run this file's rank code path - launcher, process "
+                         "group, communicator id exchange, collective settle decision, max over ranks, rank-0 JSON - on a machine "
+                         "without a GPU, with MODULE.make_backend() in place of the HIP backend.  The line then says so in `data` "
+                         "and carries value = null: nothing measured that way is a result")
     ap.add_argument("--sharded-path", action="store_true",
                     help="with --gpus 1: take the multi-GPU code path (process group of one rank, dist.sharded_* functions, RCCL "
                          "all-reduce, stage timing) - a smoke test of it on a one-GPU box")
@@ -469,16 +581,16 @@ def main():
         reexec_under_torchrun(args.gpus)  # does not return
     import torch
 
-    from ov_plane_amd import capi
-
+    be = load_backend(torch, args.standin)
+    capi = getattr(be, "capi", None)
     world = max(world_env, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if not be.available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    be.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.sharded_path
     real_stdout = None
@@ -492,33 +604,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29571")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=be.dist_backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     # the product path of a multi-GPU step is the C entry (ovp_msckf_update_sharded) on a communicator created through the library's
     # own RCCL binding; torch.distributed only carries the 128-byte id to the ranks.  --collective torch (or a failure to create the
-    # communicator, reported in the line) takes ov_plane_amd.dist instead
-    native_comm, collective = None, "none"
+    # communicator on any rank, agreed on collectively and reported in the line) takes ov_plane_amd.dist instead
+    native_comm, collective, comm_note = None, "none", None
     if sharded:
         collective = "torch.distributed"
         if args.collective == "native":
-            try:
-                uid = [capi.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                native_comm = capi.rccl_comm_create(uid[0], rank, world, local_rank)
+            native_comm, comm_note = create_native_comm(be, dist, rank, world, local_rank)
+            if native_comm:
                 collective = "rccl-native (ovp_msckf_update_sharded)"
-            except Exception as e:  # noqa: BLE001
-                print("native RCCL communicator not created (%r): falling back to torch.distributed" % (e,), file=sys.stderr)
-                native_comm = None
-            ok = torch.tensor([1 if native_comm else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if not bool(ok.item()):
-                native_comm, collective = None, "torch.distributed"
+            else:
+                print("native RCCL communicator not created (%s): falling back to torch.distributed" % comm_note, file=sys.stderr)
     name = args.workload if args.workload != "auto" else ("config4" if sharded else "config3")
-    sc = make_workload(name)
-    run = StepRunner(capi, torch, sc, local_rank)
+    sc = be.make_workload(name)
+    run = be.make_runner(sc, local_rank)
     barrier = (lambda: dist.barrier()) if sharded else None
-
-    with torch.cuda.stream(run.stream):
+    with be.stream_ctx(run):
         if sharded:
             sharded_step = (lambda r, timing=None: r.step_sharded_native(native_comm, rank, world, timing)) if native_comm else \
                            (lambda r, timing=None: r.step_sharded(rank, world, timing))
@@ -529,19 +633,19 @@ def main():
 
         gcw = GcWatch()
         gc.callbacks.append(gcw)
-        n_prewarm, prewarm_blocks = settle(torch, fn, dist if sharded else None)
+        n_prewarm, prewarm_blocks = settle(be, fn, dist if sharded else None)
         gc_prewarm = gcw.take()
         if args.python_gc == "off":
             gc.collect()
             gc.disable()
             gcw.take()  # (the collection just asked for)
         run.ctx.host_timing(reset=True)
-        elapsed, last, per_step = time_steps(torch, fn, args.steps, args.warmup, barrier)
-        pl, pt = last.results() if isinstance(last, StepRunner) else last
+        elapsed, last, per_step = time_steps(be, fn, args.steps, args.warmup, barrier)
+        pl, pt = last.results() if hasattr(last, "results") else last
         host_acc = run.ctx.host_timing(reset=True)
         gc_w1 = gcw.take()
         # a second window of the same length right behind the first (reported beside it, never `value`)
-        elapsed2, _, per_step2 = time_steps(torch, fn, args.steps, 0, barrier)
+        elapsed2, _, per_step2 = time_steps(be, fn, args.steps, 0, barrier)
         gc_w2 = gcw.take()
         gc.enable()
         gc.callbacks.remove(gcw)
@@ -549,7 +653,7 @@ def main():
         # microseconds each, they must not sit in the timed region above)
         run.ctx.kernel_timer(enable=True, reset=True)
         run.ctx.plane_kernel_timer(enable=1, reset=True)
-        time_steps(torch, fn, max(5, min(args.steps, 20)), 0, barrier)
+        time_steps(be, fn, max(5, min(args.steps, 20)), 0, barrier)
         k1_ms, k1_n = run.ctx.kernel_timer(enable=False, reset=False)
         c2_ms, c2_n = run.ctx.plane_kernel_timer(enable=0, reset=False)
         # device clock of the two halves of a step (a pass of its own: one event pair around the plane loop, K1 start .. last
@@ -582,14 +686,14 @@ def main():
     point_only = None
     if sharded and name != "config2":
         # the part of the path that shards, on the same ranks: BASELINE config 2's shape (2000 point features, no planes) strong-scaled
-        sc2 = make_workload("config2")
-        r2 = StepRunner(capi, torch, sc2, local_rank)
-        with torch.cuda.stream(r2.stream):
+        sc2 = be.make_workload("config2")
+        r2 = be.make_runner(sc2, local_rank)
+        with be.stream_ctx(r2):
             blocks = []
             for blk in range(5):
-                el_b, _, _ = time_steps(torch, lambda: sharded_step(r2), 10, 3 if blk == 0 else 0, barrier)
+                el_b, _, _ = time_steps(be, lambda: sharded_step(r2), 10, 3 if blk == 0 else 0, barrier)
                 blocks.append(el_b / 10)
-        tb = torch.tensor(blocks, dtype=torch.float64, device="cuda")
+        tb = torch.tensor(blocks, dtype=torch.float64, device=be.device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         med = float(sorted(tb.tolist())[2])
         point_only = {"workload": describe("config2", sc2), "ms_per_step": 1e3 * med, "features_per_s": sc2.F / med,
@@ -597,7 +701,7 @@ def main():
                       "timing": "median of 5 blocks of 10 steps, max over ranks per block"}
         r2.close()
     if sharded:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -608,7 +712,7 @@ def main():
         n_pts_done = int(run.shard_size) if sharded else int((~pl["used"]).sum()) if pl is not None else sc.F
         line = {
             "metric": "MSCKF+plane update-step features/sec at %d clones" % C,
-            "value": value,
+            "value": value if be.name == "hip" else None,
             "unit": "features/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -619,7 +723,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": be.data,
             "config": {"workload": describe(name, sc), "baseline_config": name, "clones": C, "feats": int(sc.F),
                        "state_dim": int(sc.N), "planes": int(sc.cp.shape[0]),
                        "planes_accepted": int(pl["ok"].sum()) if pl is not None else 0,
@@ -708,23 +812,25 @@ def main():
             tot_st = sum(stages.values()) or 1.0
             line["multi_gpu"] = {
                 "rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(), "collective": collective,
+                "collective_note": comm_note,
                 "rank0_stage_ms": stages,
                 "serial_fraction": stages.get("plane_loop_ms", 0.0) / tot_st,
                 "serial_fraction_note": "plane loop (replicated on every rank, sequential across planes: update/UpdaterMSCKF.cpp:413-649) / "
                                         "sum of rank 0's stages; Amdahl bound of the step at this rank count = 1 / (s + (1 - s) / N)",
                 "amdahl_bound_speedup": 1.0 / (stages.get("plane_loop_ms", 0.0) / tot_st + (1.0 - stages.get("plane_loop_ms", 0.0) / tot_st) / world),
+                "amdahl_bound_speedup_at_8_ranks": 1.0 / (stages.get("plane_loop_ms", 0.0) / tot_st + (1.0 - stages.get("plane_loop_ms", 0.0) / tot_st) / 8.0),
                 "point_only_scaling": point_only,
                 "rank0_point_shard": int(run.shard_size),
                 "note": "stage times of rank 0 from a separate pass with a host synchronisation behind every stage (plane loop "
                         "replicated on every rank; points_build = feature kernel + information pair of the rank's shard; "
                         "allreduce = one RCCL all-reduce of (N+1) x ld f64; update = EKF update from the summed pair + results)"}
         if not sharded and not args.no_extras:
-            extras(line, capi, torch, args, local_rank, name)
+            extras(line, be, capi, torch, args, local_rank, name)
         if not sharded and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"], ora = cpu_baseline(sc, name, args.cpu_sample_feats if args.cpu_sample_feats > 0 else None)
                 line["speedup_vs_cpu_baseline"] = line["cpu_baseline"]["ms_per_step"] / ms_per_step
-                with torch.cuda.stream(run.stream):
+                with be.stream_ctx(run):
                     line["parity_on_timed_frame"] = accept_set_report(run, sc, pl, pt, ora)
             except Exception as e:  # noqa: BLE001
                 line.setdefault("cpu_baseline", None)
@@ -734,7 +840,7 @@ def main():
         out_line = None
     run.close()
     if native_comm:
-        capi.rccl_comm_destroy(native_comm)
+        be.comm_destroy(native_comm)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
@@ -746,7 +852,7 @@ def main():
             print(out_line)
 
 
-def extras(line, capi, torch, args, device, headline):
+def extras(line, be, capi, torch, args, device, headline):
     """Side figures, measured after the timed region, never `value`."""
     # the headline frame with its feature batch resident in HBM before the timed region starts (the headline's step carries the H2D of
     # the batch - the boundary hands over host buffers, so `value` is the PCIe-inclusive rate, the stricter of the two)
@@ -757,7 +863,7 @@ def extras(line, capi, torch, args, device, headline):
             r.step()  # uploads the batch
             els = []
             for blk in range(5):
-                el_b, last, _ = time_steps(torch, r.step_resident, 10, 3 if blk == 0 else 0)
+                el_b, last, _ = time_steps(be, r.step_resident, 10, 3 if blk == 0 else 0)
                 els.append(el_b / 10)
             pl, pt = last.results()
             el = sorted(els)[2]
@@ -782,7 +888,7 @@ def extras(line, capi, torch, args, device, headline):
                 # figure would otherwise be its whole value
                 els = []
                 for blk in range(5):
-                    el_b, last, _ = time_steps(torch, r.step, 10, 3 if blk == 0 else 0)
+                    el_b, last, _ = time_steps(be, r.step, 10, 3 if blk == 0 else 0)
                     pl, pt = last.results()
                     els.append(el_b / 10)
                 el = 20 * sorted(els)[2]

@@ -35,7 +35,8 @@ enum {
   OVP_E_NODEVICE = -5,  /* no HIP device / wrong architecture */
   OVP_E_STATE = -6,     /* call order violated (e.g. update before upload) */
   OVP_E_TIMEOUT = -7,   /* a device-side hand-over between the two workgroups of the plane solve did not arrive (bounded spin) */
-  OVP_E_RCCL = -8       /* librccl could not be loaded, or an RCCL call failed (message on stderr) */
+  OVP_E_RCCL = -8,      /* librccl could not be loaded, or an RCCL call failed (message on stderr) */
+  OVP_E_PEER = -9       /* sharded update: another rank's build failed; every rank of the call reports an error (errors are collective) */
 };
 
 typedef struct ovp_ctx ovp_ctx;
@@ -185,8 +186,20 @@ int ovp_rccl_allreduce_gram(ovp_ctx *ctx, void *nccl_comm);
  * staged entries and ovp_batch_set_range themselves): balanced over the features of the update, consecutive ranks tile the batch,
  * lo == hi = an empty share */
 int ovp_shard_range(ovp_ctx *ctx, const ovp_update_opts *opts, int rank, int world, int *lo, int *hi);
+/* the same arithmetic without a context (pure host code, no device): used[n_feats] = the mask ovp_msckf_plane_update returned
+ * (non-zero = consumed by an accepted plane), NULL = no plane loop ran */
+int ovp_shard_range_of_mask(const uint8_t *used, int n_feats, int rank, int world, int *lo, int *hi);
+/* ERRORS ARE COLLECTIVE: argument / call-order errors are detected before the collective from inputs that are the same on every
+ * rank; a rank whose build fails afterwards still enters the all-reduce (zero pair, one more summed f64 word raised), so its peers
+ * complete the call and return OVP_E_PEER - no rank is left waiting inside RCCL.  After OVP_E_PEER the covariance of the
+ * context is invalid (OVP_E_STATE until the next ovp_cov_upload): the reference treats every failure on this path as fatal
+ * (state/StateHelper.cpp:185-187). */
 int ovp_msckf_update_sharded(ovp_ctx *ctx, const ovp_update_opts *opts, void *nccl_comm, int rank, int world, double *dx_host,
                              uint8_t *accepted_host, double *chi2_host, ovp_update_info *info, int *shard_lo, int *shard_hi);
+/* Completes accepted_host[n_feats] (and chi2_host, may be NULL) of a sharded update on EVERY rank: the shares are disjoint and zero
+ * elsewhere, so an ncclAllReduce(sum) is a gather.  For callers that act on every feature's decision on every replica - the
+ * Updater surface erases rejected features from feature_vec (update/UpdaterMSCKF.cpp:755-757).  Collective; nccl_comm = NULL: no-op. */
+int ovp_rccl_gather_decisions(ovp_ctx *ctx, void *nccl_comm, uint8_t *accepted_host, double *chi2_host);
 
 /* ext ov_core::FeatureInitializerOptions (open_vins ov_core/src/feat/FeatureInitializerOptions.h; not in the reference tree) */
 typedef struct {

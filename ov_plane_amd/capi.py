@@ -139,7 +139,8 @@ EXPORTS = [
     "ovp_last_timings", "ovp_kernel_timer", "ovp_msckf_plane_update", "ovp_cov_augment_dt", "ovp_cov_initialize_invertible", "ovp_plane_init",
     "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
     "ovp_slam_update", "ovp_cov_clone_jitter", "ovp_rccl_unique_id", "ovp_rccl_comm_create", "ovp_rccl_comm_destroy",
-    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded", "ovp_slam_delayed_init", "ovp_shard_range",
+    "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded", "ovp_slam_delayed_init", "ovp_shard_range", "ovp_shard_range_of_mask",
+    "ovp_rccl_gather_decisions",
 ]
 
 
@@ -184,6 +185,8 @@ def lib():
         L.ovp_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.ovp_rccl_allreduce_gram.argtypes = [C.c_void_p, C.c_void_p]
         L.ovp_shard_range.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ovp_shard_range_of_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ovp_rccl_gather_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ovp_msckf_update_sharded.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.POINTER(UpdateInfo), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ovp_slam_update.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.POINTER(SlamBatch), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -239,6 +242,18 @@ def rccl_comm_create(uid: bytes, rank: int, world: int, device: int = 0) -> int:
 
 def rccl_comm_destroy(comm: int):
     _chk(lib().ovp_rccl_comm_destroy(C.c_void_p(comm)), "ovp_rccl_comm_destroy")
+
+
+def shard_range_of_mask(used, n_feats: int, rank: int, world: int):
+    """ovp_shard_range_of_mask: the index range of the resident batch ovp_msckf_update_sharded gives to `rank` (pure host
+    arithmetic of the library - callable without a GPU)."""
+    import numpy as np
+
+    lo, hi = C.c_int(0), C.c_int(0)
+    u = None if used is None else np.ascontiguousarray(np.asarray(used).astype(np.uint8))
+    _chk(lib().ovp_shard_range_of_mask(u.ctypes.data if u is not None else None, int(n_feats), int(rank), int(world), C.byref(lo),
+                                       C.byref(hi)), "ovp_shard_range_of_mask")
+    return lo.value, hi.value
 
 
 def opts_from_scene(sc) -> UpdateOpts:
@@ -448,6 +463,14 @@ class Context:
         lo, hi = C.c_int(0), C.c_int(0)
         _chk(lib().ovp_shard_range(self._h, C.byref(opts), int(rank), int(world), C.byref(lo), C.byref(hi)), "ovp_shard_range")
         return lo.value, hi.value
+
+    def rccl_gather_decisions(self, comm, accepted, chi2=None):
+        """ovp_rccl_gather_decisions: completes a sharded update's per-feature decisions on every rank (in place; collective)."""
+        acc = np.ascontiguousarray(np.asarray(accepted).astype(np.uint8))
+        ch = None if chi2 is None else np.ascontiguousarray(np.asarray(chi2, dtype=np.float64))
+        _chk(lib().ovp_rccl_gather_decisions(self._h, C.c_void_p(comm) if comm else None, acc.ctypes.data,
+                                             ch.ctypes.data if ch is not None else None), "ovp_rccl_gather_decisions")
+        return acc.astype(bool), ch
 
     def rccl_allreduce_gram(self, comm):
         _chk(lib().ovp_rccl_allreduce_gram(self._h, C.c_void_p(comm)), "ovp_rccl_allreduce_gram")

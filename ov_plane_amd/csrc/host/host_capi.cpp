@@ -37,6 +37,20 @@ extern "C" void ovph_set_plane_fit(int enable, int min_feat, double max_cond, in
   g_fit_variant = shuffle_variant;
 }
 
+// next ovph_run_msckf_update: the State lives on this device and the updater takes the sharded point loop on this communicator
+static void *g_comm = nullptr;
+static int g_comm_rank = 0, g_comm_world = 1, g_device = 0, g_last_shard[2] = {0, 0};
+extern "C" void ovph_set_shard_comm(void *nccl_comm, int rank, int world, int device) {
+  g_comm = nccl_comm;
+  g_comm_rank = rank;
+  g_comm_world = world;
+  g_device = device;
+}
+extern "C" void ovph_last_shard(int *lo, int *hi) {
+  *lo = g_last_shard[0];
+  *hi = g_last_shard[1];
+}
+
 extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double *clone_p, const double *clone_q_fej,
                                      const double *clone_p_fej, const double *calib_q, const double *calib_p,
                                      const double *intr, int n_planes_in_state, const double *cp_state,
@@ -61,6 +75,7 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   }
   so.max_state_size = N + 8;
   so.max_features = F + 8;
+  so.gpu_device = g_device;
   auto state = std::make_shared<State>(so);
   state->_cam_fisheye[0] = g_fisheye != 0;
   g_fisheye = 0;
@@ -156,7 +171,13 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   uo.chi2_multipler = chi2_mult;
   ov_core::FeatureInitializerOptions fio;
   UpdaterMSCKF updater(uo, fio);
+  if (g_comm || g_comm_world > 1) updater.set_communicator(g_comm, g_comm_rank, g_comm_world);
   updater.update(state, fv, fextra, fused, feat2plane);
+  updater.last_shard(g_last_shard[0], g_last_shard[1]);
+  g_comm = nullptr;
+  g_comm_rank = 0;
+  g_comm_world = 1;
+  g_device = 0;
   g_uv_norm = nullptr;
   g_fit_planes = 0;
   // outputs

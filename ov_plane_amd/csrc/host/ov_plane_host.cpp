@@ -70,7 +70,7 @@ State::State(StateOptions &options_) {
         Cov(id + 4 + k, id + 4 + k) = 0.005 * 0.005;
       }
     }
-  gpu_check(ovp_ctx_create(0, _options.max_state_size, std::min(64, _options.max_clone_size + 2), _options.max_features, nullptr, &_gpu),
+  gpu_check(ovp_ctx_create(_options.gpu_device, _options.max_state_size, std::min(64, _options.max_clone_size + 2), _options.max_features, nullptr, &_gpu),
             "ovp_ctx_create");
   gpu_check(ovp_cov_upload(_gpu, Cov.data(), current_id, current_id), "ovp_cov_upload");
   PlaneFitting::bind(_gpu, _options.planefit_shuffle_variant);
@@ -1124,7 +1124,21 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     tr.do_calib_intr = o.do_calib_camera_intrinsics;
   }
   std::vector<double> chi2v(tos ? feature_vec.size() : 0, 0.0);
-  int rc = ovp_msckf_update(state->_gpu, &o, dx.data(), ok.data(), tos ? chi2v.data() : nullptr, &info);
+  int rc;
+  if (_comm || _world > 1) {
+    // feature-sharded point loop: the batch above is the same on every replica; accepted / chi2 come back for this rank's share
+    // and are completed over the communicator (errors are collective, see ovplane_hip.h)
+    rc = ovp_msckf_update_sharded(state->_gpu, &o, _comm, _rank, _world, dx.data(), ok.data(), tos ? chi2v.data() : nullptr, &info,
+                                  &_shard_lo, &_shard_hi);
+    if (rc == 0 || rc == OVP_E_NEGDIAG) {
+      const int rg = ovp_rccl_gather_decisions(state->_gpu, _comm, ok.data(), tos ? chi2v.data() : nullptr);
+      if (rc == 0) rc = rg;
+      info.n_accepted = 0;
+      for (uint8_t a : ok) info.n_accepted += a ? 1 : 0;
+    }
+  } else {
+    rc = ovp_msckf_update(state->_gpu, &o, dx.data(), ok.data(), tos ? chi2v.data() : nullptr, &info);
+  }
   if (rc == OVP_E_NEGDIAG) {
     PRINT_ERROR("StateHelper::EKFUpdate() - negative covariance diagonal\n");
     std::exit(EXIT_FAILURE);

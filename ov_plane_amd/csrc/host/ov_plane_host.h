@@ -58,6 +58,9 @@ struct StateOptions {
   // capacity of the device context (not in the reference: Eigen resizes dynamically)
   int max_state_size = 320;
   int max_features = 8192;
+  // HIP device the State's context (covariance, pose tables, feature batches) lives on.  One process per GPU: rank r of a
+  // multi-GPU job constructs its replica of the filter with gpu_device = its local rank.  Not in the reference.
+  int gpu_device = 0;
 };
 
 // update/UpdaterOptions.h:37-53
@@ -276,9 +279,28 @@ public:
               std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_extra,
               std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec_used, const std::map<size_t, size_t> &feat2plane);
 
+  // Multi-GPU (no counterpart in the reference, which runs on one core).  One process per GPU, every process a
+  // replica of the filter that is fed the same frames; with a communicator set, update() runs the plane loop on every replica
+  // (sequential across planes: update/UpdaterMSCKF.cpp:413-649) and hands the point loop (:695-814) to ovp_msckf_update_sharded:
+  // this rank's share of the features -> information pair -> ncclAllReduce -> identical EKF update on every replica; the per-feature
+  // gate decisions of the other shares arrive through ovp_rccl_gather_decisions, so feature_vec ends up the same everywhere.
+  // nccl_comm: an ncclComm_t the caller owns (or one made by ovp_rccl_comm_create); NULL / world 1 = the single-GPU path.
+  void set_communicator(void *nccl_comm, int rank, int world) {
+    _comm = nccl_comm;
+    _rank = rank;
+    _world = world < 1 ? 1 : world;
+  }
+  // index range of the last point batch this rank built (diagnostics and tests)
+  void last_shard(int &lo, int &hi) const {
+    lo = _shard_lo;
+    hi = _shard_hi;
+  }
+
 protected:
   UpdaterOptions _options;
   ov_core::FeatureInitializerOptions _featinit;  // reference: std::shared_ptr<ov_core::FeatureInitializer> initializer_feat
+  void *_comm = nullptr;
+  int _rank = 0, _world = 1, _shard_lo = 0, _shard_hi = 0;
 };
 
 // utils/NoiseManager.h:36-79 (continuous-time IMU noise densities; *_2 are filled by the Propagator constructor)

@@ -22,12 +22,16 @@ def lib():
     return _LIB
 
 
-def run_msckf_update(sc, triangulate=False, fit_planes=None):
+def run_msckf_update(sc, triangulate=False, fit_planes=None, comm=None, rank=0, world=1, device=0):
     """Drives ov_plane::UpdaterMSCKF::update (C++ host classes over the C-ABI) on a synth.Scene.
     triangulate=True: the features carry uvs_norm and no position; the updater triangulates them first.
     fit_planes=dict(min_feat, max_cond, variant): no plane estimates are handed over - the updater fits the planes that are
-    not in the state (PlaneFitting::plane_fitting) and refines planes and on-plane features (optimize_plane) itself."""
+    not in the state (PlaneFitting::plane_fitting) and refines planes and on-plane features (optimize_plane) itself.
+    comm / rank / world / device: UpdaterMSCKF::set_communicator + StateOptions::gpu_device - the point loop goes through
+    ovp_msckf_update_sharded on this rank's share (out["shard"] = its index range of the point batch)."""
     L = lib()
+    L.ovph_set_shard_comm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.ovph_set_shard_comm(C.c_void_p(comm) if comm else None, int(rank), int(world), int(device))
     L.ovph_set_fisheye(1 if sc.get("fisheye", False) else 0)
     if fit_planes is not None:
         L.ovph_set_plane_fit.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
@@ -66,6 +70,9 @@ def run_msckf_update(sc, triangulate=False, fit_planes=None):
     out["cp_state"] = out["cp_state"][: len(in_state)]
     for k in ("kept", "used", "deleted"):
         out[k] = out[k].astype(bool)
+    lo, hi = C.c_int(0), C.c_int(0)
+    L.ovph_last_shard(C.byref(lo), C.byref(hi))
+    out["shard"] = (lo.value, hi.value)
     return out
 
 

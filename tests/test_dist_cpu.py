@@ -211,3 +211,37 @@ def test_plane_loop_replicated_points_sharded_on_two_gloo_ranks():
     assert np.array_equal(res[0][1], res[1][1])
     for _, P, dx, _, _, _ in res:
         assert np.abs(dx - ref["dx"]).max() < 1e-9 and np.abs(P - ref["P"]).max() < 1e-10
+
+
+def test_library_and_python_split_agree_at_config4_size():
+    """The two statements of a rank's share - ovp_shard_range_of_mask (what ovp_msckf_update_sharded gives a rank; C, no device
+    needed) and dist.leftover_range (what the torch.distributed path and bench.py's stage pass use) - are the same index ranges
+    at BASELINE config 4's size (8000 features, 2500 of them on 50 planes) for 1, 2, 4 and 8 ranks, and at the edges: nothing
+    consumed, everything consumed, fewer leftovers than ranks."""
+    from ov_plane_amd import capi
+    from ov_plane_amd.dist import leftover_range
+
+    rng = np.random.default_rng(4)
+    F = 8000
+    masks = []
+    for n_acc in (50, 43, 0):        # all 50 planes accepted, the bench frame's typical count, none
+        used = np.zeros(F, dtype=bool)
+        on_plane = rng.permutation(F)[:2500].reshape(50, 50)
+        used[on_plane[:n_acc].ravel()] = True
+        masks.append(used)
+    masks += [np.ones(F, dtype=bool), np.r_[np.ones(F - 3, dtype=bool), np.zeros(3, dtype=bool)]]
+    for used in masks:
+        for world in (1, 2, 4, 8):
+            prev_hi, covered = 0, 0
+            for rank in range(world):
+                lo, hi, mine = leftover_range(used, rank, world)
+                assert capi.shard_range_of_mask(used, F, rank, world) == (lo, hi)
+                if len(mine):
+                    assert lo >= prev_hi and (~used[lo:hi]).sum() == len(mine)   # ranges of consecutive ranks do not overlap
+                    prev_hi = hi
+                covered += len(mine)
+            assert covered == int((~used).sum())
+    # no plane loop ran: plain balanced ranges
+    for world in (1, 3, 8):
+        for rank in range(world):
+            assert capi.shard_range_of_mask(None, 2000, rank, world) == shard_bounds(2000, rank, world)

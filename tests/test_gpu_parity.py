@@ -2883,6 +2883,64 @@ def test_native_rccl_sharded_update_on_one_rank_is_the_plain_update(hiplib, orac
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [
+    dict(C=11, F=120, seed=71, chi2_mult=1.0),
+    dict(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0),
+])
+def test_updater_surface_takes_the_sharded_point_loop(hiplib, oracle, kw):
+    """The plugin surface on several GPUs (call site core/VioManager.cpp:670): a State constructed on a given device
+    (StateOptions::gpu_device) and UpdaterMSCKF::set_communicator -> update() runs the plane loop, then the point loop through
+    ovp_msckf_update_sharded + ovp_rccl_gather_decisions.  With a communicator of one rank (the library's own RCCL binding) every
+    output - state, covariance, feature-vector side effects - is bit-equal to the plain update() and equals the oracle."""
+    from ov_plane_amd.build import build_host
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_scene(**kw)
+    ref = _oracle_full_update(oracle, sc)
+    plain = hostlib.run_msckf_update(sc)
+    comm = hiplib.rccl_comm_create(hiplib.rccl_unique_id(), 0, 1, 0)
+    try:
+        out = hostlib.run_msckf_update(sc, comm=comm, rank=0, world=1, device=0)
+    finally:
+        hiplib.rccl_comm_destroy(comm)
+    n_rest = int((~ref["used"]).sum())
+    assert out["shard"] == (0, n_rest)          # the point batch of update() holds the leftovers only; one rank owns all of it
+    for k in ("used", "kept", "deleted"):
+        assert (out[k] == plain[k]).all()
+    for k in ("clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp_state", "P"):
+        assert np.array_equal(out[k], plain[k]), k
+    assert (out["used"] == ref["used"]).all() and (out["kept"] == ref["kept"]).all()
+    assert np.abs(out["clone_p"] - ref["clone_p"]).max() < TOL_DX and relP(out["P"], ref["P"]) < TOL_P
+
+
+def test_gather_decisions_is_a_no_op_on_one_rank_and_shares_tile_the_batch(hiplib):
+    """ovp_rccl_gather_decisions on a one-rank communicator returns the arrays it was given; ovp_shard_range (context form) and
+    ovp_shard_range_of_mask (pure form) agree behind a plane loop."""
+    capi = hiplib
+    sc = make_scene(C=12, F=260, seed=72, n_planes=5, feats_per_plane=30, planes_in_state_frac=0.6, chi2_mult=1.0)
+    ctx = capi.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    ctx.batch_upload_scene(sc)
+    o = capi.opts_from_scene(sc)
+    pl = ctx.plane_update(o, sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
+    o.skip_plane_used = 1
+    for world in (1, 2, 3, 8):
+        for rank in range(world):
+            assert ctx.shard_range(o, rank, world) == capi.shard_range_of_mask(pl["used"], sc.F, rank, world)
+    comm = capi.rccl_comm_create(capi.rccl_unique_id(), 0, 1, 0)
+    try:
+        out = ctx.msckf_update_sharded(o, comm, 0, 1)
+        acc, chi2 = ctx.rccl_gather_decisions(comm, out["accepted"], out["chi2"])
+        assert (acc == out["accepted"]).all() and np.array_equal(chi2, out["chi2"]) and acc.sum() > 10
+    finally:
+        capi.rccl_comm_destroy(comm)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
     dict(C=11, F=8, seed=5, ragged=True),
     dict(C=8, F=6, seed=6, ragged=True, chi2_mult=0.6),   # two candidates fail the gate: inert blocks, removed behind the loop
     dict(C=14, F=12, seed=7, ragged=True, do_fej=False),
