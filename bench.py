@@ -32,7 +32,7 @@ sys.path.insert(0, _ROOT)
 
 import numpy as np  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r05_y_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the current tree (tools/prof_round.sh, tools/pmc_summary.py)
+PMC_TRAFFIC_FILE = "r06_final_hbm_traffic_pmc.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_round.sh, tools/pmc_summary.py); quoted only when its source_hash is the running tree's
 F64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector == matrix) peak, AMD datasheet; see DESIGN.md §6, NOTES.md §5
 WORKLOADS = {
     "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
@@ -63,17 +63,27 @@ def chol2_flops(n: int, n_inv: int) -> float:
 def pmc_traffic(kernel_substr, name, world):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (counters cannot be read from inside this process;
     quoted only for the workload the passes were taken on): 2 x FETCH_SIZE + WRITE_SIZE - the guide's gfx950 correction (wide
-    coalesced reads are tallied at half their bytes) applied as the upper bound, WRITE_SIZE as reported."""
+    coalesced reads are tallied at half their bytes) applied as the upper bound, WRITE_SIZE as reported.
+    The file records the hash of the kernel sources it was taken on (ov_plane_amd/build.py: source_tree_hash); when that is not
+    the running tree's the number is NOT quoted: (None, why)."""
     tp = os.path.join(_ROOT, "profiles", PMC_TRAFFIC_FILE)
-    if not os.path.exists(tp) or name != "config3" or world != 1:
-        return None, None
+    if name != "config3" or world != 1:
+        return None, "counter passes exist for the config-3 step on one GPU only"
+    if not os.path.exists(tp):
+        return None, "profiles/%s not found" % PMC_TRAFFIC_FILE
     with open(tp) as fh:
-        kern = json.load(fh)["kernels"]
-    hit = [v for k, v in kern.items() if kernel_substr in k]
+        doc = json.load(fh)
+    from ov_plane_amd.build import source_tree_hash
+
+    here, there = source_tree_hash(), doc.get("source_hash")
+    if there != here:
+        return None, ("profiles/%s was taken on kernel sources %s, the running tree is %s: stale counters are not quoted "
+                      "(tools/prof_round.sh retakes them)" % (PMC_TRAFFIC_FILE, there, here))
+    hit = [v for k, v in doc["kernels"].items() if kernel_substr in k]
     if not hit or "FETCH_SIZE_KB_avg_per_launch" not in hit[0]:
-        return None, None
+        return None, "kernel not in profiles/%s" % PMC_TRAFFIC_FILE
     b = (2.0 * hit[0]["FETCH_SIZE_KB_avg_per_launch"] + hit[0].get("WRITE_SIZE_KB_avg_per_launch", 0.0)) * 1024.0
-    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/%s (separate rocprofv3 --pmc passes over the same step)" % PMC_TRAFFIC_FILE
+    return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/%s (separate rocprofv3 --pmc passes over the same step, kernel sources %s)" % (PMC_TRAFFIC_FILE, here)
 
 
 def make_workload(name, seed=0, feat_seed=None, chi2_mult=1.0):
@@ -477,7 +487,7 @@ def cpu_baseline(sc, name, budget_feats=None):
 
 def interbuild_band():
     """Largest distance between two builds of the oracle on the plane-level statistic (tools/plane_gate_agreement.py, committed)."""
-    for f in ("r04_plane_gate_agreement.json", "r03_plane_gate_agreement.json"):
+    for f in ("r06_plane_gate_agreement.json", "r04_plane_gate_agreement.json", "r03_plane_gate_agreement.json"):
         p = os.path.join(_ROOT, "profiles", f)
         if os.path.exists(p):
             with open(p) as fh:
@@ -724,6 +734,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": be.data,
+            "source_hash": __import__("ov_plane_amd.build", fromlist=["source_tree_hash"]).source_tree_hash(),
             "config": {"workload": describe(name, sc), "baseline_config": name, "clones": C, "feats": int(sc.F),
                        "state_dim": int(sc.N), "planes": int(sc.cp.shape[0]),
                        "planes_accepted": int(pl["ok"].sum()) if pl is not None else 0,
@@ -796,6 +807,7 @@ def main():
                           "on one CU of the same launch, or runs beside it as k_chol2 on a side stream up to 1976 features)",
                 "achieved": exe / ks / 1e12, "peak": F64_PEAK_TFLOPS, "peak_measured": 59.5, "unit": "TFLOP/s",
                 "frac": exe / ks / 1e12 / F64_PEAK_TFLOPS, "traffic": pmc_traffic("k_feat_chol", name, world)[0],
+                "traffic_source": pmc_traffic("k_feat_chol", name, world)[1],
                 "traffic_note": "of which the kernel's OUTPUTS to K2: rec[C][F][2][21] %.1f MB + G[3F][ldg] %.1f MB (zeros for rejected / "
                                 "plane-consumed features included); B = H_x P H_x^T + I never leaves the CU since round 5" % (
                                     C * sc.F * 2 * 21 * 8 / 1e6, 3 * sc.F * (((sc.N + 4 + 15) // 16) * 16) * 8 / 1e6),

@@ -76,6 +76,21 @@ def build_fma():
     return so
 
 
+def build_variant(name):
+    """Path of another rounding of the same source (oracle/Makefile: "fma", "x87", "assoc"), None when it cannot be built or
+    loaded on this CPU.  The plain build (-ffp-contract off by default at -std=c99) is build()."""
+    assert name in ("fma", "x87", "assoc")
+    so = os.path.join(_HERE, "libovp_oracle_%s.so" % name)
+    srcs = [os.path.join(_HERE, f) for f in ("ovp_oracle.c", "ovp_oracle.h", "ovp_planefit.c", "ovp_planefit.h")]
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "-s", name])
+        C.CDLL(so)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return so
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -78,3 +78,21 @@ def build_host(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return HOST_OUT
+
+
+def source_tree_hash():
+    """sha256 over the sources libovplane_hip.so is built from (every .hip and header under csrc/, the C-ABI header), by name and
+    content: the identity of the kernels a profile was taken on.  Profiles under profiles/ record it (tools/pmc_summary.py,
+    tools/rocpd_stats.py) and bench.py quotes a committed counter file only when its hash is the running tree's - .git does not
+    travel to the GPU box, so this is computed from the files themselves."""
+    import hashlib
+
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    paths = [os.path.join(CSRC, f) for f in names] + [os.path.join(_HERE, "..", "include", "ovplane_hip.h")]
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]

@@ -30,6 +30,8 @@ extern "C" void ovph_set_feat_rep_slam(int rep) { g_feat_rep_slam = rep; }
 // mode 3 of ovph_run_updater: plane of every SLAM landmark (0 = none)
 static const int *g_slam_plane = nullptr;
 extern "C" void ovph_set_slam_planes(const int *plane_of_landmark) { g_slam_plane = plane_of_landmark; }
+// UpdaterSLAM::update takes its dense form (the one a batch the device entry refuses falls back to) until switched off again
+extern "C" void ovph_set_slam_force_dense(int on) { UpdaterSLAM::force_dense_for_tests(on != 0); }
 extern "C" void ovph_set_plane_fit(int enable, int min_feat, double max_cond, int shuffle_variant) {
   g_fit_planes = enable;
   g_fit_min_feat = min_feat;

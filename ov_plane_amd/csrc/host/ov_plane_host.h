@@ -225,6 +225,13 @@ public:
   // update/UpdaterSLAM.cpp:66-374; features with uvs_norm are triangulated on the device first, others carry p_FinG
   void delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                     const std::map<size_t, size_t> &feat2plane);
+  // The same update with every block built on the host (any track length, any number of rows): gates against marginals of the
+  // resident covariance (ovp_cov_marginal), one StateHelper::EKFUpdate on the stacked system.  update() takes it when the device
+  // entry refuses the batch (a landmark with more than OVP_MAX_MEAS new observations, OVP_E_CAPACITY of the gate kernel): the
+  // reference has no size limit on this path.  force_dense_for_tests(true) makes update() take it always.
+  void update_dense(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                    const std::map<size_t, size_t> &feat2plane);
+  static void force_dense_for_tests(bool on) { _force_dense = on; }
   // update/UpdaterSLAM.cpp:684-706: landmarks anchored in the clone that is about to be marginalised move to the newest one
   void change_anchors(std::shared_ptr<State> state);
   // the per-candidate form of delayed_init (host Jacobians, one StateHelper::initialize each): representations other than
@@ -245,6 +252,7 @@ protected:
                                     std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec);
   UpdaterOptions _options_slam, _options_aruco;
   ov_core::FeatureInitializerOptions _featinit;  // ext FeatureInitializer options (the reference keeps an initializer_feat)
+  static bool _force_dense;
   friend struct UpdaterSLAMTestAccess;
 };
 

@@ -539,9 +539,9 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   const int L = (int)feature_vec.size();
   int M = 1;
   for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
-  if (M > OVP_MAX_MEAS) {
-    fprintf(stderr, "UpdaterSLAM::update() - more than %d observations of a landmark are not supported\n", OVP_MAX_MEAS);
-    std::exit(EXIT_FAILURE);
+  if (M > OVP_MAX_MEAS || _force_dense) {  // a track longer than one wavefront's rows: the dense form has no such limit
+    update_dense(state, feature_vec, feat2plane);
+    return;
   }
   std::vector<float> uv((size_t)L * M * 2, 0.f);
   std::vector<int> cidx((size_t)L * M, -1), nm(L), lmid(L), psid(L, -1), pre_rows(L, 0), pre_cols(L, 0), pre_ids;
@@ -666,6 +666,10 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
     fprintf(stderr, "StateHelper::EKFUpdate() - negative covariance diagonal\n");
     std::exit(EXIT_FAILURE);
   }
+  if (rc == OVP_E_CAPACITY) {  // the gate kernel's LDS bound: nothing was touched, the dense form takes the batch
+    update_dense(state, feature_vec, feat2plane);
+    return;
+  }
   gpu_check2(rc, "ovp_slam_update");
   // :547-624 side effects of the gate, in the order of the vector
   size_t l = 0;
@@ -686,6 +690,163 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   }
   for (size_t f = 0; f < feature_vec.size(); f++) feature_vec[f]->to_delete = true;  // :657-659
   if (info.n_accepted > 0) StateHelper::apply_correction(state, dx.data());  // :673 Type::update of every variable
+}
+
+bool UpdaterSLAM::_force_dense = false;
+
+namespace {
+// one landmark's linearised measurement: [H_x | H_landmark] over `order` (the landmark last), residual
+struct DenseBlock {
+  MatrixXd H;
+  VectorXd r;
+  std::vector<std::shared_ptr<Type>> order;
+};
+
+// r^T (H P H^T + I)^-1 r with P the marginal of the block's variables, by a Cholesky solve; +inf when S is not positive definite
+double dense_block_chi2(std::shared_ptr<State> state, const DenseBlock &b) {
+  const MatrixXd Pm = StateHelper::get_marginal_covariance(state, b.order);
+  const int m = b.H.rows(), c = b.H.cols();
+  std::vector<double> HP((size_t)m * c, 0.0), S((size_t)m * m, 0.0), y(m);
+  for (int j = 0; j < c; ++j)
+    for (int k = 0; k < c; ++k) {
+      const double pkj = Pm(k, j);
+      if (pkj == 0.0) continue;
+      for (int i = 0; i < m; ++i) HP[(size_t)j * m + i] += b.H(i, k) * pkj;
+    }
+  for (int a = 0; a < m; ++a)
+    for (int i = a; i < m; ++i) {
+      double v = (i == a) ? 1.0 : 0.0;
+      for (int j = 0; j < c; ++j) v += HP[(size_t)j * m + i] * b.H(a, j);
+      S[(size_t)a * m + i] = v;  // lower triangle, column-major
+    }
+  double chi2 = 0.0;
+  for (int j = 0; j < m; ++j) {  // left-looking factorization fused with the forward substitution of r
+    double d = S[(size_t)j * m + j];
+    for (int k = 0; k < j; ++k) d -= S[(size_t)k * m + j] * S[(size_t)k * m + j];
+    if (!(d > 0.0)) return INFINITY;
+    d = std::sqrt(d);
+    S[(size_t)j * m + j] = d;
+    double rj = b.r(j);
+    for (int k = 0; k < j; ++k) rj -= S[(size_t)k * m + j] * y[k];
+    y[j] = rj / d;
+    chi2 += y[j] * y[j];
+    for (int i = j + 1; i < m; ++i) {
+      double v = S[(size_t)j * m + i];
+      for (int k = 0; k < j; ++k) v -= S[(size_t)k * m + i] * S[(size_t)k * m + j];
+      S[(size_t)j * m + i] = v / d;
+    }
+  }
+  return chi2;
+}
+}  // namespace
+
+void UpdaterSLAM::update_dense(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
+                               const std::map<size_t, size_t> &feat2plane) {
+  typedef LandmarkRepresentation LR;
+  const double sigma_c = state->_options.sigma_constraint, mult = _options_slam.chi2_multipler;
+  // the landmark at its current estimate in its own representation, with or without the point-on-plane rows (update/UpdaterSLAM.cpp:478-522)
+  auto linearize = [&](const ov_core::Feature &ft, const std::shared_ptr<Landmark> &lm, size_t planeid) {
+    UpdaterHelper::UpdaterHelperFeature hf;
+    hf.featid = ft.featid;
+    hf.uvs = ft.uvs;
+    hf.timestamps = ft.timestamps;
+    const bool single = lm->_feat_representation == LR::ANCHORED_INVERSE_DEPTH_SINGLE;
+    hf.feat_representation = single ? LR::ANCHORED_MSCKF_INVERSE_DEPTH : lm->_feat_representation;
+    if (LR::is_relative_representation(hf.feat_representation)) {
+      hf.anchor_cam_id = lm->_anchor_cam_id;
+      hf.anchor_clone_timestamp = lm->_anchor_clone_timestamp;
+      lm->get_xyz(false, hf.p_FinA);
+      lm->get_xyz(true, hf.p_FinA_fej);
+    } else {
+      lm->get_xyz(false, hf.p_FinG);
+      lm->get_xyz(true, hf.p_FinG_fej);
+    }
+    if (planeid != 0) {
+      hf.planeid = planeid;
+      const auto pl = state->_features_PLANE.at(planeid);
+      for (int k = 0; k < 3; ++k) hf.cp_FinG[k] = pl->value()(k), hf.cp_FinG_fej[k] = pl->fej()(k);
+    }
+    MatrixXd H_f, H_x;
+    DenseBlock b;
+    UpdaterHelper::get_feature_jacobian_full(state, hf, _options_slam.sigma_pix, sigma_c, H_f, H_x, b.r, b.order);
+    const int keep_f = single ? 1 : H_f.cols(), first_f = H_f.cols() - keep_f;  // single: only the depth column stays a variable
+    MatrixXd H(H_x.rows(), H_x.cols() + keep_f);
+    for (int i = 0; i < H_x.rows(); ++i) {
+      for (int j = 0; j < H_x.cols(); ++j) H(i, j) = H_x(i, j);
+      for (int j = 0; j < keep_f; ++j) H(i, H_x.cols() + j) = H_f(i, first_f + j);
+    }
+    if (single) {  // :499-515 the bearing columns are projected out
+      MatrixXd H_b = H_f.block(0, 0, H_f.rows(), first_f);
+      UpdaterHelper::nullspace_project_inplace(H_b, H, b.r);
+    }
+    b.H = H;
+    b.order.push_back(lm);
+    return b;
+  };
+  std::vector<DenseBlock> taken;
+  std::vector<std::shared_ptr<ov_core::Feature>> survivors;
+  for (auto &fp : feature_vec) {
+    ov_core::Feature &ft = *fp;
+    const auto lm = state->_features_SLAM.at(ft.featid);
+    size_t pid = 0;
+    {  // :465-475 a plane in the state that this landmark has not been taken off
+      const auto it = feat2plane.find(ft.featid);
+      const auto bad = state->_features_SLAM_to_PLANE.find(ft.featid);
+      if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamu && it != feat2plane.end() &&
+          state->_features_PLANE.count(it->second) && !(bad != state->_features_SLAM_to_PLANE.end() && bad->second == 0))
+        pid = it->second;
+    }
+    if (pid != 0 && lm->_feat_representation != LR::GLOBAL_3D) {
+      fprintf(stderr, "UpdaterSLAM::update() - point-on-plane rows need a GLOBAL_3D landmark\n");
+      std::exit(EXIT_FAILURE);
+    }
+    DenseBlock blk = linearize(ft, lm, pid);
+    bool pass = dense_block_chi2(state, blk) <= mult * ovp_chi2_quantile_095(blk.r.rows());
+    if (!pass && pid != 0) {  // :547-609 once more without the plane; the landmark is taken off it either way
+      state->_features_SLAM_to_PLANE[ft.featid] = 0;
+      pid = 0;
+      blk = linearize(ft, lm, 0);
+      pass = dense_block_chi2(state, blk) <= mult * ovp_chi2_quantile_095(blk.r.rows());
+    }
+    ft.to_delete = true;  // rejected: :612, kept: :657-659
+    if (!pass) {
+      lm->should_marg = true;
+      continue;
+    }
+    if (pid != 0) state->_features_SLAM_to_PLANE[ft.featid] = pid;
+    taken.push_back(blk);
+    survivors.push_back(fp);
+  }
+  feature_vec = survivors;
+  if (taken.empty()) return;
+  // column layout of the stacked system: variables in order of first appearance (:634-646)
+  std::vector<std::shared_ptr<Type>> big_order;
+  std::map<const Type *, int> col_of;
+  int n_cols = 0, n_rows = 0;
+  for (const auto &b : taken) {
+    n_rows += b.r.rows();
+    for (const auto &v : b.order)
+      if (!col_of.count(v.get())) {
+        col_of[v.get()] = n_cols;
+        big_order.push_back(v);
+        n_cols += v->size();
+      }
+  }
+  MatrixXd H_big = MatrixXd::Zero(n_rows, n_cols), R_big = MatrixXd::Identity(n_rows, n_rows);
+  VectorXd r_big = VectorXd::Zero(n_rows, 1);
+  int row0 = 0;
+  for (const auto &b : taken) {
+    int src = 0;
+    for (const auto &v : b.order) {
+      const int dst = col_of.at(v.get());
+      for (int j = 0; j < v->size(); ++j)
+        for (int i = 0; i < b.H.rows(); ++i) H_big(row0 + i, dst + j) = b.H(i, src + j);
+      src += v->size();
+    }
+    for (int i = 0; i < b.r.rows(); ++i) r_big(row0 + i) = b.r(i);
+    row0 += b.r.rows();
+  }
+  StateHelper::EKFUpdate(state, big_order, H_big, r_big, R_big);  // :673
 }
 
 // update/UpdaterSLAM.cpp:120-166 (the same block opens UpdaterMSCKF::update and UpdaterPlane::init_vio_plane): features that

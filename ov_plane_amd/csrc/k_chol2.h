@@ -52,6 +52,7 @@ struct PlaneSolve {
   double thr;
   int rows_live, rows_u, n_involved;  // rows_live: residual directions that can carry energy (2m - 2 per feature, see the gate)
   int force;                // ovp_plane_batch::force_decision (0 / 1), anything else = the gate decides
+  double noise_scale;       // weight of the expected energy of the rounding-decided rows (OVP_PLANE_NOISE_KAPPA; a study may override it)
   double tol_strict, tol_loose;
   double* res_out;          // [4]: chi2, accept, rank deficiency, pr
   // split factorization: [0] part A's share of |z|^2, [1] its pivot verdict; y blocks of part B's columns; sequence words

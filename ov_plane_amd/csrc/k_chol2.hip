@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
       const double noise_rows = fmax((double)ps.rows_u - rank, 0.0);
       const double denom = (double)ps.rows_live - rank;
       const double frac = denom > 0.5 ? fmin(noise_rows / denom, 1.0) : 1.0;
-      const double chi2 = (pr - zz) + frac * fmax(rr - pr, 0.0);
+      const double chi2 = (pr - zz) + ps.noise_scale * frac * fmax(rr - pr, 0.0);
       // any failure upstream (chol(P) of the loop's start, an earlier plane's factorization) rejects this and every later plane
       // BEFORE anything is committed: with a failed L0 the tables and the covariance would otherwise drift apart
       const int upstream = J.flag ? __hip_atomic_load(J.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -1454,8 +1454,8 @@ hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, co
   const Chol2Job& b = j1 ? *j1 : dummy;
   const PlaneSolve& p = ps ? *ps : psd;
   const dim3 grid(j0->split_h > 0 ? 3 : (j1 ? 2 : 1)), block(C2_WAVES * 64);
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr_mask = 0;  // per device (ovp_kernels.h)
+  if (ovp_lds_attr_needed(&attr_mask)) {
     (void)hipFuncSetAttribute((const void*)k_chol2<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<15, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<17, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1464,8 +1464,8 @@ hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, co
     (void)hipFuncSetAttribute((const void*)k_chol2<13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_chol2<22, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr = true;
+    (void)hipGetLastError();  // (a kernel with static LDS refuses the full 160 KB: harmless, a real shortage fails the launch itself)
+    ovp_lds_attr_done(&attr_mask);
   }
   if (j0->split_h > 0) {  // the split kernels: the slot counts of BASELINE config 3 (forced, tests) and config 4, and a catch-all
     if (slots <= 13)

@@ -6,8 +6,10 @@
 //   k_dinit_rows    one workgroup: Type::update of the device pose tables with the previous candidate's correction (its
 //                   commit), the candidate's bearing rows at those tables (UpdaterHelper.cpp:345-444), the orthogonal split of
 //                   H_f = Q [R3; 0] (Householder instead of the Givens sweep of StateHelper.cpp:434-446: init rows, update rows
-//                   and everything derived from them are invariant under the choice of the orthogonal factor), H_L^-1 = R3^-1,
-//                   and M = P[:, ids] [H_init; H_up]^T for the two kernels below
+//                   and everything derived from them are invariant under the choice of the orthogonal factor), H_L^-1 = R3^-1
+//   k_init_m        (k_init.hip) M = P[:, ids] [H_init; H_up]^T on many workgroups (forming it inside k_dinit_rows - one workgroup,
+//                   prefetched operand - was built in round 5, was no faster and read columns a rejected predecessor had just
+//                   rewritten without a fence: removed in round 6)
 //   k_init_core     (k_init.hip) chi2 of the update rows against the prior (:464-475), initialize_invertible (:520-573)
 //   k_init_update   (k_init.hip) EKFUpdate with the update rows (:483-485), IN PLACE
 //
@@ -55,8 +57,6 @@ __device__ __forceinline__ void dinit_rot_update(double* R, const double* dth) {
 __device__ __forceinline__ void di_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define DI_T 1024   // threads of the one workgroup
-#define DI_KC 16    // columns of P[ids, :] staged per chunk of the M product
-#define DI_PRE 16   // prefetched elements of P[ids, :] per thread (full staging: cols x n_pad <= DI_PRE * DI_T)
 
 // (16 waves = 4 per SIMD: 128 VGPRs each; without the attribute the compiler aims at 8 waves per SIMD, stops at 64 registers and
 // spills the prefetch to scratch - a dispatch that needs scratch behind ones that do not costs tens of microseconds on this stack)
@@ -105,32 +105,6 @@ __global__ __launch_bounds__(DI_T) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (t >= 64 && t < 67) ld4 = p.p_FinG[3 * l + (t - 64)];
   }
   DI_STAMP();
-  // (b) P[ids, :] (the operand of the M product at the end), into registers; wave <-> (column k, 64-row segment): k is
-  // wave-uniform, so its state column comes out of the kernel arguments through the scalar unit (dp.idv)
-  double pre[DI_PRE];
-  const int wv = t >> 6, lane = t & 63;
-  const int nseg = (dp.n + 63) >> 6;
-  if (l >= 0 && dp.full) {
-    // the state column of a (wave-uniform) k: every wave holds the list in four registers (one vector load each, all in flight
-    // together) and picks its entry with v_readlane - reading dp.idv[k] through the scalar unit was one s_load round trip per
-    // prefetched element, one after the other (12 us of this kernel's first version)
-    int idr[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) idr[j] = (64 * j + lane < cols) ? dp.ids[64 * j + lane] : 0;
-    int k = wv / nseg, seg = wv - k * nseg;
-    const int dk = 16 / nseg, ds = 16 - dk * nseg;
-#pragma unroll
-    for (int q = 0; q < DI_PRE; ++q) {
-      const int r = 64 * seg + lane;
-      const int kc = k < cols ? k : 0;
-      const int sel = kc >> 6, ln = kc & 63;
-      const int idk = __builtin_amdgcn_readlane(sel == 0 ? idr[0] : sel == 1 ? idr[1] : sel == 2 ? idr[2] : idr[3], ln);
-      pre[q] = (k < cols && r < dp.n) ? dp.P[(size_t)idk * p.ldp + r] : 0.0;
-      k += dk;
-      seg += ds;
-      if (seg >= nseg) seg -= nseg, ++k;
-    }
-  }
   DI_STAMP();
   // (c) into LDS
   if (t < OVP_LDG_CAP) dxs[t] = ld0;
@@ -180,27 +154,7 @@ __global__ __launch_bounds__(DI_T) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   if (l < 0) return;  // commit only (behind the last candidate)
   double* A = sm;                 // [rows][W] row-major
   double* v = A + (size_t)rows * W;  // [rows] Householder vector
-  double* Pc = v + rows + 8;         // [2][DI_KC][n_pad]: chunks of P[ids, :] for the M product (or all of it, dp.full)
-  int* ids_s = (int*)(Pc + (dp.full ? (size_t)cols * dp.n_pad : 2 * (size_t)DI_KC * dp.n_pad));
-  DI_STAMP();
-  if (dp.full) {
-    // the prefetched operand goes to LDS now (it was requested right behind the loads the commit just waited for, so it is here or
-    // nearly so), which frees its registers for the measurement model below
-    double* Pall = Pc;
-    const int npad = dp.n_pad;
-    {
-      int k = wv / nseg, seg = wv - k * nseg;
-      const int dk = 16 / nseg, ds = 16 - dk * nseg;
-#pragma unroll
-      for (int q = 0; q < DI_PRE; ++q) {
-        const int r = 64 * seg + lane;
-        if (k < cols && r < npad) Pall[(size_t)k * npad + r] = pre[q];
-        k += dk;
-        seg += ds;
-        if (seg >= nseg) seg -= nseg, ++k;
-      }
-    }
-  }
+  int* ids_s = (int*)(v + rows + 8);
   DI_STAMP();
   for (int e = t; e < rows * W; e += DI_T) A[e] = 0.0;
   for (int e = t; e < cols; e += DI_T) ids_s[e] = dp.idv[e];
@@ -289,119 +243,22 @@ __global__ __launch_bounds__(DI_T) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     dp.Ht[e] = A[(size_t)i * W + 3 + a];
   }
   for (int i = 3 + t; i < rows; i += DI_T) dp.resid[i - 3] = A[(size_t)i * W + 3 + cols];
-  // ---- M = P[:, ids] H_all^T (n x rows).  Every P[r][ids[k]] is needed exactly once (n x cols values, read as P[ids[k]][r]: P is
-  // symmetric, so a wave walks a row): chunks of DI_KC columns go through LDS, double-buffered (the loads of chunk c + 1 are in
-  // flight while chunk c is consumed); thread <-> (state row r = t % 256 (+ 256), row group g = t / 256), accumulators for the
-  // stacked rows g, g + 4, ... in registers
-  const int n = dp.n, npad = dp.n_pad;
-  const int g = t >> 8, rl = t & 255;
-  const int nchunk = (cols + DI_KC - 1) / DI_KC;
-  auto stage = [&](int ch, int buf) {
-    double* dst = Pc + (size_t)buf * DI_KC * npad;
-    const int k0 = ch * DI_KC;
-    for (int e = t; e < DI_KC * npad; e += DI_T) {
-      const int kk = e / npad, r = e - kk * npad;
-      dst[e] = (k0 + kk < cols && r < n) ? dp.P[(size_t)ids_s[k0 + kk] * p.ldp + r] : 0.0;
-    }
-  };
-  if (dp.skip_m) return;  // M = P[:, ids] H_all^T comes from k_init_m (many workgroups) behind this launch
-  DI_STAMP();
-  if (dp.full) {
-    double* Pall = Pc;  // [cols][npad], staged above
-    di_lds_barrier();
-    DI_STAMP();
-    // M tile by tile on v_mfma_f64_16x16x4_f64, operands from LDS: A operand = P[ids[k]][r] (lane: r = r0 + lane % 16, k = k0 + lane / 16),
-    // B operand = H[i][k] (i = i0 + lane % 16), D[r0 + lane / 16 + 4 v][i0 + lane % 16]
-    {
-      const int tr = (n + 15) >> 4, ti = (rows + 15) >> 4;
-      const int ij = lane & 15, kk = lane >> 4;
-      for (int tile = wv; tile < tr * ti; tile += DI_T / 64) {
-        const int r0 = (tile / ti) * 16, i0 = (tile % ti) * 16;
-        const int ra = r0 + ij, ib = i0 + ij;
-        const double* pa = Pall + ra;
-        const double* hb = A + (size_t)ib * W + 3;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-        const bool ra_ok = ra < npad, ib_ok = ib < rows;
-        for (int k0 = 0; k0 < cols; k0 += 16) {   // four steps at a time: eight LDS reads in flight, two accumulation chains
-          double av[4], bv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int k = k0 + 4 * u + kk;
-            av[u] = (k < cols && ra_ok) ? pa[(size_t)k * npad] : 0.0;
-            bv[u] = (k < cols && ib_ok) ? hb[k] : 0.0;
-          }
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
-        }
-        acc += acc2;
-#pragma unroll
-        for (int vq = 0; vq < 4; ++vq) {
-          const int r = r0 + kk + 4 * vq, i = i0 + ij;
-          if (r < n && i < rows) dp.Mall[(size_t)r * rows + i] = acc[vq];
-        }
-      }
-    }
-#ifdef OVP_DI_STAMPS
-    DI_STAMP();
-    if (t == 0)
-      printf("[k_dinit_rows m=%d n=%d] issue a %lld | issue b %lld | wait+lds %lld | commit %lld | pre->lds %lld | zero %lld | rows %lld | householder %lld | inverse+Ht %lld | bar %lld | M %lld (ns)\n", m,
-             dp.n, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[10] - st[9], st[11] - st[10]);
-#endif
-    return;
-  }
-  for (int r0 = 0; r0 < n; r0 += 256) {   // (n <= 256 in every configuration: one pass)
-    const int r = r0 + rl;
-    double acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
-    di_lds_barrier();
-    stage(0, 0);
-    for (int ch = 0; ch < nchunk; ++ch) {
-      di_lds_barrier();
-      if (ch + 1 < nchunk) stage(ch + 1, (ch + 1) & 1);
-      const double* src = Pc + (size_t)(ch & 1) * DI_KC * npad;
-      const int k0 = ch * DI_KC;
-      if (r < n) {
-#pragma unroll 4
-        for (int kk = 0; kk < DI_KC; ++kk) {
-          const double pv = src[kk * npad + r];
-          const double* hcol = A + 3 + k0 + kk;
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (g + 4 * q < rows) acc[q] = fma(pv, (k0 + kk < cols) ? hcol[(size_t)(g + 4 * q) * W] : 0.0, acc[q]);
-        }
-      }
-    }
-    if (r < n) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-        if (g + 4 * q < rows) dp.Mall[(size_t)r * rows + g + 4 * q] = acc[q];
-    }
-  }
 }
 
 }  // namespace ovp
 
 extern "C" {
-size_t ovp_dinit_rows_lds(int m_obs, int ncal, int n_pad, int full) {
+size_t ovp_dinit_rows_lds(int m_obs, int ncal) {
   const int rows = 2 * m_obs, cols = 6 * m_obs + ncal, W = (cols + 4) | 1;
-  const size_t stage = full ? (size_t)cols * n_pad : 2 * (size_t)DI_KC * n_pad;
-  return sizeof(double) * ((size_t)rows * W + rows + 8 + stage + (size_t)(cols + 2) / 2 + 2);
-}
-// the whole of P[ids, :] through registers into LDS (prefetched at kernel start) when it fits both
-int ovp_dinit_full_stage(int m_obs, int ncal, int n, int n_pad) {
-  const int cols = 6 * m_obs + ncal;
-  return n <= 256 && cols <= 208 && cols * ((n + 63) / 64) <= DI_PRE * (DI_T / 64) && ovp_dinit_rows_lds(m_obs, ncal, n_pad, 1) <= OVP_DINIT_DYN_LDS;
+  return sizeof(double) * ((size_t)rows * W + rows + 8 + (size_t)(cols + 2) / 2 + 2);
 }
 
 hipError_t ovp_launch_dinit_rows(const ovp::DinitParams* dp, size_t lds, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)ovp::k_dinit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, OVP_DINIT_DYN_LDS);
-    (void)hipGetLastError();
-    attr = true;
+  static unsigned long long attr_mask = 0;  // per device (ovp_kernels.h)
+  if (ovp_lds_attr_needed(&attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)ovp::k_dinit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, OVP_DINIT_DYN_LDS);
+    (void)hipGetLastError();  // (a kernel with static LDS refuses the full 160 KB: harmless, a real shortage fails the launch itself)
+    ovp_lds_attr_done(&attr_mask);
   }
   hipLaunchKernelGGL(ovp::k_dinit_rows, dim3(1), dim3(DI_T), lds, stream, *dp);
   return hipGetLastError();

@@ -428,10 +428,11 @@ hipError_t ovp_launch_chol(const double* A, double* L, int n, int ld, int* flag,
                            hipStream_t stream) {
   const size_t shmem = (size_t)n * (ovp::CH_NB + 1) * sizeof(double);
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)ovp::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  static unsigned long long attr_mask = 0;  // per device (ovp_kernels.h)
+  if (ovp_lds_attr_needed(&attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)ovp::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();  // (a kernel with static LDS refuses the full 160 KB: harmless, a real shortage fails the launch itself)
+    ovp_lds_attr_done(&attr_mask);
   }
   hipLaunchKernelGGL(ovp::k_chol, dim3(1), dim3(ovp::CH_T), shmem, stream, A, L, n, ld, flag, add_identity);
   return hipGetLastError();

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "ovp_dev.h"
+#include "ovp_kernels.h"
 
 namespace ovp {
 
@@ -355,13 +356,13 @@ hipError_t ovp_launch_init_m(const double* P, int ldp, int n, const int* ids, in
 hipError_t ovp_launch_init_core(double* P, int ldp, int n, const int* ids, int cols, const double* Ht, int k, int rup, double* Mall,
                                 const double* Hinv, const double* Rk, const double* resid, double r_iso, double thr, double* Linv,
                                 double* y, double* res, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)ovp::k_init_core, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovp_init_max_lds());
-    hipFuncSetAttribute((const void*)ovp::k_init_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovp_init_max_lds());
-    hipFuncSetAttribute((const void*)ovp::k_init_m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovp_init_max_lds());
-    (void)hipGetLastError();
-    attr = true;
+  static unsigned long long attr_mask = 0;  // per device (ovp_kernels.h)
+  if (ovp_lds_attr_needed(&attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)ovp::k_init_core, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovp_init_max_lds());
+    (void)hipFuncSetAttribute((const void*)ovp::k_init_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovp_init_max_lds());
+    (void)hipFuncSetAttribute((const void*)ovp::k_init_m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovp_init_max_lds());
+    (void)hipGetLastError();  // (a kernel with static LDS refuses the full 160 KB: harmless, a real shortage fails the launch itself)
+    ovp_lds_attr_done(&attr_mask);
   }
   size_t lds = ovp_init_core_lds(k, rup, cols);
   const size_t hs = sizeof(double) * (size_t)cols * (k + rup);

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_plane_gate(const double* __restrict__ s
   const double noise_rows = fmax((double)rows_u - rank, 0.0);
   const double denom = (double)rows_live - rank;
   const double frac = denom > 0.5 ? fmin(noise_rows / denom, 1.0) : 1.0;
-  const double chi2 = (pr - bdx) + frac * fmax(rr - pr, 0.0);
+  const double chi2 = (pr - bdx) + OVP_PLANE_NOISE_KAPPA * frac * fmax(rr - pr, 0.0);
   // force: 0 / 1 = decision handed over by the caller (ovp_plane_batch::force_decision), anything else = the gate decides
   const bool ok = (flags[0] == 0) && (force == 0 ? false : (force == 1 ? true : (chi2 <= thr)));
   res_out[0] = chi2;

@@ -241,11 +241,11 @@ size_t ovp_slam_gate_lds(int rows_max, int cols_max, int with_h) {
 }
 
 hipError_t ovp_launch_slam_gate(const ovp::SlamParams* sp, int n_landmarks, size_t lds, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)ovp::k_slam_gate, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    (void)hipGetLastError();
-    attr = true;
+  static unsigned long long attr_mask = 0;  // per device (ovp_kernels.h)
+  if (ovp_lds_attr_needed(&attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)ovp::k_slam_gate, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    (void)hipGetLastError();  // (a kernel with static LDS refuses the full 160 KB: harmless, a real shortage fails the launch itself)
+    ovp_lds_attr_done(&attr_mask);
   }
   hipLaunchKernelGGL(ovp::k_slam_gate, dim3(n_landmarks), dim3(256), lds, stream, *sp);
   return hipGetLastError();

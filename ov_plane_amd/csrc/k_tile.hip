@@ -260,10 +260,11 @@ hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, 
     hipLaunchKernelGGL((ovp::k_tilechol<18>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
                        flag, add_identity, ovp_dbg_tilechol_skip, cond);
   } else if (slots <= 25) {
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute((const void*)ovp::k_tilechol<25>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      attr = true;
+    static unsigned long long attr_mask = 0;  // per device (ovp_kernels.h)
+    if (ovp_lds_attr_needed(&attr_mask)) {
+      (void)hipFuncSetAttribute((const void*)ovp::k_tilechol<25>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipGetLastError();  // (a kernel with static LDS refuses the full 160 KB: harmless, a real shortage fails the launch itself)
+      ovp_lds_attr_done(&attr_mask);
     }
     hipLaunchKernelGGL((ovp::k_tilechol<25>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
                        flag, add_identity, ovp_dbg_tilechol_skip, cond);

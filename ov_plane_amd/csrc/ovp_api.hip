@@ -1154,7 +1154,19 @@ static int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o) {
   return 0;
 }
 
+static int build_gate_gram_tail_impl(ovp_ctx* c, int n, int F);
 static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
+  const int rc = build_gate_gram_tail_impl(c, n, F);
+  if (rc && c->need_join) {
+    // a failing exit behind the fork of chol(P): the main stream waits for the side stream before anything else is enqueued on it
+    // (the regular join sits in ekf_from_gram, which a failed build never reaches)
+    (void)hipEventRecord(c->ev_join, c->stream2);
+    (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    c->need_join = false;
+  }
+  return rc;
+}
+static int build_gate_gram_tail_impl(ovp_ctx* c, int n, int F) {
   ovp::FeatParams& fp = c->fp;
   // Round 5: the features that are not part of this update - consumed by an accepted plane (skip mask), outside this rank's index
   // range - no longer occupy rows of rec / G (they used to write 16 KB of zeros each, which K2 then read): the host knows both sets,
@@ -1264,10 +1276,10 @@ static int ovp_build_gate_gram_tail(ovp_ctx* c, int n, int F) {
       j.boost_n = cj.boost_n;
       j.boost_rel = cj.boost_rel;
       HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+      c->need_join = true;  // (from here on the side stream may hold work: ovp_build_gate_gram_tail joins on a failing exit)
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       HIPCHK(ovp_launch_chol2(&j, nullptr, nullptr, c->stream2));
       HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-      c->need_join = true;
       cj.n = 0;
     }
     HIPCHK(ovp_launch_feat_chol(&fp, &cj, c->stream));
@@ -2265,16 +2277,29 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   // L0 = chol(P), dense lower triangular in c->L.  Nothing needs it before the first plane's W = A L0, so it runs on the side
   // stream beside that plane's rows / Gram pair / assembly (round 5; one workgroup - the small kernels of the front end leave it a
   // CU on every XCD) and is joined in front of that product.  OVP_PL_CHOL_SIDE=0: on the loop's own stream, in front of everything.
-  bool chol_forked = false;
+  // (every way out of this function behind the fork - HIPCHK returns included - makes the loop's stream wait for the side stream:
+  // the next call must not race a factorization that is still writing c->L / c->flags)
+  struct ForkGuard {
+    hipStream_t s;
+    hipEvent_t ev_join;
+    hipStream_t side;
+    bool forked;
+    ~ForkGuard() {
+      if (!forked) return;
+      (void)hipEventRecord(ev_join, side);  // (a second record behind whatever the side stream got: harmless when the first one made it)
+      (void)hipStreamWaitEvent(s, ev_join, 0);
+    }
+  } fork_guard{s, c->ev_join, c->stream2, false};
+  bool& chol_forked = fork_guard.forked;
   if (any_candidate) {
     const char* side_env = getenv("OVP_PL_CHOL_SIDE");  // (read per call: the tests switch it)
     if (!(side_env && side_env[0] == '0') && s == c->stream) {
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      chol_forked = true;
       rc = chol_of_P(c, c->stream2);
       if (rc) return rc;
       HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-      chol_forked = true;
     } else {
       rc = chol_of_P(c, s);
       if (rc) return rc;
@@ -2433,6 +2458,10 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   double* d_slam_p = dd + 6 * NP;
   double* d_slam_pfej = dd + 6 * NP + 3 * n_slam;
   const double white_c = 1.0 / o->sigma_constraint;
+  // weight of the expected energy of the rounding-decided rows in the gate statistic (k_chol2.hip); OVP_PL_NOISE_SCALE overrides the
+  // calibrated constant for the study that produced it (tools/plane_gate_agreement.py --fit)
+  double noise_scale = OVP_PLANE_NOISE_KAPPA;
+  if (const char* ns_env = getenv("OVP_PL_NOISE_SCALE")) noise_scale = atof(ns_env);  // (read per call)
   for (int jn = 0; jn < NJ; ++jn) {
     const PlaneJobH& j = jobs[jn];
     // leading block this plane's products and factorization run on (plane_update_ordered): every column involved so far
@@ -2552,6 +2581,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     ps.rows_u = j.rows_u;
     ps.n_involved = j.n_inv_cols;
     ps.force = pb->force_decision ? (int)pb->force_decision[j.pl] : -1;
+    ps.noise_scale = noise_scale;
     ps.tol_strict = 1e-5;
     ps.tol_loose = 1e-5;
     ps.res_out = c->pl_res + 4 * j.pl;
@@ -3361,7 +3391,7 @@ extern "C" int ovp_slam_delayed_init(ovp_ctx* c, const ovp_update_opts* o, const
     const int cols = 6 * m + ncal, rup = 2 * m - 3;
     // outside the one-workgroup S-form (k_init.hip): the caller takes StateHelper::initialize candidate by candidate; nothing touched
     if (rup > ovp_init_max_rows() || ovp_init_core_lds(3, rup, cols) > ovp_init_max_lds() ||
-        ovp_dinit_rows_lds(m, ncal, (n0 + 3 * L) | 1, 0) > OVP_DINIT_DYN_LDS) return OVP_E_CAPACITY;
+        ovp_dinit_rows_lds(m, ncal) > OVP_DINIT_DYN_LDS) return OVP_E_CAPACITY;
     cols_max = std::max(cols_max, cols);
     rows_max = std::max(rows_max, 2 * m);
   }
@@ -3430,13 +3460,11 @@ extern "C" int ovp_slam_delayed_init(ovp_ctx* c, const ovp_update_opts* o, const
   dp.fp.white_px = 1.0 / o->sigma_px;
   dp.fp.ldp = ld;
   dp.n_max = c->n_max;
-  dp.n_pad = (n0 + 3 * L) | 1;
   dp.P = c->P;
   dp.clone_R = c->clone_R;
   dp.clone_p = c->clone_p;
   dp.cal = c->cal;
   dp.Ht = dHt;
-  dp.Mall = dM;
   dp.Hinv = dHinv;
   dp.Rk = dRk;
   dp.resid = dresid;
@@ -3444,26 +3472,19 @@ extern "C" int ovp_slam_delayed_init(ovp_ctx* c, const ovp_update_opts* o, const
     const int m = b->n_meas[l], cols = 6 * m + ncal, rows = 2 * m, rup = rows - 3, n = n0 + 3 * l;
     dp.cand = l;
     dp.m_obs = m;
-    // M = P[:, ids] H_all^T: inside the rows kernel (one workgroup, MFMA from LDS: 3 launches per candidate) or by k_init_m on many
-    // workgroups (4 launches); OVP_DINIT_FUSED_M=1 selects the former
-    static const bool fused_m = getenv("OVP_DINIT_FUSED_M") != nullptr;
-    dp.skip_m = fused_m ? 0 : 1;
-    dp.full = fused_m ? ovp_dinit_full_stage(m, ncal, n, dp.n_pad) : 0;
     dp.n = n;
     dp.prev_res = l ? dres0 + res_doubles * (l - 1) : nullptr;
     dp.ids = (const int*)(d + o_id) + (size_t)l * cols_max;
     memcpy(dp.idv, (const int*)(h + o_id) + (size_t)l * cols_max, sizeof(int) * cols);
     dp.res = dres0 + res_doubles * l;
-    HIPCHK(ovp_launch_dinit_rows(&dp, ovp_dinit_rows_lds(m, ncal, dp.n_pad, dp.full), s));
-    if (dp.skip_m) HIPCHK(ovp_launch_init_m(c->P, ld, n, dp.ids, cols, dHt, rows, dM, s));
+    HIPCHK(ovp_launch_dinit_rows(&dp, ovp_dinit_rows_lds(m, ncal), s));
+    HIPCHK(ovp_launch_init_m(c->P, ld, n, dp.ids, cols, dHt, rows, dM, s));  // M = P[:, ids] H_all^T on many workgroups
     // chi2 of the update rows with dof = all rows (StateHelper.cpp:471), initialize_invertible, update in place
     const double thr = o->chi2_multiplier * ovp_chi2_quantile_095(rows);
     HIPCHK(ovp_launch_init_core(c->P, ld, n, dp.ids, cols, dHt, 3, rup, dM, dHinv, dRk, dresid, 1.0, thr, dLi, dy, dp.res, s));
     HIPCHK(ovp_launch_init_update(c->P, c->P, ld, n + 3, dM, rows, 3, rup, dLi, dy, dp.res, dp.res + 4, s));
   }
   dp.cand = -1;
-  dp.skip_m = 1;
-  dp.full = 0;
   dp.n = (int)n_end;
   dp.prev_res = dres0 + res_doubles * (L - 1);
   HIPCHK(ovp_launch_dinit_rows(&dp, 64, s));

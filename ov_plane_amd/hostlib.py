@@ -104,6 +104,11 @@ def run_initialize(sc, order, H_R, H_L, res, r_iso, chi2_mult, new_value0):
     return out
 
 
+def set_slam_force_dense(on: bool):
+    """UpdaterSLAM::update through its dense form (the fallback of batches the device entry refuses) until switched off."""
+    lib().ovph_set_slam_force_dense(C.c_int(1 if on else 0))
+
+
 def run_updater(sc, mode, const_init_multi=5.0, const_init_chi2=1.0, fit_planes=None, slam=None, slam_rep=None,
                 feat_rep_slam=None):
     """Drives the C++ host mirrors on a synth scene.

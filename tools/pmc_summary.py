@@ -11,6 +11,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ov_plane_amd.build import source_tree_hash  # noqa: E402
+
 
 def main():
     out, note, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
@@ -30,7 +33,9 @@ def main():
             e["launches"] = len(disp)
         kernels[k] = e
     with open(out, "w") as fh:
-        json.dump({"note": note, "kernels": kernels}, fh, indent=1)
+        # source_hash: identity of the kernel sources the passes ran on (ov_plane_amd/build.py); bench.py quotes this file only when
+        # it equals the running tree's
+        json.dump({"note": note, "source_hash": source_tree_hash(), "kernels": kernels}, fh, indent=1)
     for k, e in kernels.items():
         print(k[:70], e)
 

@@ -3,8 +3,12 @@
 name, calls, total / average / min / max duration in microseconds, share of the GPU time, launch geometry and register counts.
 Usage: python tools/rocpd_stats.py RESULTS.db [OUT.csv]"""
 import csv
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ov_plane_amd.build import source_tree_hash  # noqa: E402
 
 
 def main():
@@ -15,6 +19,7 @@ def main():
         "order by 3 desc"))
     tot = float(sum(r[2] for r in rows)) or 1.0
     out = open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout
+    out.write("# source_hash %s (ov_plane_amd/build.py: source_tree_hash - the kernel sources this run was taken on)\n" % source_tree_hash())
     w = csv.writer(out)
     w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "MinUs", "MaxUs", "Percentage", "GridX", "WorkgroupX", "LDS",
                 "VGPR", "AGPR", "SGPR", "Scratch"])
