@@ -6,8 +6,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ovp_api.hip", "k_feat.hip", "k_gram.hip", "k_ekf.hip", "k_init.hip", "k_tile.hip", "k_chol2.hip", "k_plane.hip", "k_plane2.hip", "k_triang.hip", "k_planefit.hip", "k_slam.hip", "k_dinit.hip"]
-HEADERS = ["ovp_dev.h", "ovp_kernels.h", "ovp_feat_model.h", "k_chol2.h", "k_plane2.h", "k_tile_body.h", "k_dpp.h", "k_slam.h", "k_dinit.h", os.path.join("..", "..", "include", "ovplane_hip.h")]
+SOURCES = ["ovp_api_ctx.hip", "ovp_api_point.hip", "ovp_api_rccl.hip", "ovp_api_plane.hip", "ovp_api_slam.hip", "k_feat.hip", "k_gram.hip", "k_ekf.hip", "k_init.hip", "k_tile.hip", "k_chol2.hip", "k_plane.hip", "k_plane2.hip", "k_triang.hip", "k_planefit.hip", "k_slam.hip", "k_dinit.hip"]
+HEADERS = ["ovp_ctx.h", "ovp_dev.h", "ovp_kernels.h", "ovp_feat_model.h", "k_chol2.h", "k_plane2.h", "k_tile_body.h", "k_dpp.h", "k_slam.h", "k_dinit.h", os.path.join("..", "..", "include", "ovplane_hip.h")]
 OUT = os.path.join(_HERE, "libovplane_hip.so")
 
 

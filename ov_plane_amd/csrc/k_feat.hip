@@ -1022,7 +1022,7 @@ static bool k1_through_scratch() { return getenv("OVP_K1_BSCR") != nullptr; }  /
 
 extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t stream) {
   if (p->n_feats <= 0) return hipSuccess;
-  if (p->max_meas <= 30 && !getenv("OVP_K1_LEGACY")) {
+  if (p->max_meas <= 30) {
     if (k1_through_scratch())
       hipLaunchKernelGGL((ovp::k_feat_gate<true, false>), dim3(p->n_feats), dim3(64), 0, stream, *p);
     else
@@ -1035,23 +1035,15 @@ extern "C" hipError_t ovp_launch_feat_gate(const ovp::FeatParams* p, hipStream_t
 
 // 1 if ovp_launch_feat_chol can take this batch / matrix (otherwise: ovp_launch_feat_gate + ovp_launch_tilechol)
 extern "C" int ovp_feat_chol_supported(const ovp::FeatParams* p, int n) {
-  static const bool off = getenv("OVP_K1_UNFUSED") != nullptr || getenv("OVP_K1_LEGACY") != nullptr;
   const int nt = (n + 15) >> 4;
-  return !off && p->n_feats > 0 && p->max_meas <= 30 && nt <= OVP_TC_MAX_TILES;
+  return p->n_feats > 0 && p->max_meas <= 30 && nt <= OVP_TC_MAX_TILES;
 }
 
 // features the fused-shape launch takes in ONE round while leaving a CU per XCD to a kernel on another stream
 extern "C" int ovp_feat_chol_side_capacity(void) { return 247 * 8; }
 
 extern "C" hipError_t ovp_launch_feat_chol(const ovp::FeatParams* p, const ovp::CholJob* c_in, hipStream_t stream) {
-  static const bool dbg_nochol = getenv("OVP_DBG_FUSED_NOCHOL") != nullptr;  // timing experiment only (results are wrong)
-  ovp::CholJob cj = *c_in;
-  if (dbg_nochol) cj.n = 0;
-  const ovp::CholJob* c = &cj;
-  static const bool dbg_nofeat = getenv("OVP_DBG_FUSED_NOFEAT") != nullptr;  // timing experiment only (results are wrong)
-  ovp::FeatParams pf = *p;
-  if (dbg_nofeat) pf.n_feats = 1;
-  p = &pf;
+  const ovp::CholJob* c = c_in;
   const int F = p->n_feats;
   // feature workgroups of one round: 256 CUs, one of them factorizes.  Without a factorization in workgroup 0 (c_in->n == 0 while the
   // caller runs chol(P) as a kernel of its own on a side stream, see ovp_feat_chol_side_capacity) the round is 247 workgroups:

@@ -444,16 +444,6 @@ hipError_t ovp_launch_gram_pair(const double* rec, int n_clones, int n_feats, in
   j.rows_per_split = rps;
   j.part = part;
   *n_split_used = ns;
-  static const int dbg = getenv("OVP_DBG_GRAM") ? atoi(getenv("OVP_DBG_GRAM")) : 0;  // timing experiments (wrong results)
-  if (dbg == 1) {
-    hipLaunchKernelGGL(ovp::k_gram_pair, dim3(n_chunks * n_clones), dim3(256), 0, stream, j);
-    return hipGetLastError();
-  }
-  if (dbg == 2) {
-    j.n_chunks = 0;
-    hipLaunchKernelGGL(ovp::k_gram_pair, dim3(n_macro * ns), dim3(256), 0, stream, j);
-    return hipGetLastError();
-  }
   hipLaunchKernelGGL(ovp::k_gram_pair, dim3(n_chunks * n_clones + n_macro * ns), dim3(256), 0, stream, j);
   return hipGetLastError();
 }

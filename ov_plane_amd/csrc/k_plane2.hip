@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_select_copy(double* __restrict__ dst, c
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Plane loop on a sub-state (state above the tile factorization's limit, ovp_api.hip: plane_update_substate).  The loop runs on the
+// Plane loop on a sub-state (state above the tile factorization's limit, ovp_api_plane.hip: plane_update_substate).  The loop runs on the
 // ns involved columns s; the correction of the WHOLE state for an accepted plane k is dx_k = P0[:, s] u_k with
 //     u_k = (I + A^(k) P0ss)^-1 b_k = b_k - A^(k) dx_k[s],        A^(k) = sum of the pairs accepted so far including plane k,
 // (push-through identity; no solve with P0ss).  One block per row r of the pair: Asum[r, :] += A_k[r, :], u[r] = b_k[r] - Asum[r, :] dx.

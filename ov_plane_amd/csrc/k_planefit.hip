@@ -25,7 +25,7 @@
 #include <cstring>
 #include <vector>
 
-extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);  // ovp_api.hip: pinned host + device block per context
+extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);  // ovp_api_ctx.hip: pinned host + device block per context
 
 namespace ovp {
 

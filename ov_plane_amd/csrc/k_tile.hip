@@ -252,11 +252,10 @@ hipError_t ovp_launch_tilechol_unless(const double* A, double* L, double* Dinv, 
   const int ntiles = nt * (nt + 1) / 2;
   const int slots = (ntiles + ovp::TC_TILE_WAVES - 1) / ovp::TC_TILE_WAVES;
   const size_t shmem = ((size_t)(2 + nt + ovp::TC_WAVES) * ovp::TSZ + 256) * sizeof(double) + 16;
-  static const bool force25 = getenv("OVP_TC_FORCE25") != nullptr;  // diagnostics: cost of the per-slot tests
-  if (slots <= 15 && !force25) {
+  if (slots <= 15) {
     hipLaunchKernelGGL((ovp::k_tilechol<15>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
                        flag, add_identity, ovp_dbg_tilechol_skip, cond);
-  } else if (slots <= 18 && !force25) {  // N <= 240: still without register spills
+  } else if (slots <= 18) {  // N <= 240: still without register spills
     hipLaunchKernelGGL((ovp::k_tilechol<18>), dim3(1), dim3(ovp::TC_WAVES * 64), shmem, stream, A, L, Dinv, Lpack, n, ld,
                        flag, add_identity, ovp_dbg_tilechol_skip, cond);
   } else if (slots <= 25) {

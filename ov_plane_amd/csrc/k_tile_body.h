@@ -171,7 +171,7 @@ __device__ __forceinline__ void tilechol_body(const double* __restrict__ A, doub
   // Lr[n - 1 - r][c] = chol(J A J)[r][c] (J = exchange matrix): Lr Lr^T = A, and column j of Lr is zero below row n - 1 - j.
   // A point update whose information matrix lives on the TRAILING columns [s0, n) of the state (clones and calibration behind
   // the IMU block) then has  T = I + Lr^T A Lr = blockdiag(T_lead, I)  with a leading block of n - s0 columns - in the state's
-  // own order, without a permutation of P (ovp_api.hip: ekf_from_gram).
+  // own order, without a permutation of P (ovp_api_point.hip: ekf_from_gram).
   const int nt = (n + 15) >> 4;
   const int ntiles = nt * (nt + 1) / 2;
   double* Dbuf = lds;

@@ -856,7 +856,7 @@ def test_plane_loop_with_slam_landmarks_matches_oracle(hiplib, oracle, kw, k_row
 def test_plane_loop_above_the_factorization_limit_runs_on_the_involved_columns(hiplib, oracle, kw, k_rows):
     """update/UpdaterMSCKF.cpp:413-649 has no size limit.  States above the tile factorization (config/sim shape: 11 clones, 60
     landmarks, 12 planes in the state -> N = 312; 30 clones + 27 landmarks -> N = 300) run the plane loop on the columns its planes
-    involve and carry the rest along (ovp_api.hip: plane_update_substate): decisions (the oracle's imposed where the gate is
+    involve and carry the rest along (ovp_api_plane.hip: plane_update_substate): decisions (the oracle's imposed where the gate is
     active), state corrections - also of the variables no plane touches (IMU state, free landmarks) -, covariance of the whole
     state against the oracle."""
     from ov_plane_amd.synth import slam_rows_on_planes
