@@ -132,6 +132,8 @@ def test_no_dpp_read_after_valu_write_hazard_in_the_built_kernels():
     n_total = 0
     for o in objs:
         bad, n, ncos = chk.check_object(o)
-        assert ncos >= 1 and not bad, bad
+        assert not bad, bad
+        # every kernel translation unit carries a gfx950 code object; the entry-point files (ovp_api_*.hip) may be host code only
+        assert ncos >= 1 or os.path.basename(o).startswith("ovp_api_"), o
         n_total += n
     assert n_total > 10000  # the chains are there (k_chol2 alone holds ~16 K DPP instructions)
