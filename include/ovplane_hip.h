@@ -148,6 +148,19 @@ int ovp_batch_set_range(ovp_ctx *ctx, int lo, int hi);
 int ovp_msckf_update(ovp_ctx *ctx, const ovp_update_opts *opts, double *dx_host, uint8_t *accepted_host,
                      double *chi2_host, ovp_update_info *info);
 
+/* Features the batch format cannot carry - a track of more than OVP_MAX_MEAS observations, observations of a camera other than
+ * camera 0 (the reference loops over every camera's measurements of a feature, update/UpdaterHelper.cpp:335-344, and stacks any
+ * number of them, update/UpdaterMSCKF.cpp:686-691) - join the SAME update as dense blocks: block k is the feature's system after
+ * the nullspace projection, H_k (rows[k] x cols[k], column-major, concatenated in H), its state columns (col_ids, Type::id() +
+ * offset, concatenated) and residual (res, concatenated), noise already whitened (R = I).  The call gates every block against the
+ * RESIDENT covariance - chi2 = r^T (H P H^T + I)^-1 r <= chi2_multiplier * quantile_0.95(rows), update/UpdaterMSCKF.cpp:739-757 -
+ * and keeps the information pair of the accepted ones; the next ovp_msckf_update / ovp_msckf_build_gate_gram_async of the context
+ * adds it to the pair of the batch, so batch features and dense blocks are ONE EKF update as in the reference.  Any call that
+ * writes the covariance in between drops the pending pair.  Slow path (marginal of the involved columns to the host, gates on
+ * the host): meant for the few features per frame that need it.  accepted / chi2: per block, may be NULL. */
+int ovp_msckf_dense_blocks(ovp_ctx *ctx, double chi2_multiplier, int n_blocks, const int *rows, const int *cols, const double *H,
+                           const int *col_ids, const double *res, uint8_t *accepted, double *chi2);
+
 /* Staged form of the same step, for feature-sharded multi-GPU runs:
  *   stage 1 (per rank, local shard): build + project + gate + local information pair
  *            Ab_dev = [A | b], A = sum_f Hp_f^T Hp_f (n_state x n_state), b = sum_f Hp_f^T r_f,

@@ -178,18 +178,31 @@ def feature_jacobian_full(sc, f, sigma_c=None, p_FinG=None, cp=None, cp_fej=None
     m = int(sc.n_meas[f])
     idx = sc.clone_idx[f, :m]
     ids = sc.ids
+    # which camera took measurement k (synth.make_stereo_scene: sc.cam_idx, sc.cam1); UpdaterHelper.cpp:335-344 loops over the
+    # cameras of a feature, each with its own extrinsics / intrinsics (State.cpp:52-72)
+    cam_of = sc.cam_idx[f, :m] if "cam_idx" in sc else np.zeros(m, dtype=np.int64)
+    cams = sorted(set(int(c) for c in cam_of)) or [0]
+
+    def cam_tables(c):
+        if c == 0:
+            return quat_2_rot(st["calib_q"]), np.asarray(st["calib_p"]), np.asarray(st["intr"]), ids["calib"], ids["intr"]
+        c1 = state["cam1"] if (state is not None and "cam1" in state) else sc.cam1
+        return quat_2_rot(c1["calib_q"]), np.asarray(c1["calib_p"]), np.asarray(c1["intr"]), ids["calib1"], ids["intr1"]
+
     # column bookkeeping (UpdaterHelper.cpp:205-277)
     order = []
     col_of = {}
     tot = 0
-    if o["do_calib_pose"]:
-        col_of["calib"] = tot
-        order.append((int(ids["calib"]), 6))
-        tot += 6
-    if o["do_calib_intr"]:
-        col_of["intr"] = tot
-        order.append((int(ids["intr"]), 8))
-        tot += 8
+    for c_ in cams:
+        _, _, _, cid_, iid_ = cam_tables(c_)
+        if o["do_calib_pose"]:
+            col_of[("calib", c_)] = tot
+            order.append((int(cid_), 6))
+            tot += 6
+        if o["do_calib_intr"]:
+            col_of[("intr", c_)] = tot
+            order.append((int(iid_), 8))
+            tot += 8
     for k in range(m):
         ci = int(idx[k])
         if ("c", ci) not in col_of:
@@ -210,12 +223,11 @@ def feature_jacobian_full(sc, f, sigma_c=None, p_FinG=None, cp=None, cp_fej=None
     H_f = np.zeros((meas, jac))
     H_x = np.zeros((meas, tot))
     white = 1.0 / o["sigma_px"]
-    R_ItoC = quat_2_rot(st["calib_q"])
-    p_IinC = np.asarray(st["calib_p"])
-    intr = np.asarray(st["intr"])
     c = 0
     for k in range(m):
         ci = int(idx[k])
+        cam = int(cam_of[k])
+        R_ItoC, p_IinC, intr, _, _ = cam_tables(cam)
         R_GtoIi = quat_2_rot(st["clone_q"][ci])
         p_IiinG = st["clone_p"][ci]
         p_FinIi = R_GtoIi @ (p_f - p_IiinG)
@@ -245,10 +257,10 @@ def feature_jacobian_full(sc, f, sigma_c=None, p_FinG=None, cp=None, cp_fej=None
             dpfc_dcalib = np.zeros((3, 6))
             dpfc_dcalib[:, :3] = skew(p_FinCi - p_IinC)
             dpfc_dcalib[:, 3:] = np.eye(3)
-            cc = col_of["calib"]
+            cc = col_of[("calib", cam)]
             H_x[c : c + 2, cc : cc + 6] += white * dz_dpfc @ dpfc_dcalib
         if o["do_calib_intr"]:
-            cc = col_of["intr"]
+            cc = col_of[("intr", cam)]
             H_x[c : c + 2, cc : cc + 8] = white * dz_dzeta
         c += 2
     if planeid != 0:
@@ -651,3 +663,38 @@ def triangulate_feature(sc, f, refine=True, opts=None):
         if pA[2] < o["min_dist"] or pA[2] > o["max_dist"] or np.linalg.norm(pA) / base > o["max_baseline"]:
             return False, np.zeros(3)
     return True, R_GtoA.T @ pA + p_AinG
+
+
+# ------------------------------------------------------------------------------------------------
+# The point update of UpdaterMSCKF::update (update/UpdaterMSCKF.cpp:695-814) in dense numpy, any number of cameras: rows of every
+# feature over all of its measurements, nullspace projection (QR), gate against the prior, stacking, StateHelper::EKFUpdate
+# (state/StateHelper.cpp:121-202, R = I).  The reference for scenes the C oracle's record format cannot carry (two cameras).
+# ------------------------------------------------------------------------------------------------
+def msckf_point_update_dense(sc, chi2_table):
+    N = sc.N
+    P = np.asarray(sc.P, dtype=np.float64)
+    Hs, rs, accepted, chi2 = [], [], np.zeros(sc.F, dtype=bool), np.zeros(sc.F)
+    for f in range(sc.F):
+        if int(sc.n_meas[f]) < 2:
+            continue
+        H_f, H_x, res, order = feature_jacobian_full(sc, f)
+        Q, _ = np.linalg.qr(H_f, mode="complete")
+        Nf = Q[:, H_f.shape[1]:]
+        Ho, ro = Nf.T @ H_x, Nf.T @ res
+        cols = order_cols(order)
+        S = Ho @ P[np.ix_(cols, cols)] @ Ho.T + np.eye(Ho.shape[0])
+        chi2[f] = float(ro @ np.linalg.solve(S, ro))
+        if chi2[f] > sc.opts["chi2_mult"] * chi2_table[Ho.shape[0]]:
+            continue
+        accepted[f] = True
+        Hb = np.zeros((Ho.shape[0], N))
+        Hb[:, cols] = Ho
+        Hs.append(Hb)
+        rs.append(ro)
+    if not Hs:
+        return dict(accepted=accepted, chi2=chi2, dx=np.zeros(N), P=P.copy())
+    H, r = np.vstack(Hs), np.concatenate(rs)
+    S = H @ P @ H.T + np.eye(H.shape[0])
+    K = np.linalg.solve(S, H @ P).T
+    Pn = P - K @ H @ P
+    return dict(accepted=accepted, chi2=chi2, dx=K @ r, P=0.5 * (Pn + Pn.T))

@@ -140,7 +140,7 @@ EXPORTS = [
     "ovp_ctx_stream", "ovp_cov_initialize", "ovp_debug_chol2", "ovp_debug_chol2_floor", "ovp_plane_kernel_timer", "ovp_host_timing", "ovp_triang_defaults", "ovp_triangulate", "ovp_plane_fitting", "ovp_plane_optimize",
     "ovp_slam_update", "ovp_cov_clone_jitter", "ovp_rccl_unique_id", "ovp_rccl_comm_create", "ovp_rccl_comm_destroy",
     "ovp_rccl_allreduce_gram", "ovp_msckf_update_sharded", "ovp_slam_delayed_init", "ovp_shard_range", "ovp_shard_range_of_mask",
-    "ovp_rccl_gather_decisions",
+    "ovp_rccl_gather_decisions", "ovp_msckf_dense_blocks",
 ]
 
 
@@ -185,6 +185,8 @@ def lib():
         L.ovp_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.ovp_rccl_allreduce_gram.argtypes = [C.c_void_p, C.c_void_p]
         L.ovp_shard_range.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ovp_msckf_dense_blocks.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
         L.ovp_shard_range_of_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ovp_rccl_gather_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ovp_msckf_update_sharded.argtypes = [C.c_void_p, C.POINTER(UpdateOpts), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -443,6 +445,22 @@ class Context:
         if rc != 0 and raise_on_error:
             raise OvpError(rc, "ovp_msckf_update")
         return dict(dx=dx, accepted=acc[: self.n_feats].astype(bool), chi2=chi2[: self.n_feats], info=info, rc=rc)
+
+    def msckf_dense_blocks(self, chi2_mult, blocks):
+        """ovp_msckf_dense_blocks: blocks = list of (H [rows, cols], col_ids [cols], res [rows]) - features the batch format cannot
+        carry, after the nullspace projection.  Returns (accepted [bool], chi2); the accepted ones join the next msckf_update."""
+        nb = len(blocks)
+        rows = np.array([b[0].shape[0] for b in blocks], dtype=np.int32)
+        cols = np.array([b[0].shape[1] for b in blocks], dtype=np.int32)
+        H = np.concatenate([np.asfortranarray(b[0], dtype=np.float64).ravel(order="F") for b in blocks]) if nb else np.zeros(1)
+        ids = np.concatenate([np.asarray(b[1], dtype=np.int32) for b in blocks]) if nb else np.zeros(1, dtype=np.int32)
+        res = np.concatenate([np.asarray(b[2], dtype=np.float64) for b in blocks]) if nb else np.zeros(1)
+        acc = np.zeros(max(nb, 1), dtype=np.uint8)
+        chi2 = np.zeros(max(nb, 1))
+        _chk(lib().ovp_msckf_dense_blocks(self._h, C.c_double(float(chi2_mult)), nb, rows.ctypes.data, cols.ctypes.data, H.ctypes.data,
+                                          np.ascontiguousarray(ids).ctypes.data, res.ctypes.data, acc.ctypes.data, chi2.ctypes.data),
+             "ovp_msckf_dense_blocks")
+        return acc[:nb].astype(bool), chi2[:nb]
 
     def msckf_update_sharded(self, opts: UpdateOpts, comm, rank=0, world=1, raise_on_error=True):
         """ovp_msckf_update_sharded: this rank's share of the point features -> pair -> ncclAllReduce -> update (comm: handle from

@@ -39,6 +39,18 @@ extern "C" void ovph_set_plane_fit(int enable, int min_feat, double max_cond, in
   g_fit_variant = shuffle_variant;
 }
 
+// next ovph_run_msckf_update: a second camera (num_cameras = 2) with these calibration values; cam_of_meas[F][M] says which camera
+// took each measurement of the feature batch
+static const double *g_cam1_q = nullptr, *g_cam1_p = nullptr, *g_cam1_intr = nullptr;
+static const int *g_cam_of_meas = nullptr;
+static double g_last_cam1[15];  // [q (4) | p (3) | intrinsics (8)] of camera 1 after the last run that had one
+extern "C" void ovph_last_second_camera(double *out15) { memcpy(out15, g_last_cam1, sizeof(g_last_cam1)); }
+extern "C" void ovph_set_second_camera(const double *calib_q, const double *calib_p, const double *intr, const int *cam_of_meas) {
+  g_cam1_q = calib_q;
+  g_cam1_p = calib_p;
+  g_cam1_intr = intr;
+  g_cam_of_meas = cam_of_meas;
+}
 // next ovph_run_msckf_update: the State lives on this device and the updater takes the sharded point loop on this communicator
 static void *g_comm = nullptr;
 static int g_comm_rank = 0, g_comm_world = 1, g_device = 0, g_last_shard[2] = {0, 0};
@@ -78,8 +90,20 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   so.max_state_size = N + 8;
   so.max_features = F + 8;
   so.gpu_device = g_device;
+  if (g_cam1_q) so.num_cameras = 2;
   auto state = std::make_shared<State>(so);
   state->_cam_fisheye[0] = g_fisheye != 0;
+  if (g_cam1_q) {
+    VectorXd v(7, 1), iv(8, 1);
+    for (int k = 0; k < 4; ++k) v(k) = g_cam1_q[k];
+    for (int k = 0; k < 3; ++k) v(4 + k) = g_cam1_p[k];
+    for (int k = 0; k < 8; ++k) iv(k) = g_cam1_intr[k];
+    state->_calib_IMUtoCAM.at(1)->set_value(v);
+    state->_calib_IMUtoCAM.at(1)->set_fej(v);
+    state->_cam_intrinsics.at(1)->set_value(iv);
+    state->_cam_intrinsics.at(1)->set_fej(iv);
+    state->_cam_fisheye[1] = false;
+  }
   g_fisheye = 0;
   // calibration values
   {
@@ -139,6 +163,10 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
     order.push_back(state->_calib_dt_CAMtoIMU);
     order.push_back(state->_calib_IMUtoCAM.at(0));
     order.push_back(state->_cam_intrinsics.at(0));
+    if (g_cam1_q) {
+      order.push_back(state->_calib_IMUtoCAM.at(1));
+      order.push_back(state->_cam_intrinsics.at(1));
+    }
     for (auto &c : state->_clones_IMU) order.push_back(c.second);
     for (auto &p : planes) order.push_back(p);
     MatrixXd Pm(N, N);
@@ -155,6 +183,7 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
       ft->timestamps.push_back(times[clone_idx[(size_t)f * M + k]]);
       ft->uvs.push_back(uv[((size_t)f * M + k) * 2]);
       ft->uvs.push_back(uv[((size_t)f * M + k) * 2 + 1]);
+      if (g_cam_of_meas) ft->cam_ids.push_back(g_cam_of_meas[(size_t)f * M + k]);
     }
     if (g_uv_norm) {
       for (int k = 0; k < n_meas[f]; ++k) {
@@ -176,6 +205,13 @@ extern "C" int ovph_run_msckf_update(int C, const double *clone_q, const double 
   if (g_comm || g_comm_world > 1) updater.set_communicator(g_comm, g_comm_rank, g_comm_world);
   updater.update(state, fv, fextra, fused, feat2plane);
   updater.last_shard(g_last_shard[0], g_last_shard[1]);
+  if (g_cam1_q) {
+    memcpy(g_last_cam1, state->_calib_IMUtoCAM.at(1)->quat(), 4 * sizeof(double));
+    memcpy(g_last_cam1 + 4, state->_calib_IMUtoCAM.at(1)->pos(), 3 * sizeof(double));
+    memcpy(g_last_cam1 + 7, state->_cam_intrinsics.at(1)->value().data(), 8 * sizeof(double));
+  }
+  g_cam1_q = g_cam1_p = g_cam1_intr = nullptr;
+  g_cam_of_meas = nullptr;
   g_comm = nullptr;
   g_comm_rank = 0;
   g_comm_world = 1;

@@ -674,10 +674,12 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     auto &ft = **it0;
     std::vector<float> uv2, uvn2;
     std::vector<double> ts2;
+    std::vector<int> cam2;
     const bool has_norm = ft.uvs_norm.size() == ft.uvs.size();
     for (size_t k = 0; k < ft.timestamps.size(); ++k)
       if (clone_slot.count(ft.timestamps[k])) {
         ts2.push_back(ft.timestamps[k]);
+        if (!ft.cam_ids.empty()) cam2.push_back(ft.cam_of(k));
         uv2.push_back(ft.uvs[2 * k]);
         uv2.push_back(ft.uvs[2 * k + 1]);
         if (has_norm) {
@@ -686,6 +688,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
         }
       }
     ft.timestamps = ts2;
+    ft.cam_ids = cam2;
     ft.uvs = uv2;
     ft.uvs_norm = uvn2;
     if (ts2.size() < 2) {
@@ -731,19 +734,20 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     st.cam_fisheye = (state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0)) ? 1 : 0;
     gpu_check(ovp_state_upload(state->_gpu, &st), "ovp_state_upload");
   };
+  // what the device batch can carry: camera 0's measurements, at most OVP_MAX_MEAS of them (one wavefront's rows).  Everything
+  // else takes the dense side channel of the point update below (ovp_msckf_dense_blocks); in the uploads in front of it (device
+  // triangulation, plane loop) such a feature is present with NO measurements, i.e. it takes no part there
+  auto fits_batch = [](const ov_core::Feature &f) { return f.only_camera0() && (int)f.timestamps.size() <= OVP_MAX_MEAS; };
   auto upload_batch = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv) {
     const int F = (int)fv.size();
     int M = 1;
-    for (auto &f : fv) M = std::max(M, (int)f->timestamps.size());
-    if (M > OVP_MAX_MEAS) {
-      PRINT_ERROR("UpdaterMSCKF::update() - more than %d observations per feature are not supported\n", OVP_MAX_MEAS);
-      std::exit(EXIT_FAILURE);
-    }
+    for (auto &f : fv)
+      if (fits_batch(*f)) M = std::max(M, (int)f->timestamps.size());
     std::vector<float> uv((size_t)F * M * 2, 0.f);
     std::vector<int> cidx((size_t)F * M, -1), nm(F);
     std::vector<double> pf((size_t)F * 3);
     for (int f = 0; f < F; ++f) {
-      nm[f] = (int)fv[f]->timestamps.size();
+      nm[f] = fits_batch(*fv[f]) ? (int)fv[f]->timestamps.size() : 0;
       for (int k = 0; k < nm[f]; ++k) {
         cidx[(size_t)f * M + k] = clone_slot.at(fv[f]->timestamps[k]);
         uv[((size_t)f * M + k) * 2] = fv[f]->uvs[2 * k];
@@ -837,10 +841,12 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
         auto &ft = **itx;
         std::vector<float> uv2, uvn2;
         std::vector<double> ts2;
+        std::vector<int> cam2;
         const bool has_norm = ft.uvs_norm.size() == ft.uvs.size();
         for (size_t k = 0; k < ft.timestamps.size(); ++k)
           if (clone_slot.count(ft.timestamps[k])) {
             ts2.push_back(ft.timestamps[k]);
+            if (!ft.cam_ids.empty()) cam2.push_back(ft.cam_of(k));
             uv2.push_back(ft.uvs[2 * k]);
             uv2.push_back(ft.uvs[2 * k + 1]);
             if (has_norm) {
@@ -849,6 +855,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
             }
           }
         ft.timestamps = ts2;
+        ft.cam_ids = cam2;
         ft.uvs = uv2;
         ft.uvs_norm = uvn2;
         if (ts2.size() < 2) itx = feature_vec_extra.erase(itx);
@@ -977,7 +984,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
         if (fitted_planes.count(it->second) && !plane_feat_kept.count(feature_vec[f]->featid)) continue;  // not an inlier of the fit
         // the plane kernels take a feature's 2 m bearing rows in one wavefront (the constraint row is wave-uniform): a track with
         // more than 32 observations keeps its bearing measurements but not the plane constraint (it goes through the point loop)
-        if (feature_vec[f]->timestamps.size() > 32) continue;
+        if (feature_vec[f]->timestamps.size() > 32 || !feature_vec[f]->only_camera0()) continue;
         auto pos = std::find(used_planes.begin(), used_planes.end(), it->second);
         if (pos != used_planes.end()) pof[f] = 1 + (int)(pos - used_planes.begin());
       }
@@ -1068,7 +1075,8 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   if (tos) {
     const int F = (int)feature_vec.size();
     int M = 1;
-    for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
+    for (auto &f : feature_vec)
+      if (fits_batch(*f)) M = std::max(M, (int)f->timestamps.size());
     tr.timestamp = state->_timestamp;
     tr.C = C;
     tr.F = F;
@@ -1097,7 +1105,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     tr.n_meas.assign(F, 0);
     tr.p_FinG.assign((size_t)F * 3, 0.0);
     for (int f = 0; f < F; ++f) {
-      tr.n_meas[f] = (int)feature_vec[f]->timestamps.size();
+      tr.n_meas[f] = fits_batch(*feature_vec[f]) ? (int)feature_vec[f]->timestamps.size() : 0;
       for (int k = 0; k < tr.n_meas[f]; ++k) {
         tr.clone_idx[(size_t)f * M + k] = clone_slot.at(feature_vec[f]->timestamps[k]);
         tr.uv[((size_t)f * M + k) * 2] = feature_vec[f]->uvs[2 * k];
@@ -1113,6 +1121,42 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     tr.do_calib_intr = o.do_calib_camera_intrinsics;
   }
   std::vector<double> chi2v(tos ? feature_vec.size() : 0, 0.0);
+  // ---- features the batch format cannot carry (a second camera's measurements, a track longer than OVP_MAX_MEAS): the reference
+  // treats them like any other (:695-786 - Jacobian over every camera's measurements, nullspace projection, gate); here each
+  // becomes a dense block beside the batch and joins the same EKF update (ovp_msckf_dense_blocks) ----
+  std::vector<size_t> dense_idx;
+  for (size_t f = 0; f < feature_vec.size(); ++f)
+    if (!fits_batch(*feature_vec[f])) dense_idx.push_back(f);
+  std::vector<uint8_t> dense_ok(dense_idx.size(), 0);
+  if (!dense_idx.empty()) {
+    std::vector<int> b_rows, b_cols, b_ids;
+    std::vector<double> b_H, b_res;
+    for (size_t f : dense_idx) {
+      const ov_core::Feature &ft = *feature_vec[f];
+      UpdaterHelper::UpdaterHelperFeature hf;
+      hf.featid = ft.featid;
+      hf.uvs = ft.uvs;
+      hf.timestamps = ft.timestamps;
+      hf.cam_ids = ft.cam_ids;
+      hf.feat_representation = LandmarkRepresentation::GLOBAL_3D;  // (the projected system of an MSCKF feature does not depend on it)
+      memcpy(hf.p_FinG, ft.p_FinG, 3 * sizeof(double));
+      memcpy(hf.p_FinG_fej, ft.p_FinG, 3 * sizeof(double));  // :721-722
+      MatrixXd H_f, H_x;
+      VectorXd r;
+      std::vector<std::shared_ptr<Type>> order;
+      UpdaterHelper::get_feature_jacobian_full(state, hf, _options.sigma_pix, state->_options.sigma_constraint, H_f, H_x, r, order);
+      UpdaterHelper::nullspace_project_inplace(H_f, H_x, r);  // :730
+      b_rows.push_back(H_x.rows());
+      b_cols.push_back(H_x.cols());
+      b_H.insert(b_H.end(), H_x.data(), H_x.data() + (size_t)H_x.rows() * H_x.cols());
+      b_res.insert(b_res.end(), r.data(), r.data() + r.rows());
+      for (const auto &v : order)
+        for (int k = 0; k < v->size(); ++k) b_ids.push_back(v->id() + k);
+    }
+    gpu_check(ovp_msckf_dense_blocks(state->_gpu, _options.chi2_multipler, (int)dense_idx.size(), b_rows.data(), b_cols.data(), b_H.data(),
+                                     b_ids.data(), b_res.data(), dense_ok.data(), nullptr),
+              "ovp_msckf_dense_blocks");
+  }
   int rc;
   if (_comm || _world > 1) {
     // feature-sharded point loop: the batch above is the same on every replica; accepted / chi2 come back for this rank's share
@@ -1133,6 +1177,10 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     std::exit(EXIT_FAILURE);
   }
   gpu_check(rc, "ovp_msckf_update");
+  for (size_t i = 0; i < dense_idx.size(); ++i) {  // the dense blocks' gate decisions take their places in the vector's order
+    ok[dense_idx[i]] = dense_ok[i];
+    info.n_accepted += dense_ok[i] ? 1 : 0;
+  }
   if (tos) {
     tr.dx = dx;
     tr.accepted = ok;

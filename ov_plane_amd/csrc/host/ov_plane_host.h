@@ -190,10 +190,11 @@ private:
 // update/UpdaterHelper.h:55-157: host (dense) versions for the small SLAM / initialisation systems
 class UpdaterHelper {
 public:
-  struct UpdaterHelperFeature {  // update/UpdaterHelper.h:62-105, mono
+  struct UpdaterHelperFeature {  // update/UpdaterHelper.h:62-105 (the per-camera maps flattened: cam_ids[k] = camera of measurement k)
     size_t featid = 0;
     std::vector<float> uvs;          // [2k]
     std::vector<double> timestamps;  // [k]
+    std::vector<int> cam_ids;        // [k], empty = camera 0
     ov_type::LandmarkRepresentation::Representation feat_representation = ov_type::LandmarkRepresentation::GLOBAL_3D;
     int anchor_cam_id = -1;
     double anchor_clone_timestamp = -1;

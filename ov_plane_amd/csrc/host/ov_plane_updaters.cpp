@@ -157,7 +157,7 @@ void UpdaterHelper::get_feature_jacobian_representation(std::shared_ptr<State> s
     }
 }
 
-// ---- update/UpdaterHelper.cpp:195-513 (every landmark representation, radtan / equidistant, mono) ---
+// ---- update/UpdaterHelper.cpp:195-513 (every landmark representation, radtan / equidistant, any number of cameras) ---
 void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, UpdaterHelperFeature &feature, double sigma_px,
                                               double sigma_c, MatrixXd &H_f, MatrixXd &H_x, VectorXd &res,
                                               std::vector<std::shared_ptr<Type>> &x_order) {
@@ -170,17 +170,28 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
       if (p.first == v) return p.second;
     return -1;
   };
-  std::shared_ptr<PoseJPL> calibration = state->_calib_IMUtoCAM.at(0);
-  std::shared_ptr<Vec> distortion = state->_cam_intrinsics.at(0);
-  if (state->_options.do_calib_camera_pose) {  // :216-220
-    map_hx.push_back({calibration, total_hx});
-    x_order.push_back(calibration);
-    total_hx += calibration->size();
-  }
-  if (state->_options.do_calib_camera_intrinsics) {  // :223-227
-    map_hx.push_back({distortion, total_hx});
-    x_order.push_back(distortion);
-    total_hx += distortion->size();
+  // :205-228 every camera that measured the feature brings its extrinsics / intrinsics (when they are estimated), in camera order
+  auto cam_of = [&](int m) { return (size_t)m < feature.cam_ids.size() ? feature.cam_ids[m] : 0; };
+  {
+    std::vector<int> cams;
+    for (int m = 0; m < total_meas; m++) cams.push_back(cam_of(m));
+    if (cams.empty()) cams.push_back(0);
+    std::sort(cams.begin(), cams.end());
+    cams.erase(std::unique(cams.begin(), cams.end()), cams.end());
+    for (int cam : cams) {
+      std::shared_ptr<PoseJPL> calibration = state->_calib_IMUtoCAM.at((size_t)cam);
+      std::shared_ptr<Vec> distortion = state->_cam_intrinsics.at((size_t)cam);
+      if (state->_options.do_calib_camera_pose) {  // :216-220
+        map_hx.push_back({calibration, total_hx});
+        x_order.push_back(calibration);
+        total_hx += calibration->size();
+      }
+      if (state->_options.do_calib_camera_intrinsics) {  // :223-227
+        map_hx.push_back({distortion, total_hx});
+        x_order.push_back(distortion);
+        total_hx += distortion->size();
+      }
+    }
   }
   for (int m = 0; m < total_meas; m++) {  // :230-239
     std::shared_ptr<PoseJPL> clone_Ci = state->_clones_IMU.at(feature.timestamps[m]);
@@ -235,10 +246,14 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
   H_f = MatrixXd::Zero(meassize, jacobsize);
   H_x = MatrixXd::Zero(meassize, total_hx);
   const double white_px = 1.0 / sigma_px;
-  const double *R_ItoC = calibration->Rot();
-  const double *p_IinC = calibration->pos();
-  const double *v = distortion->value().data();
   for (int m = 0; m < total_meas; m++) {
+    // the camera that took this measurement (:335-344 loops over the cameras, then over each one's measurements)
+    const size_t cam = (size_t)cam_of(m);
+    std::shared_ptr<PoseJPL> calibration = state->_calib_IMUtoCAM.at(cam);
+    std::shared_ptr<Vec> distortion = state->_cam_intrinsics.at(cam);
+    const double *R_ItoC = calibration->Rot();
+    const double *p_IinC = calibration->pos();
+    const double *v = distortion->value().data();
     std::shared_ptr<PoseJPL> clone_Ii = state->_clones_IMU.at(feature.timestamps[m]);
     const double *R_GtoIi = clone_Ii->Rot();
     const double *p_IiinG = clone_Ii->pos();
@@ -249,7 +264,7 @@ void UpdaterHelper::get_feature_jacobian_full(std::shared_ptr<State> state, Upda
     for (int k = 0; k < 3; ++k) p_FinCi[k] += p_IinC[k];
     const double x = p_FinCi[0] / p_FinCi[2], y = p_FinCi[1] / p_FinCi[2];
     // ext CamRadtan::distort_d / CamEqui::distort_d (:365)
-    const bool fisheye = state->_cam_fisheye.count(0) && state->_cam_fisheye.at(0);
+    const bool fisheye = state->_cam_fisheye.count(cam) && state->_cam_fisheye.at(cam);
     const double r2 = x * x + y * y, r4 = r2 * r2, g = 1 + v[4] * r2 + v[5] * r4;
     double x1, y1;
     double rr = 0, th = 0, th_d = 0, inv_r = 1, cdist = 1;

@@ -443,9 +443,18 @@ namespace ov_core {
 struct Feature {
   size_t featid = 0;
   bool to_delete = false;
-  std::vector<float> uvs;          // [2*k] raw pixels of camera 0 (reference: unordered_map<cam, vector<VectorXf>>)
+  std::vector<float> uvs;          // [2*k] raw pixels (reference: unordered_map<cam, vector<VectorXf>>; here flat, cam_ids says whose)
   std::vector<float> uvs_norm;     // [2*k] undistorted normalised coordinates (filled by the tracker); empty = p_FinG is given
-  std::vector<double> timestamps;  // [k] clone timestamps of camera 0
+  std::vector<double> timestamps;  // [k] clone timestamps
+  // [k] camera of every measurement (reference: the key of the per-camera maps uvs / timestamps); empty = all of camera 0.  A
+  // feature seen by two cameras at one clone time carries two measurements with the same timestamp.
+  std::vector<int> cam_ids;
+  int cam_of(size_t k) const { return k < cam_ids.size() ? cam_ids[k] : 0; }
+  bool only_camera0() const {
+    for (int c : cam_ids)
+      if (c != 0) return false;
+    return true;
+  }
   double p_FinG[3] = {0, 0, 0};
   // anchor of the triangulated position (ext FeatureInitializer::single_triangulation: the last pose of the camera that saw
   // the feature most); -1 = triangulation has not filled it, p_FinA is then derived from p_FinG where it is needed

@@ -386,9 +386,29 @@ __global__ void k_scatter_gram(const double* __restrict__ Acc, const double* __r
     Ab[(size_t)n * lda + col_ids[j]] = bcc[j];
 }
 
+// the same with += : a second pair (the dense blocks of ovp_msckf_dense_blocks) joins the one K2 assembled.  One thread per entry,
+// every entry of Ab is touched by at most one thread (col_ids are distinct)
+__global__ void k_scatter_gram_add(const double* __restrict__ Acc, const double* __restrict__ bcc, int cols,
+                                   const int* __restrict__ col_ids, double* __restrict__ Ab, int lda, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;  // 0..cols (cols = b)
+  if (j >= cols) return;
+  if (i < cols)
+    Ab[(size_t)col_ids[i] * lda + col_ids[j]] += Acc[(size_t)i * cols + j];
+  else
+    Ab[(size_t)n * lda + col_ids[j]] += bcc[j];
+}
+
 }  // namespace ovp
 
 extern "C" {
+
+hipError_t ovp_launch_scatter_gram_add(const double* Acc, const double* bcc, int cols, const int* col_ids, double* Ab, int lda, int n,
+                                       hipStream_t stream) {
+  hipLaunchKernelGGL(ovp::k_scatter_gram_add, dim3((cols + 127) / 128, cols + 1), dim3(128), 0, stream, Acc, bcc, cols, col_ids, Ab,
+                     lda, n);
+  return hipGetLastError();
+}
 
 hipError_t ovp_launch_struct_gram(const double* rec, int n_clones, int n_feats, int rows_per_chunk, int n_chunks,
                                   double* gramS, hipStream_t stream) {

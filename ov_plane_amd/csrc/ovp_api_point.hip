@@ -337,6 +337,7 @@ static int build_gate_gram_tail_impl(ovp_ctx* c, int n, int F) {
       for (int k = 0; k < 6; ++k) ids.push_back(c->calib_id + k);
     if (fp.calmask & (0xFFu << 6))
       for (int k = 0; k < 8; ++k) ids.push_back(c->intr_id + k);
+    for (int dc : c->dense_cols) ids.push_back(dc);
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
     int rs = set_substate(c, ids);
@@ -390,6 +391,7 @@ static int build_gate_gram_tail_impl(ovp_ctx* c, int n, int F) {
       for (int cid : c->h_clone_id) s0 = cid < s0 ? cid : s0;
       if (fp.calmask & 0x3Fu) s0 = c->calib_id < s0 ? c->calib_id : s0;
       if (fp.calmask & (0xFFu << 6)) s0 = c->intr_id < s0 ? c->intr_id : s0;
+      for (int dc : c->dense_cols) s0 = dc < s0 ? dc : s0;  // (pending dense blocks may involve columns of their own: a second camera)
       if (!no_flip && s0 >= 8 && s0 < c->n) {
         cj.flip = 1;
         c->point_nl = c->n - s0;
@@ -465,10 +467,126 @@ static int build_gate_gram_tail_impl(ovp_ctx* c, int n, int F) {
   } else {
     HIPCHK(hipMemsetAsync(c->Ab, 0, sizeof(double) * (size_t)(n + 1) * c->ld, s2k));
   }
+  if (!c->dense_cols.empty()) {
+    // the pair of the dense blocks accepted by ovp_msckf_dense_blocks joins the batch's (same update, update/UpdaterMSCKF.cpp:767-814)
+    const int m = (int)c->dense_cols.size();
+    if (!c->Acc) HIPCHK(dalloc(&c->Acc, (size_t)c->n_max * c->n_max));
+    if (!c->bcc) HIPCHK(dalloc(&c->bcc, (size_t)c->n_max));
+    HIPCHK(hipMemcpyAsync(c->Acc, c->dense_A.data(), sizeof(double) * (size_t)m * m, hipMemcpyHostToDevice, s2k));
+    HIPCHK(hipMemcpyAsync(c->bcc, c->dense_b.data(), sizeof(double) * m, hipMemcpyHostToDevice, s2k));
+    HIPCHK(hipMemcpyAsync(c->idbuf, c->dense_cols.data(), sizeof(int) * m, hipMemcpyHostToDevice, s2k));
+    HIPCHK(ovp_launch_scatter_gram_add(c->Acc, c->bcc, m, c->idbuf, c->Ab, c->ld, n, s2k));
+    HIPCHK(hipStreamSynchronize(s2k));  // (the host vectors are pageable and about to be cleared; slow path)
+    c->dense_cols.clear();
+  }
   if (overlap_mode == 2) {
     // the Gram pair must be complete on the main stream when this call returns (the caller may all-reduce it there)
     HIPCHK(hipEventRecord(c->ev_join, c->stream2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  }
+  return 0;
+}
+
+// Dense blocks beside the batch (see ovplane_hip.h): gates on the host against the marginal of the involved columns, pair kept for
+// the point update that follows.
+extern "C" int ovp_msckf_dense_blocks(ovp_ctx* c, double chi2_multiplier, int n_blocks, const int* rows, const int* cols, const double* H,
+                                      const int* col_ids, const double* res, uint8_t* accepted, double* chi2) {
+  if (!c || n_blocks < 0 || (n_blocks > 0 && (!rows || !cols || !H || !col_ids || !res))) return OVP_E_ARG;
+  if (!c->have_cov) return OVP_E_STATE;
+  c->dense_cols.clear();
+  if (n_blocks == 0) return 0;
+  // union of the columns, in ascending order
+  std::vector<int> uni;
+  {
+    size_t oc = 0;
+    for (int k = 0; k < n_blocks; ++k) {
+      if (rows[k] < 1 || cols[k] < 1) return OVP_E_ARG;
+      for (int j = 0; j < cols[k]; ++j) {
+        const int id = col_ids[oc + j];
+        if (id < 0 || id >= c->n) return OVP_E_ARG;
+        uni.push_back(id);
+      }
+      oc += cols[k];
+    }
+    std::sort(uni.begin(), uni.end());
+    uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+  }
+  const int m = (int)uni.size();
+  std::vector<int> ones((size_t)m, 1), pos((size_t)c->n, -1);
+  for (int i = 0; i < m; ++i) pos[uni[i]] = i;
+  std::vector<double> Pm((size_t)m * m);
+  {
+    const int rm = ovp_cov_marginal(c, uni.data(), ones.data(), m, Pm.data());
+    if (rm) return rm;
+  }
+  std::vector<double> A((size_t)m * m, 0.0), b((size_t)m, 0.0);
+  size_t oH = 0, oc = 0, orr = 0;
+  int n_acc = 0;
+  for (int k = 0; k < n_blocks; ++k) {
+    const int r = rows[k], q = cols[k];
+    const double* Hk = H + oH;        // column-major r x q
+    const int* idk = col_ids + oc;
+    const double* rk = res + orr;
+    oH += (size_t)r * q;
+    oc += q;
+    orr += r;
+    // S = H Pm H^T + I (lower triangle), chi2 = |L^-1 r|^2
+    std::vector<double> HP((size_t)r * q, 0.0), S((size_t)r * r, 0.0), y((size_t)r);
+    for (int j = 0; j < q; ++j)
+      for (int l = 0; l < q; ++l) {
+        const double p = Pm[(size_t)pos[idk[l]] * m + pos[idk[j]]];
+        if (p == 0.0) continue;
+        for (int i = 0; i < r; ++i) HP[(size_t)j * r + i] += Hk[(size_t)l * r + i] * p;
+      }
+    for (int a = 0; a < r; ++a)
+      for (int i = a; i < r; ++i) {
+        double v = (i == a) ? 1.0 : 0.0;
+        for (int j = 0; j < q; ++j) v += HP[(size_t)j * r + i] * Hk[(size_t)j * r + a];
+        S[(size_t)a * r + i] = v;
+      }
+    double x2 = 0.0;
+    bool spd = true;
+    for (int j = 0; j < r && spd; ++j) {
+      double d = S[(size_t)j * r + j];
+      for (int l = 0; l < j; ++l) d -= S[(size_t)l * r + j] * S[(size_t)l * r + j];
+      if (!(d > 0.0)) {
+        spd = false;
+        break;
+      }
+      d = sqrt(d);
+      S[(size_t)j * r + j] = d;
+      double rj = rk[j];
+      for (int l = 0; l < j; ++l) rj -= S[(size_t)l * r + j] * y[l];
+      y[j] = rj / d;
+      x2 += y[j] * y[j];
+      for (int i = j + 1; i < r; ++i) {
+        double v = S[(size_t)j * r + i];
+        for (int l = 0; l < j; ++l) v -= S[(size_t)l * r + i] * S[(size_t)l * r + j];
+        S[(size_t)j * r + i] = v / d;
+      }
+    }
+    if (!spd) x2 = INFINITY;
+    const bool ok = x2 <= chi2_multiplier * ovp_chi2_quantile_095(r);
+    if (accepted) accepted[k] = ok ? 1 : 0;
+    if (chi2) chi2[k] = x2;
+    if (!ok) continue;
+    ++n_acc;
+    for (int j = 0; j < q; ++j) {
+      const int pj = pos[idk[j]];
+      double bj = 0.0;
+      for (int i = 0; i < r; ++i) bj += Hk[(size_t)j * r + i] * rk[i];
+      b[pj] += bj;
+      for (int l = 0; l < q; ++l) {
+        double v = 0.0;
+        for (int i = 0; i < r; ++i) v += Hk[(size_t)j * r + i] * Hk[(size_t)l * r + i];
+        A[(size_t)pos[idk[l]] * m + pj] += v;
+      }
+    }
+  }
+  if (n_acc > 0) {
+    c->dense_cols = uni;
+    c->dense_A = A;
+    c->dense_b = b;
   }
   return 0;
 }

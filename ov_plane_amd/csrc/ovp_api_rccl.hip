@@ -142,6 +142,12 @@ extern "C" int ovp_msckf_update_sharded(ovp_ctx* c, const ovp_update_opts* o, vo
   const double t0 = host_now_ms();
   const size_t pair_elems = (size_t)(c->n + 1) * c->ld;
   int rc = ovp_batch_set_range(c, lo, hi);
+  if (rank != 0 && !c->dense_cols.empty()) {
+    // a pending pair of dense blocks (ovp_msckf_dense_blocks: gated identically on every replica) is summed ONCE: rank 0 brings
+    // it, the others keep its columns (the same leading block of T everywhere) and contribute zeros
+    std::fill(c->dense_A.begin(), c->dense_A.end(), 0.0);
+    std::fill(c->dense_b.begin(), c->dense_b.end(), 0.0);
+  }
   if (!rc) rc = ovp_msckf_build_gate_gram_async(c, o);
   int rc_coll = 0;
   if (nccl_comm) {

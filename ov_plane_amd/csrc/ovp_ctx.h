@@ -28,6 +28,8 @@
 
 extern "C" int ovp_dbg_tilechol_skip;
 extern "C" {
+hipError_t ovp_launch_scatter_gram_add(const double* Acc, const double* bcc, int cols, const int* col_ids, double* Ab, int lda, int n,
+                                       hipStream_t stream);
 hipError_t ovp_launch_scatter_gram(const double* Acc, const double* bcc, int cols, const int* col_ids, double* Ab,
                                    int lda, int n, hipStream_t stream);
 hipError_t ovp_launch_gather_marginal(const double* P, int ldp, const int* cols, int m, double* out, hipStream_t stream);
@@ -159,6 +161,10 @@ struct ovp_ctx {
   double* dx = nullptr;
   int* flags = nullptr;  // [0] not spd, [1] neg diag
   double *Hd = nullptr, *Acc = nullptr, *bcc = nullptr, *resd = nullptr;  // dense-H path
+  // ovp_msckf_dense_blocks: the information pair of the accepted dense blocks over the union of their columns, waiting for the
+  // point update of the same frame (added to Ab behind K2); empty = none
+  std::vector<int> dense_cols;
+  std::vector<double> dense_A, dense_b;
   void* slam_res = nullptr;        // ovp_slam_update: per-landmark [chi2 | status]
   double* slam_hscr = nullptr;     // ... blocks that do not fit LDS
   size_t slam_res_cap = 0, slam_hscr_cap = 0;
@@ -275,6 +281,7 @@ static inline void drop_kept_factor(ovp_ctx* c) {
   c->point_nl = 0;
   c->point_boost_n = 0;
   c->kept_boost = false;
+  c->dense_cols.clear();  // (a pending dense pair was gated against the covariance that is being replaced)
 }
 
 static inline double host_now_ms() {

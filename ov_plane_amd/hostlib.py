@@ -30,6 +30,12 @@ def run_msckf_update(sc, triangulate=False, fit_planes=None, comm=None, rank=0, 
     comm / rank / world / device: UpdaterMSCKF::set_communicator + StateOptions::gpu_device - the point loop goes through
     ovp_msckf_update_sharded on this rank's share (out["shard"] = its index range of the point batch)."""
     L = lib()
+    cam1 = sc.get("cam1", None)  # synth.make_stereo_scene: dict(calib_q, calib_p, intr), sc.cam_idx [F, M]
+    if cam1 is not None:
+        c1q, c1p, c1i = (np.ascontiguousarray(cam1[k], dtype=np.float64) for k in ("calib_q", "calib_p", "intr"))
+        cam_of = np.ascontiguousarray(sc.cam_idx, dtype=np.int32)
+        L.ovph_set_second_camera(c1q.ctypes.data_as(C.c_void_p), c1p.ctypes.data_as(C.c_void_p), c1i.ctypes.data_as(C.c_void_p),
+                                 cam_of.ctypes.data_as(C.c_void_p))
     L.ovph_set_shard_comm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.ovph_set_shard_comm(C.c_void_p(comm) if comm else None, int(rank), int(world), int(device))
     L.ovph_set_fisheye(1 if sc.get("fisheye", False) else 0)
@@ -73,6 +79,10 @@ def run_msckf_update(sc, triangulate=False, fit_planes=None, comm=None, rank=0, 
     lo, hi = C.c_int(0), C.c_int(0)
     L.ovph_last_shard(C.byref(lo), C.byref(hi))
     out["shard"] = (lo.value, hi.value)
+    if cam1 is not None:
+        c1 = np.zeros(15)
+        L.ovph_last_second_camera(c1.ctypes.data_as(C.c_void_p))
+        out["cam1"] = dict(calib_q=c1[:4].copy(), calib_p=c1[4:7].copy(), intr=c1[7:].copy())
     return out
 
 

@@ -533,6 +533,78 @@ def make_scene(
     return sc
 
 
+def make_stereo_scene(C=8, F=60, seed=0, stereo_frac=0.5, baseline=0.11, **kw):
+    """A scene with TWO cameras (update/UpdaterHelper.cpp:335-344 loops over the cameras that measured a feature; state/State.cpp:52-72
+    keeps extrinsics and intrinsics per camera).  Built on make_scene: the mono scene's state gets camera 1's 14 calibration columns
+    behind camera 0's (the order State::State registers them in: [imu | dt | cam0 extrinsics, intrinsics | cam1 extrinsics,
+    intrinsics | clones ...]), a covariance extended with correlated calibration errors for them, and the first
+    round(stereo_frac * F) features are ALSO observed by camera 1 at every clone that observes them - their measurement list is
+    [camera 0's observations | camera 1's observations], `cam_idx[f, k]` says whose.  Camera 1 sits `baseline` metres beside camera 0
+    (along camera 0's x axis) with slightly different intrinsics.
+    Extra keys: cam1 = dict(calib_q, calib_p, intr, calib_id, intr_id), cam_idx [F, M] (M = 2 C), ids["calib1"], ids["intr1"]."""
+    base = make_scene(C=C, F=F, seed=seed, **kw)
+    assert base.cp.shape[0] == 0 and base.opts["do_calib_pose"] and not base.get("fisheye", False)
+    rng = np.random.default_rng(9000 + seed)
+    N0, at = int(base.N), 30            # camera 1's block goes in front of the clones (id 30 in the mono layout)
+    N = N0 + 14
+    old_of_new = np.r_[np.arange(at), -np.ones(14, dtype=np.int64), np.arange(at, N0)]
+    # covariance: P_ext = B B^T with B = [[L, 0], [M, D]] in the mono order, then permuted: camera 1's calibration errors are
+    # correlated with everything else through M
+    L = np.linalg.cholesky(base.P)
+    scale = np.r_[np.full(3, 3.0e-3), np.full(3, 5.0e-3), np.full(4, 0.5), np.full(4, 2.0e-3)]
+    M = 0.3 * scale[:, None] * rng.standard_normal((14, N0)) / np.sqrt(N0)
+    B = np.zeros((N, N))
+    B[:N0, :N0] = L
+    B[N0:, :N0] = M
+    B[N0:, N0:] = np.diag(scale)
+    Pe = np.zeros((N, N))
+    for k in range(N):
+        bk = B[:, k]
+        nz = np.nonzero(bk)[0]
+        Pe[np.ix_(nz, nz)] += np.multiply.outer(bk[nz], bk[nz])
+    Pe = 0.5 * (Pe + Pe.T)
+    src = np.where(old_of_new >= 0, old_of_new, N0 + (np.arange(N) - at))   # column of Pe (mono order, cam 1 last) for every new column
+    P = Pe[np.ix_(src, src)]
+    # camera 1: truth beside camera 0's truth, estimate = truth - (its share of the error: drawn, not tied to the mono error draw)
+    R_CtoI = T_IMU_CAM[:3, :3]
+    p_C0inI = T_IMU_CAM[:3, 3]
+    R_ItoC0 = R_CtoI.T
+    p_IinC0 = -R_ItoC0 @ p_C0inI
+    R_ItoC1_true = rotz(0.01) @ roty(-0.008) @ R_ItoC0
+    p_IinC1_true = p_IinC0 - np.array([baseline, 0.0, 0.0])
+    intr1_true = INTRINSICS * np.r_[1.01, 1.01, 0.99, 1.01, 1.0, 1.0, 1.0, 1.0]
+    e1 = 0.85 * scale * rng.standard_normal(14)
+    cam1 = dict(calib_q=quat_boxplus(rot_2_quat(R_ItoC1_true), -e1[:3]), calib_p=p_IinC1_true - e1[3:6], intr=intr1_true - e1[6:],
+                calib_id=at, intr_id=at + 6)
+    # measurements of camera 1
+    n_st = int(round(stereo_frac * F))
+    tr = base.truth
+    uv1_true, _ = project_all(tr["p_f"], tr["R"], tr["p"], R_ItoC1_true, p_IinC1_true, intr1_true, False)
+    Mm = 2 * C
+    uv = np.zeros((F, Mm, 2), dtype=np.float32)
+    clone_idx = -np.ones((F, Mm), dtype=np.int32)
+    cam_idx = np.zeros((F, Mm), dtype=np.int32)
+    n_meas = base.n_meas.copy()
+    for f in range(F):
+        m = int(base.n_meas[f])
+        uv[f, :m] = base.uv[f, :m]
+        clone_idx[f, :m] = base.clone_idx[f, :m]
+        if f < n_st:
+            ci = base.clone_idx[f, :m]
+            uv[f, m : 2 * m] = (uv1_true[f, ci] + base.opts["sigma_px"] * rng.standard_normal((m, 2))).astype(np.float32)
+            clone_idx[f, m : 2 * m] = ci
+            cam_idx[f, m : 2 * m] = 1
+            n_meas[f] = 2 * m
+    ids = dict(base.ids)
+    ids["calib1"], ids["intr1"] = at, at + 6
+    ids["clones"] = np.asarray(base.ids["clones"]) + 14
+    ids["N"] = N
+    sc = Scene(base)
+    sc.update(N=N, ids=ids, P=P, uv=uv, clone_idx=clone_idx, cam_idx=cam_idx, n_meas=n_meas, cam1=cam1, n_stereo=n_st,
+              uv_norm=np.zeros((F, Mm, 2), dtype=np.float32))
+    return sc
+
+
 def make_slam_scene(C=11, n_slam=12, seed=0, n_planes=0, ragged=True, outliers=0, wrong_plane=0, **kw):
     """Scene whose F = n_slam features are new observations of SLAM landmarks that are already in the state.
 

@@ -2964,6 +2964,89 @@ def test_native_rccl_sharded_update_on_one_rank_is_the_plain_update(hiplib, orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(C=11, F=90, seed=81, chi2_mult=1.0, ragged=True), dict(C=30, F=60, seed=82, chi2_mult=0.7)])
+def test_dense_blocks_join_the_batch_in_one_update(hiplib, oracle, kw):
+    """ovp_msckf_dense_blocks: features the batch format cannot carry (a track of more than OVP_MAX_MEAS observations, a second
+    camera's observations) enter the update as dense blocks [H after the nullspace projection | columns | residual], are gated
+    against the resident covariance like every feature (update/UpdaterMSCKF.cpp:739-757) and their information pair joins the
+    batch's: ONE EKF update (:767-814).  Here a third of an ordinary scene's features is taken out of the batch and handed over as
+    blocks (rows from the numpy restatement, nullspace by QR): gate decisions, correction and covariance must equal the update
+    with every feature in the batch, and the oracle's."""
+    from oracle import np_ref as R
+
+    capi = hiplib
+    sc = make_scene(**kw)
+    ref = oracle.msckf_point_update(sc)
+    dense = np.arange(sc.F) % 3 == 1
+    blocks = []
+    for f in np.where(dense)[0]:
+        H_f, H_x, res, order = R.feature_jacobian_full(sc, int(f))
+        Q, _ = np.linalg.qr(H_f, mode="complete")
+        N = Q[:, H_f.shape[1]:]
+        blocks.append((N.T @ H_x, R.order_cols(order), N.T @ res))
+    ctx = capi.Context(sc.N, sc.C, sc.F)
+    ctx.cov_upload(sc.P)
+    ctx.state_upload(sc)
+    acc_d, chi2_d = ctx.msckf_dense_blocks(sc.opts["chi2_mult"], blocks)
+    assert (acc_d == ref["accepted"][dense]).all() and (kw["chi2_mult"] >= 1.0 or not acc_d.all())
+    assert np.abs(chi2_d - ref["chi2"][dense]).max() <= 1e-8 * np.abs(ref["chi2"]).max()
+    ctx.batch_upload_scene(sc, np.where(~dense)[0])
+    out = ctx.msckf_update(capi.opts_from_scene(sc))
+    assert (out["accepted"] == ref["accepted"][~dense]).all()
+    assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX and relP(ctx.cov_download(), ref["P"]) < TOL_P
+    # a pending pair dies with the covariance it was gated against: the next frame's update sees only its own batch
+    ctx.cov_upload(sc.P)
+    ctx.msckf_dense_blocks(sc.opts["chi2_mult"], blocks)
+    ctx.cov_upload(sc.P)
+    ctx.batch_upload_scene(sc, np.where(~dense)[0])
+    out2 = ctx.msckf_update(capi.opts_from_scene(sc))
+    ref2 = oracle.msckf_point_update(sc, feats=np.where(~dense)[0])
+    assert np.abs(out2["dx"] - ref2["dx"]).max() < TOL_DX and relP(ctx.cov_download(), ref2["P"]) < TOL_P
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(C=8, F=60, seed=3, chi2_mult=1.0), dict(C=11, F=80, seed=5, chi2_mult=0.75, stereo_frac=0.3),
+                                dict(C=20, F=40, seed=6, chi2_mult=1.0, stereo_frac=0.5)])
+def test_updater_msckf_with_two_cameras(hiplib, oracle, kw):
+    """UpdaterMSCKF::update on a state with TWO cameras (StateOptions::num_cameras = 2: extrinsics and intrinsics per camera,
+    state/State.cpp:52-72): part of the features is seen by camera 0 only - they take the device batch (K1) - the others by both
+    cameras at every clone (update/UpdaterHelper.cpp:335-344), which the batch format cannot carry: their rows are built by the host's
+    get_feature_jacobian_full over both cameras, projected, and handed over as dense blocks (ovp_msckf_dense_blocks) that are gated
+    against the resident covariance and join the SAME EKF update.  The third scene's stereo features have 40 measurements each -
+    more than OVP_MAX_MEAS.  Reference: the dense numpy restatement of the whole update (np_ref.msckf_point_update_dense, pinned
+    against the C oracle on one camera and by finite differences on two)."""
+    from ov_plane_amd.build import build_host
+    from ov_plane_amd.synth import make_stereo_scene, quat_boxplus
+    from oracle import np_ref as R
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_stereo_scene(**kw)
+    assert sc.n_stereo > 0 and sc.n_stereo < sc.F and int(sc.n_meas.max()) == 2 * sc.C
+    tab = np.load(os.path.join(GOLD, "chi2_095_table.npy"))
+    ref = R.msckf_point_update_dense(sc, tab)
+    assert ref["accepted"].sum() >= 0.6 * sc.F and (kw["chi2_mult"] >= 1.0 or not ref["accepted"].all())
+    out = hostlib.run_msckf_update(sc)
+    assert (out["kept"] == ref["accepted"]).all() and out["deleted"].all() and not out["used"].any()
+    dx = ref["dx"]
+    ids = sc.ids
+    for i in range(sc.C):
+        cid = ids["clones"][i]
+        assert np.abs(out["clone_q"][i] - quat_boxplus(sc.clone_q[i], dx[cid:cid + 3])).max() < TOL_DX
+        assert np.abs(out["clone_p"][i] - (sc.clone_p[i] + dx[cid + 3:cid + 6])).max() < TOL_DX
+    assert np.abs(out["calib_p"] - (sc.calib_p + dx[ids["calib"] + 3:ids["calib"] + 6])).max() < TOL_DX
+    assert np.abs(out["intr"] - (sc.intr + dx[ids["intr"]:ids["intr"] + 8])).max() < TOL_DX
+    c1 = out["cam1"]
+    assert np.abs(c1["calib_q"] - quat_boxplus(sc.cam1["calib_q"], dx[ids["calib1"]:ids["calib1"] + 3])).max() < TOL_DX
+    assert np.abs(c1["calib_p"] - (sc.cam1["calib_p"] + dx[ids["calib1"] + 3:ids["calib1"] + 6])).max() < TOL_DX
+    assert np.abs(c1["intr"] - (sc.cam1["intr"] + dx[ids["intr1"]:ids["intr1"] + 8])).max() < TOL_DX
+    assert np.abs(dx[ids["calib1"]:ids["calib1"] + 14]).max() > 1e-6     # camera 1's calibration really was corrected
+    assert relP(out["P"], ref["P"]) < TOL_P
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kw", [
     dict(C=11, F=120, seed=71, chi2_mult=1.0),
     dict(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0),

@@ -95,6 +95,74 @@ def test_jacobian_finite_differences(oracle, fisheye):
         assert np.abs(num - H_f[:, k]).max() / max(1.0, np.abs(H_f[:, k]).max()) < 5e-5
 
 
+def test_two_camera_rows_by_finite_differences():
+    """Rows of a feature seen by TWO cameras (update/UpdaterHelper.cpp:335-344: one pass per camera with that camera's extrinsics and
+    intrinsics, state/State.cpp:52-72) in the numpy restatement: every column block - both cameras' calibration and intrinsics, the
+    clones (each measured twice), the feature - against central differences of the residual, and the column bookkeeping (camera
+    1's measurements touch camera 1's columns only)."""
+    from ov_plane_amd.synth import make_stereo_scene
+
+    sc = make_stereo_scene(C=5, F=4, seed=7, do_fej=False)
+    sc.clone_q_fej, sc.clone_p_fej = sc.clone_q.copy(), sc.clone_p.copy()
+    f = 0
+    m = int(sc.n_meas[f])
+    assert m == 10 and (sc.cam_idx[f, :5] == 0).all() and (sc.cam_idx[f, 5:10] == 1).all()
+    H_f, H_x, res0, order = np_ref.feature_jacobian_full(sc, f)
+    assert [o[0] for o in order[:4]] == [sc.ids["calib"], sc.ids["intr"], sc.ids["calib1"], sc.ids["intr1"]]
+    assert H_x.shape == (20, 28 + 6 * 5) and np.abs(H_x[:10, 14:28]).max() == 0.0 and np.abs(H_x[10:, :14]).max() == 0.0
+    eps = 1e-6
+
+    def resid(**over):
+        st = dict(clone_q=sc.clone_q.copy(), clone_p=sc.clone_p.copy(), calib_q=sc.calib_q, calib_p=sc.calib_p, intr=sc.intr,
+                  cam1=dict(sc.cam1))
+        st.update(over)
+        st["clone_q_fej"], st["clone_p_fej"] = st["clone_q"], st["clone_p"]
+        return np_ref.feature_jacobian_full(sc, f, state=st)[2]
+
+    col = 0
+    for sid, sz in order:
+        for k in range(sz):
+            d = np.zeros(sz)
+            d[k] = eps
+            rr = []
+            for sgn in (+1.0, -1.0):
+                dd = sgn * d
+                if sid == sc.ids["calib"]:
+                    rr.append(resid(calib_q=quat_boxplus(sc.calib_q, dd[:3]), calib_p=sc.calib_p + dd[3:]))
+                elif sid == sc.ids["intr"]:
+                    rr.append(resid(intr=sc.intr + dd))
+                elif sid == sc.ids["calib1"]:
+                    rr.append(resid(cam1=dict(sc.cam1, calib_q=quat_boxplus(sc.cam1["calib_q"], dd[:3]), calib_p=sc.cam1["calib_p"] + dd[3:])))
+                elif sid == sc.ids["intr1"]:
+                    rr.append(resid(cam1=dict(sc.cam1, intr=sc.cam1["intr"] + dd)))
+                else:
+                    ci = int(np.where(sc.ids["clones"] == sid)[0][0])
+                    cq, cp = sc.clone_q.copy(), sc.clone_p.copy()
+                    cq[ci] = quat_boxplus(sc.clone_q[ci], dd[:3])
+                    cp[ci] = sc.clone_p[ci] + dd[3:]
+                    rr.append(resid(clone_q=cq, clone_p=cp))
+            num = -(rr[0] - rr[1]) / (2 * eps)
+            assert np.abs(num - H_x[:, col]).max() / max(1.0, np.abs(H_x[:, col]).max()) < 1e-6, (sid, k)
+            col += 1
+    for k in range(3):
+        p = sc.p_FinG[f].copy()
+        p[k] += eps
+        r1 = np_ref.feature_jacobian_full(sc, f, p_FinG=p)[2]
+        p[k] -= 2 * eps
+        r2 = np_ref.feature_jacobian_full(sc, f, p_FinG=p)[2]
+        assert np.abs(-(r1 - r2) / (2 * eps) - H_f[:, k]).max() / max(1.0, np.abs(H_f[:, k]).max()) < 1e-6
+
+
+def test_numpy_dense_update_equals_the_c_oracle_on_one_camera(oracle):
+    """np_ref.msckf_point_update_dense - the reference of the two-camera tests - against the C oracle where both apply."""
+    tab = np.load(os.path.join(GOLD, "chi2_095_table.npy"))
+    for kw in (dict(C=8, F=40, seed=3, chi2_mult=1.0), dict(C=7, F=30, seed=4, ragged=True, chi2_mult=0.6)):
+        sc = make_scene(**kw)
+        a, b = np_ref.msckf_point_update_dense(sc, tab), oracle.msckf_point_update(sc)
+        assert (a["accepted"] == b["accepted"]).all() and np.abs(a["chi2"] - b["chi2"]).max() < 1e-9 * np.abs(b["chi2"]).max()
+        assert np.abs(a["dx"] - b["dx"]).max() < 1e-12 and np.abs(a["P"] - b["P"]).max() < 1e-13
+
+
 def test_nullspace_projection_identities(oracle):
     sc = make_scene(C=8, F=4, seed=9)
     H_f, H_x, res, _ = oracle.feature_jacobian_full(sc, 0)
