@@ -507,10 +507,12 @@ UpdaterSLAM::UpdaterSLAM(UpdaterOptions &options_slam, UpdaterOptions &options_a
 static void clean_old_measurements(ov_core::Feature &ft, const std::map<double, std::shared_ptr<PoseJPL>> &clones) {
   std::vector<float> uv2, uvn2;
   std::vector<double> ts2;
+  std::vector<int> cam2;
   const bool has_norm = ft.uvs_norm.size() == ft.uvs.size();
   for (size_t k = 0; k < ft.timestamps.size(); ++k)
     if (clones.count(ft.timestamps[k])) {
       ts2.push_back(ft.timestamps[k]);
+      if (!ft.cam_ids.empty()) cam2.push_back(ft.cam_of(k));
       uv2.push_back(ft.uvs[2 * k]);
       uv2.push_back(ft.uvs[2 * k + 1]);
       if (has_norm) {
@@ -519,6 +521,7 @@ static void clean_old_measurements(ov_core::Feature &ft, const std::map<double, 
       }
     }
   ft.timestamps = ts2;
+  ft.cam_ids = cam2;
   ft.uvs = uv2;
   ft.uvs_norm = uvn2;
 }
@@ -553,8 +556,14 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   UpdaterSLAM::upload_state_tables(state, clone_slot, clones);
   const int L = (int)feature_vec.size();
   int M = 1;
-  for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
-  if (M > OVP_MAX_MEAS || _force_dense) {  // a track longer than one wavefront's rows: the dense form has no such limit
+  bool other_camera = false;
+  for (auto &f : feature_vec) {
+    M = std::max(M, (int)f->timestamps.size());
+    other_camera = other_camera || !f->only_camera0();
+  }
+  // a track longer than one wavefront's rows, or measurements of a camera other than camera 0 (the device batch carries one
+  // calibration block per row): the dense form has neither limit
+  if (M > OVP_MAX_MEAS || other_camera || _force_dense) {
     update_dense(state, feature_vec, feat2plane);
     return;
   }
@@ -765,6 +774,7 @@ void UpdaterSLAM::update_dense(std::shared_ptr<State> state, std::vector<std::sh
     hf.featid = ft.featid;
     hf.uvs = ft.uvs;
     hf.timestamps = ft.timestamps;
+    hf.cam_ids = ft.cam_ids;
     const bool single = lm->_feat_representation == LR::ANCHORED_INVERSE_DEPTH_SINGLE;
     hf.feat_representation = single ? LR::ANCHORED_MSCKF_INVERSE_DEPTH : lm->_feat_representation;
     if (LR::is_relative_representation(hf.feat_representation)) {
@@ -1004,8 +1014,12 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     std::vector<std::shared_ptr<PoseJPL>> clones;
     upload_state_tables(state, clone_slot, clones);
     int M = 2;
-    for (int l = 0; l < L; ++l) M = std::max(M, (int)feature_vec[run_begin + l]->timestamps.size());
-    if (M > OVP_MAX_MEAS) return (size_t)-1;
+    bool other_camera = false;
+    for (int l = 0; l < L; ++l) {
+      M = std::max(M, (int)feature_vec[run_begin + l]->timestamps.size());
+      other_camera = other_camera || !feature_vec[run_begin + l]->only_camera0();
+    }
+    if (M > OVP_MAX_MEAS || other_camera) return (size_t)-1;  // (the per-candidate host loop has neither limit)
     std::vector<float> uv((size_t)L * M * 2, 0.f);
     std::vector<int> cidx((size_t)L * M, -1), nm(L);
     std::vector<double> pf((size_t)L * 3);
@@ -1109,6 +1123,7 @@ void UpdaterSLAM::delayed_init_host_loop(std::shared_ptr<State> state, std::vect
     feat.featid = (*it2)->featid;
     feat.uvs = (*it2)->uvs;
     feat.timestamps = (*it2)->timestamps;
+    feat.cam_ids = (*it2)->cam_ids;
     if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamd &&
         feat2plane.find((*it2)->featid) != feat2plane.end() &&
         state->_features_PLANE.find(feat2plane.at((*it2)->featid)) != state->_features_PLANE.end()) {

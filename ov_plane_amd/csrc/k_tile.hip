@@ -57,7 +57,11 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
 
   // accumulators = right-hand side tiles: element [row][col] of tile i is M[16 i + row][16 cblk + col];
   // for M = L^T (dense == 0) that is L[16 cblk + col][16 i + row], zero for i > cblk
-  double4_t acc[FW_ROWS], a_cur[FW_ROWS], a_nxt[FW_ROWS];
+  // A operands (tiles of Lt) are fetched TWO steps ahead into a ring of three register sets (round 6): with one step of lead the
+  // copy "next -> current" at the end of a step waited for loads issued ~1000 cycles earlier - a global round trip (~3000 cycles
+  // from another XCD's L2) stalled every one of the nt steps; the ring needs no copies, so a load is waited for two steps after
+  // its issue
+  double4_t acc[FW_ROWS], ring[3][FW_ROWS];
   sfor<FW_ROWS>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
     const int i = wave + 4 * r;
@@ -73,10 +77,9 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
       }
     }
     acc[r] = t;
-    a_cur[r] = double4_t{0.0, 0.0, 0.0, 0.0};
-    a_nxt[r] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) ring[u][r] = double4_t{0.0, 0.0, 0.0, 0.0};
   });
-  // A operands of step 0: tiles (i, 0), i > 0
   auto prefetch = [&](double4_t (&dst)[FW_ROWS], int k) {
     sfor<FW_ROWS>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
@@ -88,23 +91,36 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
       }
     });
   };
-  prefetch(a_cur, 0);
+  prefetch(ring[0], 0);
+  prefetch(ring[1], 1);
+  // the inverted diagonal blocks of this wave's rows, all of them up front (round 6): fetched at the start of the owner's step they
+  // were one global round trip on the dependent chain of EVERY step
+  double dqs[FW_ROWS][4];
+  sfor<FW_ROWS>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    const int i = wave + 4 * r;
+    const double* di = Dinv + (size_t)(i < ntl ? i : 0) * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dqs[r][q] = di[lc * 16 + lr + 4 * q];
+  });
 
-  for (int k = 0; k < nt; ++k) {
+  auto step = [&](int k, double4_t (&a_cur)[FW_ROWS], double4_t (&a_far)[FW_ROWS]) {
     double* vk = vt[k & 1];
     // diagonal solve by the owner of row k
     if ((k & 3) == wave) {
-      const double* di = Dinv + (size_t)(k < ntl ? k : 0) * 256;
-      double dq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dq[q] = di[lc * 16 + lr + 4 * q];
       double4_t vi = {0.0, 0.0, 0.0, 0.0};
       sfor<FW_ROWS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if (wave + 4 * r == k) {
           if (k < ntl) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vi = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[q], acc[r][q], vi, 0, 0, 0);
+            // two independent accumulation chains of two instead of one of four (a dependent f64 MFMA starts ~200 cycles behind
+            // its predecessor)
+            double4_t vj = {0.0, 0.0, 0.0, 0.0};
+            vi = __builtin_amdgcn_mfma_f64_16x16x4f64(dqs[r][0], acc[r][0], vi, 0, 0, 0);
+            vj = __builtin_amdgcn_mfma_f64_16x16x4f64(dqs[r][1], acc[r][1], vj, 0, 0, 0);
+            vi = __builtin_amdgcn_mfma_f64_16x16x4f64(dqs[r][2], acc[r][2], vi, 0, 0, 0);
+            vj = __builtin_amdgcn_mfma_f64_16x16x4f64(dqs[r][3], acc[r][3], vj, 0, 0, 0);
+            vi += vj;
           } else {
             vi = acc[r];  // behind the leading block Lt is the identity
           }
@@ -118,8 +134,11 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
         if (gr < n && gc < n) V[(size_t)gr * ld + gc] = vi[v];
       }
     }
-    prefetch(a_nxt, k + 1);
-    __syncthreads();
+    prefetch(a_far, k + 2);
+    // a barrier that orders LDS traffic only: __syncthreads() carries an s_waitcnt vmcnt(0), i.e. every step would wait for the
+    // operand tiles just requested and for the stores of V; V_k went to vt[k & 1] (double buffered: the write of step k + 2 is two
+    // barriers behind the reads of step k)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // trailing update of the rows i > k (increasing i: row k+1 first)
     double b[4];
 #pragma unroll
@@ -128,11 +147,19 @@ __global__ __launch_bounds__(256) void k_fwdsub(const double* __restrict__ Ltp, 
       constexpr int r = decltype(rc)::value;
       const int i = wave + 4 * r;
       if (i < ntl && i > k && k < ntl) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][q], b[q], acc[r], 0, 0, 0);
+        double4_t t2 = {0.0, 0.0, 0.0, 0.0};  // (second chain, see the diagonal solve)
+        acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][0], b[0], acc[r], 0, 0, 0);
+        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][1], b[1], t2, 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][2], b[2], acc[r], 0, 0, 0);
+        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_cur[r][3], b[3], t2, 0, 0, 0);
+        acc[r] += t2;
       }
-      a_cur[r] = a_nxt[r];
     });
+  };
+  for (int k = 0; k < nt; k += 3) {
+    step(k, ring[0], ring[2]);
+    if (k + 1 < nt) step(k + 1, ring[1], ring[0]);
+    if (k + 2 < nt) step(k + 2, ring[2], ring[1]);
   }
 }
 
