@@ -2,7 +2,7 @@
 # The profile set of a round, on the GPU box (from the repo root): usage tools/prof_round.sh TAG   (writes gpurun_out/TAG_*)
 # kernel statistics under rocprofv3 (config 3 = the headline, config 2, config 4), HBM traffic and SQ counters as separate --pmc
 # passes (never combined with a trace domain), the bench lines themselves, the closed-loop session.
-tag=${1:-r05_z}
+tag=${1:-r06_final}
 root=$GRAFT_REPO_ROOT
 [ -z "$root" ] && root=$(pwd)
 out=$root/gpurun_out
