@@ -58,7 +58,7 @@ extern "C" double ovp_chi2_quantile_095(int dof) {
   return 2.0 * x;
 }
 
-extern "C" const char* ovp_version(void) { return "ovplane_hip 0.5 (gfx950)"; }
+extern "C" const char* ovp_version(void) { return "ovplane_hip 0.6 (gfx950)"; }
 
 extern "C" const char* ovp_error_string(int code) {
   switch (code) {
