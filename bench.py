@@ -86,6 +86,49 @@ def pmc_traffic(kernel_substr, name, world):
     return b, "2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/%s (separate rocprofv3 --pmc passes over the same step, kernel sources %s)" % (PMC_TRAFFIC_FILE, here)
 
 
+SQ_COUNTER_FILE = "r06_final_sq_counters_pmc.json"   # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... pass of the same command
+KERNEL_STATS_FILE = "r06_final_kernel_stats.csv"      # rocprofv3 --kernel-trace --stats of the same command
+
+
+def mfma_utilisation(name, world):
+    """MFMA busy fraction of the kernels that run on the matrix cores - the covariance GEMMs (k_gemm4, k_plane_dT), the information
+    pair's SYRK (k_gram_pair) - from the committed rocprofv3 passes of the config-3 step: SQ_VALU_MFMA_BUSY_CYCLES per launch (cycles,
+    summed over the SIMDs that ran the kernel) / (average launch duration x 2.4 GHz x 1024 SIMDs).  Quoted only when both files were
+    taken on the running tree's kernel sources (source_hash)."""
+    if name != "config3" or world != 1:
+        return None
+    from ov_plane_amd.build import source_tree_hash
+
+    here = source_tree_hash()
+    pc, ks = os.path.join(_ROOT, "profiles", SQ_COUNTER_FILE), os.path.join(_ROOT, "profiles", KERNEL_STATS_FILE)
+    if not (os.path.exists(pc) and os.path.exists(ks)):
+        return {"note": "profiles/%s or profiles/%s not found" % (SQ_COUNTER_FILE, KERNEL_STATS_FILE)}
+    with open(pc) as fh:
+        doc = json.load(fh)
+    with open(ks) as fh:
+        first = fh.readline()
+        import csv
+
+        rows = list(csv.reader(fh))
+    there = (doc.get("source_hash"), first.split()[2] if first.startswith("# source_hash") else None)
+    if there != (here, here):
+        return {"note": "committed SQ counters / kernel statistics were taken on kernel sources %s / %s, the running tree is %s: not quoted" % (there[0], there[1], here)}
+    dur = {r[0]: float(r[3]) for r in rows[1:] if len(r) > 3}
+    out = {}
+    for kname, v in doc["kernels"].items():
+        busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES_avg_per_launch", 0.0)
+        if busy <= 0 or kname not in dur:
+            continue
+        short = kname.split("(")[0].replace("void ", "").replace("ovp::", "")
+        out[short] = {"mfma_busy_cycles_per_launch": busy, "avg_launch_us": dur[kname],
+                      "busy_fraction_of_chip": busy / (dur[kname] * 2400.0 * 1024.0)}
+    return {"kernels": out, "clock_ghz_assumed": 2.4, "simds": 1024,
+            "note": "f64 MFMA busy cycles / (launch duration x clock x SIMDs of the chip), per launch, from profiles/%s and profiles/%s "
+                    "(kernel sources %s).  The covariance GEMMs (k_gemm4: W = A L0, T, P+ = V^T V at N <= 240; k_plane_dT) are 20-27 MFLOP "
+                    "launches of 5-6 us: latency-bound at this size, the north star's 40 %% needs a GEMM that lasts longer than its own "
+                    "launch" % (SQ_COUNTER_FILE, KERNEL_STATS_FILE, here)}
+
+
 def make_workload(name, seed=0, feat_seed=None, chi2_mult=1.0):
     from ov_plane_amd.synth import make_scene
 
@@ -820,6 +863,9 @@ def main():
             }
             if "roofline" not in line:
                 line["roofline"] = line["roofline_point_kernel"]
+        mu = mfma_utilisation(name, world)
+        if mu is not None:
+            line["mfma_utilisation"] = mu
         if stages is not None:
             tot_st = sum(stages.values()) or 1.0
             line["multi_gpu"] = {

@@ -154,7 +154,7 @@ extern "C" int ovp_msckf_update_sharded(ovp_ctx* c, const ovp_update_opts* o, vo
     if (rc) {
       // rank-local failure (a HIP error in the build): a zero pair and a raised word, so that the peers' collective completes
       hipMemsetAsync(c->Ab, 0, sizeof(double) * pair_elems, c->stream);
-      const double one = 1.0;
+      static const double one = 1.0;  // (static: the asynchronous copy may read it after this block is left)
       hipMemcpyAsync(c->Ab + pair_elems, &one, sizeof(double), hipMemcpyHostToDevice, c->stream);
     } else {
       hipMemsetAsync(c->Ab + pair_elems, 0, sizeof(double), c->stream);

@@ -2994,6 +2994,18 @@ def test_dense_blocks_join_the_batch_in_one_update(hiplib, oracle, kw):
     out = ctx.msckf_update(capi.opts_from_scene(sc))
     assert (out["accepted"] == ref["accepted"][~dense]).all()
     assert np.abs(out["dx"] - ref["dx"]).max() < TOL_DX and relP(ctx.cov_download(), ref["P"]) < TOL_P
+    # the sharded entry carries the pending pair as well (rank 0 brings it to the all-reduce, the others contribute zeros for it):
+    # on a one-rank communicator the result is the same, bit for bit
+    P_plain, dx_plain = ctx.cov_download(), out["dx"].copy()
+    comm = capi.rccl_comm_create(capi.rccl_unique_id(), 0, 1, 0)
+    try:
+        ctx.cov_upload(sc.P)
+        ctx.msckf_dense_blocks(sc.opts["chi2_mult"], blocks)
+        ctx.batch_upload_scene(sc, np.where(~dense)[0])
+        outs = ctx.msckf_update_sharded(capi.opts_from_scene(sc), comm, 0, 1)
+        assert np.array_equal(outs["dx"], dx_plain) and np.array_equal(ctx.cov_download(), P_plain)
+    finally:
+        capi.rccl_comm_destroy(comm)
     # a pending pair dies with the covariance it was gated against: the next frame's update sees only its own batch
     ctx.cov_upload(sc.P)
     ctx.msckf_dense_blocks(sc.opts["chi2_mult"], blocks)
