@@ -736,6 +736,18 @@ def main():
                 sharded_step(run, stages)
             stages = {k: v / n_diag for k, v in stages.items()}
 
+    # the same workload on ONE GPU, measured by rank 0 of this very job (the others wait): the driver's N = 1 line is the headline
+    # configuration (config 3), not this one, so the line carries its own strong-scaling reference
+    one_gpu = None
+    if sharded:
+        if rank == 0:
+            with be.stream_ctx(run):
+                els = []
+                for blk in range(3):
+                    el_b, _, _ = time_steps(be, run.step, 10, 3 if blk == 0 else 0)
+                    els.append(el_b / 10)
+            one_gpu = {"ms_per_step": 1e3 * sorted(els)[1], "timing": "median of 3 blocks of 10 unsharded steps on rank 0 while the other ranks wait"}
+        dist.barrier()
     point_only = None
     if sharded and name != "config2":
         # the part of the path that shards, on the same ranks: BASELINE config 2's shape (2000 point features, no planes) strong-scaled
@@ -877,6 +889,8 @@ def main():
                                         "sum of rank 0's stages; Amdahl bound of the step at this rank count = 1 / (s + (1 - s) / N)",
                 "amdahl_bound_speedup": 1.0 / (stages.get("plane_loop_ms", 0.0) / tot_st + (1.0 - stages.get("plane_loop_ms", 0.0) / tot_st) / world),
                 "amdahl_bound_speedup_at_8_ranks": 1.0 / (stages.get("plane_loop_ms", 0.0) / tot_st + (1.0 - stages.get("plane_loop_ms", 0.0) / tot_st) / 8.0),
+                "one_gpu_same_workload": one_gpu,
+                "speedup_vs_one_gpu_same_workload": (one_gpu["ms_per_step"] / ms_per_step) if one_gpu else None,
                 "point_only_scaling": point_only,
                 "rank0_point_shard": int(run.shard_size),
                 "note": "stage times of rank 0 from a separate pass with a host synchronisation behind every stage (plane loop "

@@ -47,6 +47,7 @@ def test_two_ranks_through_bench_main_native_collective(tmp_path):
     assert 0.0 < s < 1.0
     assert abs(mg["amdahl_bound_speedup"] - 1.0 / (s + (1.0 - s) / 2.0)) < 1e-12
     assert abs(mg["amdahl_bound_speedup_at_8_ranks"] - 1.0 / (s + (1.0 - s) / 8.0)) < 1e-12
+    assert mg["one_gpu_same_workload"]["ms_per_step"] > 0 and mg["speedup_vs_one_gpu_same_workload"] > 0   # the line's own strong-scaling reference
     po = mg["point_only_scaling"]
     assert po is not None and po["ms_per_step"] > 0 and po["rank0_point_shard"] == 12      # 24 point features over two ranks
     assert mg["rank0_point_shard"] > 0
