@@ -738,25 +738,39 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   // else takes the dense side channel of the point update below (ovp_msckf_dense_blocks); in the uploads in front of it (device
   // triangulation, plane loop) such a feature is present with NO measurements, i.e. it takes no part there
   auto fits_batch = [](const ov_core::Feature &f) { return f.only_camera0() && (int)f.timestamps.size() <= OVP_MAX_MEAS; };
-  auto upload_batch = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv) {
+  // measurements of a feature that go into a batch upload: all of them when the feature fits; for the device TRIANGULATION a
+  // feature that does not fit still takes part with its first OVP_MAX_MEAS measurements of camera 0 (a position estimate needs
+  // no more; the update below linearises over all of them); for the update's batches it has none
+  auto batch_meas = [&](const ov_core::Feature &f, bool for_triangulation) {
+    std::vector<size_t> sel;
+    if (fits_batch(f)) {
+      for (size_t k = 0; k < f.timestamps.size(); ++k) sel.push_back(k);
+    } else if (for_triangulation) {
+      for (size_t k = 0; k < f.timestamps.size() && (int)sel.size() < OVP_MAX_MEAS; ++k)
+        if (f.cam_of(k) == 0) sel.push_back(k);
+    }
+    return sel;
+  };
+  auto upload_batch = [&](const std::vector<std::shared_ptr<ov_core::Feature>> &fv, bool for_triangulation = false) {
     const int F = (int)fv.size();
     int M = 1;
-    for (auto &f : fv)
-      if (fits_batch(*f)) M = std::max(M, (int)f->timestamps.size());
+    for (auto &f : fv) M = std::max(M, (int)batch_meas(*f, for_triangulation).size());
     std::vector<float> uv((size_t)F * M * 2, 0.f);
     std::vector<int> cidx((size_t)F * M, -1), nm(F);
     std::vector<double> pf((size_t)F * 3);
     for (int f = 0; f < F; ++f) {
-      nm[f] = fits_batch(*fv[f]) ? (int)fv[f]->timestamps.size() : 0;
+      const std::vector<size_t> sel = batch_meas(*fv[f], for_triangulation);
+      nm[f] = (int)sel.size();
       for (int k = 0; k < nm[f]; ++k) {
-        cidx[(size_t)f * M + k] = clone_slot.at(fv[f]->timestamps[k]);
-        uv[((size_t)f * M + k) * 2] = fv[f]->uvs[2 * k];
-        uv[((size_t)f * M + k) * 2 + 1] = fv[f]->uvs[2 * k + 1];
+        cidx[(size_t)f * M + k] = clone_slot.at(fv[f]->timestamps[sel[k]]);
+        uv[((size_t)f * M + k) * 2] = fv[f]->uvs[2 * sel[k]];
+        uv[((size_t)f * M + k) * 2 + 1] = fv[f]->uvs[2 * sel[k] + 1];
       }
       memcpy(&pf[3 * f], fv[f]->p_FinG, 3 * sizeof(double));
     }
     ovp_feature_batch fb{F, M, uv.data(), cidx.data(), nm.data(), pf.data()};
     gpu_check(ovp_batch_upload(state->_gpu, &fb), "ovp_batch_upload");
+    return M;
   };
   ovp_update_opts o{_options.sigma_pix,
                     _options.chi2_multipler,
@@ -772,13 +786,17 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     bool any_norm = false;
     for (auto &f : feature_vec) any_norm = any_norm || (!f->uvs_norm.empty() && f->uvs_norm.size() == f->uvs.size());
     if (any_norm) {
-      upload_batch(feature_vec);
+      const int M = upload_batch(feature_vec, true);
       const int F = (int)feature_vec.size();
-      int M = 1;
-      for (auto &f : feature_vec) M = std::max(M, (int)f->timestamps.size());
       std::vector<float> uvn((size_t)F * M * 2, 0.f);
-      for (int f = 0; f < F; ++f)
-        for (size_t k = 0; k < feature_vec[f]->uvs_norm.size(); ++k) uvn[(size_t)f * M * 2 + k] = feature_vec[f]->uvs_norm[k];
+      for (int f = 0; f < F; ++f) {
+        if (feature_vec[f]->uvs_norm.size() != feature_vec[f]->uvs.size()) continue;  // (position handed over)
+        const std::vector<size_t> sel = batch_meas(*feature_vec[f], true);
+        for (size_t k = 0; k < sel.size(); ++k) {
+          uvn[((size_t)f * M + k) * 2] = feature_vec[f]->uvs_norm[2 * sel[k]];
+          uvn[((size_t)f * M + k) * 2 + 1] = feature_vec[f]->uvs_norm[2 * sel[k] + 1];
+        }
+      }
       ovp_triang_opts to;
       to.refine_features = _featinit.refine_features ? 1 : 0;
       to.triangulate_1d = _featinit.triangulate_1d ? 1 : 0;
@@ -830,6 +848,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       for (auto &feat : vec) {
         auto it = feat2plane.find(feat->featid);
         if (it == feat2plane.end()) continue;
+        if (!fits_batch(*feat)) continue;  // (the fit / refinement kernels know camera 0 and 32 views: such a feature stays a point feature)
         all_norm = all_norm && (feat->uvs_norm.size() == 2 * feat->timestamps.size());
         plane_feats[it->second].push_back(feat);
       }

@@ -599,9 +599,17 @@ def make_stereo_scene(C=8, F=60, seed=0, stereo_frac=0.5, baseline=0.11, **kw):
     ids["calib1"], ids["intr1"] = at, at + 6
     ids["clones"] = np.asarray(base.ids["clones"]) + 14
     ids["N"] = N
+    # normalised measurements as the tracker stores them: undistorted with the estimate of the intrinsics of the camera that took them
+    uv_norm = np.zeros((F, Mm, 2), dtype=np.float32)
+    for cam, intr_c in ((0, base.intr), (1, cam1["intr"])):
+        xn, yn = radtan_undistort(uv[..., 0].astype(np.float64), uv[..., 1].astype(np.float64), intr_c)
+        sel = cam_idx == cam
+        uv_norm[..., 0][sel] = xn[sel].astype(np.float32)
+        uv_norm[..., 1][sel] = yn[sel].astype(np.float32)
+    for f in range(F):
+        uv_norm[f, int(n_meas[f]):] = 0.0
     sc = Scene(base)
-    sc.update(N=N, ids=ids, P=P, uv=uv, clone_idx=clone_idx, cam_idx=cam_idx, n_meas=n_meas, cam1=cam1, n_stereo=n_st,
-              uv_norm=np.zeros((F, Mm, 2), dtype=np.float32))
+    sc.update(N=N, ids=ids, P=P, uv=uv, clone_idx=clone_idx, cam_idx=cam_idx, n_meas=n_meas, cam1=cam1, n_stereo=n_st, uv_norm=uv_norm)
     return sc
 
 

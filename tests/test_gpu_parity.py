@@ -3059,6 +3059,40 @@ def test_updater_msckf_with_two_cameras(hiplib, oracle, kw):
 
 
 @pytest.mark.gpu
+def test_updater_msckf_with_two_cameras_triangulates_first(hiplib, oracle):
+    """The same with features that arrive WITHOUT positions (uvs_norm only, update/UpdaterMSCKF.cpp:120-166): the device
+    triangulation knows camera 0, so a two-camera feature (and a track of more than 32 observations: the stereo features here have
+    40) is triangulated from its first <= 32 observations of camera 0, then linearised over ALL of its measurements.  Reference:
+    the oracle's triangulation of the camera-0 sub-tracks, then the dense numpy update at those positions."""
+    from ov_plane_amd.build import build_host
+    from ov_plane_amd.synth import Scene, make_stereo_scene, quat_boxplus
+    from oracle import np_ref as R
+
+    build_host()
+    from ov_plane_amd import hostlib
+
+    sc = make_stereo_scene(C=20, F=40, seed=6, chi2_mult=1.0, stereo_frac=0.5)
+    C = sc.C
+    mono = Scene(sc)     # camera 0's measurements of every feature: the first n_meas / 2 (stereo) or all of them
+    m0 = np.where(np.arange(sc.F) < sc.n_stereo, sc.n_meas // 2, sc.n_meas).astype(np.int32)
+    mono.update(n_meas=m0, uv=sc.uv[:, :C].copy(), uv_norm=sc.uv_norm[:, :C].copy(), clone_idx=sc.clone_idx[:, :C].copy())
+    tri = oracle.triangulate(mono)
+    assert tri["ok"].all()
+    sc2 = Scene(sc)
+    sc2["p_FinG"] = tri["p_FinG"]
+    ref = R.msckf_point_update_dense(sc2, np.load(os.path.join(GOLD, "chi2_095_table.npy")))
+    out = hostlib.run_msckf_update(sc, triangulate=True)
+    assert (out["kept"] == ref["accepted"]).all() and ref["accepted"].sum() >= 30
+    dx, ids = ref["dx"], sc.ids
+    for i in range(C):
+        cid = ids["clones"][i]
+        assert np.abs(out["clone_q"][i] - quat_boxplus(sc.clone_q[i], dx[cid:cid + 3])).max() < TOL_DX
+        assert np.abs(out["clone_p"][i] - (sc.clone_p[i] + dx[cid + 3:cid + 6])).max() < TOL_DX
+    assert np.abs(out["cam1"]["intr"] - (sc.cam1["intr"] + dx[ids["intr1"]:ids["intr1"] + 8])).max() < TOL_DX
+    assert relP(out["P"], ref["P"]) < TOL_P
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kw", [
     dict(C=11, F=120, seed=71, chi2_mult=1.0),
     dict(C=10, F=150, seed=72, n_planes=4, feats_per_plane=20, chi2_mult=99999.0),
