@@ -223,91 +223,86 @@ MatrixXd StateHelper::get_full_covariance(std::shared_ptr<State> state) {
 }
 
 // ---- state/StateHelper.cpp:276-344 -------------------------------------------------------------
+// The covariance loses the variable's rows / columns on the device; on the host the variable leaves _variables and everything
+// behind it moves up by its size.
 void StateHelper::marginalize(std::shared_ptr<State> state, std::shared_ptr<Type> marg) {
-  if (std::find(state->_variables.begin(), state->_variables.end(), marg) == state->_variables.end()) {
-    PRINT_ERROR("StateHelper::marginalize() - Called on variable that is not in the state\n");
+  auto &vars = state->_variables;
+  const auto where = std::find(vars.begin(), vars.end(), marg);
+  if (where == vars.end()) {
+    PRINT_ERROR("StateHelper::marginalize() - the variable is not part of the state\n");
     std::exit(EXIT_FAILURE);
   }
-  const int marg_size = marg->size();
-  const int marg_id = marg->id();
-  gpu_check(ovp_cov_marginalize(state->_gpu, marg_id, marg_size), "ovp_cov_marginalize");
-  std::vector<std::shared_ptr<Type>> remaining_variables;
-  for (size_t i = 0; i < state->_variables.size(); i++) {
-    if (state->_variables.at(i) != marg) {
-      if (state->_variables.at(i)->id() > marg_id) state->_variables.at(i)->set_local_id(state->_variables.at(i)->id() - marg_size);
-      remaining_variables.push_back(state->_variables.at(i));
-    }
-  }
+  const int gone_at = marg->id(), gone = marg->size();
+  gpu_check(ovp_cov_marginalize(state->_gpu, gone_at, gone), "ovp_cov_marginalize");
+  vars.erase(where);
+  for (auto &v : vars)
+    if (v->id() > gone_at) v->set_local_id(v->id() - gone);
   marg->set_local_id(-1);
-  state->_variables = remaining_variables;
 }
 
 // ---- state/StateHelper.cpp:346-396 -------------------------------------------------------------
+// The variable to copy is either a state variable itself or a sub-variable of one (the IMU's pose): the first state variable that
+// owns it decides where its block sits; the copy goes to the end of the covariance.
 std::shared_ptr<Type> StateHelper::clone(std::shared_ptr<State> state, std::shared_ptr<Type> variable_to_clone) {
-  const int total_size = variable_to_clone->size();
-  const int new_loc = ovp_cov_size(state->_gpu);
-  std::shared_ptr<Type> new_clone = nullptr;
-  for (size_t k = 0; k < state->_variables.size(); k++) {
-    std::shared_ptr<Type> type_check = state->_variables.at(k)->check_if_subvariable(variable_to_clone);
-    if (state->_variables.at(k) == variable_to_clone) {
-      type_check = state->_variables.at(k);
-    } else if (type_check != variable_to_clone) {
-      continue;
-    }
-    const int old_loc = type_check->id();
-    gpu_check(ovp_cov_clone(state->_gpu, old_loc, total_size), "ovp_cov_clone");
-    new_clone = type_check->clone();
-    new_clone->set_local_id(new_loc);
-    break;
+  std::shared_ptr<Type> source;
+  for (const auto &v : state->_variables) {
+    source = (v == variable_to_clone) ? v : v->check_if_subvariable(variable_to_clone);
+    if (source == variable_to_clone) break;
+    source = nullptr;
   }
-  if (new_clone == nullptr) {
-    PRINT_ERROR("StateHelper::clone() - Called on variable is not in the state\n");
+  if (!source) {
+    PRINT_ERROR("StateHelper::clone() - the variable is not part of the state\n");
     std::exit(EXIT_FAILURE);
   }
-  state->_variables.push_back(new_clone);
-  return new_clone;
+  const int appended_at = ovp_cov_size(state->_gpu);
+  gpu_check(ovp_cov_clone(state->_gpu, source->id(), variable_to_clone->size()), "ovp_cov_clone");
+  std::shared_ptr<Type> copy = source->clone();
+  copy->set_local_id(appended_at);
+  state->_variables.push_back(copy);
+  return copy;
 }
 
 // ---- state/StateHelper.cpp:588-625 -------------------------------------------------------------
+// Stochastic clone of the IMU pose at the state's time; with the camera time offset in the state the clone also depends on it
+// through the motion during the offset (d clone / d dt = [w; v], :613-624).
 void StateHelper::augment_clone(std::shared_ptr<State> state, const double last_w[3]) {
-  if (state->_clones_IMU.find(state->_timestamp) != state->_clones_IMU.end()) {
-    PRINT_ERROR("TRIED TO INSERT A CLONE AT THE SAME TIME AS AN EXISTING CLONE, EXITING!#!@#!@#\n");
+  const double now = state->_timestamp;
+  if (state->_clones_IMU.count(now)) {
+    PRINT_ERROR("StateHelper::augment_clone() - there is a clone at this time already\n");
     std::exit(EXIT_FAILURE);
   }
-  std::shared_ptr<Type> posetemp = StateHelper::clone(state, state->_imu->pose());
-  std::shared_ptr<PoseJPL> pose = std::dynamic_pointer_cast<PoseJPL>(posetemp);
-  if (pose == nullptr) {
-    PRINT_ERROR("INVALID OBJECT RETURNED FROM STATEHELPER CLONE, EXITING!#!@#!@#\n");
+  auto pose = std::dynamic_pointer_cast<PoseJPL>(StateHelper::clone(state, state->_imu->pose()));
+  if (!pose) {
+    PRINT_ERROR("StateHelper::augment_clone() - the clone of the IMU pose is not a pose\n");
     std::exit(EXIT_FAILURE);
   }
-  state->_clones_IMU[state->_timestamp] = pose;
-  if (state->_options.do_calib_camera_timeoffset) {
-    double dnc_dt[6] = {last_w[0], last_w[1], last_w[2], state->_imu->vel()[0], state->_imu->vel()[1], state->_imu->vel()[2]};
-    gpu_check(ovp_cov_augment_dt(state->_gpu, pose->id(), state->_calib_dt_CAMtoIMU->id(), dnc_dt), "ovp_cov_augment_dt");
-  }
+  state->_clones_IMU[now] = pose;
+  if (!state->_options.do_calib_camera_timeoffset) return;
+  const double *v = state->_imu->vel();
+  const double dnc_dt[6] = {last_w[0], last_w[1], last_w[2], v[0], v[1], v[2]};
+  gpu_check(ovp_cov_augment_dt(state->_gpu, pose->id(), state->_calib_dt_CAMtoIMU->id(), dnc_dt), "ovp_cov_augment_dt");
 }
 
 // ---- state/StateHelper.cpp:627-636 -------------------------------------------------------------
+// One clone more than the window holds: the oldest goes (std::map keeps the clones ordered by time).
 void StateHelper::marginalize_old_clone(std::shared_ptr<State> state) {
-  if ((int)state->_clones_IMU.size() > state->_options.max_clone_size) {
-    double marginal_time = state->margtimestep();
-    assert(marginal_time != INFINITY);
-    StateHelper::marginalize(state, state->_clones_IMU.at(marginal_time));
-    state->_clones_IMU.erase(marginal_time);
-  }
+  auto &clones = state->_clones_IMU;
+  if ((int)clones.size() <= state->_options.max_clone_size) return;
+  const auto oldest = clones.begin();
+  StateHelper::marginalize(state, oldest->second);
+  clones.erase(oldest);
 }
 
 // ---- state/StateHelper.cpp:638-652 -------------------------------------------------------------
+// Landmarks flagged by the updaters leave the state (ArUco ids, the first 4 * max_aruco_features, are never dropped).
 void StateHelper::marginalize_slam(std::shared_ptr<State> state) {
-  auto it0 = state->_features_SLAM.begin();
-  while (it0 != state->_features_SLAM.end()) {
-    if ((*it0).second->should_marg && (int)(*it0).first > 4 * state->_options.max_aruco_features) {
-      StateHelper::marginalize(state, (*it0).second);
-      state->_features_SLAM_to_PLANE.erase((*it0).first);
-      it0 = state->_features_SLAM.erase(it0);
-    } else {
-      it0++;
-    }
+  std::vector<size_t> leaving;
+  for (const auto &lm : state->_features_SLAM)
+    if (lm.second->should_marg && (int)lm.first > 4 * state->_options.max_aruco_features) leaving.push_back(lm.first);
+  for (size_t id : leaving) {
+    StateHelper::marginalize(state, state->_features_SLAM.at(id));
+    state->_features_SLAM_to_PLANE.erase(id);
+    state->_features_SLAM.erase(id);
   }
 }
 

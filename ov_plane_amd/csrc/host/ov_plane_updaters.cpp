@@ -1117,103 +1117,90 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
 // fallback), StateHelper::initialize on the device per candidate
 void UpdaterSLAM::delayed_init_host_loop(std::shared_ptr<State> state, std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec,
                                          const std::map<size_t, size_t> &feat2plane) {
-  auto it2 = feature_vec.begin();
-  while (it2 != feature_vec.end()) {
+  typedef LandmarkRepresentation LR;
+  const auto rep_state = state->_options.feat_rep_slam;
+  // :230-246 the single inverse depth is linearised as the MSCKF inverse depth, its depth column moved to the state side
+  const bool single = rep_state == LR::ANCHORED_INVERSE_DEPTH_SINGLE;
+  const auto rep_lin = single ? LR::ANCHORED_MSCKF_INVERSE_DEPTH : rep_state;
+  const bool anchored = LR::is_relative_representation(rep_lin);
+  const double sigma_c = state->_options.sigma_constraint, mult = _options_slam.chi2_multipler;
+  // the plane a candidate may be initialised on: in the state, and not one this feature was taken off before (:210-228)
+  auto plane_of = [&](size_t featid) -> size_t {
+    if (!(state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamd)) return 0;
+    const auto it = feat2plane.find(featid);
+    if (it == feat2plane.end() || !state->_features_PLANE.count(it->second)) return 0;
+    const auto off = state->_features_SLAM_to_PLANE.find(featid);
+    return (off != state->_features_SLAM_to_PLANE.end() && off->second == 0) ? 0 : it->second;
+  };
+  std::vector<std::shared_ptr<ov_core::Feature>> survivors;
+  for (auto &fp : feature_vec) {
+    ov_core::Feature &ft = *fp;
     UpdaterHelper::UpdaterHelperFeature feat;
-    feat.featid = (*it2)->featid;
-    feat.uvs = (*it2)->uvs;
-    feat.timestamps = (*it2)->timestamps;
-    feat.cam_ids = (*it2)->cam_ids;
-    if (state->_options.use_plane_constraint && state->_options.use_plane_constraint_slamd &&
-        feat2plane.find((*it2)->featid) != feat2plane.end() &&
-        state->_features_PLANE.find(feat2plane.at((*it2)->featid)) != state->_features_PLANE.end()) {
-      if (state->_features_SLAM_to_PLANE.find((*it2)->featid) == state->_features_SLAM_to_PLANE.end() ||
-          state->_features_SLAM_to_PLANE.at((*it2)->featid) != 0) {
-        feat.planeid = feat2plane.at((*it2)->featid);
-        auto pl = state->_features_PLANE.at(feat.planeid);
-        for (int k = 0; k < 3; ++k) {
-          feat.cp_FinG[k] = pl->value()(k);
-          feat.cp_FinG_fej[k] = pl->fej()(k);
-        }
-      }
-    }
-    // :230-246 representation of the new landmark; the single inverse depth is linearised as the MSCKF inverse depth
-    const auto feat_rep = state->_options.feat_rep_slam;
-    const bool single = feat_rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE;
-    feat.feat_representation = single ? LandmarkRepresentation::Representation::ANCHORED_MSCKF_INVERSE_DEPTH : feat_rep;
-    if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
-      ov_core::Feature &ft = **it2;
+    feat.featid = ft.featid;
+    feat.uvs = ft.uvs;
+    feat.timestamps = ft.timestamps;
+    feat.cam_ids = ft.cam_ids;
+    feat.feat_representation = rep_lin;
+    double *value = anchored ? feat.p_FinA : feat.p_FinG, *first = anchored ? feat.p_FinA_fej : feat.p_FinG_fej;
+    memcpy(value, anchored ? ft.p_FinA : ft.p_FinG, 3 * sizeof(double));
+    memcpy(first, value, 3 * sizeof(double));  // a new landmark's first estimate is its value
+    if (anchored) {
       feat.anchor_cam_id = ft.anchor_cam_id;
       feat.anchor_clone_timestamp = ft.anchor_clone_timestamp;
-      memcpy(feat.p_FinA, ft.p_FinA, sizeof(feat.p_FinA));
-      memcpy(feat.p_FinA_fej, ft.p_FinA, sizeof(feat.p_FinA));
-    } else {
-      memcpy(feat.p_FinG, (*it2)->p_FinG, sizeof(feat.p_FinG));
-      memcpy(feat.p_FinG_fej, (*it2)->p_FinG, sizeof(feat.p_FinG));
     }
-    MatrixXd H_f, H_x;
-    VectorXd res;
-    std::vector<std::shared_ptr<Type>> Hx_order;
-    const double sigma_c = state->_options.sigma_constraint;
-    // :262-283 single inverse depth: the depth column joins the state side, the bearing columns are projected out
-    auto jacobian = [&]() {
-      UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, Hx_order);
-      if (!single) return;
-      MatrixXd H_xf(H_x.rows(), H_x.cols() + 1);
-      for (int j = 0; j < H_x.cols(); ++j)
-        for (int i = 0; i < H_x.rows(); ++i) H_xf(i, j) = H_x(i, j);
-      for (int i = 0; i < H_x.rows(); ++i) H_xf(i, H_x.cols()) = H_f(i, H_f.cols() - 1);
-      MatrixXd H_b = H_f.block(0, 0, H_f.rows(), H_f.cols() - 1);
-      UpdaterHelper::nullspace_project_inplace(H_b, H_xf, res);
-      H_x = H_xf.block(0, 0, H_xf.rows(), H_xf.cols() - 1);
-      H_f = H_xf.block(0, H_xf.cols() - 1, H_xf.rows(), 1);
-    };
-    const double t_b = now_s();
-    jacobian();
-    g_diprof.t_jac += now_s() - t_b;
-    g_diprof.cands++;
     auto landmark = std::make_shared<Landmark>(single ? 1 : 3);  // :285-296
-    landmark->_featid = feat.featid;
-    landmark->_feat_representation = feat_rep;
-    landmark->_unique_camera_id = (*it2)->anchor_cam_id;
-    if (LandmarkRepresentation::is_relative_representation(feat.feat_representation)) {
-      landmark->_anchor_cam_id = feat.anchor_cam_id;
-      landmark->_anchor_clone_timestamp = feat.anchor_clone_timestamp;
-      landmark->set_from_xyz(feat.p_FinA, false);
-      landmark->set_from_xyz(feat.p_FinA_fej, true);
-    } else {
-      landmark->set_from_xyz(feat.p_FinG, false);
-      landmark->set_from_xyz(feat.p_FinG_fej, true);
+    landmark->_featid = ft.featid;
+    landmark->_feat_representation = rep_state;
+    landmark->_unique_camera_id = ft.anchor_cam_id;
+    if (anchored) {
+      landmark->_anchor_cam_id = ft.anchor_cam_id;
+      landmark->_anchor_clone_timestamp = ft.anchor_clone_timestamp;
     }
-    MatrixXd R = MatrixXd::Identity(res.rows(), res.rows());
-    const double chi2_multipler = _options_slam.chi2_multipler;
-    const double t_c = now_s();
-    const bool init_ok = StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler);  // :304
-    g_diprof.t_init += now_s() - t_c;
-    g_diprof.accepted += init_ok;
-    if (init_ok) {
-      state->_features_SLAM.insert({(*it2)->featid, landmark});
-      (*it2)->to_delete = true;
-      if (feat.planeid != 0) state->_features_SLAM_to_PLANE[(*it2)->featid] = feat.planeid;
-      it2++;
-    } else if (feat.planeid != 0) {  // :310-359 fallback without the plane
-      feat.planeid = 0;
-      state->_features_SLAM_to_PLANE[(*it2)->featid] = 0;
-      jacobian();
-      R = MatrixXd::Identity(res.rows(), res.rows());
-      if (StateHelper::initialize(state, landmark, Hx_order, H_x, H_f, R, res, chi2_multipler)) {
-        state->_features_SLAM.insert({(*it2)->featid, landmark});
-        (*it2)->to_delete = true;
-        it2++;
-      } else {
-        (*it2)->to_delete = true;
-        it2 = feature_vec.erase(it2);
+    landmark->set_from_xyz(value, false);
+    landmark->set_from_xyz(first, true);
+    // with the plane's rows first, then - when that fails the gate - once more without them (:304-359)
+    size_t pid = plane_of(ft.featid);
+    bool in_state = false;
+    for (int attempt = 0; attempt < 2 && !in_state; ++attempt) {
+      feat.planeid = pid;
+      if (pid != 0) {
+        const auto pl = state->_features_PLANE.at(pid);
+        for (int k = 0; k < 3; ++k) feat.cp_FinG[k] = pl->value()(k), feat.cp_FinG_fej[k] = pl->fej()(k);
       }
-    } else {
-      (*it2)->to_delete = true;
-      it2 = feature_vec.erase(it2);
+      MatrixXd H_f, H_x;
+      VectorXd res;
+      std::vector<std::shared_ptr<Type>> order;
+      const double t_b = now_s();
+      UpdaterHelper::get_feature_jacobian_full(state, feat, _options_slam.sigma_pix, sigma_c, H_f, H_x, res, order);
+      if (single) {  // :262-283 the depth column joins the state side, the bearing columns are projected out
+        MatrixXd H_xd(H_x.rows(), H_x.cols() + 1);
+        for (int i = 0; i < H_x.rows(); ++i) {
+          for (int j = 0; j < H_x.cols(); ++j) H_xd(i, j) = H_x(i, j);
+          H_xd(i, H_x.cols()) = H_f(i, H_f.cols() - 1);
+        }
+        MatrixXd H_bearing = H_f.block(0, 0, H_f.rows(), H_f.cols() - 1);
+        UpdaterHelper::nullspace_project_inplace(H_bearing, H_xd, res);
+        H_x = H_xd.block(0, 0, H_xd.rows(), H_xd.cols() - 1);
+        H_f = H_xd.block(0, H_xd.cols() - 1, H_xd.rows(), 1);
+      }
+      g_diprof.t_jac += now_s() - t_b;
+      if (attempt == 0) g_diprof.cands++;
+      MatrixXd R = MatrixXd::Identity(res.rows(), res.rows());
+      const double t_c = now_s();
+      in_state = StateHelper::initialize(state, landmark, order, H_x, H_f, R, res, mult);
+      g_diprof.t_init += now_s() - t_c;
+      if (in_state || pid == 0) break;
+      state->_features_SLAM_to_PLANE[ft.featid] = 0;  // the plane is dropped for this feature, whatever the second attempt says
+      pid = 0;
     }
+    g_diprof.accepted += in_state;
+    ft.to_delete = true;
+    if (!in_state) continue;
+    state->_features_SLAM.insert({ft.featid, landmark});
+    if (pid != 0) state->_features_SLAM_to_PLANE[ft.featid] = pid;
+    survivors.push_back(fp);
   }
+  feature_vec = survivors;
 }
 
 // ---- update/UpdaterPlane.cpp ---------------------------------------------------------------------
