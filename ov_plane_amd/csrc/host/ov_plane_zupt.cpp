@@ -50,10 +50,7 @@ bool UpdaterZeroVelocity::try_update(std::shared_ptr<State> state, double timest
     return no_update();
   }
   // :119-125 order [q, bg, ba]
-  std::vector<std::shared_ptr<Type>> Hx_order;
-  Hx_order.push_back(state->_imu->q());
-  Hx_order.push_back(state->_imu->bg());
-  Hx_order.push_back(state->_imu->ba());
+  const std::vector<std::shared_ptr<Type>> Hx_order{state->_imu->q(), state->_imu->bg(), state->_imu->ba()};
   const int h_size = 9, n_int = (int)imu_recent.size() - 1, m_size = 6 * n_int;
   MatrixXd H = MatrixXd::Zero(m_size, h_size);
   VectorXd res = VectorXd::Zero(m_size, 1);
@@ -151,11 +148,8 @@ bool UpdaterZeroVelocity::try_update(std::shared_ptr<State> state, double timest
   if (last_zupt_state_timestamp > 0.0 && _db) _db->cleanup_measurements_exact(last_zupt_state_timestamp);
   // :256-262 bias random walk, Phi = I
   {
-    MatrixXd Phi_bias = MatrixXd::Identity(6, 6);
-    std::vector<std::shared_ptr<Type>> Phi_order;
-    Phi_order.push_back(state->_imu->bg());
-    Phi_order.push_back(state->_imu->ba());
-    StateHelper::EKFPropagation(state, Phi_order, Phi_order, Phi_bias, Q_bias);
+    const std::vector<std::shared_ptr<Type>> biases{state->_imu->bg(), state->_imu->ba()};
+    StateHelper::EKFPropagation(state, biases, biases, MatrixXd::Identity(6, 6), Q_bias);
   }
   StateHelper::EKFUpdate(state, Hx_order, H, res, R);  // :265
   state->_timestamp = timestamp;
