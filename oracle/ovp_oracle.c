@@ -2405,7 +2405,9 @@ static void tri_sym3_eig(const double A[9], double ev[3]) { /* cyclic Jacobi on 
   memcpy(a, A, sizeof(a));
   for (int sweep = 0; sweep < 30; ++sweep) {
     const double off = fabs(a[1]) + fabs(a[2]) + fabs(a[5]);
-    if (off < 1e-300) break;
+    /* converged: the off-diagonal part is below the rounding of the diagonal (cyclic Jacobi converges quadratically - four or five
+     * sweeps; the bound of 30 is never reached).  The eigenvalues only feed the condition-number test of the triangulation. */
+    if (off <= 1e-17 * (fabs(a[0]) + fabs(a[4]) + fabs(a[8]))) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         const double apq = a[3 * p + q];
