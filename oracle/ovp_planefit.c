@@ -129,7 +129,9 @@ static void sym3_eigvals(const double S[9], double w[3]) {
   memcpy(a, S, sizeof(a));
   for (int sweep = 0; sweep < 30; ++sweep) {
     const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
-    if (off < 1e-300) break;
+    /* converged: the off-diagonal part is below the rounding of the diagonal (cyclic Jacobi: four or five sweeps; the eigenvalues
+     * only feed the condition-number test of fit_plane) */
+    if (off <= 1e-34 * (a[0] * a[0] + a[4] * a[4] + a[8] * a[8])) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         const double apq = a[3 * p + q];

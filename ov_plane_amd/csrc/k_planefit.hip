@@ -38,7 +38,8 @@ __device__ __forceinline__ void pf_sym3_eig(const double (&A)[9], double (&ev)[3
   for (int i = 0; i < 9; ++i) a[i] = A[i];
   for (int sweep = 0; sweep < 30; ++sweep) {
     const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
-    if (off < 1e-300) break;
+    // converged (same test as the oracle's; until round 6 all thirty sweeps ran for every RANSAC hypothesis)
+    if (off <= 1e-34 * (a[0] * a[0] + a[4] * a[4] + a[8] * a[8])) break;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
