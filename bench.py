@@ -38,6 +38,7 @@ WORKLOADS = {
     "config2": dict(C=30, F=2000, n_planes=0, feats_per_plane=0),
     "config3": dict(C=30, F=2000, n_planes=20, feats_per_plane=50),
     "config4": dict(C=30, F=8000, n_planes=50, feats_per_plane=50),
+    "points8000": dict(C=30, F=8000, n_planes=0, feats_per_plane=0),   # config 4 without its planes: the part of the path that shards
 }
 
 
@@ -608,7 +609,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=["auto", "config2", "config3", "config4"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "config2", "config3", "config4", "points8000"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (point_config, config4_1gpu, propagation)")
     ap.add_argument("--cpu-sample-feats", type=int, default=0, help="0 = the oracle runs every feature of the frame")
@@ -749,9 +750,10 @@ def main():
             one_gpu = {"ms_per_step": 1e3 * sorted(els)[1], "timing": "median of 3 blocks of 10 unsharded steps on rank 0 while the other ranks wait"}
         dist.barrier()
     point_only = None
-    if sharded and name != "config2":
-        # the part of the path that shards, on the same ranks: BASELINE config 2's shape (2000 point features, no planes) strong-scaled
-        sc2 = be.make_workload("config2")
+    if sharded and name not in ("config2", "points8000"):
+        # the part of the path that shards, on the same ranks: config 4's 8000 features WITHOUT its planes, strong-scaled, with its
+        # own one-GPU reference (rank 0, unsharded, while the others wait)
+        sc2 = be.make_workload("points8000")
         r2 = be.make_runner(sc2, local_rank)
         with be.stream_ctx(r2):
             blocks = []
@@ -761,9 +763,20 @@ def main():
         tb = torch.tensor(blocks, dtype=torch.float64, device=be.device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         med = float(sorted(tb.tolist())[2])
-        point_only = {"workload": describe("config2", sc2), "ms_per_step": 1e3 * med, "features_per_s": sc2.F / med,
+        ref1 = None
+        if rank == 0:
+            with be.stream_ctx(r2):
+                els = []
+                for blk in range(3):
+                    el_b, _, _ = time_steps(be, r2.step, 10, 3 if blk == 0 else 0)
+                    els.append(el_b / 10)
+            ref1 = sorted(els)[1]
+        dist.barrier()
+        point_only = {"workload": describe("points8000", sc2), "ms_per_step": 1e3 * med, "features_per_s": sc2.F / med,
                       "rank0_point_shard": int(r2.shard_size),
-                      "timing": "median of 5 blocks of 10 steps, max over ranks per block"}
+                      "one_gpu_ms_per_step": 1e3 * ref1 if ref1 else None, "speedup_vs_one_gpu": (ref1 / med) if ref1 else None,
+                      "timing": "median of 5 blocks of 10 steps, max over ranks per block; one-GPU reference: median of 3 blocks of 10 "
+                                "unsharded steps on rank 0"}
         r2.close()
     if sharded:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=be.device)

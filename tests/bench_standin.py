@@ -27,6 +27,7 @@ SMALL = {
     "config2": dict(C=6, F=24, seed=3, chi2_mult=1.0),
     "config3": dict(C=6, F=40, seed=1, n_planes=2, feats_per_plane=10, chi2_mult=99999.0),
     "config4": dict(C=6, F=48, seed=2, n_planes=3, feats_per_plane=8, chi2_mult=99999.0),
+    "points8000": dict(C=6, F=24, seed=3, chi2_mult=1.0),
 }
 
 

@@ -50,6 +50,7 @@ def test_two_ranks_through_bench_main_native_collective(tmp_path):
     assert mg["one_gpu_same_workload"]["ms_per_step"] > 0 and mg["speedup_vs_one_gpu_same_workload"] > 0   # the line's own strong-scaling reference
     po = mg["point_only_scaling"]
     assert po is not None and po["ms_per_step"] > 0 and po["rank0_point_shard"] == 12      # 24 point features over two ranks
+    assert po["one_gpu_ms_per_step"] > 0 and po["speedup_vs_one_gpu"] > 0
     assert mg["rank0_point_shard"] > 0
     assert line["prewarm"]["steps"] >= 4 and line["prewarm"]["steps"] % 2 == 0             # settle(): the ranks stopped together
     # both replicas ended the last config-4 step with the same covariance and correction, bit for bit
