@@ -27,7 +27,7 @@ struct Chol2Job {
   double* Dinv_out;     // inverted diagonal blocks of the n x n part, [ceil(n/16)][16][16] (what k_fwdsub reads beside Lpack)
   const int* skip_cond; // optional {have, want}: return at once when the factor this launch would produce is already there
   long long* stamps;    // optional [nt + 1][8] cycle stamps of wave 0 (diagnostics)
-  int dbg;              // timing experiments only: 1 = skip the fused elimination, 2 = skip the trailing MFMAs, 4 = skip LDS staging
+  int dbg;              // timing experiments, -DOVP_C2_STAMPS builds only: 1 = skip the fused elimination, 2 = skip the trailing MFMAs
   // mode 1 on two workgroups (k_chol2.hip, chol2_factor): tile columns < split_h on block 0, the rest on block 2
   int split_h;          // 0 = one workgroup
   double* xbuf;         // [split_h][nt][256] exported panel tiles (rows >= split_h), row-major
@@ -95,6 +95,7 @@ struct PlaneSolve {
 
 extern "C" {
 int ovp_chol2_max_n(void);
+int ovp_chol2_stamps_compiled(void);  // 1 in a build under -DOVP_C2_STAMPS (tools/build_c2_stamps.sh): Chol2Job::stamps is written
 hipError_t ovp_launch_max_diag(const double* A, int n, int ld, double* out, hipStream_t stream);
 hipError_t ovp_launch_chol2_packed(const double* A, double* Dinv, double* Lpack, int n, int ld, int* flag, int add_identity,
                                    const int* cond, hipStream_t stream);

@@ -101,14 +101,20 @@ __device__ __forceinline__ bool fused_elim16(double (&d)[16], double (&p)[16], d
 // k = 4 lr + q (q = MFMA, lr = the lane's row group) instead of k = 4 q + lr: both operands use the same assignment, so the product
 // is the same sum, and a lane's four operand values of a tile are 32 contiguous bytes - two 16-byte LDS reads per operand and tile
 // instead of four 8-byte ones (the trailing update of the first tile columns is what the elimination waves wait for).
-__device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* Y, double4_t acc, int lc, int lr) {
-  const dbl2_t* xp = reinterpret_cast<const dbl2_t*>(X + lc * C2_TS + 4 * lr);
-  const dbl2_t* yp = reinterpret_cast<const dbl2_t*>(Y + lc * C2_TS + 4 * lr);
-  const dbl2_t x0 = xp[0], y0 = yp[0], x1 = xp[1], y1 = yp[1];
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[0], y0[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[1], y0[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[0], y1[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[1], y1[1], acc, 0, 0, 0);
+// `off` = the lane's place inside a tile image in BYTES, 8 (lc * C2_TS + 4 * lr) - formed once per step by the caller: as `lc, lr` arguments
+// the compiler rebuilt it for every tile (a 16-cycle v_mul_lo_u32 among them), and VALU instructions of a tile wave queue behind the
+// 64-cycle f64 MFMAs of the other tile wave on the SIMD.  The sign rides on the MFMA's operand modifier (for the f64 MFMAs the BLGP
+// field is NEG[a, b, c]) instead of four v_xor per tile, and all four operand pieces are requested BEFORE the first MFMA: left to
+// itself the compiler fetched the second half behind the first two MFMAs - two LDS round trips per tile instead of one.
+__device__ __forceinline__ double4_t c2_mfma_xyT(const double* X, const double* Y, double4_t acc, int off) {
+  const dbl2_t* xp = reinterpret_cast<const dbl2_t*>(reinterpret_cast<const char*>(X) + off);
+  const dbl2_t* yp = reinterpret_cast<const dbl2_t*>(reinterpret_cast<const char*>(Y) + off);
+  dbl2_t x0 = xp[0], y0 = yp[0], x1 = xp[1], y1 = yp[1];
+  asm volatile("" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1));
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[0], y0[0], acc, 0, 0, 1);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[1], y0[1], acc, 0, 0, 1);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[0], y1[0], acc, 0, 0, 1);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[1], y1[1], acc, 0, 0, 1);
   return acc;
 }
 
@@ -150,17 +156,17 @@ __device__ __forceinline__ void c2_last_update(double* Dbuf, double* Dupd, doubl
 #pragma unroll
     for (int t = 0; t < NS; ++t) acc2[t] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[t][0], y0[0], acc[t], 0, 0, 0);
+    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[t][0], y0[0], acc[t], 0, 0, 1);
 #pragma unroll
-    for (int t = 0; t < NS; ++t) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[S0 + t][0], y1[0], acc2[t], 0, 0, 0);
+    for (int t = 0; t < NS; ++t) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[S0 + t][0], y1[0], acc2[t], 0, 0, 1);
 #pragma unroll
-    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[t][1], y0[1], acc[t], 0, 0, 0);
+    for (int t = 0; t <= NH; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[t][1], y0[1], acc[t], 0, 0, 1);
 #pragma unroll
-    for (int t = 0; t < NS; ++t) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[S0 + t][1], y1[1], acc2[t], 0, 0, 0);
+    for (int t = 0; t < NS; ++t) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[S0 + t][1], y1[1], acc2[t], 0, 0, 1);
 #pragma unroll
-    for (int t = 0; t < S0; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][0], y1[0], acc[t], 0, 0, 0);
+    for (int t = 0; t < S0; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[t][0], y1[0], acc[t], 0, 0, 1);
 #pragma unroll
-    for (int t = 0; t < S0; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[t][1], y1[1], acc[t], 0, 0, 0);
+    for (int t = 0; t < S0; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[t][1], y1[1], acc[t], 0, 0, 1);
 #pragma unroll
     for (int t = 0; t < NS; ++t) acc[S0 + t] = acc[S0 + t] + acc2[t];
   }
@@ -306,10 +312,21 @@ __device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int
   if (cs - tw < 0) lo = 0;
 }
 
+// Cycle stamps (diagnostics, OVP_PL_STAMPS): compiled in only under -DOVP_C2_STAMPS (tools/build_c2_stamps.sh builds that library
+// beside the product one).  Even as `if (J.stamps && ...)` around nothing they are not free: ~10 tests per step and wave, each a
+// scalar branch on a chain that is all latency - 1 us of the 78 per launch (measured round 6: five more of them, +1.0 us).
+#ifdef OVP_C2_STAMPS
+#define C2_STAMPS_ON 1
 #define C2_STAMP(kk, i)                                                                              \
   do {                                                                                               \
     if (J.stamps && lane == 0) J.stamps[(kk) * 16 + (i)] = (long long)__builtin_readcyclecounter();  \
   } while (0)
+#else
+#define C2_STAMPS_ON 0
+#define C2_STAMP(kk, i) \
+  do {                  \
+  } while (0)
+#endif
 
 // The factorization proper.  On return (tile waves): tile[] = final factor tiles (MFMA accumulator layout); S.Dsave = diagonal
 // blocks, S.zbuf = border row (if any), S.pivs = pivots.  Every wave of the workgroup (C2_WAVES x 64 threads) must call it.
@@ -412,7 +429,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           const int a = __hip_atomic_load(cnt_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const int b = __hip_atomic_load(cnt_panel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const int c = __hip_atomic_load(cnt_trail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (J.stamps && spins == 0 && ew == 0 && lane == 0)  // diagnostics: what the step found on arrival
+          if (C2_STAMPS_ON && J.stamps && spins == 0 && ew == 0 && lane == 0)  // diagnostics: what the step found on arrival
             J.stamps[k * 16 + 4] = (long long)(a - t_col) * 1000000 + (long long)(b - t_panel) * 1000 + (c - t_trail) + 500500500;
           if (a >= t_col && b >= t_panel && c >= t_trail) break;
           asm volatile("s_nop 7");
@@ -447,7 +464,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
           if (k >= 1) {
             const int i0 = k + 1 + base + ew;  // (wave-uniform: tile rows of the four DPP rows are i0, i0 + 4, i0 + 8, i0 + 12)
             const int nh = i0 >= nt ? 0 : ((nt - i0 + C2_EW - 1) / C2_EW < 4 ? (nt - i0 + C2_EW - 1) / C2_EW : 4);
-            const bool skip = (J.dbg & 2) != 0;
+            const bool skip = C2_STAMPS_ON && (J.dbg & 2) != 0;  // (timing experiments: diagnostics build only)
             switch (nh) {
               case 0: c2_last_update<0>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
               case 1: c2_last_update<1>(S.Dbuf, S.Dupd, S.Dsave, pbp, k, i0, g, r, skip); break;
@@ -477,7 +494,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
             c2_signal(cnt_used, lane);
             used = true;
           }
-          if (!(J.dbg & 1)) {
+          if (!(C2_STAMPS_ON && (J.dbg & 1))) {
             dbl2_t* pvw = reinterpret_cast<dbl2_t*>(S.pivs + 16 * k);
             // (the plane update, mode 1, never looks at its pivots: the stores are 2 us of its 75)
             dbl2_t* dw = reinterpret_cast<dbl2_t*>(S.Dsave + k * C2_TSZ + r * C2_TS);
@@ -668,6 +685,10 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       // per-step opaque copies: otherwise the LDS address arithmetic of every slot is hoisted out of the step loop and spills
       int lc_k = lc, lr_k = lr;
       asm volatile("" : "+v"(lc_k), "+v"(lr_k));
+      int s_last_k = s_last;  // (opaque too: the fifteen `slot <= s_last` flags are loop invariants otherwise, spilled to VGPR lanes)
+      asm volatile("" : "+s"(s_last_k));
+      int off_k = 8 * (lc_k * C2_TS + 4 * lr_k);  // (the lane's operand offset of the trailing update in bytes, see c2_mfma_xyT)
+      asm volatile("" : "+v"(off_k));
       if (k >= cl) c2_col_slots(k, nt, tw, lo, hi, loff);
       auto put_rowmajor_k = [&](double* buf, const double4_t& t) {
 #pragma unroll
@@ -680,16 +701,18 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         return t;
       };
       if (k + 2 >= cl) c2_col_slots(k + 2, nt, tw, lo2, hi2, loff);  // (lo2 = first slot behind column k + 1; 0 = every owned tile)
-      if (hi2 > s_last) hi2 = s_last;  // (a column of the other workgroup: nothing of it is in the list)
+      if (hi2 > s_last_k) hi2 = s_last_k;  // (a column of the other workgroup: nothing of it is in the list)
       if (tw == 0) C2_STAMP(k, 8);
       c2_wait_ge(cnt_panel, C2_EW * (k + 1), S.cnt + 6);  // panel k is in LDS
       if (tw == 0) C2_STAMP(k, 9);
+      if (tw == C2_TW - 1) C2_STAMP(k, 7);
       // ---- the trailing update (column k + 2 first in the list) ----
-      slot_range<MAXSLOT>(lo2, s_last, [&](auto sc) {
+      slot_range<MAXSLOT>(lo2, s_last_k, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if (!(J.dbg & 2)) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], lc_k, lr_k);
+        if (!(C2_STAMPS_ON && (J.dbg & 2))) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], off_k);
       });
       if (tw == 0) C2_STAMP(k, 10);
+      if (tw == C2_TW - 1) C2_STAMP(k, 5);  // (the last tile wave - the youngest on its SIMD, the one the step waits for)
       // own tiles of column k take their final values (the panel buffer lives until step k + 2; L_kk is put down behind the
       // elimination waves' signal, its owner waits for a counter of its own)
       slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
@@ -704,8 +727,10 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       // column k + 2 goes out LAST: the elimination waves need it a whole step of theirs from now, and they have taken column
       // k + 1 out of the same LDS words by now (publishing right behind its update - the tile wave idled 2 - 10 K cycles for that
       // in the first steps, where the elimination waves are themselves held up by the tile waves' previous update)
+      if (tw == 0 && k >= 2) C2_STAMP(k, 13);  // (rows 0 and 1 carry the prologue's stamps there)
       if (pub) {
         c2_wait_ge(cnt_used, C2_EW * (k + 2 - cl), S.cnt + 6);
+        if (tw == 0 && k >= 2) C2_STAMP(k, 14);
         slot_range<MAXSLOT>(lo2, hi2, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
           if (ti[s] == k + 2) put_rowmajor_k(S.Dbuf, tile[s]);
@@ -716,6 +741,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (tw == 0) C2_STAMP(k, 11);
       c2_signal(cnt_trail, lane);  // done with panel k
       if (tw == 0) C2_STAMP(k, 12);
+      if (tw == C2_TW - 1) C2_STAMP(k, 6);
     }
   }
   bad_out = (bad && !(J.piv_floor > 0.0)) ? 1 : 0;
@@ -788,7 +814,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
   if (k_hi < 0) k_hi = nt;
 #define BS_STAMP(kk, i)                                                                       \
   do {                                                                                        \
-    if (stamps && lane == 0) stamps[(kk) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+    if (C2_STAMPS_ON && stamps && lane == 0) stamps[(kk) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1431,6 +1457,8 @@ hipError_t ovp_launch_chol2_packed(const double* A, double* Dinv, double* Lpack,
 
 // one workgroup (j1 == nullptr), two (plane loop: update part and range part side by side) or three (the update part split over
 // two workgroups, j0->split_h > 0: block 0 = tile columns < split_h, block 2 = the rest)
+int ovp_chol2_stamps_compiled(void) { return C2_STAMPS_ON; }
+
 hipError_t ovp_launch_chol2(const ovp::Chol2Job* j0, const ovp::Chol2Job* j1, const ovp::PlaneSolve* ps, hipStream_t stream) {
   using namespace ovp;
   auto ntof = [](const Chol2Job* j) { return ((j->brow ? j->n + 1 : j->n) + 15) / 16; };

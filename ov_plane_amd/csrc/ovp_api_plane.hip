@@ -818,7 +818,9 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
       }
       HIPCHK(hipEventRecord(c->pl_ev[2 * jn], s));
     }
-    static const bool pl_stamps = getenv("OVP_PL_STAMPS") != nullptr;  // diagnostics: cycle stamps of the last plane's tail
+    // diagnostics: cycle stamps of the last plane's launch - only a library whose k_chol2 was compiled with them writes any
+    // (tools/build_c2_stamps.sh; the product build leaves them out: their tests cost 1 us per launch)
+    static const bool pl_stamps = getenv("OVP_PL_STAMPS") != nullptr && ovp_chol2_stamps_compiled();
     static long long* d_stamps = nullptr;
     if (pl_stamps) {
       if (!d_stamps) HIPCHK(hipMalloc((void**)&d_stamps, sizeof(long long) * 2 * 16 * 32));
@@ -847,8 +849,13 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
           for (int k = 0; k < ntb; ++k) {
             const long long* q = hp + k * 16;
             if (!q[0] && !q[8]) continue;
-            fprintf(stderr, "  k=%2d E %7lld %7lld %7lld %7lld | T %7lld %7lld %7lld %7lld %7lld\n", k, q[0] - t0, q[1] - t0, q[2] - t0,
-                    q[3] - t0, q[8] - t0, q[9] - t0, q[10] - t0, q[11] - t0, q[12] - t0);
+            // arrival word of the elimination step: what was missing of {column, panel, trailing} when wave 0 first looked (0 = there)
+            const long long aw = q[4] - 500500500;
+            const long long am = llround((double)aw / 1e6), ar = aw - am * 1000000, ap = llround((double)ar / 1e3), at = ar - ap * 1000;
+            fprintf(stderr, "  k=%2d E %7lld %7lld %7lld %7lld [%3lld %3lld %3lld] | T %7lld %7lld %7lld %7lld %7lld | T7 %7lld %7lld %7lld\n", k,
+                    q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0, am, ap, at, q[8] - t0, q[9] - t0, q[10] - t0, q[11] - t0, q[12] - t0,
+                    q[7] - t0, q[5] - t0, q[6] - t0);
+            if (k >= 2 && atoi(getenv("OVP_PL_STAMPS")) >= 3) fprintf(stderr, "        T own tiles final %7lld, column k+1 taken %7lld\n", q[13] - t0, q[14] - t0);
           }
           const long long* m = hp + (ntb + 1) * 16;
           fprintf(stderr, "  tail: factor done %lld, gate %lld, backsolve %lld, dx %lld, commit %lld\n", m[0] - t0, m[1] - t0, m[2] - t0,
