@@ -690,14 +690,21 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       int off_k = 8 * (lc_k * C2_TS + 4 * lr_k);  // (the lane's operand offset of the trailing update in bytes, see c2_mfma_xyT)
       asm volatile("" : "+v"(off_k));
       if (k >= cl) c2_col_slots(k, nt, tw, lo, hi, loff);
+      // the lane's place in a tile image in the ACCUMULATOR layout (rows lr + 4 v of column lc), in bytes, once per step: the four
+      // elements are then one address add and immediate offsets (as `(lr_k + 4 v) * C2_TS + lc_k` the address arithmetic was rebuilt
+      // at every node of the slot dispatch - VALU instructions that queue behind the other waves' MFMAs)
+      int acc_off_k = 8 * (lr_k * C2_TS + lc_k);
+      asm volatile("" : "+v"(acc_off_k));
       auto put_rowmajor_k = [&](double* buf, const double4_t& t) {
+        double* b = reinterpret_cast<double*>(reinterpret_cast<char*>(buf) + acc_off_k);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) buf[(lr_k + 4 * v) * C2_TS + lc_k] = t[v];
+        for (int v = 0; v < 4; ++v) b[4 * v * C2_TS] = t[v];
       };
       auto get_acc_k = [&](const double* buf) {
+        const double* b = reinterpret_cast<const double*>(reinterpret_cast<const char*>(buf) + acc_off_k);
         double4_t t;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) t[v] = buf[(lr_k + 4 * v) * C2_TS + lc_k];
+        for (int v = 0; v < 4; ++v) t[v] = b[4 * v * C2_TS];
         return t;
       };
       if (k + 2 >= cl) c2_col_slots(k + 2, nt, tw, lo2, hi2, loff);  // (lo2 = first slot behind column k + 1; 0 = every owned tile)
@@ -717,11 +724,14 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       // elimination waves' signal, its owner waits for a counter of its own)
       slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        tile[s] = (ti[s] == k) ? get_acc_k(S.Dsave + k * C2_TSZ) : get_acc_k(pbk + ti[s] * C2_TSZ);
+        tile[s] = get_acc_k((ti[s] == k) ? S.Dsave + k * C2_TSZ : pbk + ti[s] * C2_TSZ);
         // the border row of the factor, z = L^-1 brow^T: row rb of the tiles of tile row tb (columns behind the border are not z)
-        if (nb > n && ti[s] == tb && lr_k == (rb & 3)) {
-          const int col = 16 * k + lc_k;
-          if (col < n) S.zbuf[col] = tile[s][rb >> 2];
+        if (nb > n && ti[s] == tb) {  // (wave-uniform: a branch, not a lane mask evaluated for every tile)
+          asm volatile("");
+          if (lr_k == (rb & 3)) {
+            const int col = 16 * k + lc_k;
+            if (col < n) S.zbuf[col] = tile[s][rb >> 2];
+          }
         }
       });
       // column k + 2 goes out LAST: the elimination waves need it a whole step of theirs from now, and they have taken column
