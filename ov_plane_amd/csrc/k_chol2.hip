@@ -678,8 +678,24 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
     // elimination waves, who own the chain - and column k + 2, then complete up to that panel, is published for them: a step
     // ahead of its use, so nothing here is waited for by the chain (the publication only has to follow the elimination waves'
     // "column k + 1 taken": it goes into the same LDS words - Dbuf and the images of L_ii, i >= k + 3, free until step i).
+    // (tile row, tile column) of a slot as ONE scalar inside the step loop, unpacked where it is used from a per-step opaque copy:
+    // with ti[] / tj[] the compiler hoists every slot's `ti * tile size`, `tj * tile size` out of the step loop - 45 live scalars for
+    // fifteen slots, most of them spilled to VGPR lanes and fetched back with v_readlane (VALU, behind the other waves' MFMAs)
+    int tij[MAXSLOT];
+    sfor<MAXSLOT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      tij[s] = (ti[s] & 0xff) | ((tj[s] & 0xff) << 8);
+    });
     for (int k = 0; k < kend; ++k) {
       double* pbk = S.PB + (k & 1) * nt * C2_TSZ;
+      int tq[MAXSLOT];
+      sfor<MAXSLOT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        tq[s] = tij[s];
+        asm volatile("" : "+s"(tq[s]));
+      });
+      auto TI = [&](auto sc) { return (tq[decltype(sc)::value] << 24) >> 24; };  // (signed bytes: -1 = no tile)
+      auto TJ = [&](auto sc) { return (tq[decltype(sc)::value] << 16) >> 24; };
       int lo = 0, hi = -1, lo2 = 0, hi2 = -1;
       const bool pub = (k + 2 >= cl) && (k + 2 < kend);  // column k + 2 is this workgroup's to publish
       // per-step opaque copies: otherwise the LDS address arithmetic of every slot is hoisted out of the step loop and spills
@@ -716,7 +732,7 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       // ---- the trailing update (column k + 2 first in the list) ----
       slot_range<MAXSLOT>(lo2, s_last_k, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if (!(C2_STAMPS_ON && (J.dbg & 2))) tile[s] = c2_mfma_xyT(pbk + ti[s] * C2_TSZ, pbk + tj[s] * C2_TSZ, tile[s], off_k);
+        if (!(C2_STAMPS_ON && (J.dbg & 2))) tile[s] = c2_mfma_xyT(pbk + TI(sc) * C2_TSZ, pbk + TJ(sc) * C2_TSZ, tile[s], off_k);
       });
       if (tw == 0) C2_STAMP(k, 10);
       if (tw == C2_TW - 1) C2_STAMP(k, 5);  // (the last tile wave - the youngest on its SIMD, the one the step waits for)
@@ -724,9 +740,10 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       // elimination waves' signal, its owner waits for a counter of its own)
       slot_range<MAXSLOT>(lo, hi, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        tile[s] = get_acc_k((ti[s] == k) ? S.Dsave + k * C2_TSZ : pbk + ti[s] * C2_TSZ);
+        const int ti_s = TI(sc);
+        tile[s] = get_acc_k((ti_s == k) ? S.Dsave + k * C2_TSZ : pbk + ti_s * C2_TSZ);
         // the border row of the factor, z = L^-1 brow^T: row rb of the tiles of tile row tb (columns behind the border are not z)
-        if (nb > n && ti[s] == tb) {  // (wave-uniform: a branch, not a lane mask evaluated for every tile)
+        if (nb > n && ti_s == tb) {  // (wave-uniform: a branch, not a lane mask evaluated for every tile)
           asm volatile("");
           if (lr_k == (rb & 3)) {
             const int col = 16 * k + lc_k;
@@ -743,8 +760,9 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
         if (tw == 0 && k >= 2) C2_STAMP(k, 14);
         slot_range<MAXSLOT>(lo2, hi2, [&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if (ti[s] == k + 2) put_rowmajor_k(S.Dbuf, tile[s]);
-          else put_rowmajor_k(S.Dsave + ti[s] * C2_TSZ, tile[s]);
+          const int ti_s = TI(sc);
+          if (ti_s == k + 2) put_rowmajor_k(S.Dbuf, tile[s]);
+          else put_rowmajor_k(S.Dsave + ti_s * C2_TSZ, tile[s]);
         });
         c2_signal(cnt_col, lane);
       }
@@ -753,6 +771,11 @@ __device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& 
       if (tw == 0) C2_STAMP(k, 12);
       if (tw == C2_TW - 1) C2_STAMP(k, 6);
     }
+    sfor<MAXSLOT>([&](auto sc) {  // (for the callers: the arrays need not live across the loop)
+      constexpr int s = decltype(sc)::value;
+      ti[s] = (tij[s] << 24) >> 24;
+      tj[s] = (tij[s] << 16) >> 24;
+    });
   }
   bad_out = (bad && !(J.piv_floor > 0.0)) ? 1 : 0;
 }
