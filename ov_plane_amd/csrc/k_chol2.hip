@@ -235,9 +235,17 @@ __device__ __forceinline__ void c2_wait_ge(int* ctr, int target, int* tmo) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// The counter behind the data WITHOUT the wait of a release fence (round 6; until then `fence release` + atomic add: an
+// `s_waitcnt lgkmcnt(0)` - one LDS round trip - in front of every hand-over, most of them on the critical chain, and a dozen
+// instructions of wave-aggregation around the add).  The LDS executes a wave's operations in order and keeps no copies: once the
+// add has executed, the wave's stores in front of it have, and a reader that has seen the increment reads them.  The compiler is held
+// by the memory clobbers; its lgkmcnt bookkeeping does not know the add is in flight, which only makes its waits more conservative
+// (the counter is in order for LDS operations).
 __device__ __forceinline__ void c2_signal(int* ctr, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) int*)ctr;
+  asm volatile("" ::: "memory");
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(a), "v"(1) : "memory");
+  asm volatile("" ::: "memory");
 }
 
 // f(slot) for the slots lo..hi (wave-uniform bounds) of the statically indexed tile registers: one jump into the unrolled
@@ -976,7 +984,7 @@ __device__ __forceinline__ void chol2_backsolve(const Chol2Lds& S, int n, int nt
       y = (y0 + y1) + (y2 + y3);
       if (16 * k + r >= n) y = 0.0;
       if (lane < 16) S.ybuf[16 * k + r] = y;
-      c2_signal(cnt_y, lane);  // (before the next operands are requested: the release fence waits for everything in flight)
+      c2_signal(cnt_y, lane);
       load_di(k - 1);
       BS_STAMP(k, 7);
     }
