@@ -1051,6 +1051,10 @@ __device__ __forceinline__ void c2_pack_tile(double* __restrict__ Lpack, const d
   }
 }
 
+// offset of the third kernel argument (k_chol2(Chol2Job, Chol2Job, PlaneSolve)) in the kernel-argument segment
+static constexpr size_t C2_PS_KERNARG_OFFSET = (2 * sizeof(Chol2Job) + alignof(PlaneSolve) - 1) / alignof(PlaneSolve) * alignof(PlaneSolve);
+static_assert(sizeof(Chol2Job) % alignof(Chol2Job) == 0 && alignof(Chol2Job) == 8 && alignof(PlaneSolve) == 8, "kernel-argument layout");
+
 struct Chol2Shared {  // workgroup variables both role instantiations of the body see
   int bad, ok;
   double zz;
@@ -1261,36 +1265,44 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   __syncthreads();
   if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
   M1_STAMP(1);
+  // From here on the plane's parameters are read AFRESH from the kernel-argument segment (scalar loads through a pointer the compiler
+  // cannot see through): as members of the by-value argument every field the tail uses - some thirty pointers and counts - was
+  // fetched at the kernel's entry and carried through the factorization in scalar registers, i.e. in spill lanes of vector registers
+  // written and read back (v_writelane / v_readlane, VALU instructions) around its loops.
+  typedef const PlaneSolve __attribute__((address_space(4))) PlaneSolveK;
+  PlaneSolveK* pk = (PlaneSolveK*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + C2_PS_KERNARG_OFFSET);
+  asm volatile("" : "+s"(pk));
+  PlaneSolveK& pq = *pk;
 
   const int ntn = (n + 15) >> 4;           // tile rows of the n x n part
   const int h_bs = part >= 0 ? (J.split_h < ntn ? J.split_h : ntn) : 0;
   if (part == 0)  // y blocks of part B's columns (published before its decision)
-    for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) S.ybuf[i] = ps.xy[i];
+    for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) S.ybuf[i] = pq.xy[i];
   chol2_backsolve<NS, ROLE>(S, n, ntn, tile, ti, tj, nullptr, part == 0 ? h_bs : ntn, part == 1 ? h_bs : 0);
   M1_STAMP(2);
   if (part == 1) {
     // ---- part B ends here: its y blocks and the decision go to part A, its share of the factor to the buffers behind the loop ----
-    for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) ps.xy[i] = S.ybuf[i];
+    for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) pq.xy[i] = S.ybuf[i];
     __syncthreads();
     if (tid == 0) {
       const bool fine = S.cnt[6] == 0;  // no hand-over of the back substitution timed out
       if (!fine) {
         if (J.flag) atomicOr(J.flag, 2);
-        ps.res_out[1] = 0.0;
+        pq.res_out[1] = 0.0;
       }
-      __hip_atomic_store(ps.xsync + 1, ((ps.seq & 0x7fffffffu) << 1) | (fine ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pq.xsync + 1, ((pq.seq & 0x7fffffffu) << 1) | (fine ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (ps.cond && ps.emit && S.cnt[6] == 0) {
+    if (pq.cond && pq.emit && S.cnt[6] == 0) {
       if constexpr (ROLE == 1) {
         sfor<MAXSLOT>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc, ps.n_full);
+          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(pq.Lpack, tile[s], ti[s], tj[s], n, lr, lc, pq.n_full);
         });
       } else {
         for (int e = 256 * h_bs + tid; e < ntn * 256; e += C2_EW * 64) {
           const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
           const int gr = 16 * k + i, gc = 16 * k + c;
-          ps.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
+          pq.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
         }
       }
     }
@@ -1298,14 +1310,14 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   }
   // dx = L0 y  (L0 dense lower triangular, row-major).  Two threads per row, each streaming half of the row's non-zeros with
   // 16-byte loads that are all in flight together (a wave-per-row loop serialised one L2 round trip per row: 40 us).
-  const int nfull = ps.n_full > n ? ps.n_full : n;  // rows of L0 (the factorization may have run on the leading n columns only)
+  const int nfull = pq.n_full > n ? pq.n_full : n;  // rows of L0 (the factorization may have run on the leading n columns only)
   double* dxs = nfull > n ? S.PB : S.zbuf;  // z is no longer needed; the panel buffers (free behind the back substitution) when
                                             // the correction is longer than the factorized dimension
   __syncthreads();
   if (S.cnt[6]) {  // a hand-over of the back substitution timed out: nothing is committed, the call fails
     if (tid == 0) {
       if (J.flag) atomicOr(J.flag, 2);
-      ps.res_out[1] = 0.0;
+      pq.res_out[1] = 0.0;
     }
     return;
   }
@@ -1333,7 +1345,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
         const int row = wv + 12 * (JLO + j);
         const int lastc = row < n ? row : n - 1;  // last column of the row's non-zeros that meets y
         const int npair = (lastc + 2) >> 1;       // 16-byte pairs covering columns 0..lastc (ld is even, rows are 16-byte aligned)
-        const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(ps.L0 + (size_t)row * ps.ld0);
+        const dbl2_t* lrow = reinterpret_cast<const dbl2_t*>(pq.L0 + (size_t)row * pq.ld0);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const int q = ln + 64 * k;
@@ -1372,11 +1384,11 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   M1_STAMP(3);
   // ---- commit (ext Type::update on the device tables, update/UpdaterMSCKF.cpp:646-648) ----
   for (int i = tid; i < nfull; i += C2_WAVES * 64) {
-    ps.dx_out[i] = dxs[i];
-    ps.dx_last[i] = dxs[i];
+    pq.dx_out[i] = dxs[i];
+    pq.dx_last[i] = dxs[i];
   }
-  if (tid == 0) *ps.cur ^= 1;  // the accumulated T of this plane becomes the current one
-  for (int i = tid; i < ps.n_feat_local; i += C2_WAVES * 64) ps.feat_used[ps.feat_list[i]] = 1;
+  if (tid == 0) *pq.cur ^= 1;  // the accumulated T of this plane becomes the current one
+  for (int i = tid; i < pq.n_feat_local; i += C2_WAVES * 64) pq.feat_used[pq.feat_list[i]] = 1;
   auto rot_update = [&](double* R, const double* dth) {
     double qx = 0.5 * dth[0], qy = 0.5 * dth[1], qz = 0.5 * dth[2], qw = 1.0;
     const double nn = 1.0 / sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
@@ -1400,33 +1412,33 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
       for (int j = 0; j < 3; ++j) O[3 * i + j] = D[3 * i] * R[j] + D[3 * i + 1] * R[3 + j] + D[3 * i + 2] * R[6 + j];
     for (int i = 0; i < 9; ++i) R[i] = O[i];
   };
-  if (tid < ps.n_clones) {
-    const int id = ps.clone_id[tid];
-    rot_update(ps.clone_R + 9 * tid, dxs + id);
-    for (int k = 0; k < 3; ++k) ps.clone_p[3 * tid + k] += dxs[id + 3 + k];
-  } else if (tid == ps.n_clones) {
-    if (ps.calib_id >= 0) {
-      rot_update(ps.cal, dxs + ps.calib_id);
-      for (int k = 0; k < 3; ++k) ps.cal[9 + k] += dxs[ps.calib_id + 3 + k];
+  if (tid < pq.n_clones) {
+    const int id = pq.clone_id[tid];
+    rot_update(pq.clone_R + 9 * tid, dxs + id);
+    for (int k = 0; k < 3; ++k) pq.clone_p[3 * tid + k] += dxs[id + 3 + k];
+  } else if (tid == pq.n_clones) {
+    if (pq.calib_id >= 0) {
+      rot_update(pq.cal, dxs + pq.calib_id);
+      for (int k = 0; k < 3; ++k) pq.cal[9 + k] += dxs[pq.calib_id + 3 + k];
     }
-    if (ps.intr_id >= 0)
-      for (int k = 0; k < 8; ++k) ps.cal[12 + k] += dxs[ps.intr_id + k];
-  } else if (tid > ps.n_clones && tid <= ps.n_clones + ps.n_planes) {
-    const int pl = tid - ps.n_clones - 1;
-    if (ps.plane_sid[pl] >= 0)
-      for (int k = 0; k < 3; ++k) ps.cp[3 * pl + k] += dxs[ps.plane_sid[pl] + k];
+    if (pq.intr_id >= 0)
+      for (int k = 0; k < 8; ++k) pq.cal[12 + k] += dxs[pq.intr_id + k];
+  } else if (tid > pq.n_clones && tid <= pq.n_clones + pq.n_planes) {
+    const int pl = tid - pq.n_clones - 1;
+    if (pq.plane_sid[pl] >= 0)
+      for (int k = 0; k < 3; ++k) pq.cp[3 * pl + k] += dxs[pq.plane_sid[pl] + k];
   }
-  for (int q = tid; q < ps.n_slam; q += C2_WAVES * 64)
-    for (int k = 0; k < 3; ++k) ps.slam_p[3 * q + k] += dxs[ps.slam_id[q] + k];
+  for (int q = tid; q < pq.n_slam; q += C2_WAVES * 64)
+    for (int k = 0; k < 3; ++k) pq.slam_p[3 * q + k] += dxs[pq.slam_id[q] + k];
   M1_STAMP(4);
   // ---- the factor for the covariance product behind the loop ----
-  if (ps.cond) {
-    if (tid == 0) ps.cond[1] = ps.seq_plane;
-    if (ps.emit) {
+  if (pq.cond) {
+    if (tid == 0) pq.cond[1] = pq.seq_plane;
+    if (pq.emit) {
       if constexpr (ROLE == 1) {
         sfor<MAXSLOT>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(ps.Lpack, tile[s], ti[s], tj[s], n, lr, lc, ps.n_full);
+          if (ti[s] >= 0 && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(pq.Lpack, tile[s], ti[s], tj[s], n, lr, lc, pq.n_full);
         });
       } else {
         // inverses of the diagonal blocks (the back substitution left them in S.Dsave), identity at / behind the border row
@@ -1434,9 +1446,9 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
         for (int e = tid; e < (part == 0 ? h_bs : ntn) * 256; e += C2_EW * 64) {
           const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
           const int gr = 16 * k + i, gc = 16 * k + c;
-          ps.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
+          pq.Dinv[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
         }
-        if (tid == 0) ps.cond[0] = ps.seq_plane;
+        if (tid == 0) pq.cond[0] = pq.seq_plane;
       }
     }
   }
