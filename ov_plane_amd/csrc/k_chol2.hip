@@ -1061,7 +1061,7 @@ struct Chol2Shared {  // workgroup variables both role instantiations of the bod
 };
 
 template <int MAXSLOT, int ROLE, bool SPLIT>
-__device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve& ps, double* lds, Chol2Shared& sh) {
+__device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve& ps, double* lds, Chol2Shared& sh, const int joff) {
   const int n = J0_.n;
   const int nb = J0_.brow ? n + 1 : n;
   const int nt = (nb + 15) >> 4;
@@ -1092,56 +1092,68 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   if (tid == 0 && S.cnt[6]) atomicOr(&sh_bad, 2);  // a hand-over timed out (c2_wait_ge)
   __syncthreads();
   bad = sh_bad;
-  if (bad && tid == 0 && J.flag) atomicOr(J.flag, bad);
+  // From here on the job and the plane's parameters are read AFRESH from the kernel-argument segment (scalar loads through pointers
+  // the compiler cannot see through): as members of the by-value arguments every field the code behind the factorization uses - some
+  // forty pointers and counts - was fetched at the kernel's entry and carried through the factorization in scalar registers, i.e. in
+  // spill lanes of vector registers written and read back (v_writelane / v_readlane, VALU instructions) around its loops.
+  typedef const PlaneSolve __attribute__((address_space(4))) PlaneSolveK;
+  typedef const Chol2Job __attribute__((address_space(4))) Chol2JobK;
+  typedef const char __attribute__((address_space(4))) KernargByte;
+  PlaneSolveK* pk = (PlaneSolveK*)((KernargByte*)__builtin_amdgcn_kernarg_segment_ptr() + C2_PS_KERNARG_OFFSET);
+  Chol2JobK* jk = (Chol2JobK*)((KernargByte*)__builtin_amdgcn_kernarg_segment_ptr() + joff);
+  asm volatile("" : "+s"(pk), "+s"(jk));
+  PlaneSolveK& pq = *pk;
+  Chol2JobK& jq = *jk;
+  if (bad && tid == 0 && jq.flag) atomicOr(jq.flag, bad);
 
-  if (J.mode == 0) {
+  if (jq.mode == 0) {
     // ---- outputs of a plain factorization ----
-    if (J.z_out)
-      for (int i = tid; i < n; i += C2_WAVES * 64) J.z_out[i] = S.zbuf[i];
-    if (J.y_out) {  // diagnostics: y = L^-T z
-      chol2_backsolve<NS, ROLE>(S, n, (n + 15) >> 4, tile, ti, tj, J.stamps);
-      for (int i = tid; i < n; i += C2_WAVES * 64) J.y_out[i] = S.ybuf[i];
+    if (jq.z_out)
+      for (int i = tid; i < n; i += C2_WAVES * 64) jq.z_out[i] = S.zbuf[i];
+    if (jq.y_out) {  // diagnostics: y = L^-T z
+      chol2_backsolve<NS, ROLE>(S, n, (n + 15) >> 4, tile, ti, tj, jq.stamps);
+      for (int i = tid; i < n; i += C2_WAVES * 64) jq.y_out[i] = S.ybuf[i];
     }
     if constexpr (ROLE == 1) {
     sfor<MAXSLOT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if (ti[s] >= 0) {
-        if (J.Ldense) {
+        if (jq.Ldense) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int rr = 16 * ti[s] + lr + 4 * v, cc = 16 * tj[s] + lc;
             if (rr < nb && cc < nb) {
-              const int ro = J.flip ? n - 1 - rr : rr, rz = J.flip ? n - 1 - cc : cc;  // (flip: no border row, nb == n)
-              J.Ldense[(size_t)ro * J.ldo + cc] = (cc <= rr) ? tile[s][v] : 0.0;
-              if (ti[s] != tj[s]) J.Ldense[(size_t)rz * J.ldo + rr] = 0.0;
+              const int ro = jq.flip ? n - 1 - rr : rr, rz = jq.flip ? n - 1 - cc : cc;  // (flip: no border row, nb == n)
+              jq.Ldense[(size_t)ro * jq.ldo + cc] = (cc <= rr) ? tile[s][v] : 0.0;
+              if (ti[s] != tj[s]) jq.Ldense[(size_t)rz * jq.ldo + rr] = 0.0;
             }
           }
         }
-        if (J.Lpack && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(J.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
+        if (jq.Lpack && 16 * ti[s] < n && 16 * tj[s] < n) c2_pack_tile(jq.Lpack, tile[s], ti[s], tj[s], n, lr, lc);
       }
     });
     }
-    if (J.piv_out)
-      for (int i = tid; i < n; i += C2_WAVES * 64) J.piv_out[i] = S.pivs[i];
-    if (J.Dinv_out) {
+    if (jq.piv_out)
+      for (int i = tid; i < n; i += C2_WAVES * 64) jq.piv_out[i] = S.pivs[i];
+    if (jq.Dinv_out) {
       // inverses of the diagonal blocks in the layout k_fwdsub reads (identity at / behind the border row): with Lpack this is
       // everything the covariance product behind an update needs from chol(T)
       const int ntn = (n + 15) >> 4;
       if constexpr (ROLE == 0)
-        if (!J.y_out) c2_invert_diag_blocks(S, 0, ntn, wave, lr, lc);  // (the back substitution has inverted them already)
+        if (!jq.y_out) c2_invert_diag_blocks(S, 0, ntn, wave, lr, lc);  // (the back substitution has inverted them already)
       __syncthreads();
       if constexpr (ROLE == 0) {
         for (int e = tid; e < ntn * 256; e += C2_EW * 64) {
           const int k = e >> 8, i = (e >> 4) & 15, c = e & 15;
           const int gr = 16 * k + i, gc = 16 * k + c;
-          J.Dinv_out[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
+          jq.Dinv_out[e] = (gr < n && gc < n) ? S.Dsave[k * C2_TSZ + i * C2_TS + c] : (i == c ? 1.0 : 0.0);
         }
       }
     }
     return;
   }
 
-  if (J.mode == 2) {
+  if (jq.mode == 2) {
     // ---- range part of the plane's residual:  pr = |Lr^-1 bn|^2, rank deficiency of the normalised Gram ----
     // Rank: with the regularisation eps on the unit diagonal a deficient direction shows up as a pivot of eps x (1 .. 1e5) - the
     // factor is |v|^2 / v_c^2 for the null vector v completed at column c - while the pivots of the well-determined directions
@@ -1155,8 +1167,8 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
       // rank deficiency = pivots below tol_strict + pivots below tol_loose behind the first of those, counted by the whole wave
       // (one lane walking the ~200 pivots in LDS was 20 K cycles at the end of this workgroup - the gate of the other one waited)
       int first = 0x7fffffff, n_strict = 0;
-      for (int i = lane; i < ps.n_involved; i += 64) {
-        if (S.pivs[i] < ps.tol_strict) {
+      for (int i = lane; i < pq.n_involved; i += 64) {
+        if (S.pivs[i] < pq.tol_strict) {
           ++n_strict;
           first = i < first ? i : first;
         }
@@ -1168,18 +1180,18 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
         first = o < first ? o : first;
       }
       int n_loose = 0;
-      for (int i = lane; i < ps.n_involved; i += 64) {
+      for (int i = lane; i < pq.n_involved; i += 64) {
         const double pv = S.pivs[i];
-        if (i > first && !(pv < ps.tol_strict) && pv < ps.tol_loose) ++n_loose;
+        if (i > first && !(pv < pq.tol_strict) && pv < pq.tol_loose) ++n_loose;
       }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) n_loose += __shfl_xor(n_loose, m);
       if (lane == 0) {
         const int ndeg = n_strict + n_loose;
-        ps.scal[1] = pr;
-        ps.scal[2] = (double)ndeg;
+        pq.scal[1] = pr;
+        pq.scal[2] = (double)ndeg;
         __threadfence();
-        __hip_atomic_store(ps.range_done, ps.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pq.range_done, pq.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -1194,20 +1206,20 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
     zz = wave_sum(zz);
     if (lane == 0 && part == 0) {
       // part A: its share of |z|^2 and the verdict on its pivots go to part B, which decides; then wait for the decision
-      ps.xzz[0] = zz;
-      ps.xzz[1] = (double)bad;
-      __hip_atomic_store(ps.xsync, ps.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      pq.xzz[0] = zz;
+      pq.xzz[1] = (double)bad;
+      __hip_atomic_store(pq.xsync, pq.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       unsigned v = 0u;
       bool timed_out = false;
-      while (((v = __hip_atomic_load(ps.xsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (ps.seq & 0x7fffffffu)) {
+      while (((v = __hip_atomic_load(pq.xsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (pq.seq & 0x7fffffffu)) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 19)) {
           timed_out = true;
           break;
         }
       }
-      if (timed_out && J.flag) atomicOr(J.flag, 2);
+      if (timed_out && jq.flag) atomicOr(jq.flag, 2);
       sh_zz = zz;
       sh_ok = (!timed_out && (v & 1u)) ? 1 : 0;
     } else if (lane == 0) {
@@ -1217,65 +1229,57 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
       int spins = 0;
       bool timed_out = false;
       if (part == 1) {  // the other half of |z|^2
-        while (__hip_atomic_load(ps.xsync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) {
+        while (__hip_atomic_load(pq.xsync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != pq.seq) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1 << 19)) {
             timed_out = true;
             break;
           }
         }
-        zz += ps.xzz[0];
-        bad |= (int)ps.xzz[1];
+        zz += pq.xzz[0];
+        bad |= (int)pq.xzz[1];
         spins = 0;
       }
-      while (__hip_atomic_load(ps.range_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ps.seq) {
+      while (__hip_atomic_load(pq.range_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != pq.seq) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 18)) {
           timed_out = true;
           break;
         }
       }
-      if (timed_out && J.flag) atomicOr(J.flag, 2);
-      const double rr = ps.scal[0], pr = ps.scal[1], ndeg = ps.scal[2];
+      if (timed_out && jq.flag) atomicOr(jq.flag, 2);
+      const double rr = pq.scal[0], pr = pq.scal[1], ndeg = pq.scal[2];
       // The reference keeps rows_u rows of the Givens-compressed system of which (rows_u - rank) carry no Jacobian: each is a
       // combination of the rows below it weighted by the ROUNDING NOISE those rows hold in a deficient column.  The m identical
       // constraint rows of a feature leave m - 1 rows that are zero to the last bit (no noise, no weight), so the retained rows
       // sample the rows_live = sum(2m - 2) directions that carry residual energy, not all 3m - 3 of them
       // (tools/plane_gate_study.py: energy per retained junk row 0.98 against 0.64 per stacked row on config-3 planes).
-      const double rank = (double)ps.n_involved - ndeg;
-      const double noise_rows = fmax((double)ps.rows_u - rank, 0.0);
-      const double denom = (double)ps.rows_live - rank;
+      const double rank = (double)pq.n_involved - ndeg;
+      const double noise_rows = fmax((double)pq.rows_u - rank, 0.0);
+      const double denom = (double)pq.rows_live - rank;
       const double frac = denom > 0.5 ? fmin(noise_rows / denom, 1.0) : 1.0;
-      const double chi2 = (pr - zz) + ps.noise_scale * frac * fmax(rr - pr, 0.0);
+      const double chi2 = (pr - zz) + pq.noise_scale * frac * fmax(rr - pr, 0.0);
       // any failure upstream (chol(P) of the loop's start, an earlier plane's factorization) rejects this and every later plane
       // BEFORE anything is committed: with a failed L0 the tables and the covariance would otherwise drift apart
-      const int upstream = J.flag ? __hip_atomic_load(J.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      const int upstream = jq.flag ? __hip_atomic_load(jq.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       const bool fact_ok = (bad == 0) && !timed_out && upstream == 0;
-      const bool ok = fact_ok && (ps.force == 0 ? false : (ps.force == 1 ? true : (chi2 <= ps.thr)));
-      ps.res_out[0] = chi2;
-      ps.res_out[1] = ok ? 1.0 : 0.0;
-      ps.res_out[2] = ndeg;
-      ps.res_out[3] = pr;
+      const bool ok = fact_ok && (pq.force == 0 ? false : (pq.force == 1 ? true : (chi2 <= pq.thr)));
+      pq.res_out[0] = chi2;
+      pq.res_out[1] = ok ? 1.0 : 0.0;
+      pq.res_out[2] = ndeg;
+      pq.res_out[3] = pr;
       sh_zz = zz;
       sh_ok = ok ? 1 : 0;
       if (part == 1 && !ok)  // part A is waiting for the decision
-        __hip_atomic_store(ps.xsync + 1, (ps.seq & 0x7fffffffu) << 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pq.xsync + 1, (pq.seq & 0x7fffffffu) << 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
   if (!sh_ok) return;  // rejected: nothing changes (update/UpdaterMSCKF.cpp:613-631)
   M1_STAMP(1);
-  // From here on the plane's parameters are read AFRESH from the kernel-argument segment (scalar loads through a pointer the compiler
-  // cannot see through): as members of the by-value argument every field the tail uses - some thirty pointers and counts - was
-  // fetched at the kernel's entry and carried through the factorization in scalar registers, i.e. in spill lanes of vector registers
-  // written and read back (v_writelane / v_readlane, VALU instructions) around its loops.
-  typedef const PlaneSolve __attribute__((address_space(4))) PlaneSolveK;
-  PlaneSolveK* pk = (PlaneSolveK*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + C2_PS_KERNARG_OFFSET);
-  asm volatile("" : "+s"(pk));
-  PlaneSolveK& pq = *pk;
 
   const int ntn = (n + 15) >> 4;           // tile rows of the n x n part
-  const int h_bs = part >= 0 ? (J.split_h < ntn ? J.split_h : ntn) : 0;
+  const int h_bs = part >= 0 ? (jq.split_h < ntn ? jq.split_h : ntn) : 0;
   if (part == 0)  // y blocks of part B's columns (published before its decision)
     for (int i = 16 * h_bs + tid; i < 16 * ntn; i += C2_WAVES * 64) S.ybuf[i] = pq.xy[i];
   chol2_backsolve<NS, ROLE>(S, n, ntn, tile, ti, tj, nullptr, part == 0 ? h_bs : ntn, part == 1 ? h_bs : 0);
@@ -1287,7 +1291,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
     if (tid == 0) {
       const bool fine = S.cnt[6] == 0;  // no hand-over of the back substitution timed out
       if (!fine) {
-        if (J.flag) atomicOr(J.flag, 2);
+        if (jq.flag) atomicOr(jq.flag, 2);
         pq.res_out[1] = 0.0;
       }
       __hip_atomic_store(pq.xsync + 1, ((pq.seq & 0x7fffffffu) << 1) | (fine ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1316,7 +1320,7 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   __syncthreads();
   if (S.cnt[6]) {  // a hand-over of the back substitution timed out: nothing is committed, the call fails
     if (tid == 0) {
-      if (J.flag) atomicOr(J.flag, 2);
+      if (jq.flag) atomicOr(jq.flag, 2);
       pq.res_out[1] = 0.0;
     }
     return;
@@ -1461,8 +1465,9 @@ __global__ __launch_bounds__(C2_WAVES * 64) void k_chol2(const Chol2Job J0, cons
   const Chol2Job& J = blockIdx.x == 1 ? J1 : J0;  // block 2 = part B of a split plane update (same job as block 0)
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // both instantiations execute the same sequence of workgroup barriers
-  if (wave < C2_EW) chol2_body<MAXSLOT, 0, SPLIT>(J, ps, lds, sh);
-  else chol2_body<MAXSLOT, 1, SPLIT>(J, ps, lds, sh);
+  const int joff = blockIdx.x == 1 ? (int)sizeof(Chol2Job) : 0;  // where J sits in the kernel-argument segment (chol2_body)
+  if (wave < C2_EW) chol2_body<MAXSLOT, 0, SPLIT>(J, ps, lds, sh, joff);
+  else chol2_body<MAXSLOT, 1, SPLIT>(J, ps, lds, sh, joff);
 }
 
 // out[0] = max_i A_ii (one workgroup): the scale the drop threshold of a semi-definite factorization refers to
