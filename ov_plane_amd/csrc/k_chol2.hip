@@ -295,7 +295,8 @@ __device__ __forceinline__ Chol2Lds chol2_carve(double* lds, int nt) {
 }
 
 // Element (r, c) of the matrix that is factorized: the n x n input (+ I), the border row n, identity padding behind it.
-__device__ __forceinline__ double c2_elem(const Chol2Job& J, const double* __restrict__ A, int r, int c, int nb) {
+template <class JOB>
+__device__ __forceinline__ double c2_elem(const JOB& J, const double* __restrict__ A, int r, int c, int nb) {
   const int n = J.n;
   double x;
   if (r < n && c < n) {
@@ -351,8 +352,8 @@ __device__ __forceinline__ void c2_col_slots(int k, int nt, int tw, int& lo, int
 // Part A's trailing updates shrink to its own columns (its steps become pivot-chain bound), part B's run on a CU of their own,
 // and no workgroup holds more than ~2/3 of the tiles (n = 285: 126 of 171 - they fit the registers again).
 // SPLIT = false compiles the ownership tests away (cl = 0, ch = nt): the single-workgroup kernel is the code it was before.
-template <int MAXSLOT, int ROLE, bool SPLIT>
-__device__ __forceinline__ void chol2_factor(const Chol2Job& J, const Chol2Lds& S, double4_t (&tile)[MAXSLOT], int (&ti)[MAXSLOT],
+template <int MAXSLOT, int ROLE, bool SPLIT, class JOB>
+__device__ __forceinline__ void chol2_factor(const JOB& J, const Chol2Lds& S, double4_t (&tile)[MAXSLOT], int (&ti)[MAXSLOT],
                                              int (&tj)[MAXSLOT], int& bad_out, const int cl_arg, const int ch_arg) {
   const int n = J.n;
   const int nb = J.brow ? n + 1 : n;  // bordered dimension
@@ -1062,14 +1063,19 @@ struct Chol2Shared {  // workgroup variables both role instantiations of the bod
 
 template <int MAXSLOT, int ROLE, bool SPLIT>
 __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve& ps, double* lds, Chol2Shared& sh, const int joff) {
-  const int n = J0_.n;
-  const int nb = J0_.brow ? n + 1 : n;
+  // The job is read from the kernel-argument segment directly (joff: where it sits there): as `blockIdx.x == 1 ? J1 : J0` every field
+  // was two scalar loads and a select, all of them fetched at the kernel's entry.
+  typedef const Chol2Job __attribute__((address_space(4))) Chol2JobK;
+  typedef const char __attribute__((address_space(4))) KernargByte;
+  Chol2JobK& Jf = *(Chol2JobK*)((KernargByte*)__builtin_amdgcn_kernarg_segment_ptr() + joff);
+  const int n = Jf.n;
+  const int nb = Jf.brow ? n + 1 : n;
   const int nt = (nb + 15) >> 4;
   const Chol2Lds S = chol2_carve(lds, nt);
   constexpr int NS = ROLE == 1 ? MAXSLOT : 1;  // tile registers exist on the tile waves only
   // cond = {have, want} on the device: the factor this launch would produce is already there when the two agree (the last
   // accepted plane of a plane loop left it behind)
-  if (J0_.skip_cond && J0_.skip_cond[0] != 0 && J0_.skip_cond[0] == J0_.skip_cond[1]) return;
+  if (Jf.skip_cond && Jf.skip_cond[0] != 0 && Jf.skip_cond[0] == Jf.skip_cond[1]) return;
   double4_t tile[NS];
   int ti[NS], tj[NS];
   int bad = 0;
@@ -1078,12 +1084,16 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   double& sh_zz = sh.zz;
   if (threadIdx.x == 0) sh_bad = 0;
   // split factorization of the plane update (see chol2_factor): block 0 = part A (tile columns < h), block 2 = part B
-  const int part = (SPLIT && J0_.mode == 1 && J0_.split_h > 0) ? (blockIdx.x == 2 ? 1 : 0) : -1;
-  const int c_lo = part == 1 ? J0_.split_h : 0, c_hi = part == 0 ? J0_.split_h : nt;
+  const int part = (SPLIT && Jf.mode == 1 && Jf.split_h > 0) ? (blockIdx.x == 2 ? 1 : 0) : -1;
+  const int c_lo = part == 1 ? Jf.split_h : 0, c_hi = part == 0 ? Jf.split_h : nt;
+#if C2_STAMPS_ON
   Chol2Job Jl = J0_;
   if (part == 1 && Jl.stamps) Jl.stamps += 16 * 32;  // diagnostics: part B stamps into the second half
   const Chol2Job& J = Jl;
-  chol2_factor<NS, ROLE, SPLIT>(J, S, tile, ti, tj, bad, c_lo, c_hi);
+  chol2_factor<NS, ROLE, SPLIT, Chol2Job>(J, S, tile, ti, tj, bad, c_lo, c_hi);
+#else
+  chol2_factor<NS, ROLE, SPLIT, Chol2JobK>(Jf, S, tile, ti, tj, bad, c_lo, c_hi);
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
@@ -1097,8 +1107,6 @@ __device__ __forceinline__ void chol2_body(const Chol2Job& J0_, const PlaneSolve
   // forty pointers and counts - was fetched at the kernel's entry and carried through the factorization in scalar registers, i.e. in
   // spill lanes of vector registers written and read back (v_writelane / v_readlane, VALU instructions) around its loops.
   typedef const PlaneSolve __attribute__((address_space(4))) PlaneSolveK;
-  typedef const Chol2Job __attribute__((address_space(4))) Chol2JobK;
-  typedef const char __attribute__((address_space(4))) KernargByte;
   PlaneSolveK* pk = (PlaneSolveK*)((KernargByte*)__builtin_amdgcn_kernarg_segment_ptr() + C2_PS_KERNARG_OFFSET);
   Chol2JobK* jk = (Chol2JobK*)((KernargByte*)__builtin_amdgcn_kernarg_segment_ptr() + joff);
   asm volatile("" : "+s"(pk), "+s"(jk));
