@@ -95,6 +95,33 @@ struct PlaneJobH { int pl, start, nf, rows_total, rows_live, rows_u, n_involved,
 extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_plane_batch* pb, double* dx_planes,
                                       uint8_t* plane_ok, double* plane_chi2, int* plane_dof, uint8_t* feat_used);
 
+// The plane loop's results go to the host as the point update's do (ovp_api_point.hip: k_publish_results): ONE kernel behind the
+// loop writes [chi2, decision, ... per plane | dx per plane | consumed features | flags] into mapped pinned memory and then a
+// sequence number the host spins on - instead of four copy commands (a blit kernel of ~4 us each on the stream) and a stream
+// synchronisation (interrupt + wake-up).  It also clears the device flags for the next call (was a fill command).
+__global__ __launch_bounds__(1024) void k_publish_plane_results(const double* __restrict__ res, int n_res, const double* __restrict__ dx,
+                                                               int n_dx, const unsigned char* __restrict__ used, int n_used,
+                                                               int* __restrict__ flags, double* __restrict__ dst_res,
+                                                               double* __restrict__ dst_dx, unsigned char* __restrict__ dst_used,
+                                                               int* __restrict__ dst_flags, volatile unsigned* seq_host, unsigned seq) {
+  const int t = threadIdx.x;
+  for (int i = t; i < n_res; i += 1024) dst_res[i] = res[i];
+  for (int i = t; i < n_dx; i += 1024) dst_dx[i] = dx[i];
+  {
+    // (8 bytes at a time: `used` and its mirror are 8-byte aligned, the tail byte by byte)
+    const int w = n_used >> 3;
+    const unsigned long long* us = reinterpret_cast<const unsigned long long*>(used);
+    unsigned long long* ud = reinterpret_cast<unsigned long long*>(dst_used);
+    for (int i = t; i < w; i += 1024) ud[i] = us[i];
+    for (int i = 8 * w + t; i < n_used; i += 1024) dst_used[i] = used[i];
+  }
+  if (t < 4) dst_flags[t] = flags[t];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) *seq_host = seq;
+  if (t < 4) flags[t] = 0;
+}
+
 static int ensure_pl_used(ovp_ctx* c) {
   if (!c->pl_used) HIPCHK(hipMalloc((void**)&c->pl_used, (size_t)c->f_max + 16));
   return 0;
@@ -132,7 +159,9 @@ int plane2_buffers(ovp_ctx* c, int NP, size_t stage_bytes, size_t res_bytes) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->pl_hres) hipHostFree(c->pl_hres);
     c->pl_hres_cap = res_bytes + 4096;
-    HIPCHK(hipHostMalloc(&c->pl_hres, c->pl_hres_cap, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->pl_hres, c->pl_hres_cap, hipHostMallocMapped));
+    memset(c->pl_hres, 0, c->pl_hres_cap);
+    HIPCHK(hipHostGetDevicePointer(&c->pl_hres_dev, c->pl_hres, 0));
   }
   return 0;
 }
@@ -426,7 +455,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   fp.range_hi = 0x7fffffff;
   // ---- what does not depend on the grouping goes to the device first: the fills and chol(P) (~70 us) run while the host sorts the
   // features by plane and builds the per-plane tables (~40 us at config 3, during which the stream used to be idle) ----
-  const size_t res_bytes = sizeof(double) * (4 * (size_t)NP + (size_t)n * NP) + (size_t)F + 64;
+  const size_t res_bytes = sizeof(double) * (4 * (size_t)NP + (size_t)n * NP) + (size_t)F + 64 + 256;  // (+ flags and sequence word)
   rc = plane_buffers(c, NP);  // shared with the first generation: pl_res, pl_dx, pl_cst, pl_An, ...
   if (rc) return rc;
   rc = plane2_buffers(c, NP, 0, res_bytes);
@@ -914,12 +943,32 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
   double* hres = (double*)c->pl_hres;
   double* hdx = hres + 4 * (size_t)NP;
   unsigned char* hused = (unsigned char*)(hdx + (size_t)n * NP);
-  HIPCHK(hipMemcpyAsync(hres, c->pl_res, sizeof(double) * 4 * NP, hipMemcpyDeviceToHost, s));
-  if (dx_planes) HIPCHK(hipMemcpyAsync(hdx, c->pl_dx, sizeof(double) * (size_t)n * NP, hipMemcpyDeviceToHost, s));
-  if (F) HIPCHK(hipMemcpyAsync(hused, c->pl_used, (size_t)F, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  // (behind `used`, each on a 64-byte line of its own: the flags, the sequence word)
+  char* hflags_pub = (char*)hused + (((size_t)F + 63) & ~(size_t)63);
+  volatile unsigned* hseq = (volatile unsigned*)(hflags_pub + 64);
+  const unsigned seq = ++c->pl_pub_seq;
+  {
+    char* dbase = (char*)c->pl_hres_dev;
+    auto dev_of = [&](const void* hp) { return dbase + ((const char*)hp - (const char*)c->pl_hres); };
+    hipLaunchKernelGGL(k_publish_plane_results, dim3(1), dim3(1024), 0, s, c->pl_res, 4 * NP, c->pl_dx, dx_planes ? n * NP : 0, c->pl_used,
+                       F, c->flags, (double*)dev_of(hres), (double*)dev_of(hdx), (unsigned char*)dev_of(hused), (int*)dev_of(hflags_pub),
+                       (volatile unsigned*)dev_of((const void*)hseq), seq);
+    HIPCHK(hipGetLastError());
+  }
   const double t_enq = host_now_ms();
-  HIPCHK(hipStreamSynchronize(s));
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n((const unsigned*)hseq, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        HIPCHK(hipStreamSynchronize(s));  // error path: surface a fault instead of spinning forever
+        if (__atomic_load_n((const unsigned*)hseq, __ATOMIC_ACQUIRE) != seq) return OVP_E_STATE;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    memcpy(c->h_flags, hflags_pub, sizeof(int) * 4);
+  }
   {
     c->host_acc[0] += t_first - t_entry;
     c->host_acc[1] += t_enq - t_entry;
@@ -947,8 +996,7 @@ extern "C" int ovp_msckf_plane_update(ovp_ctx* c, const ovp_update_opts* o, cons
     if (plane_chi2) plane_chi2[j.pl] = hres[4 * j.pl];
     if (plane_dof) plane_dof[j.pl] = j.rows_u;
   }
-  const int bad = c->h_flags[0] | c->h_flags[2];
-  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 4, s));
+  const int bad = c->h_flags[0] | c->h_flags[2];  // (the device words were cleared by the publishing kernel)
   if (bad) {
     // A failed factorization / timed-out hand-over rejects its plane and every later one before anything is committed, and the
     // covariance product behind the loop is cancelled (the resident P is the prior).  Planes accepted BEFORE the failure have

@@ -227,6 +227,8 @@ struct ovp_ctx {
   void *pl_hstage = nullptr, *pl_dstage = nullptr;  // pinned host / device staging of the per-call tables
   size_t pl_stage_cap = 0;
   void* pl_hres = nullptr;            // pinned host copy of the plane results
+  void* pl_hres_dev = nullptr;        // ... its device address (mapped: the plane loop publishes its results into it from a kernel)
+  unsigned pl_pub_seq = 0;            // sequence number of the plane loop's last publication
   size_t pl_hres_cap = 0;
   // one device block + one pinned staging block each for the pose tables and for the feature batch (a single copy per upload)
   void *state_block = nullptr, *h_state_stage = nullptr, *batch_block = nullptr, *h_batch_stage = nullptr;
