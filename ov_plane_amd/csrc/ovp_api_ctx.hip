@@ -553,13 +553,27 @@ extern "C" int ovp_cov_propagate(ovp_ctx* c, int new_start, int phi_size, const 
     HIPCHK(hipMemcpyAsync(ad, ah, bytes, hipMemcpyHostToDevice, c->stream));
     const double* dPhi = (const double*)ad;
     const double* dQ = dPhi + (size_t)phi_size * nold;
-    HIPCHK(ovp_launch_propagate(c->P, c->ld, n, new_start, phi_size, (const int*)((char*)ad + o_id), nold, dPhi, dQ, dCPT, dPCP,
-                                c->flags + 1, c->stream));
+    // the verdict comes back through mapped pinned memory (two words 16 bytes behind the point update's sequence word, in the same
+    // 64-byte slack of the result block) and a sequence number of its own: no copy command, no stream synchronisation
+    volatile unsigned* hw = c->h_seq + 4;
+    unsigned* hw_dev = (unsigned*)((char*)c->h_res_block_dev + ((char*)hw - (char*)c->h_res_block));
+    const unsigned seq = ++c->prop_seq;
+    HIPCHK(ovp_launch_propagate_publish(c->P, c->ld, n, new_start, phi_size, (const int*)((char*)ad + o_id), nold, dPhi, dQ, dCPT, dPCP,
+                                        c->flags + 1, hw_dev, seq, c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n((const unsigned*)hw, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        HIPCHK(hipStreamSynchronize(c->stream));  // error path: surface a fault instead of spinning forever
+        if (__atomic_load_n((const unsigned*)hw, __ATOMIC_ACQUIRE) != seq) return OVP_E_STATE;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    const int neg = (int)hw[1];
+    if (neg_diag) *neg_diag = neg;
+    return neg ? OVP_E_NEGDIAG : 0;
   }
-  HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (neg_diag) *neg_diag = c->h_flags[1];
-  return c->h_flags[1] ? OVP_E_NEGDIAG : 0;
 }
 
 extern "C" int ovp_cov_clone(ovp_ctx* c, int src_id, int size) {

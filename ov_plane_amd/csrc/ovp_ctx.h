@@ -53,6 +53,9 @@ hipError_t ovp_launch_cov_marginalize(const double* src, double* dst, int ld, in
 hipError_t ovp_launch_propagate(double* P, int ldp, int n, int start, int phi, const int* oldcol, int nold,
                                 const double* Phi, const double* Q, double* CPT, double* PCP, int* negdiag,
                                 hipStream_t stream);
+hipError_t ovp_launch_propagate_publish(double* P, int ldp, int n, int start, int phi, const int* oldcol, int nold, const double* Phi,
+                                        const double* Q, double* CPT, double* PCP, int* negdiag, unsigned* host_dev, unsigned seq,
+                                        hipStream_t stream);
 hipError_t ovp_launch_augment_dt(double* P, int ldp, int n, int pose, int dt, const double* d, hipStream_t stream);
 hipError_t ovp_launch_init_invertible(double* P, int ldp, int n, const int* cols, int ncols, const double* HR, int k,
                                       double* Ma, const double* Hinv, const double* Rk, hipStream_t stream);
@@ -254,6 +257,7 @@ struct ovp_ctx {
   void *res_block = nullptr, *h_res_block = nullptr;  // [flags | dx | chi2 | accept], device and pinned host
   void* h_res_block_dev = nullptr;                    // device address of the pinned block
   volatile unsigned* h_seq = nullptr;                 // sequence word behind it (written last by k_publish_results)
+  unsigned prop_seq = 0;                              // ovp_cov_propagate's own sequence (words [4], [5] behind h_seq: seq, verdict)
   unsigned seq = 0, pub_seq = 0;
   bool pub_pending = false;      // the running update publishes its results itself (k_dx_rows)
   bool need_join = false;     // chol(P) / K2 of the current update finish on stream2 (ev_join) rather than on the main stream
