@@ -703,11 +703,11 @@ extern "C" int ovp_cov_initialize(ovp_ctx* c, const double* Hx_init, const doubl
   if (upd) {
     // P+ = P - W W^T goes to the second covariance buffer (a tile reads entries other tiles overwrite)
     HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, ld, n2, dM, m, k, rup, dLi, dy, dres, dres + 4, s));
-    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * (4 + (size_t)n2), hipMemcpyDeviceToHost, s));
-  } else {
-    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
   }
-  HIPCHK(hipStreamSynchronize(s));
+  {
+    const int rf = ovp_fetch_to_hres(c, dres, sizeof(double) * (upd ? 4 + (size_t)n2 : 4), s);
+    if (rf) return rf;
+  }
   const bool ok = hres[1] > 0.5;
   if (accepted) *accepted = ok ? 1 : 0;
   if (chi2) *chi2 = hres[0];

@@ -122,6 +122,45 @@ __global__ __launch_bounds__(1024) void k_publish_plane_results(const double* __
   if (t < 4) flags[t] = 0;
 }
 
+// A device block -> the start of the pinned result block (c->pl_hres), by a kernel + sequence word instead of a copy command and a
+// stream synchronisation (the entry points with a handful of results: SLAM update, delayed initialisation, initialize, dense update).
+// Falls back to the copy when the block has no room for the sequence word.
+__global__ __launch_bounds__(1024) void k_fetch_block(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int bytes,
+                                                     volatile unsigned* seq_host, unsigned seq) {
+  const int w = bytes >> 3;
+  const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(src);
+  unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+  for (int i = threadIdx.x; i < w; i += 1024) d8[i] = s8[i];
+  for (int i = 8 * w + threadIdx.x; i < bytes; i += 1024) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *seq_host = seq;
+}
+int ovp_fetch_to_hres(ovp_ctx* c, const void* dsrc, size_t bytes, hipStream_t s) {
+  if (!c->pl_hres_dev || bytes + 64 > c->pl_hres_cap || (((size_t)dsrc) & 7) || bytes > (size_t)0x7fffffff) {
+    HIPCHK(hipMemcpyAsync(c->pl_hres, dsrc, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+  }
+  const size_t o_seq = (c->pl_hres_cap - 64) & ~(size_t)63;
+  volatile unsigned* hseq = (volatile unsigned*)((char*)c->pl_hres + o_seq);
+  const unsigned seq = ++c->pl_pub_seq;
+  hipLaunchKernelGGL(k_fetch_block, dim3(1), dim3(1024), 0, s, (const unsigned char*)dsrc, (unsigned char*)c->pl_hres_dev, (int)bytes,
+                     (volatile unsigned*)((char*)c->pl_hres_dev + o_seq), seq);
+  HIPCHK(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n((const unsigned*)hseq, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      HIPCHK(hipStreamSynchronize(s));  // error path: surface a fault instead of spinning forever
+      if (__atomic_load_n((const unsigned*)hseq, __ATOMIC_ACQUIRE) != seq) return OVP_E_STATE;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  return 0;
+}
+
 static int ensure_pl_used(ovp_ctx* c) {
   if (!c->pl_used) HIPCHK(hipMalloc((void**)&c->pl_used, (size_t)c->f_max + 16));
   return 0;

@@ -740,8 +740,10 @@ extern "C" int ovp_ekf_update(ovp_ctx* c, const double* H_host, int rows, int co
                                 1e300, dLi, dy, dres, s));
     HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, c->ld, n, dM, rows, 0, rows, dLi, dy, dres, dres + 4, s));
     double* hres = (double*)c->pl_hres;
-    HIPCHK(hipMemcpyAsync(hres, dres, sizeof(double) * (4 + (size_t)n), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    {
+      const int rf = ovp_fetch_to_hres(c, dres, sizeof(double) * (4 + (size_t)n), s);
+      if (rf) return rf;
+    }
     if (info) {
       memset(info, 0, sizeof(*info));
       info->n_rows = rows;

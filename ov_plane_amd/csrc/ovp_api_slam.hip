@@ -317,8 +317,10 @@ extern "C" int ovp_slam_update(ovp_ctx* c, const ovp_update_opts* o, const ovp_s
     HIPCHK(ovp_launch_init_core(c->P, c->ld, n, dgid, gcols, c->Hd, 0, rows, dM, c->resd /* unused: k = 0 */, c->resd, c->resd, 1.0, 1e300,
                                 dLi, dy, dres, s));
     HIPCHK(ovp_launch_init_update(c->P, c->P_tmp, c->ld, n, dM, rows, 0, rows, dLi, dy, dres, dres + 4, s));
-    HIPCHK(hipMemcpyAsync(hres, dres, res_doubles * sizeof(double) + lres_bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    {
+      const int rf = ovp_fetch_to_hres(c, dres, res_doubles * sizeof(double) + lres_bytes, s);
+      if (rf) return rf;
+    }
     finish_landmarks();
     if (info) {
       info->not_spd = hres_d[1] > 0.5 ? 0 : 1;
@@ -495,8 +497,10 @@ extern "C" int ovp_slam_delayed_init(ovp_ctx* c, const ovp_update_opts* o, const
   dp.prev_res = dres0 + res_doubles * (L - 1);
   HIPCHK(ovp_launch_dinit_rows(&dp, 64, s));
   double* hres = (double*)c->pl_hres;
-  HIPCHK(hipMemcpyAsync(hres, dres0, sizeof(double) * res_doubles * L, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  {
+    const int rf = ovp_fetch_to_hres(c, dres0, sizeof(double) * res_doubles * L, s);
+    if (rf) return rf;
+  }
   c->n = (int)n_end;
   // final layout: the inert blocks of the rejected candidates go (last first), the accepted ones move up
   std::vector<int> final_id(L, -1);

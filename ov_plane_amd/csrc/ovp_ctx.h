@@ -304,6 +304,7 @@ static hipError_t dalloc(T** p, size_t count) {
 extern "C" int ovp_io_arena(ovp_ctx* c, size_t bytes, void** host, void** dev);  // pinned staging arena (ovp_api_ctx.hip)
 // ovp_api_point.hip
 int fill_feat_params(ovp_ctx* c, const ovp_update_opts* o);
+int ovp_fetch_to_hres(ovp_ctx* c, const void* dsrc, size_t bytes, hipStream_t s);  // device block -> c->pl_hres, waited for (ovp_api_plane.hip)
 int chol_of_P(ovp_ctx* c, hipStream_t s);
 hipError_t chol_of_T(ovp_ctx* c, const double* T, int n, int ld, int add_identity, const int* cond, hipStream_t s);
 int set_substate(ovp_ctx* c, const std::vector<int>& ids);
